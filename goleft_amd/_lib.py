@@ -1,0 +1,103 @@
+"""ctypes binding of libgoleft_depth.so (include/goleft_depth.h).
+
+Fails loudly when the HIP library is missing: there is no CPU fallback."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(HERE, "libgoleft_depth.so")
+
+
+class GdParams(C.Structure):
+    _fields_ = [("window_size", C.c_int32), ("min_mapq", C.c_int32), ("min_cov", C.c_int32),
+                ("max_mean_depth", C.c_int32), ("flag_mask", C.c_uint32),
+                ("max_span_hint", C.c_int32), ("step", C.c_int64)]
+
+
+class GdBatch(C.Structure):
+    _fields_ = [("pos", C.c_void_p), ("flag", C.c_void_p), ("mapq", C.c_void_p),
+                ("cigar_off", C.c_void_p), ("cigar", C.c_void_p),
+                ("reads_cap", C.c_size_t), ("ops_cap", C.c_size_t), ("slot", C.c_int32)]
+
+
+class GdRun(C.Structure):
+    _fields_ = [("start", C.c_int32), ("end", C.c_int32), ("cls", C.c_int32)]
+
+
+class GdStats(C.Structure):
+    _fields_ = [("n_reads", C.c_uint64), ("n_ops", C.c_uint64), ("n_ref_bases", C.c_uint64),
+                ("n_windows", C.c_uint64), ("n_tiles", C.c_uint64), ("n_runs", C.c_uint64),
+                ("tile_positions", C.c_int32), ("lookback", C.c_int32),
+                ("max_span_seen", C.c_int32), ("reruns", C.c_int32)]
+
+
+# every symbol include/goleft_depth.h declares: (restype, argtypes)
+_P = C.c_void_p
+SYMBOLS = {
+    "gd_strerror": (C.c_char_p, [C.c_int]),
+    "gd_abi_version": (C.c_int, []),
+    "gd_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "gd_create": (C.c_int, [C.c_int, C.POINTER(_P)]),
+    "gd_destroy": (None, [_P]),
+    "gd_last_error": (C.c_char_p, [_P]),
+    "gd_set_stream": (C.c_int, [_P, _P]),
+    "gd_set_params": (C.c_int, [_P, C.POINTER(GdParams)]),
+    "gd_default_params": (C.c_int, [C.POINTER(GdParams)]),
+    "gd_set_contigs": (C.c_int, [_P, C.c_int, _P]),
+    "gd_select_contigs": (C.c_int, [_P, C.c_int, _P]),
+    "gd_acquire": (C.c_int, [_P, C.c_size_t, C.c_size_t, C.POINTER(GdBatch)]),
+    "gd_commit": (C.c_int, [_P, C.POINTER(GdBatch), C.c_int32, C.c_size_t, C.c_size_t]),
+    "gd_push": (C.c_int, [_P, C.c_int32, _P, _P, _P, _P, _P, C.c_size_t, C.c_size_t]),
+    "gd_adopt_device": (C.c_int, [_P, C.c_int32, C.POINTER(GdBatch), C.c_size_t, C.c_size_t]),
+    "gd_reset": (C.c_int, [_P]),
+    "gd_compute": (C.c_int, [_P]),
+    "gd_perbase": (C.c_int, [_P, C.c_int32, C.c_int64, C.c_int64, _P]),
+    "gd_windows": (C.c_int, [_P, C.c_int32, _P, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "gd_callable": (C.c_int, [_P, C.c_int32, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "gd_region_windows": (C.c_int, [_P, C.c_int32, C.c_int64, C.c_int64, _P, _P, C.c_size_t,
+                                    C.POINTER(C.c_size_t)]),
+    "gd_region_callable": (C.c_int, [_P, C.c_int32, C.c_int64, C.c_int64, _P, C.c_size_t,
+                                     C.POINTER(C.c_size_t)]),
+    "gd_device_perbase": (C.c_int, [_P, C.c_int32, C.POINTER(_P), C.POINTER(C.c_int64)]),
+    "gd_device_windows": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(C.c_size_t)]),
+    "gd_window_offset": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    "gd_device_runs": (C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_size_t)]),
+    "gd_get_stats": (C.c_int, [_P, C.POINTER(GdStats)]),
+    "gd_set_profiling": (C.c_int, [_P, C.c_int]),
+    "gd_kernel_ms": (C.c_int, [_P, C.c_int, C.POINTER(C.c_float)]),
+}
+
+_LIB = None
+
+
+def build(force: bool = False) -> str:
+    """Compile the HIP library in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    src_dir = os.path.join(HERE, "csrc")
+    srcs = [os.path.join(src_dir, f) for f in ("gd_api.hip", "gd_kernels.hpp")]
+    srcs.append(os.path.join(os.path.dirname(HERE), "include", "goleft_depth.h"))
+    stale = (not os.path.exists(SO_PATH)
+             or any(os.path.getmtime(s) > os.path.getmtime(SO_PATH) for s in srcs))
+    if force or stale:
+        subprocess.check_call(["make", "-s", "-C", src_dir] + (["-B"] if force else []))
+    return SO_PATH
+
+
+def load():
+    """Load the library; raises (never falls back) when it is absent."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(SO_PATH):
+        raise ImportError(
+            "goleft_amd: %s is missing -- run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback." % SO_PATH)
+    lib = C.CDLL(SO_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)   # AttributeError if the .so does not export it
+        fn.restype = res
+        fn.argtypes = args
+    _LIB = lib
+    return lib

@@ -1,0 +1,891 @@
+// gd_api.hip -- C ABI of the per-base depth engine (include/goleft_depth.h).
+//
+// Host-side runtime around the CDNA4 kernels of gd_kernels.hpp: contexts,
+// pinned staging ring + copy stream (records host -> HBM), HBM-resident
+// per-contig record streams, launch sequencing, result read-back.
+// Replaces gargs' process.Runner + the samtools child + the callback's parse
+// loop (/root/reference/depth/depth.go:392-394, :45, :282-325).
+#include "../../include/goleft_depth.h"
+#include "gd_kernels.hpp"
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+namespace {
+
+constexpr int kRingSlots = 3;
+constexpr int kDefaultLookback = 1024;
+
+struct ContigHost {
+    int64_t length = 0;
+    // device record stream (owned unless adopted)
+    int32_t*  pos = nullptr;
+    uint16_t* flag = nullptr;
+    uint8_t*  mapq = nullptr;
+    uint32_t* off = nullptr;
+    uint32_t* cigar = nullptr;
+    size_t n_reads = 0, n_ops = 0;
+    size_t cap_reads = 0, cap_ops = 0;
+    bool adopted = false;
+    int32_t last_pos = -0x7fffffff;
+    // layout in the result arrays of the last compute (-1 = not computed)
+    int64_t base_off = -1;
+    int64_t win_off = -1;
+    int64_t n_win = 0;
+    size_t run_beg = 0, run_end = 0;   // slice of ctx->bounds
+};
+
+struct RingSlot {
+    gd_batch b{};
+    hipEvent_t done = nullptr;
+    bool busy = false;
+};
+
+}  // namespace
+
+struct gd_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;       // compute stream
+    bool own_stream = true;
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t copy_done = nullptr;
+    gd_params params{};
+    std::vector<ContigHost> contigs;
+    std::vector<int32_t> selected;      // empty = all
+    RingSlot ring[kRingSlots];
+    int ring_next = 0;
+    std::string err;
+
+    int tile_T = 8192;
+    int lookback = kDefaultLookback;
+
+    // device job state
+    gd::ContigDev* d_ctgs = nullptr;  size_t cap_ctgs = 0;
+    std::vector<gd::ContigDev> h_ctgs;
+    std::vector<int32_t> job_tids;      // contig table index -> tid
+    gd::TileInfo* d_tiles = nullptr;  size_t cap_tiles = 0;
+    int32_t* d_perbase = nullptr;     size_t cap_perbase = 0;
+    int64_t* d_wsum = nullptr;        size_t cap_win = 0;
+    int32_t* d_wmin = nullptr;
+    int2* d_chunks = nullptr;         size_t cap_runs = 0;
+    int2* d_ordered = nullptr;
+    uint32_t* d_tile_cnt = nullptr;
+    uint32_t* d_tile_off = nullptr;
+    uint32_t* d_tile_dst = nullptr;
+    gd::Counters* d_counters = nullptr;
+    gd::Counters* h_counters = nullptr;   // pinned
+    uint32_t* d_region_cursor = nullptr;
+
+    bool computed = false;
+    int64_t n_tiles = 0, n_win_total = 0, n_bases = 0;
+    std::vector<int2> bounds;             // ordered run boundaries of the last compute
+    gd_stats stats{};
+
+    bool profiling = false;
+    hipEvent_t ev[GD_K_COUNT + 1] = {};
+    float kernel_ms[GD_K_COUNT] = {};
+};
+
+namespace {
+
+int fail(gd_ctx* c, int code, const char* fmt, ...)
+{
+    if (c) {
+        char buf[512];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof buf, fmt, ap);
+        va_end(ap);
+        c->err = buf;
+    }
+    return code;
+}
+
+#define HIPCHK(ctx, call)                                                              \
+    do {                                                                               \
+        hipError_t e_ = (call);                                                        \
+        if (e_ != hipSuccess)                                                          \
+            return fail((ctx), e_ == hipErrorOutOfMemory ? GD_E_NOMEM : GD_E_HIP,      \
+                        "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_),         \
+                        __FILE__, __LINE__);                                           \
+    } while (0)
+
+template <typename Tp>
+int ensure_dev(gd_ctx* c, Tp** p, size_t* cap, size_t need, bool keep = false, size_t used = 0)
+{
+    if (need <= *cap && *p) return GD_OK;
+    size_t ncap = std::max(need, *cap + *cap / 2);
+    if (ncap == 0) ncap = 1;
+    Tp* np = nullptr;
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&np), ncap * sizeof(Tp)));
+    if (*p) {
+        if (keep && used)
+            HIPCHK(c, hipMemcpyAsync(np, *p, used * sizeof(Tp), hipMemcpyDeviceToDevice,
+                                     c->copy_stream));
+        HIPCHK(c, hipStreamSynchronize(c->copy_stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipFree(*p));
+    }
+    *p = np;
+    *cap = ncap;
+    return GD_OK;
+}
+
+void free_contig(ContigHost& h)
+{
+    if (!h.adopted) {
+        if (h.pos) (void)hipFree(h.pos);
+        if (h.flag) (void)hipFree(h.flag);
+        if (h.mapq) (void)hipFree(h.mapq);
+        if (h.off) (void)hipFree(h.off);
+        if (h.cigar) (void)hipFree(h.cigar);
+    }
+    h.pos = nullptr; h.flag = nullptr; h.mapq = nullptr; h.off = nullptr; h.cigar = nullptr;
+    h.n_reads = h.n_ops = h.cap_reads = h.cap_ops = 0;
+    h.adopted = false;
+    h.last_pos = -0x7fffffff;
+    h.base_off = h.win_off = -1;
+    h.n_win = 0;
+    h.run_beg = h.run_end = 0;
+}
+
+int64_t derive_step(const gd_params& p)
+{
+    if (p.step > 0) return p.step;
+    // depth/depth.go:48,:132
+    int64_t s = 10000000 / p.window_size;
+    if (s < 1) s = 1;
+    return s * p.window_size;
+}
+
+int set_device(gd_ctx* c)
+{
+    HIPCHK(c, hipSetDevice(c->device));
+    return GD_OK;
+}
+
+template <int T>
+void launch_prep(gd_ctx* c, const gd::Job& job)
+{
+    int64_t work = std::max<int64_t>(job.n_tiles, std::min<int64_t>(job.n_win_total, 1 << 22));
+    int blocks = (int)((work + 255) / 256);
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(gd::gd_prep_kernel<T>, dim3(blocks), dim3(256), 0, c->stream, job);
+}
+
+template <int T, int NT>
+void launch_tile(gd_ctx* c, const gd::Job& job)
+{
+    hipLaunchKernelGGL((gd::gd_tile_kernel<T, NT>), dim3(job.n_tiles), dim3(NT), 0, c->stream, job);
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* gd_strerror(int s)
+{
+    switch (s) {
+    case GD_OK: return "ok";
+    case GD_E_INVALID: return "invalid argument";
+    case GD_E_NOMEM: return "out of memory";
+    case GD_E_HIP: return "HIP runtime error";
+    case GD_E_STATE: return "call out of order";
+    case GD_E_RANGE: return "tid or coordinate out of range";
+    case GD_E_NODEVICE: return "no usable HIP device";
+    case GD_E_UNSORTED: return "records not coordinate sorted";
+    case GD_E_CAPACITY: return "output buffer too small";
+    }
+    return "unknown status";
+}
+
+int gd_abi_version(void) { return GD_ABI_VERSION; }
+
+int gd_device_count(int* n)
+{
+    if (!n) return GD_E_INVALID;
+    int k = 0;
+    hipError_t e = hipGetDeviceCount(&k);
+    if (e != hipSuccess) { *n = 0; return GD_E_NODEVICE; }
+    *n = k;
+    return GD_OK;
+}
+
+int gd_default_params(gd_params* p)
+{
+    if (!p) return GD_E_INVALID;
+    // depth/depth.go:164-167
+    p->window_size = 250;
+    p->min_mapq = 1;
+    p->min_cov = 4;
+    p->max_mean_depth = 0;
+    p->flag_mask = GD_DEFAULT_FLAG_MASK;
+    p->max_span_hint = 0;
+    p->step = 0;
+    return GD_OK;
+}
+
+int gd_create(int device_id, gd_ctx** out)
+{
+    if (!out) return GD_E_INVALID;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return GD_E_NODEVICE;
+    if (device_id < 0 || device_id >= n) return GD_E_RANGE;
+    gd_ctx* c = new (std::nothrow) gd_ctx();
+    if (!c) return GD_E_NOMEM;
+    c->device = device_id;
+    gd_default_params(&c->params);
+    if (const char* e = getenv("GOLEFT_GD_TILE")) {
+        int t = atoi(e);
+        if (t == 4096 || t == 8192 || t == 16384) c->tile_T = t;
+    }
+    auto bail = [&](hipError_t e) {
+        (void)e;
+        gd_destroy(c);
+        return GD_E_HIP;
+    };
+    hipError_t e;
+    if ((e = hipSetDevice(device_id)) != hipSuccess) return bail(e);
+    if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail(e);
+    if ((e = hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking)) != hipSuccess) return bail(e);
+    if ((e = hipEventCreateWithFlags(&c->copy_done, hipEventDisableTiming)) != hipSuccess) return bail(e);
+    for (auto& s : c->ring)
+        if ((e = hipEventCreateWithFlags(&s.done, hipEventDisableTiming)) != hipSuccess) return bail(e);
+    for (auto& ev : c->ev)
+        if ((e = hipEventCreate(&ev)) != hipSuccess) return bail(e);
+    if ((e = hipMalloc(reinterpret_cast<void**>(&c->d_counters), sizeof(gd::Counters))) != hipSuccess) return bail(e);
+    if ((e = hipMalloc(reinterpret_cast<void**>(&c->d_region_cursor), sizeof(uint32_t))) != hipSuccess) return bail(e);
+    if ((e = hipHostMalloc(reinterpret_cast<void**>(&c->h_counters), sizeof(gd::Counters), hipHostMallocDefault)) != hipSuccess) return bail(e);
+    *out = c;
+    return GD_OK;
+}
+
+void gd_destroy(gd_ctx* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
+    for (auto& h : c->contigs) free_contig(h);
+    for (auto& s : c->ring) {
+        if (s.b.pos) (void)hipHostFree(s.b.pos);
+        if (s.b.flag) (void)hipHostFree(s.b.flag);
+        if (s.b.mapq) (void)hipHostFree(s.b.mapq);
+        if (s.b.cigar_off) (void)hipHostFree(s.b.cigar_off);
+        if (s.b.cigar) (void)hipHostFree(s.b.cigar);
+        if (s.done) (void)hipEventDestroy(s.done);
+    }
+    for (auto& ev : c->ev) if (ev) (void)hipEventDestroy(ev);
+    if (c->copy_done) (void)hipEventDestroy(c->copy_done);
+    void* frees[] = {c->d_ctgs, c->d_tiles, c->d_perbase, c->d_wsum, c->d_wmin, c->d_chunks,
+                     c->d_ordered, c->d_tile_cnt, c->d_tile_off, c->d_tile_dst, c->d_counters,
+                     c->d_region_cursor};
+    for (void* p : frees) if (p) (void)hipFree(p);
+    if (c->h_counters) (void)hipHostFree(c->h_counters);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+    delete c;
+}
+
+const char* gd_last_error(const gd_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+int gd_set_stream(gd_ctx* c, void* s)
+{
+    if (!c) return GD_E_INVALID;
+    if (int r = set_device(c)) return r;
+    if (c->own_stream && c->stream) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipStreamDestroy(c->stream));
+    }
+    if (s) {
+        c->stream = static_cast<hipStream_t>(s);
+        c->own_stream = false;
+    } else {
+        HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        c->own_stream = true;
+    }
+    return GD_OK;
+}
+
+int gd_set_params(gd_ctx* c, const gd_params* p)
+{
+    if (!c || !p) return GD_E_INVALID;
+    if (p->window_size < 1) return fail(c, GD_E_INVALID, "window_size must be >= 1");
+    if (p->step < 0) return fail(c, GD_E_INVALID, "step must be >= 0");
+    if (p->step > 0 && p->step % p->window_size != 0)
+        return fail(c, GD_E_INVALID, "step must be a multiple of window_size");
+    c->params = *p;
+    if (p->max_span_hint > 0) c->lookback = p->max_span_hint;
+    c->computed = false;
+    return GD_OK;
+}
+
+int gd_set_contigs(gd_ctx* c, int n, const int64_t* lengths)
+{
+    if (!c || n < 0 || (n > 0 && !lengths)) return GD_E_INVALID;
+    if (int r = set_device(c)) return r;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->copy_stream));
+    for (auto& h : c->contigs) free_contig(h);
+    c->contigs.assign(n, ContigHost());
+    for (int i = 0; i < n; ++i) {
+        if (lengths[i] < 0 || lengths[i] > 0x7fffffffLL)
+            return fail(c, GD_E_RANGE, "contig %d length %lld out of range", i, (long long)lengths[i]);
+        c->contigs[i].length = lengths[i];
+    }
+    c->selected.clear();
+    c->computed = false;
+    return GD_OK;
+}
+
+int gd_select_contigs(gd_ctx* c, int n, const int32_t* tids)
+{
+    if (!c || n < 0 || (n > 0 && !tids)) return GD_E_INVALID;
+    std::vector<int32_t> s(tids, tids + n);
+    for (int32_t t : s)
+        if (t < 0 || (size_t)t >= c->contigs.size()) return fail(c, GD_E_RANGE, "tid %d out of range", t);
+    std::sort(s.begin(), s.end());
+    s.erase(std::unique(s.begin(), s.end()), s.end());
+    c->selected.swap(s);
+    c->computed = false;
+    return GD_OK;
+}
+
+int gd_acquire(gd_ctx* c, size_t reads_cap, size_t ops_cap, gd_batch* out)
+{
+    if (!c || !out) return GD_E_INVALID;
+    if (int r = set_device(c)) return r;
+    RingSlot& s = c->ring[c->ring_next];
+    if (s.busy) {
+        HIPCHK(c, hipEventSynchronize(s.done));
+        s.busy = false;
+    }
+    if (reads_cap < 1) reads_cap = 1;
+    if (ops_cap < 1) ops_cap = 1;
+    if (s.b.reads_cap < reads_cap) {
+        if (s.b.pos) { (void)hipHostFree(s.b.pos); (void)hipHostFree(s.b.flag);
+                       (void)hipHostFree(s.b.mapq); (void)hipHostFree(s.b.cigar_off); }
+        s.b.pos = nullptr; s.b.flag = nullptr; s.b.mapq = nullptr; s.b.cigar_off = nullptr;
+        s.b.reads_cap = 0;
+        HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&s.b.pos), reads_cap * sizeof(int32_t), hipHostMallocDefault));
+        HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&s.b.flag), reads_cap * sizeof(uint16_t), hipHostMallocDefault));
+        HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&s.b.mapq), reads_cap * sizeof(uint8_t), hipHostMallocDefault));
+        HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&s.b.cigar_off), (reads_cap + 1) * sizeof(uint32_t), hipHostMallocDefault));
+        s.b.reads_cap = reads_cap;
+    }
+    if (s.b.ops_cap < ops_cap) {
+        if (s.b.cigar) (void)hipHostFree(s.b.cigar);
+        s.b.cigar = nullptr;
+        s.b.ops_cap = 0;
+        HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&s.b.cigar), ops_cap * sizeof(uint32_t), hipHostMallocDefault));
+        s.b.ops_cap = ops_cap;
+    }
+    s.b.slot = c->ring_next;
+    *out = s.b;
+    return GD_OK;
+}
+
+int gd_commit(gd_ctx* c, const gd_batch* b, int32_t tid, size_t n_reads, size_t n_ops)
+{
+    if (!c || !b) return GD_E_INVALID;
+    if (int r = set_device(c)) return r;
+    if (b->slot < 0 || b->slot >= kRingSlots || c->ring[b->slot].b.pos != b->pos)
+        return fail(c, GD_E_INVALID, "batch was not obtained from gd_acquire");
+    if (tid < 0 || (size_t)tid >= c->contigs.size()) return fail(c, GD_E_RANGE, "tid %d out of range", tid);
+    if (n_reads > b->reads_cap || n_ops > b->ops_cap) return fail(c, GD_E_INVALID, "batch overflow");
+    RingSlot& s = c->ring[b->slot];
+    c->ring_next = (b->slot + 1) % kRingSlots;
+    if (n_reads == 0) return GD_OK;
+    ContigHost& h = c->contigs[tid];
+    if (h.adopted) return fail(c, GD_E_STATE, "contig %d holds adopted device records", tid);
+    if (b->cigar_off[0] != 0 || b->cigar_off[n_reads] != n_ops)
+        return fail(c, GD_E_INVALID, "cigar_off must start at 0 and end at n_ops");
+    if ((uint64_t)h.n_ops + n_ops > 0xffffffffull)
+        return fail(c, GD_E_RANGE, "more than 2^32 CIGAR ops on contig %d", tid);
+    // coordinate order (BAM SO:coordinate) is what makes the tile search valid
+    int32_t last = h.last_pos;
+    for (size_t i = 0; i < n_reads; ++i) {
+        if (b->pos[i] < last) return fail(c, GD_E_UNSORTED, "contig %d record %zu: pos %d < %d", tid, h.n_reads + i, b->pos[i], last);
+        if (b->cigar_off[i + 1] < b->cigar_off[i]) return fail(c, GD_E_INVALID, "cigar_off not monotone");
+        last = b->pos[i];
+    }
+    // rebase CSR offsets to the contig stream
+    const uint32_t base = (uint32_t)h.n_ops;
+    if (base)
+        for (size_t i = 0; i <= n_reads; ++i) b->cigar_off[i] += base;
+    size_t cr = h.cap_reads, cr1 = h.cap_reads ? h.cap_reads + 1 : 0, co = h.cap_ops;
+    size_t need_r = h.n_reads + n_reads;
+    if (need_r > h.cap_reads) {
+        size_t ncap = std::max(need_r, h.cap_reads * 2);
+        size_t c1 = cr, c2 = cr, c3 = cr;
+        if (int r = ensure_dev(c, &h.pos, &c1, ncap, true, h.n_reads)) return r;
+        if (int r = ensure_dev(c, &h.flag, &c2, ncap, true, h.n_reads)) return r;
+        if (int r = ensure_dev(c, &h.mapq, &c3, ncap, true, h.n_reads)) return r;
+        if (int r = ensure_dev(c, &h.off, &cr1, ncap + 1, true, h.n_reads ? h.n_reads + 1 : 0)) return r;
+        h.cap_reads = ncap;
+    }
+    if (h.n_ops + n_ops > h.cap_ops) {
+        size_t ncap = std::max(h.n_ops + n_ops, h.cap_ops * 2);
+        if (int r = ensure_dev(c, &h.cigar, &co, ncap, true, h.n_ops)) return r;
+        h.cap_ops = ncap;
+    }
+    hipStream_t cs = c->copy_stream;
+    HIPCHK(c, hipMemcpyAsync(h.pos + h.n_reads, b->pos, n_reads * sizeof(int32_t), hipMemcpyHostToDevice, cs));
+    HIPCHK(c, hipMemcpyAsync(h.flag + h.n_reads, b->flag, n_reads * sizeof(uint16_t), hipMemcpyHostToDevice, cs));
+    HIPCHK(c, hipMemcpyAsync(h.mapq + h.n_reads, b->mapq, n_reads * sizeof(uint8_t), hipMemcpyHostToDevice, cs));
+    HIPCHK(c, hipMemcpyAsync(h.off + h.n_reads, b->cigar_off, (n_reads + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, cs));
+    if (n_ops)
+        HIPCHK(c, hipMemcpyAsync(h.cigar + h.n_ops, b->cigar, n_ops * sizeof(uint32_t), hipMemcpyHostToDevice, cs));
+    HIPCHK(c, hipEventRecord(s.done, cs));
+    s.busy = true;
+    h.n_reads += n_reads;
+    h.n_ops += n_ops;
+    h.last_pos = last;
+    c->computed = false;
+    return GD_OK;
+}
+
+int gd_push(gd_ctx* c, int32_t tid, const int32_t* pos, const uint16_t* flag, const uint8_t* mapq,
+            const uint32_t* cigar_off, const uint32_t* cigar, size_t n_reads, size_t n_ops)
+{
+    if (!c) return GD_E_INVALID;
+    if (n_reads == 0) return GD_OK;
+    if (!pos || !flag || !mapq || !cigar_off || (n_ops && !cigar)) return GD_E_INVALID;
+    const size_t chunk = 1u << 22;   // records per staging block
+    size_t i = 0;
+    while (i < n_reads) {
+        size_t n = std::min(chunk, n_reads - i);
+        size_t o0 = cigar_off[i], o1 = cigar_off[i + n];
+        if (o1 < o0 || o1 > n_ops) return fail(c, GD_E_INVALID, "cigar_off out of range");
+        gd_batch b;
+        if (int r = gd_acquire(c, n, o1 - o0, &b)) return r;
+        memcpy(b.pos, pos + i, n * sizeof(int32_t));
+        memcpy(b.flag, flag + i, n * sizeof(uint16_t));
+        memcpy(b.mapq, mapq + i, n * sizeof(uint8_t));
+        for (size_t k = 0; k <= n; ++k) b.cigar_off[k] = cigar_off[i + k] - (uint32_t)o0;
+        if (o1 > o0) memcpy(b.cigar, cigar + o0, (o1 - o0) * sizeof(uint32_t));
+        if (int r = gd_commit(c, &b, tid, n, o1 - o0)) return r;
+        i += n;
+    }
+    return GD_OK;
+}
+
+int gd_adopt_device(gd_ctx* c, int32_t tid, const gd_batch* d, size_t n_reads, size_t n_ops)
+{
+    if (!c || !d) return GD_E_INVALID;
+    if (int r = set_device(c)) return r;
+    if (tid < 0 || (size_t)tid >= c->contigs.size()) return fail(c, GD_E_RANGE, "tid %d out of range", tid);
+    if (n_reads && (!d->pos || !d->flag || !d->mapq || !d->cigar_off)) return GD_E_INVALID;
+    if (n_ops > 0xffffffffull) return fail(c, GD_E_RANGE, "more than 2^32 CIGAR ops");
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->copy_stream));
+    ContigHost& h = c->contigs[tid];
+    int64_t len = h.length;
+    free_contig(h);
+    h.length = len;
+    h.pos = d->pos; h.flag = d->flag; h.mapq = d->mapq; h.off = d->cigar_off; h.cigar = d->cigar;
+    h.n_reads = n_reads; h.n_ops = n_ops;
+    h.adopted = true;
+    c->computed = false;
+    return GD_OK;
+}
+
+int gd_reset(gd_ctx* c)
+{
+    if (!c) return GD_E_INVALID;
+    if (int r = set_device(c)) return r;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->copy_stream));
+    for (auto& h : c->contigs) {
+        int64_t len = h.length;
+        free_contig(h);
+        h.length = len;
+    }
+    c->bounds.clear();
+    c->computed = false;
+    return GD_OK;
+}
+
+int gd_compute(gd_ctx* c)
+{
+    if (!c) return GD_E_INVALID;
+    if (int r = set_device(c)) return r;
+    if (c->contigs.empty()) return fail(c, GD_E_STATE, "gd_set_contigs has not been called");
+    const int T = c->tile_T;
+    const gd_params& P = c->params;
+
+    // ---- contig table ------------------------------------------------------
+    std::vector<int32_t> tids = c->selected;
+    if (tids.empty()) { tids.resize(c->contigs.size()); for (size_t i = 0; i < tids.size(); ++i) tids[i] = (int32_t)i; }
+    for (auto& h : c->contigs) { h.base_off = h.win_off = -1; h.n_win = 0; h.run_beg = h.run_end = 0; }
+    c->h_ctgs.clear();
+    c->job_tids.clear();
+    int64_t tile_beg = 0, base_off = 0, win_off = 0, bases = 0;
+    uint64_t n_reads = 0, n_ops = 0;
+    for (int32_t tid : tids) {
+        ContigHost& h = c->contigs[tid];
+        if (h.length <= 0) continue;
+        gd::ContigDev d{};
+        d.pos = h.pos; d.flag = h.flag; d.mapq = h.mapq; d.off = h.off; d.cigar = h.cigar;
+        d.n_reads = (uint32_t)h.n_reads;
+        d.length = (int32_t)h.length;
+        d.tile_beg = (int32_t)tile_beg;
+        d.n_tiles = (int32_t)((h.length + T - 1) / T);
+        d.base_off = base_off;
+        d.win_off = win_off;
+        d.tid = tid;
+        h.base_off = base_off;
+        h.win_off = win_off;
+        h.n_win = (h.length + P.window_size - 1) / P.window_size;
+        tile_beg += d.n_tiles;
+        base_off += (int64_t)d.n_tiles * T;
+        win_off += h.n_win;
+        bases += h.length;
+        n_reads += h.n_reads;
+        n_ops += h.n_ops;
+        c->h_ctgs.push_back(d);
+        c->job_tids.push_back(tid);
+    }
+    if (tile_beg > 0x7fffffffLL) return fail(c, GD_E_RANGE, "too many tiles");
+    c->n_tiles = tile_beg;
+    c->n_win_total = win_off;
+    c->n_bases = bases;
+    c->bounds.clear();
+    memset(c->kernel_ms, 0, sizeof c->kernel_ms);
+    if (c->n_tiles == 0) { c->computed = true; return GD_OK; }
+
+    // ---- allocations -------------------------------------------------------
+    size_t cap;
+    if (int r = ensure_dev(c, &c->d_ctgs, &c->cap_ctgs, c->h_ctgs.size())) return r;
+    cap = c->cap_tiles;
+    if ((size_t)c->n_tiles > c->cap_tiles) {
+        size_t c1 = cap, c2 = cap, c3 = cap, c4 = cap;
+        if (int r = ensure_dev(c, &c->d_tiles, &c1, (size_t)c->n_tiles)) return r;
+        if (int r = ensure_dev(c, &c->d_tile_cnt, &c2, (size_t)c->n_tiles)) return r;
+        if (int r = ensure_dev(c, &c->d_tile_off, &c3, (size_t)c->n_tiles)) return r;
+        if (int r = ensure_dev(c, &c->d_tile_dst, &c4, (size_t)c->n_tiles)) return r;
+        c->cap_tiles = c1;
+    }
+    if (int r = ensure_dev(c, &c->d_perbase, &c->cap_perbase, (size_t)base_off)) return r;
+    if ((size_t)win_off > c->cap_win || !c->d_wsum) {
+        size_t c1 = c->cap_win, c2 = c->cap_win;
+        if (int r = ensure_dev(c, &c->d_wsum, &c1, (size_t)std::max<int64_t>(win_off, 1))) return r;
+        if (int r = ensure_dev(c, &c->d_wmin, &c2, (size_t)std::max<int64_t>(win_off, 1))) return r;
+        c->cap_win = c1;
+    }
+    if (!c->d_chunks) {
+        size_t want = std::max<size_t>(1u << 16, (size_t)c->n_tiles * 2);
+        size_t c1 = 0, c2 = 0;
+        if (int r = ensure_dev(c, &c->d_chunks, &c1, want)) return r;
+        if (int r = ensure_dev(c, &c->d_ordered, &c2, want)) return r;
+        c->cap_runs = c1;
+    }
+    HIPCHK(c, hipMemcpyAsync(c->d_ctgs, c->h_ctgs.data(), c->h_ctgs.size() * sizeof(gd::ContigDev),
+                             hipMemcpyHostToDevice, c->stream));
+    // records staged on the copy stream must have landed
+    HIPCHK(c, hipEventRecord(c->copy_done, c->copy_stream));
+    HIPCHK(c, hipStreamWaitEvent(c->stream, c->copy_done, 0));
+
+    int reruns = 0;
+    for (;;) {
+        gd::Job job{};
+        job.ctgs = c->d_ctgs;
+        job.n_ctgs = (int32_t)c->h_ctgs.size();
+        job.n_tiles = (int32_t)c->n_tiles;
+        job.tiles = c->d_tiles;
+        job.perbase = c->d_perbase;
+        job.win_sum = c->d_wsum;
+        job.win_min = c->d_wmin;
+        job.n_win_total = c->n_win_total;
+        job.run_chunks = c->d_chunks;
+        job.run_cap = (uint32_t)std::min<size_t>(c->cap_runs, 0xffffffffu);
+        job.tile_cnt = c->d_tile_cnt;
+        job.tile_off = c->d_tile_off;
+        job.counters = c->d_counters;
+        job.W = P.window_size;
+        job.Q = P.min_mapq;
+        job.mincov = P.min_cov;
+        job.maxmean = P.max_mean_depth;
+        job.flag_mask = P.flag_mask;
+        job.lookback = c->lookback;
+        job.step = derive_step(P);
+
+        if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+        switch (T) {
+        case 4096: launch_prep<4096>(c, job); break;
+        case 16384: launch_prep<16384>(c, job); break;
+        default: launch_prep<8192>(c, job); break;
+        }
+        if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+        switch (T) {
+        case 4096: launch_tile<4096, 256>(c, job); break;
+        case 16384: launch_tile<16384, 512>(c, job); break;
+        default: launch_tile<8192, 256>(c, job); break;
+        }
+        if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
+        hipLaunchKernelGGL(gd::gd_runs_scan_kernel, dim3(1), dim3(1024), 0, c->stream,
+                           c->d_tile_cnt, c->d_tile_dst, (int)c->n_tiles);
+        {
+            int64_t threads = c->n_tiles * 64;
+            hipLaunchKernelGGL(gd::gd_runs_gather_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
+                               c->stream, c->d_chunks, job.run_cap, c->d_tile_cnt, c->d_tile_off,
+                               c->d_tile_dst, c->d_ordered, (int)c->n_tiles);
+        }
+        if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipMemcpyAsync(c->h_counters, c->d_counters, sizeof(gd::Counters), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+
+        const gd::Counters k = *c->h_counters;
+        c->stats.max_span_seen = k.max_span > 0 ? k.max_span : 0;
+        if (k.max_span > c->lookback) {
+            // a kept read spans more reference than the look-back: redo with the observed maximum
+            c->lookback = (k.max_span + 255) & ~255;
+            ++reruns;
+            continue;
+        }
+        if ((size_t)k.run_cursor > c->cap_runs) {
+            size_t want = (size_t)k.run_cursor + (size_t)k.run_cursor / 8 + 1024;
+            size_t c1 = c->cap_runs, c2 = c->cap_runs;
+            if (int r = ensure_dev(c, &c->d_chunks, &c1, want)) return r;
+            if (int r = ensure_dev(c, &c->d_ordered, &c2, want)) return r;
+            c->cap_runs = c1;
+            ++reruns;
+            continue;
+        }
+        // ---- ordered boundaries to the host (small) -------------------------
+        c->bounds.resize(k.run_cursor);
+        if (k.run_cursor)
+            HIPCHK(c, hipMemcpy(c->bounds.data(), c->d_ordered, (size_t)k.run_cursor * sizeof(int2), hipMemcpyDeviceToHost));
+        break;
+    }
+    if (c->profiling) {
+        for (int i = 0; i < GD_K_COUNT; ++i) {
+            float ms = 0;
+            HIPCHK(c, hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]));
+            c->kernel_ms[i] = ms;
+        }
+    }
+    // slice the boundary list per contig
+    {
+        size_t i = 0;
+        const size_t n = c->bounds.size();
+        for (size_t j = 0; j < c->job_tids.size(); ++j) {
+            ContigHost& h = c->contigs[c->job_tids[j]];
+            h.run_beg = i;
+            while (i < n && (size_t)(c->bounds[i].y >> 2) == j) ++i;
+            h.run_end = i;
+        }
+        if (i != n) return fail(c, GD_E_HIP, "run boundaries out of order (internal error)");
+    }
+    c->stats.n_reads = n_reads;
+    c->stats.n_ops = n_ops;
+    c->stats.n_ref_bases = (uint64_t)bases;
+    c->stats.n_windows = (uint64_t)c->n_win_total;
+    c->stats.n_tiles = (uint64_t)c->n_tiles;
+    c->stats.n_runs = c->bounds.size();
+    c->stats.tile_positions = T;
+    c->stats.lookback = c->lookback;
+    c->stats.reruns = reruns;
+    c->computed = true;
+    return GD_OK;
+}
+
+static int check_result_tid(gd_ctx* c, int32_t tid)
+{
+    if (!c->computed) return fail(c, GD_E_STATE, "no results: call gd_compute first");
+    if (tid < 0 || (size_t)tid >= c->contigs.size()) return fail(c, GD_E_RANGE, "tid %d out of range", tid);
+    if (c->contigs[tid].length > 0 && c->contigs[tid].base_off < 0)
+        return fail(c, GD_E_RANGE, "contig %d was not selected in the last gd_compute", tid);
+    return GD_OK;
+}
+
+int gd_perbase(gd_ctx* c, int32_t tid, int64_t start, int64_t end, int32_t* out)
+{
+    if (!c || !out) return GD_E_INVALID;
+    if (int r = set_device(c)) return r;
+    if (int r = check_result_tid(c, tid)) return r;
+    const ContigHost& h = c->contigs[tid];
+    if (start < 0 || end < start || end > h.length) return fail(c, GD_E_RANGE, "region [%lld,%lld) outside contig of length %lld", (long long)start, (long long)end, (long long)h.length);
+    if (end == start) return GD_OK;
+    HIPCHK(c, hipMemcpy(out, c->d_perbase + h.base_off + start, (size_t)(end - start) * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return GD_OK;
+}
+
+int gd_windows(gd_ctx* c, int32_t tid, int64_t* sums, int32_t* mins, size_t cap, size_t* n)
+{
+    if (!c || !n) return GD_E_INVALID;
+    if (int r = set_device(c)) return r;
+    if (int r = check_result_tid(c, tid)) return r;
+    const ContigHost& h = c->contigs[tid];
+    *n = (size_t)h.n_win;
+    if (h.n_win == 0) return GD_OK;
+    if (cap < (size_t)h.n_win || !sums) return fail(c, GD_E_CAPACITY, "need room for %lld windows", (long long)h.n_win);
+    HIPCHK(c, hipMemcpy(sums, c->d_wsum + h.win_off, (size_t)h.n_win * sizeof(int64_t), hipMemcpyDeviceToHost));
+    if (mins)
+        HIPCHK(c, hipMemcpy(mins, c->d_wmin + h.win_off, (size_t)h.n_win * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return GD_OK;
+}
+
+int gd_callable(gd_ctx* c, int32_t tid, gd_run* out, size_t cap, size_t* n)
+{
+    if (!c || !n) return GD_E_INVALID;
+    if (int r = check_result_tid(c, tid)) return r;
+    const ContigHost& h = c->contigs[tid];
+    const size_t k = h.run_end - h.run_beg;
+    *n = k;
+    if (k == 0) return GD_OK;
+    if (cap < k || !out) return fail(c, GD_E_CAPACITY, "need room for %zu runs", k);
+    for (size_t i = 0; i < k; ++i) {
+        const int2 b = c->bounds[h.run_beg + i];
+        out[i].start = b.x;
+        out[i].cls = b.y & 3;
+        out[i].end = (i + 1 < k) ? c->bounds[h.run_beg + i + 1].x : (int32_t)h.length;
+    }
+    return GD_OK;
+}
+
+int gd_region_windows(gd_ctx* c, int32_t tid, int64_t start, int64_t end, int64_t* sums,
+                      int32_t* mins, size_t cap, size_t* n)
+{
+    if (!c || !n) return GD_E_INVALID;
+    if (int r = set_device(c)) return r;
+    if (int r = check_result_tid(c, tid)) return r;
+    if (start < 0 || end < start) return fail(c, GD_E_RANGE, "bad region");
+    const ContigHost& h = c->contigs[tid];
+    const int64_t W = c->params.window_size;
+    if (end == start) { *n = 0; return GD_OK; }
+    const int64_t first = start / W, last = (end - 1) / W;
+    const size_t k = (size_t)(last - first + 1);
+    *n = k;
+    if (cap < k || !sums) return fail(c, GD_E_CAPACITY, "need room for %zu windows", k);
+    if (h.length <= 0) { for (size_t i = 0; i < k; ++i) { sums[i] = 0; if (mins) mins[i] = 0; } return GD_OK; }
+    int64_t* d_s = nullptr;
+    int32_t* d_m = nullptr;
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&d_s), k * sizeof(int64_t)));
+    if (hipMalloc(reinterpret_cast<void**>(&d_m), k * sizeof(int32_t)) != hipSuccess) { (void)hipFree(d_s); return fail(c, GD_E_NOMEM, "hipMalloc"); }
+    hipLaunchKernelGGL(gd::gd_region_windows_kernel, dim3((unsigned)k), dim3(256), 0, c->stream,
+                       c->d_perbase + h.base_off, h.length, start, end, (int32_t)W, first, d_s, d_m);
+    hipError_t e1 = hipMemcpyAsync(sums, d_s, k * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream);
+    hipError_t e2 = mins ? hipMemcpyAsync(mins, d_m, k * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream) : hipSuccess;
+    hipError_t e3 = hipStreamSynchronize(c->stream);
+    (void)hipFree(d_s);
+    (void)hipFree(d_m);
+    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) return fail(c, GD_E_HIP, "region window reduction failed");
+    return GD_OK;
+}
+
+int gd_region_callable(gd_ctx* c, int32_t tid, int64_t start, int64_t end, gd_run* out, size_t cap, size_t* n)
+{
+    if (!c || !n) return GD_E_INVALID;
+    if (int r = set_device(c)) return r;
+    if (int r = check_result_tid(c, tid)) return r;
+    if (start < 0 || end < start || end > 0x7fffffffLL) return fail(c, GD_E_RANGE, "bad region");
+    const ContigHost& h = c->contigs[tid];
+    if (end == start) { *n = 0; return GD_OK; }
+    if (h.length <= 0) {
+        *n = 1;
+        if (cap < 1 || !out) return fail(c, GD_E_CAPACITY, "need room for 1 run");
+        out[0].start = (int32_t)start; out[0].end = (int32_t)end; out[0].cls = GD_NO_COVERAGE;
+        return GD_OK;
+    }
+    size_t bcap = std::max<size_t>(cap, 1024);
+    for (;;) {
+        int2* d_b = nullptr;
+        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&d_b), bcap * sizeof(int2)));
+        (void)hipMemsetAsync(c->d_region_cursor, 0, sizeof(uint32_t), c->stream);
+        int64_t len = end - start;
+        unsigned blocks = (unsigned)std::min<int64_t>((len + 255) / 256, 4096);
+        hipLaunchKernelGGL(gd::gd_region_bounds_kernel, dim3(blocks), dim3(256), 0, c->stream,
+                           c->d_perbase + h.base_off, h.length, start, end, c->params.min_cov,
+                           c->params.max_mean_depth, d_b, (uint32_t)std::min<size_t>(bcap, 0xffffffffu),
+                           c->d_region_cursor);
+        uint32_t cnt = 0;
+        hipError_t e1 = hipMemcpyAsync(&cnt, c->d_region_cursor, sizeof cnt, hipMemcpyDeviceToHost, c->stream);
+        hipError_t e2 = hipStreamSynchronize(c->stream);
+        if (e1 != hipSuccess || e2 != hipSuccess) { (void)hipFree(d_b); return fail(c, GD_E_HIP, "region class reduction failed"); }
+        if (cnt > bcap) { (void)hipFree(d_b); bcap = cnt; continue; }
+        std::vector<int2> b(cnt);
+        hipError_t e3 = cnt ? hipMemcpy(b.data(), d_b, cnt * sizeof(int2), hipMemcpyDeviceToHost) : hipSuccess;
+        (void)hipFree(d_b);
+        if (e3 != hipSuccess) return fail(c, GD_E_HIP, "region class copy failed");
+        std::sort(b.begin(), b.end(), [](const int2& a, const int2& z) { return a.x < z.x; });
+        *n = cnt;
+        if (cap < cnt || !out) return fail(c, GD_E_CAPACITY, "need room for %u runs", cnt);
+        for (uint32_t i = 0; i < cnt; ++i) {
+            out[i].start = b[i].x;
+            out[i].cls = b[i].y & 3;
+            out[i].end = (i + 1 < cnt) ? b[i + 1].x : (int32_t)end;
+        }
+        return GD_OK;
+    }
+}
+
+int gd_device_perbase(gd_ctx* c, int32_t tid, const int32_t** dptr, int64_t* len)
+{
+    if (!c || !dptr) return GD_E_INVALID;
+    if (int r = check_result_tid(c, tid)) return r;
+    const ContigHost& h = c->contigs[tid];
+    *dptr = h.length > 0 ? c->d_perbase + h.base_off : nullptr;
+    if (len) *len = h.length;
+    return GD_OK;
+}
+
+int gd_device_windows(gd_ctx* c, const int64_t** d_sums, const int32_t** d_mins, size_t* n_total)
+{
+    if (!c) return GD_E_INVALID;
+    if (!c->computed) return fail(c, GD_E_STATE, "no results: call gd_compute first");
+    if (d_sums) *d_sums = c->d_wsum;
+    if (d_mins) *d_mins = c->d_wmin;
+    if (n_total) *n_total = (size_t)c->n_win_total;
+    return GD_OK;
+}
+
+int gd_window_offset(gd_ctx* c, int32_t tid, size_t* off, size_t* n)
+{
+    if (!c) return GD_E_INVALID;
+    if (int r = check_result_tid(c, tid)) return r;
+    const ContigHost& h = c->contigs[tid];
+    if (off) *off = h.win_off < 0 ? 0 : (size_t)h.win_off;
+    if (n) *n = (size_t)h.n_win;
+    return GD_OK;
+}
+
+int gd_device_runs(gd_ctx* c, const int32_t** d_bounds, size_t* n_bounds)
+{
+    if (!c) return GD_E_INVALID;
+    if (!c->computed) return fail(c, GD_E_STATE, "no results: call gd_compute first");
+    if (d_bounds) *d_bounds = reinterpret_cast<const int32_t*>(c->d_ordered);
+    if (n_bounds) *n_bounds = c->bounds.size();
+    return GD_OK;
+}
+
+int gd_get_stats(gd_ctx* c, gd_stats* out)
+{
+    if (!c || !out) return GD_E_INVALID;
+    *out = c->stats;
+    return GD_OK;
+}
+
+int gd_set_profiling(gd_ctx* c, int on)
+{
+    if (!c) return GD_E_INVALID;
+    c->profiling = on != 0;
+    return GD_OK;
+}
+
+int gd_kernel_ms(gd_ctx* c, int id, float* ms)
+{
+    if (!c || !ms || id < 0 || id >= GD_K_COUNT) return GD_E_INVALID;
+    *ms = c->kernel_ms[id];
+    return GD_OK;
+}
+
+}  // extern "C"

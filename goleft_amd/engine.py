@@ -1,0 +1,209 @@
+"""DepthEngine -- thin Python handle on the C ABI (include/goleft_depth.h).
+
+Host-side convenience used by the `depth` front end (depth.py), the tests and
+bench.py.  All arithmetic happens in the HIP library; numpy is only the
+container for inputs and results."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+from ._lib import GdBatch, GdParams, GdRun, GdStats
+
+CLASS_NAMES = ("NO_COVERAGE", "LOW_COVERAGE", "CALLABLE", "EXCESSIVE_COVERAGE")
+K_PREP, K_TILE, K_RUNS = 0, 1, 2
+
+
+class GdError(RuntimeError):
+    def __init__(self, status: int, msg: str):
+        super().__init__("goleft_depth: %s (status %d)" % (msg, status))
+        self.status = status
+
+
+class DepthEngine:
+    """One context == one HIP device."""
+
+    def __init__(self, device: int = 0, stream: Optional[int] = None):
+        self._lib = _lib.load()
+        self._ctx = C.c_void_p()
+        rc = self._lib.gd_create(device, C.byref(self._ctx))
+        if rc != 0:
+            raise GdError(rc, self._lib.gd_strerror(rc).decode())
+        self.device = device
+        self.contig_lengths: list[int] = []
+        self._keep = []   # device tensors adopted by the engine must stay alive
+        if stream is not None:
+            self._chk(self._lib.gd_set_stream(self._ctx, C.c_void_p(stream)))
+
+    # -- plumbing ---------------------------------------------------------
+    def _chk(self, rc: int):
+        if rc != 0:
+            detail = self._lib.gd_last_error(self._ctx).decode()
+            raise GdError(rc, "%s: %s" % (self._lib.gd_strerror(rc).decode(), detail))
+
+    def close(self):
+        if getattr(self, "_ctx", None) is not None and self._ctx:
+            self._lib.gd_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # -- configuration ----------------------------------------------------
+    def set_params(self, window_size=250, min_mapq=1, min_cov=4, max_mean_depth=0,
+                   flag_mask=0x704, max_span_hint=0, step=0):
+        p = GdParams(window_size, min_mapq, min_cov, max_mean_depth, flag_mask, max_span_hint, step)
+        self._chk(self._lib.gd_set_params(self._ctx, C.byref(p)))
+        self.params = p
+
+    def set_contigs(self, lengths: Sequence[int]):
+        a = np.asarray(lengths, dtype=np.int64)
+        self._chk(self._lib.gd_set_contigs(self._ctx, len(a), a.ctypes.data))
+        self.contig_lengths = [int(x) for x in a]
+        self._keep = []
+
+    def select_contigs(self, tids: Sequence[int]):
+        a = np.asarray(tids, dtype=np.int32)
+        self._chk(self._lib.gd_select_contigs(self._ctx, len(a), a.ctypes.data if len(a) else None))
+
+    # -- ingest -----------------------------------------------------------
+    def push(self, tid: int, pos, flag, mapq, cigar_off, cigar):
+        pos = np.ascontiguousarray(pos, np.int32)
+        flag = np.ascontiguousarray(flag, np.uint16)
+        mapq = np.ascontiguousarray(mapq, np.uint8)
+        cigar_off = np.ascontiguousarray(cigar_off, np.uint32)
+        cigar = np.ascontiguousarray(cigar, np.uint32)
+        n = pos.shape[0]
+        assert cigar_off.shape[0] == n + 1
+        self._chk(self._lib.gd_push(self._ctx, tid, pos.ctypes.data, flag.ctypes.data,
+                                    mapq.ctypes.data, cigar_off.ctypes.data,
+                                    cigar.ctypes.data if cigar.shape[0] else None,
+                                    n, cigar.shape[0]))
+
+    def acquire(self, reads_cap: int, ops_cap: int) -> GdBatch:
+        b = GdBatch()
+        self._chk(self._lib.gd_acquire(self._ctx, reads_cap, ops_cap, C.byref(b)))
+        return b
+
+    def commit(self, b: GdBatch, tid: int, n_reads: int, n_ops: int):
+        self._chk(self._lib.gd_commit(self._ctx, C.byref(b), tid, n_reads, n_ops))
+
+    def adopt_device(self, tid: int, pos, flag, mapq, cigar_off, cigar):
+        """Zero-copy: torch device tensors (int32/int16/uint8/int32/int32 storage)."""
+        n = int(pos.shape[0])
+        m = int(cigar.shape[0])
+        assert int(cigar_off.shape[0]) == n + 1
+        for t, sz in ((pos, 4), (flag, 2), (mapq, 1), (cigar_off, 4), (cigar, 4)):
+            assert t.is_cuda and t.is_contiguous() and t.element_size() == sz
+        b = GdBatch(pos.data_ptr(), flag.data_ptr(), mapq.data_ptr(), cigar_off.data_ptr(),
+                    cigar.data_ptr(), n, m, -1)
+        self._chk(self._lib.gd_adopt_device(self._ctx, tid, C.byref(b), n, m))
+        self._keep.append((pos, flag, mapq, cigar_off, cigar))
+
+    def reset(self):
+        self._chk(self._lib.gd_reset(self._ctx))
+        self._keep = []
+
+    # -- compute ----------------------------------------------------------
+    def compute(self):
+        self._chk(self._lib.gd_compute(self._ctx))
+
+    def set_profiling(self, on: bool):
+        self._chk(self._lib.gd_set_profiling(self._ctx, int(on)))
+
+    def kernel_ms(self, kernel_id: int) -> float:
+        ms = C.c_float()
+        self._chk(self._lib.gd_kernel_ms(self._ctx, kernel_id, C.byref(ms)))
+        return float(ms.value)
+
+    def stats(self) -> GdStats:
+        s = GdStats()
+        self._chk(self._lib.gd_get_stats(self._ctx, C.byref(s)))
+        return s
+
+    # -- results ----------------------------------------------------------
+    def perbase(self, tid: int, start: int = 0, end: Optional[int] = None) -> np.ndarray:
+        if end is None:
+            end = self.contig_lengths[tid]
+        out = np.empty(max(0, end - start), np.int32)
+        self._chk(self._lib.gd_perbase(self._ctx, tid, start, end, out.ctypes.data))
+        return out
+
+    def windows(self, tid: int):
+        n = C.c_size_t()
+        W = self.params.window_size
+        cap = (self.contig_lengths[tid] + W - 1) // W
+        sums = np.empty(cap, np.int64)
+        mins = np.empty(cap, np.int32)
+        self._chk(self._lib.gd_windows(self._ctx, tid, sums.ctypes.data, mins.ctypes.data, cap,
+                                       C.byref(n)))
+        return sums[:n.value], mins[:n.value]
+
+    def _runs(self, fn, *args):
+        n = C.c_size_t()
+        cap = 1024
+        while True:
+            buf = (GdRun * cap)()
+            rc = fn(self._ctx, *args, buf, cap, C.byref(n))
+            if rc == -8:  # GD_E_CAPACITY
+                cap = n.value
+                continue
+            self._chk(rc)
+            a = np.frombuffer(buf, dtype=np.int32, count=3 * n.value).reshape(-1, 3).copy()
+            return a
+
+    def callable_runs(self, tid: int) -> np.ndarray:
+        """[n,3] int32 rows (start, end, class)."""
+        return self._runs(self._lib.gd_callable, tid)
+
+    def region_windows(self, tid: int, start: int, end: int):
+        n = C.c_size_t()
+        W = self.params.window_size
+        cap = max(1, (end - 1) // W - start // W + 1) if end > start else 1
+        sums = np.empty(cap, np.int64)
+        mins = np.empty(cap, np.int32)
+        self._chk(self._lib.gd_region_windows(self._ctx, tid, start, end, sums.ctypes.data,
+                                              mins.ctypes.data, cap, C.byref(n)))
+        return sums[:n.value], mins[:n.value]
+
+    def region_callable(self, tid: int, start: int, end: int) -> np.ndarray:
+        return self._runs(self._lib.gd_region_callable, tid, start, end)
+
+    def device_windows(self):
+        """(ptr_sums, ptr_mins, n_total) device views of the concatenated window arrays."""
+        ps, pm, n = C.c_void_p(), C.c_void_p(), C.c_size_t()
+        self._chk(self._lib.gd_device_windows(self._ctx, C.byref(ps), C.byref(pm), C.byref(n)))
+        return ps.value, pm.value, n.value
+
+    def device_runs(self):
+        p, n = C.c_void_p(), C.c_size_t()
+        self._chk(self._lib.gd_device_runs(self._ctx, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def device_perbase(self, tid: int):
+        p, n = C.c_void_p(), C.c_int64()
+        self._chk(self._lib.gd_device_perbase(self._ctx, tid, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def window_offset(self, tid: int):
+        o, n = C.c_size_t(), C.c_size_t()
+        self._chk(self._lib.gd_window_offset(self._ctx, tid, C.byref(o), C.byref(n)))
+        return o.value, n.value
+
+
+def device_count() -> int:
+    n = C.c_int()
+    _lib.load().gd_device_count(C.byref(n))
+    return n.value

@@ -1,0 +1,215 @@
+/*
+ * goleft_depth.h -- C ABI of the MI355X-native per-base depth engine.
+ *
+ * This is the drop-in boundary for ONE path of brentp/goleft: the `depth`
+ * subcommand (reference paths below are relative to /root/reference).
+ * The reference has no FFI for this path: its seam is a subprocess per
+ * 10 Mb tile -- `samtools depth -Q q -d D -r chr:s-e bam` spawned through
+ * gargs `process.Runner` (depth/depth.go:45, :392-394) whose text output is
+ * re-parsed by the `callback` closure (depth/depth.go:238-364).  This library
+ * replaces that subprocess, the text pipe and the per-line parse; the host
+ * keeps flags, tiling and BED formatting (INTEGRATION.md shows the cgo stub).
+ *
+ * Conventions
+ *   - plain C: opaque context, plain pointers and sizes, no C++/torch types;
+ *   - every call returns 0 (GD_OK) or a negative gd_status; the library never
+ *     exits or aborts (the Go host folds failures into its exit code the way
+ *     depth/depth.go:395-399 does);
+ *   - the library never retains caller host pointers after a call returns
+ *     (cgo rule); staging memory handed out by gd_acquire is library-owned
+ *     pinned memory; device pointers given to gd_adopt_device stay owned by
+ *     the caller and must outlive the context or the next gd_reset;
+ *   - all results are integers (int32 per base, int64 window sums, int32
+ *     window minima, {start,end,class} runs); `%.4g` and BED text stay on the
+ *     host so results are bit-exact by construction;
+ *   - coordinates are 0-based half-open; CIGARs use the BAM encoding
+ *     (len<<4 | op, op in MIDNSHP=X = 0..8), i.e. biogo `sam.CigarOp` memory.
+ *   - calls on one context must be serialised by the caller; distinct
+ *     contexts (one per device / per producer thread) are independent.
+ */
+#ifndef GOLEFT_DEPTH_H
+#define GOLEFT_DEPTH_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GD_ABI_VERSION 1
+
+typedef enum {
+    GD_OK = 0,
+    GD_E_INVALID = -1,   /* bad argument */
+    GD_E_NOMEM = -2,     /* host or device allocation failed */
+    GD_E_HIP = -3,       /* a HIP runtime call failed (see gd_last_error) */
+    GD_E_STATE = -4,     /* call out of order (e.g. results before compute) */
+    GD_E_RANGE = -5,     /* tid / coordinate out of range */
+    GD_E_NODEVICE = -6,  /* no usable gfx950 device */
+    GD_E_UNSORTED = -7,  /* records not coordinate sorted within a contig */
+    GD_E_CAPACITY = -8   /* caller buffer too small (needed size reported) */
+} gd_status;
+
+/* Coverage classes, depth/depth.go:223-234 getCovClass. */
+enum { GD_NO_COVERAGE = 0, GD_LOW_COVERAGE = 1, GD_CALLABLE = 2, GD_EXCESSIVE_COVERAGE = 3 };
+
+/* samtools depth default read filter UNMAP|SECONDARY|QCFAIL|DUP. */
+#define GD_DEFAULT_FLAG_MASK 0x704u
+
+typedef struct gd_ctx gd_ctx;
+
+/* Mirrors the `dargs` fields that reach the arithmetic (depth/depth.go:27-41;
+ * defaults depth/depth.go:164-167). */
+typedef struct {
+    int32_t  window_size;     /* --windowsize, default 250 */
+    int32_t  min_mapq;        /* -Q, default 1 (samtools depth -Q) */
+    int32_t  min_cov;         /* --mincov, default 4 */
+    int32_t  max_mean_depth;  /* --maxmeandepth, default 0 (EXCESSIVE class off) */
+    uint32_t flag_mask;       /* reads with flag & mask are dropped; 0x704 */
+    int32_t  max_span_hint;   /* expected max reference span of a read (0 = default 1024);
+                                 only a performance hint: the engine verifies it on device
+                                 and transparently re-runs with the observed maximum */
+    int64_t  step;            /* callable runs are split at multiples of this
+                                 (depth/depth.go:48,:132; quirk Q1); 0 = derive
+                                 max(1,10000000/W)*W */
+} gd_params;
+
+/* One block of decoded records, SoA.  For gd_acquire the pointers are pinned
+ * host memory owned by the library; for gd_adopt_device they are device
+ * pointers owned by the caller. */
+typedef struct {
+    int32_t*  pos;        /* [reads_cap]   0-based leftmost position */
+    uint16_t* flag;       /* [reads_cap]   BAM FLAG */
+    uint8_t*  mapq;       /* [reads_cap]   MAPQ */
+    uint32_t* cigar_off;  /* [reads_cap+1] CSR offsets into cigar[], block relative */
+    uint32_t* cigar;      /* [ops_cap]     BAM-encoded CIGAR ops */
+    size_t    reads_cap;
+    size_t    ops_cap;
+    int32_t   slot;       /* ring slot (library use) */
+} gd_batch;
+
+typedef struct {
+    int32_t start;        /* 0-based */
+    int32_t end;          /* exclusive */
+    int32_t cls;          /* GD_NO_COVERAGE .. GD_EXCESSIVE_COVERAGE */
+} gd_run;
+
+typedef struct {
+    uint64_t n_reads;        /* records resident on the device */
+    uint64_t n_ops;          /* CIGAR ops resident on the device */
+    uint64_t n_ref_bases;    /* sum of contig lengths computed */
+    uint64_t n_windows;
+    uint64_t n_tiles;        /* LDS tiles (= workgroups of the tile kernel) */
+    uint64_t n_runs;         /* callable runs found */
+    int32_t  tile_positions; /* reference positions per LDS tile */
+    int32_t  lookback;       /* look-back span in use */
+    int32_t  max_span_seen;  /* largest reference span among kept reads */
+    int32_t  reruns;         /* times the last gd_compute re-ran (span / run capacity) */
+} gd_stats;
+
+/* Kernel ids for gd_kernel_ms. */
+enum { GD_K_PREP = 0, GD_K_TILE = 1, GD_K_RUNS = 2, GD_K_COUNT = 3 };
+
+const char* gd_strerror(int status);
+int         gd_abi_version(void);
+int         gd_device_count(int* n);
+
+/* Create a context bound to one HIP device (hipSetDevice is re-issued inside
+ * every entry point, so calls may come from any OS thread / goroutine). */
+int  gd_create(int device_id, gd_ctx** out);
+void gd_destroy(gd_ctx* ctx);
+const char* gd_last_error(const gd_ctx* ctx);
+
+/* Optional: run all work on a caller-provided hipStream_t (passed as void*). */
+int gd_set_stream(gd_ctx* ctx, void* hip_stream);
+
+int gd_set_params(gd_ctx* ctx, const gd_params* p);
+int gd_default_params(gd_params* p);
+
+/* Reference sequence table (@SQ LN of the BAM header / .fai lengths,
+ * depth/depth.go:134-149).  Drops all records and results. */
+int gd_set_contigs(gd_ctx* ctx, int n_contigs, const int64_t* lengths);
+
+/* Restrict computation to a subset of contigs (--chrom, depth/depth.go:145).
+ * n == 0 selects all. */
+int gd_select_contigs(gd_ctx* ctx, int n, const int32_t* tids);
+
+/* ---- record ingest: pinned ring buffers -> HBM (replaces the BGZF/BAM read
+ * that each `samtools depth` child performs) --------------------------------*/
+
+/* Borrow a pinned staging block with at least the given capacities.  Blocks
+ * until a ring slot is free. */
+int gd_acquire(gd_ctx* ctx, size_t reads_cap, size_t ops_cap, gd_batch* out);
+
+/* Append n_reads records (n_ops ops) of contig tid from a block obtained from
+ * gd_acquire; the H2D copy is asynchronous on the copy stream and the block
+ * returns to the ring when it completes.  Records of one contig must be
+ * committed in coordinate order. */
+int gd_commit(gd_ctx* ctx, const gd_batch* b, int32_t tid, size_t n_reads, size_t n_ops);
+
+/* Convenience: copy records from ordinary host memory (copies before
+ * returning; never keeps the pointers). */
+int gd_push(gd_ctx* ctx, int32_t tid, const int32_t* pos, const uint16_t* flag,
+            const uint8_t* mapq, const uint32_t* cigar_off, const uint32_t* cigar,
+            size_t n_reads, size_t n_ops);
+
+/* Use records already resident in HBM (zero copy).  Replaces any records of
+ * that contig. */
+int gd_adopt_device(gd_ctx* ctx, int32_t tid, const gd_batch* dev, size_t n_reads, size_t n_ops);
+
+/* Drop records and results, keep contigs/params/allocations. */
+int gd_reset(gd_ctx* ctx);
+
+/* ---- compute -------------------------------------------------------------*/
+
+/* Per-base depth for every selected contig, fused with the per-window
+ * sum/min reduction and the coverage-class run-length encoding (what
+ * `samtools depth` + callback compute per tile).  Synchronous: returns when
+ * results are ready. */
+int gd_compute(gd_ctx* ctx);
+
+/* ---- results -------------------------------------------------------------*/
+
+/* depth[start..end) of contig tid into host memory. */
+int gd_perbase(gd_ctx* ctx, int32_t tid, int64_t start, int64_t end, int32_t* out);
+
+/* Window sums (and optionally minima; mins may be NULL) for W-anchored
+ * windows of contig tid: window k covers [k*W, min((k+1)*W, len)).
+ * *n receives the window count; GD_E_CAPACITY if cap is too small. */
+int gd_windows(gd_ctx* ctx, int32_t tid, int64_t* sums, int32_t* mins, size_t cap, size_t* n);
+
+/* Coverage-class runs of contig tid in coordinate order, split at multiples
+ * of params.step (reference quirk Q1) and nowhere else. */
+int gd_callable(gd_ctx* ctx, int32_t tid, gd_run* out, size_t cap, size_t* n);
+
+/* --bed mode (depth/depth.go:103-120): reductions over an arbitrary region of
+ * the already computed per-base vector.  Windows stay anchored at absolute
+ * multiples of W and are clipped to [start,end) (depth/depth.go:297-298);
+ * positions past the contig end have depth 0. */
+int gd_region_windows(gd_ctx* ctx, int32_t tid, int64_t start, int64_t end,
+                      int64_t* sums, int32_t* mins, size_t cap, size_t* n);
+int gd_region_callable(gd_ctx* ctx, int32_t tid, int64_t start, int64_t end,
+                       gd_run* out, size_t cap, size_t* n);
+
+/* Device-side views of the results (for RCCL gathers and zero-copy
+ * consumers).  Pointers stay valid until the next gd_compute/gd_reset. */
+int gd_device_perbase(gd_ctx* ctx, int32_t tid, const int32_t** dptr, int64_t* len);
+int gd_device_windows(gd_ctx* ctx, const int64_t** d_sums, const int32_t** d_mins,
+                      size_t* n_total);
+/* Window offset of contig tid inside the concatenated window arrays. */
+int gd_window_offset(gd_ctx* ctx, int32_t tid, size_t* off, size_t* n);
+/* Ordered run boundaries {pos, cls | tid<<2} of all contigs. */
+int gd_device_runs(gd_ctx* ctx, const int32_t** d_bounds, size_t* n_bounds);
+
+/* ---- measurement ---------------------------------------------------------*/
+int gd_get_stats(gd_ctx* ctx, gd_stats* out);
+/* HIP-event timing of the kernels of the last gd_compute, recorded on the
+ * stream the kernels ran on.  Enable before gd_compute. */
+int gd_set_profiling(gd_ctx* ctx, int on);
+int gd_kernel_ms(gd_ctx* ctx, int kernel_id, float* ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GOLEFT_DEPTH_H */

@@ -1,0 +1,334 @@
+"""Python twin of the CPU oracle (TEST INFRASTRUCTURE ONLY).
+
+Parity status: "parity unpinned" -- see oracle/depth_oracle.h.  This module
+holds (a) an independent brute-force per-position counter used to cross-check
+the C restatement, (b) a second, independent restatement of the reference's
+`callback` reducer (/root/reference/depth/depth.go:238-364) that emits the BED
+rows as strings, and (c) a ctypes binding of oracle/libdepth_oracle.so.
+
+Nothing under goleft_amd/ may import this module.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+from dataclasses import dataclass
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_FLAG_MASK = 0x704  # UNMAP|SECONDARY|QCFAIL|DUP (samtools depth default)
+
+# BAM cigar op codes: MIDNSHP=X
+OP_M, OP_I, OP_D, OP_N, OP_S, OP_H, OP_P, OP_EQ, OP_X = range(9)
+_CONSUMES_REF = {OP_M, OP_D, OP_N, OP_EQ, OP_X}
+_COUNTED = {OP_M, OP_EQ, OP_X}
+CLASS_NAMES = ("NO_COVERAGE", "LOW_COVERAGE", "CALLABLE", "EXCESSIVE_COVERAGE")
+
+
+@dataclass
+class Reads:
+    """One contig's decoded records (coordinate sorted), SoA."""
+    pos: np.ndarray        # int32 [n]
+    flag: np.ndarray       # uint16 [n]
+    mapq: np.ndarray       # uint8 [n]
+    cigar_off: np.ndarray  # uint32 [n+1]
+    cigar: np.ndarray      # uint32 [m]
+
+    def __post_init__(self):
+        self.pos = np.ascontiguousarray(self.pos, dtype=np.int32)
+        self.flag = np.ascontiguousarray(self.flag, dtype=np.uint16)
+        self.mapq = np.ascontiguousarray(self.mapq, dtype=np.uint8)
+        self.cigar_off = np.ascontiguousarray(self.cigar_off, dtype=np.uint32)
+        self.cigar = np.ascontiguousarray(self.cigar, dtype=np.uint32)
+        assert self.cigar_off.shape[0] == self.pos.shape[0] + 1
+
+    @property
+    def n(self) -> int:
+        return int(self.pos.shape[0])
+
+    @property
+    def n_ops(self) -> int:
+        return int(self.cigar.shape[0])
+
+    def slice(self, lo: int, hi: int) -> "Reads":
+        off = self.cigar_off[lo:hi + 1].astype(np.int64)
+        return Reads(self.pos[lo:hi], self.flag[lo:hi], self.mapq[lo:hi],
+                     (off - off[0]).astype(np.uint32),
+                     self.cigar[off[0]:off[-1]])
+
+
+# --------------------------------------------------------------------------
+# (a) independent brute force: a dict-free, loop-per-base counter
+# --------------------------------------------------------------------------
+def perbase_bruteforce(r: Reads, q: int, start: int, end: int,
+                       flag_mask: int = DEFAULT_FLAG_MASK) -> np.ndarray:
+    """samtools>=1.13 `depth -Q q` semantics, one Python loop per base."""
+    out = [0] * max(0, end - start)
+    for i in range(r.n):
+        if int(r.flag[i]) & flag_mask:
+            continue
+        if int(r.mapq[i]) < q:
+            continue
+        cur = int(r.pos[i])
+        for k in range(int(r.cigar_off[i]), int(r.cigar_off[i + 1])):
+            c = int(r.cigar[k])
+            op, ln = c & 0xF, c >> 4
+            if op in _COUNTED:
+                for p in range(max(cur, start), min(cur + ln, end)):
+                    out[p - start] += 1
+            if op in _CONSUMES_REF:
+                cur += ln
+    return np.asarray(out, dtype=np.int32)
+
+
+def perbase_numpy(r: Reads, q: int, start: int, end: int,
+                  flag_mask: int = DEFAULT_FLAG_MASK) -> np.ndarray:
+    """Vectorised twin (diff marks + cumsum) for mid-sized inputs."""
+    L = max(0, end - start)
+    if L == 0:
+        return np.zeros(0, np.int32)
+    nops = np.diff(r.cigar_off.astype(np.int64))
+    read_of_op = np.repeat(np.arange(r.n), nops)
+    op = (r.cigar & 0xF).astype(np.int64)
+    ln = (r.cigar >> 4).astype(np.int64)
+    consumes = np.isin(op, list(_CONSUMES_REF))
+    adv = np.where(consumes, ln, 0)
+    cum = np.cumsum(adv) - adv                      # exclusive over all ops
+    first = r.cigar_off[:-1].astype(np.int64)
+    safe_first = np.minimum(first, max(len(cum) - 1, 0))
+    base = np.where(nops > 0, cum[safe_first] if len(cum) else 0, 0)
+    ref_start = r.pos.astype(np.int64)[read_of_op] + cum - base[read_of_op]
+    keep = ((r.flag.astype(np.int64) & flag_mask) == 0) & (r.mapq.astype(np.int64) >= q)
+    counted = np.isin(op, list(_COUNTED)) & keep[read_of_op] & (ln > 0)
+    s = np.clip(ref_start[counted], start, end)
+    e = np.clip(ref_start[counted] + ln[counted], start, end)
+    ok = s < e
+    diff = np.zeros(L + 1, np.int64)
+    np.add.at(diff, s[ok] - start, 1)
+    np.add.at(diff, e[ok] - start, -1)
+    return np.cumsum(diff[:L]).astype(np.int32)
+
+
+# --------------------------------------------------------------------------
+# (b) second restatement of depth/depth.go:238-364 (string output)
+# --------------------------------------------------------------------------
+def cov_class(depth: int, mincov: int, maxmean: int) -> str:
+    """depth/depth.go:223-234."""
+    if depth == 0:
+        return "NO_COVERAGE"
+    if depth < mincov:
+        return "LOW_COVERAGE"
+    if maxmean > 0 and depth >= maxmean:
+        return "EXCESSIVE_COVERAGE"
+    return "CALLABLE"
+
+
+def fmt_g4(x: float) -> str:
+    """Go %.4g == C %.4g."""
+    return "%.4g" % x
+
+
+def callback_py(chrom: str, region_start: int, region_end: int,
+                depth: np.ndarray, W: int, mincov: int, maxmean: int):
+    """Returns (depth_bed_rows, callable_bed_rows) as lists of str (no \\n).
+
+    `depth[i]` is the depth at region_start+i; only positions with depth>0
+    are 'printed by samtools'."""
+    hd, ca = [], []
+    cache_sum, cache_len = 0.0, 0
+    pos = 0
+    last_window = max(0, region_start // W)
+    c0 = c1 = region_start - 1
+    last_cls = ""
+
+    def mean(l):
+        if cache_len == 0 or l == 0:
+            return 0.0
+        return cache_sum / float(l)
+
+    covered = np.nonzero(np.asarray(depth) > 0)[0]
+    for idx in covered:
+        pos = region_start + int(idx)
+        d = int(depth[idx])
+        if pos // W != last_window:
+            this_window = pos // W
+            for iw in range(last_window, this_window):
+                s = max(region_start, iw * W)
+                e = min(region_end, (iw + 1) * W)
+                hd.append("%s\t%d\t%d\t%s" % (chrom, s, e, fmt_g4(mean(e - s))))
+                cache_sum, cache_len = 0.0, 0
+            last_window = this_window
+        cache_sum += float(d)
+        cache_len += 1
+        cls = cov_class(d, mincov, maxmean)
+        if cls != last_cls or pos != c1 + 1:
+            if last_cls != "":
+                ca.append("%s\t%d\t%d\t%s" % (chrom, c0, c1 + 1, last_cls))
+            if pos != c1 + 1:
+                ca.append("%s\t%d\t%d\t%s" % (chrom, c1 + 1, pos, "NO_COVERAGE"))
+            last_cls = cls
+            c0 = c1 = pos
+        else:
+            c1 = pos
+    if c0 != -1 and last_cls != "":
+        ca.append("%s\t%d\t%d\t%s" % (chrom, c0, c1 + 1, last_cls))
+    if cache_len > 0:
+        s = pos // W * W
+        if s < region_end:
+            s = max(s, region_start)
+            e = min(region_end, s + W)
+            hd.append("%s\t%d\t%d\t%s" % (chrom, s, e, fmt_g4(mean(e - s))))
+            cache_sum, cache_len = 0.0, 0
+            pos = e
+    if c1 + 1 < region_end:
+        if c1 != -1:
+            ca.append("%s\t%d\t%d\tNO_COVERAGE" % (chrom, c1 + 1, region_end))
+        else:
+            ca.append("%s\t%d\t%d\tNO_COVERAGE" % (chrom, region_start, region_end))
+        ds = max(region_start, pos) // W * W
+        while ds < region_end and pos < region_end:
+            de = min(region_end, ds + W)
+            s = max(ds, region_start)
+            hd.append("%s\t%d\t%d\t%s" % (chrom, s, de, fmt_g4(mean(de - s))))
+            cache_sum, cache_len = 0.0, 0
+            ds += W
+    return hd, ca
+
+
+def step_for(W: int) -> int:
+    """depth/depth.go:48,:132."""
+    return max(1, 10000000 // W) * W
+
+
+def tiles_for(length: int, W: int):
+    """depth/depth.go:150-154 as 0-based half-open (start, end)."""
+    step = step_for(W)
+    return [(i, min(i + step, length)) for i in range(0, length, step)]
+
+
+# --------------------------------------------------------------------------
+# (c) ctypes binding of the C restatement
+# --------------------------------------------------------------------------
+class _GdoReads(ctypes.Structure):
+    _fields_ = [("pos", ctypes.c_void_p), ("flag", ctypes.c_void_p),
+                ("mapq", ctypes.c_void_p), ("cigar_off", ctypes.c_void_p),
+                ("cigar", ctypes.c_void_p), ("n", ctypes.c_size_t)]
+
+
+_LIB = None
+
+
+def build(force: bool = False) -> str:
+    so = os.path.join(HERE, "libdepth_oracle.so")
+    src = os.path.join(HERE, "depth_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-s", "-C", HERE, "-B", "libdepth_oracle.so"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        L = ctypes.CDLL(build())
+        L.gdo_perbase.argtypes = [ctypes.POINTER(_GdoReads), ctypes.c_int, ctypes.c_uint32,
+                                  ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p]
+        L.gdo_perbase.restype = None
+        L.gdo_perbase_diff.argtypes = L.gdo_perbase.argtypes
+        L.gdo_perbase_diff.restype = None
+        L.gdo_cov_class.argtypes = [ctypes.c_int] * 3
+        L.gdo_cov_class.restype = ctypes.c_int
+        L.gdo_chrom_start_end.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p,
+                                          ctypes.c_size_t, ctypes.POINTER(ctypes.c_long),
+                                          ctypes.POINTER(ctypes.c_long)]
+        L.gdo_chrom_start_end.restype = ctypes.c_int
+        L.gdo_step.argtypes = [ctypes.c_int]
+        L.gdo_step.restype = ctypes.c_long
+        L.gdo_tiles.argtypes = [ctypes.c_long, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                ctypes.c_size_t]
+        L.gdo_tiles.restype = ctypes.c_size_t
+        L.gdo_callback_append.argtypes = [ctypes.c_char_p, ctypes.c_long, ctypes.c_long,
+                                          ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+                                          ctypes.c_int, ctypes.c_char_p, ctypes.c_char_p]
+        L.gdo_callback_append.restype = ctypes.c_int
+        _LIB = L
+    return _LIB
+
+
+def _as_struct(r: Reads) -> _GdoReads:
+    return _GdoReads(r.pos.ctypes.data, r.flag.ctypes.data, r.mapq.ctypes.data,
+                     r.cigar_off.ctypes.data, r.cigar.ctypes.data, r.n)
+
+
+def perbase_c(r: Reads, q: int, start: int, end: int,
+              flag_mask: int = DEFAULT_FLAG_MASK, diff: bool = False) -> np.ndarray:
+    out = np.zeros(max(0, end - start), np.int32)
+    st = _as_struct(r)
+    fn = lib().gdo_perbase_diff if diff else lib().gdo_perbase
+    fn(ctypes.byref(st), q, flag_mask, start, end, out.ctypes.data)
+    return out
+
+
+def chrom_start_end_c(line: bytes):
+    chrom = ctypes.create_string_buffer(1024)
+    s, e = ctypes.c_long(), ctypes.c_long()
+    rc = lib().gdo_chrom_start_end(line, len(line), chrom, 1024, ctypes.byref(s), ctypes.byref(e))
+    if rc != 0:
+        raise ValueError("couldn't get region from line %r" % line)
+    return chrom.value.decode(), s.value, e.value
+
+
+def tiles_c(length: int, W: int):
+    cap = lib().gdo_tiles(length, W, None, None, 0)
+    s = np.zeros(cap, np.int64)
+    e = np.zeros(cap, np.int64)
+    lib().gdo_tiles(length, W, s.ctypes.data, e.ctypes.data, cap)
+    return list(zip(s.tolist(), e.tolist()))
+
+
+def callback_c(chrom: str, region_start: int, region_end: int, depth: np.ndarray,
+               W: int, mincov: int, maxmean: int, depth_path: str, callable_path: str):
+    d = np.ascontiguousarray(depth, dtype=np.int32)
+    assert d.shape[0] == max(0, region_end - region_start)
+    rc = lib().gdo_callback_append(chrom.encode(), region_start, region_end, d.ctypes.data,
+                                   W, mincov, maxmean, depth_path.encode(),
+                                   callable_path.encode())
+    if rc != 0:
+        raise OSError("gdo_callback_append failed")
+
+
+def depth_run_oracle(contigs, reads_by_tid, W=250, Q=1, mincov=4, maxmean=0,
+                     flag_mask=DEFAULT_FLAG_MASK, regions=None):
+    """Whole `goleft depth` run through the oracle.
+
+    contigs: list of (name, length).  reads_by_tid: {tid: Reads}.
+    regions: None for whole-genome tiling (depth/depth.go:122-159), else a list
+    of (chrom, start0, end) as --bed rows would give (depth.go:103-120).
+    Returns (depth_bed_text, callable_bed_text) in genome / row order
+    (what --ordered produces)."""
+    import tempfile
+    names = [c[0] for c in contigs]
+    empty = Reads(np.zeros(0, np.int32), np.zeros(0, np.uint16), np.zeros(0, np.uint8),
+                  np.zeros(1, np.uint32), np.zeros(0, np.uint32))
+    jobs = []
+    if regions is None:
+        for tid, (name, length) in enumerate(contigs):
+            for s, e in tiles_c(length, W):
+                jobs.append((tid, name, s, e))
+    else:
+        for chrom, s, e in regions:
+            jobs.append((names.index(chrom) if chrom in names else -1, chrom, s, e))
+    with tempfile.TemporaryDirectory() as td:
+        hd, ca = os.path.join(td, "d.bed"), os.path.join(td, "c.bed")
+        open(hd, "w").close()
+        open(ca, "w").close()
+        for tid, name, s, e in jobs:
+            r = reads_by_tid.get(tid, empty)
+            d = perbase_c(r, Q, s, e, flag_mask)
+            if tid >= 0:
+                clen = contigs[tid][1]
+                if e > clen:       # samtools prints nothing past the contig end
+                    d[max(0, clen - s):] = 0
+            callback_c(name, s, e, d, W, mincov, maxmean, hd, ca)
+        return open(hd).read(), open(ca).read()
