@@ -20,7 +20,8 @@
 namespace {
 
 constexpr int kRingSlots = 3;
-constexpr int kDefaultLookback = 1024;
+constexpr int kDefaultLookback = 512;
+constexpr uint64_t kMaxReadsPerContig = 1ull << 30;
 
 struct ContigHost {
     int64_t length = 0;
@@ -63,6 +64,7 @@ struct gd_ctx {
     std::string err;
 
     int tile_T = 8192;
+    int tile_NT = 256;
     int lookback = kDefaultLookback;
 
     // device job state
@@ -77,7 +79,7 @@ struct gd_ctx {
     int2* d_ordered = nullptr;
     uint32_t* d_tile_cnt = nullptr;
     uint32_t* d_tile_off = nullptr;
-    uint32_t* d_tile_dst = nullptr;
+    uint32_t* d_super_cnt = nullptr;
     gd::Counters* d_counters = nullptr;
     gd::Counters* h_counters = nullptr;   // pinned
     uint32_t* d_region_cursor = nullptr;
@@ -246,6 +248,10 @@ int gd_create(int device_id, gd_ctx** out)
         int t = atoi(e);
         if (t == 4096 || t == 8192 || t == 16384) c->tile_T = t;
     }
+    if (const char* e = getenv("GOLEFT_GD_THREADS")) {
+        int t = atoi(e);
+        if (t == 256 || t == 512 || t == 1024) c->tile_NT = t;
+    }
     auto bail = [&](hipError_t e) {
         (void)e;
         gd_destroy(c);
@@ -285,7 +291,7 @@ void gd_destroy(gd_ctx* c)
     for (auto& ev : c->ev) if (ev) (void)hipEventDestroy(ev);
     if (c->copy_done) (void)hipEventDestroy(c->copy_done);
     void* frees[] = {c->d_ctgs, c->d_tiles, c->d_perbase, c->d_wsum, c->d_wmin, c->d_chunks,
-                     c->d_ordered, c->d_tile_cnt, c->d_tile_off, c->d_tile_dst, c->d_counters,
+                     c->d_ordered, c->d_tile_cnt, c->d_tile_off, c->d_super_cnt, c->d_counters,
                      c->d_region_cursor};
     for (void* p : frees) if (p) (void)hipFree(p);
     if (c->h_counters) (void)hipHostFree(c->h_counters);
@@ -409,6 +415,8 @@ int gd_commit(gd_ctx* c, const gd_batch* b, int32_t tid, size_t n_reads, size_t 
         return fail(c, GD_E_INVALID, "cigar_off must start at 0 and end at n_ops");
     if ((uint64_t)h.n_ops + n_ops > 0xffffffffull)
         return fail(c, GD_E_RANGE, "more than 2^32 CIGAR ops on contig %d", tid);
+    if ((uint64_t)h.n_reads + n_reads >= kMaxReadsPerContig)
+        return fail(c, GD_E_RANGE, "more than 2^30 records on contig %d", tid);
     // coordinate order (BAM SO:coordinate) is what makes the tile search valid
     int32_t last = h.last_pos;
     for (size_t i = 0; i < n_reads; ++i) {
@@ -484,6 +492,8 @@ int gd_adopt_device(gd_ctx* c, int32_t tid, const gd_batch* d, size_t n_reads, s
     if (tid < 0 || (size_t)tid >= c->contigs.size()) return fail(c, GD_E_RANGE, "tid %d out of range", tid);
     if (n_reads && (!d->pos || !d->flag || !d->mapq || !d->cigar_off)) return GD_E_INVALID;
     if (n_ops > 0xffffffffull) return fail(c, GD_E_RANGE, "more than 2^32 CIGAR ops");
+    // depth <= records of the contig; the window reduction adds four depths in 32 bits
+    if (n_reads >= kMaxReadsPerContig) return fail(c, GD_E_RANGE, "more than 2^30 records on one contig");
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipStreamSynchronize(c->copy_stream));
     ContigHost& h = c->contigs[tid];
@@ -570,7 +580,7 @@ int gd_compute(gd_ctx* c)
         if (int r = ensure_dev(c, &c->d_tiles, &c1, (size_t)c->n_tiles)) return r;
         if (int r = ensure_dev(c, &c->d_tile_cnt, &c2, (size_t)c->n_tiles)) return r;
         if (int r = ensure_dev(c, &c->d_tile_off, &c3, (size_t)c->n_tiles)) return r;
-        if (int r = ensure_dev(c, &c->d_tile_dst, &c4, (size_t)c->n_tiles)) return r;
+        if (int r = ensure_dev(c, &c->d_super_cnt, &c4, (size_t)c->n_tiles / gd::SUPER + 1)) return r;
         c->cap_tiles = c1;
     }
     if (int r = ensure_dev(c, &c->d_perbase, &c->cap_perbase, (size_t)base_off)) return r;
@@ -608,6 +618,7 @@ int gd_compute(gd_ctx* c)
         job.run_cap = (uint32_t)std::min<size_t>(c->cap_runs, 0xffffffffu);
         job.tile_cnt = c->d_tile_cnt;
         job.tile_off = c->d_tile_off;
+        job.super_cnt = c->d_super_cnt;
         job.counters = c->d_counters;
         job.W = P.window_size;
         job.Q = P.min_mapq;
@@ -624,20 +635,24 @@ int gd_compute(gd_ctx* c)
         default: launch_prep<8192>(c, job); break;
         }
         if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
-        switch (T) {
-        case 4096: launch_tile<4096, 256>(c, job); break;
-        case 16384: launch_tile<16384, 512>(c, job); break;
-        default: launch_tile<8192, 256>(c, job); break;
+        {
+            const int key = T + c->tile_NT;   // (T, NT) variants compiled below
+            switch (key) {
+            case 4096 + 256: launch_tile<4096, 256>(c, job); break;
+            case 4096 + 512: launch_tile<4096, 512>(c, job); break;
+            case 8192 + 512: launch_tile<8192, 512>(c, job); break;
+            case 8192 + 1024: launch_tile<8192, 1024>(c, job); break;
+            case 16384 + 256: launch_tile<16384, 256>(c, job); break;
+            case 16384 + 512: launch_tile<16384, 512>(c, job); break;
+            case 16384 + 1024: launch_tile<16384, 1024>(c, job); break;
+            default: launch_tile<8192, 256>(c, job); break;
+            }
         }
         if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
-        hipLaunchKernelGGL(gd::gd_runs_scan_kernel, dim3(1), dim3(1024), 0, c->stream,
-                           c->d_tile_cnt, c->d_tile_dst, (int)c->n_tiles);
-        {
-            int64_t threads = c->n_tiles * 64;
-            hipLaunchKernelGGL(gd::gd_runs_gather_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
-                               c->stream, c->d_chunks, job.run_cap, c->d_tile_cnt, c->d_tile_off,
-                               c->d_tile_dst, c->d_ordered, (int)c->n_tiles);
-        }
+        hipLaunchKernelGGL(gd::gd_runs_order_kernel,
+                           dim3((unsigned)((c->n_tiles + gd::SUPER - 1) / gd::SUPER)), dim3(gd::SUPER), 0,
+                           c->stream, c->d_chunks, job.run_cap, c->d_tile_cnt, c->d_tile_off,
+                           c->d_super_cnt, c->d_ordered, (int)c->n_tiles);
         if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipMemcpyAsync(c->h_counters, c->d_counters, sizeof(gd::Counters), hipMemcpyDeviceToHost, c->stream));

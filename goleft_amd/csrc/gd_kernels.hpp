@@ -36,6 +36,7 @@
 namespace gd {
 
 constexpr int WAVE = 64;
+constexpr int SUPER = 1024;   // tiles per ordering group (one workgroup of gd_runs_order_kernel)
 
 // One contig as the device sees it.
 struct ContigDev {
@@ -80,6 +81,7 @@ struct Job {
     uint32_t  run_cap;
     uint32_t* tile_cnt;
     uint32_t* tile_off;
+    uint32_t* super_cnt;      // boundary entries per group of SUPER consecutive tiles
     Counters* counters;
     int32_t   W;
     int32_t   Q;
@@ -122,6 +124,7 @@ __global__ void gd_prep_kernel(Job job)
         job.win_sum[w] = 0;
         job.win_min[w] = 0x7fffffff;
     }
+    for (int64_t g = gid; g < (job.n_tiles + SUPER - 1) / SUPER; g += gsz) job.super_cnt[g] = 0;
     if (gid == 0) {
         job.counters->max_span = 0;
         job.counters->run_cursor = 0;
@@ -189,6 +192,50 @@ __device__ __forceinline__ int wave_min(int v)
 // ---------------------------------------------------------------------------
 // K1: the tile kernel
 // ---------------------------------------------------------------------------
+// Wave-wide helpers built on DPP (no LDS traffic).
+__device__ __forceinline__ int wave_total(int v)     // sum over the wave, valid in every lane
+{
+    return __builtin_amdgcn_readlane(wave_inclusive_scan(v), 63);
+}
+
+// value of lane-1 (lane 0 receives `first`): DPP wave_shr:1
+__device__ __forceinline__ int wave_prev_lane(int v, int first)
+{
+    return __builtin_amdgcn_update_dpp(first, v, 0x138, 0xf, 0xf, false);
+}
+
+// Walk one CIGAR (generic path): merge adjacent M/=/X ops into reference
+// intervals, clip to the tile, mark +1/-1 in the LDS difference array.
+// Returns the reference span of the read.
+__device__ __forceinline__ int32_t walk_cigar(const uint32_t* __restrict__ cigar, uint32_t o0,
+                                              uint32_t o1, int32_t p, int32_t t0, int32_t tend,
+                                              int32_t clen, int32_t* s_diff, int& prev_cnt)
+{
+    int32_t cur = p;
+    int32_t rs = -1;                               // open run start, -1 = none
+    for (uint32_t k = o0; k <= o1; ++k) {
+        uint32_t op = 2, len = 0;                  // sentinel: a zero-length D closes the run
+        if (k < o1) { const uint32_t cg = cigar[k]; op = cg & 0xf; len = cg >> 4; }
+        const bool counted = (0x181u >> op) & 1u;  // M = X
+        const bool consumes = (0x18du >> op) & 1u; // M D N = X
+        if (counted) {
+            if (rs < 0 && len > 0) rs = cur;
+        } else if (consumes && rs >= 0) {
+            int32_t s = rs, e = cur;               // close run [rs, cur)
+            if (e > clen) e = clen;
+            if (s < t0 && e >= t0) prev_cnt++;     // covers t0-1
+            if (e > t0 && s < tend) {
+                const int32_t cs = (s > t0 ? s : t0) - t0;
+                atomicAdd(&s_diff[cs], 1);
+                if (e < tend) atomicAdd(&s_diff[e - t0], -1);
+            }
+            rs = -1;
+        }
+        if (consumes) cur += (int32_t)len;
+    }
+    return cur - p;
+}
+
 template <int T, int NT>
 __global__ __launch_bounds__(NT) void gd_tile_kernel(Job job)
 {
@@ -196,17 +243,21 @@ __global__ __launch_bounds__(NT) void gd_tile_kernel(Job job)
     constexpr int CHUNK = T / NW;          // positions per wave
     constexpr int ROWS = CHUNK / 256;      // rows of 256 positions per wave
     constexpr int NWORDS = T / 32;         // bitmap words
+    constexpr int QCAP = 1024;             // multi-op read queue (indices)
+    constexpr int BIG = 0x3fffffff;
     static_assert(CHUNK % 256 == 0, "wave chunk must be whole rows");
 
     __shared__ __attribute__((aligned(16))) int32_t s_diff[T];
     __shared__ uint32_t s_bmap[NWORDS];    // boundary bit per position
     __shared__ uint32_t s_clo[NWORDS];     // class bit 0 at boundary positions
     __shared__ uint32_t s_chi[NWORDS];     // class bit 1 at boundary positions
+    __shared__ uint32_t s_queue[QCAP];
     __shared__ int32_t  s_wtot[NW];
     __shared__ uint32_t s_wcnt[NW];
     __shared__ int32_t  s_prev;            // depth at t0-1
     __shared__ uint32_t s_hasb;
     __shared__ uint32_t s_base;
+    __shared__ uint32_t s_qn;
 
     const int tid = threadIdx.x;
     const int lane = tid & (WAVE - 1);
@@ -215,6 +266,7 @@ __global__ __launch_bounds__(NT) void gd_tile_kernel(Job job)
     const ContigDev c = job.ctgs[ti.ctg];
     const int32_t t0 = ti.t0;
     const int32_t tend = t0 + T < c.length ? t0 + T : c.length;   // clipped tile end
+    const int tlen = tend - t0;                                   // valid positions, 1..T
 
     // ---- zero LDS -------------------------------------------------------
     {
@@ -223,50 +275,81 @@ __global__ __launch_bounds__(NT) void gd_tile_kernel(Job job)
 #pragma unroll
         for (int i = tid; i < T / 4; i += NT) d4[i] = z;
         for (int i = tid; i < NWORDS; i += NT) { s_bmap[i] = 0; s_clo[i] = 0; s_chi[i] = 0; }
-        if (tid == 0) { s_prev = 0; s_hasb = 0; }
+        if (tid == 0) { s_prev = 0; s_hasb = 0; s_qn = 0; }
     }
     __syncthreads();
 
-    // ---- phase A: CIGAR walk -> clipped intervals -> LDS +1/-1 ----------
+    // ---- phase A: reads -> clipped intervals -> LDS +1/-1 -----------------
+    // U reads per lane are in flight at once (the phase is latency bound).
+    // Single-op reads (the bulk of short-read data) are handled branch-light;
+    // multi-op reads are queued and walked afterwards with dense lanes.
+    int prev_cnt = 0;
+    int span_max = 0;
     {
-        int prev_cnt = 0;
-        int span_max = 0;
-        for (uint32_t i = ti.lo + tid; i < ti.hi; i += NT) {
-            const int32_t p = c.pos[i];
-            const uint32_t f = c.flag[i];
-            const int mq = c.mapq[i];
-            const uint32_t o0 = c.off[i];
-            const uint32_t o1 = c.off[i + 1];
-            if ((f & job.flag_mask) != 0 || mq < job.Q) continue;
-            int32_t cur = p;
-            int32_t rs = -1;                       // open run start, -1 = none
-            for (uint32_t k = o0; k <= o1; ++k) {
-                uint32_t op = 2, len = 0;          // sentinel: a zero-length D closes the run
-                if (k < o1) { const uint32_t cg = c.cigar[k]; op = cg & 0xf; len = cg >> 4; }
-                const bool counted = (0x181u >> op) & 1u;    // M = X
-                const bool consumes = (0x18du >> op) & 1u;   // M D N = X
-                if (counted) {
-                    if (rs < 0 && len > 0) rs = cur;
-                } else if (consumes && rs >= 0) {
-                    // close run [rs, cur)
-                    int32_t s = rs, e = cur;
+        constexpr int U = 4;
+        for (uint32_t base = ti.lo; base < ti.hi; base += NT * U) {
+            int32_t  p[U];
+            uint32_t f[U], o0[U], o1[U], c0[U], idx[U];
+            int      mq[U];
+            bool     ok[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t i = base + u * NT + tid;
+                ok[u] = i < ti.hi;
+                idx[u] = ok[u] ? i : ti.lo;                     // any valid index
+                p[u] = c.pos[idx[u]];
+                f[u] = c.flag[idx[u]];
+                mq[u] = c.mapq[idx[u]];
+                o0[u] = c.off[idx[u]];
+                o1[u] = c.off[idx[u] + 1];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                ok[u] = ok[u] && (f[u] & job.flag_mask) == 0 && mq[u] >= job.Q && o1[u] > o0[u];
+                c0[u] = ok[u] ? c.cigar[o0[u]] : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t op = c0[u] & 0xf;
+                const int32_t len = (int32_t)(c0[u] >> 4);
+                const bool single = (o1[u] - o0[u]) == 1u;
+                const bool simple = ok[u] && single && ((0x181u >> op) & 1u) && len > 0;
+                if (simple) {
+                    const int32_t s = p[u];
+                    int32_t e = s + len;
+                    span_max = len > span_max ? len : span_max;
                     if (e > c.length) e = c.length;
-                    if (s < t0 && e >= t0) prev_cnt++;        // covers t0-1
+                    if (s < t0 && e >= t0) prev_cnt++;
                     if (e > t0 && s < tend) {
                         const int32_t cs = (s > t0 ? s : t0) - t0;
                         atomicAdd(&s_diff[cs], 1);
                         if (e < tend) atomicAdd(&s_diff[e - t0], -1);
                     }
-                    rs = -1;
+                } else if (ok[u]) {
+                    const uint32_t slot = atomicAdd(&s_qn, 1u);
+                    if (slot < (uint32_t)QCAP) {
+                        s_queue[slot] = idx[u];
+                    } else {                                     // queue full: walk in place
+                        const int32_t span = walk_cigar(c.cigar, o0[u], o1[u], p[u], t0, tend,
+                                                        c.length, s_diff, prev_cnt);
+                        span_max = span > span_max ? span : span_max;
+                    }
                 }
-                if (consumes) cur += (int32_t)len;
             }
-            const int32_t span = cur - p;
+        }
+    }
+    __syncthreads();
+    {
+        const uint32_t nq = s_qn < (uint32_t)QCAP ? s_qn : (uint32_t)QCAP;
+        for (uint32_t j = tid; j < nq; j += NT) {
+            const uint32_t i = s_queue[j];
+            const int32_t span = walk_cigar(c.cigar, c.off[i], c.off[i + 1], c.pos[i], t0, tend,
+                                            c.length, s_diff, prev_cnt);
             span_max = span > span_max ? span : span_max;
         }
         // rare: publish look-back violations so the host can re-run
         if (span_max > job.lookback) atomicMax(&job.counters->max_span, span_max);
-        const int pc = wave_sum(prev_cnt);
+        const int pc = wave_total(prev_cnt);
         if (lane == 0 && pc != 0) atomicAdd(&s_prev, pc);
     }
     __syncthreads();
@@ -280,12 +363,13 @@ __global__ __launch_bounds__(NT) void gd_tile_kernel(Job job)
             const int4 v = *reinterpret_cast<const int4*>(&s_diff[chunk0 + r * 256 + lane * 4]);
             tot += v.x + v.y + v.z + v.w;
         }
-        tot = wave_sum(tot);
+        tot = wave_total(tot);
         if (lane == 0) s_wtot[wv] = tot;
     }
     __syncthreads();
 
     // ---- phase B pass 2: scan, store, window reduce, class boundaries ----
+    // All positions are tile relative 32-bit ints here; absolute = t0 + rel.
     {
         int carry = 0;                                   // depth at chunk start - 1
         for (int v = 0; v < wv; ++v) carry += s_wtot[v];
@@ -294,20 +378,27 @@ __global__ __launch_bounds__(NT) void gd_tile_kernel(Job job)
         const int W = job.W;
         const int64_t cpos0 = (int64_t)t0 + chunk0;      // first position of this chunk
         int64_t cur_win = cpos0 / W;
-        int64_t nb = (cur_win + 1) * (int64_t)W;         // next window boundary
+        const int64_t nb_abs = (cur_win + 1) * (int64_t)W;
+        int nb = (nb_abs - t0) > BIG ? BIG : (int)(nb_abs - t0);    // next window boundary (rel)
         const int64_t step = job.step;
-        int64_t nf = ((cpos0 + step - 1) / step) * step; // next forced run break
+        const int64_t nf_abs = ((cpos0 + step - 1) / step) * step;
+        int nf = (nf_abs - t0) > BIG ? BIG : (int)(nf_abs - t0);    // next forced run break (rel)
+        const int wstep = W > BIG ? BIG : W;
+        const int fstep = step > BIG ? BIG : (int)step;
         int64_t* wsum = job.win_sum + c.win_off;
         int32_t* wmin = job.win_min + c.win_off;
-        long long acc = 0;
+        unsigned long long acc = 0;
         int mn = 0x7fffffff;
         bool any_pos = false;
         int32_t* out = job.perbase + c.base_off + t0;
+        const int lo_thr = job.mincov > 1 ? job.mincov : 1;          // all depths in [lo_thr, hi_thr)
+        const int hi_thr = job.maxmean > 0 ? job.maxmean : 0x7fffffff;  // are CALLABLE
 
+#pragma unroll
         for (int r = 0; r < ROWS; ++r) {
-            const int ib = chunk0 + r * 256 + lane * 4;  // index inside the tile
-            const int64_t rp = cpos0 + r * 256;          // row start (contig position)
-            if (rp >= tend) {
+            const int rb = chunk0 + r * 256;             // row start (rel)
+            const int ib = rb + lane * 4;                // this lane's first position (rel)
+            if (rb >= tlen) {
                 // rows past the (clipped) tile end: keep the padded per-base array zero
                 *reinterpret_cast<int4*>(&out[ib]) = make_int4(0, 0, 0, 0);
                 continue;
@@ -317,30 +408,32 @@ __global__ __launch_bounds__(NT) void gd_tile_kernel(Job job)
             const int incl = wave_inclusive_scan(x3);
             const int base = carry + incl - x3;
             carry += __builtin_amdgcn_readlane(incl, 63);
-            const int64_t p0 = rp + lane * 4;            // position of d0
-            const int nvalid = (int)((tend - p0) < 0 ? 0 : ((tend - p0) > 4 ? 4 : (tend - p0)));
+            int nvalid = tlen - ib;
+            nvalid = nvalid < 0 ? 0 : (nvalid > 4 ? 4 : nvalid);
             // positions at or past the contig end hold depth 0 (nothing is printed there)
             const int d0 = nvalid > 0 ? base + x0 : 0, d1 = nvalid > 1 ? base + x1 : 0;
             const int d2 = nvalid > 2 ? base + x2 : 0, d3 = nvalid > 3 ? base + x3 : 0;
             *reinterpret_cast<int4*>(&out[ib]) = make_int4(d0, d1, d2, d3);
             any_pos = true;
+            const bool full_row = rb + 256 <= tlen;
+            const int m01 = d0 < d1 ? d0 : d1, m23 = d2 < d3 ? d2 : d3;
+            const int rmin = m01 < m23 ? m01 : m23;
 
             // ---- window sum / min (depth/depth.go:181-189, :293-305) -----
-            if (nb >= rp + 256 && rp + 256 <= tend) {
-                acc += (long long)d0 + d1 + d2 + d3;
-                int m01 = d0 < d1 ? d0 : d1, m23 = d2 < d3 ? d2 : d3;
-                int m = m01 < m23 ? m01 : m23;
-                mn = m < mn ? m : mn;
+            if (nb >= rb + 256 && full_row) {
+                // depths are < 2^30 (records per contig are capped), so 4 fit in 32 bits
+                acc += (uint32_t)d0 + (uint32_t)d1 + (uint32_t)d2 + (uint32_t)d3;
+                mn = rmin < mn ? rmin : mn;
             } else {
-                int64_t seg = rp;
+                int seg = rb;
                 const int dd[4] = {d0, d1, d2, d3};
-                while (nb < rp + 256 && nb < tend) {
+                while (nb < rb + 256 && nb < tlen) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const int64_t pj = p0 + j;
-                        if (pj >= seg && pj < nb) { acc += dd[j]; mn = dd[j] < mn ? dd[j] : mn; }
+                        const int pj = ib + j;
+                        if (pj >= seg && pj < nb) { acc += (uint32_t)dd[j]; mn = dd[j] < mn ? dd[j] : mn; }
                     }
-                    const long long tot = wave_sum64(acc);
+                    const long long tot = wave_sum64((long long)acc);
                     const int m = wave_min(mn);
                     if (lane == 0) {
                         atomicAdd(reinterpret_cast<unsigned long long*>(&wsum[cur_win]),
@@ -348,49 +441,56 @@ __global__ __launch_bounds__(NT) void gd_tile_kernel(Job job)
                         atomicMin(&wmin[cur_win], m);
                     }
                     acc = 0; mn = 0x7fffffff;
-                    cur_win++; seg = nb; nb += W;
+                    cur_win++; seg = nb;
+                    nb = nb + wstep > BIG ? BIG : nb + wstep;
                 }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const int64_t pj = p0 + j;
-                    if (pj >= seg && j < nvalid) { acc += dd[j]; mn = dd[j] < mn ? dd[j] : mn; }
+                    const int pj = ib + j;
+                    if (pj >= seg && j < nvalid) { acc += (uint32_t)dd[j]; mn = dd[j] < mn ? dd[j] : mn; }
                 }
             }
 
             // ---- coverage class boundaries (depth/depth.go:307-323) -----
-            int pl = __shfl_up(d3, 1, WAVE);
-            if (lane == 0) pl = prev_last;
+            const int pl = wave_prev_lane(d3, prev_last);
             prev_last = __builtin_amdgcn_readlane(d3, 63);
-            const int c0 = cov_class(d0, job.mincov, job.maxmean);
-            const int c1 = cov_class(d1, job.mincov, job.maxmean);
-            const int c2 = cov_class(d2, job.mincov, job.maxmean);
-            const int c3 = cov_class(d3, job.mincov, job.maxmean);
-            const int cp = cov_class(pl, job.mincov, job.maxmean);
-            uint32_t bm = (uint32_t)(c0 != cp) | ((uint32_t)(c1 != c0) << 1) |
-                          ((uint32_t)(c2 != c1) << 2) | ((uint32_t)(c3 != c2) << 3);
-            while (nf < rp + 256) {                      // forced breaks (quirk Q1), incl. position 0
-                const int64_t o = nf - p0;
-                if (o >= 0 && o < 4) bm |= 1u << (int)o;
-                nf += step;
-            }
-            bm &= (1u << nvalid) - 1u;
-            if (__ballot(bm != 0) != 0ull) {
-                if (bm != 0) {
-                    const uint32_t lo = ((uint32_t)(c0 & 1)) | ((uint32_t)(c1 & 1) << 1) |
-                                        ((uint32_t)(c2 & 1) << 2) | ((uint32_t)(c3 & 1) << 3);
-                    const uint32_t hi = ((uint32_t)(c0 >> 1)) | ((uint32_t)(c1 >> 1) << 1) |
-                                        ((uint32_t)(c2 >> 1) << 2) | ((uint32_t)(c3 >> 1) << 3);
-                    const int w = ib >> 5, sh = ib & 31;
-                    atomicOr(&s_bmap[w], bm << sh);
-                    atomicOr(&s_clo[w], (lo & bm) << sh);
-                    atomicOr(&s_chi[w], (hi & bm) << sh);
+            const int x01 = d0 > d1 ? d0 : d1, x23 = d2 > d3 ? d2 : d3;
+            int rmax = x01 > x23 ? x01 : x23;
+            rmax = pl > rmax ? pl : rmax;
+            const int rmin2 = pl < rmin ? pl : rmin;
+            const bool quiet = rmin2 >= lo_thr && rmax < hi_thr;   // every class here is CALLABLE
+            if (__ballot(!quiet) != 0ull || nf < rb + 256) {
+                const int c0 = cov_class(d0, job.mincov, job.maxmean);
+                const int c1 = cov_class(d1, job.mincov, job.maxmean);
+                const int c2 = cov_class(d2, job.mincov, job.maxmean);
+                const int c3 = cov_class(d3, job.mincov, job.maxmean);
+                const int cp = cov_class(pl, job.mincov, job.maxmean);
+                uint32_t bm = (uint32_t)(c0 != cp) | ((uint32_t)(c1 != c0) << 1) |
+                              ((uint32_t)(c2 != c1) << 2) | ((uint32_t)(c3 != c2) << 3);
+                while (nf < rb + 256) {                  // forced breaks (quirk Q1), incl. position 0
+                    const int o = nf - ib;
+                    if (o >= 0 && o < 4) bm |= 1u << o;
+                    nf = nf + fstep > BIG ? BIG : nf + fstep;
                 }
-                if (lane == 0) s_hasb = 1;
+                bm &= (1u << nvalid) - 1u;
+                if (__ballot(bm != 0) != 0ull) {
+                    if (bm != 0) {
+                        const uint32_t lo = ((uint32_t)(c0 & 1)) | ((uint32_t)(c1 & 1) << 1) |
+                                            ((uint32_t)(c2 & 1) << 2) | ((uint32_t)(c3 & 1) << 3);
+                        const uint32_t hi = ((uint32_t)(c0 >> 1)) | ((uint32_t)(c1 >> 1) << 1) |
+                                            ((uint32_t)(c2 >> 1) << 2) | ((uint32_t)(c3 >> 1) << 3);
+                        const int w = ib >> 5, sh = ib & 31;
+                        atomicOr(&s_bmap[w], bm << sh);
+                        atomicOr(&s_clo[w], (lo & bm) << sh);
+                        atomicOr(&s_chi[w], (hi & bm) << sh);
+                    }
+                    if (lane == 0) s_hasb = 1;
+                }
             }
         }
         // flush the open window segment of this wave
         if (any_pos) {
-            const long long tot = wave_sum64(acc);
+            const long long tot = wave_sum64((long long)acc);
             const int m = wave_min(mn);
             if (lane == 0) {
                 atomicAdd(reinterpret_cast<unsigned long long*>(&wsum[cur_win]),
@@ -425,6 +525,7 @@ __global__ __launch_bounds__(NT) void gd_tile_kernel(Job job)
             s_base = b;
             job.tile_cnt[blockIdx.x] = total;
             job.tile_off[blockIdx.x] = b;
+            atomicAdd(&job.super_cnt[blockIdx.x / SUPER], total);
         }
         __syncthreads();
         uint32_t dst = s_base + before + incl - cnt;
@@ -450,45 +551,46 @@ __global__ __launch_bounds__(NT) void gd_tile_kernel(Job job)
 // ---------------------------------------------------------------------------
 // K2: order the per-tile boundary chunks (tiles are in genome order)
 // ---------------------------------------------------------------------------
-// Single workgroup: exclusive scan of tile_cnt -> tile_dst.
-__global__ __launch_bounds__(1024) void gd_runs_scan_kernel(const uint32_t* __restrict__ tile_cnt,
-                                                            uint32_t* __restrict__ tile_dst,
-                                                            int n_tiles)
+// One workgroup per group of SUPER tiles.  Its destination base is the sum of
+// the group counts before it (a few hundred values), then one block scan of the
+// group's tile counts places every chunk.  Groups without boundaries exit at
+// once, which is the common case for whole-genome data.
+__global__ __launch_bounds__(SUPER) void gd_runs_order_kernel(const int2* __restrict__ chunks,
+                                                              uint32_t run_cap,
+                                                              const uint32_t* __restrict__ tile_cnt,
+                                                              const uint32_t* __restrict__ tile_off,
+                                                              const uint32_t* __restrict__ super_cnt,
+                                                              int2* __restrict__ ordered, int n_tiles)
 {
-    __shared__ uint32_t s_part[1024];
-    const int tid = threadIdx.x;
-    const int per = (n_tiles + 1023) / 1024;
-    const int beg = tid * per;
-    const int end = beg + per < n_tiles ? beg + per : n_tiles;
-    uint32_t s = 0;
-    for (int i = beg; i < end; ++i) s += tile_cnt[i];
-    s_part[tid] = s;
+    __shared__ uint32_t s_w[SUPER / WAVE];
+    __shared__ uint32_t s_base;
+    const int g = blockIdx.x;
+    if (super_cnt[g] == 0) return;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    uint32_t part = 0;
+    for (int i = tid; i < g; i += SUPER) part += super_cnt[i];
+    part = (uint32_t)wave_sum((int)part);
+    if (lane == 0) s_w[wv] = part;
     __syncthreads();
-    // Hillis-Steele over 1024 partials
-    for (int d = 1; d < 1024; d <<= 1) {
-        uint32_t v = tid >= d ? s_part[tid - d] : 0;
-        __syncthreads();
-        s_part[tid] += v;
-        __syncthreads();
+    if (tid == 0) {
+        uint32_t b = 0;
+        for (int i = 0; i < SUPER / WAVE; ++i) b += s_w[i];
+        s_base = b;
     }
-    uint32_t run = s_part[tid] - s;
-    for (int i = beg; i < end; ++i) { tile_dst[i] = run; run += tile_cnt[i]; }
-}
-
-__global__ void gd_runs_gather_kernel(const int2* __restrict__ chunks, uint32_t run_cap,
-                                      const uint32_t* __restrict__ tile_cnt,
-                                      const uint32_t* __restrict__ tile_off,
-                                      const uint32_t* __restrict__ tile_dst,
-                                      int2* __restrict__ ordered, int n_tiles)
-{
-    // one wave per tile; lanes stride the tile's entries
-    const int t = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
-    const int lane = threadIdx.x & 63;
-    if (t >= n_tiles) return;
-    const uint32_t cnt = tile_cnt[t];
+    __syncthreads();
+    const uint32_t base = s_base;
+    __syncthreads();
+    const int t = g * SUPER + tid;
+    const uint32_t cnt = t < n_tiles ? tile_cnt[t] : 0;
+    const uint32_t incl = (uint32_t)wave_inclusive_scan((int)cnt);
+    if (lane == 63) s_w[wv] = incl;
+    __syncthreads();
+    uint32_t before = 0;
+    for (int i = 0; i < wv; ++i) before += s_w[i];
     if (cnt == 0) return;
-    const uint32_t src = tile_off[t], dst = tile_dst[t];
-    for (uint32_t k = lane; k < cnt; k += 64)
+    const uint32_t dst = base + before + incl - cnt;
+    const uint32_t src = tile_off[t];
+    for (uint32_t k = 0; k < cnt; ++k)
         if (src + k < run_cap && dst + k < run_cap) ordered[dst + k] = chunks[src + k];
 }
 

@@ -67,7 +67,7 @@ typedef struct {
     int32_t  min_cov;         /* --mincov, default 4 */
     int32_t  max_mean_depth;  /* --maxmeandepth, default 0 (EXCESSIVE class off) */
     uint32_t flag_mask;       /* reads with flag & mask are dropped; 0x704 */
-    int32_t  max_span_hint;   /* expected max reference span of a read (0 = default 1024);
+    int32_t  max_span_hint;   /* expected max reference span of a read (0 = default 512);
                                  only a performance hint: the engine verifies it on device
                                  and transparently re-runs with the observed maximum */
     int64_t  step;            /* callable runs are split at multiples of this
