@@ -63,8 +63,9 @@ struct gd_ctx {
     int ring_next = 0;
     std::string err;
 
-    int tile_T = 8192;
+    int tile_T = 4096;
     int tile_NT = 256;
+    int ablate = 0;                     // debug: GOLEFT_GD_ABLATE
     int lookback = kDefaultLookback;
 
     // device job state
@@ -248,6 +249,7 @@ int gd_create(int device_id, gd_ctx** out)
         int t = atoi(e);
         if (t == 4096 || t == 8192 || t == 16384) c->tile_T = t;
     }
+    if (const char* e = getenv("GOLEFT_GD_ABLATE")) c->ablate = atoi(e);
     if (const char* e = getenv("GOLEFT_GD_THREADS")) {
         int t = atoi(e);
         if (t == 256 || t == 512 || t == 1024) c->tile_NT = t;
@@ -545,6 +547,7 @@ int gd_compute(gd_ctx* c)
         gd::ContigDev d{};
         d.pos = h.pos; d.flag = h.flag; d.mapq = h.mapq; d.off = h.off; d.cigar = h.cigar;
         d.n_reads = (uint32_t)h.n_reads;
+        d.n_ops = (uint32_t)h.n_ops;
         d.length = (int32_t)h.length;
         d.tile_beg = (int32_t)tile_beg;
         d.n_tiles = (int32_t)((h.length + T - 1) / T);
@@ -626,26 +629,27 @@ int gd_compute(gd_ctx* c)
         job.maxmean = P.max_mean_depth;
         job.flag_mask = P.flag_mask;
         job.lookback = c->lookback;
+        job.ablate = c->ablate;
         job.step = derive_step(P);
 
         if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
         switch (T) {
-        case 4096: launch_prep<4096>(c, job); break;
+        case 8192: launch_prep<8192>(c, job); break;
         case 16384: launch_prep<16384>(c, job); break;
-        default: launch_prep<8192>(c, job); break;
+        default: launch_prep<4096>(c, job); break;
         }
         if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
         {
             const int key = T + c->tile_NT;   // (T, NT) variants compiled below
             switch (key) {
-            case 4096 + 256: launch_tile<4096, 256>(c, job); break;
             case 4096 + 512: launch_tile<4096, 512>(c, job); break;
             case 8192 + 512: launch_tile<8192, 512>(c, job); break;
             case 8192 + 1024: launch_tile<8192, 1024>(c, job); break;
             case 16384 + 256: launch_tile<16384, 256>(c, job); break;
             case 16384 + 512: launch_tile<16384, 512>(c, job); break;
             case 16384 + 1024: launch_tile<16384, 1024>(c, job); break;
-            default: launch_tile<8192, 256>(c, job); break;
+            case 8192 + 256: launch_tile<8192, 256>(c, job); break;
+            default: launch_tile<4096, 256>(c, job); break;
             }
         }
         if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[2], c->stream));

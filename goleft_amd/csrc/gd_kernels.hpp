@@ -46,19 +46,32 @@ struct ContigDev {
     const uint32_t* off;      // n_reads+1 CSR offsets (relative to cigar)
     const uint32_t* cigar;
     uint32_t n_reads;
+    uint32_t n_ops;
     int32_t  length;
     int32_t  tile_beg;        // first global tile id of this contig
     int32_t  n_tiles;
     int64_t  base_off;        // element offset of this contig in the per-base array
     int64_t  win_off;         // element offset in the window arrays
     int32_t  tid;             // reference id in the BAM header
-    int32_t  pad;
 };
 
-struct TileInfo {
+// Everything a workgroup needs for its tile in ONE 80-byte record (one scalar
+// load burst, no dependent contig-table lookup).  Written by gd_prep_kernel.
+struct __attribute__((aligned(16))) TileInfo {
+    const int32_t*  pos;
+    const uint16_t* flag;
+    const uint8_t*  mapq;
+    const uint32_t* off;
+    const uint32_t* cigar;
+    int64_t  base_off;        // per-base array offset of the contig
+    int64_t  win_off;         // window array offset of the contig
+    int32_t  length;          // contig length
     int32_t  ctg;             // index into the ContigDev table
     int32_t  t0;              // first reference position of the tile
     uint32_t lo, hi;          // read index range [lo,hi) that can touch the tile
+    uint32_t n_reads;         // records of the contig (bounds for the vector loads)
+    uint32_t n_ops;           // CIGAR ops of the contig
+    uint32_t clo, chi;        // CIGAR op range [off[lo], off[hi]) of those reads
 };
 
 // Device-side counters, read back once per gd_compute.
@@ -89,6 +102,8 @@ struct Job {
     int32_t   maxmean;
     uint32_t  flag_mask;
     int32_t   lookback;
+    int32_t   ablate;         // debug only (GOLEFT_GD_ABLATE): 1 skip phase A, 2 skip LDS marks,
+                              // 4 skip per-base stores, 8 skip window/class reductions
     int64_t   step;
 };
 
@@ -139,12 +154,17 @@ __global__ void gd_prep_kernel(Job job)
     }
     const ContigDev c = job.ctgs[lo];
     TileInfo ti;
+    ti.pos = c.pos; ti.flag = c.flag; ti.mapq = c.mapq; ti.off = c.off; ti.cigar = c.cigar;
+    ti.base_off = c.base_off; ti.win_off = c.win_off; ti.length = c.length;
+    ti.n_reads = c.n_reads; ti.n_ops = c.n_ops;
     ti.ctg = lo;
     ti.t0 = (t - c.tile_beg) * T;
     int32_t tend = ti.t0 + T < c.length ? ti.t0 + T : c.length;
     int32_t from = ti.t0 > job.lookback ? ti.t0 - job.lookback : 0;
     ti.lo = lower_bound_i32(c.pos, c.n_reads, from);
     ti.hi = lower_bound_i32(c.pos, c.n_reads, tend);
+    ti.clo = c.n_reads ? c.off[ti.lo] : 0u;
+    ti.chi = c.n_reads ? c.off[ti.hi] : 0u;
     job.tiles[t] = ti;
 }
 
@@ -204,31 +224,38 @@ __device__ __forceinline__ int wave_prev_lane(int v, int first)
     return __builtin_amdgcn_update_dpp(first, v, 0x138, 0xf, 0xf, false);
 }
 
-// Walk one CIGAR (generic path): merge adjacent M/=/X ops into reference
-// intervals, clip to the tile, mark +1/-1 in the LDS difference array.
-// Returns the reference span of the read.
-__device__ __forceinline__ int32_t walk_cigar(const uint32_t* __restrict__ cigar, uint32_t o0,
-                                              uint32_t o1, int32_t p, int32_t t0, int32_t tend,
+// Mark the clipped interval [s,e) of a read in the tile's difference array.
+__device__ __forceinline__ void mark_interval(int32_t s, int32_t e, int32_t t0, int32_t tend,
                                               int32_t clen, int32_t* s_diff, int& prev_cnt)
+{
+    if (e > clen) e = clen;
+    prev_cnt += (s < t0 && e >= t0) ? 1 : 0;       // covers t0-1
+    if (e > t0 && s < tend) {
+        const int32_t cs = (s > t0 ? s : t0) - t0;
+        atomicAdd(&s_diff[cs], 1);
+        if (e < tend) atomicAdd(&s_diff[e - t0], -1);
+    }
+}
+
+// Walk one CIGAR (generic path): merge adjacent M/=/X ops into reference
+// intervals and mark them.  `ops` points at op o0 of the read (LDS staging
+// area or global memory).  Returns the reference span of the read.
+template <typename OpPtr>
+__device__ __forceinline__ int32_t walk_cigar(OpPtr ops, uint32_t n, int32_t p, int32_t t0,
+                                              int32_t tend, int32_t clen, int32_t* s_diff,
+                                              int& prev_cnt)
 {
     int32_t cur = p;
     int32_t rs = -1;                               // open run start, -1 = none
-    for (uint32_t k = o0; k <= o1; ++k) {
+    for (uint32_t k = 0; k <= n; ++k) {
         uint32_t op = 2, len = 0;                  // sentinel: a zero-length D closes the run
-        if (k < o1) { const uint32_t cg = cigar[k]; op = cg & 0xf; len = cg >> 4; }
+        if (k < n) { const uint32_t cg = ops[k]; op = cg & 0xf; len = cg >> 4; }
         const bool counted = (0x181u >> op) & 1u;  // M = X
         const bool consumes = (0x18du >> op) & 1u; // M D N = X
         if (counted) {
             if (rs < 0 && len > 0) rs = cur;
         } else if (consumes && rs >= 0) {
-            int32_t s = rs, e = cur;               // close run [rs, cur)
-            if (e > clen) e = clen;
-            if (s < t0 && e >= t0) prev_cnt++;     // covers t0-1
-            if (e > t0 && s < tend) {
-                const int32_t cs = (s > t0 ? s : t0) - t0;
-                atomicAdd(&s_diff[cs], 1);
-                if (e < tend) atomicAdd(&s_diff[e - t0], -1);
-            }
+            mark_interval(rs, cur, t0, tend, clen, s_diff, prev_cnt);
             rs = -1;
         }
         if (consumes) cur += (int32_t)len;
@@ -243,109 +270,170 @@ __global__ __launch_bounds__(NT) void gd_tile_kernel(Job job)
     constexpr int CHUNK = T / NW;          // positions per wave
     constexpr int ROWS = CHUNK / 256;      // rows of 256 positions per wave
     constexpr int NWORDS = T / 32;         // bitmap words
-    constexpr int QCAP = 1024;             // multi-op read queue (indices)
     constexpr int BIG = 0x3fffffff;
+    constexpr int CQ = (T * 3) / 8;        // staged CIGAR ops (30x/150 bp needs ~T/4)
     static_assert(CHUNK % 256 == 0, "wave chunk must be whole rows");
 
     __shared__ __attribute__((aligned(16))) int32_t s_diff[T];
     __shared__ uint32_t s_bmap[NWORDS];    // boundary bit per position
     __shared__ uint32_t s_clo[NWORDS];     // class bit 0 at boundary positions
     __shared__ uint32_t s_chi[NWORDS];     // class bit 1 at boundary positions
-    __shared__ uint32_t s_queue[QCAP];
+    __shared__ __attribute__((aligned(16))) uint32_t s_cig[CQ];      // staged CIGAR ops
+    __shared__ uint32_t s_wq[NW * 3 * WAVE]; // per-wave queues of multi-op reads
     __shared__ int32_t  s_wtot[NW];
     __shared__ uint32_t s_wcnt[NW];
     __shared__ int32_t  s_prev;            // depth at t0-1
     __shared__ uint32_t s_hasb;
     __shared__ uint32_t s_base;
-    __shared__ uint32_t s_qn;
 
     const int tid = threadIdx.x;
     const int lane = tid & (WAVE - 1);
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const TileInfo ti = job.tiles[blockIdx.x];
-    const ContigDev c = job.ctgs[ti.ctg];
+    const TileInfo& c = ti;                // contig fields live in the same record
     const int32_t t0 = ti.t0;
     const int32_t tend = t0 + T < c.length ? t0 + T : c.length;   // clipped tile end
     const int tlen = tend - t0;                                   // valid positions, 1..T
 
-    // ---- zero LDS -------------------------------------------------------
+    // ---- loads first: records of the first batch and the tile's CIGAR range --
+    // The reads [lo,hi) of a tile are contiguous, so their ops [clo,chi) are one
+    // contiguous range: it is fetched with coalesced 16-byte loads at the same
+    // time as the record fields (one memory round trip, no dependent second
+    // one) and staged in LDS for the CIGAR decode.
+    constexpr int U = 4;                          // reads per lane in flight
+    constexpr int CCH = (CQ / 4 + NT - 1) / NT;   // 16-byte chunks per thread
+    int32_t  p[U];
+    uint32_t f[U], o0[U], o1[U], mq[U];
+    const bool run_a = !(job.ablate & 1) && ti.lo < ti.hi;
+    const uint32_t a0 = ti.clo & ~3u;             // 16-byte aligned start of the op range
+    const bool staged = ti.chi - a0 <= (uint32_t)CQ;
+    const uint32_t last = ti.hi - 1u;
+    if (run_a) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            uint32_t i = ti.lo + u * NT + tid;
+            i = i < last ? i : last;              // clamped: lanes past hi redo the last read
+            p[u] = c.pos[i];
+            f[u] = c.flag[i];
+            mq[u] = c.mapq[i];
+            o0[u] = c.off[i];
+            o1[u] = c.off[i + 1];
+        }
+        if (staged) {
+            uint4 cg4[CCH];
+            const uint32_t nst = ti.chi - a0;
+#pragma unroll
+            for (int k = 0; k < CCH; ++k) {
+                const uint32_t j = (uint32_t)(k * NT + tid) * 4u;
+                cg4[k] = make_uint4(0, 0, 0, 0);
+                if (j < nst) {
+                    const uint32_t g = a0 + j;
+                    if (g + 4u <= ti.n_ops) {
+                        cg4[k] = *reinterpret_cast<const uint4*>(c.cigar + g);
+                    } else {
+                        if (g + 0u < ti.n_ops) cg4[k].x = c.cigar[g];
+                        if (g + 1u < ti.n_ops) cg4[k].y = c.cigar[g + 1];
+                        if (g + 2u < ti.n_ops) cg4[k].z = c.cigar[g + 2];
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < CCH; ++k) {
+                const uint32_t j = (uint32_t)(k * NT + tid) * 4u;
+                if (j < nst) *reinterpret_cast<uint4*>(&s_cig[j]) = cg4[k];
+            }
+        }
+    }
+
+    // ---- zero LDS (overlaps the loads above) -----------------------------
     {
         int4 z = make_int4(0, 0, 0, 0);
         int4* d4 = reinterpret_cast<int4*>(s_diff);
 #pragma unroll
         for (int i = tid; i < T / 4; i += NT) d4[i] = z;
         for (int i = tid; i < NWORDS; i += NT) { s_bmap[i] = 0; s_clo[i] = 0; s_chi[i] = 0; }
-        if (tid == 0) { s_prev = 0; s_hasb = 0; s_qn = 0; }
+        if (tid == 0) { s_prev = 0; s_hasb = 0; }
     }
     __syncthreads();
 
     // ---- phase A: reads -> clipped intervals -> LDS +1/-1 -----------------
-    // U reads per lane are in flight at once (the phase is latency bound).
-    // Single-op reads (the bulk of short-read data) are handled branch-light;
-    // multi-op reads are queued and walked afterwards with dense lanes.
-    int prev_cnt = 0;
-    int span_max = 0;
-    {
-        constexpr int U = 4;
+    // Single-op reads (the bulk of short-read data) are marked straight away.
+    // Multi-op reads are compacted into a per-wave queue and walked afterwards
+    // with dense lanes, so the CIGAR loop runs once per wave, not once per slot.
+    if (run_a) {
+        int prev_cnt = 0;
+        int span_max = 0;
+        uint32_t* wq = &s_wq[wv * (3 * WAVE)];    // this wave's queue: p | o0 | n
+        uint32_t qn = 0;                          // entries queued (wave uniform)
         for (uint32_t base = ti.lo; base < ti.hi; base += NT * U) {
-            int32_t  p[U];
-            uint32_t f[U], o0[U], o1[U], c0[U], idx[U];
-            int      mq[U];
-            bool     ok[U];
+            if (base != ti.lo) {                  // further batches (deep tiles)
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    uint32_t i = base + u * NT + tid;
+                    i = i < last ? i : last;
+                    p[u] = c.pos[i];
+                    f[u] = c.flag[i];
+                    mq[u] = c.mapq[i];
+                    o0[u] = c.off[i];
+                    o1[u] = c.off[i + 1];
+                }
+            }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const uint32_t i = base + u * NT + tid;
-                ok[u] = i < ti.hi;
-                idx[u] = ok[u] ? i : ti.lo;                     // any valid index
-                p[u] = c.pos[idx[u]];
-                f[u] = c.flag[idx[u]];
-                mq[u] = c.mapq[idx[u]];
-                o0[u] = c.off[idx[u]];
-                o1[u] = c.off[idx[u] + 1];
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                ok[u] = ok[u] && (f[u] & job.flag_mask) == 0 && mq[u] >= job.Q && o1[u] > o0[u];
-                c0[u] = ok[u] ? c.cigar[o0[u]] : 0u;
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const uint32_t op = c0[u] & 0xf;
-                const int32_t len = (int32_t)(c0[u] >> 4);
-                const bool single = (o1[u] - o0[u]) == 1u;
-                const bool simple = ok[u] && single && ((0x181u >> op) & 1u) && len > 0;
+                const uint32_t n = o1[u] - o0[u];
+                const bool keep = i < ti.hi && (f[u] & job.flag_mask) == 0 &&
+                                  (int)mq[u] >= job.Q && n > 0;
+                uint32_t cg = 0;
+                if (keep) cg = staged ? s_cig[o0[u] - a0] : c.cigar[o0[u]];
+                const uint32_t op = cg & 0xf;
+                const int32_t len = (int32_t)(cg >> 4);
+                const bool simple = keep && n == 1u && ((0x181u >> op) & 1u) && len > 0;
                 if (simple) {
-                    const int32_t s = p[u];
-                    int32_t e = s + len;
                     span_max = len > span_max ? len : span_max;
-                    if (e > c.length) e = c.length;
-                    if (s < t0 && e >= t0) prev_cnt++;
-                    if (e > t0 && s < tend) {
-                        const int32_t cs = (s > t0 ? s : t0) - t0;
-                        atomicAdd(&s_diff[cs], 1);
-                        if (e < tend) atomicAdd(&s_diff[e - t0], -1);
+                    if (!(job.ablate & 2))
+                        mark_interval(p[u], p[u] + len, t0, tend, c.length, s_diff, prev_cnt);
+                }
+                const bool cx = keep && !simple;
+                const unsigned long long m = __ballot(cx);
+                if (m != 0ull) {                  // wave uniform
+                    const uint32_t r = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32),
+                                            __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                    if (cx) {
+                        if (r < (uint32_t)WAVE) {
+                            wq[r] = (uint32_t)p[u]; wq[WAVE + r] = o0[u]; wq[2 * WAVE + r] = n;
+                        } else {                  // queue full: walk in place
+                            const int32_t span = staged
+                                ? walk_cigar(&s_cig[o0[u] - a0], n, p[u], t0, tend, c.length, s_diff, prev_cnt)
+                                : walk_cigar(c.cigar + o0[u], n, p[u], t0, tend, c.length, s_diff, prev_cnt);
+                            span_max = span > span_max ? span : span_max;
+                        }
                     }
-                } else if (ok[u]) {
-                    const uint32_t slot = atomicAdd(&s_qn, 1u);
-                    if (slot < (uint32_t)QCAP) {
-                        s_queue[slot] = idx[u];
-                    } else {                                     // queue full: walk in place
-                        const int32_t span = walk_cigar(c.cigar, o0[u], o1[u], p[u], t0, tend,
-                                                        c.length, s_diff, prev_cnt);
+                    qn += (uint32_t)__popcll(m);
+                    if (qn >= (uint32_t)WAVE) {   // drain a full queue
+                        __builtin_amdgcn_wave_barrier();
+                        const int32_t qp = (int32_t)wq[lane];
+                        const uint32_t qo = wq[WAVE + lane], qk = wq[2 * WAVE + lane];
+                        const int32_t span = staged
+                            ? walk_cigar(&s_cig[qo - a0], qk, qp, t0, tend, c.length, s_diff, prev_cnt)
+                            : walk_cigar(c.cigar + qo, qk, qp, t0, tend, c.length, s_diff, prev_cnt);
                         span_max = span > span_max ? span : span_max;
+                        __builtin_amdgcn_wave_barrier();
+                        qn = 0;
                     }
                 }
             }
         }
-    }
-    __syncthreads();
-    {
-        const uint32_t nq = s_qn < (uint32_t)QCAP ? s_qn : (uint32_t)QCAP;
-        for (uint32_t j = tid; j < nq; j += NT) {
-            const uint32_t i = s_queue[j];
-            const int32_t span = walk_cigar(c.cigar, c.off[i], c.off[i + 1], c.pos[i], t0, tend,
-                                            c.length, s_diff, prev_cnt);
-            span_max = span > span_max ? span : span_max;
+        if (qn != 0) {                            // drain the rest
+            __builtin_amdgcn_wave_barrier();
+            if ((uint32_t)lane < qn) {
+                const int32_t qp = (int32_t)wq[lane];
+                const uint32_t qo = wq[WAVE + lane], qk = wq[2 * WAVE + lane];
+                const int32_t span = staged
+                    ? walk_cigar(&s_cig[qo - a0], qk, qp, t0, tend, c.length, s_diff, prev_cnt)
+                    : walk_cigar(c.cigar + qo, qk, qp, t0, tend, c.length, s_diff, prev_cnt);
+                span_max = span > span_max ? span : span_max;
+            }
         }
         // rare: publish look-back violations so the host can re-run
         if (span_max > job.lookback) atomicMax(&job.counters->max_span, span_max);
@@ -413,8 +501,9 @@ __global__ __launch_bounds__(NT) void gd_tile_kernel(Job job)
             // positions at or past the contig end hold depth 0 (nothing is printed there)
             const int d0 = nvalid > 0 ? base + x0 : 0, d1 = nvalid > 1 ? base + x1 : 0;
             const int d2 = nvalid > 2 ? base + x2 : 0, d3 = nvalid > 3 ? base + x3 : 0;
-            *reinterpret_cast<int4*>(&out[ib]) = make_int4(d0, d1, d2, d3);
+            if (!(job.ablate & 4)) *reinterpret_cast<int4*>(&out[ib]) = make_int4(d0, d1, d2, d3);
             any_pos = true;
+            if (job.ablate & 8) { acc += (uint32_t)d0 ^ (uint32_t)d3; continue; }
             const bool full_row = rb + 256 <= tlen;
             const int m01 = d0 < d1 ? d0 : d1, m23 = d2 < d3 ? d2 : d3;
             const int rmin = m01 < m23 ? m01 : m23;
