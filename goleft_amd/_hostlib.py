@@ -1,0 +1,148 @@
+"""ctypes binding of libgoleft_host.so (include/goleft_depth_host.h): the C++
+host side of `goleft depth` (BAM decode, tiling, BED rows, CLI entry)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from . import _lib
+from ._lib import GdRun
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(HERE, "libgoleft_host.so")
+_P = C.c_void_p
+
+SYMBOLS = {
+    "gdh_depth_main": (C.c_int, [C.c_int, C.POINTER(C.c_char_p)]),
+    "gdh_chrom_start_end": (C.c_int, [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t,
+                                      C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "gdh_step": (C.c_int64, [C.c_int32]),
+    "gdh_format_region": (C.c_int, [C.c_char_p, C.c_int64, C.c_int64, C.c_int32, _P, C.c_size_t,
+                                    _P, C.c_size_t, C.c_char_p, C.c_char_p]),
+    "gdh_bam_open": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(_P)]),
+    "gdh_bam_close": (None, [_P]),
+    "gdh_bam_error": (C.c_char_p, [_P]),
+    "gdh_bam_n_contigs": (C.c_int, [_P]),
+    "gdh_bam_contig_name": (C.c_char_p, [_P, C.c_int]),
+    "gdh_bam_contig_length": (C.c_int64, [_P, C.c_int]),
+    "gdh_bam_seek_contig": (C.c_int, [_P, C.c_int]),
+    "gdh_bam_next": (C.c_int, [_P, C.c_size_t, C.POINTER(C.c_int32), C.POINTER(C.c_size_t),
+                               C.POINTER(C.c_size_t), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P),
+                               C.POINTER(_P), C.POINTER(_P)]),
+    "gdh_bam_n_records": (C.c_uint64, [_P]),
+    "gdh_intervals_read": (C.c_int, [C.POINTER(C.c_char_p), C.c_int, C.POINTER(_P)]),
+    "gdh_intervals_free": (None, [_P]),
+    "gdh_intervals_overlaps": (C.c_int, [_P, C.c_char_p, C.c_int64, C.c_int64]),
+    "gdh_intervals_count": (C.c_size_t, [_P, C.c_char_p]),
+}
+
+_LIB = None
+
+
+def load():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    _lib.load()   # the host library links against the device library
+    if not os.path.exists(SO_PATH):
+        raise ImportError("goleft_amd: %s is missing -- run __graft_entry__.build()" % SO_PATH)
+    lib = C.CDLL(SO_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _LIB = lib
+    return lib
+
+
+def chrom_start_end(line: bytes):
+    """depth/depth.go:75-94."""
+    chrom = C.create_string_buffer(4096)
+    s, e = C.c_int64(), C.c_int64()
+    if load().gdh_chrom_start_end(line, len(line), chrom, 4096, C.byref(s), C.byref(e)) != 0:
+        raise ValueError("couldn't get region from line %r" % line)
+    return chrom.value.decode(), s.value, e.value
+
+
+def format_region(chrom, start, end, W, sums, runs, depth_path, callable_path):
+    import numpy as np
+    sums = np.ascontiguousarray(sums, np.int64)
+    runs = np.ascontiguousarray(runs, np.int32).reshape(-1, 3)
+    rc = load().gdh_format_region(chrom.encode(), start, end, W, sums.ctypes.data, len(sums),
+                                  runs.ctypes.data, len(runs), depth_path.encode(),
+                                  callable_path.encode())
+    if rc != 0:
+        raise OSError("gdh_format_region failed")
+
+
+def read_bam(path: str, threads: int = 0, max_reads: int = 1 << 20, seek_tid=None):
+    """Decode a BAM with the C++ reader -> (contigs, {tid: (pos, flag, mapq, off, cigar)}, n_records)."""
+    import numpy as np
+    lib = load()
+    h = _P()
+    rc = lib.gdh_bam_open(path.encode(), threads, C.byref(h))
+    try:
+        if rc != 0:
+            raise OSError(lib.gdh_bam_error(h).decode() if h else "open failed")
+        contigs = [(lib.gdh_bam_contig_name(h, i).decode(), lib.gdh_bam_contig_length(h, i))
+                   for i in range(lib.gdh_bam_n_contigs(h))]
+        if seek_tid is not None:
+            lib.gdh_bam_seek_contig(h, seek_tid)
+        parts = {}
+        tid, n, m = C.c_int32(), C.c_size_t(), C.c_size_t()
+        pp, pf, pm, po, pc = _P(), _P(), _P(), _P(), _P()
+        while True:
+            rc = lib.gdh_bam_next(h, max_reads, C.byref(tid), C.byref(n), C.byref(m), C.byref(pp),
+                                  C.byref(pf), C.byref(pm), C.byref(po), C.byref(pc))
+            if rc < 0:
+                raise OSError(lib.gdh_bam_error(h).decode())
+            if rc == 0:
+                break
+
+            def arr(ptr, dt, cnt):
+                if cnt == 0:
+                    return np.zeros(0, dt)
+                return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)),
+                                             (cnt * np.dtype(dt).itemsize,)).view(dt).copy()
+            parts.setdefault(tid.value, []).append(
+                (arr(pp, np.int32, n.value), arr(pf, np.uint16, n.value), arr(pm, np.uint8, n.value),
+                 arr(po, np.uint32, n.value + 1), arr(pc, np.uint32, m.value)))
+        out = {}
+        for t, ps in parts.items():
+            pos = np.concatenate([p[0] for p in ps])
+            flag = np.concatenate([p[1] for p in ps])
+            mapq = np.concatenate([p[2] for p in ps])
+            cig = np.concatenate([p[4] for p in ps])
+            offs, base = [np.zeros(1, np.uint32)], 0
+            for p in ps:
+                offs.append(p[3][1:] + np.uint32(base))
+                base += len(p[4])
+            out[t] = (pos, flag, mapq, np.concatenate(offs), cig)
+        return contigs, out, int(lib.gdh_bam_n_records(h))
+    finally:
+        if h:
+            lib.gdh_bam_close(h)
+
+
+class Intervals:
+    """depth/intervals.go ReadTree / Overlaps."""
+
+    def __init__(self, *paths: str):
+        self._lib = load()
+        self._h = _P()
+        arr = (C.c_char_p * len(paths))(*[p.encode() for p in paths])
+        if self._lib.gdh_intervals_read(arr, len(paths), C.byref(self._h)) != 0:
+            raise OSError("ReadTree failed")
+
+    def overlaps(self, chrom: str, start: int, end: int) -> bool:
+        return bool(self._lib.gdh_intervals_overlaps(self._h, chrom.encode(), start, end))
+
+    def count(self, chrom: str) -> int:
+        return int(self._lib.gdh_intervals_count(self._h, chrom.encode()))
+
+    def __del__(self):
+        try:
+            if self._h:
+                self._lib.gdh_intervals_free(self._h)
+        except Exception:
+            pass

@@ -74,14 +74,10 @@ _LIB = None
 
 
 def build(force: bool = False) -> str:
-    """Compile the HIP library in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    """Compile everything in-tree for gfx950 (hipcc cross-compiles without a GPU):
+    libgoleft_depth.so (HIP engine), libgoleft_host.so (C++ host), goleft-depth (CLI)."""
     src_dir = os.path.join(HERE, "csrc")
-    srcs = [os.path.join(src_dir, f) for f in ("gd_api.hip", "gd_kernels.hpp")]
-    srcs.append(os.path.join(os.path.dirname(HERE), "include", "goleft_depth.h"))
-    stale = (not os.path.exists(SO_PATH)
-             or any(os.path.getmtime(s) > os.path.getmtime(SO_PATH) for s in srcs))
-    if force or stale:
-        subprocess.check_call(["make", "-s", "-C", src_dir] + (["-B"] if force else []))
+    subprocess.check_call(["make", "-s", "-C", src_dir, "all"] + (["-B"] if force else []))
     return SO_PATH
 
 

@@ -1,0 +1,80 @@
+// bam_reader.hpp -- BGZF/BAM decode to the engine's SoA record blocks.
+//
+// Replaces the BAM read that every `samtools depth` child of the reference
+// performs (/root/reference/depth/depth.go:45): BGZF members are inflated in
+// parallel (zlib), records are decoded to {pos, flag, mapq, CIGAR} -- the only
+// fields `samtools depth -Q q` without -q ever consults.
+// Format: SAMv1 section 4 (BGZF, BAM), long-CIGAR convention 4.2.2 (CG:B,I).
+#pragma once
+
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+namespace gdh {
+
+struct BamContig {
+    std::string name;
+    int64_t length;
+};
+
+// One block of decoded records of a single contig, coordinate order.
+struct RecordBlock {
+    int32_t tid = -1;
+    std::vector<int32_t> pos;
+    std::vector<uint16_t> flag;
+    std::vector<uint8_t> mapq;
+    std::vector<uint32_t> cigar_off;   // n+1, starts at 0
+    std::vector<uint32_t> cigar;
+    void clear()
+    {
+        tid = -1;
+        pos.clear(); flag.clear(); mapq.clear(); cigar.clear();
+        cigar_off.assign(1, 0);
+    }
+    size_t size() const { return pos.size(); }
+};
+
+class BamReader {
+public:
+    BamReader() = default;
+    ~BamReader();
+    BamReader(const BamReader&) = delete;
+    BamReader& operator=(const BamReader&) = delete;
+
+    // Opens the file, inflates and parses the header.  threads <= 0: all cores.
+    bool open(const std::string& path, int threads, std::string* err);
+    const std::vector<BamContig>& contigs() const { return contigs_; }
+    const std::string& header_text() const { return text_; }
+
+    // Position the stream at the first record of contig `tid` using the .bai
+    // (path + ".bai"); returns false (stream untouched) when there is no usable
+    // index or the contig has no records.
+    bool seek_contig(int32_t tid, std::string* err);
+
+    // Fills `out` with up to max_reads records, all of one contig (a block ends
+    // at a contig change).  Records with refID < 0 are skipped and counted.
+    // Returns 1 on success, 0 at end of file, -1 on error.
+    int next_block(RecordBlock& out, size_t max_reads, std::string* err);
+
+    uint64_t n_records() const { return n_records_; }
+    uint64_t n_unplaced() const { return n_unplaced_; }
+
+private:
+    bool fill(std::string* err);             // inflate the next batch of BGZF members
+    bool need(size_t n, std::string* err);   // make n decoded bytes available at cur_
+
+    FILE* fp_ = nullptr;
+    std::string path_;
+    int threads_ = 1;
+    bool eof_ = false;
+    std::vector<uint8_t> raw_;                // compressed batch
+    std::vector<uint8_t> buf_;                // decoded bytes not yet consumed
+    size_t cur_ = 0;
+    std::vector<BamContig> contigs_;
+    std::string text_;
+    uint64_t n_records_ = 0, n_unplaced_ = 0;
+};
+
+}  // namespace gdh

@@ -1,0 +1,525 @@
+// depth_host.cpp -- host side of `goleft depth` above the device C ABI.
+//
+// C++ twin of the reference's Go front end (/root/reference/depth/depth.go;
+// the Go toolchain is absent from the build image).  It keeps the reference's
+// flags (:27-41), defaults (:164-167), .fai tiling (:122-159), --bed regions
+// (:103-120), output naming (:382-388) and the exact BED rows of the callback
+// (:238-364, including quirks Q1/Q2 of SURVEY.md section 3.3), but where the
+// reference spawns `samtools depth` per tile and parses its text, this host
+// streams decoded BAM records into the HIP engine (goleft_depth.h) and formats
+// rows from the integer results (window sums, coverage-class runs).
+#include "../../../include/goleft_depth_host.h"
+
+#include <algorithm>
+#include <cerrno>
+#include <cinttypes>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "bam_reader.hpp"
+#include "fasta_stats.hpp"
+
+namespace {
+
+const char* const kClassName[4] = {"NO_COVERAGE", "LOW_COVERAGE", "CALLABLE", "EXCESSIVE_COVERAGE"};
+
+// ---- depth/depth.go:27-41 dargs ------------------------------------------
+struct DArgs {
+    int window_size = 250;      // --windowsize / -w
+    int max_mean_depth = 0;     // --maxmeandepth / -m
+    bool ordered = false;       // --ordered / -o   (output is always ordered here)
+    int q = 1;                  // --q / -Q
+    std::string chrom;          // --chrom / -c
+    int min_cov = 4;            // --mincov
+    bool stats = false;         // --stats / -s
+    std::string reference;      // --reference / -r
+    int processes = 0;          // --processes / -p  (BGZF inflate threads here)
+    std::string bed;            // --bed / -b
+    std::string prefix;         // --prefix (required)
+    std::string bam;            // positional (required)
+};
+
+void usage(FILE* f)
+{
+    fputs("usage: goleft depth [--windowsize WINDOWSIZE] [--maxmeandepth MAXMEANDEPTH] [--ordered] "
+          "[--q Q] [--chrom CHROM] [--mincov MINCOV] [--stats] [--reference REFERENCE] "
+          "[--processes PROCESSES] [--bed BED] --prefix PREFIX BAM\n", f);
+}
+
+bool parse_int(const char* s, int* out)
+{
+    char* end = nullptr;
+    errno = 0;
+    long v = strtol(s, &end, 10);
+    if (errno || end == s || *end) return false;
+    *out = (int)v;
+    return true;
+}
+
+// returns 0 ok, 1 help shown, -1 error (message printed)
+int parse_args(int argc, const char* const* argv, DArgs* a)
+{
+    struct Opt { const char* lng; const char* sht; int kind; };  // kind 0 flag, 1 int, 2 string
+    static const Opt opts[] = {
+        {"--windowsize", "-w", 1}, {"--maxmeandepth", "-m", 1}, {"--ordered", "-o", 0},
+        {"--q", "-Q", 1}, {"--chrom", "-c", 2}, {"--mincov", nullptr, 1}, {"--stats", "-s", 0},
+        {"--reference", "-r", 2}, {"--processes", "-p", 1}, {"--bed", "-b", 2}, {"--prefix", nullptr, 2}};
+    std::vector<std::string> positional;
+    for (int i = 1; i < argc; ++i) {
+        std::string arg = argv[i];
+        if (arg == "--help" || arg == "-h") { usage(stdout); return 1; }
+        if (arg.size() < 2 || arg[0] != '-') { positional.push_back(arg); continue; }
+        std::string val;
+        bool has_val = false;
+        size_t eq = arg.find('=');
+        if (eq != std::string::npos) { val = arg.substr(eq + 1); arg = arg.substr(0, eq); has_val = true; }
+        const Opt* o = nullptr;
+        for (const Opt& c : opts)
+            if (arg == c.lng || (c.sht && arg == c.sht)) o = &c;
+        if (!o) { fprintf(stderr, "error: unknown argument %s\n", arg.c_str()); usage(stderr); return -1; }
+        if (o->kind != 0 && !has_val) {
+            if (i + 1 >= argc) { fprintf(stderr, "error: missing value for %s\n", arg.c_str()); usage(stderr); return -1; }
+            val = argv[++i];
+        }
+        int iv = 0;
+        if (o->kind == 1 && !parse_int(val.c_str(), &iv)) {
+            fprintf(stderr, "error: error processing %s: invalid integer %s\n", arg.c_str(), val.c_str());
+            usage(stderr);
+            return -1;
+        }
+        const std::string n = o->lng;
+        if (n == "--windowsize") a->window_size = iv;
+        else if (n == "--maxmeandepth") a->max_mean_depth = iv;
+        else if (n == "--ordered") a->ordered = !has_val || val == "true";
+        else if (n == "--q") a->q = iv;
+        else if (n == "--chrom") a->chrom = val;
+        else if (n == "--mincov") a->min_cov = iv;
+        else if (n == "--stats") a->stats = !has_val || val == "true";
+        else if (n == "--reference") a->reference = val;
+        else if (n == "--processes") a->processes = iv;
+        else if (n == "--bed") a->bed = val;
+        else if (n == "--prefix") a->prefix = val;
+    }
+    if (positional.size() > 1) { fprintf(stderr, "error: too many positional arguments at '%s'\n", positional[1].c_str()); usage(stderr); return -1; }
+    if (positional.size() == 1) a->bam = positional[0];
+    if (a->prefix.empty()) { fprintf(stderr, "error: --prefix is required\n"); usage(stderr); return -1; }
+    if (a->bam.empty()) { fprintf(stderr, "error: bam is required\n"); usage(stderr); return -1; }
+    if (a->window_size < 1) { fprintf(stderr, "error: --windowsize must be >= 1\n"); return -1; }
+    return 0;
+}
+
+// ---- depth/depth.go:73-94 -------------------------------------------------
+// regexp `(.+?)[:\t](\d+)([\-\t])(\d+).*?`, leftmost match with a lazy chrom:
+// the first separator (':' or TAB, not at column 0) that is followed by
+// digits, '-' or TAB, and at least one more digit.
+bool chrom_start_end(const char* line, size_t len, std::string* chrom, int64_t* start, int64_t* end)
+{
+    auto digits = [&](size_t from) {
+        size_t j = from;
+        while (j < len && line[j] >= '0' && line[j] <= '9') ++j;
+        return j;
+    };
+    for (size_t sep = 1; sep < len; ++sep) {
+        const char c = line[sep];
+        if (c == '\n') break;                    // '.' does not cross a newline
+        if (c != ':' && c != '\t') continue;
+        const size_t d1 = digits(sep + 1);
+        if (d1 == sep + 1 || d1 >= len) continue;
+        const char mid = line[d1];
+        if (mid != '-' && mid != '\t') continue;
+        const size_t d2 = digits(d1 + 1);
+        if (d2 == d1 + 1) continue;
+        chrom->assign(line, sep);
+        int64_t s = strtoll(std::string(line + sep + 1, d1 - sep - 1).c_str(), nullptr, 10);
+        const int64_t e = strtoll(std::string(line + d1 + 1, d2 - d1 - 1).c_str(), nullptr, 10);
+        if (mid == '-') --s;                     // chr:s-e is 1-based (:86-88)
+        *start = s < 0 ? 0 : s;                  // :93
+        *end = e;
+        return true;
+    }
+    return false;
+}
+
+int64_t step_for(int window_size)
+{
+    // depth/depth.go:48,:132
+    int64_t n = 10000000 / window_size;
+    if (n < 1) n = 1;
+    return n * window_size;
+}
+
+// ---- rows of one region (depth/depth.go:238-364 restated over integer results)
+struct RowWriter {
+    std::string hd, ca;     // buffered rows
+};
+
+void fmt_depth_row(std::string* out, const char* chrom, int64_t s, int64_t e, int64_t sum,
+                   const std::string& stats)
+{
+    char buf[96];
+    const int64_t l = e - s;
+    const double mean = (sum == 0 || l == 0) ? 0.0 : (double)sum / (double)l;   // :181-189
+    int n = snprintf(buf, sizeof buf, "\t%" PRId64 "\t%" PRId64 "\t%.4g", s, e, mean);
+    out->append(chrom);
+    out->append(buf, (size_t)n);
+    out->append(stats);
+    out->push_back('\n');
+}
+
+void fmt_callable_row(std::string* out, const char* chrom, int64_t s, int64_t e, int cls)
+{
+    char buf[64];
+    int n = snprintf(buf, sizeof buf, "\t%" PRId64 "\t%" PRId64 "\t", s, e);
+    out->append(chrom);
+    out->append(buf, (size_t)n);
+    out->append(kClassName[cls & 3]);
+    out->push_back('\n');
+}
+
+// sums[k] belongs to window first_win + k.  stats may be null.
+void format_region(RowWriter* w, const char* chrom, int64_t rs, int64_t re, int W,
+                   const int64_t* sums, size_t n_sums, const gd_run* runs, size_t n_runs,
+                   gdh::FastaStats* fa)
+{
+    if (re <= rs) return;
+    const int64_t first_win = rs / W;
+    auto sum_of = [&](int64_t iw) -> int64_t {
+        const int64_t k = iw - first_win;
+        return (k >= 0 && (size_t)k < n_sums) ? sums[k] : 0;
+    };
+    auto stats_of = [&](int64_t s, int64_t e) { return fa ? fa->stats_columns(chrom, s, e) : std::string(); };
+    // callable.bed: the run-length encoding is exactly what :307-328 and :343-350 emit
+    int64_t lastcov = -1;
+    for (size_t i = 0; i < n_runs; ++i) {
+        fmt_callable_row(&w->ca, chrom, runs[i].start, runs[i].end, runs[i].cls);
+        if (runs[i].cls != GD_NO_COVERAGE) lastcov = (int64_t)runs[i].end - 1;
+    }
+    // depth.bed
+    int64_t pos = 0;
+    if (lastcov >= 0) {
+        const int64_t this_window = lastcov / W;
+        for (int64_t iw = first_win; iw < this_window; ++iw) {            // :296-303
+            const int64_t s = std::max(rs, iw * W), e = std::min(re, (iw + 1) * W);
+            fmt_depth_row(&w->hd, chrom, s, e, sum_of(iw), stats_of(s, e));
+        }
+        const int64_t s = std::max(this_window * (int64_t)W, rs);         // :330-333 (quirk Q2)
+        const int64_t e = std::min(re, s + W);
+        fmt_depth_row(&w->hd, chrom, s, e, sum_of(this_window), stats_of(s, e));
+        pos = e;                                                          // :338
+    }
+    if (lastcov + 1 < re) {                                               // :343
+        for (int64_t ds = std::max(rs, pos) / W * W; ds < re && pos < re; ds += W) {   // :351
+            const int64_t de = std::min(re, ds + W), s = std::max(ds, rs);
+            fmt_depth_row(&w->hd, chrom, s, de, 0, stats_of(s, de));
+        }
+    }
+}
+
+bool flush_rows(RowWriter* w, FILE* fhd, FILE* fca)
+{
+    bool ok = true;
+    if (!w->hd.empty()) ok = fwrite(w->hd.data(), 1, w->hd.size(), fhd) == w->hd.size() && ok;
+    if (!w->ca.empty()) ok = fwrite(w->ca.data(), 1, w->ca.size(), fca) == w->ca.size() && ok;
+    w->hd.clear();
+    w->ca.clear();
+    return ok;
+}
+
+struct Region {
+    std::string chrom;
+    int64_t start, end;
+    int tid;
+};
+
+struct FaiEntry {
+    std::string name;
+    int64_t length;
+};
+
+bool read_fai(const std::string& path, std::vector<FaiEntry>* out)
+{
+    FILE* f = fopen(path.c_str(), "r");
+    if (!f) return false;
+    char* line = nullptr;
+    size_t cap = 0;
+    ssize_t n;
+    while ((n = getline(&line, &cap, f)) > 0) {
+        std::string s(line, (size_t)n);
+        const size_t t1 = s.find('\t');
+        if (t1 == std::string::npos) continue;
+        FaiEntry e;
+        e.name = s.substr(0, t1);
+        e.length = strtoll(s.c_str() + t1 + 1, nullptr, 10);
+        out->push_back(e);
+    }
+    free(line);
+    fclose(f);
+    return true;
+}
+
+#define GDCHK(call)                                                                    \
+    do {                                                                               \
+        int rc_ = (call);                                                              \
+        if (rc_ != GD_OK) {                                                            \
+            fprintf(stderr, "goleft depth: %s failed: %s (%s)\n", #call, gd_strerror(rc_), \
+                    ctx ? gd_last_error(ctx) : "");                                    \
+            if (ctx) gd_destroy(ctx);                                                  \
+            return 1;                                                                  \
+        }                                                                              \
+    } while (0)
+
+int run(const DArgs& args)
+{
+    int exit_code = 0;
+    gd_ctx* ctx = nullptr;
+    std::string err;
+    gdh::BamReader bam;
+    if (!bam.open(args.bam, args.processes, &err)) {
+        fprintf(stderr, "goleft depth: %s\n", err.c_str());
+        return 1;
+    }
+    const auto& contigs = bam.contigs();
+    std::map<std::string, int> tid_of;
+    for (size_t i = 0; i < contigs.size(); ++i) tid_of.emplace(contigs[i].name, (int)i);
+
+    // ---- regions: --bed rows (:103-120) or .fai tiles (:122-159) ------------
+    const int W = args.window_size;
+    const int64_t step = step_for(W);
+    std::vector<Region> regions;
+    if (!args.bed.empty()) {
+        FILE* f = fopen(args.bed.c_str(), "r");
+        if (!f) { fprintf(stderr, "goleft depth: open %s: %s\n", args.bed.c_str(), strerror(errno)); return 1; }
+        char* line = nullptr;
+        size_t cap = 0;
+        ssize_t n;
+        while ((n = getline(&line, &cap, f)) > 0) {
+            Region r;
+            if (!chrom_start_end(line, (size_t)n, &r.chrom, &r.start, &r.end)) {
+                fprintf(stderr, "couldn't get region from line%s", line);      // :78 log.Fatal
+                free(line);
+                fclose(f);
+                return 1;
+            }
+            auto it = tid_of.find(r.chrom);
+            r.tid = it == tid_of.end() ? -1 : it->second;
+            regions.push_back(r);
+        }
+        free(line);
+        fclose(f);
+    } else {
+        std::vector<FaiEntry> fai;
+        if (!read_fai(args.reference + ".fai", &fai)) {
+            fprintf(stderr, "goleft depth: open %s.fai: %s\n", args.reference.c_str(), strerror(errno));
+            return 1;                                                           // pcheck -> log.Fatal
+        }
+        for (const FaiEntry& e : fai) {
+            if (!args.chrom.empty() && e.name != args.chrom) continue;          // :145
+            auto it = tid_of.find(e.name);
+            const int tid = it == tid_of.end() ? -1 : it->second;
+            for (int64_t i = 0; i < e.length; i += step)                        // :150-154
+                regions.push_back(Region{e.name, i, std::min(i + step, e.length), tid});
+        }
+    }
+    std::vector<int32_t> wanted;
+    for (const Region& r : regions)
+        if (r.tid >= 0) wanted.push_back(r.tid);
+    std::sort(wanted.begin(), wanted.end());
+    wanted.erase(std::unique(wanted.begin(), wanted.end()), wanted.end());
+
+    // ---- outputs (:382-388) ---------------------------------------------------
+    const std::string suffix = args.chrom.empty() ? "" : "." + args.chrom;
+    const std::string ca_path = args.prefix + suffix + ".callable.bed";
+    const std::string hd_path = args.prefix + suffix + ".depth.bed";
+    FILE* fca = fopen(ca_path.c_str(), "w");
+    FILE* fhd = fca ? fopen(hd_path.c_str(), "w") : nullptr;
+    if (!fca || !fhd) {
+        fprintf(stderr, "goleft depth: cannot create %s\n", fca ? hd_path.c_str() : ca_path.c_str());
+        if (fca) fclose(fca);
+        return 1;
+    }
+    auto close_all = [&]() { fclose(fca); fclose(fhd); };
+
+    gdh::FastaStats fasta;
+    gdh::FastaStats* fa = nullptr;
+    if (args.stats) {                                                           // :244-252
+        if (!fasta.open(args.reference, &err)) {
+            fprintf(stderr, "goleft depth: %s\n", err.c_str());
+            close_all();
+            return 1;
+        }
+        fa = &fasta;
+    }
+
+    // ---- device engine ----------------------------------------------------------
+    int device = 0;
+    if (const char* e = getenv("GOLEFT_DEVICE")) device = atoi(e);
+    {
+        int rc = gd_create(device, &ctx);
+        if (rc != GD_OK) {
+            fprintf(stderr, "goleft depth: no usable MI355X device (%s); this build has no CPU path\n", gd_strerror(rc));
+            close_all();
+            return 1;
+        }
+    }
+    gd_params P;
+    gd_default_params(&P);
+    P.window_size = W;
+    P.min_mapq = args.q;
+    P.min_cov = args.min_cov;
+    P.max_mean_depth = args.max_mean_depth;
+    P.step = args.bed.empty() ? step : 0;
+    GDCHK(gd_set_params(ctx, &P));
+    std::vector<int64_t> lens(contigs.size());
+    for (size_t i = 0; i < contigs.size(); ++i) lens[i] = contigs[i].length;
+    GDCHK(gd_set_contigs(ctx, (int)lens.size(), lens.data()));
+    if (!contigs.empty()) GDCHK(gd_select_contigs(ctx, (int)wanted.size(), wanted.data()));
+
+    // ---- stream decoded records into HBM (replaces the samtools children) -------
+    if (!wanted.empty()) {
+        if (wanted.size() == 1) bam.seek_contig(wanted[0], &err);   // .bai shortcut for --chrom
+        std::vector<char> want(contigs.size(), 0);
+        for (int32_t t : wanted) want[(size_t)t] = 1;
+        const int32_t last_wanted = wanted.back();
+        gdh::RecordBlock blk;
+        for (;;) {
+            const int rc = bam.next_block(blk, 1u << 21, &err);
+            if (rc < 0) {
+                fprintf(stderr, "goleft depth: %s\n", err.c_str());
+                gd_destroy(ctx);
+                close_all();
+                return 1;
+            }
+            if (rc == 0) break;
+            if (blk.tid > last_wanted) break;                       // coordinate sorted: done
+            if (blk.tid >= (int32_t)contigs.size() || !want[(size_t)blk.tid]) continue;
+            gd_batch b;
+            GDCHK(gd_acquire(ctx, blk.size(), blk.cigar.size(), &b));
+            memcpy(b.pos, blk.pos.data(), blk.size() * sizeof(int32_t));
+            memcpy(b.flag, blk.flag.data(), blk.size() * sizeof(uint16_t));
+            memcpy(b.mapq, blk.mapq.data(), blk.size() * sizeof(uint8_t));
+            memcpy(b.cigar_off, blk.cigar_off.data(), (blk.size() + 1) * sizeof(uint32_t));
+            if (!blk.cigar.empty()) memcpy(b.cigar, blk.cigar.data(), blk.cigar.size() * sizeof(uint32_t));
+            GDCHK(gd_commit(ctx, &b, blk.tid, blk.size(), blk.cigar.size()));
+        }
+        GDCHK(gd_compute(ctx));
+    }
+
+    // ---- rows, in input order (what --ordered gives; Q4) -------------------------
+    RowWriter rows;
+    std::vector<int64_t> sums;
+    std::vector<gd_run> runs;
+    int cached_tid = -1;            // whole-contig results of the current contig
+    std::vector<int64_t> csums;
+    std::vector<gd_run> cruns;
+    size_t run_cursor = 0;
+    bool io_ok = true;
+    for (const Region& r : regions) {
+        if (r.tid < 0) {
+            // samtools would fail on an unknown reference name: the callback then sees an
+            // empty stream (all-zero rows) and the exit code becomes non-zero (:395-399)
+            fprintf(stderr, "ERROR with command: region %s:%" PRId64 "-%" PRId64 " not in the BAM header\n",
+                    r.chrom.c_str(), r.start + 1, r.end);
+            exit_code = std::max(exit_code, 1);
+            gd_run nr{(int32_t)r.start, (int32_t)r.end, GD_NO_COVERAGE};
+            format_region(&rows, r.chrom.c_str(), r.start, r.end, W, nullptr, 0, &nr, r.end > r.start ? 1 : 0, fa);
+        } else {
+            const int64_t clen = contigs[(size_t)r.tid].length;
+            // fused device results are W/step aligned over the BAM contig length; a tile cut
+            // short by a disagreeing .fai length goes through the region reductions instead
+            const bool fused = args.bed.empty() && r.start % step == 0 &&
+                               (r.end == clen || (r.end < clen && r.end % step == 0));
+            if (fused) {
+                if (cached_tid != r.tid) {
+                    size_t n = 0;
+                    csums.resize((size_t)((clen + W - 1) / W));
+                    GDCHK(gd_windows(ctx, r.tid, csums.data(), nullptr, csums.size(), &n));
+                    int rc = gd_callable(ctx, r.tid, nullptr, 0, &n);
+                    if (rc != GD_OK && rc != GD_E_CAPACITY) GDCHK(rc);
+                    cruns.resize(n);
+                    if (n) GDCHK(gd_callable(ctx, r.tid, cruns.data(), cruns.size(), &n));
+                    cached_tid = r.tid;
+                    run_cursor = 0;
+                }
+                // runs are split at multiples of step, so each belongs to exactly one tile
+                while (run_cursor < cruns.size() && cruns[run_cursor].start < r.start) ++run_cursor;
+                size_t e = run_cursor;
+                while (e < cruns.size() && cruns[e].start < r.end) ++e;
+                const size_t w0 = (size_t)(r.start / W), w1 = (size_t)((r.end + W - 1) / W);
+                format_region(&rows, r.chrom.c_str(), r.start, r.end, W, csums.data() + w0, w1 - w0,
+                              cruns.data() + run_cursor, e - run_cursor, fa);
+                run_cursor = e;
+            } else if (r.end > r.start) {
+                size_t n = 0;
+                const size_t nw = (size_t)((r.end - 1) / W - r.start / W + 1);
+                sums.resize(nw);
+                GDCHK(gd_region_windows(ctx, r.tid, r.start, r.end, sums.data(), nullptr, nw, &n));
+                int rc = gd_region_callable(ctx, r.tid, r.start, r.end, nullptr, 0, &n);
+                if (rc != GD_OK && rc != GD_E_CAPACITY) GDCHK(rc);
+                runs.resize(n);
+                if (n) GDCHK(gd_region_callable(ctx, r.tid, r.start, r.end, runs.data(), runs.size(), &n));
+                format_region(&rows, r.chrom.c_str(), r.start, r.end, W, sums.data(), nw, runs.data(), n, fa);
+            }
+        }
+        if (rows.hd.size() + rows.ca.size() > (8u << 20)) io_ok = flush_rows(&rows, fhd, fca) && io_ok;
+    }
+    io_ok = flush_rows(&rows, fhd, fca) && io_ok;
+    gd_destroy(ctx);
+    ctx = nullptr;
+    if (fclose(fca) != 0) io_ok = false;
+    if (fclose(fhd) != 0) io_ok = false;
+    if (!io_ok) { fprintf(stderr, "goleft depth: write error\n"); return 1; }
+    return exit_code;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------
+extern "C" {
+
+int gdh_depth_main(int argc, const char* const* argv)
+{
+    DArgs args;                       // defaults: depth/depth.go:164-167
+    const int rc = parse_args(argc, argv, &args);
+    if (rc > 0) return 0;
+    if (rc < 0) return 255;           // go-arg p.Fail -> os.Exit(-1)
+    return run(args);
+}
+
+int gdh_chrom_start_end(const char* line, size_t len, char* chrom, size_t cap, int64_t* start, int64_t* end)
+{
+    std::string c;
+    int64_t s = 0, e = 0;
+    if (!line || !chrom || !start || !end) return -1;
+    if (!chrom_start_end(line, len, &c, &s, &e)) return -1;
+    if (c.size() + 1 > cap) return -1;
+    memcpy(chrom, c.c_str(), c.size() + 1);
+    *start = s;
+    *end = e;
+    return 0;
+}
+
+int64_t gdh_step(int32_t window_size) { return window_size > 0 ? step_for(window_size) : 0; }
+
+int gdh_format_region(const char* chrom, int64_t rs, int64_t re, int32_t W, const int64_t* sums,
+                      size_t n_sums, const gd_run* runs, size_t n_runs, const char* depth_path,
+                      const char* callable_path)
+{
+    if (!chrom || W < 1 || !depth_path || !callable_path) return -1;
+    RowWriter w;
+    format_region(&w, chrom, rs, re, W, sums, n_sums, runs, n_runs, nullptr);
+    FILE* fhd = fopen(depth_path, "a");
+    if (!fhd) return -1;
+    FILE* fca = fopen(callable_path, "a");
+    if (!fca) { fclose(fhd); return -1; }
+    const bool ok = flush_rows(&w, fhd, fca);
+    const int c1 = fclose(fhd), c2 = fclose(fca);
+    return ok && c1 == 0 && c2 == 0 ? 0 : -1;
+}
+
+}  // extern "C"

@@ -1,0 +1,143 @@
+// host_api.cpp -- C ABI wrappers: BAM decode and depth/intervals.go.
+#include "../../../include/goleft_depth_host.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "bam_reader.hpp"
+
+struct gdh_bam {
+    gdh::BamReader rd;
+    gdh::RecordBlock blk;
+    std::string err;
+};
+
+// depth/intervals.go: per-chromosome interval sets.  The reference keeps a
+// biogo interval tree per chromosome (intervals.go:42-79) and only ever asks
+// "does anything overlap [s,e)?" (Overlaps, :25-39), so a start-sorted array
+// with a running maximum of the ends answers the same query in O(log n).
+struct gdh_intervals {
+    struct Set {
+        std::vector<std::pair<int64_t, int64_t>> iv;   // (start, end), sorted by start
+        std::vector<int64_t> max_end;                  // prefix maximum of end
+    };
+    std::map<std::string, Set> by_chrom;
+};
+
+extern "C" {
+
+int gdh_bam_open(const char* path, int threads, gdh_bam** out)
+{
+    if (!path || !out) return -1;
+    gdh_bam* b = new (std::nothrow) gdh_bam();
+    if (!b) return -1;
+    *out = b;                                   // returned even on failure so the error can be read
+    return b->rd.open(path, threads, &b->err) ? 0 : -1;
+}
+
+void gdh_bam_close(gdh_bam* b) { delete b; }
+const char* gdh_bam_error(const gdh_bam* b) { return b ? b->err.c_str() : "null"; }
+int gdh_bam_n_contigs(const gdh_bam* b) { return b ? (int)b->rd.contigs().size() : 0; }
+
+const char* gdh_bam_contig_name(const gdh_bam* b, int tid)
+{
+    if (!b || tid < 0 || (size_t)tid >= b->rd.contigs().size()) return nullptr;
+    return b->rd.contigs()[(size_t)tid].name.c_str();
+}
+
+int64_t gdh_bam_contig_length(const gdh_bam* b, int tid)
+{
+    if (!b || tid < 0 || (size_t)tid >= b->rd.contigs().size()) return -1;
+    return b->rd.contigs()[(size_t)tid].length;
+}
+
+int gdh_bam_seek_contig(gdh_bam* b, int tid)
+{
+    if (!b) return -1;
+    return b->rd.seek_contig(tid, &b->err) ? 1 : 0;
+}
+
+int gdh_bam_next(gdh_bam* b, size_t max_reads, int32_t* tid, size_t* n_reads, size_t* n_ops,
+                 const int32_t** pos, const uint16_t** flag, const uint8_t** mapq,
+                 const uint32_t** cigar_off, const uint32_t** cigar)
+{
+    if (!b || !tid || !n_reads || !n_ops) return -1;
+    const int rc = b->rd.next_block(b->blk, max_reads ? max_reads : 1, &b->err);
+    if (rc <= 0) { *n_reads = 0; *n_ops = 0; return rc; }
+    *tid = b->blk.tid;
+    *n_reads = b->blk.size();
+    *n_ops = b->blk.cigar.size();
+    if (pos) *pos = b->blk.pos.data();
+    if (flag) *flag = b->blk.flag.data();
+    if (mapq) *mapq = b->blk.mapq.data();
+    if (cigar_off) *cigar_off = b->blk.cigar_off.data();
+    if (cigar) *cigar = b->blk.cigar.data();
+    return 1;
+}
+
+uint64_t gdh_bam_n_records(const gdh_bam* b) { return b ? b->rd.n_records() : 0; }
+
+int gdh_intervals_read(const char* const* paths, int n_paths, gdh_intervals** out)
+{
+    if (!out || n_paths < 0) return -1;
+    gdh_intervals* t = new (std::nothrow) gdh_intervals();
+    if (!t) return -1;
+    for (int i = 0; i < n_paths; ++i) {
+        if (!paths[i] || !paths[i][0]) continue;                 // intervals.go:46-48
+        FILE* f = fopen(paths[i], "r");
+        if (!f) { delete t; return -1; }                         // the reference panics
+        char* line = nullptr;
+        size_t cap = 0;
+        ssize_t n;
+        while ((n = getline(&line, &cap, f)) > 0) {
+            char chrom[4096];
+            int64_t s, e;
+            if (gdh_chrom_start_end(line, (size_t)n, chrom, sizeof chrom, &s, &e) != 0) {
+                free(line); fclose(f); delete t;
+                return -1;                                       // log.Fatal in the reference
+            }
+            if (s >= e) continue;                                // intervals.go:66
+            t->by_chrom[chrom].iv.emplace_back(s, e);
+        }
+        free(line);
+        fclose(f);
+    }
+    for (auto& kv : t->by_chrom) {
+        auto& set = kv.second;
+        std::sort(set.iv.begin(), set.iv.end());
+        set.max_end.resize(set.iv.size());
+        int64_t m = INT64_MIN;
+        for (size_t i = 0; i < set.iv.size(); ++i) { m = std::max(m, set.iv[i].second); set.max_end[i] = m; }
+    }
+    *out = t;
+    return 0;
+}
+
+void gdh_intervals_free(gdh_intervals* t) { delete t; }
+
+int gdh_intervals_overlaps(const gdh_intervals* t, const char* chrom, int64_t start, int64_t end)
+{
+    if (!t || !chrom) return 0;                                  // nil tree -> false (intervals.go:26-28)
+    auto it = t->by_chrom.find(chrom);
+    if (it == t->by_chrom.end()) return 0;
+    const auto& set = it->second;
+    // half-open: i.End > q.Start && i.Start < q.End (intervals.go:16-19)
+    const size_t k = (size_t)(std::lower_bound(set.iv.begin(), set.iv.end(), std::make_pair(end, INT64_MIN)) - set.iv.begin());
+    if (k == 0) return 0;
+    return set.max_end[k - 1] > start ? 1 : 0;
+}
+
+size_t gdh_intervals_count(const gdh_intervals* t, const char* chrom)
+{
+    if (!t || !chrom) return 0;
+    auto it = t->by_chrom.find(chrom);
+    return it == t->by_chrom.end() ? 0 : it->second.iv.size();
+}
+
+}  // extern "C"

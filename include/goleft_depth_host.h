@@ -1,0 +1,78 @@
+/*
+ * goleft_depth_host.h -- C ABI of the host side of `goleft depth` (C++ twin of
+ * the reference's Go front end, /root/reference/depth/depth.go and
+ * depth/intervals.go).  The Go toolchain is absent from the build image, so
+ * the host that keeps the reference's CLI flags, tiling and BED formatting is
+ * written in C++ above the device ABI (goleft_depth.h); these entry points
+ * exist so that tests (ctypes) and other hosts can drive it piecewise.
+ */
+#ifndef GOLEFT_DEPTH_HOST_H
+#define GOLEFT_DEPTH_HOST_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "goleft_depth.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* `goleft depth` with the reference's flags (depth/depth.go:27-41):
+ *   --windowsize/-w --maxmeandepth/-m --ordered/-o --q/-Q --chrom/-c --mincov
+ *   --stats/-s --reference/-r --processes/-p --bed/-b --prefix  BAM
+ * argv[0] is the program name.  Returns the process exit code
+ * (depth/depth.go:174, :398).  Needs an MI355X: there is no CPU path. */
+int gdh_depth_main(int argc, const char* const* argv);
+
+/* depth/depth.go:73-94 chromStartEndFromLine: `chr:s-e` (1-based inclusive) or
+ * `chr\ts\te` (BED) -> chrom, 0-based start, end.  Returns 0, or -1 when the
+ * line does not match (the reference calls log.Fatal there). */
+int gdh_chrom_start_end(const char* line, size_t len, char* chrom, size_t cap,
+                        int64_t* start, int64_t* end);
+
+/* depth/depth.go:48,:132: tile step for a window size. */
+int64_t gdh_step(int32_t window_size);
+
+/* Rows of one region, formatted exactly like the reference's callback
+ * (depth/depth.go:238-364) from integer results:
+ *   sums[k]  sum of depth over the W-anchored window first_window+k clipped to
+ *            [region_start, region_end)  (n_sums = windows touching the region)
+ *   runs     coverage-class runs covering [region_start, region_end) exactly
+ * Appends to the two files.  Returns 0 or -1 (I/O). */
+int gdh_format_region(const char* chrom, int64_t region_start, int64_t region_end,
+                      int32_t window_size, const int64_t* sums, size_t n_sums,
+                      const gd_run* runs, size_t n_runs,
+                      const char* depth_path, const char* callable_path);
+
+/* ---- BAM decode (replaces the read side of the samtools child) ---------- */
+typedef struct gdh_bam gdh_bam;
+int  gdh_bam_open(const char* path, int threads, gdh_bam** out);
+void gdh_bam_close(gdh_bam* b);
+const char* gdh_bam_error(const gdh_bam* b);
+int  gdh_bam_n_contigs(const gdh_bam* b);
+const char* gdh_bam_contig_name(const gdh_bam* b, int tid);
+int64_t gdh_bam_contig_length(const gdh_bam* b, int tid);
+/* Position at the first record of contig tid through the .bai; 1 = positioned,
+ * 0 = no index / no records (stream untouched). */
+int  gdh_bam_seek_contig(gdh_bam* b, int tid);
+/* Decode the next block (<= max_reads records of one contig).  Returns 1, 0 at
+ * EOF, -1 on error.  The arrays stay valid until the next call. */
+int  gdh_bam_next(gdh_bam* b, size_t max_reads, int32_t* tid, size_t* n_reads, size_t* n_ops,
+                  const int32_t** pos, const uint16_t** flag, const uint8_t** mapq,
+                  const uint32_t** cigar_off, const uint32_t** cigar);
+uint64_t gdh_bam_n_records(const gdh_bam* b);
+
+/* ---- depth/intervals.go: ReadTree / Overlaps ---------------------------- */
+typedef struct gdh_intervals gdh_intervals;
+/* ReadTree(paths...): BED rows with start >= end are skipped (intervals.go:66). */
+int  gdh_intervals_read(const char* const* paths, int n_paths, gdh_intervals** out);
+void gdh_intervals_free(gdh_intervals* t);
+/* Overlaps(tree[chrom], start, end): half-open overlap test (intervals.go:16-19). */
+int  gdh_intervals_overlaps(const gdh_intervals* t, const char* chrom, int64_t start, int64_t end);
+size_t gdh_intervals_count(const gdh_intervals* t, const char* chrom);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,217 @@
+"""CPU: the C++ host side (libgoleft_host.so) -- region parsing, BED rows from
+integer results, BAM decode, intervals -- and that both C-ABI libraries load
+and export every symbol their headers declare.  No compute calls (no GPU)."""
+import os
+import re
+import tempfile
+
+import numpy as np
+import pytest
+from hypothesis import given, settings, strategies as st
+
+from oracle import bamio, pyoracle as po
+from tests import helpers as H
+
+ROOT = H.ROOT
+REF_TEST = "/root/reference/depth/test"
+
+
+@pytest.fixture(scope="module")
+def hostlib():
+    from goleft_amd import _hostlib
+    _hostlib.load()
+    return _hostlib
+
+
+def _declared(header, prefix):
+    txt = open(os.path.join(ROOT, "include", header)).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(%s\w+)\s*\(" % prefix, txt)))
+
+
+def test_device_abi_exports_every_declared_symbol():
+    from goleft_amd import _lib
+    lib = _lib.load()
+    names = _declared("goleft_depth.h", "gd_")
+    assert len(names) >= 28
+    assert sorted(_lib.SYMBOLS) == names
+    for n in names:
+        assert getattr(lib, n) is not None
+    assert lib.gd_abi_version() == 1
+    assert lib.gd_strerror(-7) == b"records not coordinate sorted"
+
+
+def test_host_abi_exports_every_declared_symbol(hostlib):
+    lib = hostlib.load()
+    names = _declared("goleft_depth_host.h", "gdh_")
+    assert sorted(hostlib.SYMBOLS) == names
+    for n in names:
+        assert getattr(lib, n) is not None
+
+
+def test_engine_fails_loudly_without_device():
+    import ctypes as C
+    from goleft_amd import _lib
+    lib = _lib.load()
+    n = C.c_int(-1)
+    lib.gd_device_count(C.byref(n))
+    if n.value > 0:
+        pytest.skip("a GPU is present")
+    ctx = C.c_void_p()
+    assert lib.gd_create(0, C.byref(ctx)) == -6   # GD_E_NODEVICE, never a CPU fallback
+    from goleft_amd.engine import DepthEngine, GdError
+    with pytest.raises(GdError):
+        DepthEngine(0)
+
+
+@pytest.mark.parametrize("line", [
+    b"chr22\t14250\t15500\n", b"chrM:1-16571\n", b"HLA-A*01:01:01:01:1-16571\n", b"chr1:0-5",
+    b"a\t3\t9\tname\t0\t+\n", b"x:y:12-40\n", b"c\t7-9\n", b"chrUn_gl000220\t0\t161802\n"])
+def test_region_parse_matches_oracle(hostlib, line):
+    assert hostlib.chrom_start_end(line) == po.chrom_start_end_c(line)
+
+
+def test_region_parse_failure(hostlib):
+    with pytest.raises(ValueError):
+        hostlib.chrom_start_end(b"nothing to see\n")
+
+
+@pytest.mark.parametrize("W", [1, 13, 250, 1000, 9999999, 10000000, 10000001, 1000000000])
+def test_step(hostlib, W):
+    assert hostlib.load().gdh_step(W) == po.step_for(W)
+
+
+def _rows_from_host(hostlib, chrom, start, depth, W, mincov, maxmean):
+    end = start + len(depth)
+    sums, _ = H.oracle_windows(depth, W, start)
+    runs = H.oracle_runs(depth, mincov, maxmean, 1 << 62, start)
+    with tempfile.TemporaryDirectory() as td:
+        hd, ca = os.path.join(td, "d"), os.path.join(td, "c")
+        open(hd, "w").close()
+        open(ca, "w").close()
+        hostlib.format_region(chrom, start, end, W, sums, runs, hd, ca)
+        return open(hd).read(), open(ca).read()
+
+
+def _rows_from_oracle(chrom, start, depth, W, mincov, maxmean):
+    with tempfile.TemporaryDirectory() as td:
+        hd, ca = os.path.join(td, "d"), os.path.join(td, "c")
+        po.callback_c(chrom, start, start + len(depth), depth, W, mincov, maxmean, hd, ca)
+        return open(hd).read(), open(ca).read()
+
+
+@settings(max_examples=150, deadline=None)
+@given(st.integers(0, 2 ** 31), st.integers(1, 500), st.integers(1, 80), st.integers(0, 400),
+       st.integers(1, 8), st.sampled_from([0, 5, 30]))
+def test_format_region_equals_reference_callback(hostlib, seed, length, W, start, mincov, maxmean):
+    """BED rows rebuilt from (window sums, class runs) == the line-by-line callback."""
+    rng = np.random.default_rng(seed)
+    depth = rng.integers(0, 40, size=length).astype(np.int32)
+    depth[rng.random(length) < rng.random()] = 0
+    if rng.random() < 0.3:
+        depth[int(rng.integers(0, length)):] = 0     # coverage ends early (quirk Q2 territory)
+    if rng.random() < 0.15:
+        depth[:] = 0
+    assert _rows_from_host(hostlib, "chrQ", start, depth, W, mincov, maxmean) == \
+        _rows_from_oracle("chrQ", start, depth, W, mincov, maxmean)
+
+
+def test_format_region_big_values(hostlib):
+    depth = np.full(3000, 123456, np.int32)
+    depth[1000:1100] = 0
+    for W in (7, 1000, 4000):
+        assert _rows_from_host(hostlib, "c", 0, depth, W, 4, 0) == _rows_from_oracle("c", 0, depth, W, 4, 0)
+
+
+def test_format_region_fixture_regions(hostlib):
+    """All --bed rows of depth/test/windows.bed on the t.bam stream (golden per-base)."""
+    contigs, reads, z = H.load_golden_bam("t")
+    beds = H.golden_beds()["t"]
+    names = [c[0] for c in contigs]
+    for W in (10, 50, 55, 60, 71, 13, 2002, 1000000):
+        hd_all, ca_all = "", ""
+        for chrom, s, e in beds["regions"]:
+            pb = z["perbase_Q1_%d" % names.index(chrom)]
+            d = np.zeros(e - s, np.int32)
+            hi = min(e, len(pb))
+            d[:max(0, hi - s)] = pb[s:hi]
+            hd, ca = _rows_from_host(hostlib, chrom, s, d, W, 4, 0)
+            hd_all += hd
+            ca_all += ca
+        assert hd_all == beds["bed_w%d" % W]["depth"]
+        assert ca_all == beds["bed_w%d" % W]["callable"]
+
+
+def _same_streams(got, want_reads):
+    assert set(got) == set(want_reads)
+    for tid, r in want_reads.items():
+        g = got[tid]
+        assert np.array_equal(g[0], r.pos) and np.array_equal(g[1], r.flag)
+        assert np.array_equal(g[2], r.mapq) and np.array_equal(g[3], r.cigar_off)
+        assert np.array_equal(g[4], r.cigar)
+
+
+@pytest.mark.parametrize("name", ["t", "hla", "t_empty"])
+@pytest.mark.parametrize("threads", [1, 4])
+def test_bam_reader_roundtrip(hostlib, name, threads, tmp_path):
+    contigs, reads, z = H.load_golden_bam(name)
+    path = str(tmp_path / "x.bam")
+    bamio.write_bam(path, contigs, reads, unplaced=7)
+    c2, got, n = hostlib.read_bam(path, threads=threads, max_reads=5000)
+    assert c2 == contigs
+    assert n == sum(r.n for r in reads.values()) + 7
+    _same_streams(got, reads)
+
+
+def test_bam_reader_long_cigar_cg_tag(hostlib, tmp_path):
+    rng = np.random.default_rng(5)
+    n_ops = 70000                       # > 65535: stored through the CG:B,I convention
+    ops = rng.choice([0, 1, 2], size=n_ops, p=[0.6, 0.2, 0.2]).astype(np.uint32)
+    lens = rng.integers(1, 30, size=n_ops).astype(np.uint32)
+    cig = (lens << 4) | ops
+    short = np.asarray([(50 << 4) | 0], np.uint32)
+    reads = {0: po.Reads([10, 20], [0, 16], [60, 60], [0, n_ops, n_ops + 1], np.concatenate([cig, short]))}
+    contigs = [("long", 5_000_000)]
+    path = str(tmp_path / "l.bam")
+    bamio.write_bam(path, contigs, reads)
+    _, py_reads, _ = bamio.read_bam(path)[1:]
+    _, got, n = hostlib.read_bam(path, threads=2)
+    assert n == 2
+    _same_streams(got, reads)
+    assert np.array_equal(py_reads[0].cigar, reads[0].cigar)
+
+
+def test_bam_reader_rejects_garbage(hostlib, tmp_path):
+    p = tmp_path / "bad.bam"
+    p.write_bytes(b"this is not a bam file at all" * 10)
+    with pytest.raises(OSError):
+        hostlib.read_bam(str(p))
+    with pytest.raises(OSError):
+        hostlib.read_bam(str(tmp_path / "missing.bam"))
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_TEST), reason="reference fixtures only exist in the build container")
+@pytest.mark.parametrize("name,key", [("t", "t"), ("hla", "hla"), ("t-empty", "t_empty")])
+def test_bam_reader_on_reference_fixtures(hostlib, name, key):
+    contigs, reads, z = H.load_golden_bam(key)
+    c2, got, n = hostlib.read_bam(os.path.join(REF_TEST, name + ".bam"), threads=3)
+    assert c2 == contigs and n == int(z["n_records_total"])
+    _same_streams(got, reads)
+    if name == "t":   # .bai seek: chr22 only
+        _, got22, _ = hostlib.read_bam(os.path.join(REF_TEST, "t.bam"), seek_tid=1)
+        assert 0 not in got22 and np.array_equal(got22[1][0], reads[1].pos)
+
+
+def test_intervals_readtree_overlaps(hostlib, tmp_path):
+    bed = tmp_path / "a.bed"
+    bed.write_text("chr1\t10\t20\nchr1\t15\t40\nchr1\t100\t100\nchr2:5-9\nchr1\t200\t300\n")
+    t = hostlib.Intervals(str(bed), "")
+    assert t.count("chr1") == 3 and t.count("chr2") == 1      # start>=end rows skipped (intervals.go:66)
+    rng = np.random.default_rng(0)
+    ivs = {"chr1": [(10, 20), (15, 40), (200, 300)], "chr2": [(4, 9)], "chr3": []}
+    for _ in range(2000):
+        c = str(rng.choice(["chr1", "chr2", "chr3"]))
+        s = int(rng.integers(0, 320))
+        e = s + int(rng.integers(0, 50))
+        want = any(ie > s and is_ < e for is_, ie in ivs[c])   # intervals.go:16-19
+        assert t.overlaps(c, s, e) == want
