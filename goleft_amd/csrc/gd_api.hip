@@ -22,6 +22,7 @@ namespace {
 constexpr int kRingSlots = 3;
 constexpr int kDefaultLookback = 512;
 constexpr uint64_t kMaxReadsPerContig = 1ull << 30;
+constexpr int kMaxSpan = 1 << 27;   // tile-relative byte offsets of the tile kernel stay in 32 bits
 
 struct ContigHost {
     int64_t length = 0;
@@ -65,7 +66,10 @@ struct gd_ctx {
 
     int tile_T = 4096;
     int tile_NT = 256;
-    int ablate = 0;                     // debug: GOLEFT_GD_ABLATE
+    int ablate = 0;                     // debug: GOLEFT_GD_ABLATE (v5 kernel only)
+    int kernel_gen = 6;                 // debug: GOLEFT_GD_KERNEL=v5 selects the previous tile kernel
+    int tile_opt = 0;                   // GOLEFT_GD_OPT bit 0: non-temporal per-base stores
+    bool lookback_pinned = false;       // max_span_hint given: never shrink below it
     int lookback = kDefaultLookback;
 
     // device job state
@@ -185,7 +189,16 @@ void launch_prep(gd_ctx* c, const gd::Job& job)
 template <int T, int NT>
 void launch_tile(gd_ctx* c, const gd::Job& job)
 {
-    hipLaunchKernelGGL((gd::gd_tile_kernel<T, NT>), dim3(job.n_tiles), dim3(NT), 0, c->stream, job);
+    if (c->kernel_gen == 5) {
+        hipLaunchKernelGGL((gd::v5::gd_tile_kernel<T, NT>), dim3(job.n_tiles), dim3(NT), 0, c->stream, job);
+        return;
+    }
+    // 8 XCDs: the grid is 8 equal slices of the tile list (see the kernel)
+    const unsigned grid = (unsigned)(((job.n_tiles + 7) / 8) * 8);
+    if (c->tile_opt & 1)
+        hipLaunchKernelGGL((gd::gd_tile_kernel<T, NT, 1>), dim3(grid), dim3(NT), 0, c->stream, job);
+    else
+        hipLaunchKernelGGL((gd::gd_tile_kernel<T, NT, 0>), dim3(grid), dim3(NT), 0, c->stream, job);
 }
 
 }  // namespace
@@ -247,12 +260,14 @@ int gd_create(int device_id, gd_ctx** out)
     gd_default_params(&c->params);
     if (const char* e = getenv("GOLEFT_GD_TILE")) {
         int t = atoi(e);
-        if (t == 4096 || t == 8192 || t == 16384) c->tile_T = t;
+        if (t == 4096 || t == 8192) c->tile_T = t;
     }
     if (const char* e = getenv("GOLEFT_GD_ABLATE")) c->ablate = atoi(e);
+    if (const char* e = getenv("GOLEFT_GD_KERNEL")) c->kernel_gen = (e[0] == 'v' && e[1] == '5') ? 5 : 6;
+    if (const char* e = getenv("GOLEFT_GD_OPT")) c->tile_opt = atoi(e) & 1;
     if (const char* e = getenv("GOLEFT_GD_THREADS")) {
         int t = atoi(e);
-        if (t == 256 || t == 512 || t == 1024) c->tile_NT = t;
+        if (t == 256 || t == 512) c->tile_NT = t;
     }
     auto bail = [&](hipError_t e) {
         (void)e;
@@ -330,7 +345,8 @@ int gd_set_params(gd_ctx* c, const gd_params* p)
     if (p->step > 0 && p->step % p->window_size != 0)
         return fail(c, GD_E_INVALID, "step must be a multiple of window_size");
     c->params = *p;
-    if (p->max_span_hint > 0) c->lookback = p->max_span_hint;
+    if (p->max_span_hint > 0) { c->lookback = p->max_span_hint; c->lookback_pinned = true; }
+    else c->lookback_pinned = false;
     c->computed = false;
     return GD_OK;
 }
@@ -350,6 +366,8 @@ int gd_set_contigs(gd_ctx* c, int n, const int64_t* lengths)
     }
     c->selected.clear();
     c->computed = false;
+    // a new data set: forget the look-back learnt from the previous one
+    c->lookback = c->params.max_span_hint > 0 ? c->params.max_span_hint : kDefaultLookback;
     return GD_OK;
 }
 
@@ -522,6 +540,7 @@ int gd_reset(gd_ctx* c)
     }
     c->bounds.clear();
     c->computed = false;
+    c->lookback = c->params.max_span_hint > 0 ? c->params.max_span_hint : kDefaultLookback;
     return GD_OK;
 }
 
@@ -607,6 +626,7 @@ int gd_compute(gd_ctx* c)
     HIPCHK(c, hipStreamWaitEvent(c->stream, c->copy_done, 0));
 
     int reruns = 0;
+    int used_lookback = c->lookback;
     for (;;) {
         gd::Job job{};
         job.ctgs = c->d_ctgs;
@@ -635,7 +655,6 @@ int gd_compute(gd_ctx* c)
         if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
         switch (T) {
         case 8192: launch_prep<8192>(c, job); break;
-        case 16384: launch_prep<16384>(c, job); break;
         default: launch_prep<4096>(c, job); break;
         }
         if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
@@ -644,10 +663,6 @@ int gd_compute(gd_ctx* c)
             switch (key) {
             case 4096 + 512: launch_tile<4096, 512>(c, job); break;
             case 8192 + 512: launch_tile<8192, 512>(c, job); break;
-            case 8192 + 1024: launch_tile<8192, 1024>(c, job); break;
-            case 16384 + 256: launch_tile<16384, 256>(c, job); break;
-            case 16384 + 512: launch_tile<16384, 512>(c, job); break;
-            case 16384 + 1024: launch_tile<16384, 1024>(c, job); break;
             case 8192 + 256: launch_tile<8192, 256>(c, job); break;
             default: launch_tile<4096, 256>(c, job); break;
             }
@@ -664,11 +679,20 @@ int gd_compute(gd_ctx* c)
 
         const gd::Counters k = *c->h_counters;
         c->stats.max_span_seen = k.max_span > 0 ? k.max_span : 0;
+        if (k.max_span >= kMaxSpan)
+            return fail(c, GD_E_RANGE, "a read spans %d reference bases (limit %d)", k.max_span, kMaxSpan - 1);
         if (k.max_span > c->lookback) {
             // a kept read spans more reference than the look-back: redo with the observed maximum
-            c->lookback = (k.max_span + 255) & ~255;
+            c->lookback = (k.max_span + 63) & ~63;
             ++reruns;
             continue;
+        }
+        used_lookback = c->lookback;
+        if (c->kernel_gen != 5 && !c->lookback_pinned) {
+            // the v6 kernel reports the true maximum: a look-back far above it only
+            // costs re-examined reads, so the next compute uses a tighter (still verified) one
+            const int want = std::max(64, (k.max_span + 63) & ~63);
+            if (want * 2 <= c->lookback) c->lookback = want;
         }
         if ((size_t)k.run_cursor > c->cap_runs) {
             size_t want = (size_t)k.run_cursor + (size_t)k.run_cursor / 8 + 1024;
@@ -711,7 +735,7 @@ int gd_compute(gd_ctx* c)
     c->stats.n_tiles = (uint64_t)c->n_tiles;
     c->stats.n_runs = c->bounds.size();
     c->stats.tile_positions = T;
-    c->stats.lookback = c->lookback;
+    c->stats.lookback = used_lookback;
     c->stats.reruns = reruns;
     c->computed = true;
     return GD_OK;

@@ -83,3 +83,86 @@ def test_synthetic_short_reads(eng):
     check_all(eng, contigs, {0: r}, 1000, 1, 4, 0)
     st = eng.stats()
     assert st.n_reads == n and st.reruns == 0
+
+
+def _uniform_reads(pos, length, flag=0, mapq=60):
+    """n reads `<length>M` at the given sorted positions."""
+    n = len(pos)
+    off = np.arange(n + 1, dtype=np.uint32)
+    cigar = np.full(n, (length << 4) | 0, np.uint32)
+    return po.Reads(np.asarray(pos, np.int32), np.full(n, flag, np.uint16), np.full(n, mapq, np.uint8),
+                    off, cigar)
+
+
+def test_wide_pileup_64bit_windows(eng):
+    """More than 2^22 reads on one tile: depth may exceed what the 32-bit window
+    accumulation holds, so the tile takes the 64-bit path (and many record
+    batches, CIGARs read from global memory)."""
+    rng = np.random.default_rng(5)
+    n = (1 << 22) + 70001
+    L = 9000
+    pos = np.sort(rng.integers(100, 400, size=n)).astype(np.int32)
+    r = _uniform_reads(pos, 120)
+    contigs = [("deep", L)]
+    run_engine(eng, contigs, {0: r}, window_size=1000, min_mapq=1, min_cov=4, max_mean_depth=3000000)
+    check_all(eng, contigs, {0: r}, 1000, 1, 4, 3000000)
+    assert int(eng.perbase(0).max()) > (1 << 22)
+
+
+def test_many_batches_staged_boundary(eng):
+    """Tiles holding a few thousand reads: several record batches per tile, with
+    the CIGAR range on either side of the LDS staging capacity."""
+    rng = np.random.default_rng(11)
+    L = 40000
+    for n in (1400, 1536, 1537, 5000, 20000):
+        pos = np.sort(rng.integers(0, 4096 - 100, size=n)).astype(np.int32)
+        r = _uniform_reads(pos, 100)
+        # sprinkle two-op reads (soft clip + match) so the queue path is used too
+        extra = H.random_reads(rng, L, 3000)
+        contigs = [("a", L), ("b", L)]
+        run_engine(eng, contigs, {0: r, 1: extra}, window_size=250, min_mapq=1, min_cov=4)
+        check_all(eng, contigs, {0: r, 1: extra}, 250, 1, 4, 0)
+
+
+def test_lookback_adapts_and_stays_exact(eng):
+    """The look-back shrinks after a compute whose longest read is far below it,
+    grows again (one re-run) when longer reads arrive, and results stay exact."""
+    rng = np.random.default_rng(3)
+    L = 200000
+    short = _uniform_reads(np.sort(rng.integers(0, L // 2, size=30000)), 50)
+    contigs = [("c", L)]
+    run_engine(eng, contigs, {0: short}, window_size=1000, min_mapq=1, min_cov=4)
+    check_all(eng, contigs, {0: short}, 1000, 1, 4, 0)
+    st = eng.stats()
+    assert st.max_span_seen == 50 and st.reruns == 0 and st.lookback == 512
+    eng.compute()                                   # same data again: tighter, still exact
+    st = eng.stats()
+    assert st.lookback == 64 and st.reruns == 0
+    check_all(eng, contigs, {0: short}, 1000, 1, 4, 0)
+    # append longer reads (coordinate order kept): the tightened look-back is now too small
+    longer = _uniform_reads(np.sort(rng.integers(L // 2, L - 2000, size=5000)), 1500)
+    eng.push(0, longer.pos, longer.flag, longer.mapq, longer.cigar_off, longer.cigar)
+    eng.compute()
+    st = eng.stats()
+    assert st.reruns == 1 and st.max_span_seen == 1500 and st.lookback >= 1500
+    both = po.Reads(np.concatenate([short.pos, longer.pos]), np.concatenate([short.flag, longer.flag]),
+                    np.concatenate([short.mapq, longer.mapq]),
+                    np.concatenate([short.cigar_off, longer.cigar_off[1:] + short.cigar_off[-1]]).astype(np.uint32),
+                    np.concatenate([short.cigar, longer.cigar]))
+    check_all(eng, contigs, {0: both}, 1000, 1, 4, 0)
+
+
+def test_read_span_limit_is_an_error(eng):
+    """Reference spans of 2^27 bases or more are rejected, not mis-counted."""
+    from goleft_amd.engine import GdError
+    L = 1 << 20
+    off = np.array([0, 9], np.uint32)
+    cigar = np.full(9, (((1 << 24) - 1) << 4) | 3, np.uint32)   # nine N skips of ~16.7 Mb
+    cigar[0] = (100 << 4) | 0
+    r = po.Reads(np.array([10], np.int32), np.zeros(1, np.uint16), np.full(1, 60, np.uint8), off, cigar)
+    eng.set_params(window_size=1000, min_mapq=1, min_cov=4)
+    eng.set_contigs([L])
+    eng.push(0, r.pos, r.flag, r.mapq, r.cigar_off, r.cigar)
+    with pytest.raises(GdError) as ei:
+        eng.compute()
+    assert ei.value.status == -5      # GD_E_RANGE
