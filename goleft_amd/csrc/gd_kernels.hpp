@@ -127,38 +127,39 @@ __device__ __forceinline__ uint32_t lower_bound_i32(const int32_t* a, uint32_t n
     return lo;
 }
 
-// lower_bound restricted to [lo, hi) after checking that the answer lies there.
-__device__ __forceinline__ uint32_t lower_bound_range(const int32_t* a, uint32_t lo, uint32_t hi, int32_t key)
+// Two lower_bounds over the same sorted array in ONE latency chain: a 4-ary
+// search (three probes per round) for each key, both advanced in the same loop
+// iteration, so a round has six independent loads in flight and the chain is
+// ~log4(n) rounds instead of 2*log2(n) dependent loads.  keyB >= keyA.
+__device__ __forceinline__ void lower_bound_pair(const int32_t* a, uint32_t n, int32_t keyA,
+                                                 int32_t keyB, uint32_t& outA, uint32_t& outB)
 {
-    while (lo < hi) {
-        uint32_t mid = lo + ((hi - lo) >> 1);
-        if (a[mid] < key) lo = mid + 1; else hi = mid;
+    uint32_t la = 0, ha = n, lb = 0, hb = n;
+    if (n == 0) { outA = 0; outB = 0; return; }
+    const uint32_t last = n - 1;
+    while (ha > la || hb > lb) {
+        const uint32_t wa = ha - la, wb = hb - lb;
+        uint32_t a1 = la + (wa >> 2), a2 = la + (wa >> 1), a3 = la + wa - (wa >> 2) - (wa != 0);
+        uint32_t b1 = lb + (wb >> 2), b2 = lb + (wb >> 1), b3 = lb + wb - (wb >> 2) - (wb != 0);
+        a1 = a1 < last ? a1 : last; a2 = a2 < last ? a2 : last; a3 = a3 < last ? a3 : last;
+        b1 = b1 < last ? b1 : last; b2 = b2 < last ? b2 : last; b3 = b3 < last ? b3 : last;
+        const int32_t va1 = a[a1], va2 = a[a2], va3 = a[a3];
+        const int32_t vb1 = a[b1], vb2 = a[b2], vb3 = a[b3];
+        if (wa != 0) {
+            if (va3 < keyA) la = a3 + 1;
+            else if (va2 < keyA) { la = a2 + 1; ha = a3; }
+            else if (va1 < keyA) { la = a1 + 1; ha = a2; }
+            else ha = a1;
+        }
+        if (wb != 0) {
+            if (vb3 < keyB) lb = b3 + 1;
+            else if (vb2 < keyB) { lb = b2 + 1; hb = b3; }
+            else if (vb1 < keyB) { lb = b1 + 1; hb = b2; }
+            else hb = b1;
+        }
     }
-    return lo;
-}
-
-// lower_bound(a, n, key) with a bracket [g - d, g + d] around a guessed rank.
-__device__ __forceinline__ uint32_t lower_bound_guess(const int32_t* a, uint32_t n, int32_t key,
-                                                      uint32_t g, uint32_t d)
-{
-    if (n == 0) return 0;
-    if (g > n) g = n;
-    uint32_t lo = g > d ? g - d : 0u;
-    uint32_t hi = n - g > d ? g + d : n;
-    if (lo > 0 && a[lo - 1] >= key) { hi = lo; lo = 0; }      // answer is below the bracket
-    else if (hi < n && a[hi] < key) { lo = hi + 1; hi = n; }   // answer is above it
-    return lower_bound_range(a, lo, hi, key);
-}
-
-// lower_bound(a, n, key) knowing the answer is >= from; tries [from, from + d] first.
-__device__ __forceinline__ uint32_t lower_bound_from(const int32_t* a, uint32_t n, int32_t key,
-                                                     uint32_t from, uint32_t d)
-{
-    if (from >= n) return n;
-    uint32_t hi = n - from > d ? from + d : n;
-    uint32_t lo = from;
-    if (hi < n && a[hi] < key) { lo = hi + 1; hi = n; }
-    return lower_bound_range(a, lo, hi, key);
+    outA = la;
+    outB = lb;
 }
 
 // ---------------------------------------------------------------------------
@@ -195,13 +196,7 @@ __global__ void gd_prep_kernel(Job job)
     ti.t0 = (t - c.tile_beg) * T;
     int32_t tend = ti.t0 + T < c.length ? ti.t0 + T : c.length;
     int32_t from = ti.t0 > job.lookback ? ti.t0 - job.lookback : 0;
-    // Both searches start from a verified bracket instead of [0, n): under
-    // roughly uniform coverage rank(key) ~ n * key / length (a guess checked with
-    // two loads; on a miss the search falls back to the full range), and the
-    // tile's last read is rarely more than a few thousand records past its first.
-    ti.lo = lower_bound_guess(c.pos, c.n_reads, from,
-                              (uint32_t)(((uint64_t)c.n_reads * (uint32_t)from) / (uint32_t)c.length), 1u << 13);
-    ti.hi = lower_bound_from(c.pos, c.n_reads, tend, ti.lo, 1u << 12);
+    lower_bound_pair(c.pos, c.n_reads, from, tend, ti.lo, ti.hi);
     ti.clo = c.n_reads ? c.off[ti.lo] : 0u;
     ti.chi = c.n_reads ? c.off[ti.hi] : 0u;
     job.tiles[t] = ti;

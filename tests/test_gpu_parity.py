@@ -101,7 +101,7 @@ def test_wide_pileup_64bit_windows(eng):
     rng = np.random.default_rng(5)
     n = (1 << 22) + 70001
     L = 9000
-    pos = np.sort(rng.integers(100, 400, size=n)).astype(np.int32)
+    pos = np.sort(rng.integers(100, 140, size=n)).astype(np.int32)
     r = _uniform_reads(pos, 120)
     contigs = [("deep", L)]
     run_engine(eng, contigs, {0: r}, window_size=1000, min_mapq=1, min_cov=4, max_mean_depth=3000000)

@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""HBM traffic of gd_tile_kernel from rocprofv3 PMC passes.
+
+    python tools/traffic_from_pmc.py gpurun_out/prof_<tag> profiles/r01_wgs_traffic.json
+
+Reads the counter_collection CSVs of the separate `--pmc FETCH_SIZE` and
+`--pmc WRITE_SIZE` passes made by tools/prof.sh and applies the corrections of
+MI355X_MICROARCH.md (section HBM): both counters are in KiB; on gfx950
+FETCH_SIZE reports half of the bytes of a wide coalesced streaming read, so it
+is doubled; WRITE_SIZE is taken as is.  Values are means per dispatch.
+"""
+import csv
+import glob
+import json
+import os
+import sys
+
+root, out = sys.argv[1], sys.argv[2]
+acc = {"FETCH_SIZE": [], "WRITE_SIZE": []}
+for f in glob.glob(os.path.join(root, "pmc*", "**", "*counter_collection.csv"), recursive=True):
+    for row in csv.DictReader(open(f)):
+        if "gd_tile_kernel" in row["Kernel_Name"] and row["Counter_Name"] in acc:
+            acc[row["Counter_Name"]].append(float(row["Counter_Value"]))
+fetch_kib = sum(acc["FETCH_SIZE"]) / len(acc["FETCH_SIZE"])
+write_kib = sum(acc["WRITE_SIZE"]) / len(acc["WRITE_SIZE"])
+read_b = fetch_kib * 1024 * 2
+write_b = write_kib * 1024
+res = {
+    "kernel": "gd_tile_kernel",
+    "fetch_size_kib_raw": fetch_kib, "write_size_kib_raw": write_kib,
+    "dispatches": {k: len(v) for k, v in acc.items()},
+    "hbm_read_bytes_per_launch": read_b, "hbm_write_bytes_per_launch": write_b,
+    "hbm_bytes_per_launch": read_b + write_b,
+    "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/prof.sh), "
+              "FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md; "
+              "python bench.py --no-cpu-baseline --steps 5 --warmup 2",
+}
+json.dump(res, open(out, "w"), indent=1)
+print(json.dumps(res))
