@@ -31,7 +31,8 @@ class GdStats(C.Structure):
     _fields_ = [("n_reads", C.c_uint64), ("n_ops", C.c_uint64), ("n_ref_bases", C.c_uint64),
                 ("n_windows", C.c_uint64), ("n_tiles", C.c_uint64), ("n_runs", C.c_uint64),
                 ("tile_positions", C.c_int32), ("lookback", C.c_int32),
-                ("max_span_seen", C.c_int32), ("reruns", C.c_int32)]
+                ("max_span_seen", C.c_int32), ("reruns", C.c_int32),
+                ("path", C.c_int32), ("reserved", C.c_int32)]
 
 
 # every symbol include/goleft_depth.h declares: (restype, argtypes)
@@ -46,6 +47,7 @@ SYMBOLS = {
     "gd_set_stream": (C.c_int, [_P, _P]),
     "gd_set_params": (C.c_int, [_P, C.POINTER(GdParams)]),
     "gd_default_params": (C.c_int, [C.POINTER(GdParams)]),
+    "gd_set_path": (C.c_int, [_P, C.c_int]),
     "gd_set_contigs": (C.c_int, [_P, C.c_int, _P]),
     "gd_select_contigs": (C.c_int, [_P, C.c_int, _P]),
     "gd_acquire": (C.c_int, [_P, C.c_size_t, C.c_size_t, C.POINTER(GdBatch)]),

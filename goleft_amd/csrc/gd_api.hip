@@ -22,6 +22,7 @@ namespace {
 constexpr int kRingSlots = 3;
 constexpr int kDefaultLookback = 512;
 constexpr uint64_t kMaxReadsPerContig = 1ull << 30;
+constexpr int kAutoScatterSpan = 32768;   // GD_PATH_AUTO leaves the tile path above this read span
 constexpr int kMaxSpan = 1 << 27;   // tile-relative byte offsets of the tile kernel stay in 32 bits
 
 struct ContigHost {
@@ -70,6 +71,9 @@ struct gd_ctx {
     int kernel_gen = 6;                 // debug: GOLEFT_GD_KERNEL=v5 selects the previous tile kernel
     int tile_opt = 0;                   // GOLEFT_GD_OPT bit 0: non-temporal per-base stores
     bool lookback_pinned = false;       // max_span_hint given: never shrink below it
+    int path = GD_PATH_AUTO;            // gd_set_path / GOLEFT_GD_PATH
+    bool span_forces_scatter = false;   // AUTO: the tile path met a read too long for it
+    unsigned long long* d_status = nullptr;  size_t cap_status = 0;   // scatter path look-back words
     int lookback = kDefaultLookback;
 
     // device job state
@@ -265,6 +269,8 @@ int gd_create(int device_id, gd_ctx** out)
     if (const char* e = getenv("GOLEFT_GD_ABLATE")) c->ablate = atoi(e);
     if (const char* e = getenv("GOLEFT_GD_KERNEL")) c->kernel_gen = (e[0] == 'v' && e[1] == '5') ? 5 : 6;
     if (const char* e = getenv("GOLEFT_GD_OPT")) c->tile_opt = atoi(e) & 1;
+    if (const char* e = getenv("GOLEFT_GD_PATH"))
+        c->path = e[0] == 's' ? GD_PATH_SCATTER : (e[0] == 't' ? GD_PATH_TILE : GD_PATH_AUTO);
     if (const char* e = getenv("GOLEFT_GD_THREADS")) {
         int t = atoi(e);
         if (t == 256 || t == 512) c->tile_NT = t;
@@ -309,7 +315,7 @@ void gd_destroy(gd_ctx* c)
     if (c->copy_done) (void)hipEventDestroy(c->copy_done);
     void* frees[] = {c->d_ctgs, c->d_tiles, c->d_perbase, c->d_wsum, c->d_wmin, c->d_chunks,
                      c->d_ordered, c->d_tile_cnt, c->d_tile_off, c->d_super_cnt, c->d_counters,
-                     c->d_region_cursor};
+                     c->d_region_cursor, c->d_status};
     for (void* p : frees) if (p) (void)hipFree(p);
     if (c->h_counters) (void)hipHostFree(c->h_counters);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -351,6 +357,16 @@ int gd_set_params(gd_ctx* c, const gd_params* p)
     return GD_OK;
 }
 
+int gd_set_path(gd_ctx* c, int path)
+{
+    if (!c) return GD_E_INVALID;
+    if (path != GD_PATH_AUTO && path != GD_PATH_TILE && path != GD_PATH_SCATTER)
+        return fail(c, GD_E_INVALID, "unknown path %d", path);
+    c->path = path;
+    c->computed = false;
+    return GD_OK;
+}
+
 int gd_set_contigs(gd_ctx* c, int n, const int64_t* lengths)
 {
     if (!c || n < 0 || (n > 0 && !lengths)) return GD_E_INVALID;
@@ -368,6 +384,7 @@ int gd_set_contigs(gd_ctx* c, int n, const int64_t* lengths)
     c->computed = false;
     // a new data set: forget the look-back learnt from the previous one
     c->lookback = c->params.max_span_hint > 0 ? c->params.max_span_hint : kDefaultLookback;
+    c->span_forces_scatter = false;
     return GD_OK;
 }
 
@@ -541,6 +558,7 @@ int gd_reset(gd_ctx* c)
     c->bounds.clear();
     c->computed = false;
     c->lookback = c->params.max_span_hint > 0 ? c->params.max_span_hint : kDefaultLookback;
+    c->span_forces_scatter = false;
     return GD_OK;
 }
 
@@ -559,7 +577,7 @@ int gd_compute(gd_ctx* c)
     c->h_ctgs.clear();
     c->job_tids.clear();
     int64_t tile_beg = 0, base_off = 0, win_off = 0, bases = 0;
-    uint64_t n_reads = 0, n_ops = 0;
+    uint64_t n_reads = 0, n_ops = 0, n_units = 0;
     for (int32_t tid : tids) {
         ContigHost& h = c->contigs[tid];
         if (h.length <= 0) continue;
@@ -573,6 +591,8 @@ int gd_compute(gd_ctx* c)
         d.base_off = base_off;
         d.win_off = win_off;
         d.tid = tid;
+        d.unit_beg = (uint32_t)n_units;
+        n_units += (h.n_reads + 63) / 64;
         h.base_off = base_off;
         h.win_off = win_off;
         h.n_win = (h.length + P.window_size - 1) / P.window_size;
@@ -586,6 +606,7 @@ int gd_compute(gd_ctx* c)
         c->job_tids.push_back(tid);
     }
     if (tile_beg > 0x7fffffffLL) return fail(c, GD_E_RANGE, "too many tiles");
+    if (n_units > 0xfffffff0ull) return fail(c, GD_E_RANGE, "too many records");
     c->n_tiles = tile_beg;
     c->n_win_total = win_off;
     c->n_bases = bases;
@@ -627,6 +648,7 @@ int gd_compute(gd_ctx* c)
 
     int reruns = 0;
     int used_lookback = c->lookback;
+    bool used_scatter = false;
     for (;;) {
         gd::Job job{};
         job.ctgs = c->d_ctgs;
@@ -652,47 +674,94 @@ int gd_compute(gd_ctx* c)
         job.ablate = c->ablate;
         job.step = derive_step(P);
 
-        if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
-        switch (T) {
-        case 8192: launch_prep<8192>(c, job); break;
-        default: launch_prep<4096>(c, job); break;
-        }
-        if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
-        {
-            const int key = T + c->tile_NT;   // (T, NT) variants compiled below
-            switch (key) {
-            case 4096 + 512: launch_tile<4096, 512>(c, job); break;
-            case 8192 + 512: launch_tile<8192, 512>(c, job); break;
-            case 8192 + 256: launch_tile<8192, 256>(c, job); break;
-            default: launch_tile<4096, 256>(c, job); break;
+        job.n_units = (uint32_t)n_units;
+        job.tile_status = c->d_status;
+
+        // which device algorithm (include/goleft_depth.h GD_PATH_*)
+        const bool scatter = c->path == GD_PATH_SCATTER ||
+                             (c->path == GD_PATH_AUTO && (c->span_forces_scatter || n_ops > 6 * n_reads));
+        const unsigned runs_grid = (unsigned)((c->n_tiles + gd::SUPER - 1) / gd::SUPER);
+        if (!scatter) {
+            if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+            switch (T) {
+            case 8192: launch_prep<8192>(c, job); break;
+            default: launch_prep<4096>(c, job); break;
             }
+            if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+            {
+                const int key = T + c->tile_NT;   // (T, NT) variants compiled below
+                switch (key) {
+                case 4096 + 512: launch_tile<4096, 512>(c, job); break;
+                case 8192 + 512: launch_tile<8192, 512>(c, job); break;
+                case 8192 + 256: launch_tile<8192, 256>(c, job); break;
+                default: launch_tile<4096, 256>(c, job); break;
+                }
+            }
+            if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
+            hipLaunchKernelGGL(gd::gd_runs_order_kernel, dim3(runs_grid), dim3(gd::SUPER), 0,
+                               c->stream, c->d_chunks, job.run_cap, c->d_tile_cnt, c->d_tile_off,
+                               c->d_super_cnt, c->d_ordered, (int)c->n_tiles);
+            if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
+        } else {
+            if (int r = ensure_dev(c, &c->d_status, &c->cap_status, (size_t)c->n_tiles)) return r;
+            job.tile_status = c->d_status;
+            if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+            // the per-base array doubles as the difference array: zero it, padding included
+            HIPCHK(c, hipMemsetAsync(c->d_perbase, 0, (size_t)base_off * sizeof(int32_t), c->stream));
+            {
+                int64_t work = std::max<int64_t>(job.n_tiles, std::min<int64_t>(job.n_win_total, 1 << 22));
+                hipLaunchKernelGGL(gd::gd_linit_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0,
+                                   c->stream, job);
+            }
+            if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+            if (n_units) {
+                const uint64_t groups = (n_units + 3) / 4;
+                const unsigned grid = (unsigned)(((groups + 7) / 8) * 8);
+                hipLaunchKernelGGL(gd::gd_expand_scatter_kernel, dim3(grid), dim3(256), 0, c->stream, job);
+            }
+            if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
+            if (T == 8192)
+                hipLaunchKernelGGL((gd::gd_scan_kernel<8192, 256>), dim3((unsigned)c->n_tiles), dim3(256), 0, c->stream, job);
+            else
+                hipLaunchKernelGGL((gd::gd_scan_kernel<4096, 256>), dim3((unsigned)c->n_tiles), dim3(256), 0, c->stream, job);
+            if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
+            hipLaunchKernelGGL(gd::gd_runs_order_kernel, dim3(runs_grid), dim3(gd::SUPER), 0,
+                               c->stream, c->d_chunks, job.run_cap, c->d_tile_cnt, c->d_tile_off,
+                               c->d_super_cnt, c->d_ordered, (int)c->n_tiles);
+            if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
         }
-        if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
-        hipLaunchKernelGGL(gd::gd_runs_order_kernel,
-                           dim3((unsigned)((c->n_tiles + gd::SUPER - 1) / gd::SUPER)), dim3(gd::SUPER), 0,
-                           c->stream, c->d_chunks, job.run_cap, c->d_tile_cnt, c->d_tile_off,
-                           c->d_super_cnt, c->d_ordered, (int)c->n_tiles);
-        if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipMemcpyAsync(c->h_counters, c->d_counters, sizeof(gd::Counters), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
+        used_scatter = scatter;
 
         const gd::Counters k = *c->h_counters;
-        c->stats.max_span_seen = k.max_span > 0 ? k.max_span : 0;
-        if (k.max_span >= kMaxSpan)
-            return fail(c, GD_E_RANGE, "a read spans %d reference bases (limit %d)", k.max_span, kMaxSpan - 1);
-        if (k.max_span > c->lookback) {
-            // a kept read spans more reference than the look-back: redo with the observed maximum
-            c->lookback = (k.max_span + 63) & ~63;
-            ++reruns;
-            continue;
-        }
-        used_lookback = c->lookback;
-        if (c->kernel_gen != 5 && !c->lookback_pinned) {
-            // the v6 kernel reports the true maximum: a look-back far above it only
-            // costs re-examined reads, so the next compute uses a tighter (still verified) one
-            const int want = std::max(64, (k.max_span + 63) & ~63);
-            if (want * 2 <= c->lookback) c->lookback = want;
+        if (scatter) {
+            if (k.pad1 != 0) return fail(c, GD_E_HIP, "scan look-back timed out (internal error)");
+        } else {
+            c->stats.max_span_seen = k.max_span > 0 ? k.max_span : 0;
+            if (c->path == GD_PATH_AUTO && k.max_span > kAutoScatterSpan) {
+                // reads this long make the tile path re-examine too much: switch paths
+                c->span_forces_scatter = true;
+                ++reruns;
+                continue;
+            }
+            if (k.max_span >= kMaxSpan)
+                return fail(c, GD_E_RANGE, "a read spans %d reference bases (tile path limit %d; use GD_PATH_SCATTER)",
+                            k.max_span, kMaxSpan - 1);
+            if (k.max_span > c->lookback) {
+                // a kept read spans more reference than the look-back: redo with the observed maximum
+                c->lookback = (k.max_span + 63) & ~63;
+                ++reruns;
+                continue;
+            }
+            used_lookback = c->lookback;
+            if (c->kernel_gen != 5 && !c->lookback_pinned) {
+                // the v6 kernel reports the true maximum: a look-back far above it only
+                // costs re-examined reads, so the next compute uses a tighter (still verified) one
+                const int want = std::max(64, (k.max_span + 63) & ~63);
+                if (want * 2 <= c->lookback) c->lookback = want;
+            }
         }
         if ((size_t)k.run_cursor > c->cap_runs) {
             size_t want = (size_t)k.run_cursor + (size_t)k.run_cursor / 8 + 1024;
@@ -710,10 +779,19 @@ int gd_compute(gd_ctx* c)
         break;
     }
     if (c->profiling) {
-        for (int i = 0; i < GD_K_COUNT; ++i) {
-            float ms = 0;
-            HIPCHK(c, hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]));
-            c->kernel_ms[i] = ms;
+        auto ms = [&](int a, int b, float* out) -> int {
+            HIPCHK(c, hipEventElapsedTime(out, c->ev[a], c->ev[b]));
+            return GD_OK;
+        };
+        if (!used_scatter) {
+            if (int r = ms(0, 1, &c->kernel_ms[GD_K_PREP])) return r;
+            if (int r = ms(1, 2, &c->kernel_ms[GD_K_TILE])) return r;
+            if (int r = ms(2, 3, &c->kernel_ms[GD_K_RUNS])) return r;
+        } else {
+            if (int r = ms(0, 1, &c->kernel_ms[GD_K_PREP])) return r;
+            if (int r = ms(1, 2, &c->kernel_ms[GD_K_EXPAND])) return r;
+            if (int r = ms(2, 3, &c->kernel_ms[GD_K_SCAN])) return r;
+            if (int r = ms(3, 4, &c->kernel_ms[GD_K_RUNS])) return r;
         }
     }
     // slice the boundary list per contig
@@ -737,6 +815,9 @@ int gd_compute(gd_ctx* c)
     c->stats.tile_positions = T;
     c->stats.lookback = used_lookback;
     c->stats.reruns = reruns;
+    c->stats.path = used_scatter ? GD_PATH_SCATTER : GD_PATH_TILE;
+    c->stats.reserved = 0;
+    if (used_scatter) c->stats.max_span_seen = 0;   // not measured on this path
     c->computed = true;
     return GD_OK;
 }

@@ -53,6 +53,7 @@ struct ContigDev {
     int64_t  base_off;        // element offset of this contig in the per-base array
     int64_t  win_off;         // element offset in the window arrays
     int32_t  tid;             // reference id in the BAM header
+    uint32_t unit_beg;        // first 64-read unit of this contig (scatter path)
 };
 
 // Everything a workgroup needs for its tile in ONE 80-byte record (one scalar
@@ -78,7 +79,8 @@ struct __attribute__((aligned(16))) TileInfo {
 struct Counters {
     int32_t  max_span;        // largest reference span of a kept read
     uint32_t run_cursor;      // boundary entries allocated (may exceed capacity)
-    uint32_t pad0, pad1;
+    uint32_t pad0;            // scatter path: tile ticket of gd_scan_kernel
+    uint32_t pad1;            // scatter path: 1 if a look-back ever timed out
 };
 
 struct Job {
@@ -105,6 +107,8 @@ struct Job {
     int32_t   ablate;         // debug only (GOLEFT_GD_ABLATE): 1 skip phase A, 2 skip LDS marks,
                               // 4 skip per-base stores, 8 skip window/class reductions
     int64_t   step;
+    uint32_t  n_units;        // scatter path: 64-read units over all contigs
+    unsigned long long* tile_status;   // scatter path: look-back status word per tile
 };
 
 __device__ __forceinline__ int cov_class(int d, int mincov, int maxmean)
@@ -246,6 +250,7 @@ __device__ __forceinline__ int wave_min(int v)
 }  // namespace gd
 
 #include "gd_tile_v6.hpp"
+#include "gd_scatter.hpp"
 #include "gd_tile_v5.hpp"
 
 namespace gd {

@@ -399,6 +399,62 @@ __device__ __forceinline__ void phase_b_rows(const PhaseB& B)
     }
 }
 
+// Phase C (rare): tiles whose bitmap holds class boundaries compact them into a
+// chunk allocated with one global atomicAdd and add their count to the
+// per-SUPER-tiles group counter (ordering happens in gd_runs_order_kernel).
+// Must be called by every thread of the workgroup after a barrier.
+template <int T, int NT>
+__device__ __forceinline__ void phase_c(const Job& job, int tile, int32_t t0, int ctg, int tid, int lane,
+                                        int wv, const uint32_t* s_bmap, const uint32_t* s_clo,
+                                        const uint32_t* s_chi, uint32_t* s_wcnt, const uint32_t* s_hasb,
+                                        uint32_t* s_base)
+{
+    constexpr int NW = NT / WAVE;
+    constexpr int NWORDS = T / 32;
+    if (*s_hasb == 0) {
+        if (tid == 0) { job.tile_cnt[tile] = 0; job.tile_off[tile] = 0; }
+        return;
+    }
+    // blocked word ownership keeps thread order == position order
+    static_assert(NWORDS <= NT || NWORDS % NT == 0, "bitmap words vs threads");
+    constexpr int WPT = NWORDS <= NT ? 1 : NWORDS / NT;  // words per thread
+    uint32_t cnt = 0;
+    const int wbeg = tid * WPT;
+#pragma unroll
+    for (int j = 0; j < WPT; ++j)
+        if (wbeg + j < NWORDS) cnt += __popc(s_bmap[wbeg + j]);
+    const uint32_t incl = (uint32_t)wave_inclusive_scan((int)cnt);
+    if (lane == 63) s_wcnt[wv] = incl;
+    __syncthreads();
+    uint32_t before = 0, total = 0;
+    for (int v = 0; v < NW; ++v) { if (v < wv) before += s_wcnt[v]; total += s_wcnt[v]; }
+    if (tid == 0) {
+        const uint32_t b = atomicAdd(&job.counters->run_cursor, total);
+        *s_base = b;
+        job.tile_cnt[tile] = total;
+        job.tile_off[tile] = b;
+        atomicAdd(&job.super_cnt[tile / SUPER], total);
+    }
+    __syncthreads();
+    uint32_t dst = *s_base + before + incl - cnt;
+#pragma unroll
+    for (int j = 0; j < WPT; ++j) {
+        const int w = wbeg + j;
+        if (w >= NWORDS) break;
+        uint32_t bits = s_bmap[w];
+        const uint32_t lo = s_clo[w], hi = s_chi[w];
+        while (bits) {
+            const int b = __ffs(bits) - 1;
+            bits &= bits - 1;
+            if (dst < job.run_cap) {
+                const int cls = (int)((lo >> b) & 1u) | (int)(((hi >> b) & 1u) << 1);
+                job.run_chunks[dst] = make_int2(t0 + w * 32 + b, cls | (ctg << 2));
+            }
+            ++dst;
+        }
+    }
+}
+
 // OPT bit 0: non-temporal per-base stores.
 template <int T, int NT, int OPT>
 __global__ __launch_bounds__(NT) void gd_tile_kernel(Job job)
@@ -538,50 +594,7 @@ __global__ __launch_bounds__(NT) void gd_tile_kernel(Job job)
     __syncthreads();
 
     // ---- phase C: compact class boundaries of this tile -------------------
-    if (s_hasb == 0) {
-        if (tid == 0) { job.tile_cnt[tile] = 0; job.tile_off[tile] = 0; }
-        return;
-    }
-    {
-        // blocked word ownership keeps thread order == position order
-        static_assert(NWORDS <= NT || NWORDS % NT == 0, "bitmap words vs threads");
-        constexpr int WPT = NWORDS <= NT ? 1 : NWORDS / NT;  // words per thread
-        uint32_t cnt = 0;
-        const int wbeg = tid * WPT;
-#pragma unroll
-        for (int j = 0; j < WPT; ++j)
-            if (wbeg + j < NWORDS) cnt += __popc(s_bmap[wbeg + j]);
-        const uint32_t incl = (uint32_t)wave_inclusive_scan((int)cnt);
-        if (lane == 63) s_wcnt[wv] = incl;
-        __syncthreads();
-        uint32_t before = 0, total = 0;
-        for (int v = 0; v < NW; ++v) { if (v < wv) before += s_wcnt[v]; total += s_wcnt[v]; }
-        if (tid == 0) {
-            const uint32_t b = atomicAdd(&job.counters->run_cursor, total);
-            s_base = b;
-            job.tile_cnt[tile] = total;
-            job.tile_off[tile] = b;
-            atomicAdd(&job.super_cnt[tile / SUPER], total);
-        }
-        __syncthreads();
-        uint32_t dst = s_base + before + incl - cnt;
-#pragma unroll
-        for (int j = 0; j < WPT; ++j) {
-            const int w = wbeg + j;
-            if (w >= NWORDS) break;
-            uint32_t bits = s_bmap[w];
-            const uint32_t lo = s_clo[w], hi = s_chi[w];
-            while (bits) {
-                const int b = __ffs(bits) - 1;
-                bits &= bits - 1;
-                if (dst < job.run_cap) {
-                    const int cls = (int)((lo >> b) & 1u) | (int)(((hi >> b) & 1u) << 1);
-                    job.run_chunks[dst] = make_int2(t0 + w * 32 + b, cls | (ti.ctg << 2));
-                }
-                ++dst;
-            }
-        }
-    }
+    phase_c<T, NT>(job, tile, t0, ti.ctg, tid, lane, wv, s_bmap, s_clo, s_chi, s_wcnt, &s_hasb, &s_base);
 }
 
 }  // namespace gd

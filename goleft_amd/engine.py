@@ -14,7 +14,8 @@ from . import _lib
 from ._lib import GdBatch, GdParams, GdRun, GdStats
 
 CLASS_NAMES = ("NO_COVERAGE", "LOW_COVERAGE", "CALLABLE", "EXCESSIVE_COVERAGE")
-K_PREP, K_TILE, K_RUNS = 0, 1, 2
+K_PREP, K_TILE, K_RUNS, K_EXPAND, K_SCAN = 0, 1, 2, 3, 4
+PATH_AUTO, PATH_TILE, PATH_SCATTER = 0, 1, 2
 
 
 class GdError(RuntimeError):
@@ -67,6 +68,10 @@ class DepthEngine:
         p = GdParams(window_size, min_mapq, min_cov, max_mean_depth, flag_mask, max_span_hint, step)
         self._chk(self._lib.gd_set_params(self._ctx, C.byref(p)))
         self.params = p
+
+    def set_path(self, path: int):
+        """PATH_AUTO / PATH_TILE / PATH_SCATTER (include/goleft_depth.h GD_PATH_*)."""
+        self._chk(self._lib.gd_set_path(self._ctx, int(path)))
 
     def set_contigs(self, lengths: Sequence[int]):
         a = np.asarray(lengths, dtype=np.int64)

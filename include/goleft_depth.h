@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define GD_ABI_VERSION 1
+#define GD_ABI_VERSION 2
 
 typedef enum {
     GD_OK = 0,
@@ -106,10 +106,25 @@ typedef struct {
     int32_t  lookback;       /* look-back span in use */
     int32_t  max_span_seen;  /* largest reference span among kept reads */
     int32_t  reruns;         /* times the last gd_compute re-ran (span / run capacity) */
+    int32_t  path;           /* GD_PATH_TILE or GD_PATH_SCATTER: what the last gd_compute ran */
+    int32_t  reserved;
 } gd_stats;
 
-/* Kernel ids for gd_kernel_ms. */
-enum { GD_K_PREP = 0, GD_K_TILE = 1, GD_K_RUNS = 2, GD_K_COUNT = 3 };
+/* Kernel ids for gd_kernel_ms.  Tile path: PREP, TILE, RUNS.  Scatter path:
+ * PREP (zero-fill + init), EXPAND (CIGAR expand + scatter), SCAN (in-place scan
+ * + window / class reductions), RUNS. */
+enum { GD_K_PREP = 0, GD_K_TILE = 1, GD_K_RUNS = 2, GD_K_EXPAND = 3, GD_K_SCAN = 4, GD_K_COUNT = 5 };
+
+/* Device algorithm of gd_compute.  Both are bit exact; they differ in cost.
+ *   TILE     one workgroup per 4096-position tile re-examines the reads that
+ *            start within one maximum read span before it (LDS difference
+ *            array, fused scan): the short-read path, ~6.5 HBM bytes per base;
+ *   SCATTER  every CIGAR op is expanded once and scattered with global integer
+ *            atomics, then one in-place scan pass: no dependence on read span,
+ *            the path for long reads (ONT/PacBio) and spliced alignments;
+ *   AUTO     SCATTER when records average more than 6 CIGAR ops or a read spans
+ *            more than 32768 reference bases, else TILE (default). */
+enum { GD_PATH_AUTO = 0, GD_PATH_TILE = 1, GD_PATH_SCATTER = 2 };
 
 const char* gd_strerror(int status);
 int         gd_abi_version(void);
@@ -126,6 +141,8 @@ int gd_set_stream(gd_ctx* ctx, void* hip_stream);
 
 int gd_set_params(gd_ctx* ctx, const gd_params* p);
 int gd_default_params(gd_params* p);
+/* Choose the device algorithm (GD_PATH_*); default GD_PATH_AUTO. */
+int gd_set_path(gd_ctx* ctx, int path);
 
 /* Reference sequence table (@SQ LN of the BAM header / .fai lengths,
  * depth/depth.go:134-149).  Drops all records and results. */

@@ -8,8 +8,21 @@ from oracle import pyoracle as po
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(scope="module", params=["tile", "scatter"])
+def eng(request):
+    """Every parity test runs on both device algorithms (GD_PATH_TILE: LDS tiles
+    with look-back, the short-read path; GD_PATH_SCATTER: global scatter + in-place
+    scan, the long-read path)."""
+    from goleft_amd.engine import DepthEngine, PATH_SCATTER, PATH_TILE
+    e = DepthEngine(0)
+    e.set_path(PATH_TILE if request.param == "tile" else PATH_SCATTER)
+    e.path_name = request.param
+    yield e
+    e.close()
+
+
 @pytest.fixture(scope="module")
-def eng():
+def auto_eng():
     from goleft_amd.engine import DepthEngine
     e = DepthEngine(0)
     yield e
@@ -83,6 +96,7 @@ def test_synthetic_short_reads(eng):
     check_all(eng, contigs, {0: r}, 1000, 1, 4, 0)
     st = eng.stats()
     assert st.n_reads == n and st.reruns == 0
+    assert st.path == (1 if eng.path_name == "tile" else 2)
 
 
 def _uniform_reads(pos, length, flag=0, mapq=60):
@@ -127,6 +141,8 @@ def test_many_batches_staged_boundary(eng):
 def test_lookback_adapts_and_stays_exact(eng):
     """The look-back shrinks after a compute whose longest read is far below it,
     grows again (one re-run) when longer reads arrive, and results stay exact."""
+    if eng.path_name != "tile":
+        pytest.skip("the look-back exists only on the tile path")
     rng = np.random.default_rng(3)
     L = 200000
     short = _uniform_reads(np.sort(rng.integers(0, L // 2, size=30000)), 50)
@@ -163,6 +179,43 @@ def test_read_span_limit_is_an_error(eng):
     eng.set_params(window_size=1000, min_mapq=1, min_cov=4)
     eng.set_contigs([L])
     eng.push(0, r.pos, r.flag, r.mapq, r.cigar_off, r.cigar)
-    with pytest.raises(GdError) as ei:
+    if eng.path_name == "tile":
+        with pytest.raises(GdError) as ei:
+            eng.compute()
+        assert ei.value.status == -5      # GD_E_RANGE
+    else:                                 # the scatter path has no span limit
         eng.compute()
-    assert ei.value.status == -5      # GD_E_RANGE
+        check_all(eng, [("c", L)], {0: r}, 1000, 1, 4, 0)
+
+
+def test_auto_path_switches_on_long_spans(auto_eng):
+    """GD_PATH_AUTO: short reads run on the tile path; a read spanning more than
+    32768 bases moves the data set to the scatter path (one re-run), CIGAR-heavy
+    records start there."""
+    eng = auto_eng
+    rng = np.random.default_rng(17)
+    L = 300000
+    short = _uniform_reads(np.sort(rng.integers(0, L - 200, size=20000)), 150)
+    contigs = [("c", L)]
+    run_engine(eng, contigs, {0: short}, window_size=250, min_mapq=1, min_cov=4)
+    assert eng.stats().path == 1
+    check_all(eng, contigs, {0: short}, 250, 1, 4, 0)
+    # one spliced read with a 60 kb N skip
+    off = np.array([0, 3], np.uint32)
+    cig = np.array([(50 << 4) | 0, (60000 << 4) | 3, (70 << 4) | 0], np.uint32)
+    spliced = po.Reads(np.array([1000], np.int32), np.zeros(1, np.uint16), np.full(1, 60, np.uint8), off, cig)
+    mixed = po.Reads(np.concatenate([spliced.pos, short.pos[short.pos >= 1000]]),
+                     np.concatenate([spliced.flag, short.flag[short.pos >= 1000]]),
+                     np.concatenate([spliced.mapq, short.mapq[short.pos >= 1000]]),
+                     np.concatenate([[0], 3 + np.arange(0, (short.pos >= 1000).sum() + 1)]).astype(np.uint32),
+                     np.concatenate([cig, short.cigar[short.pos >= 1000]]))
+    run_engine(eng, contigs, {0: mixed}, window_size=250, min_mapq=1, min_cov=4)
+    st = eng.stats()
+    assert st.path == 2 and st.reruns == 1
+    check_all(eng, contigs, {0: mixed}, 250, 1, 4, 0)
+    # records averaging more than 6 ops go to the scatter path directly
+    heavy = H.random_reads(rng, L, 5000, max_ops=40)
+    run_engine(eng, contigs, {0: heavy}, window_size=250, min_mapq=1, min_cov=4)
+    st = eng.stats()
+    assert st.path == 2 and st.reruns == 0
+    check_all(eng, contigs, {0: heavy}, 250, 1, 4, 0)
