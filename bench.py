@@ -44,8 +44,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="wgs", choices=["wgs", "chr20"])
-    ap.add_argument("--coverage", type=float, default=30.0)
+    ap.add_argument("--workload", default="wgs", choices=["wgs", "chr20", "ont", "ont-chr20"],
+                    help="wgs/chr20: 30x 150 bp short reads (headline); ont/ont-chr20: 20x long reads "
+                         "(BASELINE.json config 5, scatter path)")
+    ap.add_argument("--coverage", type=float, default=None)
     ap.add_argument("--window", type=int, default=1000)
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -106,15 +108,19 @@ def run_case(args, scaling, world, rank, dev, local_rank, want_streams=False):
     import torch
     import torch.distributed as dist
     from goleft_amd import shard, synth
-    from goleft_amd.engine import DepthEngine, K_PREP, K_TILE, K_RUNS
+    from goleft_amd.engine import DepthEngine, K_PREP, K_TILE, K_RUNS, K_EXPAND, K_SCAN
 
-    if args.workload == "wgs":
+    ont = args.workload.startswith("ont")
+    if args.workload in ("wgs", "ont"):
         names1, lengths1 = list(synth.HG19_NAMES), list(synth.HG19_LENGTHS)
         seeds1 = list(range(1, len(lengths1) + 1))
         wname = "synthetic 30x WGS, hg19 contig lengths (3.1 Gb), 150 bp reads"
     else:
         names1, lengths1, seeds1 = ["chr20"], [synth.CHR20_LEN], [20]
         wname = "synthetic 30x chr20 (63 Mb), 150 bp reads"
+    if ont:
+        wname = wname.replace("30x", "%gx ONT-like" % args.coverage).replace(
+            "150 bp reads", "long reads (length-weighted median ~20 kb, ~1 CIGAR op per 13 aligned bases)")
     n_samples = world if scaling == "weak" else 1
     # the cohort is laid out as one reference of n_samples x contigs units
     names = ["s%d.%s" % (k, nm) for k in range(n_samples) for nm in names1] if n_samples > 1 else names1
@@ -132,8 +138,12 @@ def run_case(args, scaling, world, rank, dev, local_rank, want_streams=False):
     n_reads = n_ops = 0
     streams = {}
     for t in mine:
-        n = synth.n_reads_for(lengths[t], args.coverage)
-        s = synth.short_reads_torch(lengths[t], n, seeds[t], dev)
+        if ont:
+            n = synth.n_ont_reads_for(lengths[t], args.coverage)
+            s = synth.ont_reads_torch(lengths[t], n, seeds[t], dev)
+        else:
+            n = synth.n_reads_for(lengths[t], args.coverage)
+            s = synth.short_reads_torch(lengths[t], n, seeds[t], dev)
         eng.adopt_device(t, *s)
         streams[t] = s
         n_reads += n
@@ -150,7 +160,7 @@ def run_case(args, scaling, world, rank, dev, local_rank, want_streams=False):
 
     for _ in range(args.warmup):
         step()
-    tile_ms, prep_ms, runs_ms = [], [], []
+    tile_ms, prep_ms, runs_ms, expand_ms, scan_ms = [], [], [], [], []
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -160,6 +170,8 @@ def run_case(args, scaling, world, rank, dev, local_rank, want_streams=False):
         tile_ms.append(eng.kernel_ms(K_TILE))
         prep_ms.append(eng.kernel_ms(K_PREP))
         runs_ms.append(eng.kernel_ms(K_RUNS))
+        expand_ms.append(eng.kernel_ms(K_EXPAND))
+        scan_ms.append(eng.kernel_ms(K_SCAN))
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -179,6 +191,7 @@ def run_case(args, scaling, world, rank, dev, local_rank, want_streams=False):
         "n_samples": n_samples, "W": W, "Q": Q, "mincov": mincov,
         "tile_ms": float(np.mean(tile_ms)), "prep_ms": float(np.mean(prep_ms)),
         "runs_ms": float(np.mean(runs_ms)), "tile_positions": st.tile_positions, "lookback": st.lookback,
+        "expand_ms": float(np.mean(expand_ms)), "scan_ms": float(np.mean(scan_ms)), "path": int(st.path),
     }
     if not want_streams:
         streams.clear()
@@ -187,6 +200,8 @@ def run_case(args, scaling, world, rank, dev, local_rank, want_streams=False):
 
 def main():
     args = parse()
+    if args.coverage is None:
+        args.coverage = 20.0 if args.workload.startswith("ont") else 30.0
     import torch
     import torch.distributed as dist
     from goleft_amd import synth
@@ -210,11 +225,13 @@ def main():
     value = r["total_bases"] * args.steps / dt
     # roofline of the dominant kernel (gd_tile_kernel), this rank's launch
     alg_bytes = synth.algorithmic_bytes(r["n_reads"], r["n_ops"], r["my_bases"], r["my_windows"])
-    avg_tile_s = r["tile_ms"] * 1e-3
+    scatter = r["path"] == 2
+    # tile path: gd_tile_kernel does all the arithmetic; scatter path: expand + scan share it
+    avg_tile_s = (r["expand_ms"] + r["scan_ms"] if scatter else r["tile_ms"]) * 1e-3
     achieved = alg_bytes / avg_tile_s / 1e9
     traffic = None
     tr = load_traffic()
-    if tr and world == 1 and args.workload == "wgs" and args.coverage == 30.0:
+    if tr and world == 1 and args.workload == "wgs" and args.coverage == 30.0 and not scatter:
         traffic = tr.get("hbm_bytes_per_launch")   # measured on this exact launch shape
 
     # PCIe-inclusive rate (results to host) -- reported, never `value`
@@ -224,7 +241,8 @@ def main():
     d2h = time.perf_counter() - t1
 
     out = {
-        "metric": "ref bases/sec per-base depth, 30x WGS synthetic",
+        "metric": "ref bases/sec per-base depth, 30x WGS synthetic" if not args.workload.startswith("ont")
+                  else "ref bases/sec per-base depth, 20x ONT-like synthetic",
         "value": value,
         "unit": "ref-bases/s",
         "n_gpus": world,
@@ -243,13 +261,16 @@ def main():
                    "reads_rank0": r["n_reads"], "cigar_ops_rank0": r["n_ops"],
                    "sharding": "by chromosome, LPT" if world > 1 else "single GPU",
                    "outputs": "int32 per-base depth + int64/int32 window sum/min + class runs",
-                   "tile_positions": r["tile_positions"], "lookback": r["lookback"]},
+                   "tile_positions": r["tile_positions"], "lookback": r["lookback"],
+                   "device_path": "scatter" if scatter else "tile"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                     "kernel": "gd_tile_kernel", "avg_kernel_ms": avg_tile_s * 1e3,
+                     "kernel": "gd_expand_scatter_kernel+gd_scan_kernel" if scatter else "gd_tile_kernel",
+                     "avg_kernel_ms": avg_tile_s * 1e3,
                      "algorithmic_bytes_per_launch": alg_bytes,
                      "bytes_per_ref_base": alg_bytes / r["my_bases"]},
-        "kernels_ms": {"prep": r["prep_ms"], "tile": r["tile_ms"], "runs": r["runs_ms"]},
+        "kernels_ms": ({"prep": r["prep_ms"], "expand": r["expand_ms"], "scan": r["scan_ms"], "runs": r["runs_ms"]}
+                       if scatter else {"prep": r["prep_ms"], "tile": r["tile_ms"], "runs": r["runs_ms"]}),
         "with_d2h_windows_ref_bases_per_s": r["my_bases"] / (dt / args.steps + d2h) if world == 1 else None,
     }
     if traffic:

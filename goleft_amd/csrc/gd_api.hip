@@ -72,6 +72,7 @@ struct gd_ctx {
     int tile_opt = 0;                   // GOLEFT_GD_OPT bit 0: non-temporal per-base stores
     bool lookback_pinned = false;       // max_span_hint given: never shrink below it
     int path = GD_PATH_AUTO;            // gd_set_path / GOLEFT_GD_PATH
+    bool scope_wg = false;              // debug: GOLEFT_GD_SCOPE=wg (wrong results, timing only)
     bool span_forces_scatter = false;   // AUTO: the tile path met a read too long for it
     unsigned long long* d_status = nullptr;  size_t cap_status = 0;   // scatter path look-back words
     int lookback = kDefaultLookback;
@@ -269,6 +270,7 @@ int gd_create(int device_id, gd_ctx** out)
     if (const char* e = getenv("GOLEFT_GD_ABLATE")) c->ablate = atoi(e);
     if (const char* e = getenv("GOLEFT_GD_KERNEL")) c->kernel_gen = (e[0] == 'v' && e[1] == '5') ? 5 : 6;
     if (const char* e = getenv("GOLEFT_GD_OPT")) c->tile_opt = atoi(e) & 1;
+    if (const char* e = getenv("GOLEFT_GD_SCOPE")) c->scope_wg = e[0] == 'w';
     if (const char* e = getenv("GOLEFT_GD_PATH"))
         c->path = e[0] == 's' ? GD_PATH_SCATTER : (e[0] == 't' ? GD_PATH_TILE : GD_PATH_AUTO);
     if (const char* e = getenv("GOLEFT_GD_THREADS")) {
@@ -717,7 +719,10 @@ int gd_compute(gd_ctx* c)
             if (n_units) {
                 const uint64_t groups = (n_units + 3) / 4;
                 const unsigned grid = (unsigned)(((groups + 7) / 8) * 8);
-                hipLaunchKernelGGL(gd::gd_expand_scatter_kernel, dim3(grid), dim3(256), 0, c->stream, job);
+                if (c->scope_wg)   // timing experiment only: not coherent across XCDs
+                    hipLaunchKernelGGL(gd::gd_expand_scatter_kernel<true>, dim3(grid), dim3(256), 0, c->stream, job);
+                else
+                    hipLaunchKernelGGL(gd::gd_expand_scatter_kernel<false>, dim3(grid), dim3(256), 0, c->stream, job);
             }
             if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
             if (T == 8192)

@@ -38,12 +38,14 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan_sat(uint32_t v)
     return v;
 }
 
-// +1 at s, -1 at e for the counted interval [s, e) of a contig of length clen.
-__device__ __forceinline__ void scatter_interval(int32_t* diff, uint32_t s, uint32_t e, uint32_t clen)
+// One +-1 mark of the difference array.  SCOPE_WG (timing experiments only) uses
+// workgroup-scope atomics, which are NOT coherent across XCDs.
+template <bool SCOPE_WG>
+__device__ __forceinline__ void scatter_mark(int32_t* diff, uint32_t p, int v, uint32_t clen)
 {
-    if (s < clen) {
-        atomicAdd(&diff[s], 1);
-        if (e < clen) atomicAdd(&diff[e], -1);
+    if (p < clen) {
+        if (SCOPE_WG) __hip_atomic_fetch_add(&diff[p], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        else          __hip_atomic_fetch_add(&diff[p], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -67,6 +69,13 @@ __global__ void gd_linit_kernel(Job job)
 }
 
 // LK1: one wave per unit of 64 consecutive reads of one contig.
+//
+// A read contributes +1 on every maximal run of counted ops (M/=/X) that is
+// not interrupted by reference-consuming uncounted ops (D/N of positive
+// length): insertions, clips and pads between two matches leave the intervals
+// adjacent, and adjacent intervals need no marks at the shared edge.  So a
+// read costs 2 x (number of deletions/skips + 1) atomics, not 2 per match op.
+template <bool SCOPE_WG>
 __global__ __launch_bounds__(256) void gd_expand_scatter_kernel(Job job)
 {
     // XCD-contiguous order (workgroup b runs on XCD b % 8): neighbouring units
@@ -106,21 +115,25 @@ __global__ __launch_bounds__(256) void gd_expand_scatter_kernel(Job job)
     // ---- short CIGARs: each lane walks its own read ---------------------
     if (keep && n <= SHORT_OPS) {
         uint32_t cur = p;
+        bool open = false;                                // inside a run of counted ops
         for (uint32_t k = 0; k < n; ++k) {
             const uint32_t cg = cigar[o0 + k];
             const uint32_t op = cg & 0xf, len = cg >> 4;
             const bool counted = (0x181u >> op) & 1u;     // M = X
             const bool consumes = (0x18du >> op) & 1u;    // M D N = X
-            if (counted && len != 0) {
-                const uint32_t e = cur + len;             // cur <= 2^31-1, len < 2^28: no wrap
-                scatter_interval(diff, cur, e, clen);
+            if (len != 0) {
+                if (counted && !open) { scatter_mark<SCOPE_WG>(diff, cur, 1, clen); open = true; }
+                if (consumes && !counted && open) { scatter_mark<SCOPE_WG>(diff, cur, -1, clen); open = false; }
+                if (consumes) { cur += len; cur = cur < POS_CAP ? cur : POS_CAP; }
             }
-            if (consumes) { cur += len; cur = cur < POS_CAP ? cur : POS_CAP; }
         }
+        if (open) scatter_mark<SCOPE_WG>(diff, cur, -1, clen);
     }
 
     // ---- long CIGARs: the wave expands one read at a time, 64 ops per round
     unsigned long long todo = __ballot(keep && n > SHORT_OPS);
+    const unsigned long long below = lane == 0 ? 0ull : (~0ull >> (64 - lane));     // lanes < lane
+    const unsigned long long above = lane == 63 ? 0ull : (~0ull << (lane + 1));     // lanes > lane
     while (todo != 0ull) {
         const int j = __ffsll((long long)todo) - 1;
         todo &= todo - 1ull;
@@ -132,13 +145,24 @@ __global__ __launch_bounds__(256) void gd_expand_scatter_kernel(Job job)
             const uint32_t k = b + (uint32_t)lane;
             const uint32_t cg = k < nj ? cigar[oj + k] : 0u;   // a zero-length M: contributes nothing
             const uint32_t op = cg & 0xf, len = cg >> 4;
-            const bool counted = (0x181u >> op) & 1u;
-            const bool consumes = (0x18du >> op) & 1u;
+            const bool counted = ((0x181u >> op) & 1u) && len != 0;
+            const bool consumes = ((0x18du >> op) & 1u) && len != 0;
             const uint32_t cons = consumes ? len : 0u;
             const uint32_t incl = wave_inclusive_scan_sat(cons);
             uint32_t s = carry + (incl - cons);            // <= 2 * POS_CAP: no wrap
             s = s < POS_CAP ? s : POS_CAP;
-            if (counted && len != 0) scatter_interval(diff, s, s + len, clen);
+            // runs of counted ops inside this round; a run is closed at the round's end
+            // (the +1 of its continuation lands on the same position and cancels)
+            const unsigned long long cm = __ballot(counted);
+            const unsigned long long nn = cm | __ballot(consumes);       // non-neutral ops
+            if (counted) {
+                const unsigned long long pm = nn & below;
+                const bool prev_counted = pm != 0ull && ((cm >> (63 - __builtin_clzll(pm))) & 1ull);
+                const unsigned long long nm = nn & above;
+                const bool next_counted = nm != 0ull && ((cm >> (__builtin_ffsll((long long)nm) - 1)) & 1ull);
+                if (!prev_counted) scatter_mark<SCOPE_WG>(diff, s, 1, clen);
+                if (!next_counted) scatter_mark<SCOPE_WG>(diff, s + len, -1, clen);
+            }
             carry += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
             carry = carry < POS_CAP ? carry : POS_CAP;
             if (carry >= clen) break;                      // the rest of the read lies past the contig

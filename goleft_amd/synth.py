@@ -172,3 +172,108 @@ def algorithmic_bytes(n_reads: int, n_ops: int, n_bases: int, n_windows: int) ->
     """4*reads(pos) + 4*reads(CSR offsets, read on device)
     + 4*ops + 4*bases (int32 per-base write) + 8*windows (int64 sums)."""
     return 4 * n_reads + 4 * n_reads + 4 * n_ops + 4 * n_bases + 8 * n_windows
+
+
+# ---------------------------------------------------------------------------
+# Long-read model (BASELINE.json config 5: 20x ONT, N50 ~ 20 kb, indel-heavy)
+# ---------------------------------------------------------------------------
+# Integer-only, so numpy and torch agree bit for bit:
+#   * aligned length of a read = entry (u % 1024) of a 1024-point quantile table
+#     of the log-normal(mu = ln 20000 - sigma^2, sigma = 0.8) (built once with
+#     numpy on the host for both backends), i.e. length-weighted median ~20 kb;
+#   * CIGAR = S, then k alternating runs  M (1..49, mean 25)  and  I or D (1:1;
+#     length 1..5 with P = .60 .24 .10 .04 .02, mean 1.64), then S;
+#     k = max(1, aligned length // 27) match runs => ~1 op per 13 aligned bases;
+#   * flags: 10 % SUPPLEMENTARY (counted by samtools depth), 3 % SECONDARY
+#     (dropped); MAPQ 0 for 2 %, else 60; starts uniform, sorted; every other
+#     attribute is a function of the sorted rank / the global op index.
+ONT_SIGMA = 0.8
+ONT_MEDIAN_W = 20000.0
+_ONT_TABLE = None
+
+
+def ont_length_table() -> np.ndarray:
+    """1024 quantiles of the aligned-length distribution (int64, >= 200)."""
+    global _ONT_TABLE
+    if _ONT_TABLE is None:
+        from statistics import NormalDist
+        mu = np.log(ONT_MEDIAN_W) - ONT_SIGMA ** 2
+        q = (np.arange(1024) + 0.5) / 1024.0
+        z = np.array([NormalDist().inv_cdf(float(x)) for x in q])
+        _ONT_TABLE = np.maximum(200, np.exp(mu + ONT_SIGMA * z)).astype(np.int64)
+    return _ONT_TABLE
+
+
+def ont_mean_length() -> float:
+    t = ont_length_table()
+    k = np.maximum(1, t // 27)
+    return float((k * 25 + (k - 1) * 0.5 * 1.64).mean())     # M bases + D bases per read
+
+
+def n_ont_reads_for(length: int, coverage: float = 20.0) -> int:
+    return max(1, int(round(length * coverage / ont_mean_length())))
+
+
+def ont_reads_numpy(length: int, n: int, seed: int):
+    """Returns (pos i32, flag u16, mapq u8, cigar_off u32, cigar u32)."""
+    idx = np.arange(n, dtype=np.uint64)
+    pos = np.sort(_np_u(idx, seed, 11, max(1, length))).astype(np.int32)
+    tab = ont_length_table()
+    alen = tab[_np_u(idx, seed, 12, 1024)]
+    k = np.maximum(1, alen // 27)
+    nops = 2 * k + 1                                   # S (M x)* M S  with k M runs
+    off = np.zeros(n + 1, np.int64)
+    np.cumsum(nops, out=off[1:])
+    m = int(off[-1])
+    rid = np.repeat(np.arange(n, dtype=np.int64), nops)
+    j = np.arange(m, dtype=np.int64)
+    i = j - off[rid]
+    last = nops[rid] - 1
+    u = (_np_mix(j.astype(np.uint64), seed, 13) >> np.uint64(11)).astype(np.int64)
+    cigar = _ont_ops(np, i, last, u).astype(np.uint32)
+    f5 = _np_u(idx, seed, 14, 1000)
+    flag = (np.where(f5 < 100, 0x800, 0) + np.where((f5 >= 100) & (f5 < 130), 0x100, 0) +
+            (f5 % 2) * 0x10).astype(np.uint16)
+    mapq = np.where(_np_u(idx, seed, 15, 100) < 2, 0, 60).astype(np.uint8)
+    return pos, flag, mapq, off.astype(np.uint32), cigar
+
+
+def ont_reads_torch(length: int, n: int, seed: int, device):
+    """Device twin of ont_reads_numpy (pos i32, flag i16, mapq u8, cigar_off i32, cigar i32)."""
+    import torch
+    idx = torch.arange(n, dtype=torch.int64, device=device)
+    pos = torch.sort(_t_lsr(_t_mix(idx, seed, 11), 11) % max(1, length)).values.to(torch.int32)
+    tab = torch.from_numpy(ont_length_table()).to(device)
+    alen = tab[_t_lsr(_t_mix(idx, seed, 12), 11) % 1024]
+    k = torch.clamp(alen // 27, min=1)
+    nops = 2 * k + 1
+    off = torch.zeros(n + 1, dtype=torch.int64, device=device)
+    torch.cumsum(nops, 0, out=off[1:])
+    m = int(off[-1].item())
+    rid = torch.repeat_interleave(torch.arange(n, dtype=torch.int64, device=device), nops, output_size=m)
+    j = torch.arange(m, dtype=torch.int64, device=device)
+    i = j - off[rid]
+    last = nops[rid] - 1
+    del rid
+    u = _t_lsr(_t_mix(j, seed, 13), 11)
+    del j
+    cigar = _ont_ops(torch, i, last, u).to(torch.int32)
+    del i, last, u
+    f5 = _t_lsr(_t_mix(idx, seed, 14), 11) % 1000
+    flag = (torch.where(f5 < 100, 0x800, 0) + torch.where((f5 >= 100) & (f5 < 130), 0x100, 0) +
+            (f5 % 2) * 0x10).to(torch.int16)
+    mapq = torch.where(_t_lsr(_t_mix(idx, seed, 15), 11) % 100 < 2, 0, 60).to(torch.uint8)
+    return pos, flag, mapq, off.to(torch.int32), cigar
+
+
+def _ont_ops(xp, i, last, u):
+    """BAM-encoded op for local index i of a read with `last`+1 ops; u = 53 random bits."""
+    M, I, D, S = 0, 1, 2, 4
+    clip = (i == 0) | (i == last)
+    is_m = (i % 2) == 1
+    m_len = 1 + u % 49
+    g = (u >> 8) % 100
+    id_len = 1 + (g >= 60) * 1 + (g >= 84) * 1 + (g >= 94) * 1 + (g >= 98) * 1
+    id_op = xp.where(((u >> 20) & 1) == 1, xp.full_like(i, I), xp.full_like(i, D))
+    s_len = 1 + (u >> 24) % 200
+    return xp.where(clip, (s_len << 4) | S, xp.where(is_m, (m_len << 4) | M, (id_len << 4) | id_op))

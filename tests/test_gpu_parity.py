@@ -219,3 +219,24 @@ def test_auto_path_switches_on_long_spans(auto_eng):
     st = eng.stats()
     assert st.path == 2 and st.reruns == 0
     check_all(eng, contigs, {0: heavy}, 250, 1, 4, 0)
+
+
+def test_synthetic_ont_long_reads(eng):
+    """BASELINE.json config 5 in small: ~14 kb reads, ~1000 CIGAR ops each."""
+    from goleft_amd import synth
+    L = 1_500_000
+    n = synth.n_ont_reads_for(L)
+    r = po.Reads(*synth.ont_reads_numpy(L, n, 9))
+    contigs = [("chrL", L), ("chrM2", 70000)]
+    r2 = po.Reads(*synth.ont_reads_numpy(70000, 40, 10))
+    run_engine(eng, contigs, {0: r, 1: r2}, window_size=1000, min_mapq=1, min_cov=4)
+    check_all(eng, contigs, {0: r, 1: r2}, 1000, 1, 4, 0)
+
+
+def test_auto_path_picks_scatter_for_ont(auto_eng):
+    from goleft_amd import synth
+    L = 400_000
+    r = po.Reads(*synth.ont_reads_numpy(L, synth.n_ont_reads_for(L), 4))
+    run_engine(auto_eng, [("c", L)], {0: r}, window_size=250, min_mapq=1, min_cov=4)
+    assert auto_eng.stats().path == 2 and auto_eng.stats().reruns == 0
+    check_all(auto_eng, [("c", L)], {0: r}, 250, 1, 4, 0)
