@@ -19,6 +19,9 @@ SYMBOLS = {
     "gdh_step": (C.c_int64, [C.c_int32]),
     "gdh_format_region": (C.c_int, [C.c_char_p, C.c_int64, C.c_int64, C.c_int32, _P, C.c_size_t,
                                     _P, C.c_size_t, C.c_char_p, C.c_char_p]),
+    "gdh_depthwed_main": (C.c_int, [C.c_int, C.POINTER(C.c_char_p)]),
+    "gdh_depthwed_run": (C.c_int, [C.c_int64, C.POINTER(C.c_char_p), C.c_int, C.c_char_p]),
+    "gdh_depthwed_cells": (None, [_P, _P, C.c_size_t, _P]),
     "gdh_bam_open": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(_P)]),
     "gdh_bam_close": (None, [_P]),
     "gdh_bam_error": (C.c_char_p, [_P]),

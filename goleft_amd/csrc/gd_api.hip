@@ -957,6 +957,67 @@ int gd_region_callable(gd_ctx* c, int32_t tid, int64_t start, int64_t end, gd_ru
     }
 }
 
+int gd_depthwed(gd_ctx* c, int n_samples, int n_ctg, const int32_t* tids, int64_t size,
+                int64_t* cells, int32_t* row_ctg, int64_t* row_start, int64_t* row_end,
+                size_t cap_rows, size_t* n_rows)
+{
+    if (!c || !n_rows || n_samples < 1 || n_ctg < 1 || !tids || size < 1) return GD_E_INVALID;
+    if (int r = set_device(c)) return r;
+    if (!c->computed) return fail(c, GD_E_STATE, "no results: call gd_compute first");
+    const int64_t W = c->params.window_size;
+    const int64_t group = (size + W - 1) / W;      // depthwed.go:126: rows until span >= size
+    std::vector<int64_t> off((size_t)n_samples * n_ctg), nwin(n_ctg), clen(n_ctg), row_beg(n_ctg + 1);
+    int64_t rows = 0;
+    for (int j = 0; j < n_ctg; ++j) {
+        for (int s = 0; s < n_samples; ++s) {
+            const int32_t tid = tids[(size_t)s * n_ctg + j];
+            if (int r = check_result_tid(c, tid)) return r;
+            const ContigHost& h = c->contigs[tid];
+            if (s == 0) { clen[j] = h.length; nwin[j] = h.n_win; }
+            else if (h.length != clen[j])
+                return fail(c, GD_E_INVALID, "sample %d contig %d: length %lld differs from sample 0 (%lld)",
+                            s, j, (long long)h.length, (long long)clen[j]);
+            off[(size_t)s * n_ctg + j] = h.win_off < 0 ? 0 : h.win_off;
+        }
+        row_beg[j] = rows;
+        rows += (nwin[j] + group - 1) / group;
+    }
+    row_beg[n_ctg] = rows;
+    *n_rows = (size_t)rows;
+    if (rows == 0) return GD_OK;
+    if (cap_rows < (size_t)rows || !cells) return fail(c, GD_E_CAPACITY, "need room for %lld rows", (long long)rows);
+    for (int j = 0; j < n_ctg; ++j)
+        for (int64_t r = 0; r < row_beg[j + 1] - row_beg[j]; ++r) {
+            const int64_t k = row_beg[j] + r;
+            if (row_ctg) row_ctg[k] = j;
+            if (row_start) row_start[k] = r * group * W;
+            if (row_end) row_end[k] = std::min<int64_t>((r + 1) * group * W, clen[j]);
+        }
+    // small tables + the matrix live in one scratch allocation
+    const size_t n_tab = off.size() + nwin.size() + clen.size() + row_beg.size();
+    const size_t n_cells = (size_t)rows * (size_t)n_samples;
+    int64_t* d = nullptr;
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&d), (n_tab + n_cells) * sizeof(int64_t)));
+    std::vector<int64_t> tab;
+    tab.reserve(n_tab);
+    tab.insert(tab.end(), off.begin(), off.end());
+    tab.insert(tab.end(), nwin.begin(), nwin.end());
+    tab.insert(tab.end(), clen.begin(), clen.end());
+    tab.insert(tab.end(), row_beg.begin(), row_beg.end());
+    gd::WedJob j{};
+    j.win_sum = c->d_wsum;
+    j.off = d; j.nwin = d + off.size(); j.clen = j.nwin + nwin.size(); j.row_beg = j.clen + clen.size();
+    j.cells = d + n_tab;
+    j.n_samples = n_samples; j.n_ctg = n_ctg; j.n_rows = rows; j.W = W; j.group = group;
+    hipError_t e1 = hipMemcpyAsync(d, tab.data(), n_tab * sizeof(int64_t), hipMemcpyHostToDevice, c->stream);
+    hipLaunchKernelGGL(gd::gd_depthwed_kernel, dim3((unsigned)((n_cells + 255) / 256)), dim3(256), 0, c->stream, j);
+    hipError_t e2 = hipMemcpyAsync(cells, j.cells, n_cells * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream);
+    hipError_t e3 = hipStreamSynchronize(c->stream);
+    (void)hipFree(d);
+    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) return fail(c, GD_E_HIP, "depthwed matrix kernel failed");
+    return GD_OK;
+}
+
 int gd_device_perbase(gd_ctx* c, int32_t tid, const int32_t** dptr, int64_t* len)
 {
     if (!c || !dptr) return GD_E_INVALID;

@@ -251,6 +251,7 @@ __device__ __forceinline__ int wave_min(int v)
 
 #include "gd_tile_v6.hpp"
 #include "gd_scatter.hpp"
+#include "gd_depthwed.hpp"
 #include "gd_tile_v5.hpp"
 
 namespace gd {

@@ -1,6 +1,7 @@
 // goleft-depth: the `depth` entry of the reference's dispatcher
 // (/root/reference/cmd/goleft/goleft.go:25-32,:55-69) as a C++ executable.
 //   goleft-depth [flags] BAM          or          goleft-depth depth [flags] BAM
+//   goleft-depth depthwed -s SIZE a.depth.bed b.depth.bed ...   (the consumer of depth.bed files)
 #include <cstring>
 #include <vector>
 
@@ -9,6 +10,11 @@
 int main(int argc, char** argv)
 {
     std::vector<const char*> av;
+    if (argc > 1 && strcmp(argv[1], "depthwed") == 0) {
+        av.push_back("goleft depthwed");
+        for (int i = 2; i < argc; ++i) av.push_back(argv[i]);
+        return gdh_depthwed_main((int)av.size(), av.data());
+    }
     av.push_back("goleft depth");
     int first = 1;
     if (argc > 1 && strcmp(argv[1], "depth") == 0) first = 2;

@@ -186,6 +186,26 @@ class DepthEngine:
     def region_callable(self, tid: int, start: int, end: int) -> np.ndarray:
         return self._runs(self._lib.gd_region_callable, tid, start, end)
 
+    def depthwed(self, tids, size: int):
+        """Sites x samples matrix of `goleft depthwed -s size`.  tids: [n_samples][n_ctg]
+        engine contigs.  Returns (cells int64 [rows, samples], row_ctg, row_start, row_end)."""
+        t = np.ascontiguousarray(tids, np.int32)
+        assert t.ndim == 2
+        ns, nc = t.shape
+        n = C.c_size_t()
+        rc = self._lib.gd_depthwed(self._ctx, ns, nc, t.ctypes.data, size, None, None, None, None, 0, C.byref(n))
+        if rc not in (0, -8):
+            self._chk(rc)
+        rows = n.value
+        cells = np.empty((rows, ns), np.int64)
+        ctg = np.empty(rows, np.int32)
+        st = np.empty(rows, np.int64)
+        en = np.empty(rows, np.int64)
+        if rows:
+            self._chk(self._lib.gd_depthwed(self._ctx, ns, nc, t.ctypes.data, size, cells.ctypes.data,
+                                            ctg.ctypes.data, st.ctypes.data, en.ctypes.data, rows, C.byref(n)))
+        return cells, ctg, st, en
+
     def device_windows(self):
         """(ptr_sums, ptr_mins, n_total) device views of the concatenated window arrays."""
         ps, pm, n = C.c_void_p(), C.c_void_p(), C.c_size_t()

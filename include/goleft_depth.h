@@ -209,6 +209,21 @@ int gd_region_windows(gd_ctx* ctx, int32_t tid, int64_t start, int64_t end,
 int gd_region_callable(gd_ctx* ctx, int32_t tid, int64_t start, int64_t end,
                        gd_run* out, size_t cap, size_t* n);
 
+/* ---- depthwed on device (depthwed/depthwed.go; BASELINE.json config 4) -----
+ * A cohort is loaded as n_samples x n_ctg contigs of ONE context (tids[s*n_ctg+j]
+ * = engine contig holding sample s, reference contig j; the n_samples contigs of
+ * one j must have equal length).  After gd_compute, builds the sites x samples
+ * matrix `goleft depthwed -s size` would print from the samples' depth.bed files:
+ * rows = groups of ceil(size/W) consecutive windows per contig (the last group of
+ * a contig may be shorter), cell = sum over the group's windows of
+ * int(0.5 + "%.4g"(window_sum/window_len)) -- the text round trip is reproduced
+ * exactly in arithmetic, no text is formatted.  cells is row major
+ * [n_rows][n_samples]; row_ctg/row_start/row_end (each may be NULL) describe the
+ * rows.  *n_rows receives the row count; GD_E_CAPACITY if cap_rows is too small. */
+int gd_depthwed(gd_ctx* ctx, int n_samples, int n_ctg, const int32_t* tids, int64_t size,
+                int64_t* cells, int32_t* row_ctg, int64_t* row_start, int64_t* row_end,
+                size_t cap_rows, size_t* n_rows);
+
 /* Device-side views of the results (for RCCL gathers and zero-copy
  * consumers).  Pointers stay valid until the next gd_compute/gd_reset. */
 int gd_device_perbase(gd_ctx* ctx, int32_t tid, const int32_t** dptr, int64_t* len);

@@ -45,6 +45,16 @@ int gdh_format_region(const char* chrom, int64_t region_start, int64_t region_en
                       const gd_run* runs, size_t n_runs,
                       const char* depth_path, const char* callable_path);
 
+/* ---- `goleft depthwed` (depthwed/depthwed.go): N depth.bed files -> sites x samples
+ * matrix on stdout.  argv: -s/--size SIZE BEDS...  Returns the exit code. ------- */
+int gdh_depthwed_main(int argc, const char* const* argv);
+/* Same, writing to out_path (NULL = stdout). */
+int gdh_depthwed_run(int64_t size, const char* const* paths, int n_paths, const char* out_path);
+/* The integer one depth.bed row contributes to a depthwed cell, from the window's
+ * integer sum and length: int(0.5 + parse(fmt("%.4g", sum/len))) without text
+ * (goleft_amd/csrc/gd_round4g.hpp; the device matrix kernel uses the same code). */
+void gdh_depthwed_cells(const int64_t* sums, const int64_t* lens, size_t n, int64_t* out);
+
 /* ---- BAM decode (replaces the read side of the samtools child) ---------- */
 typedef struct gdh_bam gdh_bam;
 int  gdh_bam_open(const char* path, int threads, gdh_bam** out);

@@ -332,3 +332,71 @@ def depth_run_oracle(contigs, reads_by_tid, W=250, Q=1, mincov=4, maxmean=0,
                     d[max(0, clen - s):] = 0
             callback_c(name, s, e, d, W, mincov, maxmean, hd, ca)
         return open(hd).read(), open(ca).read()
+
+
+# ---------------------------------------------------------------------------
+# depthwed (BASELINE.json config 4)
+# ---------------------------------------------------------------------------
+def depthwed_name(path: str) -> str:
+    """depthwed/depthwed.go:37-46 getNameFromFile: basename, then ONE pass that strips
+    a trailing .gz, then .bed, then .depth (in that order, each at most once)."""
+    n = path.split("/")[-1]
+    for suff in (".gz", ".bed", ".depth"):
+        if n.endswith(suff):
+            n = n[:-len(suff)]
+    return n.rstrip("\n") if n.endswith("\n") else n
+
+
+def depthwed_cell(mean_text: str) -> int:
+    """depthwed/depthwed.go:96,:103: int(0.5 + ParseFloat(tok))."""
+    return int(0.5 + float(mean_text))
+
+
+def depthwed_py(beds, names, size: int) -> str:
+    """Line-by-line restatement of depthwed/depthwed.go:48-157 (`run` + `next`).
+
+    beds: list of depth.bed texts (one per sample, same number of records);
+    names: the column names (getNameFromFile of each path).  Returns the text
+    the reference writes to stdout.  Records are grouped from the current row
+    until the span reaches `size` or the next row of the FIRST file is on
+    another chromosome (:126); each constituent row adds int(0.5 + mean)."""
+    rows = [[ln for ln in b.split("\n") if ln != ""] for b in beds]
+    ptr = 0
+    n0 = len(rows[0])
+    out = ["\t".join(["#chrom", "start", "end"] + list(names))]
+
+    def next_chrom():
+        return rows[0][ptr].split("\t")[0] if ptr < n0 else ""
+
+    while True:
+        # next(): depthwed.go:117-157
+        depths = [None] * len(rows)
+        eof = False
+        k = 0
+        chrom = next_chrom()
+        span0 = 0
+        while (not eof) and span0 < size and chrom == next_chrom():
+            for i, rr in enumerate(rows):
+                if ptr >= len(rr):
+                    if i > 0 and not eof:
+                        raise RuntimeError("not all files have same number of records")
+                    eof = True
+                    continue
+                toks = rr[ptr].split("\t")
+                c, s, e, d = toks[0], int(toks[1]), int(toks[2]), depthwed_cell(toks[3])
+                if k == 0:
+                    if c != chrom:
+                        raise RuntimeError("got unexpected chromosome")
+                    depths[i] = [c, s, e, d]
+                else:
+                    depths[i][2] = e
+                    depths[i][3] += d
+            if not eof:
+                ptr += 1
+                span0 = depths[0][2] - depths[0][1]
+            k += 1
+        if eof:
+            break
+        out.append("%s\t%d\t%d" % (depths[0][0], depths[0][1], depths[0][2]) +
+                   "".join("\t%d" % d[3] for d in depths))
+    return "\n".join(out) + "\n"

@@ -240,3 +240,35 @@ def test_auto_path_picks_scatter_for_ont(auto_eng):
     run_engine(auto_eng, [("c", L)], {0: r}, window_size=250, min_mapq=1, min_cov=4)
     assert auto_eng.stats().path == 2 and auto_eng.stats().reruns == 0
     check_all(auto_eng, [("c", L)], {0: r}, 250, 1, 4, 0)
+
+
+@pytest.mark.parametrize("W,size", [(250, 1000), (250, 600), (100, 100), (1000, 16000)])
+def test_depthwed_matrix_on_device(auto_eng, W, size):
+    """BASELINE.json config 4 in small: a cohort loaded as samples x contigs of one
+    context; the device matrix equals what `goleft depthwed` prints from the samples'
+    depth.bed files (oracle restatements of depth.go's callback and depthwed.go)."""
+    from goleft_amd import synth
+    eng = auto_eng
+    ref = [("chrA", 100001), ("chrB", 35250), ("chrC", 999)]
+    n_samples = 5
+    rng = np.random.default_rng(21)
+    contigs, reads, texts = [], {}, []
+    for s in range(n_samples):
+        per_sample = {}
+        for j, (name, L) in enumerate(ref):
+            cov = [3, 30, 60, 250, 0.4][s]
+            n = int(L * cov / 150)
+            r = po.Reads(*synth.short_reads_numpy(L, n, 100 * s + j)) if n else H.empty_reads()
+            reads[len(contigs)] = r
+            per_sample[j] = r
+            contigs.append(("s%d.%s" % (s, name), L))
+        texts.append(po.depth_run_oracle(ref, per_sample, W=W, Q=1, mincov=4)[0])
+    run_engine(eng, contigs, reads, window_size=W, min_mapq=1, min_cov=4)
+    tids = np.arange(n_samples * len(ref), dtype=np.int32).reshape(n_samples, len(ref))
+    cells, ctg, st, en = eng.depthwed(tids, size)
+    want = po.depthwed_py(texts, ["s%d" % s for s in range(n_samples)], size).strip().split("\n")[1:]
+    assert len(want) == len(cells)
+    for k, line in enumerate(want):
+        t = line.split("\t")
+        assert t[0] == ref[ctg[k]][0] and int(t[1]) == st[k] and int(t[2]) == en[k]
+        assert [int(x) for x in t[3:]] == cells[k].tolist(), (k, line, cells[k])
