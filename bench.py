@@ -44,7 +44,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="wgs", choices=["wgs", "chr20", "ont", "ont-chr20"],
+    ap.add_argument("--samples", type=int, default=200, help="cohort workload: number of chr1 samples")
+    ap.add_argument("--wed-size", type=int, default=1000, help="cohort workload: depthwed -s")
+    ap.add_argument("--workload", default="wgs", choices=["wgs", "chr20", "ont", "ont-chr20", "cohort"],
                     help="wgs/chr20: 30x 150 bp short reads (headline); ont/ont-chr20: 20x long reads "
                          "(BASELINE.json config 5, scatter path)")
     ap.add_argument("--coverage", type=float, default=None)
@@ -111,7 +113,16 @@ def run_case(args, scaling, world, rank, dev, local_rank, want_streams=False):
     from goleft_amd.engine import DepthEngine, K_PREP, K_TILE, K_RUNS, K_EXPAND, K_SCAN
 
     ont = args.workload.startswith("ont")
-    if args.workload in ("wgs", "ont"):
+    cohort = args.workload == "cohort"
+    if cohort:
+        # BASELINE.json config 4: S samples x chr1, W = 250 windows -> depthwed matrix at -s 1000;
+        # windows-only output (no per-base vector: 200 x 1 GB would not fit next to the records)
+        S = args.samples
+        names1 = ["s%03d.chr1" % k for k in range(S)]
+        lengths1 = [synth.HG19_LENGTHS[0]] * S
+        seeds1 = [5000 + k for k in range(S)]
+        wname = "synthetic cohort: %d samples x chr1 (249 Mb), 150 bp reads, coverage 20-40x" % S
+    elif args.workload in ("wgs", "ont"):
         names1, lengths1 = list(synth.HG19_NAMES), list(synth.HG19_LENGTHS)
         seeds1 = list(range(1, len(lengths1) + 1))
         wname = "synthetic 30x WGS, hg19 contig lengths (3.1 Gb), 150 bp reads"
@@ -127,12 +138,16 @@ def run_case(args, scaling, world, rank, dev, local_rank, want_streams=False):
     lengths = lengths1 * n_samples
     seeds = [1000 * k + sd for k in range(n_samples) for sd in seeds1]
     W, Q, mincov = args.window, 1, 4
+    if cohort:
+        W = 250 if args.window == 1000 else args.window     # goleft depth default window
     assignment = shard.lpt_assign(lengths, world)
     mine = assignment[rank]
 
     # ---- synthetic record streams, generated on device, adopted zero-copy ----
     eng = DepthEngine(local_rank)
     eng.set_params(window_size=W, min_mapq=Q, min_cov=mincov)
+    if cohort:
+        eng.set_outputs(perbase=False)
     eng.set_contigs(lengths)
     eng.select_contigs(mine)
     n_reads = n_ops = 0
@@ -141,6 +156,10 @@ def run_case(args, scaling, world, rank, dev, local_rank, want_streams=False):
         if ont:
             n = synth.n_ont_reads_for(lengths[t], args.coverage)
             s = synth.ont_reads_torch(lengths[t], n, seeds[t], dev)
+        elif cohort:
+            cov = 20.0 + (seeds[t] * 7919 % 2001) / 100.0          # 20..40x, fixed per sample
+            n = synth.n_reads_for(lengths[t], cov)
+            s = synth.short_reads_torch(lengths[t], n, seeds[t], dev)
         else:
             n = synth.n_reads_for(lengths[t], args.coverage)
             s = synth.short_reads_torch(lengths[t], n, seeds[t], dev)
@@ -151,8 +170,14 @@ def run_case(args, scaling, world, rank, dev, local_rank, want_streams=False):
     torch.cuda.synchronize()
     eng.set_profiling(True)
 
+    wed = {}
+
     def step():
         eng.compute()
+        if cohort:
+            # the sites x samples matrix of this rank's samples (device kernel + D2H)
+            tids = np.asarray(mine, np.int32).reshape(-1, 1)
+            wed["cells"] = eng.depthwed(tids, args.wed_size)[0]
         if world > 1:
             sums, mins, bounds = shard.local_results(eng, dev)
             return shard.gather_to_root(sums, mins, bounds, assignment, lengths, W, rank, world)
@@ -192,6 +217,7 @@ def run_case(args, scaling, world, rank, dev, local_rank, want_streams=False):
         "tile_ms": float(np.mean(tile_ms)), "prep_ms": float(np.mean(prep_ms)),
         "runs_ms": float(np.mean(runs_ms)), "tile_positions": st.tile_positions, "lookback": st.lookback,
         "expand_ms": float(np.mean(expand_ms)), "scan_ms": float(np.mean(scan_ms)), "path": int(st.path),
+        "perbase": not cohort, "wed_shape": list(wed["cells"].shape) if wed else None,
     }
     if not want_streams:
         streams.clear()
@@ -224,7 +250,8 @@ def main():
     dt, W, Q, mincov = r["dt"], r["W"], r["Q"], r["mincov"]
     value = r["total_bases"] * args.steps / dt
     # roofline of the dominant kernel (gd_tile_kernel), this rank's launch
-    alg_bytes = synth.algorithmic_bytes(r["n_reads"], r["n_ops"], r["my_bases"], r["my_windows"])
+    alg_bytes = synth.algorithmic_bytes(r["n_reads"], r["n_ops"], r["my_bases"] if r["perbase"] else 0,
+                                        r["my_windows"])   # windows-only: no 4 B/base write
     scatter = r["path"] == 2
     # tile path: gd_tile_kernel does all the arithmetic; scatter path: expand + scan share it
     avg_tile_s = (r["expand_ms"] + r["scan_ms"] if scatter else r["tile_ms"]) * 1e-3
@@ -236,13 +263,14 @@ def main():
 
     # PCIe-inclusive rate (results to host) -- reported, never `value`
     t1 = time.perf_counter()
-    for t in mine:
+    for t in mine[:48]:
         eng.windows(t)
-    d2h = time.perf_counter() - t1
+    d2h = (time.perf_counter() - t1) * (len(mine) / max(1, min(len(mine), 48)))
 
     out = {
-        "metric": "ref bases/sec per-base depth, 30x WGS synthetic" if not args.workload.startswith("ont")
-                  else "ref bases/sec per-base depth, 20x ONT-like synthetic",
+        "metric": ("ref bases/sec per-base depth, 20x ONT-like synthetic" if args.workload.startswith("ont")
+                   else "ref bases/sec depth -> depthwed matrix, cohort x chr1" if args.workload == "cohort"
+                   else "ref bases/sec per-base depth, 30x WGS synthetic"),
         "value": value,
         "unit": "ref-bases/s",
         "n_gpus": world,
@@ -260,7 +288,9 @@ def main():
                    "min_mapq": Q, "min_cov": mincov, "total_ref_bases": r["total_bases"],
                    "reads_rank0": r["n_reads"], "cigar_ops_rank0": r["n_ops"],
                    "sharding": "by chromosome, LPT" if world > 1 else "single GPU",
-                   "outputs": "int32 per-base depth + int64/int32 window sum/min + class runs",
+                   "outputs": ("int32 per-base depth + " if r["perbase"] else "(windows-only) ") +
+                              "int64/int32 window sum/min + class runs" +
+                              (" + depthwed matrix %s" % r["wed_shape"] if r["wed_shape"] else ""),
                    "tile_positions": r["tile_positions"], "lookback": r["lookback"],
                    "device_path": "scatter" if scatter else "tile"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -277,7 +307,7 @@ def main():
         out["roofline"]["traffic_frac_of_peak"] = traffic / avg_tile_s / 1e9 / HBM_PEAK_GBPS
         out["roofline"]["traffic_source"] = tr.get("source")
 
-    if args.verify and rank == 0:
+    if args.verify and rank == 0 and r["perbase"]:
         from oracle import pyoracle as po
         t = mine[-1]
         rd = po.Reads(*[x.cpu().numpy() for x in streams[t]])

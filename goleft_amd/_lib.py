@@ -48,6 +48,7 @@ SYMBOLS = {
     "gd_set_params": (C.c_int, [_P, C.POINTER(GdParams)]),
     "gd_default_params": (C.c_int, [C.POINTER(GdParams)]),
     "gd_set_path": (C.c_int, [_P, C.c_int]),
+    "gd_set_outputs": (C.c_int, [_P, C.c_uint]),
     "gd_set_contigs": (C.c_int, [_P, C.c_int, _P]),
     "gd_select_contigs": (C.c_int, [_P, C.c_int, _P]),
     "gd_acquire": (C.c_int, [_P, C.c_size_t, C.c_size_t, C.POINTER(GdBatch)]),

@@ -72,6 +72,7 @@ struct gd_ctx {
     int tile_opt = 0;                   // GOLEFT_GD_OPT bit 0: non-temporal per-base stores
     bool lookback_pinned = false;       // max_span_hint given: never shrink below it
     int path = GD_PATH_AUTO;            // gd_set_path / GOLEFT_GD_PATH
+    bool keep_perbase = true;           // gd_set_outputs(GD_OUT_PERBASE)
     bool scope_wg = false;              // debug: GOLEFT_GD_SCOPE=wg (wrong results, timing only)
     bool span_forces_scatter = false;   // AUTO: the tile path met a read too long for it
     unsigned long long* d_status = nullptr;  size_t cap_status = 0;   // scatter path look-back words
@@ -200,7 +201,9 @@ void launch_tile(gd_ctx* c, const gd::Job& job)
     }
     // 8 XCDs: the grid is 8 equal slices of the tile list (see the kernel)
     const unsigned grid = (unsigned)(((job.n_tiles + 7) / 8) * 8);
-    if (c->tile_opt & 1)
+    if (!c->keep_perbase)
+        hipLaunchKernelGGL((gd::gd_tile_kernel<T, NT, 2>), dim3(grid), dim3(NT), 0, c->stream, job);
+    else if (c->tile_opt & 1)
         hipLaunchKernelGGL((gd::gd_tile_kernel<T, NT, 1>), dim3(grid), dim3(NT), 0, c->stream, job);
     else
         hipLaunchKernelGGL((gd::gd_tile_kernel<T, NT, 0>), dim3(grid), dim3(NT), 0, c->stream, job);
@@ -365,6 +368,15 @@ int gd_set_path(gd_ctx* c, int path)
     if (path != GD_PATH_AUTO && path != GD_PATH_TILE && path != GD_PATH_SCATTER)
         return fail(c, GD_E_INVALID, "unknown path %d", path);
     c->path = path;
+    c->computed = false;
+    return GD_OK;
+}
+
+int gd_set_outputs(gd_ctx* c, unsigned flags)
+{
+    if (!c) return GD_E_INVALID;
+    if (flags & ~(unsigned)GD_OUT_PERBASE) return fail(c, GD_E_INVALID, "unknown output flags 0x%x", flags);
+    c->keep_perbase = (flags & GD_OUT_PERBASE) != 0;
     c->computed = false;
     return GD_OK;
 }
@@ -628,7 +640,14 @@ int gd_compute(gd_ctx* c)
         if (int r = ensure_dev(c, &c->d_super_cnt, &c4, (size_t)c->n_tiles / gd::SUPER + 1)) return r;
         c->cap_tiles = c1;
     }
-    if (int r = ensure_dev(c, &c->d_perbase, &c->cap_perbase, (size_t)base_off)) return r;
+    if (c->keep_perbase) {
+        if (int r = ensure_dev(c, &c->d_perbase, &c->cap_perbase, (size_t)base_off)) return r;
+    } else if (c->d_perbase) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipFree(c->d_perbase));        // windows-only: give the HBM back
+        c->d_perbase = nullptr;
+        c->cap_perbase = 0;
+    }
     if ((size_t)win_off > c->cap_win || !c->d_wsum) {
         size_t c1 = c->cap_win, c2 = c->cap_win;
         if (int r = ensure_dev(c, &c->d_wsum, &c1, (size_t)std::max<int64_t>(win_off, 1))) return r;
@@ -683,6 +702,9 @@ int gd_compute(gd_ctx* c)
         const bool scatter = c->path == GD_PATH_SCATTER ||
                              (c->path == GD_PATH_AUTO && (c->span_forces_scatter || n_ops > 6 * n_reads));
         const unsigned runs_grid = (unsigned)((c->n_tiles + gd::SUPER - 1) / gd::SUPER);
+        if (scatter && !c->keep_perbase)
+            return fail(c, GD_E_INVALID, "windows-only output (gd_set_outputs without GD_OUT_PERBASE) needs the "
+                                         "tile path; these records select the scatter path");
         if (!scatter) {
             if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
             switch (T) {
@@ -844,6 +866,7 @@ int gd_perbase(gd_ctx* c, int32_t tid, int64_t start, int64_t end, int32_t* out)
     const ContigHost& h = c->contigs[tid];
     if (start < 0 || end < start || end > h.length) return fail(c, GD_E_RANGE, "region [%lld,%lld) outside contig of length %lld", (long long)start, (long long)end, (long long)h.length);
     if (end == start) return GD_OK;
+    if (!c->d_perbase) return fail(c, GD_E_STATE, "the per-base vector was not kept (gd_set_outputs)");
     HIPCHK(c, hipMemcpy(out, c->d_perbase + h.base_off + start, (size_t)(end - start) * sizeof(int32_t), hipMemcpyDeviceToHost));
     return GD_OK;
 }
@@ -896,6 +919,7 @@ int gd_region_windows(gd_ctx* c, int32_t tid, int64_t start, int64_t end, int64_
     *n = k;
     if (cap < k || !sums) return fail(c, GD_E_CAPACITY, "need room for %zu windows", k);
     if (h.length <= 0) { for (size_t i = 0; i < k; ++i) { sums[i] = 0; if (mins) mins[i] = 0; } return GD_OK; }
+    if (!c->d_perbase) return fail(c, GD_E_STATE, "the per-base vector was not kept (gd_set_outputs)");
     int64_t* d_s = nullptr;
     int32_t* d_m = nullptr;
     HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&d_s), k * sizeof(int64_t)));
@@ -925,6 +949,7 @@ int gd_region_callable(gd_ctx* c, int32_t tid, int64_t start, int64_t end, gd_ru
         out[0].start = (int32_t)start; out[0].end = (int32_t)end; out[0].cls = GD_NO_COVERAGE;
         return GD_OK;
     }
+    if (!c->d_perbase) return fail(c, GD_E_STATE, "the per-base vector was not kept (gd_set_outputs)");
     size_t bcap = std::max<size_t>(cap, 1024);
     for (;;) {
         int2* d_b = nullptr;
@@ -1023,6 +1048,7 @@ int gd_device_perbase(gd_ctx* c, int32_t tid, const int32_t** dptr, int64_t* len
     if (!c || !dptr) return GD_E_INVALID;
     if (int r = check_result_tid(c, tid)) return r;
     const ContigHost& h = c->contigs[tid];
+    if (!c->d_perbase) return fail(c, GD_E_STATE, "the per-base vector was not kept (gd_set_outputs)");
     *dptr = h.length > 0 ? c->d_perbase + h.base_off : nullptr;
     if (len) *len = h.length;
     return GD_OK;

@@ -312,8 +312,8 @@ __global__ __launch_bounds__(NT) void gd_scan_kernel(Job job)
         B.carry = carry;
         // depth inside the tile <= prefix + sum of positive differences
         const bool wide = (long long)prefix + rise >= (1 << 22);
-        if (tlen == T && !wide) phase_b_rows<ROWS, true, false, false>(B);
-        else                    phase_b_rows<ROWS, false, true, false>(B);
+        if (tlen == T && !wide) phase_b_rows<ROWS, true, false, 0>(B);
+        else                    phase_b_rows<ROWS, false, true, 0>(B);
     }
     __syncthreads();
 

@@ -215,7 +215,8 @@ struct PhaseB {
 // windows, detect class boundaries.
 //   FULL  every position of the tile is inside the contig (no masking)
 //   WIDE  depths may reach 2^22: 64-bit window accumulation everywhere
-template <int ROWS, bool FULL, bool WIDE, bool NTS>
+//   ST    per-base stores: 0 plain, 1 non-temporal, 2 none (windows-only output)
+template <int ROWS, bool FULL, bool WIDE, int ST>
 __device__ __forceinline__ void phase_b_rows(const PhaseB& B)
 {
     constexpr int BIG = 0x3fffffff;
@@ -246,7 +247,7 @@ __device__ __forceinline__ void phase_b_rows(const PhaseB& B)
         int4* dst = reinterpret_cast<int4*>(&B.out[ib]);
         if (!FULL && rb >= tlen) {
             // rows past the (clipped) tile end: keep the padded per-base array zero
-            *dst = make_int4(0, 0, 0, 0);
+            if (ST != 2) *dst = make_int4(0, 0, 0, 0);
             continue;
         }
         const int4 v = *reinterpret_cast<const int4*>(&B.s_diff[ib]);
@@ -264,7 +265,9 @@ __device__ __forceinline__ void phase_b_rows(const PhaseB& B)
             d0 = nvalid > 0 ? d0 : 0; d1 = nvalid > 1 ? d1 : 0;
             d2 = nvalid > 2 ? d2 : 0; d3 = nvalid > 3 ? d3 : 0;
         }
-        if (NTS) {
+        if (ST == 2) {
+            // windows-only output: the depth never leaves the registers
+        } else if (ST == 1) {
             typedef int v4i32 __attribute__((ext_vector_type(4)));
             v4i32 dv; dv.x = d0; dv.y = d1; dv.z = d2; dv.w = d3;
             __builtin_nontemporal_store(dv, reinterpret_cast<v4i32*>(dst));
@@ -455,7 +458,7 @@ __device__ __forceinline__ void phase_c(const Job& job, int tile, int32_t t0, in
     }
 }
 
-// OPT bit 0: non-temporal per-base stores.
+// OPT: per-base stores 0 plain, 1 non-temporal, 2 none (gd_set_outputs without GD_OUT_PERBASE).
 template <int T, int NT, int OPT>
 __global__ __launch_bounds__(NT) void gd_tile_kernel(Job job)
 {
@@ -466,7 +469,7 @@ __global__ __launch_bounds__(NT) void gd_tile_kernel(Job job)
     constexpr int CQ = (T * 3) / 8;        // staged CIGAR ops (30x/150 bp needs ~T/4)
     constexpr int U = 4;                   // reads per lane in flight
     constexpr int CCH = (CQ + NT - 1) / NT;   // staged ops per thread
-    constexpr bool NTS = (OPT & 1) != 0;
+    constexpr int ST = OPT;
     static_assert(CHUNK % 256 == 0, "wave chunk must be whole rows");
 
     __shared__ __attribute__((aligned(16))) int32_t s_diffp[T + 4];  // [3] = index -1
@@ -588,8 +591,8 @@ __global__ __launch_bounds__(NT) void gd_tile_kernel(Job job)
         // depth <= reads examined for the tile: below 2^22 the 32-bit window
         // accumulation is exact (1024 positions x depth < 2^32)
         const bool wide = nrd >= (1u << 22);
-        if (tlen == T && !wide) phase_b_rows<ROWS, true, false, NTS>(B);
-        else                    phase_b_rows<ROWS, false, true, NTS>(B);   // clipped or very deep tiles
+        if (tlen == T && !wide) phase_b_rows<ROWS, true, false, ST>(B);
+        else                    phase_b_rows<ROWS, false, true, ST>(B);   // clipped or very deep tiles
     }
     __syncthreads();
 

@@ -73,6 +73,10 @@ class DepthEngine:
         """PATH_AUTO / PATH_TILE / PATH_SCATTER (include/goleft_depth.h GD_PATH_*)."""
         self._chk(self._lib.gd_set_path(self._ctx, int(path)))
 
+    def set_outputs(self, perbase: bool = True):
+        """perbase=False: windows + class runs only (no 4 B/base vector in HBM)."""
+        self._chk(self._lib.gd_set_outputs(self._ctx, 1 if perbase else 0))
+
     def set_contigs(self, lengths: Sequence[int]):
         a = np.asarray(lengths, dtype=np.int64)
         self._chk(self._lib.gd_set_contigs(self._ctx, len(a), a.ctypes.data))

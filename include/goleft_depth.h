@@ -144,6 +144,14 @@ int gd_default_params(gd_params* p);
 /* Choose the device algorithm (GD_PATH_*); default GD_PATH_AUTO. */
 int gd_set_path(gd_ctx* ctx, int path);
 
+/* Which results gd_compute materialises in HBM.  GD_OUT_PERBASE (default): the
+ * int32 per-base vector (12.4 GB for a human genome), needed by gd_perbase,
+ * gd_device_perbase and the --bed region reductions.  Without it only window
+ * sums/minima and class runs are produced -- all `goleft depth` prints for a whole
+ * genome, and what a cohort (depthwed) needs; tile path only. */
+enum { GD_OUT_PERBASE = 1 };
+int gd_set_outputs(gd_ctx* ctx, unsigned flags);
+
 /* Reference sequence table (@SQ LN of the BAM header / .fai lengths,
  * depth/depth.go:134-149).  Drops all records and results. */
 int gd_set_contigs(gd_ctx* ctx, int n_contigs, const int64_t* lengths);

@@ -272,3 +272,31 @@ def test_depthwed_matrix_on_device(auto_eng, W, size):
         t = line.split("\t")
         assert t[0] == ref[ctg[k]][0] and int(t[1]) == st[k] and int(t[2]) == en[k]
         assert [int(x) for x in t[3:]] == cells[k].tolist(), (k, line, cells[k])
+
+
+def test_windows_only_output(auto_eng):
+    """gd_set_outputs(0): no per-base vector in HBM; windows and class runs are unchanged,
+    per-base consumers report GD_E_STATE."""
+    from goleft_amd import synth
+    from goleft_amd.engine import GdError
+    eng = auto_eng
+    L = 700_001
+    r = po.Reads(*synth.short_reads_numpy(L, synth.n_reads_for(L), 33))
+    contigs = [("c", L)]
+    eng.set_outputs(perbase=False)
+    try:
+        run_engine(eng, contigs, {0: r}, window_size=250, min_mapq=1, min_cov=4)
+        want = po.perbase_c(r, 1, 0, L)
+        ws, wm = H.oracle_windows(want, 250)
+        gs, gm = eng.windows(0)
+        assert np.array_equal(gs, ws) and np.array_equal(gm, wm)
+        assert np.array_equal(eng.callable_runs(0), H.oracle_runs(want, 4, 0, po.step_for(250)))
+        with pytest.raises(GdError) as ei:
+            eng.perbase(0)
+        assert ei.value.status == -4
+        with pytest.raises(GdError):
+            eng.region_windows(0, 10, 1000)
+    finally:
+        eng.set_outputs(perbase=True)
+    run_engine(eng, contigs, {0: r}, window_size=250, min_mapq=1, min_cov=4)
+    assert np.array_equal(eng.perbase(0), want)
