@@ -48,7 +48,7 @@ def parse():
     ap.add_argument("--wed-size", type=int, default=1000, help="cohort workload: depthwed -s")
     ap.add_argument("--workload", default="wgs", choices=["wgs", "chr20", "ont", "ont-chr20", "cohort"],
                     help="wgs/chr20: 30x 150 bp short reads (headline); ont/ont-chr20: 20x long reads "
-                         "(BASELINE.json config 5, scatter path)")
+                         "(BASELINE.json config 5, chunk path)")
     ap.add_argument("--coverage", type=float, default=None)
     ap.add_argument("--window", type=int, default=1000)
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
@@ -110,7 +110,7 @@ def run_case(args, scaling, world, rank, dev, local_rank, want_streams=False):
     import torch
     import torch.distributed as dist
     from goleft_amd import shard, synth
-    from goleft_amd.engine import DepthEngine, K_PREP, K_TILE, K_RUNS, K_EXPAND, K_SCAN
+    from goleft_amd.engine import DepthEngine, K_PREP, K_TILE, K_RUNS, K_EXPAND, K_SCAN, K_CKPT
 
     ont = args.workload.startswith("ont")
     cohort = args.workload == "cohort"
@@ -185,7 +185,7 @@ def run_case(args, scaling, world, rank, dev, local_rank, want_streams=False):
 
     for _ in range(args.warmup):
         step()
-    tile_ms, prep_ms, runs_ms, expand_ms, scan_ms = [], [], [], [], []
+    tile_ms, prep_ms, runs_ms, expand_ms, scan_ms, ckpt_ms = [], [], [], [], [], []
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -197,6 +197,7 @@ def run_case(args, scaling, world, rank, dev, local_rank, want_streams=False):
         runs_ms.append(eng.kernel_ms(K_RUNS))
         expand_ms.append(eng.kernel_ms(K_EXPAND))
         scan_ms.append(eng.kernel_ms(K_SCAN))
+        ckpt_ms.append(eng.kernel_ms(K_CKPT))
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -217,6 +218,7 @@ def run_case(args, scaling, world, rank, dev, local_rank, want_streams=False):
         "tile_ms": float(np.mean(tile_ms)), "prep_ms": float(np.mean(prep_ms)),
         "runs_ms": float(np.mean(runs_ms)), "tile_positions": st.tile_positions, "lookback": st.lookback,
         "expand_ms": float(np.mean(expand_ms)), "scan_ms": float(np.mean(scan_ms)), "path": int(st.path),
+        "ckpt_ms": float(np.mean(ckpt_ms)),
         "perbase": not cohort, "wed_shape": list(wed["cells"].shape) if wed else None,
     }
     if not want_streams:
@@ -253,12 +255,15 @@ def main():
     alg_bytes = synth.algorithmic_bytes(r["n_reads"], r["n_ops"], r["my_bases"] if r["perbase"] else 0,
                                         r["my_windows"])   # windows-only: no 4 B/base write
     scatter = r["path"] == 2
-    # tile path: gd_tile_kernel does all the arithmetic; scatter path: expand + scan share it
-    avg_tile_s = (r["expand_ms"] + r["scan_ms"] if scatter else r["tile_ms"]) * 1e-3
+    chunk = r["path"] == 3
+    # tile path: gd_tile_kernel does all the arithmetic; chunk path: checkpoint pass + long-read
+    # tile kernel (both stream the CIGARs); scatter path: expand + scan share it
+    avg_tile_s = (r["expand_ms"] + r["scan_ms"] if scatter else
+                  r["ckpt_ms"] + r["tile_ms"] if chunk else r["tile_ms"]) * 1e-3
     achieved = alg_bytes / avg_tile_s / 1e9
     traffic = None
     tr = load_traffic()
-    if tr and world == 1 and args.workload == "wgs" and args.coverage == 30.0 and not scatter:
+    if tr and world == 1 and args.workload == "wgs" and args.coverage == 30.0 and r["path"] == 1:
         traffic = tr.get("hbm_bytes_per_launch")   # measured on this exact launch shape
 
     # PCIe-inclusive rate (results to host) -- reported, never `value`
@@ -292,15 +297,18 @@ def main():
                               "int64/int32 window sum/min + class runs" +
                               (" + depthwed matrix %s" % r["wed_shape"] if r["wed_shape"] else ""),
                    "tile_positions": r["tile_positions"], "lookback": r["lookback"],
-                   "device_path": "scatter" if scatter else "tile"},
+                   "device_path": "scatter" if scatter else "chunk" if chunk else "tile"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                     "kernel": "gd_expand_scatter_kernel+gd_scan_kernel" if scatter else "gd_tile_kernel",
+                     "kernel": ("gd_expand_scatter_kernel+gd_scan_kernel" if scatter else
+                                "gd_ckpt_kernel+gd_ltile_kernel" if chunk else "gd_tile_kernel"),
                      "avg_kernel_ms": avg_tile_s * 1e3,
                      "algorithmic_bytes_per_launch": alg_bytes,
                      "bytes_per_ref_base": alg_bytes / r["my_bases"]},
         "kernels_ms": ({"prep": r["prep_ms"], "expand": r["expand_ms"], "scan": r["scan_ms"], "runs": r["runs_ms"]}
-                       if scatter else {"prep": r["prep_ms"], "tile": r["tile_ms"], "runs": r["runs_ms"]}),
+                       if scatter else
+                       {"ckpt": r["ckpt_ms"], "prep": r["prep_ms"], "ltile": r["tile_ms"], "runs": r["runs_ms"]}
+                       if chunk else {"prep": r["prep_ms"], "tile": r["tile_ms"], "runs": r["runs_ms"]}),
         "with_d2h_windows_ref_bases_per_s": r["my_bases"] / (dt / args.steps + d2h) if world == 1 else None,
     }
     if traffic:

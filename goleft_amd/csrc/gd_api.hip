@@ -22,7 +22,7 @@ namespace {
 constexpr int kRingSlots = 3;
 constexpr int kDefaultLookback = 512;
 constexpr uint64_t kMaxReadsPerContig = 1ull << 30;
-constexpr int kAutoScatterSpan = 32768;   // GD_PATH_AUTO leaves the tile path above this read span
+constexpr int kAutoLongSpan = 32768;      // GD_PATH_AUTO leaves the short-read tile path above this read span
 constexpr int kMaxSpan = 1 << 27;   // tile-relative byte offsets of the tile kernel stay in 32 bits
 
 struct ContigHost {
@@ -74,8 +74,10 @@ struct gd_ctx {
     int path = GD_PATH_AUTO;            // gd_set_path / GOLEFT_GD_PATH
     bool keep_perbase = true;           // gd_set_outputs(GD_OUT_PERBASE)
     bool scope_wg = false;              // debug: GOLEFT_GD_SCOPE=wg (wrong results, timing only)
-    bool span_forces_scatter = false;   // AUTO: the tile path met a read too long for it
+    bool span_forces_long = false;      // AUTO: the tile path met a read too long for it
     unsigned long long* d_status = nullptr;  size_t cap_status = 0;   // scatter path look-back words
+    uint32_t* d_ck = nullptr;  size_t cap_ck = 0;      // chunk path: CIGAR checkpoints
+    int32_t* d_rend = nullptr; size_t cap_rend = 0;    // chunk path: read end positions
     int lookback = kDefaultLookback;
 
     // device job state
@@ -209,6 +211,16 @@ void launch_tile(gd_ctx* c, const gd::Job& job)
         hipLaunchKernelGGL((gd::gd_tile_kernel<T, NT, 0>), dim3(grid), dim3(NT), 0, c->stream, job);
 }
 
+template <int T, int NT>
+void launch_ltile(gd_ctx* c, const gd::Job& job)
+{
+    const unsigned grid = (unsigned)(((job.n_tiles + 7) / 8) * 8);
+    if (!c->keep_perbase)
+        hipLaunchKernelGGL((gd::gd_ltile_kernel<T, NT, 2>), dim3(grid), dim3(NT), 0, c->stream, job);
+    else
+        hipLaunchKernelGGL((gd::gd_ltile_kernel<T, NT, 0>), dim3(grid), dim3(NT), 0, c->stream, job);
+}
+
 }  // namespace
 
 extern "C" {
@@ -275,7 +287,7 @@ int gd_create(int device_id, gd_ctx** out)
     if (const char* e = getenv("GOLEFT_GD_OPT")) c->tile_opt = atoi(e) & 1;
     if (const char* e = getenv("GOLEFT_GD_SCOPE")) c->scope_wg = e[0] == 'w';
     if (const char* e = getenv("GOLEFT_GD_PATH"))
-        c->path = e[0] == 's' ? GD_PATH_SCATTER : (e[0] == 't' ? GD_PATH_TILE : GD_PATH_AUTO);
+        c->path = e[0] == 's' ? GD_PATH_SCATTER : e[0] == 't' ? GD_PATH_TILE : e[0] == 'c' ? GD_PATH_CHUNK : GD_PATH_AUTO;
     if (const char* e = getenv("GOLEFT_GD_THREADS")) {
         int t = atoi(e);
         if (t == 256 || t == 512) c->tile_NT = t;
@@ -320,7 +332,7 @@ void gd_destroy(gd_ctx* c)
     if (c->copy_done) (void)hipEventDestroy(c->copy_done);
     void* frees[] = {c->d_ctgs, c->d_tiles, c->d_perbase, c->d_wsum, c->d_wmin, c->d_chunks,
                      c->d_ordered, c->d_tile_cnt, c->d_tile_off, c->d_super_cnt, c->d_counters,
-                     c->d_region_cursor, c->d_status};
+                     c->d_region_cursor, c->d_status, c->d_ck, c->d_rend};
     for (void* p : frees) if (p) (void)hipFree(p);
     if (c->h_counters) (void)hipHostFree(c->h_counters);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -365,7 +377,7 @@ int gd_set_params(gd_ctx* c, const gd_params* p)
 int gd_set_path(gd_ctx* c, int path)
 {
     if (!c) return GD_E_INVALID;
-    if (path != GD_PATH_AUTO && path != GD_PATH_TILE && path != GD_PATH_SCATTER)
+    if (path != GD_PATH_AUTO && path != GD_PATH_TILE && path != GD_PATH_SCATTER && path != GD_PATH_CHUNK)
         return fail(c, GD_E_INVALID, "unknown path %d", path);
     c->path = path;
     c->computed = false;
@@ -398,7 +410,7 @@ int gd_set_contigs(gd_ctx* c, int n, const int64_t* lengths)
     c->computed = false;
     // a new data set: forget the look-back learnt from the previous one
     c->lookback = c->params.max_span_hint > 0 ? c->params.max_span_hint : kDefaultLookback;
-    c->span_forces_scatter = false;
+    c->span_forces_long = false;
     return GD_OK;
 }
 
@@ -572,7 +584,7 @@ int gd_reset(gd_ctx* c)
     c->bounds.clear();
     c->computed = false;
     c->lookback = c->params.max_span_hint > 0 ? c->params.max_span_hint : kDefaultLookback;
-    c->span_forces_scatter = false;
+    c->span_forces_long = false;
     return GD_OK;
 }
 
@@ -591,7 +603,7 @@ int gd_compute(gd_ctx* c)
     c->h_ctgs.clear();
     c->job_tids.clear();
     int64_t tile_beg = 0, base_off = 0, win_off = 0, bases = 0;
-    uint64_t n_reads = 0, n_ops = 0, n_units = 0;
+    uint64_t n_reads = 0, n_ops = 0, n_units = 0, n_ck = 0;
     for (int32_t tid : tids) {
         ContigHost& h = c->contigs[tid];
         if (h.length <= 0) continue;
@@ -606,7 +618,10 @@ int gd_compute(gd_ctx* c)
         d.win_off = win_off;
         d.tid = tid;
         d.unit_beg = (uint32_t)n_units;
+        d.ck_off = (int64_t)n_ck;
+        d.read_off = (int64_t)n_reads;
         n_units += (h.n_reads + 63) / 64;
+        n_ck += (h.n_ops >> 6) + h.n_reads + 1;   // gd_chunk.hpp: slots (off >> 6) + read
         h.base_off = base_off;
         h.win_off = win_off;
         h.n_win = (h.length + P.window_size - 1) / P.window_size;
@@ -669,7 +684,7 @@ int gd_compute(gd_ctx* c)
 
     int reruns = 0;
     int used_lookback = c->lookback;
-    bool used_scatter = false;
+    bool used_scatter = false, used_chunk = false;
     for (;;) {
         gd::Job job{};
         job.ctgs = c->d_ctgs;
@@ -699,13 +714,47 @@ int gd_compute(gd_ctx* c)
         job.tile_status = c->d_status;
 
         // which device algorithm (include/goleft_depth.h GD_PATH_*)
-        const bool scatter = c->path == GD_PATH_SCATTER ||
-                             (c->path == GD_PATH_AUTO && (c->span_forces_scatter || n_ops > 6 * n_reads));
+        const bool scatter = c->path == GD_PATH_SCATTER;
+        const bool chunk = c->path == GD_PATH_CHUNK ||
+                           (c->path == GD_PATH_AUTO && (c->span_forces_long || n_ops > 6 * n_reads));
         const unsigned runs_grid = (unsigned)((c->n_tiles + gd::SUPER - 1) / gd::SUPER);
         if (scatter && !c->keep_perbase)
-            return fail(c, GD_E_INVALID, "windows-only output (gd_set_outputs without GD_OUT_PERBASE) needs the "
-                                         "tile path; these records select the scatter path");
-        if (!scatter) {
+            return fail(c, GD_E_INVALID, "windows-only output (gd_set_outputs without GD_OUT_PERBASE) is not "
+                                         "available on the scatter path");
+        if (chunk) {
+            if (int r = ensure_dev(c, &c->d_ck, &c->cap_ck, (size_t)n_ck)) return r;
+            if (int r = ensure_dev(c, &c->d_rend, &c->cap_rend, (size_t)std::max<uint64_t>(n_reads, 1))) return r;
+            job.ck = c->d_ck;
+            job.rend = c->d_rend;
+            job.lookback_dev = 1;
+            HIPCHK(c, hipMemsetAsync(c->d_counters, 0, sizeof(gd::Counters), c->stream));
+            if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+            if (n_units) {
+                const uint64_t groups = (n_units + 3) / 4;
+                const unsigned grid = (unsigned)(((groups + 7) / 8) * 8);
+                hipLaunchKernelGGL(gd::gd_ckpt_kernel, dim3(grid), dim3(256), 0, c->stream, job);
+            }
+            if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+            switch (T) {
+            case 8192: launch_prep<8192>(c, job); break;
+            default: launch_prep<4096>(c, job); break;
+            }
+            if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
+            {
+                const int key = T + c->tile_NT;
+                switch (key) {
+                case 4096 + 512: launch_ltile<4096, 512>(c, job); break;
+                case 8192 + 512: launch_ltile<8192, 512>(c, job); break;
+                case 8192 + 256: launch_ltile<8192, 256>(c, job); break;
+                default: launch_ltile<4096, 256>(c, job); break;
+                }
+            }
+            if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
+            hipLaunchKernelGGL(gd::gd_runs_order_kernel, dim3(runs_grid), dim3(gd::SUPER), 0,
+                               c->stream, c->d_chunks, job.run_cap, c->d_tile_cnt, c->d_tile_off,
+                               c->d_super_cnt, c->d_ordered, (int)c->n_tiles);
+            if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
+        } else if (!scatter) {
             if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
             switch (T) {
             case 8192: launch_prep<8192>(c, job); break;
@@ -761,20 +810,24 @@ int gd_compute(gd_ctx* c)
         HIPCHK(c, hipMemcpyAsync(c->h_counters, c->d_counters, sizeof(gd::Counters), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         used_scatter = scatter;
+        used_chunk = chunk;
 
         const gd::Counters k = *c->h_counters;
-        if (scatter) {
+        if (chunk) {
+            c->stats.max_span_seen = k.max_span > 0 ? k.max_span : 0;
+            used_lookback = c->stats.max_span_seen;
+        } else if (scatter) {
             if (k.pad1 != 0) return fail(c, GD_E_HIP, "scan look-back timed out (internal error)");
         } else {
             c->stats.max_span_seen = k.max_span > 0 ? k.max_span : 0;
-            if (c->path == GD_PATH_AUTO && k.max_span > kAutoScatterSpan) {
+            if (c->path == GD_PATH_AUTO && k.max_span > kAutoLongSpan) {
                 // reads this long make the tile path re-examine too much: switch paths
-                c->span_forces_scatter = true;
+                c->span_forces_long = true;
                 ++reruns;
                 continue;
             }
             if (k.max_span >= kMaxSpan)
-                return fail(c, GD_E_RANGE, "a read spans %d reference bases (tile path limit %d; use GD_PATH_SCATTER)",
+                return fail(c, GD_E_RANGE, "a read spans %d reference bases (tile path limit %d; use GD_PATH_CHUNK)",
                             k.max_span, kMaxSpan - 1);
             if (k.max_span > c->lookback) {
                 // a kept read spans more reference than the look-back: redo with the observed maximum
@@ -810,7 +863,12 @@ int gd_compute(gd_ctx* c)
             HIPCHK(c, hipEventElapsedTime(out, c->ev[a], c->ev[b]));
             return GD_OK;
         };
-        if (!used_scatter) {
+        if (used_chunk) {
+            if (int r = ms(0, 1, &c->kernel_ms[GD_K_CKPT])) return r;
+            if (int r = ms(1, 2, &c->kernel_ms[GD_K_PREP])) return r;
+            if (int r = ms(2, 3, &c->kernel_ms[GD_K_TILE])) return r;
+            if (int r = ms(3, 4, &c->kernel_ms[GD_K_RUNS])) return r;
+        } else if (!used_scatter) {
             if (int r = ms(0, 1, &c->kernel_ms[GD_K_PREP])) return r;
             if (int r = ms(1, 2, &c->kernel_ms[GD_K_TILE])) return r;
             if (int r = ms(2, 3, &c->kernel_ms[GD_K_RUNS])) return r;
@@ -842,7 +900,7 @@ int gd_compute(gd_ctx* c)
     c->stats.tile_positions = T;
     c->stats.lookback = used_lookback;
     c->stats.reruns = reruns;
-    c->stats.path = used_scatter ? GD_PATH_SCATTER : GD_PATH_TILE;
+    c->stats.path = used_chunk ? GD_PATH_CHUNK : used_scatter ? GD_PATH_SCATTER : GD_PATH_TILE;
     c->stats.reserved = 0;
     if (used_scatter) c->stats.max_span_seen = 0;   // not measured on this path
     c->computed = true;

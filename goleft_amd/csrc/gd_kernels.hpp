@@ -53,7 +53,9 @@ struct ContigDev {
     int64_t  base_off;        // element offset of this contig in the per-base array
     int64_t  win_off;         // element offset in the window arrays
     int32_t  tid;             // reference id in the BAM header
-    uint32_t unit_beg;        // first 64-read unit of this contig (scatter path)
+    uint32_t unit_beg;        // first 64-read unit of this contig (scatter / chunk paths)
+    int64_t  ck_off;          // chunk path: element offset of this contig's checkpoints in Job::ck
+    int64_t  read_off;        // chunk path: element offset of this contig's reads in Job::rend
 };
 
 // Everything a workgroup needs for its tile in ONE 80-byte record (one scalar
@@ -109,6 +111,9 @@ struct Job {
     int64_t   step;
     uint32_t  n_units;        // scatter path: 64-read units over all contigs
     unsigned long long* tile_status;   // scatter path: look-back status word per tile
+    uint32_t* ck;             // chunk path: reference position at every 64th CIGAR op of a read
+    int32_t*  rend;           // chunk path: end position of every read (-1: filtered out)
+    int32_t   lookback_dev;   // chunk path: look-back = counters->max_span (written by gd_ckpt_kernel)
 };
 
 __device__ __forceinline__ int cov_class(int d, int mincov, int maxmean)
@@ -179,8 +184,12 @@ __global__ void gd_prep_kernel(Job job)
         job.win_min[w] = 0x7fffffff;
     }
     for (int64_t g = gid; g < (job.n_tiles + SUPER - 1) / SUPER; g += gsz) job.super_cnt[g] = 0;
+    // chunk path: the exact maximum span is already on the device (no host round trip)
+    const int32_t lookback = job.lookback_dev
+        ? __hip_atomic_load(&job.counters->max_span, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+        : job.lookback;
     if (gid == 0) {
-        job.counters->max_span = 0;
+        if (!job.lookback_dev) job.counters->max_span = 0;
         job.counters->run_cursor = 0;
     }
     if (gid >= job.n_tiles) return;
@@ -199,7 +208,7 @@ __global__ void gd_prep_kernel(Job job)
     ti.ctg = lo;
     ti.t0 = (t - c.tile_beg) * T;
     int32_t tend = ti.t0 + T < c.length ? ti.t0 + T : c.length;
-    int32_t from = ti.t0 > job.lookback ? ti.t0 - job.lookback : 0;
+    int32_t from = ti.t0 > lookback ? ti.t0 - lookback : 0;
     lower_bound_pair(c.pos, c.n_reads, from, tend, ti.lo, ti.hi);
     ti.clo = c.n_reads ? c.off[ti.lo] : 0u;
     ti.chi = c.n_reads ? c.off[ti.hi] : 0u;
@@ -251,6 +260,7 @@ __device__ __forceinline__ int wave_min(int v)
 
 #include "gd_tile_v6.hpp"
 #include "gd_scatter.hpp"
+#include "gd_chunk.hpp"
 #include "gd_depthwed.hpp"
 #include "gd_tile_v5.hpp"
 

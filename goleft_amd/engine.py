@@ -14,8 +14,8 @@ from . import _lib
 from ._lib import GdBatch, GdParams, GdRun, GdStats
 
 CLASS_NAMES = ("NO_COVERAGE", "LOW_COVERAGE", "CALLABLE", "EXCESSIVE_COVERAGE")
-K_PREP, K_TILE, K_RUNS, K_EXPAND, K_SCAN = 0, 1, 2, 3, 4
-PATH_AUTO, PATH_TILE, PATH_SCATTER = 0, 1, 2
+K_PREP, K_TILE, K_RUNS, K_EXPAND, K_SCAN, K_CKPT = 0, 1, 2, 3, 4, 5
+PATH_AUTO, PATH_TILE, PATH_SCATTER, PATH_CHUNK = 0, 1, 2, 3
 
 
 class GdError(RuntimeError):
@@ -70,7 +70,7 @@ class DepthEngine:
         self.params = p
 
     def set_path(self, path: int):
-        """PATH_AUTO / PATH_TILE / PATH_SCATTER (include/goleft_depth.h GD_PATH_*)."""
+        """PATH_AUTO / PATH_TILE / PATH_SCATTER / PATH_CHUNK (include/goleft_depth.h GD_PATH_*)."""
         self._chk(self._lib.gd_set_path(self._ctx, int(path)))
 
     def set_outputs(self, perbase: bool = True):

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define GD_ABI_VERSION 2
+#define GD_ABI_VERSION 3
 
 typedef enum {
     GD_OK = 0,
@@ -106,25 +106,32 @@ typedef struct {
     int32_t  lookback;       /* look-back span in use */
     int32_t  max_span_seen;  /* largest reference span among kept reads */
     int32_t  reruns;         /* times the last gd_compute re-ran (span / run capacity) */
-    int32_t  path;           /* GD_PATH_TILE or GD_PATH_SCATTER: what the last gd_compute ran */
+    int32_t  path;           /* GD_PATH_TILE / _SCATTER / _CHUNK: what the last gd_compute ran */
     int32_t  reserved;
 } gd_stats;
 
-/* Kernel ids for gd_kernel_ms.  Tile path: PREP, TILE, RUNS.  Scatter path:
- * PREP (zero-fill + init), EXPAND (CIGAR expand + scatter), SCAN (in-place scan
- * + window / class reductions), RUNS. */
-enum { GD_K_PREP = 0, GD_K_TILE = 1, GD_K_RUNS = 2, GD_K_EXPAND = 3, GD_K_SCAN = 4, GD_K_COUNT = 5 };
+/* Kernel ids for gd_kernel_ms.  Tile path: PREP, TILE, RUNS.  Chunk path: CKPT
+ * (CIGAR checkpoints + read ends), PREP, TILE (the long-read tile kernel), RUNS.
+ * Scatter path: PREP (zero-fill + init), EXPAND (CIGAR expand + scatter), SCAN
+ * (in-place scan + window / class reductions), RUNS. */
+enum { GD_K_PREP = 0, GD_K_TILE = 1, GD_K_RUNS = 2, GD_K_EXPAND = 3, GD_K_SCAN = 4, GD_K_CKPT = 5,
+       GD_K_COUNT = 6 };
 
-/* Device algorithm of gd_compute.  Both are bit exact; they differ in cost.
- *   TILE     one workgroup per 4096-position tile re-examines the reads that
- *            start within one maximum read span before it (LDS difference
- *            array, fused scan): the short-read path, ~6.5 HBM bytes per base;
+/* Device algorithm of gd_compute.  All are bit exact; they differ in cost.
+ *   TILE     one workgroup per 4096-position tile re-walks the CIGARs of the
+ *            reads that start within one maximum read span before it (LDS
+ *            difference array, fused scan): the short-read path, ~6.5 HBM bytes
+ *            per base;
+ *   CHUNK    the same tile shape for long reads (ONT/PacBio, spliced): one pass
+ *            over the CIGARs leaves a reference-position checkpoint every 64 ops
+ *            and every read's end; a tile then expands only the 64-op chunks that
+ *            reach it (LDS marks, no global atomics, any read span);
  *   SCATTER  every CIGAR op is expanded once and scattered with global integer
- *            atomics, then one in-place scan pass: no dependence on read span,
- *            the path for long reads (ONT/PacBio) and spliced alignments;
- *   AUTO     SCATTER when records average more than 6 CIGAR ops or a read spans
+ *            atomics, then one in-place scan pass: no look-back at all, kept for
+ *            pathological span distributions and as a cross-check;
+ *   AUTO     CHUNK when records average more than 6 CIGAR ops or a read spans
  *            more than 32768 reference bases, else TILE (default). */
-enum { GD_PATH_AUTO = 0, GD_PATH_TILE = 1, GD_PATH_SCATTER = 2 };
+enum { GD_PATH_AUTO = 0, GD_PATH_TILE = 1, GD_PATH_SCATTER = 2, GD_PATH_CHUNK = 3 };
 
 const char* gd_strerror(int status);
 int         gd_abi_version(void);
@@ -148,7 +155,7 @@ int gd_set_path(gd_ctx* ctx, int path);
  * int32 per-base vector (12.4 GB for a human genome), needed by gd_perbase,
  * gd_device_perbase and the --bed region reductions.  Without it only window
  * sums/minima and class runs are produced -- all `goleft depth` prints for a whole
- * genome, and what a cohort (depthwed) needs; tile path only. */
+ * genome, and what a cohort (depthwed) needs; tile and chunk paths only. */
 enum { GD_OUT_PERBASE = 1 };
 int gd_set_outputs(gd_ctx* ctx, unsigned flags);
 

@@ -49,6 +49,29 @@ def random_reads(rng, length, n, max_ops=6, max_len=300, long_reads=False):
     return po.Reads(pos, flag, mapq, off, cigar)
 
 
+def long_cigar_reads(rng, length, n_ops_list, max_step=40, skip_every=0):
+    """One read per entry of n_ops_list with exactly that many CIGAR ops: M runs
+    interleaved with I / D (and S / = / X / P / zero-length ops), the shape of long-read
+    alignments; every skip_every-th read also carries one long N skip.  Reads start
+    at sorted random positions in the first half of the contig."""
+    n = len(n_ops_list)
+    pos = np.sort(rng.integers(0, max(1, length // 2), size=n)).astype(np.int32)
+    off = np.zeros(n + 1, np.uint32)
+    off[1:] = np.cumsum(n_ops_list)
+    m = int(off[-1])
+    ops = rng.choice(9, size=m, p=[0.5, 0.2, 0.2, 0.0, 0.02, 0.0, 0.02, 0.03, 0.03])
+    lens = rng.integers(0, max_step, size=m)
+    if skip_every:
+        for i in range(0, n, skip_every):
+            if n_ops_list[i] > 2:
+                k = int(off[i]) + int(rng.integers(1, n_ops_list[i] - 1))
+                ops[k], lens[k] = 3, int(rng.integers(5000, 40000))
+    cigar = ((lens.astype(np.uint32) << 4) | ops.astype(np.uint32)).astype(np.uint32)
+    flag = rng.choice([0, 16, 0x800, 0x400], size=n, p=[0.5, 0.3, 0.1, 0.1]).astype(np.uint16)
+    mapq = rng.choice([0, 20, 60], size=n, p=[0.05, 0.25, 0.7]).astype(np.uint8)
+    return po.Reads(pos, flag, mapq, off, cigar)
+
+
 def oracle_windows(depth, W, start=0):
     """(sums, mins) of W-anchored windows clipped to [start, start+len(depth))."""
     end = start + len(depth)

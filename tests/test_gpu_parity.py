@@ -8,14 +8,18 @@ from oracle import pyoracle as po
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=["tile", "scatter"])
+PATH_IDS = {"tile": 1, "scatter": 2, "chunk": 3}
+
+
+@pytest.fixture(scope="module", params=["tile", "chunk", "scatter"])
 def eng(request):
-    """Every parity test runs on both device algorithms (GD_PATH_TILE: LDS tiles
-    with look-back, the short-read path; GD_PATH_SCATTER: global scatter + in-place
-    scan, the long-read path)."""
-    from goleft_amd.engine import DepthEngine, PATH_SCATTER, PATH_TILE
+    """Every parity test runs on all three device algorithms (GD_PATH_TILE: LDS tiles
+    re-walking whole CIGARs, the short-read path; GD_PATH_CHUNK: LDS tiles over
+    checkpointed 64-op CIGAR chunks, the long-read path; GD_PATH_SCATTER: global
+    scatter + in-place scan)."""
+    from goleft_amd.engine import DepthEngine
     e = DepthEngine(0)
-    e.set_path(PATH_TILE if request.param == "tile" else PATH_SCATTER)
+    e.set_path(PATH_IDS[request.param])
     e.path_name = request.param
     yield e
     e.close()
@@ -96,7 +100,7 @@ def test_synthetic_short_reads(eng):
     check_all(eng, contigs, {0: r}, 1000, 1, 4, 0)
     st = eng.stats()
     assert st.n_reads == n and st.reruns == 0
-    assert st.path == (1 if eng.path_name == "tile" else 2)
+    assert st.path == PATH_IDS[eng.path_name]
 
 
 def _uniform_reads(pos, length, flag=0, mapq=60):
@@ -183,14 +187,14 @@ def test_read_span_limit_is_an_error(eng):
         with pytest.raises(GdError) as ei:
             eng.compute()
         assert ei.value.status == -5      # GD_E_RANGE
-    else:                                 # the scatter path has no span limit
+    else:                                 # the chunk and scatter paths have no span limit
         eng.compute()
         check_all(eng, [("c", L)], {0: r}, 1000, 1, 4, 0)
 
 
 def test_auto_path_switches_on_long_spans(auto_eng):
     """GD_PATH_AUTO: short reads run on the tile path; a read spanning more than
-    32768 bases moves the data set to the scatter path (one re-run), CIGAR-heavy
+    32768 bases moves the data set to the chunk path (one re-run), CIGAR-heavy
     records start there."""
     eng = auto_eng
     rng = np.random.default_rng(17)
@@ -211,13 +215,13 @@ def test_auto_path_switches_on_long_spans(auto_eng):
                      np.concatenate([cig, short.cigar[short.pos >= 1000]]))
     run_engine(eng, contigs, {0: mixed}, window_size=250, min_mapq=1, min_cov=4)
     st = eng.stats()
-    assert st.path == 2 and st.reruns == 1
+    assert st.path == 3 and st.reruns == 1
     check_all(eng, contigs, {0: mixed}, 250, 1, 4, 0)
-    # records averaging more than 6 ops go to the scatter path directly
+    # records averaging more than 6 ops go to the chunk path directly
     heavy = H.random_reads(rng, L, 5000, max_ops=40)
     run_engine(eng, contigs, {0: heavy}, window_size=250, min_mapq=1, min_cov=4)
     st = eng.stats()
-    assert st.path == 2 and st.reruns == 0
+    assert st.path == 3 and st.reruns == 0
     check_all(eng, contigs, {0: heavy}, 250, 1, 4, 0)
 
 
@@ -233,12 +237,55 @@ def test_synthetic_ont_long_reads(eng):
     check_all(eng, contigs, {0: r, 1: r2}, 1000, 1, 4, 0)
 
 
-def test_auto_path_picks_scatter_for_ont(auto_eng):
+@pytest.mark.parametrize("seed", range(3))
+def test_chunk_edges_and_huge_cigars(eng, seed):
+    """CIGAR lengths on either side of the 64-op checkpoint chunk and of the 4096-op
+    checkpoint block (strided probe), chunks that consume no reference, N skips that
+    jump over whole tiles, reads hanging over the contig end."""
+    rng = np.random.default_rng(100 + seed)
+    L = [90000, 400000, 20000][seed]
+    n_ops = [1, 2, 8, 9, 63, 64, 65, 127, 128, 129, 191, 192, 193, 1000, 4095, 4096, 4097, 8191, 8193,
+             20000, 300, 64, 64, 128, 4160] * 3
+    rng.shuffle(n_ops)
+    r = H.long_cigar_reads(rng, L, n_ops, max_step=[12, 40, 3][seed], skip_every=[0, 5, 0][seed])
+    # a read whose middle chunks consume no reference at all (insertions only)
+    ins = np.concatenate([np.full(70, (5 << 4) | 0), np.full(200, (3 << 4) | 1), np.full(70, (7 << 4) | 0)]).astype(np.uint32)
+    r2 = po.Reads(np.concatenate([r.pos, [r.pos[-1]]]).astype(np.int32), np.concatenate([r.flag, [0]]).astype(np.uint16),
+                  np.concatenate([r.mapq, [60]]).astype(np.uint8),
+                  np.concatenate([r.cigar_off, [r.cigar_off[-1] + len(ins)]]).astype(np.uint32),
+                  np.concatenate([r.cigar, ins]).astype(np.uint32))
+    contigs = [("lr", L), ("short", 5000)]
+    few = H.long_cigar_reads(rng, 5000, [130, 70, 64], max_step=30)
+    W = [1000, 250, 37][seed]
+    run_engine(eng, contigs, {0: r2, 1: few}, window_size=W, min_mapq=1, min_cov=2)
+    check_all(eng, contigs, {0: r2, 1: few}, W, 1, 2, 0)
+    assert eng.stats().path == PATH_IDS[eng.path_name]
+
+
+def test_chunk_windows_only_output():
+    """The long-read tile path also runs without the per-base vector."""
+    from goleft_amd import synth
+    from goleft_amd.engine import DepthEngine, PATH_CHUNK
+    L = 600_000
+    r = po.Reads(*synth.ont_reads_numpy(L, synth.n_ont_reads_for(L), 12))
+    with DepthEngine(0) as e:
+        e.set_path(PATH_CHUNK)
+        e.set_outputs(perbase=False)
+        run_engine(e, [("c", L)], {0: r}, window_size=1000, min_mapq=1, min_cov=4)
+        want = po.perbase_c(r, 1, 0, L)
+        ws, wm = H.oracle_windows(want, 1000)
+        gs, gm = e.windows(0)
+        assert np.array_equal(gs, ws) and np.array_equal(gm, wm)
+        assert np.array_equal(e.callable_runs(0), H.oracle_runs(want, 4, 0, po.step_for(1000)))
+        assert e.stats().path == 3
+
+
+def test_auto_path_picks_chunk_for_ont(auto_eng):
     from goleft_amd import synth
     L = 400_000
     r = po.Reads(*synth.ont_reads_numpy(L, synth.n_ont_reads_for(L), 4))
     run_engine(auto_eng, [("c", L)], {0: r}, window_size=250, min_mapq=1, min_cov=4)
-    assert auto_eng.stats().path == 2 and auto_eng.stats().reruns == 0
+    assert auto_eng.stats().path == 3 and auto_eng.stats().reruns == 0
     check_all(auto_eng, [("c", L)], {0: r}, 250, 1, 4, 0)
 
 
