@@ -67,8 +67,8 @@ struct gd_ctx {
 
     int tile_T = 4096;
     int tile_NT = 256;
-    int ablate = 0;                     // debug: GOLEFT_GD_ABLATE (v5 kernel only)
-    int kernel_gen = 6;                 // debug: GOLEFT_GD_KERNEL=v5 selects the previous tile kernel
+    int ablate = 0;                     // debug: GOLEFT_GD_ABLATE (unused by the current kernels)
+    int kernel_gen = 7;                 // debug: GOLEFT_GD_KERNEL=v6 selects the previous tile kernel
     int tile_opt = 0;                   // GOLEFT_GD_OPT bit 0: non-temporal per-base stores
     bool lookback_pinned = false;       // max_span_hint given: never shrink below it
     int path = GD_PATH_AUTO;            // gd_set_path / GOLEFT_GD_PATH
@@ -179,6 +179,18 @@ int64_t derive_step(const gd_params& p)
     return s * p.window_size;
 }
 
+// (m, s) with floor(x / d) == (x * m) >> s for every x < 2^31 (1 <= d < 2^31):
+// s = 31 + ceil(log2 d), m = ceil(2^s / d) < 2^32  (Granlund & Montgomery 1994, N = 31).
+void magic_u31(uint32_t d, uint32_t* m, uint32_t* s)
+{
+    if (d == 0) d = 1;
+    uint32_t l = 0;
+    while (l < 31 && (1u << l) < d) ++l;
+    const unsigned __int128 num = (unsigned __int128)1 << (31 + l);
+    *m = (uint32_t)((num + d - 1) / d);
+    *s = 31 + l;
+}
+
 int set_device(gd_ctx* c)
 {
     HIPCHK(c, hipSetDevice(c->device));
@@ -197,12 +209,17 @@ void launch_prep(gd_ctx* c, const gd::Job& job)
 template <int T, int NT>
 void launch_tile(gd_ctx* c, const gd::Job& job)
 {
-    if (c->kernel_gen == 5) {
-        hipLaunchKernelGGL((gd::v5::gd_tile_kernel<T, NT>), dim3(job.n_tiles), dim3(NT), 0, c->stream, job);
-        return;
-    }
     // 8 XCDs: the grid is 8 equal slices of the tile list (see the kernel)
     const unsigned grid = (unsigned)(((job.n_tiles + 7) / 8) * 8);
+    if (c->kernel_gen == 7 && T == 4096 && NT == 256) {     // v7 is built for the default shape only
+        if (!c->keep_perbase)
+            hipLaunchKernelGGL((gd::v7::gd_tile_kernel<4096, 256, 2>), dim3(grid), dim3(256), 0, c->stream, job);
+        else if (c->tile_opt & 1)
+            hipLaunchKernelGGL((gd::v7::gd_tile_kernel<4096, 256, 1>), dim3(grid), dim3(256), 0, c->stream, job);
+        else
+            hipLaunchKernelGGL((gd::v7::gd_tile_kernel<4096, 256, 0>), dim3(grid), dim3(256), 0, c->stream, job);
+        return;
+    }
     if (!c->keep_perbase)
         hipLaunchKernelGGL((gd::gd_tile_kernel<T, NT, 2>), dim3(grid), dim3(NT), 0, c->stream, job);
     else if (c->tile_opt & 1)
@@ -283,7 +300,7 @@ int gd_create(int device_id, gd_ctx** out)
         if (t == 4096 || t == 8192) c->tile_T = t;
     }
     if (const char* e = getenv("GOLEFT_GD_ABLATE")) c->ablate = atoi(e);
-    if (const char* e = getenv("GOLEFT_GD_KERNEL")) c->kernel_gen = (e[0] == 'v' && e[1] == '5') ? 5 : 6;
+    if (const char* e = getenv("GOLEFT_GD_KERNEL")) c->kernel_gen = (e[0] == 'v' && e[1] == '6') ? 6 : 7;
     if (const char* e = getenv("GOLEFT_GD_OPT")) c->tile_opt = atoi(e) & 1;
     if (const char* e = getenv("GOLEFT_GD_SCOPE")) c->scope_wg = e[0] == 'w';
     if (const char* e = getenv("GOLEFT_GD_PATH"))
@@ -709,6 +726,8 @@ int gd_compute(gd_ctx* c)
         job.lookback = c->lookback;
         job.ablate = c->ablate;
         job.step = derive_step(P);
+        magic_u31((uint32_t)job.W, &job.w_magic, &job.w_shift);
+        magic_u31(job.step > 0x7fffffffLL ? 0x7fffffffu : (uint32_t)job.step, &job.s_magic, &job.s_shift);
 
         job.n_units = (uint32_t)n_units;
         job.tile_status = c->d_status;
@@ -836,8 +855,8 @@ int gd_compute(gd_ctx* c)
                 continue;
             }
             used_lookback = c->lookback;
-            if (c->kernel_gen != 5 && !c->lookback_pinned) {
-                // the v6 kernel reports the true maximum: a look-back far above it only
+            if (!c->lookback_pinned) {
+                // the tile kernel reports the true maximum: a look-back far above it only
                 // costs re-examined reads, so the next compute uses a tighter (still verified) one
                 const int want = std::max(64, (k.max_span + 63) & ~63);
                 if (want * 2 <= c->lookback) c->lookback = want;

@@ -106,7 +106,7 @@ struct Job {
     int32_t   maxmean;
     uint32_t  flag_mask;
     int32_t   lookback;
-    int32_t   ablate;         // debug only (GOLEFT_GD_ABLATE): 1 skip phase A, 2 skip LDS marks,
+    int32_t   ablate;         // debug only (GOLEFT_GD_ABLATE), read by no current kernel: 1 skip phase A, 2 skip LDS marks,
                               // 4 skip per-base stores, 8 skip window/class reductions
     int64_t   step;
     uint32_t  n_units;        // scatter path: 64-read units over all contigs
@@ -114,6 +114,8 @@ struct Job {
     uint32_t* ck;             // chunk path: reference position at every 64th CIGAR op of a read
     int32_t*  rend;           // chunk path: end position of every read (-1: filtered out)
     int32_t   lookback_dev;   // chunk path: look-back = counters->max_span (written by gd_ckpt_kernel)
+    uint32_t  w_magic, w_shift;   // floor(x / W)    = (x * w_magic) >> w_shift for x < 2^31
+    uint32_t  s_magic, s_shift;   // floor(x / step) likewise (step clamped to 2^31-1)
 };
 
 __device__ __forceinline__ int cov_class(int d, int mincov, int maxmean)
@@ -262,7 +264,7 @@ __device__ __forceinline__ int wave_min(int v)
 #include "gd_scatter.hpp"
 #include "gd_chunk.hpp"
 #include "gd_depthwed.hpp"
-#include "gd_tile_v5.hpp"
+#include "gd_tile_v7.hpp"
 
 namespace gd {
 
