@@ -96,10 +96,15 @@ def load_traffic():
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3
     PMC passes (profiles/*_traffic.json, written by tools/traffic_from_pmc.py from
     FETCH_SIZE / WRITE_SIZE collected in separate --pmc runs of this command)."""
-    f = os.path.join(ROOT, "profiles", "r01_wgs_traffic.json")
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_wgs_traffic.json")))
+    if not files:
+        return None
     try:
-        with open(f) as fh:
-            return json.load(fh)
+        with open(files[-1]) as fh:          # the latest round's measurement
+            d = json.load(fh)
+        d["file"] = os.path.relpath(files[-1], ROOT)
+        return d
     except (OSError, ValueError):
         return None
 
@@ -313,7 +318,7 @@ def main():
     }
     if traffic:
         out["roofline"]["traffic_frac_of_peak"] = traffic / avg_tile_s / 1e9 / HBM_PEAK_GBPS
-        out["roofline"]["traffic_source"] = tr.get("source")
+        out["roofline"]["traffic_source"] = "%s: %s" % (tr.get("file"), tr.get("source"))
 
     if args.verify and rank == 0 and r["perbase"]:
         from oracle import pyoracle as po
