@@ -232,10 +232,17 @@ template <int T, int NT>
 void launch_ltile(gd_ctx* c, const gd::Job& job)
 {
     const unsigned grid = (unsigned)(((job.n_tiles + 7) / 8) * 8);
+    if (c->kernel_gen == 6) {                              // GOLEFT_GD_KERNEL=v6: the first long-read kernel
+        if (!c->keep_perbase)
+            hipLaunchKernelGGL((gd::gd_ltile_kernel<T, NT, 2>), dim3(grid), dim3(NT), 0, c->stream, job);
+        else
+            hipLaunchKernelGGL((gd::gd_ltile_kernel<T, NT, 0>), dim3(grid), dim3(NT), 0, c->stream, job);
+        return;
+    }
     if (!c->keep_perbase)
-        hipLaunchKernelGGL((gd::gd_ltile_kernel<T, NT, 2>), dim3(grid), dim3(NT), 0, c->stream, job);
+        hipLaunchKernelGGL((gd::gd_ltile2_kernel<T, NT, 2>), dim3(grid), dim3(NT), 0, c->stream, job);
     else
-        hipLaunchKernelGGL((gd::gd_ltile_kernel<T, NT, 0>), dim3(grid), dim3(NT), 0, c->stream, job);
+        hipLaunchKernelGGL((gd::gd_ltile2_kernel<T, NT, 0>), dim3(grid), dim3(NT), 0, c->stream, job);
 }
 
 }  // namespace

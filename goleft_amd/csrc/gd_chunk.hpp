@@ -324,4 +324,319 @@ __global__ __launch_bounds__(NT) void gd_ltile_kernel(Job job)
     phase_c<T, NT>(job, tile, t0, ti.ctg, tid, lane, wv, s_bmap, s_clo, s_chi, s_wcnt, &s_hasb, &s_base);
 }
 
+// ---------------------------------------------------------------------------
+// LT2: the long-read tile kernel, generation 2.
+//
+// gd_ltile_kernel (above) walks one overlapping read at a time per wave and
+// spends ~120 wave-instructions per 64 CIGAR ops; at ONT shape (4.8e9 ops,
+// every chunk expanded ~1.2 times) it is instruction-issue bound.  Here:
+//   * depth of a read = [pos <= x < end] - [x inside one of its D/N ops]
+//     (every reference-consuming op is either counted, M/=/X, or a D/N): the
+//     read contributes ONE +1/-1 pair per tile (lane-parallel, from the start /
+//     end arrays the checkpoint pass wrote) and each D/N op one -1/+1 pair.
+//     Only a quarter of ONT-like ops are deletions, the M runs need no marks at
+//     all, and no neighbour-op logic is left;
+//   * work is split into producing and consuming a per-wave queue of ITEMS
+//     {first op index, reference position of the first op, op count <= 128}
+//     (two consecutive 64-op checkpoint chunks): the checkpoints of up to four
+//     overlapping reads are fetched in one round trip, lanes whose chunk pair
+//     reaches the tile push an item (ballot + mbcnt, no atomics); items are
+//     expanded four at a time, two ops per lane (one 8-byte load), four
+//     coalesced loads in flight while the previous four expand, and the four
+//     wave scans of the reference-consuming lengths interleave (scan4).
+// Reference positions use plain 32-bit scans whenever every op of the four
+// items consumes <= 2^23 bases (128 * 2^23 + 2^31 < 2^32: no wrap); items with
+// a longer D/N op take a saturating scan.  Integer adds commute, so the
+// per-base result equals the M-run marking of gd_ltile_kernel bit for bit.
+// ---------------------------------------------------------------------------
+constexpr int LQ_CAP = 128;                   // queue items per wave: one round of 4 slots pushes <= 4 * 32
+constexpr uint32_t LQ_OPS = 2 * CK_OPS;       // ops per item
+
+struct LQueue {
+    uint32_t* ci;        // [LQ_CAP] index of the item's first op in the contig's CIGAR array
+    uint32_t* st;        // [LQ_CAP] reference position of that op
+    uint32_t* no;        // [LQ_CAP] ops in the item (1..128)
+};
+
+// -1 over [s, s+len) of a D/N op (absolute, saturated positions)
+__device__ __forceinline__ void del_mark(int32_t* s_diff, bool del, uint32_t s, uint32_t len, int t0, int tlen)
+{
+    const int rs = (int)s - t0;
+    const int re = (int)sat_pos(s + len) - t0;
+    if (del & (re >= 0) & (rs < tlen)) {                 // reaches t0-1 or beyond, starts before the tile end
+        atomicAdd(&s_diff[rs > -1 ? rs : -1], -1);
+        if (re < tlen) atomicAdd(&s_diff[re], 1);
+    }
+}
+
+// Four items, lane k holds ops 2k and 2k+1 of each (0 = nothing).
+__device__ __forceinline__ void expand4_lds(const uint2 (&cg)[4], const uint32_t (&st)[4], int t0, int tlen,
+                                            int32_t* s_diff)
+{
+    uint32_t len0[4], len1[4], cons0[4], loc[4];
+    bool del0[4], del1[4];
+    bool big = false;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const uint32_t op0 = cg[g].x & 0xf, op1 = cg[g].y & 0xf;
+        len0[g] = cg[g].x >> 4; len1[g] = cg[g].y >> 4;
+        cons0[g] = ((0x18du >> op0) & 1u) ? len0[g] : 0u;                  // M D N = X
+        const uint32_t cons1 = ((0x18du >> op1) & 1u) ? len1[g] : 0u;
+        del0[g] = ((0xcu >> op0) & 1u) && len0[g] != 0;                   // D N
+        del1[g] = ((0xcu >> op1) & 1u) && len1[g] != 0;
+        loc[g] = cons0[g] + cons1;
+        big = big || (cons0[g] | cons1) > (1u << 23);
+    }
+    int incl[4];
+    if (__builtin_amdgcn_ballot_w64(big) == 0ull) {              // wave uniform
+#pragma unroll
+        for (int g = 0; g < 4; ++g) incl[g] = (int)loc[g];
+        scan4(incl[0], incl[1], incl[2], incl[3]);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) incl[g] = (int)sat_pos(st[g] + ((uint32_t)incl[g] - loc[g]));
+    } else {
+        // rare: saturating scans (positions stay exact up to POS_CAP, then stick there)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const uint32_t inc = wave_inclusive_scan_sat(sat_pos(loc[g]));
+            const uint32_t exc = (uint32_t)wave_prev_lane((int)inc, 0);
+            incl[g] = (int)sat_pos(st[g] + exc);
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const uint32_t s0 = (uint32_t)incl[g];
+        del_mark(s_diff, del0[g], s0, len0[g], t0, tlen);
+        del_mark(s_diff, del1[g], sat_pos(s0 + cons0[g]), len1[g], t0, tlen);
+    }
+}
+
+template <int T, int NT, int OPT>
+__global__ __launch_bounds__(NT) void gd_ltile2_kernel(Job job)
+{
+    constexpr int NW = NT / WAVE;
+    constexpr int CHUNK = T / NW;
+    constexpr int ROWS = CHUNK / 256;
+    constexpr int NWORDS = T / 32;
+    constexpr int G = 4;                   // overlapping reads whose checkpoints are fetched together
+    static_assert(CHUNK % 256 == 0, "wave chunk must be whole rows");
+
+    __shared__ __attribute__((aligned(16))) int32_t s_diffp[T + 4];  // [3] = index -1
+    __shared__ uint32_t s_bmap[NWORDS];
+    __shared__ uint32_t s_clo[NWORDS];
+    __shared__ uint32_t s_chi[NWORDS];
+    __shared__ uint32_t s_q[NW * 3 * LQ_CAP];
+    __shared__ int32_t  s_wtot[NW];
+    __shared__ uint32_t s_wcnt[NW];
+    __shared__ uint32_t s_hasb;
+    __shared__ uint32_t s_base;
+    int32_t* const s_diff = s_diffp + 4;
+
+    const int per = (job.n_tiles + 7) >> 3;                // XCD-contiguous tile order
+    const int tile = (int)(blockIdx.x & 7u) * per + (int)(blockIdx.x >> 3);
+    if (tile >= job.n_tiles) return;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & (WAVE - 1);
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const TileInfo ti = job.tiles[tile];
+    const ContigDev& c = job.ctgs[ti.ctg];
+    const uint32_t* const ck = job.ck + c.ck_off;
+    const int32_t t0 = ti.t0;
+    const int32_t tend = t0 + T < ti.length ? t0 + T : ti.length;
+    const int tlen = tend - t0;
+
+    const uint32_t nrd = ti.hi - ti.lo;
+    const int32_t* const gpos = ti.pos + ti.lo;
+    const int32_t* const gend = job.rend + c.read_off + ti.lo;
+    const uint32_t* const goff = ti.off + ti.lo;
+    const uint32_t* const cigar = ti.cigar;
+
+    {
+        const int4 z = make_int4(0, 0, 0, 0);
+        int4* d4 = reinterpret_cast<int4*>(s_diffp);
+#pragma unroll
+        for (int i = tid; i < T / 4 + 1; i += NT) d4[i] = z;
+        for (int i = tid; i < NWORDS; i += NT) { s_bmap[i] = 0; s_clo[i] = 0; s_chi[i] = 0; }
+        if (tid == 0) s_hasb = 0;
+    }
+    __syncthreads();
+
+    LQueue Q;
+    Q.ci = &s_q[wv * 3 * LQ_CAP]; Q.st = Q.ci + LQ_CAP; Q.no = Q.st + LQ_CAP;
+    uint32_t qn = 0;                                       // items queued (wave uniform)
+
+    // four queued items: their ops (lane k = ops 2k, 2k+1; 0 past the item) and start positions.
+    // Items start at a multiple of 64 ops of a 4-byte aligned array, hence 8-byte aligned pairs;
+    // an odd last op is fetched alone.
+    auto fetch4 = [&](uint32_t i, uint32_t cnt, uint2 (&cg)[4], uint32_t (&st)[4]) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            cg[g] = make_uint2(0u, 0u); st[g] = POS_CAP;
+            if (i + (uint32_t)g < cnt) {                   // wave uniform
+                const uint32_t ci = (uint32_t)__builtin_amdgcn_readfirstlane((int)Q.ci[i + g]);
+                const uint32_t no = (uint32_t)__builtin_amdgcn_readfirstlane((int)Q.no[i + g]);
+                st[g] = (uint32_t)__builtin_amdgcn_readfirstlane((int)Q.st[i + g]);
+                const uint32_t k = 2u * (uint32_t)lane;
+                const uint32_t* src = cigar + ci + k;
+                if (k + 1u < no && (((uintptr_t)src) & 7u) == 0) cg[g] = *reinterpret_cast<const uint2*>(src);
+                else if (k + 1u < no) cg[g] = make_uint2(src[0], src[1]);
+                else if (k < no) cg[g].x = src[0];
+            }
+        }
+    };
+    auto drain = [&](uint32_t cnt) {
+        __builtin_amdgcn_wave_barrier();
+        uint2 cgA[4];
+        uint32_t stA[4];
+        fetch4(0, cnt, cgA, stA);
+        for (uint32_t i = 0; i < cnt; i += 4u) {
+            uint2 cgB[4];
+            uint32_t stB[4];
+            fetch4(i + 4u, cnt, cgB, stB);                 // next four are in flight while these expand
+            expand4_lds(cgA, stA, t0, tlen, s_diff);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) { cgA[g] = cgB[g]; stA[g] = stB[g]; }
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+    // ---- phase A: candidate reads -> chunk items -> LDS +1/-1 ----------------
+    // Candidate i of a batch of NT belongs to wave i % NW: the overlapping reads (mostly
+    // the latest starters) spread evenly over the waves.  G "slots" each hold one
+    // overlapping read and the block of 64 chunks under examination; a read with more
+    // than 64 chunks keeps its slot until its chunks pass the tile end.
+    for (uint32_t base = 0; base < nrd; base += (uint32_t)NT) {
+        const uint32_t idx = base + (uint32_t)(lane * NW + wv);
+        const bool inb = idx < nrd;
+        const int32_t p = inb ? gpos[idx] : 0x7fffffff;
+        const int32_t e = inb ? gend[idx] : -1;
+        const bool hit = e >= t0 && p < tend;                 // reaches t0-1 or beyond
+        uint32_t o0 = 0, n = 0;
+        if (hit) {
+            o0 = goff[idx]; n = goff[idx + 1] - o0;
+            // the read's own +1 / -1 (its D/N ops subtract below)
+            const int rs = p - t0;
+            atomicAdd(&s_diff[rs > -1 ? rs : -1], 1);
+            if (e < tend) atomicAdd(&s_diff[e - t0], -1);
+        }
+        unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
+
+        bool act[G];
+        uint32_t oj[G], nj[G], ej[G], nch[G], cb[G];
+        const uint32_t* ckj[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) { act[g] = false; oj[g] = nj[g] = ej[g] = nch[g] = cb[g] = 0; ckj[g] = ck; }
+        bool any = false;
+        while (m != 0ull || any) {
+            // free slots take the next overlapping reads
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                if (act[g] || m == 0ull) continue;            // wave uniform
+                const int j = __ffsll((long long)m) - 1;
+                m &= m - 1ull;
+                oj[g] = (uint32_t)__builtin_amdgcn_readlane((int)o0, j);
+                nj[g] = (uint32_t)__builtin_amdgcn_readlane((int)n, j);
+                ej[g] = (uint32_t)__builtin_amdgcn_readlane(e, j);
+                const uint32_t rj = ti.lo + (uint32_t)__builtin_amdgcn_readlane((int)idx, j);
+                nch[g] = (nj[g] + CK_OPS - 1u) >> 6;
+                ckj[g] = ck + ((oj[g] >> 6) + rj);
+                cb[g] = 0;
+                act[g] = true;
+                if (nch[g] > 64u) {
+                    // more than 4096 ops: a strided probe of the (monotone) checkpoints finds
+                    // the block of 64 chunks where the tile begins
+                    const uint32_t stride = (nch[g] + 63u) >> 6;
+                    const uint32_t pq = (uint32_t)lane * stride;
+                    const uint32_t pv = pq < nch[g] ? ckj[g][pq] : POS_CAP;
+                    // chunks before the last probe that starts before t0 end before t0
+                    const int pc = __popcll(__builtin_amdgcn_ballot_w64(pq < nch[g] && (int)pv < t0));
+                    cb[g] = pc > 1 ? (uint32_t)(pc - 1) * stride : 0u;
+                }
+            }
+            // the checkpoints of all slots in one round trip; even lanes own the pair of
+            // chunks (q, q+1): c0 = where it starts, c2 = where it ends
+            uint32_t c0[G], c2[G];
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const uint32_t q = cb[g] + (uint32_t)lane;
+                c0[g] = (act[g] && q < nch[g]) ? ckj[g][q] : POS_CAP;
+                c2[g] = (act[g] && q + 2u < nch[g]) ? ckj[g][q + 2u] : ej[g];
+            }
+            unsigned long long cm[G];
+            uint32_t cnt[G], tot = 0;
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const uint32_t q = cb[g] + (uint32_t)lane;
+                cm[g] = __builtin_amdgcn_ballot_w64(act[g] && (lane & 1) == 0 && q < nch[g] &&
+                                                    (int)c0[g] < tend && (int)c2[g] >= t0);
+                cnt[g] = (uint32_t)__popcll(cm[g]);
+                tot += cnt[g];
+            }
+            if (qn + tot > (uint32_t)LQ_CAP) { drain(qn); qn = 0; }   // tot <= 4 * 32 = LQ_CAP
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                if ((cm[g] >> lane) & 1ull) {
+                    const uint32_t rk = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(cm[g] >> 32),
+                                                 __builtin_amdgcn_mbcnt_lo((uint32_t)cm[g], 0u));
+                    const uint32_t first = (cb[g] + (uint32_t)lane) * CK_OPS, left = nj[g] - first;
+                    Q.ci[rk] = oj[g] + first; Q.st[rk] = c0[g]; Q.no[rk] = left < LQ_OPS ? left : LQ_OPS;
+                }
+                qn += cnt[g];
+            }
+            // a slot is done when its chunks are exhausted or start at/after the tile end
+            // (checkpoints only grow)
+            any = false;
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                if (!act[g]) continue;
+                const bool past = (int)(uint32_t)__builtin_amdgcn_readlane((int)c0[g], 63) >= tend;
+                if (cb[g] + 64u >= nch[g] || past) act[g] = false;
+                else { cb[g] += 64u; any = true; }
+            }
+        }
+    }
+    if (qn != 0u) drain(qn);
+    __syncthreads();
+
+    // ---- phase B pass 1: wave chunk totals -------------------------------
+    const int chunk0 = wv * CHUNK;
+    {
+        int tot = 0;
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            const int4 v = *reinterpret_cast<const int4*>(&s_diff[chunk0 + r * 256 + lane * 4]);
+            tot += v.x + v.y + v.z + v.w;
+        }
+        tot = wave_total(tot);
+        if (lane == 0) s_wtot[wv] = tot;
+    }
+    __syncthreads();
+
+    // ---- phase B pass 2: scan, store, window reduce, class boundaries ----
+    {
+        PhaseB B;
+        B.s_diff = s_diff; B.s_bmap = s_bmap; B.s_clo = s_clo; B.s_chi = s_chi; B.s_hasb = &s_hasb;
+        B.out = job.perbase + ti.base_off + t0;
+        B.wsum = job.win_sum + ti.win_off;
+        B.wmin = job.win_min + ti.win_off;
+        B.t0 = t0; B.tlen = tlen; B.chunk0 = chunk0; B.lane = lane;
+        B.W = job.W; B.mincov = job.mincov; B.maxmean = job.maxmean; B.step = job.step;
+        int carry = s_diff[-1];                            // depth at t0-1
+#pragma unroll
+        for (int v = 0; v < NW - 1; ++v) carry += v < wv ? s_wtot[v] : 0;
+        B.carry = carry;
+        // a read covers a position at most once: depth <= candidate reads
+        const bool wide = nrd >= (1u << 22);
+        if (tlen == T && !wide) {
+            if constexpr (ROWS == 4) v7::phase_b_rows<ROWS, OPT>(B, job.w_magic, job.w_shift, job.s_magic, job.s_shift);
+            else                     phase_b_rows<ROWS, true, false, OPT>(B);
+        } else {
+            phase_b_rows<ROWS, false, true, OPT>(B);
+        }
+    }
+    __syncthreads();
+
+    phase_c<T, NT>(job, tile, t0, ti.ctg, tid, lane, wv, s_bmap, s_clo, s_chi, s_wcnt, &s_hasb, &s_base);
+}
+
 }  // namespace gd

@@ -234,6 +234,30 @@ __device__ __forceinline__ int wave_inclusive_scan(int v)
     return v;
 }
 
+// Four independent wave64 inclusive scans, advanced together: each DPP step of
+// one row is followed by the same step of the other three, so a result is read
+// three instructions after it was written (VALU write -> DPP read needs two
+// wait states) and no hazard no-op is issued.  One volatile block: the
+// compiler would otherwise serialise the four chains again.
+__device__ __forceinline__ void scan4(int& a, int& b, int& c, int& d)
+{
+#define GD_DPP4(ctl)                                  \
+    "v_add_u32_dpp %0, %0, %0 " ctl "\n\t"            \
+    "v_add_u32_dpp %1, %1, %1 " ctl "\n\t"            \
+    "v_add_u32_dpp %2, %2, %2 " ctl "\n\t"            \
+    "v_add_u32_dpp %3, %3, %3 " ctl "\n\t"
+    asm volatile(
+        "s_nop 1\n\t"
+        GD_DPP4("row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1")
+        GD_DPP4("row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1")
+        GD_DPP4("row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1")
+        GD_DPP4("row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1")
+        GD_DPP4("row_bcast:15 row_mask:0xa bank_mask:0xf")
+        GD_DPP4("row_bcast:31 row_mask:0xc bank_mask:0xf")
+        : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+#undef GD_DPP4
+}
+
 __device__ __forceinline__ int wave_sum(int v)
 {
 #pragma unroll
@@ -261,10 +285,10 @@ __device__ __forceinline__ int wave_min(int v)
 }  // namespace gd
 
 #include "gd_tile_v6.hpp"
+#include "gd_tile_v7.hpp"
 #include "gd_scatter.hpp"
 #include "gd_chunk.hpp"
 #include "gd_depthwed.hpp"
-#include "gd_tile_v7.hpp"
 
 namespace gd {
 
