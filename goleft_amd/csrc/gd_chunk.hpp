@@ -341,22 +341,22 @@ __global__ __launch_bounds__(NT) void gd_ltile_kernel(Job job)
 //     (two consecutive 64-op checkpoint chunks): the checkpoints of up to four
 //     overlapping reads are fetched in one round trip, lanes whose chunk pair
 //     reaches the tile push an item (ballot + mbcnt, no atomics); items are
-//     expanded four at a time, two ops per lane (one 8-byte load), four
-//     coalesced loads in flight while the previous four expand, and the four
-//     wave scans of the reference-consuming lengths interleave (scan4).
+//     expanded four at a time, lane k holding op k of each of the item's two
+//     chunks (two coalesced 256-byte loads, no alignment cases), eight loads in
+//     flight while the previous four items expand, and the eight wave scans of
+//     the reference-consuming lengths interleave (scan4 twice), each seeded
+//     with its own chunk's checkpoint.
 // Reference positions use plain 32-bit scans whenever every op of the four
-// items consumes <= 2^23 bases (128 * 2^23 + 2^31 < 2^32: no wrap); items with
+// items consumes <= 2^24 bases (64 * 2^24 + 2^31 < 2^32: no wrap); items with
 // a longer D/N op take a saturating scan.  Integer adds commute, so the
 // per-base result equals the M-run marking of gd_ltile_kernel bit for bit.
 // ---------------------------------------------------------------------------
 constexpr int LQ_CAP = 128;                   // queue items per wave: one round of 4 slots pushes <= 4 * 32
 constexpr uint32_t LQ_OPS = 2 * CK_OPS;       // ops per item
 
-struct LQueue {
-    uint32_t* ci;        // [LQ_CAP] index of the item's first op in the contig's CIGAR array
-    uint32_t* st;        // [LQ_CAP] reference position of that op
-    uint32_t* no;        // [LQ_CAP] ops in the item (1..128)
-};
+// One queue item: {index of the first op in the contig's CIGAR array, reference position
+// of op 0, reference position of op 64, ops in the item (1..128)}
+typedef uint4 LItem;
 
 // -1 over [s, s+len) of a D/N op (absolute, saturated positions)
 __device__ __forceinline__ void del_mark(int32_t* s_diff, bool del, uint32_t s, uint32_t len, int t0, int tlen)
@@ -369,45 +369,53 @@ __device__ __forceinline__ void del_mark(int32_t* s_diff, bool del, uint32_t s, 
     }
 }
 
-// Four items, lane k holds ops 2k and 2k+1 of each (0 = nothing).
-__device__ __forceinline__ void expand4_lds(const uint2 (&cg)[4], const uint32_t (&st)[4], int t0, int tlen,
-                                            int32_t* s_diff)
+// Reference positions of the ops of four chunks (lane k = op k; cons = bases the op consumes).
+__device__ __forceinline__ void chunk_pos4(const uint32_t (&cons)[4], const uint32_t (&st)[4], bool big,
+                                           uint32_t (&pos)[4])
 {
-    uint32_t len0[4], len1[4], cons0[4], loc[4];
-    bool del0[4], del1[4];
-    bool big = false;
+    if (!big) {
+        int incl[4];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const uint32_t op0 = cg[g].x & 0xf, op1 = cg[g].y & 0xf;
-        len0[g] = cg[g].x >> 4; len1[g] = cg[g].y >> 4;
-        cons0[g] = ((0x18du >> op0) & 1u) ? len0[g] : 0u;                  // M D N = X
-        const uint32_t cons1 = ((0x18du >> op1) & 1u) ? len1[g] : 0u;
-        del0[g] = ((0xcu >> op0) & 1u) && len0[g] != 0;                   // D N
-        del1[g] = ((0xcu >> op1) & 1u) && len1[g] != 0;
-        loc[g] = cons0[g] + cons1;
-        big = big || (cons0[g] | cons1) > (1u << 23);
-    }
-    int incl[4];
-    if (__builtin_amdgcn_ballot_w64(big) == 0ull) {              // wave uniform
-#pragma unroll
-        for (int g = 0; g < 4; ++g) incl[g] = (int)loc[g];
+        for (int g = 0; g < 4; ++g) incl[g] = (int)cons[g];
         scan4(incl[0], incl[1], incl[2], incl[3]);
 #pragma unroll
-        for (int g = 0; g < 4; ++g) incl[g] = (int)sat_pos(st[g] + ((uint32_t)incl[g] - loc[g]));
+        for (int g = 0; g < 4; ++g) pos[g] = sat_pos(st[g] + ((uint32_t)incl[g] - cons[g]));
     } else {
         // rare: saturating scans (positions stay exact up to POS_CAP, then stick there)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const uint32_t inc = wave_inclusive_scan_sat(sat_pos(loc[g]));
-            const uint32_t exc = (uint32_t)wave_prev_lane((int)inc, 0);
-            incl[g] = (int)sat_pos(st[g] + exc);
+            const uint32_t inc = wave_inclusive_scan_sat(sat_pos(cons[g]));
+            pos[g] = sat_pos(st[g] + (uint32_t)wave_prev_lane((int)inc, 0));
         }
     }
+}
+
+// Four items: lane k holds op k of the item's first chunk (a) and of its second chunk (b);
+// 0 = nothing.  sa / sb: reference position of op 0 of each chunk.
+__device__ __forceinline__ void expand4_lds(const uint32_t (&a)[4], const uint32_t (&b)[4],
+                                            const uint32_t (&sa)[4], const uint32_t (&sb)[4],
+                                            int t0, int tlen, int32_t* s_diff)
+{
+    uint32_t la[4], lb[4], ca[4], cb[4], pa[4], pb[4];
+    bool da[4], db[4];
+    uint32_t mx = 0;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-        const uint32_t s0 = (uint32_t)incl[g];
-        del_mark(s_diff, del0[g], s0, len0[g], t0, tlen);
-        del_mark(s_diff, del1[g], sat_pos(s0 + cons0[g]), len1[g], t0, tlen);
+        const uint32_t oa = a[g] & 0xf, ob = b[g] & 0xf;
+        la[g] = a[g] >> 4; lb[g] = b[g] >> 4;
+        ca[g] = ((0x18du >> oa) & 1u) ? la[g] : 0u;                       // M D N = X
+        cb[g] = ((0x18du >> ob) & 1u) ? lb[g] : 0u;
+        da[g] = ((0xcu >> oa) & 1u) && la[g] != 0;                        // D N
+        db[g] = ((0xcu >> ob) & 1u) && lb[g] != 0;
+        mx |= ca[g] | cb[g];
+    }
+    const bool big = __builtin_amdgcn_ballot_w64(mx > (1u << 24)) != 0ull;   // wave uniform
+    chunk_pos4(ca, sa, big, pa);
+    chunk_pos4(cb, sb, big, pb);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        del_mark(s_diff, da[g], pa[g], la[g], t0, tlen);
+        del_mark(s_diff, db[g], pb[g], lb[g], t0, tlen);
     }
 }
 
@@ -425,7 +433,7 @@ __global__ __launch_bounds__(NT) void gd_ltile2_kernel(Job job)
     __shared__ uint32_t s_bmap[NWORDS];
     __shared__ uint32_t s_clo[NWORDS];
     __shared__ uint32_t s_chi[NWORDS];
-    __shared__ uint32_t s_q[NW * 3 * LQ_CAP];
+    __shared__ __attribute__((aligned(16))) LItem s_q[NW * LQ_CAP];
     __shared__ int32_t  s_wtot[NW];
     __shared__ uint32_t s_wcnt[NW];
     __shared__ uint32_t s_hasb;
@@ -462,44 +470,41 @@ __global__ __launch_bounds__(NT) void gd_ltile2_kernel(Job job)
     }
     __syncthreads();
 
-    LQueue Q;
-    Q.ci = &s_q[wv * 3 * LQ_CAP]; Q.st = Q.ci + LQ_CAP; Q.no = Q.st + LQ_CAP;
+    LItem* const Q = &s_q[wv * LQ_CAP];
     uint32_t qn = 0;                                       // items queued (wave uniform)
 
-    // four queued items: their ops (lane k = ops 2k, 2k+1; 0 past the item) and start positions.
-    // Items start at a multiple of 64 ops of a 4-byte aligned array, hence 8-byte aligned pairs;
-    // an odd last op is fetched alone.
-    auto fetch4 = [&](uint32_t i, uint32_t cnt, uint2 (&cg)[4], uint32_t (&st)[4]) {
+    // four queued items: op k of each chunk in lane k (0 past the item) and the chunks' start positions
+    auto fetch4 = [&](uint32_t i, uint32_t cnt, uint32_t (&a)[4], uint32_t (&b)[4], uint32_t (&sa)[4],
+                      uint32_t (&sb)[4]) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            cg[g] = make_uint2(0u, 0u); st[g] = POS_CAP;
+            a[g] = 0; b[g] = 0; sa[g] = POS_CAP; sb[g] = POS_CAP;
             if (i + (uint32_t)g < cnt) {                   // wave uniform
-                const uint32_t ci = (uint32_t)__builtin_amdgcn_readfirstlane((int)Q.ci[i + g]);
-                const uint32_t no = (uint32_t)__builtin_amdgcn_readfirstlane((int)Q.no[i + g]);
-                st[g] = (uint32_t)__builtin_amdgcn_readfirstlane((int)Q.st[i + g]);
-                const uint32_t k = 2u * (uint32_t)lane;
-                const uint32_t* src = cigar + ci + k;
-                if (k + 1u < no && (((uintptr_t)src) & 7u) == 0) cg[g] = *reinterpret_cast<const uint2*>(src);
-                else if (k + 1u < no) cg[g] = make_uint2(src[0], src[1]);
-                else if (k < no) cg[g].x = src[0];
+                const LItem it = Q[i + g];                 // same address in every lane: one broadcast read
+                const uint32_t ci = (uint32_t)__builtin_amdgcn_readfirstlane((int)it.x);
+                const uint32_t no = (uint32_t)__builtin_amdgcn_readfirstlane((int)it.w);
+                sa[g] = (uint32_t)__builtin_amdgcn_readfirstlane((int)it.y);
+                sb[g] = (uint32_t)__builtin_amdgcn_readfirstlane((int)it.z);
+                const uint32_t* src = cigar + ci + (uint32_t)lane;
+                if ((uint32_t)lane < no) a[g] = src[0];
+                if ((uint32_t)lane + CK_OPS < no) b[g] = src[CK_OPS];
             }
         }
     };
     auto drain = [&](uint32_t cnt) {
         __builtin_amdgcn_wave_barrier();
-        uint2 cgA[4];
-        uint32_t stA[4];
-        fetch4(0, cnt, cgA, stA);
+        uint32_t aA[4], bA[4], saA[4], sbA[4];
+        fetch4(0, cnt, aA, bA, saA, sbA);
         for (uint32_t i = 0; i < cnt; i += 4u) {
-            uint2 cgB[4];
-            uint32_t stB[4];
-            fetch4(i + 4u, cnt, cgB, stB);                 // next four are in flight while these expand
-            expand4_lds(cgA, stA, t0, tlen, s_diff);
+            uint32_t aB[4], bB[4], saB[4], sbB[4];
+            fetch4(i + 4u, cnt, aB, bB, saB, sbB);         // next four are in flight while these expand
+            expand4_lds(aA, bA, saA, sbA, t0, tlen, s_diff);
 #pragma unroll
-            for (int g = 0; g < 4; ++g) { cgA[g] = cgB[g]; stA[g] = stB[g]; }
+            for (int g = 0; g < 4; ++g) { aA[g] = aB[g]; bA[g] = bB[g]; saA[g] = saB[g]; sbA[g] = sbB[g]; }
         }
         __builtin_amdgcn_wave_barrier();
     };
+
     // ---- phase A: candidate reads -> chunk items -> LDS +1/-1 ----------------
     // Candidate i of a batch of NT belongs to wave i % NW: the overlapping reads (mostly
     // the latest starters) spread evenly over the waves.  G "slots" each hold one
@@ -555,13 +560,16 @@ __global__ __launch_bounds__(NT) void gd_ltile2_kernel(Job job)
             }
             // the checkpoints of all slots in one round trip; even lanes own the pair of
             // chunks (q, q+1): c0 = where it starts, c2 = where it ends
-            uint32_t c0[G], c2[G];
+            uint32_t c0[G], c1[G], c2[G];
 #pragma unroll
             for (int g = 0; g < G; ++g) {
                 const uint32_t q = cb[g] + (uint32_t)lane;
                 c0[g] = (act[g] && q < nch[g]) ? ckj[g][q] : POS_CAP;
                 c2[g] = (act[g] && q + 2u < nch[g]) ? ckj[g][q + 2u] : ej[g];
             }
+#pragma unroll
+            for (int g = 0; g < G; ++g)                    // start of chunk q+1 = c0 of the next lane (wave_shl:1)
+                c1[g] = (uint32_t)__builtin_amdgcn_update_dpp((int)POS_CAP, (int)c0[g], 0x130, 0xf, 0xf, false);
             unsigned long long cm[G];
             uint32_t cnt[G], tot = 0;
 #pragma unroll
@@ -579,7 +587,7 @@ __global__ __launch_bounds__(NT) void gd_ltile2_kernel(Job job)
                     const uint32_t rk = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(cm[g] >> 32),
                                                  __builtin_amdgcn_mbcnt_lo((uint32_t)cm[g], 0u));
                     const uint32_t first = (cb[g] + (uint32_t)lane) * CK_OPS, left = nj[g] - first;
-                    Q.ci[rk] = oj[g] + first; Q.st[rk] = c0[g]; Q.no[rk] = left < LQ_OPS ? left : LQ_OPS;
+                    Q[rk] = make_uint4(oj[g] + first, c0[g], c1[g], left < LQ_OPS ? left : LQ_OPS);
                 }
                 qn += cnt[g];
             }
