@@ -97,6 +97,10 @@ struct gd_ctx {
     gd::Counters* h_counters = nullptr;   // pinned
     uint32_t* d_region_cursor = nullptr;
 
+    uint8_t* d_seq = nullptr;  size_t cap_seq = 0;     // gd_seq_load: one contig's bases, zero padded
+    int64_t seq_len = -1;
+    uint32_t seq_padded = 0;
+
     bool computed = false;
     int64_t n_tiles = 0, n_win_total = 0, n_bases = 0;
     std::vector<int2> bounds;             // ordered run boundaries of the last compute
@@ -356,7 +360,7 @@ void gd_destroy(gd_ctx* c)
     if (c->copy_done) (void)hipEventDestroy(c->copy_done);
     void* frees[] = {c->d_ctgs, c->d_tiles, c->d_perbase, c->d_wsum, c->d_wmin, c->d_chunks,
                      c->d_ordered, c->d_tile_cnt, c->d_tile_off, c->d_super_cnt, c->d_counters,
-                     c->d_region_cursor, c->d_status, c->d_ck, c->d_rend};
+                     c->d_region_cursor, c->d_status, c->d_ck, c->d_rend, c->d_seq};
     for (void* p : frees) if (p) (void)hipFree(p);
     if (c->h_counters) (void)hipHostFree(c->h_counters);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -1124,6 +1128,61 @@ int gd_depthwed(gd_ctx* c, int n_samples, int n_ctg, const int32_t* tids, int64_
     hipError_t e3 = hipStreamSynchronize(c->stream);
     (void)hipFree(d);
     if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) return fail(c, GD_E_HIP, "depthwed matrix kernel failed");
+    return GD_OK;
+}
+
+int gd_seq_load(gd_ctx* c, const uint8_t* seq, int64_t len)
+{
+    if (!c || len < 0 || (len > 0 && !seq)) return GD_E_INVALID;
+    if (len >= 0x7fffffffLL - 16) return fail(c, GD_E_RANGE, "sequence of %lld bases (contigs are < 2^31)", (long long)len);
+    if (int r = set_device(c)) return r;
+    const size_t padded = (((size_t)len + 3) & ~(size_t)3) + 8;
+    if (int r = ensure_dev(c, &c->d_seq, &c->cap_seq, padded)) return r;
+    if (len) HIPCHK(c, hipMemcpyAsync(c->d_seq, seq, (size_t)len, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_seq + len, 0, padded - (size_t)len, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));          // the caller's buffer is not retained
+    c->seq_len = len;
+    c->seq_padded = (uint32_t)padded;
+    return GD_OK;
+}
+
+int gd_seq_stats(gd_ctx* c, size_t n_windows, const int64_t* start, const int64_t* end,
+                 uint32_t* n_gc, uint32_t* n_cpg, uint32_t* n_masked)
+{
+    if (!c || (n_windows && (!start || !end || !n_gc || !n_cpg || !n_masked))) return GD_E_INVALID;
+    if (int r = set_device(c)) return r;
+    if (c->seq_len < 0) return fail(c, GD_E_STATE, "gd_seq_load has not been called");
+    if (n_windows == 0) return GD_OK;
+    if (n_windows > 0x7fffffffull * 4) return fail(c, GD_E_RANGE, "too many windows");
+    // one scratch allocation: starts, ends (int64), then the three count arrays (uint32)
+    const size_t bytes = n_windows * (2 * sizeof(int64_t) + 3 * sizeof(uint32_t));
+    uint8_t* d = nullptr;
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&d), bytes));
+    int64_t* d_s = reinterpret_cast<int64_t*>(d);
+    int64_t* d_e = d_s + n_windows;
+    uint32_t* d_c = reinterpret_cast<uint32_t*>(d_e + n_windows);
+    gd::SeqStatsJob j{};
+    j.seq = c->d_seq; j.len = c->seq_len; j.padded = c->seq_padded;
+    j.win_start = d_s; j.win_end = d_e;
+    j.gc = d_c; j.cpg = d_c + n_windows; j.masked = d_c + 2 * n_windows;
+    j.n_win = (int64_t)n_windows;
+    hipError_t e1 = hipMemcpyAsync(d_s, start, n_windows * sizeof(int64_t), hipMemcpyHostToDevice, c->stream);
+    hipError_t e2 = hipMemcpyAsync(d_e, end, n_windows * sizeof(int64_t), hipMemcpyHostToDevice, c->stream);
+    if (c->profiling) (void)hipEventRecord(c->ev[0], c->stream);
+    hipLaunchKernelGGL(gd::gd_seq_stats_kernel, dim3((unsigned)((n_windows + 3) / 4)), dim3(256), 0, c->stream, j);
+    if (c->profiling) (void)hipEventRecord(c->ev[1], c->stream);
+    hipError_t e3 = hipMemcpyAsync(n_gc, j.gc, n_windows * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream);
+    hipError_t e4 = hipMemcpyAsync(n_cpg, j.cpg, n_windows * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream);
+    hipError_t e5 = hipMemcpyAsync(n_masked, j.masked, n_windows * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream);
+    hipError_t e6 = hipStreamSynchronize(c->stream);
+    if (c->profiling && e6 == hipSuccess) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) c->kernel_ms[GD_K_SEQSTATS] = ms;
+    }
+    (void)hipFree(d);
+    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess || e5 != hipSuccess ||
+        e6 != hipSuccess)
+        return fail(c, GD_E_HIP, "sequence statistics kernel failed");
     return GD_OK;
 }
 

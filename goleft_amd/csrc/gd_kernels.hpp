@@ -289,6 +289,7 @@ __device__ __forceinline__ int wave_min(int v)
 #include "gd_scatter.hpp"
 #include "gd_chunk.hpp"
 #include "gd_depthwed.hpp"
+#include "gd_seqstats.hpp"
 
 namespace gd {
 

@@ -180,10 +180,26 @@ void fmt_callable_row(std::string* out, const char* chrom, int64_t s, int64_t e,
     out->push_back('\n');
 }
 
-// sums[k] belongs to window first_win + k.  stats may be null.
+// --stats columns of the depth.bed rows of ONE format_region call (depth/depth.go:191-200).
+// The windows a region emits are data dependent (quirk Q2), so format_region runs twice:
+// collecting == true records [s, e) of every row in emission order; the device counts the
+// bases of all of them in one gd_seq_stats call; the second run pops the formatted columns.
+struct StatsPlan {
+    bool collecting = true;
+    std::vector<int64_t> s, e;
+    std::vector<std::string> cols;
+    size_t next = 0;
+    std::string take(int64_t ws, int64_t we)
+    {
+        if (collecting) { s.push_back(ws); e.push_back(we); return std::string(); }
+        return next < cols.size() ? cols[next++] : std::string();
+    }
+};
+
+// sums[k] belongs to window first_win + k.  sp may be null (no --stats).
 void format_region(RowWriter* w, const char* chrom, int64_t rs, int64_t re, int W,
                    const int64_t* sums, size_t n_sums, const gd_run* runs, size_t n_runs,
-                   gdh::FastaStats* fa)
+                   StatsPlan* sp)
 {
     if (re <= rs) return;
     const int64_t first_win = rs / W;
@@ -191,7 +207,7 @@ void format_region(RowWriter* w, const char* chrom, int64_t rs, int64_t re, int 
         const int64_t k = iw - first_win;
         return (k >= 0 && (size_t)k < n_sums) ? sums[k] : 0;
     };
-    auto stats_of = [&](int64_t s, int64_t e) { return fa ? fa->stats_columns(chrom, s, e) : std::string(); };
+    auto stats_of = [&](int64_t s, int64_t e) { return sp ? sp->take(s, e) : std::string(); };
     // callable.bed: the run-length encoding is exactly what :307-328 and :343-350 emit
     int64_t lastcov = -1;
     for (size_t i = 0; i < n_runs; ++i) {
@@ -417,7 +433,43 @@ int run(const DArgs& args)
     std::vector<gd_run> cruns;
     size_t run_cursor = 0;
     bool io_ok = true;
+    // --stats: the bases of the current contig live in HBM (gd_seq_load); per region one
+    // gd_seq_stats call counts GC / CpG / lower-case bases of every emitted window
+    std::string seq_chrom, seq_bases;
+    bool seq_known = false;
+    int stats_rc = GD_OK;
+    auto emit_region = [&](const char* chrom, int64_t rs, int64_t re, const int64_t* su, size_t n_su,
+                           const gd_run* ru, size_t n_ru) {
+        if (!fa) { format_region(&rows, chrom, rs, re, W, su, n_su, ru, n_ru, nullptr); return; }
+        StatsPlan sp;
+        RowWriter probe;
+        format_region(&probe, chrom, rs, re, W, su, n_su, ru, n_ru, &sp);
+        if (seq_chrom != chrom || seq_chrom.empty()) {
+            seq_chrom = chrom;
+            seq_known = fa->contig_bases(chrom, &seq_bases);
+            if (seq_known && stats_rc == GD_OK)
+                stats_rc = gd_seq_load(ctx, reinterpret_cast<const uint8_t*>(seq_bases.data()), (int64_t)seq_bases.size());
+            seq_bases.clear();
+            seq_bases.shrink_to_fit();
+        }
+        const size_t n = sp.s.size();
+        std::vector<uint32_t> gc(n, 0), cpg(n, 0), low(n, 0);
+        if (seq_known && n && stats_rc == GD_OK)
+            stats_rc = gd_seq_stats(ctx, n, sp.s.data(), sp.e.data(), gc.data(), cpg.data(), low.data());
+        sp.cols.resize(n);
+        for (size_t k = 0; k < n; ++k) {
+            const double tot = (double)(sp.e[k] - sp.s[k]);
+            const bool ok = seq_known && sp.e[k] > sp.s[k];
+            char buf[96];
+            snprintf(buf, sizeof buf, "\t%.3g\t%.3g\t%.3g", ok ? gc[k] / tot : 0.0, ok ? 2.0 * cpg[k] / tot : 0.0,
+                     ok ? low[k] / tot : 0.0);                               // :199
+            sp.cols[k] = buf;
+        }
+        sp.collecting = false;
+        format_region(&rows, chrom, rs, re, W, su, n_su, ru, n_ru, &sp);
+    };
     for (const Region& r : regions) {
+        if (stats_rc != GD_OK) GDCHK(stats_rc);
         if (r.tid < 0) {
             // samtools would fail on an unknown reference name: the callback then sees an
             // empty stream (all-zero rows) and the exit code becomes non-zero (:395-399)
@@ -425,7 +477,7 @@ int run(const DArgs& args)
                     r.chrom.c_str(), r.start + 1, r.end);
             exit_code = std::max(exit_code, 1);
             gd_run nr{(int32_t)r.start, (int32_t)r.end, GD_NO_COVERAGE};
-            format_region(&rows, r.chrom.c_str(), r.start, r.end, W, nullptr, 0, &nr, r.end > r.start ? 1 : 0, fa);
+            emit_region(r.chrom.c_str(), r.start, r.end, nullptr, 0, &nr, r.end > r.start ? 1 : 0);
         } else {
             const int64_t clen = contigs[(size_t)r.tid].length;
             // fused device results are W/step aligned over the BAM contig length; a tile cut
@@ -449,8 +501,8 @@ int run(const DArgs& args)
                 size_t e = run_cursor;
                 while (e < cruns.size() && cruns[e].start < r.end) ++e;
                 const size_t w0 = (size_t)(r.start / W), w1 = (size_t)((r.end + W - 1) / W);
-                format_region(&rows, r.chrom.c_str(), r.start, r.end, W, csums.data() + w0, w1 - w0,
-                              cruns.data() + run_cursor, e - run_cursor, fa);
+                emit_region(r.chrom.c_str(), r.start, r.end, csums.data() + w0, w1 - w0,
+                            cruns.data() + run_cursor, e - run_cursor);
                 run_cursor = e;
             } else if (r.end > r.start) {
                 size_t n = 0;
@@ -461,11 +513,12 @@ int run(const DArgs& args)
                 if (rc != GD_OK && rc != GD_E_CAPACITY) GDCHK(rc);
                 runs.resize(n);
                 if (n) GDCHK(gd_region_callable(ctx, r.tid, r.start, r.end, runs.data(), runs.size(), &n));
-                format_region(&rows, r.chrom.c_str(), r.start, r.end, W, sums.data(), nw, runs.data(), n, fa);
+                emit_region(r.chrom.c_str(), r.start, r.end, sums.data(), nw, runs.data(), n);
             }
         }
         if (rows.hd.size() + rows.ca.size() > (8u << 20)) io_ok = flush_rows(&rows, fhd, fca) && io_ok;
     }
+    if (stats_rc != GD_OK) GDCHK(stats_rc);
     io_ok = flush_rows(&rows, fhd, fca) && io_ok;
     gd_destroy(ctx);
     ctx = nullptr;

@@ -1,12 +1,11 @@
-// fasta_stats.hpp -- `--stats` columns (GC, CpG, masked fraction per window).
+// fasta_stats.hpp -- FASTA access for the `--stats` columns (GC, CpG, masked
+// fraction per window; /root/reference/depth/depth.go:191-200, :244-252).
 //
-// The reference appends "\t%.3g\t%.3g\t%.3g" of faidx.Stats(chrom, s, e)
-// (/root/reference/depth/depth.go:191-200).  faidx is an external module
-// (github.com/brentp/faidx @c39eb85, go.mod:12) that is not in /root/reference,
-// and no reference test asserts these values: PARITY UNPINNED.  Semantics
-// restated from the module's documentation: GC = fraction of G/C (either
-// case), masked = fraction of lower-case bases, CpG = 2 * (#C followed by G,
-// looking one base past the window) / window length.
+// The reference mmaps the FASTA through faidx (external module, go.mod:12) and
+// scans each window on the CPU.  Here the host only reads the .fai and hands a
+// contig's bases to the device (gd_seq_load); the per-window base counting is
+// gd_seq_stats (csrc/gd_seqstats.hpp) and the three "%.3g" columns are
+// formatted in depth_host.cpp.  Semantics: see gd_seqstats.hpp (PARITY UNPINNED).
 #pragma once
 
 #include <cstdint>
@@ -37,31 +36,14 @@ public:
         return true;
     }
 
-    // "\tGC\tCpG\tMasked" formatted like the reference (%.3g each)
-    std::string stats_columns(const std::string& chrom, int64_t start, int64_t end)
+    // All bases of one contig, line breaks removed; false when the contig is not in the .fai.
+    bool contig_bases(const std::string& chrom, std::string* out)
     {
-        double gc = 0, cpg = 0, masked = 0;
+        out->clear();
         auto it = idx_.find(chrom);
-        if (it != idx_.end() && end > start) {
-            const Entry& e = it->second;
-            int64_t n_gc = 0, n_cpg = 0, n_mask = 0;
-            const int64_t stop = end < e.len ? end + 1 : e.len;    // one look-ahead base
-            std::string seq;
-            fetch(e, start < e.len ? start : e.len, stop, &seq);
-            const int64_t n = (int64_t)seq.size() < end - start ? (int64_t)seq.size() : end - start;
-            for (int64_t i = 0; i < n; ++i) {
-                const char c = seq[(size_t)i];
-                if (c == 'G' || c == 'C' || c == 'g' || c == 'c') ++n_gc;
-                if (c >= 'a' && c <= 'z') ++n_mask;
-                if ((c == 'C' || c == 'c') && (size_t)(i + 1) < seq.size() &&
-                    (seq[(size_t)i + 1] == 'G' || seq[(size_t)i + 1] == 'g')) ++n_cpg;
-            }
-            const double tot = (double)(end - start);
-            gc = n_gc / tot; cpg = 2.0 * n_cpg / tot; masked = n_mask / tot;
-        }
-        char buf[96];
-        snprintf(buf, sizeof buf, "\t%.3g\t%.3g\t%.3g", gc, cpg, masked);
-        return buf;
+        if (it == idx_.end()) return false;
+        fetch(it->second, 0, it->second.len, out);
+        return true;
     }
 
 private:

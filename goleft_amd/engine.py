@@ -14,7 +14,7 @@ from . import _lib
 from ._lib import GdBatch, GdParams, GdRun, GdStats
 
 CLASS_NAMES = ("NO_COVERAGE", "LOW_COVERAGE", "CALLABLE", "EXCESSIVE_COVERAGE")
-K_PREP, K_TILE, K_RUNS, K_EXPAND, K_SCAN, K_CKPT = 0, 1, 2, 3, 4, 5
+K_PREP, K_TILE, K_RUNS, K_EXPAND, K_SCAN, K_CKPT, K_SEQSTATS = 0, 1, 2, 3, 4, 5, 6
 PATH_AUTO, PATH_TILE, PATH_SCATTER, PATH_CHUNK = 0, 1, 2, 3
 
 
@@ -209,6 +209,24 @@ class DepthEngine:
             self._chk(self._lib.gd_depthwed(self._ctx, ns, nc, t.ctypes.data, size, cells.ctypes.data,
                                             ctg.ctypes.data, st.ctypes.data, en.ctypes.data, rows, C.byref(n)))
         return cells, ctg, st, en
+
+    def seq_load(self, seq) -> None:
+        """One contig's reference bases (bytes / uint8 array, FASTA line breaks removed) into HBM."""
+        a = np.frombuffer(seq, np.uint8) if isinstance(seq, (bytes, bytearray)) else np.ascontiguousarray(seq, np.uint8)
+        self._chk(self._lib.gd_seq_load(self._ctx, a.ctypes.data if a.size else None, a.size))
+
+    def seq_stats(self, starts, ends):
+        """`--stats` counts per window [start, end): (n_gc, n_cpg, n_masked) uint32 arrays
+        (depth/depth.go:191-200; fractions and %.3g are the host's)."""
+        s = np.ascontiguousarray(starts, np.int64)
+        e = np.ascontiguousarray(ends, np.int64)
+        assert s.shape == e.shape and s.ndim == 1
+        gc = np.empty(s.size, np.uint32)
+        cpg = np.empty(s.size, np.uint32)
+        low = np.empty(s.size, np.uint32)
+        self._chk(self._lib.gd_seq_stats(self._ctx, s.size, s.ctypes.data, e.ctypes.data,
+                                         gc.ctypes.data, cpg.ctypes.data, low.ctypes.data))
+        return gc, cpg, low
 
     def device_windows(self):
         """(ptr_sums, ptr_mins, n_total) device views of the concatenated window arrays."""

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define GD_ABI_VERSION 3
+#define GD_ABI_VERSION 4
 
 typedef enum {
     GD_OK = 0,
@@ -115,7 +115,8 @@ typedef struct {
  * Scatter path: PREP (zero-fill + init), EXPAND (CIGAR expand + scatter), SCAN
  * (in-place scan + window / class reductions), RUNS. */
 enum { GD_K_PREP = 0, GD_K_TILE = 1, GD_K_RUNS = 2, GD_K_EXPAND = 3, GD_K_SCAN = 4, GD_K_CKPT = 5,
-       GD_K_COUNT = 6 };
+       GD_K_SEQSTATS = 6,   /* the kernel of the last gd_seq_stats */
+       GD_K_COUNT = 7 };
 
 /* Device algorithm of gd_compute.  All are bit exact; they differ in cost.
  *   TILE     one workgroup per 4096-position tile re-walks the CIGARs of the
@@ -238,6 +239,20 @@ int gd_region_callable(gd_ctx* ctx, int32_t tid, int64_t start, int64_t end,
 int gd_depthwed(gd_ctx* ctx, int n_samples, int n_ctg, const int32_t* tids, int64_t size,
                 int64_t* cells, int32_t* row_ctg, int64_t* row_start, int64_t* row_end,
                 size_t cap_rows, size_t* n_rows);
+
+/* ---- `--stats` columns on device (depth/depth.go:191-200, :244-252) ----------
+ * The reference appends "%.3g" of GC, CpG and masked fraction of each window's
+ * reference bases (faidx.Stats, an external module: PARITY UNPINNED, semantics
+ * restated in oracle/pyoracle.py::seq_stats).  gd_seq_load copies ONE contig's
+ * bases (FASTA line breaks removed) into HBM, replacing the previous one; the
+ * pointer is not retained.  gd_seq_stats then returns, for each window
+ * [start[k], end[k]) clipped to the contig: n_gc = bases in "GCgc", n_masked =
+ * lower-case bases, n_cpg = C/c followed by G/g (the following base may lie past
+ * the window, not past the contig).  Integer counts only: the divisions by
+ * (end - start) and the "%.3g" stay on the host.  Does not need gd_compute. */
+int gd_seq_load(gd_ctx* ctx, const uint8_t* seq, int64_t len);
+int gd_seq_stats(gd_ctx* ctx, size_t n_windows, const int64_t* start, const int64_t* end,
+                 uint32_t* n_gc, uint32_t* n_cpg, uint32_t* n_masked);
 
 /* Device-side views of the results (for RCCL gathers and zero-copy
  * consumers).  Pointers stay valid until the next gd_compute/gd_reset. */

@@ -197,6 +197,43 @@ def callback_py(chrom: str, region_start: int, region_end: int,
     return hd, ca
 
 
+def seq_stats(seq: bytes, start: int, end: int):
+    """(n_gc, n_cpg, n_masked) of seq[start:end] clipped to the contig -- the integer
+    counts behind the `--stats` columns (depth/depth.go:191-200 -> faidx.Stats, an
+    external module at go.mod:12 whose values no reference test asserts: PARITY
+    UNPINNED; this restatement IS the contract of gd_seq_stats and of
+    host/fasta_stats.hpp).  Pure Python, byte by byte."""
+    s, e = max(0, start), min(end, len(seq))
+    gc = cpg = low = 0
+    for i in range(s, e):
+        c = seq[i]
+        if c in b"GCgc":
+            gc += 1
+        if 0x61 <= c <= 0x7a:
+            low += 1
+        if c in b"Cc" and i + 1 < len(seq) and seq[i + 1] in b"Gg":
+            cpg += 1
+    return gc, cpg, low
+
+
+def fmt_g3(x: float) -> str:
+    """Go's %.3g for the magnitudes --stats prints (fractions in [0, 2])."""
+    t = "%.3g" % x
+    if "e" in t:                                  # Go prints at least two exponent digits too
+        m, ex = t.split("e")
+        t = "%se%s%02d" % (m, ex[0], int(ex[1:]))
+    return t
+
+
+def stats_columns(seq: bytes, start: int, end: int) -> str:
+    """"\tGC\tCpG\tMasked" as getStats formats them (depth/depth.go:199)."""
+    gc, cpg, low = seq_stats(seq, start, end)
+    tot = float(end - start)
+    if start >= len(seq) or end <= start:
+        return "\t0\t0\t0"
+    return "\t%s\t%s\t%s" % (fmt_g3(gc / tot), fmt_g3(2.0 * cpg / tot), fmt_g3(low / tot))
+
+
 def step_for(W: int) -> int:
     """depth/depth.go:48,:132."""
     return max(1, 10000000 // W) * W

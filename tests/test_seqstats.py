@@ -1,0 +1,121 @@
+"""`--stats` columns (depth/depth.go:191-200, :244-252): the device base-class counter
+gd_seq_stats against the oracle's byte-by-byte restatement, and the CLI with --stats
+against golden rows + the oracle's formatted columns.  The semantics live in an external
+module (faidx) that no reference test pins: PARITY UNPINNED, the oracle restatement is the
+contract (oracle/pyoracle.py::seq_stats)."""
+import numpy as np
+import pytest
+
+from oracle import bamio, pyoracle as po
+from tests import helpers as H
+
+
+def random_seq(rng, n, odd=(0, 10, 0x7b, 0x60, 0xe3, 0xc7, 0xff, ord("R"), ord("y"))):
+    """Bases with soft-masked (lower-case) stretches, N runs and a few odd bytes."""
+    s = rng.choice(np.frombuffer(b"ACGT", np.uint8), size=n)
+    i = 0
+    while i < n:
+        run = int(rng.integers(1, 400))
+        kind = rng.random()
+        if kind < 0.25:
+            s[i:i + run] |= 0x20                      # lower case
+        elif kind < 0.30:
+            s[i:i + run] = ord("N") if rng.random() < 0.5 else ord("n")
+        i += run
+    for b in odd:
+        if n:
+            s[int(rng.integers(0, n))] = b
+    return s.tobytes()
+
+
+def test_oracle_known_answers():
+    # hand-checked: ACGTacgtNNCG -> G/C at 1,2,5,6,10,11; CpG at (1,2),(5,6),(10,11); lower 4..7
+    seq = b"ACGTacgtNNCG"
+    assert po.seq_stats(seq, 0, 12) == (6, 3, 4)
+    assert po.seq_stats(seq, 0, 2) == (1, 1, 0)       # the G that completes the CpG lies past the window
+    assert po.seq_stats(seq, 11, 12) == (1, 0, 0)
+    assert po.seq_stats(seq, 10, 11) == (1, 1, 0)
+    assert po.seq_stats(seq, 11, 40) == (1, 0, 0)     # clipped to the contig; no look-ahead past its end
+    assert po.seq_stats(seq, 12, 40) == (0, 0, 0)
+    assert po.seq_stats(b"cG" * 3, 0, 6) == (6, 3, 3)  # case-insensitive pairing
+    assert po.stats_columns(seq, 0, 12) == "\t0.5\t0.5\t0.333"
+    assert po.stats_columns(seq, 20, 30) == "\t0\t0\t0"
+    assert po.stats_columns(b"ACGT" * 100, 0, 300) == "\t0.5\t0.5\t0"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [0, 1, 3, 4, 5, 63, 64, 257, 1000, 4099, 200003])
+def test_device_counts_equal_oracle(n):
+    from goleft_amd.engine import DepthEngine
+    rng = np.random.default_rng(100 + n)
+    seq = random_seq(rng, n)
+    wins = [(0, n), (0, 0), (n, n + 10), (n - 1, n + 5), (-5, 3), (1, 2), (2, 1), (3, 7), (0, 1)]
+    for W in (1, 7, 250, 1000):                       # anchored windows like the callback's
+        if n / W < 3000:
+            wins += [(k, min(k + W, n)) for k in range(0, n, W)]
+    for _ in range(300):                              # arbitrary alignment and length
+        s = int(rng.integers(-3, n + 3))
+        wins.append((s, s + int(rng.integers(0, 3000))))
+    wins = [(max(s, 0), e) for s, e in wins]
+    st = np.array([w[0] for w in wins], np.int64)
+    en = np.array([w[1] for w in wins], np.int64)
+    with DepthEngine(0) as eng:
+        eng.seq_load(seq)
+        gc, cpg, low = eng.seq_stats(st, en)
+        # a second contig replaces the first
+        eng.seq_load(b"CGcg")
+        g2 = eng.seq_stats(np.array([0], np.int64), np.array([4], np.int64))
+    sel = range(len(wins)) if n <= 5000 else rng.choice(len(wins), 400, replace=False)
+    for k in sel:
+        assert (int(gc[k]), int(cpg[k]), int(low[k])) == po.seq_stats(seq, int(st[k]), int(en[k])), (n, wins[k])
+    assert [int(x[0]) for x in g2] == [4, 2, 2]
+
+
+@pytest.mark.gpu
+def test_seq_stats_needs_a_sequence():
+    from goleft_amd.engine import DepthEngine
+    with DepthEngine(0) as eng:
+        with pytest.raises(RuntimeError):
+            eng.seq_stats(np.array([0], np.int64), np.array([4], np.int64))
+
+
+def write_fasta(path, contigs, seqs, width=60):
+    fai = []
+    with open(path, "wb") as f:
+        for (name, length), seq in zip(contigs, seqs):
+            assert len(seq) == length
+            f.write(b">" + name.encode() + b" test\n")
+            off = f.tell()
+            for i in range(0, length, width):
+                f.write(seq[i:i + width] + b"\n")
+            fai.append("%s\t%d\t%d\t%d\t%d\n" % (name, length, off, width, width + 1))
+    open(path + ".fai", "w").write("".join(fai))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,W", [("wg", 1000), ("wg", 71), ("bed", 55)])
+def test_cli_stats_columns(tmp_path, mode, W):
+    # depth/functional-test.sh passes --stats everywhere (:45,:56,:73 ...) without asserting the values
+    from goleft_amd import depth
+    contigs, reads, _ = H.load_golden_bam("t")
+    bamio.write_bam(str(tmp_path / "t.bam"), contigs, reads, unplaced=3)
+    rng = np.random.default_rng(7)
+    # (line breaks cannot be bases of a FASTA record)
+    seqs = [random_seq(rng, ln, odd=(0x7b, 0x60, 0xe3, ord("R"), ord("y"), ord("*"))) for _, ln in contigs]
+    write_fasta(str(tmp_path / "t.fa"), contigs, seqs)
+    beds = H.golden_beds()["t"]
+    prefix = str(tmp_path / "o")
+    args = ["-Q", "1", "--ordered", "--windowsize", str(W), "--stats", "--prefix", prefix,
+            "--reference", str(tmp_path / "t.fa")]
+    if mode == "bed":
+        (tmp_path / "windows.bed").write_text("".join("%s\t%d\t%d\n" % tuple(r) for r in beds["regions"]))
+        args += ["--bed", str(tmp_path / "windows.bed")]
+    assert depth.Main(args + [str(tmp_path / "t.bam")]) == 0
+    by_name = {c[0]: s for c, s in zip(contigs, seqs)}
+    want = []
+    for line in beds["%s_w%d" % (mode, W)]["depth"].splitlines():
+        chrom, s, e, _ = line.split("\t")
+        want.append(line + po.stats_columns(by_name[chrom], int(s), int(e)) + "\n")
+    got = open(prefix + ".depth.bed").read()
+    assert got == "".join(want)
+    assert open(prefix + ".callable.bed").read() == beds["%s_w%d" % (mode, W)]["callable"]
