@@ -306,7 +306,7 @@ def main():
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                      "kernel": ("gd_expand_scatter_kernel+gd_scan_kernel" if scatter else
-                                "gd_ckpt_kernel+gd_ltile_kernel" if chunk else "gd_tile_kernel"),
+                                "gd_ckpt_kernel+gd_ltile2_kernel" if chunk else "gd_tile_kernel"),
                      "avg_kernel_ms": avg_tile_s * 1e3,
                      "algorithmic_bytes_per_launch": alg_bytes,
                      "bytes_per_ref_base": alg_bytes / r["my_bases"]},
