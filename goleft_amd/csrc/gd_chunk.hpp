@@ -105,13 +105,36 @@ __global__ __launch_bounds__(256) void gd_ckpt_kernel(Job job)
                 const uint32_t k = b + (uint32_t)u * CK_OPS + (uint32_t)lane;
                 cg[u] = k < nj ? cigar[oj + k] : 0u;
             }
+            // reference bases each op consumes; the chunk totals come from eight interleaved plain
+            // 32-bit scans (scan4 twice) unless an op consumes more than 2^24 bases (64 * 2^24 <
+            // 2^31: no wrap), then from saturating scans
+            uint32_t cons[CK_UNROLL];
+            uint32_t mx = 0;
+#pragma unroll
+            for (int u = 0; u < CK_UNROLL; ++u) {
+                const uint32_t op = cg[u] & 0xf, len = cg[u] >> 4;
+                cons[u] = ((0x18du >> op) & 1u) ? len : 0u;
+                mx |= cons[u];
+            }
+            uint32_t tot[CK_UNROLL];
+            if (__builtin_amdgcn_ballot_w64(mx > (1u << 24)) == 0ull) {
+                int t[CK_UNROLL];
+#pragma unroll
+                for (int u = 0; u < CK_UNROLL; ++u) t[u] = (int)cons[u];
+                static_assert(CK_UNROLL == 8, "two scan4 groups");
+                scan4(t[0], t[1], t[2], t[3]);
+                scan4(t[4], t[5], t[6], t[7]);
+#pragma unroll
+                for (int u = 0; u < CK_UNROLL; ++u) tot[u] = (uint32_t)__builtin_amdgcn_readlane(t[u], 63);
+            } else {
+#pragma unroll
+                for (int u = 0; u < CK_UNROLL; ++u)
+                    tot[u] = (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_scan_sat(sat_pos(cons[u])), 63);
+            }
 #pragma unroll
             for (int u = 0; u < CK_UNROLL; ++u) {
                 if (b + (uint32_t)u * CK_OPS >= nj) break;            // uniform
-                const uint32_t op = cg[u] & 0xf, len = cg[u] >> 4;
-                const uint32_t cons = ((0x18du >> op) & 1u) ? len : 0u;
-                const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_scan_sat(cons), 63);
-                run = sat_pos(run + tot);
+                run = sat_pos(run + tot[u]);
                 const uint32_t nxt = (b >> 6) + (uint32_t)u + 1u;     // the chunk that starts here
                 if (nxt * CK_OPS < nj && lane == 0) ckj[nxt] = run;
             }
