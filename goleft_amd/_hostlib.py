@@ -22,6 +22,10 @@ SYMBOLS = {
     "gdh_depthwed_main": (C.c_int, [C.c_int, C.POINTER(C.c_char_p)]),
     "gdh_depthwed_run": (C.c_int, [C.c_int64, C.POINTER(C.c_char_p), C.c_int, C.c_char_p]),
     "gdh_depthwed_cells": (None, [_P, _P, C.c_size_t, _P]),
+    "gdh_multidepth_main": (C.c_int, [C.c_int, C.POINTER(C.c_char_p)]),
+    "gdh_multidepth_run": (C.c_int, [C.c_int, C.POINTER(C.c_char_p), C.c_char_p]),
+    "gdh_multidepth_blocks": (C.c_int64, [_P, _P, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
+                                          _P, _P, C.c_int64]),
     "gdh_bam_open": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(_P)]),
     "gdh_bam_close": (None, [_P]),
     "gdh_bam_error": (C.c_char_p, [_P]),
@@ -149,3 +153,23 @@ class Intervals:
                 self._lib.gdh_intervals_free(self._h)
         except Exception:
             pass
+
+
+def multidepth_blocks(any_mask, suf_mask, chunk, max_skip=10, min_size=15, window=10000000):
+    """The multidepth block state machine (multidepth/multidepth.go:188-268) over boolean
+    site masks; returns an int64 array [n_blocks, 2] of {start, end}.  No GPU needed."""
+    import numpy as np
+    a = np.asarray(any_mask, bool)
+    s = np.asarray(suf_mask, bool)
+    n = a.size
+    pack = lambda m: np.packbits(np.concatenate([m, np.zeros((-n) % 32, bool)]), bitorder="little").view(np.uint32)
+    aw, sw = pack(a), pack(s)
+    cnt = load().gdh_multidepth_blocks(aw.ctypes.data, sw.ctypes.data, n, chunk, max_skip, min_size, window,
+                                       None, None, 0)
+    if cnt < 0:
+        raise ValueError("gdh_multidepth_blocks: bad arguments")
+    st = np.zeros(cnt, np.int64)
+    en = np.zeros(cnt, np.int64)
+    load().gdh_multidepth_blocks(aw.ctypes.data, sw.ctypes.data, n, chunk, max_skip, min_size, window,
+                                 st.ctypes.data, en.ctypes.data, cnt)
+    return np.stack([st, en], 1)

@@ -97,6 +97,9 @@ struct gd_ctx {
     gd::Counters* h_counters = nullptr;   // pinned
     uint32_t* d_region_cursor = nullptr;
 
+    uint32_t* d_md_bits = nullptr; size_t cap_md = 0;  // gd_md_flags: `any` words then `suf` words
+    int64_t md_len = -1;                               // positions the bitmaps cover (-1: none yet)
+    std::vector<int32_t> md_tids;                      // the samples they were built from
     uint8_t* d_seq = nullptr;  size_t cap_seq = 0;     // gd_seq_load: one contig's bases, zero padded
     int64_t seq_len = -1;
     uint32_t seq_padded = 0;
@@ -360,7 +363,7 @@ void gd_destroy(gd_ctx* c)
     if (c->copy_done) (void)hipEventDestroy(c->copy_done);
     void* frees[] = {c->d_ctgs, c->d_tiles, c->d_perbase, c->d_wsum, c->d_wmin, c->d_chunks,
                      c->d_ordered, c->d_tile_cnt, c->d_tile_off, c->d_super_cnt, c->d_counters,
-                     c->d_region_cursor, c->d_status, c->d_ck, c->d_rend, c->d_seq};
+                     c->d_region_cursor, c->d_status, c->d_ck, c->d_rend, c->d_seq, c->d_md_bits};
     for (void* p : frees) if (p) (void)hipFree(p);
     if (c->h_counters) (void)hipHostFree(c->h_counters);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -1183,6 +1186,100 @@ int gd_seq_stats(gd_ctx* c, size_t n_windows, const int64_t* start, const int64_
     if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess || e5 != hipSuccess ||
         e6 != hipSuccess)
         return fail(c, GD_E_HIP, "sequence statistics kernel failed");
+    return GD_OK;
+}
+
+// the per-base vectors of n_samples equally long contigs of the last gd_compute
+static int md_sample_ptrs(gd_ctx* c, int n_samples, const int32_t* tids, std::vector<const int32_t*>* ptrs,
+                          int64_t* len)
+{
+    if (!c->computed) return fail(c, GD_E_STATE, "no results: call gd_compute first");
+    if (!c->d_perbase) return fail(c, GD_E_STATE, "the per-base vector was not kept (gd_set_outputs)");
+    ptrs->resize((size_t)n_samples);
+    for (int s = 0; s < n_samples; ++s) {
+        if (int r = check_result_tid(c, tids[s])) return r;
+        const ContigHost& h = c->contigs[tids[s]];
+        if (s == 0) *len = h.length;
+        else if (h.length != *len)
+            return fail(c, GD_E_INVALID, "sample %d: contig length %lld differs from sample 0 (%lld)", s,
+                        (long long)h.length, (long long)*len);
+        (*ptrs)[(size_t)s] = c->d_perbase + h.base_off;
+    }
+    return GD_OK;
+}
+
+int gd_md_flags(gd_ctx* c, int n_samples, const int32_t* tids, int32_t min_cov, int32_t min_samples,
+                uint32_t* any_bits, uint32_t* suf_bits, size_t n_words)
+{
+    if (!c || n_samples < 1 || !tids) return GD_E_INVALID;
+    if (int r = set_device(c)) return r;
+    std::vector<const int32_t*> ptrs;
+    int64_t len = 0;
+    if (int r = md_sample_ptrs(c, n_samples, tids, &ptrs, &len)) return r;
+    const size_t need = (size_t)((len + 31) / 32);
+    if (n_words < need || ((!any_bits || !suf_bits) && need))
+        return fail(c, GD_E_CAPACITY, "need room for %zu bitmap words", need);
+    c->md_len = -1;
+    if (need == 0) { c->md_len = 0; c->md_tids.assign(tids, tids + n_samples); return GD_OK; }
+    if (int r = ensure_dev(c, &c->d_md_bits, &c->cap_md, 2 * need)) return r;
+    const int32_t** d_ptrs = nullptr;
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&d_ptrs), ptrs.size() * sizeof(ptrs[0])));
+    gd::MdFlagsJob j{};
+    j.depth = d_ptrs; j.n_samples = n_samples; j.len = len; j.min_cov = min_cov; j.min_samples = min_samples;
+    j.any_bits = c->d_md_bits; j.suf_bits = c->d_md_bits + need;
+    hipError_t e1 = hipMemcpyAsync(d_ptrs, ptrs.data(), ptrs.size() * sizeof(ptrs[0]), hipMemcpyHostToDevice, c->stream);
+    if (c->profiling) (void)hipEventRecord(c->ev[0], c->stream);
+    hipLaunchKernelGGL(gd::gd_md_flags_kernel, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, c->stream, j);
+    if (c->profiling) (void)hipEventRecord(c->ev[1], c->stream);
+    hipError_t e2 = hipMemcpyAsync(any_bits, j.any_bits, need * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream);
+    hipError_t e3 = hipMemcpyAsync(suf_bits, j.suf_bits, need * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream);
+    hipError_t e4 = hipStreamSynchronize(c->stream);
+    if (c->profiling && e4 == hipSuccess) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) c->kernel_ms[GD_K_MDFLAGS] = ms;
+    }
+    (void)hipFree(d_ptrs);
+    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess)
+        return fail(c, GD_E_HIP, "multidepth flag kernel failed");
+    c->md_len = len;
+    c->md_tids.assign(tids, tids + n_samples);
+    return GD_OK;
+}
+
+int gd_md_sums(gd_ctx* c, size_t n_blocks, const int64_t* start, const int64_t* end, double* sums)
+{
+    if (!c || (n_blocks && (!start || !end || !sums))) return GD_E_INVALID;
+    if (int r = set_device(c)) return r;
+    if (c->md_len < 0) return fail(c, GD_E_STATE, "gd_md_flags has not been called");
+    if (n_blocks == 0) return GD_OK;
+    const int n_samples = (int)c->md_tids.size();
+    std::vector<const int32_t*> ptrs;
+    int64_t len = 0;
+    if (int r = md_sample_ptrs(c, n_samples, c->md_tids.data(), &ptrs, &len)) return r;
+    if (len != c->md_len) return fail(c, GD_E_STATE, "results changed since gd_md_flags");
+    for (size_t b = 0; b < n_blocks; ++b)
+        if (start[b] < 0 || end[b] < start[b] || end[b] > len)
+            return fail(c, GD_E_RANGE, "block %zu [%lld, %lld) outside the contig", b, (long long)start[b], (long long)end[b]);
+    const size_t n_cells = n_blocks * (size_t)n_samples;
+    const size_t bytes = ptrs.size() * sizeof(ptrs[0]) + 2 * n_blocks * sizeof(int64_t) + n_cells * sizeof(double);
+    uint8_t* d = nullptr;
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&d), bytes));
+    const int32_t** d_ptrs = reinterpret_cast<const int32_t**>(d);
+    int64_t* d_s = reinterpret_cast<int64_t*>(d + ptrs.size() * sizeof(ptrs[0]));
+    int64_t* d_e = d_s + n_blocks;
+    double* d_sums = reinterpret_cast<double*>(d_e + n_blocks);
+    gd::MdSumsJob j{};
+    j.depth = d_ptrs; j.suf_bits = c->d_md_bits + (size_t)((len + 31) / 32);
+    j.start = d_s; j.end = d_e; j.sums = d_sums; j.n_blocks = (int64_t)n_blocks; j.n_samples = n_samples;
+    hipError_t e1 = hipMemcpyAsync(d_ptrs, ptrs.data(), ptrs.size() * sizeof(ptrs[0]), hipMemcpyHostToDevice, c->stream);
+    hipError_t e2 = hipMemcpyAsync(d_s, start, n_blocks * sizeof(int64_t), hipMemcpyHostToDevice, c->stream);
+    hipError_t e3 = hipMemcpyAsync(d_e, end, n_blocks * sizeof(int64_t), hipMemcpyHostToDevice, c->stream);
+    hipLaunchKernelGGL(gd::gd_md_sums_kernel, dim3((unsigned)((n_cells + 63) / 64)), dim3(64), 0, c->stream, j);
+    hipError_t e4 = hipMemcpyAsync(sums, d_sums, n_cells * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+    hipError_t e5 = hipStreamSynchronize(c->stream);
+    (void)hipFree(d);
+    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess || e5 != hipSuccess)
+        return fail(c, GD_E_HIP, "multidepth block-sum kernel failed");
     return GD_OK;
 }
 

@@ -290,6 +290,7 @@ __device__ __forceinline__ int wave_min(int v)
 #include "gd_chunk.hpp"
 #include "gd_depthwed.hpp"
 #include "gd_seqstats.hpp"
+#include "gd_multidepth.hpp"
 
 namespace gd {
 

@@ -2,6 +2,7 @@
 // (/root/reference/cmd/goleft/goleft.go:25-32,:55-69) as a C++ executable.
 //   goleft-depth [flags] BAM          or          goleft-depth depth [flags] BAM
 //   goleft-depth depthwed -s SIZE a.depth.bed b.depth.bed ...   (the consumer of depth.bed files)
+//   goleft-depth multidepth -c CHROM a.bam b.bam ...            (/root/reference/multidepth, its own binary there)
 #include <cstring>
 #include <vector>
 
@@ -14,6 +15,11 @@ int main(int argc, char** argv)
         av.push_back("goleft depthwed");
         for (int i = 2; i < argc; ++i) av.push_back(argv[i]);
         return gdh_depthwed_main((int)av.size(), av.data());
+    }
+    if (argc > 1 && strcmp(argv[1], "multidepth") == 0) {
+        av.push_back("multidepth");
+        for (int i = 2; i < argc; ++i) av.push_back(argv[i]);
+        return gdh_multidepth_main((int)av.size(), av.data());
     }
     av.push_back("goleft depth");
     int first = 1;

@@ -14,7 +14,7 @@ from . import _lib
 from ._lib import GdBatch, GdParams, GdRun, GdStats
 
 CLASS_NAMES = ("NO_COVERAGE", "LOW_COVERAGE", "CALLABLE", "EXCESSIVE_COVERAGE")
-K_PREP, K_TILE, K_RUNS, K_EXPAND, K_SCAN, K_CKPT, K_SEQSTATS = 0, 1, 2, 3, 4, 5, 6
+K_PREP, K_TILE, K_RUNS, K_EXPAND, K_SCAN, K_CKPT, K_SEQSTATS, K_MDFLAGS = 0, 1, 2, 3, 4, 5, 6, 7
 PATH_AUTO, PATH_TILE, PATH_SCATTER, PATH_CHUNK = 0, 1, 2, 3
 
 
@@ -227,6 +227,28 @@ class DepthEngine:
         self._chk(self._lib.gd_seq_stats(self._ctx, s.size, s.ctypes.data, e.ctypes.data,
                                          gc.ctypes.data, cpg.ctypes.data, low.ctypes.data))
         return gc, cpg, low
+
+    def md_flags(self, tids, min_cov: int, min_samples: int):
+        """multidepth: (any, suf) boolean arrays over the samples' common contig
+        (multidepth/multidepth.go:163-171; bit x of word x // 32 on the wire)."""
+        t = np.ascontiguousarray(tids, np.int32)
+        length = self.contig_lengths[int(t[0])]
+        nw = (length + 31) // 32
+        a = np.zeros(nw, np.uint32)
+        s = np.zeros(nw, np.uint32)
+        self._chk(self._lib.gd_md_flags(self._ctx, t.size, t.ctypes.data, min_cov, min_samples,
+                                        a.ctypes.data, s.ctypes.data, nw))
+        unpack = lambda w: np.unpackbits(w.view(np.uint8), bitorder="little")[:length].astype(bool)
+        return unpack(a), unpack(s)
+
+    def md_sums(self, starts, ends, n_samples: int) -> np.ndarray:
+        """multidepth: float64 [n_blocks, n_samples] running sums of depth / 1000 over the suf
+        sites of each block, in position order (multidepth.go:270-277)."""
+        s = np.ascontiguousarray(starts, np.int64)
+        e = np.ascontiguousarray(ends, np.int64)
+        out = np.zeros((s.size, n_samples), np.float64)
+        self._chk(self._lib.gd_md_sums(self._ctx, s.size, s.ctypes.data, e.ctypes.data, out.ctypes.data))
+        return out
 
     def device_windows(self):
         """(ptr_sums, ptr_mins, n_total) device views of the concatenated window arrays."""

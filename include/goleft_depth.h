@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define GD_ABI_VERSION 4
+#define GD_ABI_VERSION 5
 
 typedef enum {
     GD_OK = 0,
@@ -116,7 +116,8 @@ typedef struct {
  * (in-place scan + window / class reductions), RUNS. */
 enum { GD_K_PREP = 0, GD_K_TILE = 1, GD_K_RUNS = 2, GD_K_EXPAND = 3, GD_K_SCAN = 4, GD_K_CKPT = 5,
        GD_K_SEQSTATS = 6,   /* the kernel of the last gd_seq_stats */
-       GD_K_COUNT = 7 };
+       GD_K_MDFLAGS = 7,    /* the kernel of the last gd_md_flags */
+       GD_K_COUNT = 8 };
 
 /* Device algorithm of gd_compute.  All are bit exact; they differ in cost.
  *   TILE     one workgroup per 4096-position tile re-walks the CIGARs of the
@@ -253,6 +254,23 @@ int gd_depthwed(gd_ctx* ctx, int n_samples, int n_ctg, const int32_t* tids, int6
 int gd_seq_load(gd_ctx* ctx, const uint8_t* seq, int64_t len);
 int gd_seq_stats(gd_ctx* ctx, size_t n_windows, const int64_t* start, const int64_t* end,
                  uint32_t* n_gc, uint32_t* n_cpg, uint32_t* n_masked);
+
+/* ---- multidepth on device (multidepth/multidepth.go) ----------------------------
+ * The S samples are S equally long contigs tids[0..S) of ONE context, computed by
+ * gd_compute with -Q = multidepth's Q (per-base output kept).  gd_md_flags replaces
+ * the multi-file `samtools depth` text stream and its parse (:203-207, :148-161)
+ * plus sufficientDepth (:163-171) with two bitmaps over the contig (bit x of word
+ * x/32, little endian): any = some sample has depth > 0 (the positions samtools
+ * prints), suf = MORE THAN min_samples samples have depth >= min_cov.  The block
+ * state machine (:217-258) then runs on the host over the bitmaps.  gd_md_sums
+ * returns, for each block [start, end) and sample, the reference's running sum
+ * `dps[i] += float64(d) / 1000.` over the block's suf sites in position order
+ * (means, :270-277) as the exact IEEE double; sums is row major [n_blocks][S] and
+ * uses the samples and bitmaps of the last gd_md_flags.  GD_E_CAPACITY if n_words
+ * < ceil(len/32). */
+int gd_md_flags(gd_ctx* ctx, int n_samples, const int32_t* tids, int32_t min_cov, int32_t min_samples,
+                uint32_t* any_bits, uint32_t* suf_bits, size_t n_words);
+int gd_md_sums(gd_ctx* ctx, size_t n_blocks, const int64_t* start, const int64_t* end, double* sums);
 
 /* Device-side views of the results (for RCCL gathers and zero-copy
  * consumers).  Pointers stay valid until the next gd_compute/gd_reset. */

@@ -55,6 +55,24 @@ int gdh_depthwed_run(int64_t size, const char* const* paths, int n_paths, const 
  * (goleft_amd/csrc/gd_round4g.hpp; the device matrix kernel uses the same code). */
 void gdh_depthwed_cells(const int64_t* sums, const int64_t* lens, size_t n, int64_t* out);
 
+/* ---- `multidepth` (multidepth/multidepth.go): N BAMs, one chromosome -> blocks where
+ * more than --minsamples of the samples reach --mincov, with every sample's mean depth.
+ * argv: [-Q Q] -c CHROM [--mincov N] [--maxcov N] [-k MAXSKIP] [-m MINSIZE] [-w WINDOW]
+ *       [-p P] [--minsamples F] BAMS...   Output: "#chrom\tstart\tend\t<names>" then one
+ * row per block, chunks in genome order.  Returns the exit code (255 usage, 2 where
+ * the reference panics). ------------------------------------------------------- */
+int gdh_multidepth_main(int argc, const char* const* argv);
+/* Same, writing to out_path (NULL = stdout). */
+int gdh_multidepth_run(int argc, const char* const* argv, const char* out_path);
+/* The block state machine alone (multidepth.go:188-268) over the two bitmaps
+ * gd_md_flags produces (bit x of word x/32): chunks of `chunk` positions, blocks cut
+ * where sufficient sites are more than max_skip apart, caches shorter than min_size
+ * dropped (except a chunk's last), split where a block would span `window`.
+ * Returns the block count (-1 on bad arguments) and fills up to cap {start, end}. */
+int64_t gdh_multidepth_blocks(const uint32_t* any_bits, const uint32_t* suf_bits, int64_t len, int64_t chunk,
+                              int32_t max_skip, int32_t min_size, int32_t window, int64_t* starts,
+                              int64_t* ends, int64_t cap);
+
 /* ---- BAM decode (replaces the read side of the samtools child) ---------- */
 typedef struct gdh_bam gdh_bam;
 int  gdh_bam_open(const char* path, int threads, gdh_bam** out);

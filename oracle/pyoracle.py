@@ -234,6 +234,91 @@ def stats_columns(seq: bytes, start: int, end: int) -> str:
     return "\t%s\t%s\t%s" % (fmt_g3(gc / tot), fmt_g3(2.0 * cpg / tot), fmt_g3(low / tot))
 
 
+# ---------------------------------------------------------------------------
+# multidepth (multidepth/multidepth.go), restated line by line.  The per-position
+# stream is what `samtools depth -q 0 -Q Q -d MaxCov -r chrom:start bams...`
+# (:203-207) prints: one row per position >= start at which at least one BAM has
+# depth > 0 (samtools >= 1.13 semantics; PARITY UNPINNED).
+# ---------------------------------------------------------------------------
+def md_means(sites, depth_rows):
+    """means (:270-283): sites = positions, depth_rows[k] = the S depths at sites[k]."""
+    dps = [0.0] * len(depth_rows[0])
+    for row in depth_rows:
+        for i, d in enumerate(row):
+            dps[i] += float(int(d)) / 1000.
+    l = sites[-1] - sites[0] + 1
+    return ["%.2f" % (d / float(l) * 1000) for d in dps]
+
+
+def md_split_blocks(chrom, cache, depth_of, window):
+    """splitBlocks (:188-201); cache = sufficient positions, depth_of(pos) -> S depths."""
+    blocks = []
+    i = lasti = 0
+    while i < len(cache):
+        start = cache[i]
+        i += 1
+        while i < len(cache) and cache[i] - start < window:
+            i += 1
+        end = cache[i - 1] + 1
+        sub = cache[lasti:i]
+        blocks.append("%s\t%d\t%d\t%s" % (chrom, start, end, "\t".join(md_means(sub, [depth_of(p) for p in sub]))))
+        lasti = i
+    return blocks
+
+
+def multidepth_py(chrom, depths, mincov=7, maxskip=10, minsize=15, window=10000000, min_samples=0.5,
+                  chunk_size=5000000):
+    """Block lines (without the header) in chunk order, i.e. what `multidepth -p 1` prints.
+    depths: S equally long int arrays (the per-base depth of each BAM at -Q)."""
+    D = np.stack([np.asarray(d, np.int64) for d in depths])
+    S, L = D.shape
+    if S > 50:
+        chunk_size //= 5                                   # :62-64
+    need = int(0.5 + min_samples * float(S))               # :66
+    printed = np.flatnonzero((D > 0).any(0))
+    suf = (D >= mincov).sum(0) > need                      # sufficientDepth :163-171 (strictly more)
+    depth_of = lambda p: D[:, p]
+    out = []
+    for i in range(0, L, chunk_size):                      # genRegions :130-141
+        rstart = i + 1                                     # 1-based
+        cache, blocks = [], []
+        seen0 = False
+        for p in printed[np.searchsorted(printed, i):]:    # aggregate :203-268
+            p = int(p)
+            s = bool(suf[p])
+            if not s:
+                seen0 = True
+                if p > rstart + chunk_size:
+                    if len(cache) == 0 or p - cache[-1] >= maxskip:
+                        break
+            if not seen0:
+                continue
+            if (len(cache) == 0 or p - (cache[-1] + 1) <= maxskip) and s:
+                cache.append(p)
+            elif len(cache) > 0 and p - (cache[-1] + 1) > maxskip:
+                if len(cache) >= minsize:
+                    blocks += md_split_blocks(chrom, cache, depth_of, window)
+                cache = []
+                if s:
+                    cache.append(p)
+        if cache:
+            blocks += md_split_blocks(chrom, cache, depth_of, window)
+        out += blocks
+    return out
+
+
+def md_short_name(path: str, rg_samples=()) -> str:
+    """indexcov.GetShortName(b, false) (indexcov/indexcov.go:213-246): the single @RG SM
+    value when there is exactly one, else from the file name."""
+    sm = set(rg_samples)
+    if len(sm) > 1:
+        raise ValueError("bam reagroup: more than one RG for %s" % path)
+    if len(sm) == 1:
+        return next(iter(sm))
+    v = path.split("/")[-1].split(".")
+    return v[0] if len(v) <= 2 else "-".join(v[:-1])
+
+
 def step_for(W: int) -> int:
     """depth/depth.go:48,:132."""
     return max(1, 10000000 // W) * W

@@ -1,0 +1,172 @@
+"""`multidepth` (/root/reference/multidepth/multidepth.go): the
+host block state machine and the device kernels against the oracle's line-by-line
+restatement.  The reference ships no test for this tool and its arithmetic front end is an
+external `samtools depth` over several BAMs: PARITY UNPINNED, the restatement
+(oracle/pyoracle.py::multidepth_py) is the contract."""
+import numpy as np
+import pytest
+
+from oracle import bamio, pyoracle as po
+from tests import helpers as H
+
+
+def random_depths(rng, L, S):
+    D = []
+    for _ in range(S):
+        d = rng.poisson(rng.choice([3, 8, 12, 40]), L)
+        for _ in range(int(rng.integers(0, 6))):
+            a = int(rng.integers(0, L))
+            d[a:a + int(rng.integers(1, 300))] = rng.choice([0, 0, 1, 30])
+        D.append(d.astype(np.int64))
+    return D
+
+
+def test_oracle_hand_case():
+    # 2 samples, mincov 2, minsamples 0.5 -> need = int(0.5 + 1.0) = 1: BOTH must reach 2
+    a = np.array([0, 3, 3, 3, 1, 3, 3, 0, 0, 3, 3, 3])
+    b = np.array([1, 2, 5, 2, 2, 2, 2, 0, 0, 2, 2, 9])
+    # printed everywhere but 7, 8; sufficient at 1,2,3,5,6,9,10,11; site 0 is the first
+    # insufficient one, so caching starts at 1; 4 is skipped (gap 1 <= maxskip)
+    got = po.multidepth_py("c", [a, b], mincov=2, maxskip=1, minsize=1, window=100, min_samples=0.5,
+                           chunk_size=1000)
+    # block 1: sites 1,2,3,5,6 span [1,7): a sums 15 -> 15/6 = 2.5, b sums 13 -> 2.17
+    # block 2 (gap 9-6-1 = 2 > 1): sites 9,10,11: a 9/3, b 13/3
+    assert got == ["c\t1\t7\t2.50\t2.17", "c\t9\t12\t3.00\t4.33"]
+    # minsize applies to flushed caches only: the last cache of a chunk is always printed
+    got = po.multidepth_py("c", [a, b], mincov=2, maxskip=1, minsize=4, window=100, chunk_size=1000)
+    assert got == ["c\t1\t7\t2.50\t2.17", "c\t9\t12\t3.00\t4.33"]
+    got = po.multidepth_py("c", [a, b], mincov=2, maxskip=1, minsize=6, window=100, chunk_size=1000)
+    assert got == ["c\t9\t12\t3.00\t4.33"]
+    # window splits a cache greedily (pos - start < window)
+    got = po.multidepth_py("c", [a, b], mincov=2, maxskip=1, minsize=1, window=3, chunk_size=1000)
+    assert [l.split("\t")[1:3] for l in got] == [["1", "4"], ["5", "7"], ["9", "12"]]
+    assert po.md_short_name("/x/y/NA12878.bam") == "NA12878"
+    assert po.md_short_name("a.b.c.bam") == "a-b-c"
+    assert po.md_short_name("a.bam", ["S1", "S1"]) == "S1"
+    with pytest.raises(ValueError):
+        po.md_short_name("a.bam", ["S1", "S2"])
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_host_state_machine_equals_oracle(seed):
+    from goleft_amd import _hostlib as hl
+    rng = np.random.default_rng(1000 + seed)
+    for _ in range(25):
+        L, S = int(rng.integers(1, 5000)), int(rng.integers(1, 6))
+        D = random_depths(rng, L, S)
+        mincov = int(rng.choice([1, 4, 7]))
+        maxskip = int(rng.choice([0, 1, 10, 50]))
+        minsize = int(rng.choice([1, 5, 15]))
+        window = int(rng.choice([1, 20, 100, 10 ** 7]))
+        chunk = int(rng.choice([37, 64, 500, 1000, 10 ** 6]))
+        ms = float(rng.choice([0.0, 0.5, 0.9]))
+        want = po.multidepth_py("c", D, mincov=mincov, maxskip=maxskip, minsize=minsize, window=window,
+                                min_samples=ms, chunk_size=chunk)
+        A = np.stack(D)
+        any_, suf = (A > 0).any(0), (A >= mincov).sum(0) > int(0.5 + ms * S)
+        got = hl.multidepth_blocks(any_, suf, chunk, maxskip, minsize, window)
+        assert [tuple(map(int, l.split("\t")[1:3])) for l in want] == [tuple(map(int, r)) for r in got]
+
+
+def test_host_state_machine_dense_words():
+    # long all-sufficient stretches take the 32-sites-at-once path; results must not change
+    from goleft_amd import _hostlib as hl
+    rng = np.random.default_rng(9)
+    L = 20000
+    d = np.full(L, 30)
+    for a in (0, 31, 32, 4999, 5000, 5033, 12000, 19990):
+        d[a:a + int(rng.integers(1, 40))] = rng.choice([0, 3])
+    want = po.multidepth_py("c", [d, d + 1], mincov=7, chunk_size=5000)
+    any_, suf = d >= 0, d >= 7
+    any_ = (np.stack([d, d + 1]) > 0).any(0)
+    got = hl.multidepth_blocks(any_, suf, 5000)
+    assert [tuple(map(int, l.split("\t")[1:3])) for l in want] == [tuple(map(int, r)) for r in got]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("S,L", [(1, 1), (2, 33), (3, 4097), (5, 70001), (9, 1000)])
+def test_device_flags_and_sums(S, L):
+    from goleft_amd.engine import DepthEngine
+    rng = np.random.default_rng(S * 1000 + L)
+    streams = [H.random_reads(rng, L, max(1, L // 20), max_len=200) for _ in range(S)]
+    Q, mincov = 5, 3
+    want = [po.perbase_c(r, Q, 0, L) for r in streams]
+    A = np.stack(want)
+    need = int(0.5 + 0.5 * S)
+    with DepthEngine(0) as eng:
+        eng.set_params(window_size=100, min_mapq=Q, min_cov=4)
+        eng.set_contigs([L] * S)
+        for s, r in enumerate(streams):
+            eng.push(s, r.pos, r.flag, r.mapq, r.cigar_off, r.cigar)
+        eng.compute()
+        any_, suf = eng.md_flags(list(range(S)), mincov, need)
+        assert np.array_equal(any_, (A > 0).any(0))
+        assert np.array_equal(suf, (A >= mincov).sum(0) > need)
+        # arbitrary blocks, incl. empty and whole contig
+        st = rng.integers(0, L, 40)
+        en = np.minimum(L, st + rng.integers(0, 3000, 40))
+        st = np.append(st, [0, L]); en = np.append(en, [L, L])
+        got = eng.md_sums(st, en, S)
+    for k in range(len(st)):
+        for s in range(S):
+            acc = 0.0
+            for p in range(int(st[k]), int(en[k])):
+                if suf[p]:
+                    acc += float(int(A[s, p])) / 1000.
+            assert got[k, s] == acc, (k, s)                   # the same doubles, not merely close
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("opts", [dict(), dict(mincov=2, maxskip=3, minsize=4, window=500, q=1, minsamples=0.3)])
+def test_cli_matches_oracle(tmp_path, opts):
+    # four "samples": the fixture's reads thinned differently
+    from goleft_amd import multidepth
+    contigs, reads, _ = H.load_golden_bam("t")
+    rng = np.random.default_rng(11)
+    paths, thinned = [], []
+    for s, frac in enumerate([1.0, 0.5, 0.2, 0.05]):
+        sub = {}
+        for tid, r in reads.items():
+            keep = np.flatnonzero(rng.random(r.n) < frac)
+            off = np.zeros(len(keep) + 1, np.uint32)
+            lens = (r.cigar_off[keep + 1] - r.cigar_off[keep]).astype(np.uint32)
+            off[1:] = np.cumsum(lens)
+            cig = np.concatenate([r.cigar[int(r.cigar_off[i]):int(r.cigar_off[i + 1])] for i in keep]) \
+                if len(keep) else np.zeros(0, np.uint32)
+            sub[tid] = po.Reads(r.pos[keep], r.flag[keep], r.mapq[keep], off, cig.astype(np.uint32))
+        p = str(tmp_path / ("s%d.x.bam" % s))
+        hdr = "@HD\tVN:1.6\tSO:coordinate\n" + "".join("@SQ\tSN:%s\tLN:%d\n" % c for c in contigs)
+        if s == 0:
+            hdr += "@RG\tID:a\tSM:first\n@RG\tID:b\tSM:first\tPL:x\n"
+        bamio.write_bam(p, contigs, sub, header_text=hdr)
+        paths.append(p)
+        thinned.append(sub)
+    n_blocks = 0
+    for chrom in ("chrM", "chr22"):
+        tid = [c[0] for c in contigs].index(chrom)
+        L = contigs[tid][1]
+        q = opts.get("q", 10)
+        D = [po.perbase_c(t[tid], q, 0, L) if tid in t else np.zeros(L, np.int32) for t in thinned]
+        kw = dict(mincov=opts.get("mincov", 7), maxskip=opts.get("maxskip", 10), minsize=opts.get("minsize", 15),
+                  window=opts.get("window", 10000000), min_samples=opts.get("minsamples", 0.5))
+        want = ["#chrom\tstart\tend\tfirst\ts1-x\ts2-x\ts3-x"] + po.multidepth_py(chrom, D, **kw)
+        out = str(tmp_path / ("md_%s.txt" % chrom))
+        argv = ["-c", chrom, "-Q", q, "--mincov", kw["mincov"], "-k", kw["maxskip"], "-m", kw["minsize"],
+                "-w", kw["window"], "--minsamples", kw["min_samples"]] + paths
+        assert multidepth.Main(argv, out) == 0
+        assert open(out).read().splitlines() == want
+        n_blocks += len(want) - 1
+    # (a contig that is sufficiently covered from its first printed site on yields NO block:
+    # the state machine only starts after an insufficient site, multidepth.go:229-246)
+    assert n_blocks > 0 or opts
+
+
+@pytest.mark.gpu
+def test_cli_errors(tmp_path):
+    from goleft_amd import multidepth
+    contigs, reads, _ = H.load_golden_bam("t")
+    p = str(tmp_path / "a.bam")
+    bamio.write_bam(p, contigs, reads)
+    assert multidepth.Main(["-c", "nope", p], str(tmp_path / "o")) == 2     # the reference panics
+    assert multidepth.Main([p], str(tmp_path / "o")) == 255                # --chrom is required
+    assert multidepth.Main(["-c", "chrM"], str(tmp_path / "o")) == 255     # no BAMs
