@@ -66,6 +66,7 @@ SYMBOLS = {
                                      C.POINTER(C.c_size_t)]),
     "gd_depthwed": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int64, _P, _P, _P, _P, C.c_size_t,
                               C.POINTER(C.c_size_t)]),
+    "gd_depthwed_device": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int64, C.POINTER(_P), C.POINTER(C.c_size_t)]),
     "gd_seq_load": (C.c_int, [_P, _P, C.c_int64]),
     "gd_seq_stats": (C.c_int, [_P, C.c_size_t, _P, _P, _P, _P, _P]),
     "gd_md_flags": (C.c_int, [_P, C.c_int, _P, C.c_int32, C.c_int32, _P, _P, C.c_size_t]),

@@ -97,6 +97,7 @@ struct gd_ctx {
     gd::Counters* h_counters = nullptr;   // pinned
     uint32_t* d_region_cursor = nullptr;
 
+    int64_t* d_wed = nullptr; size_t cap_wed = 0;      // gd_depthwed: tables + the sites x samples matrix
     uint32_t* d_md_bits = nullptr; size_t cap_md = 0;  // gd_md_flags: `any` words then `suf` words
     int64_t md_len = -1;                               // positions the bitmaps cover (-1: none yet)
     std::vector<int32_t> md_tids;                      // the samples they were built from
@@ -363,7 +364,7 @@ void gd_destroy(gd_ctx* c)
     if (c->copy_done) (void)hipEventDestroy(c->copy_done);
     void* frees[] = {c->d_ctgs, c->d_tiles, c->d_perbase, c->d_wsum, c->d_wmin, c->d_chunks,
                      c->d_ordered, c->d_tile_cnt, c->d_tile_off, c->d_super_cnt, c->d_counters,
-                     c->d_region_cursor, c->d_status, c->d_ck, c->d_rend, c->d_seq, c->d_md_bits};
+                     c->d_region_cursor, c->d_status, c->d_ck, c->d_rend, c->d_seq, c->d_md_bits, c->d_wed};
     for (void* p : frees) if (p) (void)hipFree(p);
     if (c->h_counters) (void)hipHostFree(c->h_counters);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -1073,9 +1074,10 @@ int gd_region_callable(gd_ctx* c, int32_t tid, int64_t start, int64_t end, gd_ru
     }
 }
 
-int gd_depthwed(gd_ctx* c, int n_samples, int n_ctg, const int32_t* tids, int64_t size,
-                int64_t* cells, int32_t* row_ctg, int64_t* row_start, int64_t* row_end,
-                size_t cap_rows, size_t* n_rows)
+// Builds the matrix in the context's scratch buffer; *d_cells points at [rows][n_samples].
+static int depthwed_on_device(gd_ctx* c, int n_samples, int n_ctg, const int32_t* tids, int64_t size,
+                              int32_t* row_ctg, int64_t* row_start, int64_t* row_end, size_t cap_rows,
+                              bool need_cap, size_t* n_rows, int64_t** d_cells)
 {
     if (!c || !n_rows || n_samples < 1 || n_ctg < 1 || !tids || size < 1) return GD_E_INVALID;
     if (int r = set_device(c)) return r;
@@ -1100,20 +1102,22 @@ int gd_depthwed(gd_ctx* c, int n_samples, int n_ctg, const int32_t* tids, int64_
     }
     row_beg[n_ctg] = rows;
     *n_rows = (size_t)rows;
+    *d_cells = nullptr;
     if (rows == 0) return GD_OK;
-    if (cap_rows < (size_t)rows || !cells) return fail(c, GD_E_CAPACITY, "need room for %lld rows", (long long)rows);
+    if (need_cap && cap_rows < (size_t)rows) return fail(c, GD_E_CAPACITY, "need room for %lld rows", (long long)rows);
     for (int j = 0; j < n_ctg; ++j)
         for (int64_t r = 0; r < row_beg[j + 1] - row_beg[j]; ++r) {
             const int64_t k = row_beg[j] + r;
+            if ((size_t)k >= cap_rows) break;
             if (row_ctg) row_ctg[k] = j;
             if (row_start) row_start[k] = r * group * W;
             if (row_end) row_end[k] = std::min<int64_t>((r + 1) * group * W, clen[j]);
         }
-    // small tables + the matrix live in one scratch allocation
+    // small tables + the matrix live in one context-owned allocation
     const size_t n_tab = off.size() + nwin.size() + clen.size() + row_beg.size();
     const size_t n_cells = (size_t)rows * (size_t)n_samples;
-    int64_t* d = nullptr;
-    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&d), (n_tab + n_cells) * sizeof(int64_t)));
+    if (int r = ensure_dev(c, &c->d_wed, &c->cap_wed, n_tab + n_cells)) return r;
+    int64_t* d = c->d_wed;
     std::vector<int64_t> tab;
     tab.reserve(n_tab);
     tab.insert(tab.end(), off.begin(), off.end());
@@ -1125,13 +1129,35 @@ int gd_depthwed(gd_ctx* c, int n_samples, int n_ctg, const int32_t* tids, int64_
     j.off = d; j.nwin = d + off.size(); j.clen = j.nwin + nwin.size(); j.row_beg = j.clen + clen.size();
     j.cells = d + n_tab;
     j.n_samples = n_samples; j.n_ctg = n_ctg; j.n_rows = rows; j.W = W; j.group = group;
-    hipError_t e1 = hipMemcpyAsync(d, tab.data(), n_tab * sizeof(int64_t), hipMemcpyHostToDevice, c->stream);
+    HIPCHK(c, hipMemcpyAsync(d, tab.data(), n_tab * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(gd::gd_depthwed_kernel, dim3((unsigned)((n_cells + 255) / 256)), dim3(256), 0, c->stream, j);
-    hipError_t e2 = hipMemcpyAsync(cells, j.cells, n_cells * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream);
-    hipError_t e3 = hipStreamSynchronize(c->stream);
-    (void)hipFree(d);
-    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) return fail(c, GD_E_HIP, "depthwed matrix kernel failed");
+    HIPCHK(c, hipStreamSynchronize(c->stream));       // `tab` must outlive the copy
+    *d_cells = j.cells;
     return GD_OK;
+}
+
+int gd_depthwed(gd_ctx* c, int n_samples, int n_ctg, const int32_t* tids, int64_t size,
+                int64_t* cells, int32_t* row_ctg, int64_t* row_start, int64_t* row_end,
+                size_t cap_rows, size_t* n_rows)
+{
+    int64_t* d_cells = nullptr;
+    if (n_rows && cap_rows && !cells) return GD_E_INVALID;
+    if (int r = depthwed_on_device(c, n_samples, n_ctg, tids, size, row_ctg, row_start, row_end, cap_rows, true,
+                                   n_rows, &d_cells))
+        return r;
+    if (!d_cells) return GD_OK;
+    HIPCHK(c, hipMemcpy(cells, d_cells, *n_rows * (size_t)n_samples * sizeof(int64_t), hipMemcpyDeviceToHost));
+    return GD_OK;
+}
+
+int gd_depthwed_device(gd_ctx* c, int n_samples, int n_ctg, const int32_t* tids, int64_t size,
+                       const int64_t** d_cells, size_t* n_rows)
+{
+    if (!d_cells) return GD_E_INVALID;
+    int64_t* p = nullptr;
+    const int r = depthwed_on_device(c, n_samples, n_ctg, tids, size, nullptr, nullptr, nullptr, 0, false, n_rows, &p);
+    *d_cells = p;
+    return r;
 }
 
 int gd_seq_load(gd_ctx* c, const uint8_t* seq, int64_t len)

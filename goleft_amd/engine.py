@@ -210,6 +210,15 @@ class DepthEngine:
                                             ctg.ctypes.data, st.ctypes.data, en.ctypes.data, rows, C.byref(n)))
         return cells, ctg, st, en
 
+    def depthwed_device(self, tids, size: int):
+        """The depthwed matrix left in HBM: (device pointer to int64 [rows][samples], rows)."""
+        t = np.ascontiguousarray(tids, np.int32)
+        assert t.ndim == 2
+        p, n = C.c_void_p(), C.c_size_t()
+        self._chk(self._lib.gd_depthwed_device(self._ctx, t.shape[0], t.shape[1], t.ctypes.data, size,
+                                               C.byref(p), C.byref(n)))
+        return p.value, n.value
+
     def seq_load(self, seq) -> None:
         """One contig's reference bases (bytes / uint8 array, FASTA line breaks removed) into HBM."""
         a = np.frombuffer(seq, np.uint8) if isinstance(seq, (bytes, bytearray)) else np.ascontiguousarray(seq, np.uint8)

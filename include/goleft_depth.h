@@ -240,6 +240,11 @@ int gd_region_callable(gd_ctx* ctx, int32_t tid, int64_t start, int64_t end,
 int gd_depthwed(gd_ctx* ctx, int n_samples, int n_ctg, const int32_t* tids, int64_t size,
                 int64_t* cells, int32_t* row_ctg, int64_t* row_start, int64_t* row_end,
                 size_t cap_rows, size_t* n_rows);
+/* Same matrix, left in HBM for the next consumer (the normalisation / CNV steps that read
+ * depthwed output, e.g. dcnv/dcnv.go:153-186): *d_cells is a device pointer to
+ * [n_rows][n_samples] int64, valid until the next gd_depthwed* / gd_destroy. */
+int gd_depthwed_device(gd_ctx* ctx, int n_samples, int n_ctg, const int32_t* tids, int64_t size,
+                       const int64_t** d_cells, size_t* n_rows);
 
 /* ---- `--stats` columns on device (depth/depth.go:191-200, :244-252) ----------
  * The reference appends "%.3g" of GC, CpG and masked fraction of each window's

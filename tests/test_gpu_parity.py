@@ -319,6 +319,17 @@ def test_depthwed_matrix_on_device(auto_eng, W, size):
         t = line.split("\t")
         assert t[0] == ref[ctg[k]][0] and int(t[1]) == st[k] and int(t[2]) == en[k]
         assert [int(x) for x in t[3:]] == cells[k].tolist(), (k, line, cells[k])
+    # the device-resident view holds the same matrix
+    # (read back through the HIP runtime the engine already loaded; torch.cuda is kept out of
+    # this process on purpose: it bundles its own copy of the runtime)
+    import ctypes
+    ptr, rows = eng.depthwed_device(tids, size)
+    assert rows == len(cells)
+    back = np.empty((rows, n_samples), np.int64)
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    assert hip.hipMemcpy(back.ctypes.data, ptr, back.nbytes, 2) == 0          # hipMemcpyDeviceToHost
+    assert np.array_equal(back, cells)
 
 
 def test_windows_only_output(auto_eng):
