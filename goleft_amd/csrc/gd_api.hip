@@ -15,6 +15,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -561,7 +562,7 @@ int gd_push(gd_ctx* c, int32_t tid, const int32_t* pos, const uint16_t* flag, co
     if (!c) return GD_E_INVALID;
     if (n_reads == 0) return GD_OK;
     if (!pos || !flag || !mapq || !cigar_off || (n_ops && !cigar)) return GD_E_INVALID;
-    const size_t chunk = 1u << 22;   // records per staging block
+    const size_t chunk = 1u << 21;   // records per staging block (three blocks in flight: fill, copy, copy)
     size_t i = 0;
     while (i < n_reads) {
         size_t n = std::min(chunk, n_reads - i);
@@ -569,11 +570,23 @@ int gd_push(gd_ctx* c, int32_t tid, const int32_t* pos, const uint16_t* flag, co
         if (o1 < o0 || o1 > n_ops) return fail(c, GD_E_INVALID, "cigar_off out of range");
         gd_batch b;
         if (int r = gd_acquire(c, n, o1 - o0, &b)) return r;
-        memcpy(b.pos, pos + i, n * sizeof(int32_t));
-        memcpy(b.flag, flag + i, n * sizeof(uint16_t));
-        memcpy(b.mapq, mapq + i, n * sizeof(uint8_t));
-        for (size_t k = 0; k <= n; ++k) b.cigar_off[k] = cigar_off[i + k] - (uint32_t)o0;
-        if (o1 > o0) memcpy(b.cigar, cigar + o0, (o1 - o0) * sizeof(uint32_t));
+        // the five arrays are independent: fill the pinned block with a few threads (one core
+        // moves ~11 GB/s into pinned memory, well under what the PCIe link takes)
+        auto fill_off = [&]() { for (size_t k = 0; k <= n; ++k) b.cigar_off[k] = cigar_off[i + k] - (uint32_t)o0; };
+        auto fill_cig = [&]() { if (o1 > o0) memcpy(b.cigar, cigar + o0, (o1 - o0) * sizeof(uint32_t)); };
+        auto fill_rec = [&]() {
+            memcpy(b.pos, pos + i, n * sizeof(int32_t));
+            memcpy(b.flag, flag + i, n * sizeof(uint16_t));
+            memcpy(b.mapq, mapq + i, n * sizeof(uint8_t));
+        };
+        if (n >= (1u << 16)) {
+            std::thread t1(fill_off), t2(fill_cig);
+            fill_rec();
+            t1.join();
+            t2.join();
+        } else {
+            fill_rec(); fill_off(); fill_cig();
+        }
         if (int r = gd_commit(c, &b, tid, n, o1 - o0)) return r;
         i += n;
     }
