@@ -130,12 +130,12 @@ def host_stream_scope(local_rank, W, Q, mincov, reps=3):
             "host_to_device_GBps": nbytes / best / 1e9}
 
 
-def load_traffic():
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3
-    PMC passes (profiles/*_traffic.json, written by tools/traffic_from_pmc.py from
-    FETCH_SIZE / WRITE_SIZE collected in separate --pmc runs of this command)."""
+def load_traffic(tag="wgs"):
+    """HBM bytes per launch of the dominant kernel(s) from the committed rocprofv3
+    PMC passes (profiles/*_<tag>_traffic.json: FETCH_SIZE / WRITE_SIZE collected in
+    separate --pmc runs of this very command, tools/gpu_round_r.sh)."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_wgs_traffic.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_traffic.json" % tag)))
     if not files:
         return None
     try:
@@ -321,8 +321,12 @@ def main():
                   r["ckpt_ms"] + r["tile_ms"] if chunk else r["tile_ms"]) * 1e-3
     achieved = alg_bytes / avg_tile_s / 1e9
     traffic = None
-    tr = load_traffic()
-    if tr and world == 1 and args.workload == "wgs" and args.coverage == 30.0 and r["path"] == 1:
+    tr = None
+    if world == 1 and args.workload == "wgs" and args.coverage == 30.0 and r["path"] == 1:
+        tr = load_traffic("wgs")
+    elif world == 1 and args.workload == "ont" and args.coverage == 20.0 and chunk:
+        tr = load_traffic("ont")
+    if tr:
         traffic = tr.get("hbm_bytes_per_launch")   # measured on this exact launch shape
 
     # PCIe-inclusive rate (results to host) -- reported, never `value`

@@ -19,5 +19,6 @@ for pmc in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU S
 done
 python $R/tools/pmc_summary.py $out > $out/summary.txt 2>&1
 cat $out/summary.txt
-# keep only the small CSVs
+# keep the engine's rows only (the synthetic-data generator's torch kernels dominate the raw CSVs)
+for f in $(find $out -name "*counter_collection.csv"); do { head -1 $f; grep "gd::" $f; } > $f.tmp && mv $f.tmp $f; done
 find $out -name "*.csv" -size +4M -delete

@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """HBM traffic of gd_tile_kernel from rocprofv3 PMC passes.
 
-    python tools/traffic_from_pmc.py gpurun_out/prof_<tag> profiles/r01_wgs_traffic.json
+    python tools/traffic_from_pmc.py gpurun_out/prof_<tag> profiles/r01_wgs_traffic.json [kernel,kernel...] [bench args]
+
+The optional third argument lists the kernels whose traffic is summed (default
+gd_tile_kernel; the chunk path's roofline kernel is gd_ckpt_kernel,gd_ltile2_kernel).
 
 Reads the counter_collection CSVs of the separate `--pmc FETCH_SIZE` and
 `--pmc WRITE_SIZE` passes made by tools/prof.sh and applies the corrections of
@@ -16,24 +19,30 @@ import os
 import sys
 
 root, out = sys.argv[1], sys.argv[2]
-acc = {"FETCH_SIZE": [], "WRITE_SIZE": []}
-for f in glob.glob(os.path.join(root, "pmc*", "**", "*counter_collection.csv"), recursive=True):
-    for row in csv.DictReader(open(f)):
-        if "gd_tile_kernel" in row["Kernel_Name"] and row["Counter_Name"] in acc:
-            acc[row["Counter_Name"]].append(float(row["Counter_Value"]))
-fetch_kib = sum(acc["FETCH_SIZE"]) / len(acc["FETCH_SIZE"])
-write_kib = sum(acc["WRITE_SIZE"]) / len(acc["WRITE_SIZE"])
+kernels = sys.argv[3].split(",") if len(sys.argv) > 3 else ["gd_tile_kernel"]
+bench_args = sys.argv[4] if len(sys.argv) > 4 else ""
+fetch_kib = write_kib = 0.0
+n_disp = {}
+for kname in kernels:
+    acc = {"FETCH_SIZE": [], "WRITE_SIZE": []}
+    for f in glob.glob(os.path.join(root, "pmc*", "**", "*counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(f)):
+            if ("::" + kname) in row["Kernel_Name"] and row["Counter_Name"] in acc:
+                acc[row["Counter_Name"]].append(float(row["Counter_Value"]))
+    fetch_kib += sum(acc["FETCH_SIZE"]) / len(acc["FETCH_SIZE"])      # mean per dispatch, summed over the kernels
+    write_kib += sum(acc["WRITE_SIZE"]) / len(acc["WRITE_SIZE"])
+    n_disp[kname] = {k: len(v) for k, v in acc.items()}
 read_b = fetch_kib * 1024 * 2
 write_b = write_kib * 1024
 res = {
-    "kernel": "gd_tile_kernel",
+    "kernel": "+".join(kernels),
     "fetch_size_kib_raw": fetch_kib, "write_size_kib_raw": write_kib,
-    "dispatches": {k: len(v) for k, v in acc.items()},
+    "dispatches": n_disp,
     "hbm_read_bytes_per_launch": read_b, "hbm_write_bytes_per_launch": write_b,
     "hbm_bytes_per_launch": read_b + write_b,
     "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/prof.sh), "
               "FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md; "
-              "python bench.py --no-cpu-baseline --steps 5 --warmup 2",
+              "python bench.py %s--no-cpu-baseline --no-host-stream --steps 5 --warmup 2" % (bench_args + " " if bench_args else ""),
 }
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps(res))
