@@ -8,9 +8,15 @@
 #include <cstring>
 #include <thread>
 
+#include <chrono>
 namespace gdh {
 
 namespace {
+struct Tm {                                   // GOLEFT_BAM_TIMING=1: phase wall times on stderr at close
+    double read = 0, inflate = 0, wait = 0, append = 0, hop = 0, pass1 = 0, pass2 = 0;
+    static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+};
+Tm g_tm;
 
 inline uint16_t rd16(const uint8_t* p) { return (uint16_t)(p[0] | (p[1] << 8)); }
 inline uint32_t rd32(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
@@ -70,7 +76,85 @@ bool inflate_member(const uint8_t* raw, const Member& m, uint8_t* out)
 
 BamReader::~BamReader()
 {
+    drop_prefetch();
+    if (getenv("GOLEFT_BAM_TIMING"))
+        fprintf(stderr, "bam_reader: read %.3f inflate %.3f (producer thread) | wait %.3f append %.3f hop %.3f pass1 %.3f pass2 %.3f s\n",
+                g_tm.read, g_tm.inflate, g_tm.wait, g_tm.append, g_tm.hop, g_tm.pass1, g_tm.pass2);
     if (fp_) fclose(fp_);
+}
+
+// Producer side: reads the next kChunk compressed bytes, inflates every complete BGZF member
+// in it (in parallel) and returns the decoded bytes.  Runs on a background thread one chunk
+// ahead of the record decoder (prefetch_), so file I/O + inflate overlap the decode.
+BamReader::Chunk BamReader::produce(std::vector<uint8_t> spare)
+{
+    Chunk c;
+    c.data = std::move(spare);                           // recycled pages: no fresh page faults per batch
+    c.data.clear();
+    if (eof_ && raw_.empty()) { c.end = true; return c; }
+    const size_t kChunk = 64u << 20;
+    for (;;) {
+        double t0 = Tm::now();
+        if (!eof_) {
+            const size_t old = raw_.size();
+            raw_.resize(old + kChunk);
+            const size_t got = fread(raw_.data() + old, 1, kChunk, fp_);
+            raw_.resize(old + got);
+            if (got < kChunk) eof_ = true;
+        }
+        g_tm.read += Tm::now() - t0;
+        t0 = Tm::now();
+        std::vector<Member> ms;
+        size_t off = 0, out = 0;
+        for (;;) {
+            Member m;
+            const int rc = parse_member(raw_, off, &m);
+            if (rc < 0) { c.err = "corrupt BGZF member in " + path_; c.end = true; return c; }
+            if (rc == 0) break;
+            m.out_off = out;
+            out += m.isize;
+            off += m.size;
+            ms.push_back(m);
+        }
+        if (ms.empty()) {
+            if (eof_) {
+                if (!raw_.empty()) { c.err = "truncated BGZF file " + path_; raw_.clear(); }
+                c.end = true;
+                return c;
+            }
+            continue;                                    // a member larger than what is buffered: read on
+        }
+        c.data.resize(out);
+        std::atomic<size_t> next{0};
+        std::atomic<bool> bad{false};
+        auto work = [&]() {
+            for (;;) {
+                const size_t i = next.fetch_add(8);      // eight members (~0.5 MB) per grab
+                if (i >= ms.size() || bad.load()) return;
+                for (size_t k = i; k < std::min(i + 8, ms.size()); ++k) {
+                    if (ms[k].isize == 0) continue;
+                    if (!inflate_member(raw_.data(), ms[k], c.data.data())) bad.store(true);
+                }
+            }
+        };
+        const int nt = (int)std::min<size_t>((size_t)threads_, (ms.size() + 15) / 16);
+        if (nt <= 1) {
+            work();
+        } else {
+            std::vector<std::thread> th;
+            for (int t = 0; t < nt; ++t) th.emplace_back(work);
+            for (auto& t : th) t.join();
+        }
+        if (bad.load()) { c.err = "BGZF inflate/CRC failure in " + path_; c.data.clear(); c.end = true; return c; }
+        raw_.erase(raw_.begin(), raw_.begin() + (ptrdiff_t)off);
+        g_tm.inflate += Tm::now() - t0;
+        return c;
+    }
+}
+
+void BamReader::drop_prefetch()
+{
+    if (prefetch_.valid()) (void)prefetch_.get();
 }
 
 bool BamReader::fill(std::string* err)
@@ -80,56 +164,19 @@ bool BamReader::fill(std::string* err)
         buf_.erase(buf_.begin(), buf_.begin() + (ptrdiff_t)cur_);
         cur_ = 0;
     }
-    if (eof_ && raw_.empty()) return false;
-    const size_t kChunk = 16u << 20;
-    if (!eof_) {
-        const size_t old = raw_.size();
-        raw_.resize(old + kChunk);
-        const size_t got = fread(raw_.data() + old, 1, kChunk, fp_);
-        raw_.resize(old + got);
-        if (got < kChunk) eof_ = true;
-    }
-    std::vector<Member> ms;
-    size_t off = 0, out = 0;
-    for (;;) {
-        Member m;
-        const int rc = parse_member(raw_, off, &m);
-        if (rc < 0) { if (err) *err = "corrupt BGZF member in " + path_; return false; }
-        if (rc == 0) break;
-        m.out_off = out;
-        out += m.isize;
-        off += m.size;
-        ms.push_back(m);
-    }
-    if (ms.empty()) {
-        if (eof_) {
-            if (!raw_.empty()) { if (err) *err = "truncated BGZF file " + path_; raw_.clear(); }
-            return false;
-        }
-        return true;   // need more compressed bytes; caller loops
-    }
-    const size_t base = buf_.size();
-    buf_.resize(base + out);
-    std::atomic<size_t> next{0};
-    std::atomic<bool> bad{false};
-    auto work = [&]() {
-        for (;;) {
-            const size_t i = next.fetch_add(1);
-            if (i >= ms.size() || bad.load()) return;
-            if (ms[i].isize == 0) continue;
-            if (!inflate_member(raw_.data(), ms[i], buf_.data() + base)) bad.store(true);
-        }
-    };
-    const int nt = (int)std::min<size_t>((size_t)threads_, ms.size());
-    if (nt <= 1) {
-        work();
-    } else {
-        std::vector<std::thread> th;
-        for (int t = 0; t < nt; ++t) th.emplace_back(work);
-        for (auto& t : th) t.join();
-    }
-    if (bad.load()) { if (err) *err = "BGZF inflate/CRC failure in " + path_; return false; }
-    raw_.erase(raw_.begin(), raw_.begin() + (ptrdiff_t)off);
+    if (done_) return false;
+    double t0 = Tm::now();
+    Chunk c = prefetch_.valid() ? prefetch_.get() : produce(std::vector<uint8_t>());
+    g_tm.wait += Tm::now() - t0;
+    t0 = Tm::now();
+    if (!c.err.empty()) { if (err) *err = c.err; done_ = true; return false; }
+    if (c.end) { done_ = true; return false; }
+    if (buf_.capacity() < buf_.size() + c.data.size()) buf_.reserve(3 * c.data.size() + buf_.size());
+    buf_.insert(buf_.end(), c.data.begin(), c.data.end());
+    g_tm.append += Tm::now() - t0;
+    // one batch ahead, into the buffer just emptied
+    prefetch_ = std::async(std::launch::async,
+                           [this](std::vector<uint8_t> sp) { return produce(std::move(sp)); }, std::move(c.data));
     return true;
 }
 
@@ -142,7 +189,7 @@ bool BamReader::need(size_t n, std::string* err)
             if (!e.empty() && err) *err = e;
             return false;
         }
-        if (buf_.size() - cur_ == before && eof_ && raw_.empty()) return false;
+        if (buf_.size() - cur_ == before && done_) return false;
     }
     return true;
 }
@@ -215,80 +262,142 @@ bool BamReader::seek_contig(int32_t tid, std::string* err)
     }
     if (best == ~0ull) return false;
     const uint64_t coff = best >> 16, uoff = best & 0xffff;
+    drop_prefetch();                              // the producer owns fp_/raw_ while a chunk is in flight
     if (fseeko(fp_, (off_t)coff, SEEK_SET) != 0) { if (err) *err = "seek failed"; return false; }
     raw_.clear();
     buf_.clear();
     cur_ = 0;
     eof_ = false;
+    done_ = false;
     if (!need(uoff + 1, err)) return false;
     cur_ = uoff;
     return true;
 }
 
+namespace {
+
+// The CIGAR of the record at r (block_size bytes): the stored one, or the CG:B,I tag's when the
+// stored one is the <l_seq>S<ref_len>N placeholder of the long-CIGAR convention (SAMv1 4.2.2).
+// Returns false on a corrupt record.
+bool record_cigar(const uint8_t* r, uint32_t block_size, const uint8_t** cg_out, uint32_t* n_out)
+{
+    const uint32_t l_read_name = r[8];
+    uint32_t n_cigar = rd16(r + 12);
+    const uint32_t l_seq = rd32(r + 16);
+    if (32 + l_read_name + 4ull * n_cigar > block_size) return false;
+    const uint8_t* cg = r + 32 + l_read_name;
+    const uint8_t* end = r + block_size;
+    if (n_cigar == 2 && (rd32(cg) & 0xf) == 4 && (rd32(cg) >> 4) == l_seq && (rd32(cg + 4) & 0xf) == 3) {
+        const uint8_t* t = cg + 8 + (l_seq + 1) / 2 + l_seq;
+        while (t + 3 <= end) {
+            const uint8_t t0 = t[0], t1 = t[1], ty = t[2];
+            t += 3;
+            size_t sz = 0;
+            if (ty == 'A' || ty == 'c' || ty == 'C') sz = 1;
+            else if (ty == 's' || ty == 'S') sz = 2;
+            else if (ty == 'i' || ty == 'I' || ty == 'f') sz = 4;
+            else if (ty == 'Z' || ty == 'H') { while (t < end && *t) ++t; ++t; continue; }
+            else if (ty == 'B') {
+                if (t + 5 > end) break;
+                const uint8_t sub = t[0];
+                const uint32_t cnt = rd32(t + 1);
+                t += 5;
+                const size_t es = (sub == 'c' || sub == 'C') ? 1 : (sub == 's' || sub == 'S') ? 2 : 4;
+                if (t0 == 'C' && t1 == 'G' && sub == 'I' && t + 4ull * cnt <= end) { cg = t; n_cigar = cnt; break; }
+                t += es * (size_t)cnt;
+                continue;
+            } else break;
+            t += sz;
+        }
+    }
+    *cg_out = cg;
+    *n_out = n_cigar;
+    return true;
+}
+
+template <typename F>
+void parallel_for(size_t n, int threads, F f)            // f(begin, end) over [0, n)
+{
+    const size_t grain = 1u << 15;
+    const int nt = (int)std::min<size_t>((size_t)std::max(1, threads), (n + grain - 1) / grain);
+    if (nt <= 1) { f((size_t)0, n); return; }
+    std::vector<std::thread> th;
+    for (int t = 0; t < nt; ++t)
+        th.emplace_back([&, t]() { f(n * (size_t)t / (size_t)nt, n * (size_t)(t + 1) / (size_t)nt); });
+    for (auto& t : th) t.join();
+}
+
+}  // namespace
+
+// Record boundaries are found with a sequential hop over the block_size fields (cheap); the
+// fields and CIGARs of the records found are then extracted by all threads in two passes
+// (sizes -> prefix sum -> contents), so decode no longer runs at one core's speed.
 int BamReader::next_block(RecordBlock& out, size_t max_reads, std::string* err)
 {
     out.clear();
+    const double t_hop0 = Tm::now();
+    const double wait0 = g_tm.wait + g_tm.append;
+    std::vector<size_t> at;                               // offset of every record's body, relative to cur_
+    size_t p = 0;                                         // bytes hopped over, relative to cur_
     for (;;) {
         std::string e;
-        if (!need(4, &e)) {
+        if (!need(p + 4, &e)) {
             if (!e.empty()) { if (err) *err = e; return -1; }
-            if (buf_.size() - cur_ != 0) { if (err) *err = "truncated BAM record"; return -1; }
-            return out.size() ? 1 : 0;
+            if (buf_.size() - cur_ != p) { if (err) *err = "truncated BAM record"; return -1; }
+            break;
         }
-        const uint32_t block_size = rd32(buf_.data() + cur_);
+        const uint32_t block_size = rd32(buf_.data() + cur_ + p);
         if (block_size < 32) { if (err) *err = "corrupt BAM record"; return -1; }
-        if (!need(4 + (size_t)block_size, &e)) { if (err) *err = e.empty() ? "truncated BAM record" : e; return -1; }
-        const uint8_t* r = buf_.data() + cur_ + 4;
-        const int32_t ref_id = (int32_t)rd32(r);
-        if (out.size() && (ref_id != out.tid || out.size() >= max_reads)) return 1;   // leave it for the next call
-        const int32_t pos = (int32_t)rd32(r + 4);
-        const uint32_t l_read_name = r[8];
-        const uint8_t mq = r[9];
-        uint32_t n_cigar = rd16(r + 12);
-        const uint16_t flag = rd16(r + 14);
-        const uint32_t l_seq = rd32(r + 16);
-        cur_ += 4 + block_size;
+        if (!need(p + 4 + (size_t)block_size, &e)) { if (err) *err = e.empty() ? "truncated BAM record" : e; return -1; }
+        const int32_t ref_id = (int32_t)rd32(buf_.data() + cur_ + p + 4);
+        if (!at.empty() && (ref_id != out.tid || at.size() >= max_reads)) break;   // leave it for the next call
         ++n_records_;
-        if (ref_id < 0) { ++n_unplaced_; continue; }
-        if (32 + l_read_name + 4ull * n_cigar > block_size) { if (err) *err = "corrupt BAM record"; return -1; }
-        const uint8_t* cg = r + 32 + l_read_name;
-        const uint8_t* end = r + block_size;
-        // long-CIGAR convention: <l_seq>S<ref_len>N placeholder, real CIGAR in CG:B,I
-        const uint8_t* real = nullptr;
-        uint32_t n_real = 0;
-        if (n_cigar == 2 && (rd32(cg) & 0xf) == 4 && (rd32(cg) >> 4) == l_seq && (rd32(cg + 4) & 0xf) == 3) {
-            const uint8_t* t = cg + 8 + (l_seq + 1) / 2 + l_seq;
-            while (t + 3 <= end) {
-                const uint8_t t0 = t[0], t1 = t[1], ty = t[2];
-                t += 3;
-                size_t sz = 0;
-                if (ty == 'A' || ty == 'c' || ty == 'C') sz = 1;
-                else if (ty == 's' || ty == 'S') sz = 2;
-                else if (ty == 'i' || ty == 'I' || ty == 'f') sz = 4;
-                else if (ty == 'Z' || ty == 'H') { while (t < end && *t) ++t; ++t; continue; }
-                else if (ty == 'B') {
-                    if (t + 5 > end) break;
-                    const uint8_t sub = t[0];
-                    const uint32_t cnt = rd32(t + 1);
-                    t += 5;
-                    const size_t es = (sub == 'c' || sub == 'C') ? 1 : (sub == 's' || sub == 'S') ? 2 : 4;
-                    if (t0 == 'C' && t1 == 'G' && sub == 'I' && t + 4ull * cnt <= end) { real = t; n_real = cnt; break; }
-                    t += es * (size_t)cnt;
-                    continue;
-                } else break;
-                t += sz;
-            }
-        }
-        if (real) { cg = real; n_cigar = n_real; }
-        if (out.size() == 0) out.tid = ref_id;
-        out.pos.push_back(pos);
-        out.flag.push_back(flag);
-        out.mapq.push_back(mq);
-        const size_t c0 = out.cigar.size();
-        out.cigar.resize(c0 + n_cigar);
-        for (uint32_t k = 0; k < n_cigar; ++k) out.cigar[c0 + k] = rd32(cg + 4 * (size_t)k);
-        out.cigar_off.push_back((uint32_t)out.cigar.size());
+        if (ref_id < 0) { ++n_unplaced_; p += 4 + block_size; continue; }
+        if (at.empty()) out.tid = ref_id;
+        at.push_back(p + 4);
+        p += 4 + block_size;
     }
+    const size_t n = at.size();
+    g_tm.hop += Tm::now() - t_hop0 - (g_tm.wait + g_tm.append - wait0);
+    if (n) {
+        double t1 = Tm::now();
+        const uint8_t* base = buf_.data() + cur_;
+        out.pos.resize(n); out.flag.resize(n); out.mapq.resize(n);
+        out.cigar_off.assign(n + 1, 0);
+        std::atomic<bool> bad{false};
+        parallel_for(n, threads_, [&](size_t b, size_t e) {
+            for (size_t i = b; i < e; ++i) {
+                const uint8_t* r = base + at[i];
+                const uint8_t* cg;
+                uint32_t nc;
+                if (!record_cigar(r, rd32(r - 4), &cg, &nc)) { bad.store(true); return; }
+                out.cigar_off[i + 1] = nc;
+                out.pos[i] = (int32_t)rd32(r + 4);
+                out.mapq[i] = r[9];
+                out.flag[i] = rd16(r + 14);
+            }
+        });
+        if (bad.load()) { if (err) *err = "corrupt BAM record"; return -1; }
+        g_tm.pass1 += Tm::now() - t1;
+        t1 = Tm::now();
+        uint64_t tot = 0;
+        for (size_t i = 0; i < n; ++i) { tot += out.cigar_off[i + 1]; out.cigar_off[i + 1] = (uint32_t)tot; }
+        if (tot > 0xffffffffull) { if (err) *err = "more than 2^32 CIGAR ops in one block"; return -1; }
+        out.cigar.resize((size_t)tot);
+        parallel_for(n, threads_, [&](size_t b, size_t e) {
+            for (size_t i = b; i < e; ++i) {
+                const uint8_t* r = base + at[i];
+                const uint8_t* cg;
+                uint32_t nc;
+                record_cigar(r, rd32(r - 4), &cg, &nc);
+                uint32_t* dst = out.cigar.data() + out.cigar_off[i];
+                for (uint32_t k = 0; k < nc; ++k) dst[k] = rd32(cg + 4 * (size_t)k);
+            }
+        });
+        g_tm.pass2 += Tm::now() - t1;
+    }
+    cur_ += p;
+    return n ? 1 : 0;
 }
 
 }  // namespace gdh

@@ -9,6 +9,7 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <future>
 #include <string>
 #include <vector>
 
@@ -62,13 +63,22 @@ public:
     uint64_t n_unplaced() const { return n_unplaced_; }
 
 private:
-    bool fill(std::string* err);             // inflate the next batch of BGZF members
+    struct Chunk {                           // one batch of inflated BGZF members
+        std::vector<uint8_t> data;
+        std::string err;
+        bool end = false;                    // nothing more to read (or an error)
+    };
+    Chunk produce(std::vector<uint8_t> spare);   // read + inflate the next batch (runs one batch ahead)
+    void drop_prefetch();
+    bool fill(std::string* err);             // append the next batch to buf_
     bool need(size_t n, std::string* err);   // make n decoded bytes available at cur_
 
     FILE* fp_ = nullptr;
     std::string path_;
     int threads_ = 1;
-    bool eof_ = false;
+    bool eof_ = false;                        // producer: the file is exhausted
+    bool done_ = false;                       // consumer: the last batch has been appended
+    std::future<Chunk> prefetch_;
     std::vector<uint8_t> raw_;                // compressed batch
     std::vector<uint8_t> buf_;                // decoded bytes not yet consumed
     size_t cur_ = 0;

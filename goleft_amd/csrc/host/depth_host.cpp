@@ -17,6 +17,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <chrono>
 #include <string>
 #include <vector>
 
@@ -394,6 +395,14 @@ int run(const DArgs& args)
     GDCHK(gd_set_contigs(ctx, (int)lens.size(), lens.data()));
     if (!contigs.empty()) GDCHK(gd_select_contigs(ctx, (int)wanted.size(), wanted.data()));
 
+    // GOLEFT_DEPTH_TIMING=1: wall-clock phases on stderr (measurement only, SURVEY.md 8d scope iii)
+    const bool timing = getenv("GOLEFT_DEPTH_TIMING") != nullptr;
+    auto now = []() { return std::chrono::steady_clock::now(); };
+    auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+        return std::chrono::duration<double>(b - a).count();
+    };
+    const auto t_begin = now();
+    auto t_ingested = t_begin, t_computed = t_begin;
     // ---- stream decoded records into HBM (replaces the samtools children) -------
     if (!wanted.empty()) {
         if (wanted.size() == 1) bam.seek_contig(wanted[0], &err);   // .bai shortcut for --chrom
@@ -421,7 +430,9 @@ int run(const DArgs& args)
             if (!blk.cigar.empty()) memcpy(b.cigar, blk.cigar.data(), blk.cigar.size() * sizeof(uint32_t));
             GDCHK(gd_commit(ctx, &b, blk.tid, blk.size(), blk.cigar.size()));
         }
+        t_ingested = now();
         GDCHK(gd_compute(ctx));
+        t_computed = now();
     }
 
     // ---- rows, in input order (what --ordered gives; Q4) -------------------------
@@ -525,6 +536,10 @@ int run(const DArgs& args)
     if (fclose(fca) != 0) io_ok = false;
     if (fclose(fhd) != 0) io_ok = false;
     if (!io_ok) { fprintf(stderr, "goleft depth: write error\n"); return 1; }
+    if (timing)
+        fprintf(stderr, "{\"decode_and_ingest_s\": %.4f, \"compute_s\": %.4f, \"rows_s\": %.4f, \"records\": %llu}\n",
+                secs(t_begin, t_ingested), secs(t_ingested, t_computed), secs(t_computed, now()),
+                (unsigned long long)bam.n_records());
     return exit_code;
 }
 

@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""SURVEY.md section 8d scope (iii): BAM file -> BED, end to end, through the C++ host
+(`goleft-depth depth`): BGZF inflate + record decode on the host cores, pinned ring, H2D,
+kernels, BED rows.  Host-bound by construction; reported in DESIGN.md, never as bench `value`.
+
+    python tools/scope3.py [--length 63025520] [--coverage 30] [--threads 0]
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--length", type=int, default=63025520)
+    ap.add_argument("--coverage", type=float, default=30.0)
+    ap.add_argument("--threads", type=int, default=0)
+    ap.add_argument("--window", type=int, default=1000)
+    args = ap.parse_args()
+    d = tempfile.mkdtemp(prefix="gd_scope3_", dir="/tmp")
+    bam = os.path.join(d, "synth.bam")
+    t0 = time.perf_counter()
+    info = json.loads(subprocess.check_output([os.path.join(ROOT, "goleft_amd", "synth-bam"), bam, "chr20",
+                                               str(args.length), str(args.coverage), "20"]).decode())
+    t_write = time.perf_counter() - t0
+    best = None
+    for rep in range(3):                                   # the file is in the page cache after the write
+        t0 = time.perf_counter()
+        p = subprocess.run([os.path.join(ROOT, "goleft_amd", "goleft-depth"), "depth", "-w", str(args.window),
+                            "-p", str(args.threads), "-r", os.path.join(d, "synth.fa"), "--prefix",
+                            os.path.join(d, "out"), bam],
+                           env=dict(os.environ, GOLEFT_DEPTH_TIMING="1"), stderr=subprocess.PIPE)
+        dt = time.perf_counter() - t0
+        assert p.returncode == 0, p.stderr.decode()
+        phases = json.loads(p.stderr.decode().strip().splitlines()[-1])
+        if best is None or dt < best[0]:
+            best = (dt, phases)
+    dt, phases = best
+    rows = sum(1 for _ in open(os.path.join(d, "out.depth.bed")))
+    out = {"scope": "BAM file -> depth.bed + callable.bed (goleft-depth CLI, process start to exit)",
+           "ref_bases": args.length, "coverage": args.coverage, "reads": info["reads"],
+           "bam_MB": info["bam_bytes"] / 1e6, "wall_s": dt, "ref_bases_per_s": args.length / dt,
+           "bam_MB_per_s": info["bam_bytes"] / 1e6 / dt, "phases": phases, "depth_rows": rows,
+           "host_cores": os.cpu_count(), "bam_write_s": t_write}
+    print(json.dumps(out))
+    for f in os.listdir(d):
+        os.unlink(os.path.join(d, f))
+    os.rmdir(d)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,167 @@
+// synth_bam.cpp -- writes a realistic single-contig BAM for the end-to-end timing
+// (SURVEY.md section 8d scope iii: BAM file -> BED).  MEASUREMENT TOOL, not product code.
+//
+//   synth-bam OUT.bam CONTIG LENGTH COVERAGE [SEED] [THREADS]
+//
+// 150 bp reads of the SURVEY 8d short-read model (92 % 150M, 5 % soft clip, 2 % one deletion,
+// 1 % one insertion; 5 % DUP, 0.3 % other filtered flags, 1 % MAPQ 0), coordinate sorted, WITH
+// SEQ and QUAL (random bases, run-structured qualities) so that the file has the size and the
+// inflate cost of a real one (~250 B per record before BGZF).  BGZF members are deflated in
+// parallel (zlib level 1).  Also writes OUT.bam.fai-style "<contig>\t<length>\t..." to OUT.fa.fai.
+#include <zlib.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+static inline uint64_t mix(uint64_t x)
+{
+    x += 0x9e3779b97f4a7c15ull;
+    x = (x ^ (x >> 30)) * 0xbf58476d1ce4e5b9ull;
+    x = (x ^ (x >> 27)) * 0x94d049bb133111ebull;
+    return x ^ (x >> 31);
+}
+
+static void put32(std::vector<uint8_t>& v, uint32_t x) { for (int i = 0; i < 4; ++i) v.push_back((uint8_t)(x >> (8 * i))); }
+static void put16(std::vector<uint8_t>& v, uint16_t x) { v.push_back((uint8_t)x); v.push_back((uint8_t)(x >> 8)); }
+
+static int reg2bin(int64_t beg, int64_t end)
+{
+    --end;
+    if (beg >> 14 == end >> 14) return (int)(((1 << 15) - 1) / 7 + (beg >> 14));
+    if (beg >> 17 == end >> 17) return (int)(((1 << 12) - 1) / 7 + (beg >> 17));
+    if (beg >> 20 == end >> 20) return (int)(((1 << 9) - 1) / 7 + (beg >> 20));
+    if (beg >> 23 == end >> 23) return (int)(((1 << 6) - 1) / 7 + (beg >> 23));
+    if (beg >> 26 == end >> 26) return (int)(((1 << 3) - 1) / 7 + (beg >> 26));
+    return 0;
+}
+
+static void bgzf_member(const uint8_t* data, size_t n, std::vector<uint8_t>* out)
+{
+    out->clear();
+    std::vector<uint8_t> c(n + n / 8 + 128);
+    z_stream zs;
+    memset(&zs, 0, sizeof zs);
+    deflateInit2(&zs, 1, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY);
+    zs.next_in = const_cast<uint8_t*>(data);
+    zs.avail_in = (uInt)n;
+    zs.next_out = c.data();
+    zs.avail_out = (uInt)c.size();
+    deflate(&zs, Z_FINISH);
+    const size_t clen = c.size() - zs.avail_out;
+    deflateEnd(&zs);
+    static const uint8_t hdr[16] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0};
+    out->insert(out->end(), hdr, hdr + 16);
+    put16(*out, (uint16_t)(clen + 25));
+    out->insert(out->end(), c.begin(), c.begin() + (long)clen);
+    put32(*out, (uint32_t)crc32(crc32(0L, nullptr, 0), data, (uInt)n));
+    put32(*out, (uint32_t)n);
+}
+
+int main(int argc, char** argv)
+{
+    if (argc < 5) { fprintf(stderr, "usage: synth-bam OUT.bam CONTIG LENGTH COVERAGE [SEED] [THREADS]\n"); return 2; }
+    const std::string path = argv[1], contig = argv[2];
+    const int64_t L = atoll(argv[3]);
+    const double cov = atof(argv[4]);
+    const uint64_t seed = argc > 5 ? strtoull(argv[5], nullptr, 10) : 1;
+    int threads = argc > 6 ? atoi(argv[6]) : (int)std::thread::hardware_concurrency();
+    if (threads < 1) threads = 1;
+    const int RL = 150;
+    const int64_t n = (int64_t)((double)L * cov / RL);
+    FILE* f = fopen(path.c_str(), "wb");
+    if (!f) { perror("open"); return 1; }
+
+    std::vector<uint8_t> raw;                 // uncompressed BAM bytes of the current batch
+    raw.reserve(300u << 20);
+    std::string text = "@HD\tVN:1.6\tSO:coordinate\n@SQ\tSN:" + contig + "\tLN:" + std::to_string(L) +
+                       "\n@RG\tID:rg1\tSM:synth\n";
+    raw.insert(raw.end(), {'B', 'A', 'M', 1});
+    put32(raw, (uint32_t)text.size());
+    raw.insert(raw.end(), text.begin(), text.end());
+    put32(raw, 1);
+    put32(raw, (uint32_t)contig.size() + 1);
+    raw.insert(raw.end(), contig.begin(), contig.end());
+    raw.push_back(0);
+    put32(raw, (uint32_t)L);
+
+    const size_t BLK = 0xff00;
+    uint64_t out_bytes = 0;
+    auto flush = [&](bool final) {
+        const size_t nblk = raw.size() / BLK + ((final && raw.size() % BLK) ? 1 : 0);
+        std::vector<std::vector<uint8_t>> comp(nblk);
+        std::vector<std::thread> pool;
+        for (int t = 0; t < threads; ++t)
+            pool.emplace_back([&, t]() {
+                for (size_t b = (size_t)t; b < nblk; b += (size_t)threads) {
+                    const size_t off = b * BLK, len = std::min(BLK, raw.size() - off);
+                    bgzf_member(raw.data() + off, len, &comp[b]);
+                }
+            });
+        for (auto& th : pool) th.join();
+        for (auto& c : comp) { fwrite(c.data(), 1, c.size(), f); out_bytes += c.size(); }
+        const size_t used = std::min(raw.size(), nblk * BLK);
+        raw.erase(raw.begin(), raw.begin() + (long)used);
+    };
+
+    const int64_t span = L - RL > 0 ? L - RL : 1;
+    for (int64_t i = 0; i < n; ++i) {
+        const uint64_t h = mix(seed * 0x100000001b3ull + (uint64_t)i);
+        const int64_t stride = span / n > 0 ? span / n : 1;
+        int64_t pos = (int64_t)(((__int128)i * span) / n) + (int64_t)(h % (uint64_t)stride);
+        if (pos > span) pos = span;
+        const uint32_t kind = (uint32_t)((h >> 20) % 10000);
+        uint32_t cig[3];
+        int nc = 1, ref = RL;
+        if (kind < 9200) { cig[0] = (uint32_t)RL << 4; }
+        else if (kind < 9700) { const uint32_t k = 1 + (uint32_t)((h >> 40) % 30); cig[0] = k << 4 | 4; cig[1] = (RL - k) << 4; nc = 2; ref = RL - (int)k; }
+        else if (kind < 9900) { const uint32_t a = 20 + (uint32_t)((h >> 40) % 100), d = 1 + (uint32_t)((h >> 50) % 10);
+                                cig[0] = a << 4; cig[1] = d << 4 | 2; cig[2] = (RL - a) << 4; nc = 3; ref = RL + (int)d; }
+        else { const uint32_t a = 20 + (uint32_t)((h >> 40) % 100), ins = 1 + (uint32_t)((h >> 50) % 10);
+               cig[0] = a << 4; cig[1] = ins << 4 | 1; cig[2] = (RL - a - ins) << 4; nc = 3; ref = RL - (int)ins; }
+        const uint32_t fr = (uint32_t)((h >> 8) % 1000);
+        uint16_t flag = (h & 1) ? 99 : 147;
+        if (fr < 50) flag |= 0x400; else if (fr < 51) flag |= 0x100; else if (fr < 52) flag |= 0x200; else if (fr < 57) flag |= 0x800;
+        const uint8_t mapq = ((h >> 12) % 100) == 0 ? 0 : 60;
+        char name[32];
+        const int ln = snprintf(name, sizeof name, "synth.%llu", (unsigned long long)i) + 1;
+        const uint32_t block = 32 + (uint32_t)ln + 4u * (uint32_t)nc + (RL + 1) / 2 + RL;
+        put32(raw, block);
+        put32(raw, 0);                                   // refID
+        put32(raw, (uint32_t)pos);
+        raw.push_back((uint8_t)ln);
+        raw.push_back(mapq);
+        put16(raw, (uint16_t)reg2bin(pos, pos + ref));
+        put16(raw, (uint16_t)nc);
+        put16(raw, flag);
+        put32(raw, RL);
+        put32(raw, 0xffffffffu);                         // next refID
+        put32(raw, 0xffffffffu);                         // next pos
+        put32(raw, 0);
+        raw.insert(raw.end(), name, name + ln);
+        for (int k = 0; k < nc; ++k) put32(raw, cig[k]);
+        uint64_t r = h;
+        for (int k = 0; k < (RL + 1) / 2; ++k) {         // two random bases per byte (A C G T = 1 2 4 8)
+            if ((k & 15) == 0) r = mix(r);
+            raw.push_back((uint8_t)((1u << ((r >> (4 * (k & 15))) & 3)) << 4 | (1u << ((r >> (4 * (k & 15) + 2)) & 3))));
+        }
+        uint8_t q = 37;
+        for (int k = 0; k < RL; ++k) {                   // qualities: long runs with occasional dips
+            if ((k & 7) == 0) { r = mix(r); q = (r & 7) == 0 ? (uint8_t)(2 + (r >> 8) % 35) : 37; }
+            raw.push_back(q);
+        }
+        if (raw.size() >= (256u << 20)) flush(false);
+    }
+    flush(true);
+    static const uint8_t eof[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    fwrite(eof, 1, 28, f);
+    fclose(f);
+    FILE* fai = fopen((path.substr(0, path.size() - 4) + ".fa.fai").c_str(), "w");
+    if (fai) { fprintf(fai, "%s\t%lld\t6\t60\t61\n", contig.c_str(), (long long)L); fclose(fai); }
+    printf("{\"reads\": %lld, \"bam_bytes\": %llu}\n", (long long)n, (unsigned long long)(out_bytes + 28));
+    return 0;
+}
