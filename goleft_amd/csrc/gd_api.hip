@@ -68,7 +68,6 @@ struct gd_ctx {
 
     int tile_T = 4096;
     int tile_NT = 256;
-    int ablate = 0;                     // debug: GOLEFT_GD_ABLATE (unused by the current kernels)
     int kernel_gen = 7;                 // debug: GOLEFT_GD_KERNEL=v6 selects the previous tile kernel
     int tile_opt = 1;                   // bit 0: non-temporal per-base stores (2 % faster: the vector is
                                         // never re-read by the kernel); GOLEFT_GD_OPT=0 for plain stores
@@ -316,7 +315,6 @@ int gd_create(int device_id, gd_ctx** out)
         int t = atoi(e);
         if (t == 4096 || t == 8192) c->tile_T = t;
     }
-    if (const char* e = getenv("GOLEFT_GD_ABLATE")) c->ablate = atoi(e);
     if (const char* e = getenv("GOLEFT_GD_KERNEL")) c->kernel_gen = (e[0] == 'v' && e[1] == '6') ? 6 : 7;
     if (const char* e = getenv("GOLEFT_GD_OPT")) c->tile_opt = atoi(e) & 1;
     if (const char* e = getenv("GOLEFT_GD_SCOPE")) c->scope_wg = e[0] == 'w';
@@ -753,7 +751,6 @@ int gd_compute(gd_ctx* c)
         job.maxmean = P.max_mean_depth;
         job.flag_mask = P.flag_mask;
         job.lookback = c->lookback;
-        job.ablate = c->ablate;
         job.step = derive_step(P);
         magic_u31((uint32_t)job.W, &job.w_magic, &job.w_shift);
         magic_u31(job.step > 0x7fffffffLL ? 0x7fffffffu : (uint32_t)job.step, &job.s_magic, &job.s_shift);

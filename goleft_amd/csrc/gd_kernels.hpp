@@ -106,8 +106,7 @@ struct Job {
     int32_t   maxmean;
     uint32_t  flag_mask;
     int32_t   lookback;
-    int32_t   ablate;         // debug only (GOLEFT_GD_ABLATE), read by no current kernel: 1 skip phase A, 2 skip LDS marks,
-                              // 4 skip per-base stores, 8 skip window/class reductions
+    int32_t   reserved0;
     int64_t   step;
     uint32_t  n_units;        // scatter path: 64-read units over all contigs
     unsigned long long* tile_status;   // scatter path: look-back status word per tile

@@ -4,7 +4,7 @@
     python tools/variants.py [--steps 8] [--verify] "KEY=VAL,KEY=VAL" ...
 
 Each positional argument is one variant: a comma separated list of GOLEFT_GD_*
-environment settings read by gd_create (TILE, THREADS, KERNEL, OPT, ABLATE ...;
+environment settings read by gd_create (TILE, THREADS, KERNEL=v6, OPT=0, PATH ...;
 the GOLEFT_GD_ prefix is implied).  "-" is the default configuration.
 The record streams are generated once on the device and adopted zero-copy by
 a fresh engine per variant.  --verify checks chr21 against the CPU oracle.
