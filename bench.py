@@ -400,7 +400,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_host_stream and args.workload in ("wgs", "chr20"):
         out["host_stream_scope"] = host_stream_scope(local_rank, W, Q, mincov)
 
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:      # a reported baseline, N = 1 only
         from oracle import pyoracle as po
         cores = os.cpu_count() or 1
         sample = []
