@@ -254,6 +254,14 @@ void launch_ltile(gd_ctx* c, const gd::Job& job)
         hipLaunchKernelGGL((gd::gd_ltile2_kernel<T, NT, 0>), dim3(grid), dim3(NT), 0, c->stream, job);
 }
 
+// RAII for the scratch device buffers of gd_ingest_bgzf
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
+    template <typename T> T* as() const { return static_cast<T*>(p); }
+};
+
 }  // namespace
 
 extern "C" {
@@ -1317,6 +1325,223 @@ int gd_md_sums(gd_ctx* c, size_t n_blocks, const int64_t* start, const int64_t* 
     (void)hipFree(d);
     if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess || e5 != hipSuccess)
         return fail(c, GD_E_HIP, "multidepth block-sum kernel failed");
+    return GD_OK;
+}
+
+int gd_inflate_bgzf(gd_ctx* c, const uint8_t* data, size_t n_bytes, size_t n_members, const uint64_t* in_off,
+                    const uint32_t* in_len, const uint64_t* out_off, const uint32_t* out_len, uint8_t* out,
+                    size_t out_bytes, uint32_t* status)
+{
+    if (!c || !data || !in_off || !in_len || !out_off || !out_len || !out || !status) return GD_E_INVALID;
+    if (int r = set_device(c)) return r;
+    if (n_members == 0) return GD_OK;
+    if (n_members > 0xffffffffull) return fail(c, GD_E_RANGE, "too many BGZF members");
+    for (size_t m = 0; m < n_members; ++m)
+        if (in_off[m] + in_len[m] > n_bytes || out_off[m] + out_len[m] > out_bytes)
+            return fail(c, GD_E_RANGE, "BGZF member %zu outside the given buffers", m);
+    uint8_t *d_in = nullptr, *d_out = nullptr, *d_tab = nullptr;
+    const size_t tab_bytes = n_members * (2 * sizeof(uint64_t) + 3 * sizeof(uint32_t));
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&d_in), n_bytes);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_out), out_bytes ? out_bytes : 1);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_tab), tab_bytes);
+    if (e != hipSuccess) {
+        if (d_in) (void)hipFree(d_in);
+        if (d_out) (void)hipFree(d_out);
+        return fail(c, GD_E_NOMEM, "device allocation for BGZF inflate failed");
+    }
+    uint64_t* t_in_off = reinterpret_cast<uint64_t*>(d_tab);
+    uint64_t* t_out_off = t_in_off + n_members;
+    uint32_t* t_in_len = reinterpret_cast<uint32_t*>(t_out_off + n_members);
+    uint32_t* t_out_len = t_in_len + n_members;
+    uint32_t* t_status = t_out_len + n_members;
+    hipError_t e1 = hipMemcpyAsync(d_in, data, n_bytes, hipMemcpyHostToDevice, c->stream);
+    hipError_t e2 = hipMemcpyAsync(t_in_off, in_off, n_members * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream);
+    hipError_t e3 = hipMemcpyAsync(t_out_off, out_off, n_members * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream);
+    hipError_t e4 = hipMemcpyAsync(t_in_len, in_len, n_members * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream);
+    hipError_t e5 = hipMemcpyAsync(t_out_len, out_len, n_members * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream);
+    gd::InflateJob j{};
+    j.comp = d_in; j.in_off = t_in_off; j.in_len = t_in_len; j.out_off = t_out_off; j.out_len = t_out_len;
+    j.out = d_out; j.status = t_status; j.n = (uint32_t)n_members;
+    if (c->profiling) (void)hipEventRecord(c->ev[0], c->stream);
+    hipLaunchKernelGGL(gd::gd_inflate_kernel, dim3((unsigned)((n_members + gd::INF_LANES - 1) / gd::INF_LANES)),
+                       dim3(gd::INF_LANES), 0, c->stream, j);
+    if (c->profiling) (void)hipEventRecord(c->ev[1], c->stream);
+    hipError_t e6 = hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, c->stream);
+    hipError_t e7 = hipMemcpyAsync(status, t_status, n_members * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream);
+    hipError_t e8 = hipStreamSynchronize(c->stream);
+    if (c->profiling && e8 == hipSuccess) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) c->kernel_ms[GD_K_INFLATE] = ms;
+    }
+    (void)hipFree(d_in); (void)hipFree(d_out); (void)hipFree(d_tab);
+    for (hipError_t x : {e1, e2, e3, e4, e5, e6, e7, e8})
+        if (x != hipSuccess) return fail(c, GD_E_HIP, "BGZF inflate kernel failed: %s", hipGetErrorString(x));
+    return GD_OK;
+}
+
+int gd_ingest_bgzf(gd_ctx* c, int32_t tid, const uint8_t* data, size_t n_bytes, uint64_t base_coffset,
+                   const uint64_t* anchors, size_t n_anchors, uint64_t* n_records)
+{
+    if (!c || !data || !anchors || n_anchors == 0) return GD_E_INVALID;
+    if (int r = set_device(c)) return r;
+    if (tid < 0 || (size_t)tid >= c->contigs.size()) return fail(c, GD_E_RANGE, "tid %d out of range", tid);
+    if (n_anchors > 0xfffffff0ull) return fail(c, GD_E_RANGE, "too many anchors");
+    // ---- the BGZF members of the range (SAMv1 4.1: gzip header with a BC extra subfield) -------
+    std::vector<uint64_t> m_coff, in_off, out_off;
+    std::vector<uint32_t> in_len, out_len;
+    uint64_t total = 0;
+    for (size_t p = 0; p + 18 <= n_bytes;) {
+        const uint8_t* h = data + p;
+        if (h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4))
+            return fail(c, GD_E_INVALID, "not a BGZF member at byte %zu of the range", p);
+        const size_t xlen = (size_t)h[10] | ((size_t)h[11] << 8);
+        if (p + 12 + xlen > n_bytes) break;
+        size_t q = 12, bsize = 0;
+        while (q + 4 <= 12 + xlen) {
+            const size_t slen = (size_t)h[q + 2] | ((size_t)h[q + 3] << 8);
+            if (h[q] == 66 && h[q + 1] == 67 && slen == 2) bsize = ((size_t)h[q + 4] | ((size_t)h[q + 5] << 8)) + 1;
+            q += 4 + slen;
+        }
+        if (bsize < 12 + xlen + 8) return fail(c, GD_E_INVALID, "BGZF member without a BC subfield at byte %zu", p);
+        if (p + bsize > n_bytes) break;                     // a trailing partial member is ignored
+        const uint32_t isize = (uint32_t)h[bsize - 4] | ((uint32_t)h[bsize - 3] << 8) | ((uint32_t)h[bsize - 2] << 16) |
+                               ((uint32_t)h[bsize - 1] << 24);
+        m_coff.push_back(base_coffset + p);
+        in_off.push_back(p + 12 + xlen);
+        in_len.push_back((uint32_t)(bsize - 12 - xlen - 8));
+        out_off.push_back(total);
+        out_len.push_back(isize);
+        total += isize;
+        p += bsize;
+    }
+    const size_t nm = m_coff.size();
+    if (nm == 0) return fail(c, GD_E_INVALID, "no complete BGZF member in the range");
+    // ---- anchors (virtual offsets) -> byte offsets in the inflated range ----------------------
+    std::vector<uint64_t> seg_beg(n_anchors), seg_end(n_anchors);
+    for (size_t i = 0; i < n_anchors; ++i) {
+        const uint64_t coff = anchors[i] >> 16, uoff = anchors[i] & 0xffffu;
+        const size_t k = (size_t)(std::lower_bound(m_coff.begin(), m_coff.end(), coff) - m_coff.begin());
+        if (k >= nm || m_coff[k] != coff || uoff > out_len[k])
+            return fail(c, GD_E_INVALID, "anchor %zu (virtual offset %llu) is not inside a member of the range", i,
+                        (unsigned long long)anchors[i]);
+        seg_beg[i] = out_off[k] + uoff;
+        if (i && seg_beg[i] <= seg_beg[i - 1]) return fail(c, GD_E_INVALID, "anchors must be strictly ascending");
+        if (i) seg_end[i - 1] = seg_beg[i];
+    }
+    seg_end[n_anchors - 1] = total;
+
+    // ---- device: inflate ------------------------------------------------------------------------
+    DevBuf d_in, d_out, d_tab, d_seg;
+    const size_t tab_bytes = nm * (2 * sizeof(uint64_t) + 3 * sizeof(uint32_t));
+    const size_t seg_words = n_anchors * 5;                 // seg_beg, seg_end, rec_base, op_base, n_ops (uint64 each)
+    const size_t seg_bytes = seg_words * sizeof(uint64_t) + n_anchors * 4 * sizeof(uint32_t);
+    if (d_in.alloc(n_bytes) != hipSuccess || d_out.alloc(total) != hipSuccess || d_tab.alloc(tab_bytes) != hipSuccess ||
+        d_seg.alloc(seg_bytes) != hipSuccess)
+        return fail(c, GD_E_NOMEM, "device allocation for the BAM decode failed (%zu + %llu bytes)", n_bytes,
+                    (unsigned long long)total);
+    uint64_t* t_in_off = d_tab.as<uint64_t>();
+    uint64_t* t_out_off = t_in_off + nm;
+    uint32_t* t_in_len = reinterpret_cast<uint32_t*>(t_out_off + nm);
+    uint32_t* t_out_len = t_in_len + nm;
+    uint32_t* t_status = t_out_len + nm;
+    HIPCHK(c, hipMemcpyAsync(d_in.p, data, n_bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(t_in_off, in_off.data(), nm * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(t_out_off, out_off.data(), nm * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(t_in_len, in_len.data(), nm * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(t_out_len, out_len.data(), nm * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    gd::InflateJob ij{};
+    ij.comp = d_in.as<uint8_t>(); ij.in_off = t_in_off; ij.in_len = t_in_len; ij.out_off = t_out_off;
+    ij.out_len = t_out_len; ij.out = d_out.as<uint8_t>(); ij.status = t_status; ij.n = (uint32_t)nm;
+    if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+    hipLaunchKernelGGL(gd::gd_inflate_kernel, dim3((unsigned)((nm + gd::INF_LANES - 1) / gd::INF_LANES)),
+                       dim3(gd::INF_LANES), 0, c->stream, ij);
+    if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+    std::vector<uint32_t> status(nm);
+    HIPCHK(c, hipMemcpyAsync(status.data(), t_status, nm * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+
+    // ---- device: count the records of every anchor segment -------------------------------------
+    uint64_t* s_beg = d_seg.as<uint64_t>();
+    uint64_t* s_end = s_beg + n_anchors;
+    uint64_t* s_rbase = s_end + n_anchors;
+    uint64_t* s_obase = s_rbase + n_anchors;
+    uint64_t* s_nops = s_obase + n_anchors;
+    uint32_t* s_nrec = reinterpret_cast<uint32_t*>(s_nops + n_anchors);
+    int32_t* s_first = reinterpret_cast<int32_t*>(s_nrec + n_anchors);
+    int32_t* s_last = s_first + n_anchors;
+    uint32_t* s_flags = reinterpret_cast<uint32_t*>(s_last + n_anchors);
+    HIPCHK(c, hipMemcpyAsync(s_beg, seg_beg.data(), n_anchors * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(s_end, seg_end.data(), n_anchors * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+    gd::BamSegJob bj{};
+    bj.data = d_out.as<uint8_t>(); bj.n_bytes = total; bj.seg_beg = s_beg; bj.seg_end = s_end; bj.tid = tid;
+    bj.n_seg = (uint32_t)n_anchors; bj.n_rec = s_nrec; bj.n_ops = s_nops; bj.first_pos = s_first; bj.last_pos = s_last;
+    bj.flags = s_flags;
+    const unsigned seg_grid = (unsigned)((n_anchors + 63) / 64);
+    hipLaunchKernelGGL(gd::gd_bam_walk_kernel<false>, dim3(seg_grid), dim3(64), 0, c->stream, bj);
+    std::vector<uint32_t> nrec(n_anchors), flags(n_anchors);
+    std::vector<uint64_t> nops(n_anchors);
+    std::vector<int32_t> firstp(n_anchors), lastp(n_anchors);
+    HIPCHK(c, hipMemcpyAsync(nrec.data(), s_nrec, n_anchors * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(nops.data(), s_nops, n_anchors * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(firstp.data(), s_first, n_anchors * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(lastp.data(), s_last, n_anchors * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(flags.data(), s_flags, n_anchors * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->profiling) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) c->kernel_ms[GD_K_INFLATE] = ms;
+    }
+    for (size_t m = 0; m < nm; ++m)
+        if (status[m] != 0)
+            return fail(c, GD_E_INVALID, "BGZF member at file offset %llu does not inflate (decoder code %u)",
+                        (unsigned long long)m_coff[m], status[m]);
+    std::vector<uint64_t> rbase(n_anchors), obase(n_anchors);
+    uint64_t N = 0, M = 0;
+    int32_t prev_last = -0x7fffffff;
+    for (size_t i = 0; i < n_anchors; ++i) {
+        if (flags[i] & 2u) return fail(c, GD_E_INVALID, "corrupt BAM record in anchor segment %zu", i);
+        if (flags[i] & 4u) return fail(c, GD_E_INVALID, "anchor %zu is not a record start (stale or foreign index?)", i + 1);
+        if ((flags[i] & 1u) || (nrec[i] && firstp[i] < prev_last))
+            return fail(c, GD_E_UNSORTED, "contig %d: records not coordinate sorted (anchor segment %zu)", tid, i);
+        if (nrec[i]) prev_last = lastp[i];
+        rbase[i] = N;
+        obase[i] = M;
+        N += nrec[i];
+        M += nops[i];
+    }
+    if (M > 0xffffffffull) return fail(c, GD_E_RANGE, "more than 2^32 CIGAR ops on contig %d", tid);
+    if (N >= kMaxReadsPerContig) return fail(c, GD_E_RANGE, "more than 2^30 records on contig %d", tid);
+
+    // ---- device: extract into the contig's SoA arrays -------------------------------------------
+    HIPCHK(c, hipStreamSynchronize(c->copy_stream));
+    ContigHost& h = c->contigs[tid];
+    {
+        const int64_t len = h.length;
+        free_contig(h);
+        h.length = len;
+    }
+    if (N) {
+        size_t c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0;
+        if (int r = ensure_dev(c, &h.pos, &c1, (size_t)N)) return r;
+        if (int r = ensure_dev(c, &h.flag, &c2, (size_t)N)) return r;
+        if (int r = ensure_dev(c, &h.mapq, &c3, (size_t)N)) return r;
+        if (int r = ensure_dev(c, &h.off, &c4, (size_t)N + 1)) return r;
+        if (int r = ensure_dev(c, &h.cigar, &c5, (size_t)std::max<uint64_t>(M, 1))) return r;
+        h.cap_reads = (size_t)N;
+        h.cap_ops = c5;
+        HIPCHK(c, hipMemcpyAsync(s_rbase, rbase.data(), n_anchors * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(s_obase, obase.data(), n_anchors * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+        bj.rec_base = s_rbase; bj.op_base = s_obase;
+        bj.pos = h.pos; bj.flag = h.flag; bj.mapq = h.mapq; bj.cigar_off = h.off; bj.cigar = h.cigar;
+        hipLaunchKernelGGL(gd::gd_bam_walk_kernel<true>, dim3(seg_grid), dim3(64), 0, c->stream, bj);
+        const uint32_t m32 = (uint32_t)M;
+        HIPCHK(c, hipMemcpyAsync(h.off + N, &m32, sizeof m32, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    h.n_reads = (size_t)N;
+    h.n_ops = (size_t)M;
+    h.last_pos = prev_last;
+    c->computed = false;
+    if (n_records) *n_records = N;
     return GD_OK;
 }
 

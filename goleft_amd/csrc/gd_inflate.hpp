@@ -1,0 +1,261 @@
+// gd_inflate.hpp -- BGZF (RFC 1951 DEFLATE) decompression on the device.
+//
+// The BAM read that every `samtools depth` child of the reference performs
+// (/root/reference/depth/depth.go:45) starts with inflating BGZF members; on the host that
+// is the end-to-end limiter (scope iii).  A BGZF file is a sequence of
+// independent <= 64 KiB deflate streams, so the file offers tens of thousands to millions
+// of independent decode jobs: here ONE LANE inflates ONE member, start to end, with the
+// classic canonical-Huffman bit-serial decoder (count[] / symbol[] per code length, as in
+// zlib's contrib/puff) -- no shared state between lanes, no host involvement beyond
+// listing the members.  The Huffman tables of a lane live in LDS ([entry][lane] layout: the
+// 64 lanes of a wave read/write the same entry of 64 different tables without bank
+// conflicts when they are in step), the code lengths of a dynamic block in the lane's
+// private memory, input is fetched 4 bytes at a time, output goes to the member's own
+// region of the inflated buffer (back-references read that same region).
+#pragma once
+
+namespace gd {
+
+struct InflateJob {
+    const uint8_t* comp;           // the compressed bytes
+    const uint64_t* in_off;        // [n] offset of each member's deflate payload in comp
+    const uint32_t* in_len;        // [n] payload bytes
+    const uint64_t* out_off;       // [n] offset of the member's data in out
+    const uint32_t* out_len;       // [n] ISIZE
+    uint8_t* out;
+    uint32_t* status;              // [n] 0 ok, else an error code
+    uint32_t n;
+};
+
+constexpr int INF_LANES = 64;      // lanes (= members in flight) per workgroup
+constexpr int INF_MAXL = 288, INF_MAXD = 30;
+// per-lane LDS tables, uint16: lencnt[16] lensym[288] distcnt[16] distsym[30]
+constexpr int INF_TBL = 16 + INF_MAXL + 16 + INF_MAXD;
+
+struct BitReader {
+    const uint8_t* p;              // next byte not yet fetched into `ahead`
+    const uint8_t* end;
+    uint64_t buf;                  // bits not yet consumed, LSB first
+    uint64_t ahead;                // the next 8 input bytes, fetched one refill early (hides the load latency)
+    int cnt, acnt;                 // valid bits in buf / valid BYTES in ahead
+    bool bad;
+    __device__ __forceinline__ void fetch()
+    {
+        ahead = 0;
+        acnt = 0;
+        if (p + 8 <= end) { __builtin_memcpy(&ahead, p, 8); acnt = 8; p += 8; }   // unaligned 64-bit global load
+        else while (p < end) { ahead |= (uint64_t)(*p++) << (8 * acnt); ++acnt; }
+    }
+    __device__ __forceinline__ void init(const uint8_t* b, const uint8_t* e)
+    {
+        p = b; end = e; buf = 0; cnt = 0; bad = false;
+        fetch();
+    }
+    __device__ __forceinline__ void refill()              // afterwards cnt >= 32 unless the input is exhausted
+    {
+        if (cnt <= 32 && acnt > 0) {
+            const int take = acnt < 4 ? acnt : 4;         // whole bytes that fit: 32 + 32 <= 64
+            buf |= (ahead & (take == 4 ? 0xffffffffull : ((1ull << (8 * take)) - 1))) << cnt;
+            cnt += 8 * take;
+            ahead >>= 8 * take;
+            acnt -= take;
+            if (acnt == 0) fetch();
+        }
+    }
+    __device__ __forceinline__ uint32_t bits(int n)       // n <= 16
+    {
+        if (cnt < n) { refill(); if (cnt < n) { bad = true; return 0; } }
+        const uint32_t v = (uint32_t)(buf & ((1ull << n) - 1));
+        buf >>= n;
+        cnt -= n;
+        return v;
+    }
+};
+
+// Canonical Huffman tables of one lane in LDS: t[entry * INF_LANES + lane]
+struct HuffLds {
+    uint16_t* cnt;                 // [16] codes of each length
+    uint16_t* sym;                 // symbols ordered by code
+    __device__ __forceinline__ uint16_t& c(int i) const { return cnt[i * INF_LANES]; }
+    __device__ __forceinline__ uint16_t& s(int i) const { return sym[i * INF_LANES]; }
+};
+
+// Builds the tables from code lengths (puff.c construct()); returns false for an over-subscribed set.
+__device__ __forceinline__ bool huff_build(const HuffLds& h, const uint8_t* lengths, int n)
+{
+    for (int l = 0; l <= 15; ++l) h.c(l) = 0;
+    for (int i = 0; i < n; ++i) h.c(lengths[i]) = (uint16_t)(h.c(lengths[i]) + 1);
+    int left = 1;
+    for (int l = 1; l <= 15; ++l) {
+        left <<= 1;
+        left -= h.c(l);
+        if (left < 0) return false;
+    }
+    uint16_t offs[16];
+    offs[1] = 0;
+    for (int l = 1; l < 15; ++l) offs[l + 1] = (uint16_t)(offs[l] + h.c(l));
+    for (int i = 0; i < n; ++i)
+        if (lengths[i] != 0) h.s(offs[lengths[i]]++) = (uint16_t)i;
+    return true;
+}
+
+// The 15 per-length code counts of a table, held in registers while a block is decoded (the
+// bit-serial walk below then touches LDS once per symbol instead of once per code bit).
+struct HuffCnt {
+    uint32_t w[8];                 // counts of lengths 2k, 2k+1 in the halves of w[k]
+    __device__ __forceinline__ void load(const HuffLds& h)
+    {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) w[k] = (uint32_t)h.c(2 * k) | ((uint32_t)h.c(2 * k + 1) << 16);
+    }
+    __device__ __forceinline__ int at(int len) const { return (int)((w[len >> 1] >> ((len & 1) * 16)) & 0xffffu); }
+};
+
+// One symbol (puff.c decode(), bit serial over the code lengths).
+__device__ __forceinline__ int huff_decode(BitReader& br, const HuffLds& h, const HuffCnt& hc)
+{
+    if (br.cnt < 15) br.refill();
+    int code = 0, first = 0, index = 0;
+    uint64_t b = br.buf;
+#pragma unroll
+    for (int len = 1; len <= 15; ++len) {
+        code |= (int)(b & 1);
+        b >>= 1;
+        const int count = hc.at(len);
+        if (code - count < first) {
+            if (br.cnt < len) { br.bad = true; return -1; }
+            br.buf >>= len;
+            br.cnt -= len;
+            return h.s(index + (code - first));
+        }
+        index += count;
+        first += count;
+        first <<= 1;
+        code <<= 1;
+    }
+    br.bad = true;
+    return -1;
+}
+
+__global__ __launch_bounds__(INF_LANES) void gd_inflate_kernel(InflateJob job)
+{
+    __shared__ uint16_t s_tbl[INF_TBL * INF_LANES];
+    const uint32_t m = blockIdx.x * INF_LANES + threadIdx.x;
+    if (m >= job.n) return;
+    const int lane = threadIdx.x;
+    HuffLds hl, hd;
+    hl.cnt = s_tbl + lane;
+    hl.sym = s_tbl + 16 * INF_LANES + lane;
+    hd.cnt = s_tbl + (16 + INF_MAXL) * INF_LANES + lane;
+    hd.sym = s_tbl + (16 + INF_MAXL + 16) * INF_LANES + lane;
+
+    BitReader br;
+    br.init(job.comp + job.in_off[m], job.comp + job.in_off[m] + job.in_len[m]);
+    uint8_t* const out = job.out + job.out_off[m];
+    const uint32_t olen = job.out_len[m];
+    uint32_t o = 0;
+    uint32_t err = 0;
+
+    static const uint16_t lbase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+    static const uint8_t lext[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+    static const uint16_t dbase[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+    static const uint8_t dext[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+    static const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+
+    bool last = false;
+    while (!last && err == 0) {
+        last = br.bits(1) != 0;
+        const uint32_t type = br.bits(2);
+        if (br.bad) { err = 1; break; }
+        if (type == 0) {                                   // stored
+            br.buf >>= (br.cnt & 7);                       // to the byte boundary
+            br.cnt &= ~7;
+            const uint32_t len = br.bits(16), nlen = br.bits(16);
+            if (br.bad || (len ^ 0xffffu) != nlen) { err = 2; break; }
+            if (o + len > olen) { err = 3; break; }
+            for (uint32_t k = 0; k < len; ++k) {
+                const uint32_t v = br.bits(8);
+                out[o++] = (uint8_t)v;
+            }
+            if (br.bad) { err = 1; break; }
+            continue;
+        }
+        if (type == 3) { err = 4; break; }
+        uint8_t lengths[INF_MAXL + INF_MAXD + 2];
+        if (type == 1) {                                   // fixed codes
+            int s = 0;
+            for (; s < 144; ++s) lengths[s] = 8;
+            for (; s < 256; ++s) lengths[s] = 9;
+            for (; s < 280; ++s) lengths[s] = 7;
+            for (; s < 288; ++s) lengths[s] = 8;
+            huff_build(hl, lengths, 288);
+            for (s = 0; s < 30; ++s) lengths[s] = 5;
+            huff_build(hd, lengths, 30);
+        } else {                                           // dynamic codes
+            const int nlen = (int)br.bits(5) + 257, ndist = (int)br.bits(5) + 1, ncode = (int)br.bits(4) + 4;
+            if (br.bad || nlen > INF_MAXL || ndist > INF_MAXD) { err = 5; break; }
+            int idx = 0;
+            for (; idx < ncode; ++idx) lengths[order[idx]] = (uint8_t)br.bits(3);
+            for (; idx < 19; ++idx) lengths[order[idx]] = 0;
+            if (!huff_build(hl, lengths, 19)) { err = 6; break; }     // the code-length code borrows the lit/len table
+            HuffCnt cc;
+            cc.load(hl);
+            idx = 0;
+            while (idx < nlen + ndist) {
+                int sym = huff_decode(br, hl, cc);
+                if (sym < 0) { err = 7; break; }
+                if (sym < 16) { lengths[idx++] = (uint8_t)sym; continue; }
+                int prev = 0, rep;
+                if (sym == 16) {
+                    if (idx == 0) { err = 8; break; }
+                    prev = lengths[idx - 1];
+                    rep = 3 + (int)br.bits(2);
+                } else if (sym == 17) rep = 3 + (int)br.bits(3);
+                else rep = 11 + (int)br.bits(7);
+                if (idx + rep > nlen + ndist) { err = 9; break; }
+                while (rep--) lengths[idx++] = (uint8_t)prev;
+            }
+            if (err) break;
+            if (lengths[256] == 0) { err = 10; break; }
+            uint8_t dl[INF_MAXD];
+            for (int k = 0; k < ndist; ++k) dl[k] = lengths[nlen + k];
+            if (!huff_build(hl, lengths, nlen)) { err = 11; break; }
+            if (!huff_build(hd, dl, ndist)) { err = 12; break; }
+        }
+        // ---- the block's symbols ---------------------------------------------
+        HuffCnt cl, cd;
+        cl.load(hl);
+        cd.load(hd);
+        for (;;) {
+            const int sym = huff_decode(br, hl, cl);
+            if (sym < 0) { err = 13; break; }
+            if (sym < 256) {
+                if (o >= olen) { err = 3; break; }
+                out[o++] = (uint8_t)sym;
+            } else if (sym == 256) {
+                break;
+            } else {
+                const int ls = sym - 257;
+                if (ls >= 29) { err = 14; break; }
+                const uint32_t len = lbase[ls] + br.bits(lext[ls]);
+                const int ds = huff_decode(br, hd, cd);
+                if (ds < 0 || ds >= 30) { err = 15; break; }
+                const uint32_t dist = dbase[ds] + br.bits(dext[ds]);
+                if (br.bad) { err = 1; break; }
+                if (dist > o || o + len > olen) { err = 16; break; }
+                uint32_t k = 0;
+                if (dist >= 4)                             // source and destination words do not overlap
+                    for (; k + 4 <= len; k += 4, o += 4) {
+                        uint32_t w;
+                        __builtin_memcpy(&w, out + o - dist, 4);
+                        __builtin_memcpy(out + o, &w, 4);
+                    }
+                for (; k < len; ++k, ++o) out[o] = out[o - dist];
+            }
+        }
+    }
+    if (err == 0 && (o != olen || br.bad)) err = 17;
+    job.status[m] = err;
+}
+
+}  // namespace gd

@@ -290,6 +290,8 @@ __device__ __forceinline__ int wave_min(int v)
 #include "gd_depthwed.hpp"
 #include "gd_seqstats.hpp"
 #include "gd_multidepth.hpp"
+#include "gd_inflate.hpp"
+#include "gd_bamdecode.hpp"
 
 namespace gd {
 

@@ -14,7 +14,7 @@ from . import _lib
 from ._lib import GdBatch, GdParams, GdRun, GdStats
 
 CLASS_NAMES = ("NO_COVERAGE", "LOW_COVERAGE", "CALLABLE", "EXCESSIVE_COVERAGE")
-K_PREP, K_TILE, K_RUNS, K_EXPAND, K_SCAN, K_CKPT, K_SEQSTATS, K_MDFLAGS = 0, 1, 2, 3, 4, 5, 6, 7
+K_PREP, K_TILE, K_RUNS, K_EXPAND, K_SCAN, K_CKPT, K_SEQSTATS, K_MDFLAGS, K_INFLATE = 0, 1, 2, 3, 4, 5, 6, 7, 8
 PATH_AUTO, PATH_TILE, PATH_SCATTER, PATH_CHUNK = 0, 1, 2, 3
 
 
@@ -258,6 +258,49 @@ class DepthEngine:
         out = np.zeros((s.size, n_samples), np.float64)
         self._chk(self._lib.gd_md_sums(self._ctx, s.size, s.ctypes.data, e.ctypes.data, out.ctypes.data))
         return out
+
+    def inflate_bgzf(self, data: bytes):
+        """Inflate every member of a BGZF byte string on the device; returns (bytes, status[n])."""
+        raw = np.frombuffer(data, np.uint8)
+        offs, lens, isz = [], [], []
+        p, n = 0, raw.size
+        while p + 18 <= n:
+            assert raw[p] == 0x1f and raw[p + 1] == 0x8b and raw[p + 3] & 4, "not a BGZF member at %d" % p
+            xlen = int(raw[p + 10]) | int(raw[p + 11]) << 8
+            q, bsize = p + 12, None
+            while q < p + 12 + xlen:
+                slen = int(raw[q + 2]) | int(raw[q + 3]) << 8
+                if raw[q] == 66 and raw[q + 1] == 67 and slen == 2:
+                    bsize = int(raw[q + 4]) | int(raw[q + 5]) << 8
+                q += 4 + slen
+            assert bsize is not None
+            offs.append(p + 12 + xlen)
+            lens.append(bsize + 1 - 12 - xlen - 8)
+            isz.append(int.from_bytes(raw[p + bsize - 3:p + bsize + 1].tobytes(), "little"))
+            p += bsize + 1
+        m = len(offs)
+        in_off = np.asarray(offs, np.uint64)
+        in_len = np.asarray(lens, np.uint32)
+        out_len = np.asarray(isz, np.uint32)
+        out_off = np.zeros(m, np.uint64)
+        if m:
+            out_off[1:] = np.cumsum(out_len[:-1].astype(np.uint64))
+        total = int(out_len.astype(np.uint64).sum())
+        out = np.empty(max(total, 1), np.uint8)
+        status = np.zeros(max(m, 1), np.uint32)
+        self._chk(self._lib.gd_inflate_bgzf(self._ctx, raw.ctypes.data, raw.size, m, in_off.ctypes.data,
+                                            in_len.ctypes.data, out_off.ctypes.data, out_len.ctypes.data,
+                                            out.ctypes.data, total, status.ctypes.data))
+        return out[:total].tobytes(), status[:m]
+
+    def ingest_bgzf(self, tid: int, data: bytes, base_coffset: int, anchors) -> int:
+        """Inflate + decode one contig's records on the device (see gd_ingest_bgzf); returns the record count."""
+        raw = np.frombuffer(data, np.uint8)
+        a = np.ascontiguousarray(anchors, np.uint64)
+        n = C.c_uint64()
+        self._chk(self._lib.gd_ingest_bgzf(self._ctx, tid, raw.ctypes.data, raw.size, base_coffset,
+                                           a.ctypes.data, a.size, C.byref(n)))
+        return int(n.value)
 
     def device_windows(self):
         """(ptr_sums, ptr_mins, n_total) device views of the concatenated window arrays."""

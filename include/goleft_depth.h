@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define GD_ABI_VERSION 5
+#define GD_ABI_VERSION 6
 
 typedef enum {
     GD_OK = 0,
@@ -117,7 +117,8 @@ typedef struct {
 enum { GD_K_PREP = 0, GD_K_TILE = 1, GD_K_RUNS = 2, GD_K_EXPAND = 3, GD_K_SCAN = 4, GD_K_CKPT = 5,
        GD_K_SEQSTATS = 6,   /* the kernel of the last gd_seq_stats */
        GD_K_MDFLAGS = 7,    /* the kernel of the last gd_md_flags */
-       GD_K_COUNT = 8 };
+       GD_K_INFLATE = 8,    /* the kernel of the last gd_inflate_bgzf */
+       GD_K_COUNT = 9 };
 
 /* Device algorithm of gd_compute.  All are bit exact; they differ in cost.
  *   TILE     one workgroup per 4096-position tile re-walks the CIGARs of the
@@ -276,6 +277,30 @@ int gd_seq_stats(gd_ctx* ctx, size_t n_windows, const int64_t* start, const int6
 int gd_md_flags(gd_ctx* ctx, int n_samples, const int32_t* tids, int32_t min_cov, int32_t min_samples,
                 uint32_t* any_bits, uint32_t* suf_bits, size_t n_words);
 int gd_md_sums(gd_ctx* ctx, size_t n_blocks, const int64_t* start, const int64_t* end, double* sums);
+
+/* ---- BGZF inflate on device (the first stage of the BAM read of depth/depth.go:45) ----
+ * A BGZF file is a sequence of independent <= 64 KiB DEFLATE streams ("members").  The
+ * caller lists them (payload offset/length inside data, ISIZE, and where each member's
+ * bytes go in out); one GPU lane inflates one member.  status[m] is 0 or a decoder error
+ * code (corrupt stream, ISIZE mismatch); CRC32 is not verified on the device.  data, out
+ * and status are host buffers. */
+int gd_inflate_bgzf(gd_ctx* ctx, const uint8_t* data, size_t n_bytes, size_t n_members,
+                    const uint64_t* in_off, const uint32_t* in_len, const uint64_t* out_off,
+                    const uint32_t* out_len, uint8_t* out, size_t out_bytes, uint32_t* status);
+
+/* ---- the whole BAM read of one contig on the device -------------------------------------
+ * data: a byte range of the BAM file that begins at a BGZF member boundary (its file offset
+ * is base_coffset) and holds every record of contig tid.  anchors: virtual file offsets
+ * (coffset << 16 | uoffset, as stored in the .bai) of record starts inside the range,
+ * strictly ascending, anchors[0] = the contig's first record -- the .bai linear index
+ * provides one per 16 kb of reference (SAMv1 5.2).  The device inflates the members (one
+ * lane each), one lane per anchor walks the records up to the next anchor (a record of
+ * another reference ends the contig) and {pos, flag, mapq, CIGAR (CG:B,I resolved)} become
+ * the contig's record arrays in HBM, replacing what it held -- the state gd_push / gd_commit
+ * would have left, without any decode on the host.  Errors: GD_E_INVALID (corrupt member or
+ * record, anchor that is not a record start), GD_E_UNSORTED. */
+int gd_ingest_bgzf(gd_ctx* ctx, int32_t tid, const uint8_t* data, size_t n_bytes, uint64_t base_coffset,
+                   const uint64_t* anchors, size_t n_anchors, uint64_t* n_records);
 
 /* Device-side views of the results (for RCCL gathers and zero-copy
  * consumers).  Pointers stay valid until the next gd_compute/gd_reset. */

@@ -45,7 +45,7 @@ def bgzf_decompress(raw: bytes) -> bytes:
     return b"".join(out)
 
 
-def bgzf_compress(data: bytes, block: int = 0xff00, level: int = 6) -> bytes:
+def bgzf_compress(data: bytes, block: int = 0xff00, level: int = 6, sizes: list | None = None) -> bytes:
     def member(chunk: bytes) -> bytes:
         co = zlib.compressobj(level, zlib.DEFLATED, -15)
         c = co.compress(chunk) + co.flush()
@@ -54,6 +54,8 @@ def bgzf_compress(data: bytes, block: int = 0xff00, level: int = 6) -> bytes:
                 + struct.pack("<H", bsize) + c
                 + struct.pack("<II", zlib.crc32(chunk) & 0xFFFFFFFF, len(chunk)))
     out = [member(data[i:i + block]) for i in range(0, len(data), block)]
+    if sizes is not None:
+        sizes.extend(len(m) for m in out)                # compressed size of every data member
     out.append(member(b""))  # EOF marker
     return b"".join(out)
 
@@ -149,7 +151,7 @@ def _reg2bin(beg: int, end: int) -> int:
 
 
 def write_bam(path: str, contigs, reads_by_tid, header_text: str | None = None,
-              long_cigar_as_cg: bool = True, unplaced: int = 0, level: int = 1):
+              long_cigar_as_cg: bool = True, unplaced: int = 0, level: int = 1, index: bool = False):
     """Write a coordinate-sorted BAM holding the given record streams.
 
     Sequence/quality are written as l_seq=0 ('*'), which is legal BAM and is
@@ -164,6 +166,8 @@ def write_bam(path: str, contigs, reads_by_tid, header_text: str | None = None,
         nb = name.encode() + b"\x00"
         out.append(struct.pack("<i", len(nb)) + nb + struct.pack("<i", length))
     rid = 0
+    cur = sum(len(x) for x in out)                       # uncompressed offset of the next record
+    recs = []                                            # (tid, pos, end, offset, offset after) for the index
     for tid in sorted(reads_by_tid):
         r = reads_by_tid[tid]
         for i in range(r.n):
@@ -182,10 +186,67 @@ def write_bam(path: str, contigs, reads_by_tid, header_text: str | None = None,
                                int(r.flag[i]), 0, -1, -1, 0)
             body += name + stored.astype("<u4").tobytes() + tags
             out.append(struct.pack("<i", len(body)) + body)
+            recs.append((tid, pos, pos + max(ref_len, 1), cur, cur + 4 + len(body)))
+            cur += 4 + len(body)
     for _ in range(unplaced):
         name = ("u%d" % rid).encode() + b"\x00"
         rid += 1
         body = struct.pack("<iiBBHHHiiii", -1, -1, len(name), 0, 4680, 0, 4, 0, -1, -1, 0) + name
         out.append(struct.pack("<i", len(body)) + body)
+    sizes: list = []
     with open(path, "wb") as fh:
-        fh.write(bgzf_compress(b"".join(out), level=level))
+        fh.write(bgzf_compress(b"".join(out), level=level, sizes=sizes))
+    if index:
+        write_bai(path + ".bai", len(contigs), recs, sizes)
+
+
+def write_bai(path: str, n_ref: int, recs, member_sizes, block: int = 0xff00):
+    """A .bai (SAMv1 5.2) for records (tid, pos, end, uncompressed offset, offset after) of a
+    file whose data members all hold `block` uncompressed bytes: per reference the binning
+    index (one merged chunk per bin) and the 16 kb linear index (virtual offset of the first
+    record overlapping each window; empty leading windows 0, later ones inherit)."""
+    coff = np.concatenate([[0], np.cumsum(member_sizes)]).astype(np.int64)
+    voff = lambda o: (int(coff[o // block]) << 16) | (o % block)
+    bins = [dict() for _ in range(n_ref)]
+    lin = [dict() for _ in range(n_ref)]
+    for tid, pos, end, o0, o1 in recs:
+        b = _reg2bin(pos, end)
+        v0, v1 = voff(o0), voff(o1)
+        lo, hi = bins[tid].get(b, (v0, v1))
+        bins[tid][b] = (min(lo, v0), max(hi, v1))
+        for w in range(pos >> 14, ((end - 1) >> 14) + 1):
+            lin[tid].setdefault(w, v0)
+    out = [b"BAI\x01", struct.pack("<i", n_ref)]
+    for tid in range(n_ref):
+        out.append(struct.pack("<i", len(bins[tid])))
+        for b in sorted(bins[tid]):
+            out.append(struct.pack("<Ii", b, 1) + struct.pack("<QQ", *bins[tid][b]))
+        n_intv = max(lin[tid]) + 1 if lin[tid] else 0
+        out.append(struct.pack("<i", n_intv))
+        last = 0
+        for w in range(n_intv):
+            last = lin[tid].get(w, last)
+            out.append(struct.pack("<Q", last))
+    with open(path, "wb") as fh:
+        fh.write(b"".join(out))
+
+
+def read_bai_linear(path: str):
+    """{tid: sorted unique non-zero linear-index virtual offsets} of a .bai."""
+    d = open(path, "rb").read()
+    assert d[:4] == b"BAI\x01"
+    n_ref, = struct.unpack_from("<i", d, 4)
+    p = 8
+    res = {}
+    for tid in range(n_ref):
+        n_bin, = struct.unpack_from("<i", d, p)
+        p += 4
+        for _ in range(n_bin):
+            _b, n_chunk = struct.unpack_from("<Ii", d, p)
+            p += 8 + 16 * n_chunk
+        n_intv, = struct.unpack_from("<i", d, p)
+        p += 4
+        io = np.frombuffer(d, "<u8", n_intv, p)
+        p += 8 * n_intv
+        res[tid] = np.unique(io[io != 0])
+    return res

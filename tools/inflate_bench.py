@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Device BGZF inflate (gd_inflate_bgzf) against zlib on a synthetic BAM: correctness + kernel time."""
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from goleft_amd.engine import DepthEngine, K_INFLATE
+from oracle import bamio
+
+length = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
+path = "/tmp/gd_inflate_test.bam"
+subprocess.check_call([os.path.join(ROOT, "goleft_amd", "synth-bam"), path, "chr20", str(length), "30", "20"],
+                      stdout=subprocess.DEVNULL)
+data = open(path, "rb").read()
+t0 = time.perf_counter()
+want = bamio.bgzf_decompress(data)
+t_cpu = time.perf_counter() - t0
+with DepthEngine(0) as eng:
+    eng.set_profiling(True)
+    eng.inflate_bgzf(data[:1 << 20] if False else data)          # warm-up (allocations, code load)
+    t0 = time.perf_counter()
+    got, status = eng.inflate_bgzf(data)
+    t_all = time.perf_counter() - t0
+    ms = eng.kernel_ms(K_INFLATE)
+print("members %d, %.1f MB -> %.1f MB; status ok %s; equal %s" % (len(status), len(data) / 1e6, len(want) / 1e6,
+                                                                  bool((status == 0).all()), got == want))
+print("kernel %.2f ms = %.2f GB/s of output (%.2f GB/s of BGZF); python zlib 1 thread %.2f s; call incl. H2D/D2H %.3f s"
+      % (ms, len(want) / ms / 1e6, len(data) / ms / 1e6, t_cpu, t_all))
+os.unlink(path)
