@@ -73,6 +73,8 @@ SYMBOLS = {
     "gd_md_sums": (C.c_int, [_P, C.c_size_t, _P, _P, _P]),
     "gd_inflate_bgzf": (C.c_int, [_P, _P, C.c_size_t, C.c_size_t, _P, _P, _P, _P, _P, C.c_size_t, _P]),
     "gd_ingest_bgzf": (C.c_int, [_P, C.c_int32, _P, C.c_size_t, C.c_uint64, _P, C.c_size_t, C.POINTER(C.c_uint64)]),
+    "gd_host_alloc": (C.c_int, [_P, C.c_size_t, C.POINTER(_P)]),
+    "gd_host_free": (C.c_int, [_P, _P]),
     "gd_device_perbase": (C.c_int, [_P, C.c_int32, C.POINTER(_P), C.POINTER(C.c_int64)]),
     "gd_device_windows": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(C.c_size_t)]),
     "gd_window_offset": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),

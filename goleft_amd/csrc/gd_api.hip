@@ -9,6 +9,7 @@
 #include "gd_kernels.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -1379,6 +1380,24 @@ int gd_inflate_bgzf(gd_ctx* c, const uint8_t* data, size_t n_bytes, size_t n_mem
     return GD_OK;
 }
 
+int gd_host_alloc(gd_ctx* c, size_t bytes, void** out)
+{
+    if (!c || !out) return GD_E_INVALID;
+    if (int r = set_device(c)) return r;
+    *out = nullptr;
+    if (hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess)
+        return fail(c, GD_E_NOMEM, "cannot page-lock %zu bytes", bytes);
+    return GD_OK;
+}
+
+int gd_host_free(gd_ctx* c, void* p)
+{
+    if (!c) return GD_E_INVALID;
+    if (int r = set_device(c)) return r;
+    if (p) HIPCHK(c, hipHostFree(p));
+    return GD_OK;
+}
+
 int gd_ingest_bgzf(gd_ctx* c, int32_t tid, const uint8_t* data, size_t n_bytes, uint64_t base_coffset,
                    const uint64_t* anchors, size_t n_anchors, uint64_t* n_records)
 {
@@ -1386,6 +1405,16 @@ int gd_ingest_bgzf(gd_ctx* c, int32_t tid, const uint8_t* data, size_t n_bytes, 
     if (int r = set_device(c)) return r;
     if (tid < 0 || (size_t)tid >= c->contigs.size()) return fail(c, GD_E_RANGE, "tid %d out of range", tid);
     if (n_anchors > 0xfffffff0ull) return fail(c, GD_E_RANGE, "too many anchors");
+    const bool tm = getenv("GOLEFT_GD_TIMING") != nullptr;     // phase wall times on stderr (measurement only)
+    auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_prev = now();
+    auto lap = [&](const char* what) {
+        if (!tm) return;
+        (void)hipStreamSynchronize(c->stream);
+        const double t = now();
+        fprintf(stderr, "gd_ingest_bgzf: %-22s %.4f s\n", what, t - t_prev);
+        t_prev = t;
+    };
     // ---- the BGZF members of the range (SAMv1 4.1: gzip header with a BC extra subfield) -------
     std::vector<uint64_t> m_coff, in_off, out_off;
     std::vector<uint32_t> in_len, out_len;
@@ -1429,6 +1458,7 @@ int gd_ingest_bgzf(gd_ctx* c, int32_t tid, const uint8_t* data, size_t n_bytes, 
         if (i) seg_end[i - 1] = seg_beg[i];
     }
     seg_end[n_anchors - 1] = total;
+    lap("member + anchor tables");
 
     // ---- device: inflate ------------------------------------------------------------------------
     DevBuf d_in, d_out, d_tab, d_seg;
@@ -1439,6 +1469,7 @@ int gd_ingest_bgzf(gd_ctx* c, int32_t tid, const uint8_t* data, size_t n_bytes, 
         d_seg.alloc(seg_bytes) != hipSuccess)
         return fail(c, GD_E_NOMEM, "device allocation for the BAM decode failed (%zu + %llu bytes)", n_bytes,
                     (unsigned long long)total);
+    lap("device allocations");
     uint64_t* t_in_off = d_tab.as<uint64_t>();
     uint64_t* t_out_off = t_in_off + nm;
     uint32_t* t_in_len = reinterpret_cast<uint32_t*>(t_out_off + nm);
@@ -1449,6 +1480,7 @@ int gd_ingest_bgzf(gd_ctx* c, int32_t tid, const uint8_t* data, size_t n_bytes, 
     HIPCHK(c, hipMemcpyAsync(t_out_off, out_off.data(), nm * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(t_in_len, in_len.data(), nm * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(t_out_len, out_len.data(), nm * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    lap("H2D compressed bytes");
     gd::InflateJob ij{};
     ij.comp = d_in.as<uint8_t>(); ij.in_off = t_in_off; ij.in_len = t_in_len; ij.out_off = t_out_off;
     ij.out_len = t_out_len; ij.out = d_out.as<uint8_t>(); ij.status = t_status; ij.n = (uint32_t)nm;
@@ -1456,6 +1488,7 @@ int gd_ingest_bgzf(gd_ctx* c, int32_t tid, const uint8_t* data, size_t n_bytes, 
     hipLaunchKernelGGL(gd::gd_inflate_kernel, dim3((unsigned)((nm + gd::INF_LANES - 1) / gd::INF_LANES)),
                        dim3(gd::INF_LANES), 0, c->stream, ij);
     if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+    lap("inflate kernel");
     std::vector<uint32_t> status(nm);
     HIPCHK(c, hipMemcpyAsync(status.data(), t_status, nm * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
 
@@ -1486,6 +1519,7 @@ int gd_ingest_bgzf(gd_ctx* c, int32_t tid, const uint8_t* data, size_t n_bytes, 
     HIPCHK(c, hipMemcpyAsync(lastp.data(), s_last, n_anchors * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(flags.data(), s_flags, n_anchors * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    lap("count walk + D2H");
     if (c->profiling) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) c->kernel_ms[GD_K_INFLATE] = ms;
@@ -1537,6 +1571,7 @@ int gd_ingest_bgzf(gd_ctx* c, int32_t tid, const uint8_t* data, size_t n_bytes, 
         HIPCHK(c, hipMemcpyAsync(h.off + N, &m32, sizeof m32, hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
+    lap("alloc + extract walk");
     h.n_reads = (size_t)N;
     h.n_ops = (size_t)M;
     h.last_pos = prev_last;

@@ -223,6 +223,54 @@ bool BamReader::open(const std::string& path, int threads, std::string* err)
     return true;
 }
 
+namespace {
+bool load_bai(const std::string& bam_path, std::vector<uint8_t>* d)
+{
+    FILE* fi = fopen((bam_path + ".bai").c_str(), "rb");
+    if (!fi) {
+        std::string alt = bam_path;
+        if (alt.size() > 4 && alt.substr(alt.size() - 4) == ".bam") alt = alt.substr(0, alt.size() - 4) + ".bai";
+        fi = fopen(alt.c_str(), "rb");
+        if (!fi) return false;
+    }
+    uint8_t tmp[65536];
+    size_t g;
+    while ((g = fread(tmp, 1, sizeof tmp, fi)) > 0) d->insert(d->end(), tmp, tmp + g);
+    fclose(fi);
+    return d->size() >= 8 && memcmp(d->data(), "BAI\1", 4) == 0;
+}
+}  // namespace
+
+bool BamReader::linear_index(const std::string& bam_path, std::vector<std::vector<uint64_t>>* per_ref, std::string* err)
+{
+    std::vector<uint8_t> d;
+    if (!load_bai(bam_path, &d)) return false;
+    const int32_t n_ref = (int32_t)rd32(d.data() + 4);
+    per_ref->assign((size_t)std::max(n_ref, 0), std::vector<uint64_t>());
+    size_t p = 8;
+    for (int32_t r = 0; r < n_ref; ++r) {
+        if (p + 4 > d.size()) { if (err) *err = "truncated BAI"; return false; }
+        const int32_t n_bin = (int32_t)rd32(d.data() + p);
+        p += 4;
+        for (int32_t b = 0; b < n_bin; ++b) {
+            if (p + 8 > d.size()) { if (err) *err = "truncated BAI"; return false; }
+            const int32_t n_chunk = (int32_t)rd32(d.data() + p + 4);
+            p += 8 + 16 * (size_t)n_chunk;
+        }
+        if (p + 4 > d.size()) { if (err) *err = "truncated BAI"; return false; }
+        const int32_t n_intv = (int32_t)rd32(d.data() + p);
+        p += 4;
+        if (p + 8 * (size_t)n_intv > d.size()) { if (err) *err = "truncated BAI"; return false; }
+        std::vector<uint64_t>& v = (*per_ref)[(size_t)r];
+        for (int32_t i = 0; i < n_intv; ++i) {
+            const uint64_t x = rd64(d.data() + p + 8 * (size_t)i);
+            if (x != 0 && (v.empty() || x > v.back())) v.push_back(x);   // the index is non-decreasing
+        }
+        p += 8 * (size_t)n_intv;
+    }
+    return true;
+}
+
 bool BamReader::seek_contig(int32_t tid, std::string* err)
 {
     FILE* fi = fopen((path_ + ".bai").c_str(), "rb");

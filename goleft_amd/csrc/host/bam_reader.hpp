@@ -54,6 +54,12 @@ public:
     // index or the contig has no records.
     bool seek_contig(int32_t tid, std::string* err);
 
+    // The .bai linear index (SAMv1 5.2): for every reference the sorted, distinct, non-zero
+    // virtual offsets of record starts (one per 16 kb window that holds reads).  false when
+    // there is no usable index next to the file.  Static: needs no open reader.
+    static bool linear_index(const std::string& bam_path, std::vector<std::vector<uint64_t>>* per_ref,
+                             std::string* err);
+
     // Fills `out` with up to max_reads records, all of one contig (a block ends
     // at a contig change).  Records with refID < 0 are skipped and counted.
     // Returns 1 on success, 0 at end of file, -1 on error.

@@ -402,9 +402,53 @@ int run(const DArgs& args)
         return std::chrono::duration<double>(b - a).count();
     };
     const auto t_begin = now();
+    uint64_t n_gpu_records = 0;
     auto t_ingested = t_begin, t_computed = t_begin;
-    // ---- stream decoded records into HBM (replaces the samtools children) -------
+    // ---- records into HBM (replaces the samtools children) ---------------------------
+    // With a .bai next to the BAM (goleft depth needs one anyway: `samtools depth -r`), the whole
+    // read happens on the device: the contig's byte range goes to gd_ingest_bgzf, which inflates
+    // the BGZF members and decodes the records there (GOLEFT_GPU_DECODE=0 keeps the host decoder).
     if (!wanted.empty()) {
+        std::vector<std::vector<uint64_t>> lin;
+        const char* gd_env = getenv("GOLEFT_GPU_DECODE");
+        bool gpu_decode = !(gd_env && gd_env[0] == '0') && gdh::BamReader::linear_index(args.bam, &lin, &err) &&
+                          lin.size() == contigs.size();
+        if (gpu_decode) {
+            FILE* fb = fopen(args.bam.c_str(), "rb");
+            if (!fb) gpu_decode = false;
+            uint8_t* bytes = nullptr;                                 // page-locked staging, grown as needed
+            size_t bytes_cap = 0;
+            for (size_t w = 0; gpu_decode && w < wanted.size(); ++w) {
+                const int32_t t = wanted[w];
+                if (lin[(size_t)t].empty()) continue;                 // no records on this contig
+                const uint64_t beg = lin[(size_t)t].front() >> 16;
+                // up to the member in which the next reference with records starts (inclusive), or EOF
+                uint64_t end = ~0ull;
+                for (size_t u = (size_t)t + 1; u < lin.size(); ++u)
+                    if (!lin[u].empty()) { end = (lin[u].front() >> 16) + 65536 + 26; break; }
+                if (fseeko(fb, 0, SEEK_END) != 0) { gpu_decode = false; break; }
+                const uint64_t fsize = (uint64_t)ftello(fb);
+                if (end > fsize) end = fsize;
+                if (beg >= end || fseeko(fb, (off_t)beg, SEEK_SET) != 0) { gpu_decode = false; break; }
+                const size_t nb = (size_t)(end - beg);
+                if (nb > bytes_cap) {
+                    if (bytes) GDCHK(gd_host_free(ctx, bytes));
+                    bytes = nullptr;
+                    void* pp = nullptr;
+                    GDCHK(gd_host_alloc(ctx, nb + nb / 4, &pp));
+                    bytes = static_cast<uint8_t*>(pp);
+                    bytes_cap = nb + nb / 4;
+                }
+                if (fread(bytes, 1, nb, fb) != nb) { gpu_decode = false; break; }
+                uint64_t n = 0;
+                GDCHK(gd_ingest_bgzf(ctx, t, bytes, nb, beg, lin[(size_t)t].data(), lin[(size_t)t].size(), &n));
+                n_gpu_records += n;
+            }
+            if (bytes) GDCHK(gd_host_free(ctx, bytes));
+            if (fb) fclose(fb);
+            if (!gpu_decode) GDCHK(gd_reset(ctx));                    // fall back to the host decoder below
+        }
+        if (!gpu_decode) {
         if (wanted.size() == 1) bam.seek_contig(wanted[0], &err);   // .bai shortcut for --chrom
         std::vector<char> want(contigs.size(), 0);
         for (int32_t t : wanted) want[(size_t)t] = 1;
@@ -429,6 +473,7 @@ int run(const DArgs& args)
             memcpy(b.cigar_off, blk.cigar_off.data(), (blk.size() + 1) * sizeof(uint32_t));
             if (!blk.cigar.empty()) memcpy(b.cigar, blk.cigar.data(), blk.cigar.size() * sizeof(uint32_t));
             GDCHK(gd_commit(ctx, &b, blk.tid, blk.size(), blk.cigar.size()));
+        }
         }
         t_ingested = now();
         GDCHK(gd_compute(ctx));
@@ -537,9 +582,9 @@ int run(const DArgs& args)
     if (fclose(fhd) != 0) io_ok = false;
     if (!io_ok) { fprintf(stderr, "goleft depth: write error\n"); return 1; }
     if (timing)
-        fprintf(stderr, "{\"decode_and_ingest_s\": %.4f, \"compute_s\": %.4f, \"rows_s\": %.4f, \"records\": %llu}\n",
+        fprintf(stderr, "{\"decode_and_ingest_s\": %.4f, \"compute_s\": %.4f, \"rows_s\": %.4f, \"records\": %llu, \"decoder\": \"%s\"}\n",
                 secs(t_begin, t_ingested), secs(t_ingested, t_computed), secs(t_computed, now()),
-                (unsigned long long)bam.n_records());
+                (unsigned long long)(n_gpu_records ? n_gpu_records : bam.n_records()), n_gpu_records ? "device" : "host");
     return exit_code;
 }
 

@@ -301,6 +301,11 @@ int gd_inflate_bgzf(gd_ctx* ctx, const uint8_t* data, size_t n_bytes, size_t n_m
  * record, anchor that is not a record start), GD_E_UNSORTED. */
 int gd_ingest_bgzf(gd_ctx* ctx, int32_t tid, const uint8_t* data, size_t n_bytes, uint64_t base_coffset,
                    const uint64_t* anchors, size_t n_anchors, uint64_t* n_records);
+/* Page-locked host memory for the byte range handed to gd_ingest_bgzf (read the file
+ * straight into it: the H2D copy then runs at PCIe speed instead of through a bounce
+ * buffer).  Plain pageable memory works too, only slower. */
+int gd_host_alloc(gd_ctx* ctx, size_t bytes, void** out);
+int gd_host_free(gd_ctx* ctx, void* p);
 
 /* Device-side views of the results (for RCCL gathers and zero-copy
  * consumers).  Pointers stay valid until the next gd_compute/gd_reset. */

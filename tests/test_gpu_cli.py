@@ -28,6 +28,19 @@ def workdir(tmp_path_factory):
     return d
 
 
+@pytest.fixture(scope="module")
+def indexed(workdir):
+    """The same BAMs with a .bai next to them: `goleft-depth` then reads them entirely on the
+    device (gd_ingest_bgzf) instead of through the host decoder."""
+    d = workdir / "idx"
+    d.mkdir(exist_ok=True)
+    for name in ("t", "hla", "t_empty"):
+        contigs, reads, _ = H.load_golden_bam(name)
+        bamio.write_bam(str(d / (name + ".bam")), contigs, reads, unplaced=3, index=True)
+        (d / (name + ".fa.fai")).write_text("".join("%s\t%d\t6\t60\t61\n" % c for c in contigs))
+    return d
+
+
 def run_depth(args):
     from goleft_amd import depth
     return depth.Main([str(a) for a in args])
@@ -143,3 +156,53 @@ def test_synthetic_multi_tile_contig(workdir):
     assert read(prefix, "depth") == hd
     assert read(prefix, "callable") == ca
     assert any(l.split("\t")[2] == "10000000" for l in ca.splitlines())
+
+
+@pytest.mark.parametrize("W", [100, 1000, 13])
+def test_device_decoder_wgs_matches_oracle(workdir, indexed, W, capfd):
+    beds = H.golden_beds()["t"]["wg_w%d" % W]
+    prefix = indexed / ("wg%d" % W)
+    os.environ["GOLEFT_DEPTH_TIMING"] = "1"
+    try:
+        rc = run_depth(["-Q", 1, "--ordered", "--windowsize", W, "--prefix", prefix,
+                        "--reference", indexed / "t.fa", indexed / "t.bam"])
+    finally:
+        del os.environ["GOLEFT_DEPTH_TIMING"]
+    assert rc == 0
+    assert '"decoder": "device"' in capfd.readouterr().err       # the GPU path really ran
+    assert read(prefix, "depth") == beds["depth"]
+    assert read(prefix, "callable") == beds["callable"]
+
+
+def test_device_decoder_bed_chrom_hla_empty(workdir, indexed):
+    beds = H.golden_beds()
+    prefix = indexed / "bed"
+    assert run_depth(["--bed", workdir / "windows.bed", "-Q", 1, "--windowsize", 55, "--prefix", prefix,
+                      indexed / "t.bam"]) == 0
+    assert read(prefix, "depth") == beds["t"]["bed_w55"]["depth"]
+    assert read(prefix, "callable") == beds["t"]["bed_w55"]["callable"]
+    prefix = indexed / "c22"
+    assert run_depth(["-c", "chr22", "-w", 1000, "-r", indexed / "t.fa", "--prefix", prefix, indexed / "t.bam"]) == 0
+    want = "".join(l + "\n" for l in beds["t"]["wg_w1000"]["depth"].splitlines() if l.startswith("chr22\t"))
+    assert read(prefix, "depth", "chr22") == want
+    prefix = indexed / "hla"
+    assert run_depth(["-r", indexed / "hla.fa", "--prefix", prefix, indexed / "hla.bam"]) == 0
+    assert read(prefix, "depth") == beds["hla"]["wg_w250"]["depth"]
+    assert read(prefix, "callable") == beds["hla"]["wg_w250"]["callable"]
+    prefix = indexed / "empty"
+    assert run_depth(["--windowsize", 13, "--reference", indexed / "t_empty.fa", "--prefix", prefix,
+                      indexed / "t_empty.bam"]) == 0
+    assert read(prefix, "depth") == beds["t-empty"]["wg_w13"]["depth"]
+
+
+def test_host_decoder_still_selectable(workdir, indexed, capfd):
+    beds = H.golden_beds()["t"]["wg_w1000"]
+    prefix = indexed / "hostdec"
+    os.environ["GOLEFT_DEPTH_TIMING"] = "1"
+    os.environ["GOLEFT_GPU_DECODE"] = "0"
+    try:
+        assert run_depth(["-Q", 1, "-w", 1000, "--prefix", prefix, "-r", indexed / "t.fa", indexed / "t.bam"]) == 0
+    finally:
+        del os.environ["GOLEFT_DEPTH_TIMING"], os.environ["GOLEFT_GPU_DECODE"]
+    assert '"decoder": "host"' in capfd.readouterr().err
+    assert read(prefix, "depth") == beds["depth"]

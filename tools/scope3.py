@@ -29,25 +29,32 @@ def main():
     info = json.loads(subprocess.check_output([os.path.join(ROOT, "goleft_amd", "synth-bam"), bam, "chr20",
                                                str(args.length), str(args.coverage), "20"]).decode())
     t_write = time.perf_counter() - t0
-    best = None
-    for rep in range(3):                                   # the file is in the page cache after the write
-        t0 = time.perf_counter()
-        p = subprocess.run([os.path.join(ROOT, "goleft_amd", "goleft-depth"), "depth", "-w", str(args.window),
-                            "-p", str(args.threads), "-r", os.path.join(d, "synth.fa"), "--prefix",
-                            os.path.join(d, "out"), bam],
-                           env=dict(os.environ, GOLEFT_DEPTH_TIMING="1"), stderr=subprocess.PIPE)
-        dt = time.perf_counter() - t0
-        assert p.returncode == 0, p.stderr.decode()
-        phases = json.loads(p.stderr.decode().strip().splitlines()[-1])
-        if best is None or dt < best[0]:
-            best = (dt, phases)
-    dt, phases = best
-    rows = sum(1 for _ in open(os.path.join(d, "out.depth.bed")))
     out = {"scope": "BAM file -> depth.bed + callable.bed (goleft-depth CLI, process start to exit)",
            "ref_bases": args.length, "coverage": args.coverage, "reads": info["reads"],
-           "bam_MB": info["bam_bytes"] / 1e6, "wall_s": dt, "ref_bases_per_s": args.length / dt,
-           "bam_MB_per_s": info["bam_bytes"] / 1e6 / dt, "phases": phases, "depth_rows": rows,
-           "host_cores": os.cpu_count(), "bam_write_s": t_write}
+           "bam_MB": info["bam_bytes"] / 1e6, "host_cores": os.cpu_count(), "bam_write_s": t_write}
+    beds = {}
+    for decoder, env in (("device", {}), ("host", {"GOLEFT_GPU_DECODE": "0"})):
+        best = None
+        for rep in range(3):                               # the file is in the page cache after the write
+            t0 = time.perf_counter()
+            p = subprocess.run([os.path.join(ROOT, "goleft_amd", "goleft-depth"), "depth", "-w", str(args.window),
+                                "-p", str(args.threads), "-r", os.path.join(d, "synth.fa"), "--prefix",
+                                os.path.join(d, "out_" + decoder), bam],
+                               env=dict(os.environ, GOLEFT_DEPTH_TIMING="1", **env), stderr=subprocess.PIPE)
+            dt = time.perf_counter() - t0
+            assert p.returncode == 0, p.stderr.decode()
+            phases = json.loads(p.stderr.decode().strip().splitlines()[-1])
+            assert phases["decoder"] == decoder, phases
+            if rep == 2 and os.environ.get("GOLEFT_GD_TIMING"):
+                sys.stderr.write(p.stderr.decode())
+            if best is None or dt < best[0]:
+                best = (dt, phases)
+        dt, phases = best
+        beds[decoder] = open(os.path.join(d, "out_%s.depth.bed" % decoder)).read()
+        out[decoder + "_decoder"] = {"wall_s": dt, "ref_bases_per_s": args.length / dt,
+                                     "bam_MB_per_s": info["bam_bytes"] / 1e6 / dt, "phases": phases}
+    out["outputs_identical"] = beds["device"] == beds["host"]
+    out["depth_rows"] = beds["device"].count("\n")
     print(json.dumps(out))
     for f in os.listdir(d):
         os.unlink(os.path.join(d, f))

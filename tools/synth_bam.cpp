@@ -7,7 +7,9 @@
 // 1 % one insertion; 5 % DUP, 0.3 % other filtered flags, 1 % MAPQ 0), coordinate sorted, WITH
 // SEQ and QUAL (random bases, run-structured qualities) so that the file has the size and the
 // inflate cost of a real one (~250 B per record before BGZF).  BGZF members are deflated in
-// parallel (zlib level 1).  Also writes OUT.bam.fai-style "<contig>\t<length>\t..." to OUT.fa.fai.
+// parallel (zlib level 1).  Also writes a "<contig>\t<length>\t..." line to OUT.fa.fai and
+// OUT.bam.bai (exact 16 kb linear index; the binning index is collapsed into bin 0, enough
+// for this repository's readers, not for region queries by other tools).
 #include <zlib.h>
 
 #include <cstdint>
@@ -91,6 +93,10 @@ int main(int argc, char** argv)
 
     const size_t BLK = 0xff00;
     uint64_t out_bytes = 0;
+    std::vector<uint32_t> csize;               // compressed size of every data member, in file order
+    std::vector<uint64_t> lin((size_t)(L >> 14) + 1, ~0ull);   // uncompressed offset of the first record per 16 kb window
+    uint64_t stream_off = 0;                   // uncompressed bytes written to `raw` so far (whole file)
+    uint64_t first_rec = ~0ull, after_last = 0;
     auto flush = [&](bool final) {
         const size_t nblk = raw.size() / BLK + ((final && raw.size() % BLK) ? 1 : 0);
         std::vector<std::vector<uint8_t>> comp(nblk);
@@ -103,9 +109,10 @@ int main(int argc, char** argv)
                 }
             });
         for (auto& th : pool) th.join();
-        for (auto& c : comp) { fwrite(c.data(), 1, c.size(), f); out_bytes += c.size(); }
+        for (auto& c : comp) { fwrite(c.data(), 1, c.size(), f); out_bytes += c.size(); csize.push_back((uint32_t)c.size()); }
         const size_t used = std::min(raw.size(), nblk * BLK);
         raw.erase(raw.begin(), raw.begin() + (long)used);
+        stream_off += used;
     };
 
     const int64_t span = L - RL > 0 ? L - RL : 1;
@@ -130,6 +137,13 @@ int main(int argc, char** argv)
         char name[32];
         const int ln = snprintf(name, sizeof name, "synth.%llu", (unsigned long long)i) + 1;
         const uint32_t block = 32 + (uint32_t)ln + 4u * (uint32_t)nc + (RL + 1) / 2 + RL;
+        {
+            const uint64_t off = stream_off + raw.size();   // raw holds the not yet flushed tail of the stream
+            if (first_rec == ~0ull) first_rec = off;
+            after_last = off + 4 + block;
+            for (int64_t w = pos >> 14; w <= (pos + ref - 1) >> 14 && (size_t)w < lin.size(); ++w)
+                if (lin[(size_t)w] == ~0ull) lin[(size_t)w] = off;
+        }
         put32(raw, block);
         put32(raw, 0);                                   // refID
         put32(raw, (uint32_t)pos);
@@ -160,6 +174,30 @@ int main(int argc, char** argv)
     static const uint8_t eof[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     fwrite(eof, 1, 28, f);
     fclose(f);
+    {
+        std::vector<uint64_t> coff(csize.size() + 1, 0);
+        for (size_t k = 0; k < csize.size(); ++k) coff[k + 1] = coff[k] + csize[k];
+        auto voff = [&](uint64_t o) { return (coff[o / BLK] << 16) | (o % BLK); };
+        std::vector<uint8_t> b;
+        b.insert(b.end(), {'B', 'A', 'I', 1});
+        put32(b, 1);
+        if (first_rec != ~0ull) {
+            put32(b, 1); put32(b, 0); put32(b, 1);                  // one bin (0) with one chunk
+            const uint64_t v0 = voff(first_rec), v1 = voff(after_last);
+            for (int i = 0; i < 8; ++i) b.push_back((uint8_t)(v0 >> (8 * i)));
+            for (int i = 0; i < 8; ++i) b.push_back((uint8_t)(v1 >> (8 * i)));
+        } else put32(b, 0);
+        size_t n_intv = lin.size();
+        while (n_intv && lin[n_intv - 1] == ~0ull) --n_intv;
+        put32(b, (uint32_t)n_intv);
+        uint64_t last = 0;
+        for (size_t w = 0; w < n_intv; ++w) {
+            if (lin[w] != ~0ull) last = voff(lin[w]);
+            for (int i = 0; i < 8; ++i) b.push_back((uint8_t)(last >> (8 * i)));
+        }
+        FILE* fb = fopen((path + ".bai").c_str(), "wb");
+        if (fb) { fwrite(b.data(), 1, b.size(), fb); fclose(fb); }
+    }
     FILE* fai = fopen((path.substr(0, path.size() - 4) + ".fa.fai").c_str(), "w");
     if (fai) { fprintf(fai, "%s\t%lld\t6\t60\t61\n", contig.c_str(), (long long)L); fclose(fai); }
     printf("{\"reads\": %lld, \"bam_bytes\": %llu}\n", (long long)n, (unsigned long long)(out_bytes + 28));
