@@ -244,6 +244,15 @@ __global__ __launch_bounds__(INF_LANES) void gd_inflate_kernel(InflateJob job)
                 if (br.bad) { err = 1; break; }
                 if (dist > o || o + len > olen) { err = 16; break; }
                 uint32_t k = 0;
+                if (dist >= 16)                            // 16-byte groups: four loads in flight, then four stores
+                    for (; k + 16 <= len; k += 16, o += 16) {
+                        uint32_t w0, w1, w2, w3;
+                        const uint8_t* src = out + o - dist;
+                        __builtin_memcpy(&w0, src, 4); __builtin_memcpy(&w1, src + 4, 4);
+                        __builtin_memcpy(&w2, src + 8, 4); __builtin_memcpy(&w3, src + 12, 4);
+                        __builtin_memcpy(out + o, &w0, 4); __builtin_memcpy(out + o + 4, &w1, 4);
+                        __builtin_memcpy(out + o + 8, &w2, 4); __builtin_memcpy(out + o + 12, &w3, 4);
+                    }
                 if (dist >= 4)                             // source and destination words do not overlap
                     for (; k + 4 <= len; k += 4, o += 4) {
                         uint32_t w;
