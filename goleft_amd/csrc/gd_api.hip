@@ -1398,7 +1398,7 @@ int gd_host_free(gd_ctx* c, void* p)
     return GD_OK;
 }
 
-int gd_ingest_bgzf(gd_ctx* c, int32_t tid, const uint8_t* data, size_t n_bytes, uint64_t base_coffset,
+int gd_ingest_bgzf(gd_ctx* c, int32_t tid, int32_t ref_id, const uint8_t* data, size_t n_bytes, uint64_t base_coffset,
                    const uint64_t* anchors, size_t n_anchors, uint64_t* n_records)
 {
     if (!c || !data || !anchors || n_anchors == 0) return GD_E_INVALID;
@@ -1505,7 +1505,7 @@ int gd_ingest_bgzf(gd_ctx* c, int32_t tid, const uint8_t* data, size_t n_bytes, 
     HIPCHK(c, hipMemcpyAsync(s_beg, seg_beg.data(), n_anchors * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(s_end, seg_end.data(), n_anchors * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
     gd::BamSegJob bj{};
-    bj.data = d_out.as<uint8_t>(); bj.n_bytes = total; bj.seg_beg = s_beg; bj.seg_end = s_end; bj.tid = tid;
+    bj.data = d_out.as<uint8_t>(); bj.n_bytes = total; bj.seg_beg = s_beg; bj.seg_end = s_end; bj.tid = ref_id;
     bj.n_seg = (uint32_t)n_anchors; bj.n_rec = s_nrec; bj.n_ops = s_nops; bj.first_pos = s_first; bj.last_pos = s_last;
     bj.flags = s_flags;
     const unsigned seg_grid = (unsigned)((n_anchors + 63) / 64);

@@ -23,6 +23,7 @@
 
 #include "bam_reader.hpp"
 #include "fasta_stats.hpp"
+#include "gpu_ingest.hpp"
 
 namespace {
 
@@ -416,35 +417,15 @@ int run(const DArgs& args)
         if (gpu_decode) {
             FILE* fb = fopen(args.bam.c_str(), "rb");
             if (!fb) gpu_decode = false;
-            uint8_t* bytes = nullptr;                                 // page-locked staging, grown as needed
-            size_t bytes_cap = 0;
+            gdh::PinnedStage stage(ctx);
             for (size_t w = 0; gpu_decode && w < wanted.size(); ++w) {
-                const int32_t t = wanted[w];
-                if (lin[(size_t)t].empty()) continue;                 // no records on this contig
-                const uint64_t beg = lin[(size_t)t].front() >> 16;
-                // up to the member in which the next reference with records starts (inclusive), or EOF
-                uint64_t end = ~0ull;
-                for (size_t u = (size_t)t + 1; u < lin.size(); ++u)
-                    if (!lin[u].empty()) { end = (lin[u].front() >> 16) + 65536 + 26; break; }
-                if (fseeko(fb, 0, SEEK_END) != 0) { gpu_decode = false; break; }
-                const uint64_t fsize = (uint64_t)ftello(fb);
-                if (end > fsize) end = fsize;
-                if (beg >= end || fseeko(fb, (off_t)beg, SEEK_SET) != 0) { gpu_decode = false; break; }
-                const size_t nb = (size_t)(end - beg);
-                if (nb > bytes_cap) {
-                    if (bytes) GDCHK(gd_host_free(ctx, bytes));
-                    bytes = nullptr;
-                    void* pp = nullptr;
-                    GDCHK(gd_host_alloc(ctx, nb + nb / 4, &pp));
-                    bytes = static_cast<uint8_t*>(pp);
-                    bytes_cap = nb + nb / 4;
-                }
-                if (fread(bytes, 1, nb, fb) != nb) { gpu_decode = false; break; }
                 uint64_t n = 0;
-                GDCHK(gd_ingest_bgzf(ctx, t, bytes, nb, beg, lin[(size_t)t].data(), lin[(size_t)t].size(), &n));
+                bool io_ok = true;
+                const int rc = gdh::ingest_reference_on_device(ctx, fb, lin, wanted[w], wanted[w], &stage, &n, &io_ok);
+                if (rc != GD_OK) { if (fb) fclose(fb); GDCHK(rc); }
+                if (!io_ok) gpu_decode = false;
                 n_gpu_records += n;
             }
-            if (bytes) GDCHK(gd_host_free(ctx, bytes));
             if (fb) fclose(fb);
             if (!gpu_decode) GDCHK(gd_reset(ctx));                    // fall back to the host decoder below
         }

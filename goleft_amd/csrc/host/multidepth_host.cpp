@@ -25,6 +25,7 @@
 #include "../../../include/goleft_depth.h"
 #include "../../../include/goleft_depth_host.h"
 #include "bam_reader.hpp"
+#include "gpu_ingest.hpp"
 
 namespace {
 
@@ -288,11 +289,27 @@ int run(const MArgs& a, FILE* out)
     MDCHK(gd_set_contigs(ctx, S, lens.data()));
 
     // ---- every BAM's records of the chromosome -> contig s of the engine -----------
+    const char* gd_env = getenv("GOLEFT_GPU_DECODE");
+    const bool want_gpu = !(gd_env && gd_env[0] == '0');
     for (int s = 0; s < S; ++s) {
         if (chrom_tid[(size_t)s] < 0) continue;             // samtools prints 0 for a file without the contig
+        const int32_t want = chrom_tid[(size_t)s];
+        // with a .bai: the file's bytes of this reference are inflated and decoded on the device
+        std::vector<std::vector<uint64_t>> lin;
+        if (want_gpu && gdh::BamReader::linear_index(a.bams[(size_t)s], &lin, &err) && (size_t)want < lin.size()) {
+            FILE* fb = fopen(a.bams[(size_t)s].c_str(), "rb");
+            if (fb) {
+                gdh::PinnedStage stage(ctx);
+                uint64_t n = 0;
+                bool io_ok = true;
+                const int rc = gdh::ingest_reference_on_device(ctx, fb, lin, want, s, &stage, &n, &io_ok);
+                fclose(fb);
+                if (rc != GD_OK) MDCHK(rc);
+                if (io_ok) continue;
+            }
+        }
         gdh::BamReader br;
         if (!br.open(a.bams[(size_t)s], a.processes, &err)) { fprintf(stderr, "multidepth: %s\n", err.c_str()); gd_destroy(ctx); return 2; }
-        const int32_t want = chrom_tid[(size_t)s];
         br.seek_contig(want, &err);                         // .bai shortcut when there is one
         gdh::RecordBlock blk;
         for (;;) {

@@ -293,12 +293,14 @@ class DepthEngine:
                                             out.ctypes.data, total, status.ctypes.data))
         return out[:total].tobytes(), status[:m]
 
-    def ingest_bgzf(self, tid: int, data: bytes, base_coffset: int, anchors) -> int:
-        """Inflate + decode one contig's records on the device (see gd_ingest_bgzf); returns the record count."""
+    def ingest_bgzf(self, tid: int, data: bytes, base_coffset: int, anchors, ref_id: int | None = None) -> int:
+        """Inflate + decode the records of BAM reference ref_id (default: tid) on the device into
+        engine contig tid (see gd_ingest_bgzf); returns the record count."""
         raw = np.frombuffer(data, np.uint8)
         a = np.ascontiguousarray(anchors, np.uint64)
         n = C.c_uint64()
-        self._chk(self._lib.gd_ingest_bgzf(self._ctx, tid, raw.ctypes.data, raw.size, base_coffset,
+        self._chk(self._lib.gd_ingest_bgzf(self._ctx, tid, tid if ref_id is None else ref_id,
+                                           raw.ctypes.data, raw.size, base_coffset,
                                            a.ctypes.data, a.size, C.byref(n)))
         return int(n.value)
 

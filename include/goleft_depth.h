@@ -290,17 +290,19 @@ int gd_inflate_bgzf(gd_ctx* ctx, const uint8_t* data, size_t n_bytes, size_t n_m
 
 /* ---- the whole BAM read of one contig on the device -------------------------------------
  * data: a byte range of the BAM file that begins at a BGZF member boundary (its file offset
- * is base_coffset) and holds every record of contig tid.  anchors: virtual file offsets
+ * is base_coffset) and holds every record of the BAM reference ref_id, which become the records
+ * of engine contig tid (the same number for `goleft depth`; multidepth maps one reference of S
+ * files onto S contigs).  anchors: virtual file offsets
  * (coffset << 16 | uoffset, as stored in the .bai) of record starts inside the range,
  * strictly ascending, anchors[0] = the contig's first record -- the .bai linear index
  * provides one per 16 kb of reference (SAMv1 5.2).  The device inflates the members (one
  * lane each), one lane per anchor walks the records up to the next anchor (a record of
- * another reference ends the contig) and {pos, flag, mapq, CIGAR (CG:B,I resolved)} become
+ * another reference ends the walk) and {pos, flag, mapq, CIGAR (CG:B,I resolved)} become
  * the contig's record arrays in HBM, replacing what it held -- the state gd_push / gd_commit
  * would have left, without any decode on the host.  Errors: GD_E_INVALID (corrupt member or
  * record, anchor that is not a record start), GD_E_UNSORTED. */
-int gd_ingest_bgzf(gd_ctx* ctx, int32_t tid, const uint8_t* data, size_t n_bytes, uint64_t base_coffset,
-                   const uint64_t* anchors, size_t n_anchors, uint64_t* n_records);
+int gd_ingest_bgzf(gd_ctx* ctx, int32_t tid, int32_t ref_id, const uint8_t* data, size_t n_bytes,
+                   uint64_t base_coffset, const uint64_t* anchors, size_t n_anchors, uint64_t* n_records);
 /* Page-locked host memory for the byte range handed to gd_ingest_bgzf (read the file
  * straight into it: the H2D copy then runs at PCIe speed instead of through a bounce
  * buffer).  Plain pageable memory works too, only slower. */
