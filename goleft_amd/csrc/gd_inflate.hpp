@@ -156,10 +156,6 @@ __global__ __launch_bounds__(INF_LANES) void gd_inflate_kernel(InflateJob job)
     uint32_t o = 0;
     uint32_t err = 0;
 
-    static const uint16_t lbase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
-    static const uint8_t lext[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
-    static const uint16_t dbase[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
-    static const uint8_t dext[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
     static const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
     bool last = false;
@@ -235,15 +231,47 @@ __global__ __launch_bounds__(INF_LANES) void gd_inflate_kernel(InflateJob job)
             } else if (sym == 256) {
                 break;
             } else {
+                // base value and extra-bit count of length / distance symbols in closed form
+                // (RFC 1951 3.2.5) -- table lookups would be dependent global loads on the
+                // critical path of every match
                 const int ls = sym - 257;
                 if (ls >= 29) { err = 14; break; }
-                const uint32_t len = lbase[ls] + br.bits(lext[ls]);
+                uint32_t len;
+                if (ls < 8) len = 3u + (uint32_t)ls;
+                else if (ls == 28) len = 258u;
+                else { const int e = (ls >> 2) - 1; len = 3u + ((4u + (uint32_t)(ls & 3)) << e) + br.bits(e); }
                 const int ds = huff_decode(br, hd, cd);
                 if (ds < 0 || ds >= 30) { err = 15; break; }
-                const uint32_t dist = dbase[ds] + br.bits(dext[ds]);
+                uint32_t dist;
+                if (ds < 4) dist = 1u + (uint32_t)ds;
+                else { const int e = (ds >> 1) - 1; dist = 1u + ((2u + (uint32_t)(ds & 1)) << e) + br.bits(e); }
                 if (br.bad) { err = 1; break; }
                 if (dist > o || o + len > olen) { err = 16; break; }
                 uint32_t k = 0;
+                if (dist < 4) {
+                    // run-length style matches (distance 1..3, up to 258 bytes): the pattern is read
+                    // once and replayed from registers -- a byte loop here would chain a
+                    // store -> load round trip through memory per output byte
+                    const uint32_t b0 = out[o - dist];
+                    const uint32_t b1 = dist > 1 ? out[o - dist + 1] : b0;
+                    const uint32_t b2 = dist > 2 ? out[o - dist + 2] : (dist == 2 ? b0 : b0);
+                    uint32_t w[3];
+                    if (dist == 1) { w[0] = w[1] = w[2] = b0 * 0x01010101u; }
+                    else if (dist == 2) { w[0] = w[1] = w[2] = b0 | (b1 << 8) | (b0 << 16) | (b1 << 24); }
+                    else {
+                        w[0] = b0 | (b1 << 8) | (b2 << 16) | (b0 << 24);
+                        w[1] = b1 | (b2 << 8) | (b0 << 16) | (b1 << 24);
+                        w[2] = b2 | (b0 << 8) | (b1 << 16) | (b2 << 24);
+                    }
+                    uint32_t ph = 0;
+                    for (; k + 4 <= len; k += 4, o += 4) {
+                        const uint32_t v = ph == 0 ? w[0] : ph == 1 ? w[1] : w[2];
+                        __builtin_memcpy(out + o, &v, 4);
+                        ph = ph == 2 ? 0 : ph + 1;
+                    }
+                    uint32_t v = ph == 0 ? w[0] : ph == 1 ? w[1] : w[2];
+                    for (; k < len; ++k, ++o, v >>= 8) out[o] = (uint8_t)v;
+                }
                 if (dist >= 16)                            // 16-byte groups: four loads in flight, then four stores
                     for (; k + 16 <= len; k += 16, o += 16) {
                         uint32_t w0, w1, w2, w3;

@@ -11,7 +11,7 @@ root = sys.argv[1]
 
 def short(name):
     for k in ("gd_tile_kernel", "gd_ltile2_kernel", "gd_ltile_kernel", "gd_ckpt_kernel", "gd_prep_kernel", "gd_runs_order_kernel",
-              "gd_expand_scatter_kernel", "gd_scan_kernel", "gd_depthwed", "gd_region", "gd_"):
+              "gd_expand_scatter_kernel", "gd_scan_kernel", "gd_depthwed", "gd_inflate_kernel", "gd_bam_walk_kernel", "gd_region", "gd_"):
         if k in name:
             return k + (name[name.index("<"):name.index(">") + 1] if "<" in name else "")
     return name[:60]
