@@ -40,6 +40,45 @@ def test_inflate_varied_payloads():
         assert got == b"".join(parts)
 
 
+@pytest.mark.parametrize("seed", range(4))
+def test_inflate_random_streams(seed):
+    # many members of random size / entropy / compression level and strategy in one call,
+    # incl. Z_FIXED (fixed Huffman blocks), Z_RLE and Z_HUFFMAN_ONLY streams
+    from goleft_amd.engine import DepthEngine
+    rng = np.random.default_rng(seed)
+    parts, blobs = [], []
+    for _ in range(150):
+        n = int(rng.integers(0, 65281))
+        kind = rng.integers(0, 5)
+        if kind == 0:
+            x = rng.integers(0, 256, n, dtype=np.uint8)
+        elif kind == 1:
+            x = rng.integers(0, 4, n, dtype=np.uint8) + 65
+        elif kind == 2:
+            x = np.repeat(rng.integers(0, 256, n // 50 + 1, dtype=np.uint8), 50)[:n]
+        elif kind == 3:
+            base = rng.integers(0, 256, 97, dtype=np.uint8)
+            x = np.tile(base, n // 97 + 1)[:n]
+        else:
+            x = np.zeros(n, np.uint8)
+        x = x.tobytes()
+        level = int(rng.integers(0, 10))
+        strategy = int(rng.choice([zlib.Z_DEFAULT_STRATEGY, zlib.Z_FIXED, zlib.Z_RLE, zlib.Z_HUFFMAN_ONLY, zlib.Z_FILTERED]))
+        co = zlib.compressobj(level, zlib.DEFLATED, -15, 8, strategy)
+        c = co.compress(x) + co.flush()
+        if len(c) + 26 > 65536:                            # would not fit a BGZF member: store a smaller piece
+            x = x[:30000]
+            co = zlib.compressobj(level, zlib.DEFLATED, -15, 8, strategy)
+            c = co.compress(x) + co.flush()
+        blobs.append(b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", len(c) + 25) + c
+                     + struct.pack("<II", zlib.crc32(x) & 0xFFFFFFFF, len(x)))
+        parts.append(x)
+    with DepthEngine(0) as eng:
+        got, status = eng.inflate_bgzf(b"".join(blobs))
+    assert (status == 0).all()
+    assert got == b"".join(parts)
+
+
 def test_inflate_reports_corrupt_members():
     from goleft_amd.engine import DepthEngine
     good = bamio.bgzf_compress(b"hello world, " * 1000, level=6)
