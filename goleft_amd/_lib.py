@@ -71,7 +71,7 @@ SYMBOLS = {
     "gd_seq_stats": (C.c_int, [_P, C.c_size_t, _P, _P, _P, _P, _P]),
     "gd_md_flags": (C.c_int, [_P, C.c_int, _P, C.c_int32, C.c_int32, _P, _P, C.c_size_t]),
     "gd_md_sums": (C.c_int, [_P, C.c_size_t, _P, _P, _P]),
-    "gd_inflate_bgzf": (C.c_int, [_P, _P, C.c_size_t, C.c_size_t, _P, _P, _P, _P, _P, C.c_size_t, _P]),
+    "gd_inflate_bgzf": (C.c_int, [_P, _P, C.c_size_t, C.c_size_t, _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),
     "gd_ingest_bgzf": (C.c_int, [_P, C.c_int32, C.c_int32, _P, C.c_size_t, C.c_uint64, _P, C.c_size_t,
                                  C.POINTER(C.c_uint64)]),
     "gd_host_alloc": (C.c_int, [_P, C.c_size_t, C.POINTER(_P)]),

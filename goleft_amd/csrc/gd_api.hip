@@ -1330,8 +1330,8 @@ int gd_md_sums(gd_ctx* c, size_t n_blocks, const int64_t* start, const int64_t* 
 }
 
 int gd_inflate_bgzf(gd_ctx* c, const uint8_t* data, size_t n_bytes, size_t n_members, const uint64_t* in_off,
-                    const uint32_t* in_len, const uint64_t* out_off, const uint32_t* out_len, uint8_t* out,
-                    size_t out_bytes, uint32_t* status)
+                    const uint32_t* in_len, const uint64_t* out_off, const uint32_t* out_len, const uint32_t* crc,
+                    uint8_t* out, size_t out_bytes, uint32_t* status)
 {
     if (!c || !data || !in_off || !in_len || !out_off || !out_len || !out || !status) return GD_E_INVALID;
     if (int r = set_device(c)) return r;
@@ -1341,7 +1341,7 @@ int gd_inflate_bgzf(gd_ctx* c, const uint8_t* data, size_t n_bytes, size_t n_mem
         if (in_off[m] + in_len[m] > n_bytes || out_off[m] + out_len[m] > out_bytes)
             return fail(c, GD_E_RANGE, "BGZF member %zu outside the given buffers", m);
     uint8_t *d_in = nullptr, *d_out = nullptr, *d_tab = nullptr;
-    const size_t tab_bytes = n_members * (2 * sizeof(uint64_t) + 3 * sizeof(uint32_t));
+    const size_t tab_bytes = n_members * (2 * sizeof(uint64_t) + 4 * sizeof(uint32_t));
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&d_in), n_bytes);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_out), out_bytes ? out_bytes : 1);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_tab), tab_bytes);
@@ -1355,6 +1355,8 @@ int gd_inflate_bgzf(gd_ctx* c, const uint8_t* data, size_t n_bytes, size_t n_mem
     uint32_t* t_in_len = reinterpret_cast<uint32_t*>(t_out_off + n_members);
     uint32_t* t_out_len = t_in_len + n_members;
     uint32_t* t_status = t_out_len + n_members;
+    uint32_t* t_crc = t_status + n_members;
+    if (crc && hipMemcpyAsync(t_crc, crc, n_members * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream) != hipSuccess) crc = nullptr;
     hipError_t e1 = hipMemcpyAsync(d_in, data, n_bytes, hipMemcpyHostToDevice, c->stream);
     hipError_t e2 = hipMemcpyAsync(t_in_off, in_off, n_members * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream);
     hipError_t e3 = hipMemcpyAsync(t_out_off, out_off, n_members * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream);
@@ -1362,6 +1364,7 @@ int gd_inflate_bgzf(gd_ctx* c, const uint8_t* data, size_t n_bytes, size_t n_mem
     hipError_t e5 = hipMemcpyAsync(t_out_len, out_len, n_members * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream);
     gd::InflateJob j{};
     j.comp = d_in; j.in_off = t_in_off; j.in_len = t_in_len; j.out_off = t_out_off; j.out_len = t_out_len;
+    j.crc = crc ? t_crc : nullptr;
     j.out = d_out; j.status = t_status; j.n = (uint32_t)n_members;
     if (c->profiling) (void)hipEventRecord(c->ev[0], c->stream);
     hipLaunchKernelGGL(gd::gd_inflate_kernel, dim3((unsigned)((n_members + gd::INF_LANES - 1) / gd::INF_LANES)),
@@ -1417,7 +1420,7 @@ int gd_ingest_bgzf(gd_ctx* c, int32_t tid, int32_t ref_id, const uint8_t* data, 
     };
     // ---- the BGZF members of the range (SAMv1 4.1: gzip header with a BC extra subfield) -------
     std::vector<uint64_t> m_coff, in_off, out_off;
-    std::vector<uint32_t> in_len, out_len;
+    std::vector<uint32_t> in_len, out_len, m_crc;
     uint64_t total = 0;
     for (size_t p = 0; p + 18 <= n_bytes;) {
         const uint8_t* h = data + p;
@@ -1435,6 +1438,8 @@ int gd_ingest_bgzf(gd_ctx* c, int32_t tid, int32_t ref_id, const uint8_t* data, 
         if (p + bsize > n_bytes) break;                     // a trailing partial member is ignored
         const uint32_t isize = (uint32_t)h[bsize - 4] | ((uint32_t)h[bsize - 3] << 8) | ((uint32_t)h[bsize - 2] << 16) |
                                ((uint32_t)h[bsize - 1] << 24);
+        m_crc.push_back((uint32_t)h[bsize - 8] | ((uint32_t)h[bsize - 7] << 8) | ((uint32_t)h[bsize - 6] << 16) |
+                        ((uint32_t)h[bsize - 5] << 24));
         m_coff.push_back(base_coffset + p);
         in_off.push_back(p + 12 + xlen);
         in_len.push_back((uint32_t)(bsize - 12 - xlen - 8));
@@ -1462,7 +1467,7 @@ int gd_ingest_bgzf(gd_ctx* c, int32_t tid, int32_t ref_id, const uint8_t* data, 
 
     // ---- device: inflate ------------------------------------------------------------------------
     DevBuf d_in, d_out, d_tab, d_seg;
-    const size_t tab_bytes = nm * (2 * sizeof(uint64_t) + 3 * sizeof(uint32_t));
+    const size_t tab_bytes = nm * (2 * sizeof(uint64_t) + 4 * sizeof(uint32_t));
     const size_t seg_words = n_anchors * 5;                 // seg_beg, seg_end, rec_base, op_base, n_ops (uint64 each)
     const size_t seg_bytes = seg_words * sizeof(uint64_t) + n_anchors * 4 * sizeof(uint32_t);
     if (d_in.alloc(n_bytes) != hipSuccess || d_out.alloc(total) != hipSuccess || d_tab.alloc(tab_bytes) != hipSuccess ||
@@ -1475,6 +1480,8 @@ int gd_ingest_bgzf(gd_ctx* c, int32_t tid, int32_t ref_id, const uint8_t* data, 
     uint32_t* t_in_len = reinterpret_cast<uint32_t*>(t_out_off + nm);
     uint32_t* t_out_len = t_in_len + nm;
     uint32_t* t_status = t_out_len + nm;
+    uint32_t* t_crc = t_status + nm;
+    HIPCHK(c, hipMemcpyAsync(t_crc, m_crc.data(), nm * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(d_in.p, data, n_bytes, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(t_in_off, in_off.data(), nm * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(t_out_off, out_off.data(), nm * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
@@ -1483,7 +1490,7 @@ int gd_ingest_bgzf(gd_ctx* c, int32_t tid, int32_t ref_id, const uint8_t* data, 
     lap("H2D compressed bytes");
     gd::InflateJob ij{};
     ij.comp = d_in.as<uint8_t>(); ij.in_off = t_in_off; ij.in_len = t_in_len; ij.out_off = t_out_off;
-    ij.out_len = t_out_len; ij.out = d_out.as<uint8_t>(); ij.status = t_status; ij.n = (uint32_t)nm;
+    ij.out_len = t_out_len; ij.crc = t_crc; ij.out = d_out.as<uint8_t>(); ij.status = t_status; ij.n = (uint32_t)nm;
     if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
     hipLaunchKernelGGL(gd::gd_inflate_kernel, dim3((unsigned)((nm + gd::INF_LANES - 1) / gd::INF_LANES)),
                        dim3(gd::INF_LANES), 0, c->stream, ij);
@@ -1526,8 +1533,8 @@ int gd_ingest_bgzf(gd_ctx* c, int32_t tid, int32_t ref_id, const uint8_t* data, 
     }
     for (size_t m = 0; m < nm; ++m)
         if (status[m] != 0)
-            return fail(c, GD_E_INVALID, "BGZF member at file offset %llu does not inflate (decoder code %u)",
-                        (unsigned long long)m_coff[m], status[m]);
+            return fail(c, GD_E_INVALID, "BGZF member at file offset %llu %s (decoder code %u)",
+                        (unsigned long long)m_coff[m], status[m] == 18 ? "fails its CRC32" : "does not inflate", status[m]);
     std::vector<uint64_t> rbase(n_anchors), obase(n_anchors);
     uint64_t N = 0, M = 0;
     int32_t prev_last = -0x7fffffff;

@@ -259,10 +259,11 @@ class DepthEngine:
         self._chk(self._lib.gd_md_sums(self._ctx, s.size, s.ctypes.data, e.ctypes.data, out.ctypes.data))
         return out
 
-    def inflate_bgzf(self, data: bytes):
-        """Inflate every member of a BGZF byte string on the device; returns (bytes, status[n])."""
+    def inflate_bgzf(self, data: bytes, check_crc: bool = True):
+        """Inflate every member of a BGZF byte string on the device (CRC32 of each member
+        verified unless check_crc is False); returns (bytes, status[n])."""
         raw = np.frombuffer(data, np.uint8)
-        offs, lens, isz = [], [], []
+        offs, lens, isz, crcs = [], [], [], []
         p, n = 0, raw.size
         while p + 18 <= n:
             assert raw[p] == 0x1f and raw[p + 1] == 0x8b and raw[p + 3] & 4, "not a BGZF member at %d" % p
@@ -277,11 +278,13 @@ class DepthEngine:
             offs.append(p + 12 + xlen)
             lens.append(bsize + 1 - 12 - xlen - 8)
             isz.append(int.from_bytes(raw[p + bsize - 3:p + bsize + 1].tobytes(), "little"))
+            crcs.append(int.from_bytes(raw[p + bsize - 7:p + bsize - 3].tobytes(), "little"))
             p += bsize + 1
         m = len(offs)
         in_off = np.asarray(offs, np.uint64)
         in_len = np.asarray(lens, np.uint32)
         out_len = np.asarray(isz, np.uint32)
+        crc = np.asarray(crcs, np.uint32)
         out_off = np.zeros(m, np.uint64)
         if m:
             out_off[1:] = np.cumsum(out_len[:-1].astype(np.uint64))
@@ -290,6 +293,7 @@ class DepthEngine:
         status = np.zeros(max(m, 1), np.uint32)
         self._chk(self._lib.gd_inflate_bgzf(self._ctx, raw.ctypes.data, raw.size, m, in_off.ctypes.data,
                                             in_len.ctypes.data, out_off.ctypes.data, out_len.ctypes.data,
+                                            crc.ctypes.data if check_crc else None,
                                             out.ctypes.data, total, status.ctypes.data))
         return out[:total].tobytes(), status[:m]
 

@@ -281,12 +281,14 @@ int gd_md_sums(gd_ctx* ctx, size_t n_blocks, const int64_t* start, const int64_t
 /* ---- BGZF inflate on device (the first stage of the BAM read of depth/depth.go:45) ----
  * A BGZF file is a sequence of independent <= 64 KiB DEFLATE streams ("members").  The
  * caller lists them (payload offset/length inside data, ISIZE, and where each member's
- * bytes go in out); one GPU lane inflates one member.  status[m] is 0 or a decoder error
- * code (corrupt stream, ISIZE mismatch); CRC32 is not verified on the device.  data, out
- * and status are host buffers. */
+ * bytes go in out); one GPU lane inflates one member and checks it against crc[m], the
+ * CRC32 of the gzip trailer (crc may be NULL: not checked).  status[m] is 0 or a decoder
+ * error code (corrupt stream, ISIZE mismatch, 18 = CRC32 mismatch).  data, out and status
+ * are host buffers. */
 int gd_inflate_bgzf(gd_ctx* ctx, const uint8_t* data, size_t n_bytes, size_t n_members,
                     const uint64_t* in_off, const uint32_t* in_len, const uint64_t* out_off,
-                    const uint32_t* out_len, uint8_t* out, size_t out_bytes, uint32_t* status);
+                    const uint32_t* out_len, const uint32_t* crc, uint8_t* out, size_t out_bytes,
+                    uint32_t* status);
 
 /* ---- the whole BAM read of one contig on the device -------------------------------------
  * data: a byte range of the BAM file that begins at a BGZF member boundary (its file offset
@@ -299,8 +301,9 @@ int gd_inflate_bgzf(gd_ctx* ctx, const uint8_t* data, size_t n_bytes, size_t n_m
  * lane each), one lane per anchor walks the records up to the next anchor (a record of
  * another reference ends the walk) and {pos, flag, mapq, CIGAR (CG:B,I resolved)} become
  * the contig's record arrays in HBM, replacing what it held -- the state gd_push / gd_commit
- * would have left, without any decode on the host.  Errors: GD_E_INVALID (corrupt member or
- * record, anchor that is not a record start), GD_E_UNSORTED. */
+ * would have left, without any decode on the host.  Every member's CRC32 is verified.
+ * Errors: GD_E_INVALID (corrupt member or record, CRC mismatch, anchor that is not a record
+ * start), GD_E_UNSORTED. */
 int gd_ingest_bgzf(gd_ctx* ctx, int32_t tid, int32_t ref_id, const uint8_t* data, size_t n_bytes,
                    uint64_t base_coffset, const uint64_t* anchors, size_t n_anchors, uint64_t* n_records);
 /* Page-locked host memory for the byte range handed to gd_ingest_bgzf (read the file
