@@ -54,6 +54,9 @@ struct RingSlot {
 
 }  // namespace
 
+// State of a device BAM read between gd_ingest_begin and gd_ingest_finish.
+struct IngestState;
+
 struct gd_ctx {
     int device = 0;
     hipStream_t stream = nullptr;       // compute stream
@@ -103,6 +106,7 @@ struct gd_ctx {
     uint32_t* d_md_bits = nullptr; size_t cap_md = 0;  // gd_md_flags: `any` words then `suf` words
     int64_t md_len = -1;                               // positions the bitmaps cover (-1: none yet)
     std::vector<int32_t> md_tids;                      // the samples they were built from
+    IngestState* ing = nullptr;                        // gd_ingest_begin .. gd_ingest_finish
     uint8_t* d_seq = nullptr;  size_t cap_seq = 0;     // gd_seq_load: one contig's bases, zero padded
     int64_t seq_len = -1;
     uint32_t seq_padded = 0;
@@ -265,6 +269,27 @@ struct DevBuf {
 
 }  // namespace
 
+struct IngestState {
+    static constexpr size_t kStage = 64u << 20;        // bytes per page-locked staging buffer
+    uint64_t n_bytes = 0, fed = 0, total = 0;           // compressed bytes announced / received, inflated bytes
+    size_t nm = 0, next = 0;                            // members, first member not yet handed to the inflate kernel
+    std::vector<uint64_t> m_coff, m_end, out_off;       // file offset, end offset in the range, offset in the inflated bytes
+    std::vector<uint32_t> out_len;
+    DevBuf d_in, d_out, d_tab;
+    uint64_t *t_in_off = nullptr, *t_out_off = nullptr;
+    uint32_t *t_in_len = nullptr, *t_out_len = nullptr, *t_status = nullptr, *t_crc = nullptr;
+    uint8_t* stage[2] = {nullptr, nullptr};
+    hipEvent_t staged[2] = {nullptr, nullptr};
+    bool stage_used[2] = {false, false};
+    int cur = 0;
+    // One lane inflates one member start to end (~0.1 s whatever the member count), so the members are
+    // handed to the kernel in at most kBatches launches, each on its own stream: they overlap each other
+    // and the upload of the bytes still to come.
+    static constexpr int kBatches = 4;
+    hipStream_t inf_stream[kBatches] = {};
+    int n_launch = 0;
+};
+
 extern "C" {
 
 const char* gd_strerror(int s)
@@ -360,6 +385,7 @@ void gd_destroy(gd_ctx* c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
+    (void)gd_ingest_abort(c);
     for (auto& h : c->contigs) free_contig(h);
     for (auto& s : c->ring) {
         if (s.b.pos) (void)hipHostFree(s.b.pos);
@@ -1401,105 +1427,156 @@ int gd_host_free(gd_ctx* c, void* p)
     return GD_OK;
 }
 
-int gd_ingest_bgzf(gd_ctx* c, int32_t tid, int32_t ref_id, const uint8_t* data, size_t n_bytes, uint64_t base_coffset,
-                   const uint64_t* anchors, size_t n_anchors, uint64_t* n_records)
+// ---- device BAM read: begin (member tables, allocations) / feed (bytes) / finish (records) ----
+int gd_ingest_abort(gd_ctx* c)
 {
-    if (!c || !data || !anchors || n_anchors == 0) return GD_E_INVALID;
+    if (!c) return GD_E_INVALID;
+    if (!c->ing) return GD_OK;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->copy_stream);
+    (void)hipStreamSynchronize(c->stream);
+    for (hipStream_t s : c->ing->inf_stream)
+        if (s) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
+    for (int k = 0; k < 2; ++k) {
+        if (c->ing->stage[k]) (void)hipHostFree(c->ing->stage[k]);
+        if (c->ing->staged[k]) (void)hipEventDestroy(c->ing->staged[k]);
+    }
+    delete c->ing;
+    c->ing = nullptr;
+    return GD_OK;
+}
+
+int gd_ingest_begin(gd_ctx* c, uint64_t n_bytes, uint64_t base_coffset, size_t n_members, const uint64_t* member_off,
+                    const uint32_t* member_size, const uint16_t* header_size, const uint32_t* isize, const uint32_t* crc)
+{
+    if (!c || n_members == 0 || !member_off || !member_size || !header_size || !isize || !crc) return GD_E_INVALID;
     if (int r = set_device(c)) return r;
+    if (n_members > 0xfffffff0ull) return fail(c, GD_E_RANGE, "too many BGZF members");
+    (void)gd_ingest_abort(c);
+    IngestState* g = new (std::nothrow) IngestState();
+    if (!g) return GD_E_NOMEM;
+    c->ing = g;
+    auto bail = [&](int code, const char* msg) { (void)gd_ingest_abort(c); return fail(c, code, "%s", msg); };
+    g->n_bytes = n_bytes;
+    g->nm = n_members;
+    g->m_coff.resize(n_members); g->m_end.resize(n_members);
+    std::vector<uint64_t> in_off(n_members), out_off(n_members);
+    std::vector<uint32_t> in_len(n_members);
+    g->out_off.resize(n_members); g->out_len.assign(isize, isize + n_members);
+    uint64_t total = 0;
+    for (size_t m = 0; m < n_members; ++m) {
+        if (member_size[m] < (uint32_t)header_size[m] + 8u || member_off[m] + member_size[m] > n_bytes ||
+            (m && member_off[m] < member_off[m - 1] + member_size[m - 1]))
+            return bail(GD_E_INVALID, "inconsistent BGZF member table");
+        g->m_coff[m] = base_coffset + member_off[m];
+        g->m_end[m] = member_off[m] + member_size[m];
+        in_off[m] = member_off[m] + header_size[m];
+        in_len[m] = member_size[m] - header_size[m] - 8u;
+        out_off[m] = total;
+        g->out_off[m] = total;
+        total += isize[m];
+    }
+    g->total = total;
+    const size_t tab_bytes = n_members * (2 * sizeof(uint64_t) + 4 * sizeof(uint32_t));
+    if (g->d_in.alloc((size_t)n_bytes) != hipSuccess || g->d_out.alloc((size_t)total) != hipSuccess ||
+        g->d_tab.alloc(tab_bytes) != hipSuccess)
+        return bail(GD_E_NOMEM, "device allocation for the BAM decode failed");
+    for (int k = 0; k < 2; ++k)
+        if (hipHostMalloc(reinterpret_cast<void**>(&g->stage[k]), IngestState::kStage, hipHostMallocDefault) != hipSuccess ||
+            hipEventCreateWithFlags(&g->staged[k], hipEventDisableTiming) != hipSuccess)
+            return bail(GD_E_NOMEM, "cannot allocate the page-locked staging buffers");
+    for (hipStream_t& s : g->inf_stream)
+        if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return bail(GD_E_HIP, "cannot create a stream");
+    g->t_in_off = g->d_tab.as<uint64_t>();
+    g->t_out_off = g->t_in_off + n_members;
+    g->t_in_len = reinterpret_cast<uint32_t*>(g->t_out_off + n_members);
+    g->t_out_len = g->t_in_len + n_members;
+    g->t_status = g->t_out_len + n_members;
+    g->t_crc = g->t_status + n_members;
+    // (pageable sources: each copy is complete on return)
+    if (hipMemcpy(g->t_in_off, in_off.data(), n_members * sizeof(uint64_t), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(g->t_out_off, out_off.data(), n_members * sizeof(uint64_t), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(g->t_in_len, in_len.data(), n_members * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(g->t_out_len, isize, n_members * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(g->t_crc, crc, n_members * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess)
+        return bail(GD_E_HIP, "uploading the BGZF member table failed");
+    return GD_OK;
+}
+
+int gd_ingest_feed(gd_ctx* c, const uint8_t* bytes, size_t n)
+{
+    if (!c || (n && !bytes)) return GD_E_INVALID;
+    if (int r = set_device(c)) return r;
+    IngestState* g = c->ing;
+    if (!g) return fail(c, GD_E_STATE, "gd_ingest_begin has not been called");
+    if (g->fed + n > g->n_bytes) return fail(c, GD_E_RANGE, "more bytes fed than announced");
+    size_t done = 0;
+    while (done < n) {
+        const size_t piece = std::min(n - done, IngestState::kStage);
+        const int k = g->cur;
+        if (g->stage_used[k]) HIPCHK(c, hipEventSynchronize(g->staged[k]));       // its previous H2D has left the buffer
+        memcpy(g->stage[k], bytes + done, piece);                                // the caller's pointer is not retained
+        HIPCHK(c, hipMemcpyAsync(g->d_in.as<uint8_t>() + g->fed, g->stage[k], piece, hipMemcpyHostToDevice, c->copy_stream));
+        HIPCHK(c, hipEventRecord(g->staged[k], c->copy_stream));
+        g->stage_used[k] = true;
+        g->cur ^= 1;
+        g->fed += piece;
+        done += piece;
+        // inflate the members that are now completely on the device, behind the copy: a quarter of
+        // the range at a time (or whatever is left once every byte is in)
+        size_t last = g->next;
+        while (last < g->nm && g->m_end[last] <= g->fed) ++last;
+        const size_t quota = std::max<size_t>((g->nm + IngestState::kBatches - 1) / IngestState::kBatches, 1);
+        if (last > g->next && (last - g->next >= quota || last == g->nm) ) {
+            hipStream_t is = g->inf_stream[g->n_launch++ % IngestState::kBatches];
+            HIPCHK(c, hipStreamWaitEvent(is, g->staged[k], 0));
+            gd::InflateJob ij{};
+            ij.comp = g->d_in.as<uint8_t>();
+            ij.in_off = g->t_in_off + g->next; ij.in_len = g->t_in_len + g->next;
+            ij.out_off = g->t_out_off + g->next; ij.out_len = g->t_out_len + g->next;
+            ij.crc = g->t_crc + g->next; ij.out = g->d_out.as<uint8_t>(); ij.status = g->t_status + g->next;
+            ij.n = (uint32_t)(last - g->next);
+            hipLaunchKernelGGL(gd::gd_inflate_kernel, dim3((unsigned)((ij.n + gd::INF_LANES - 1) / gd::INF_LANES)),
+                               dim3(gd::INF_LANES), 0, is, ij);
+            g->next = last;
+        }
+    }
+    return GD_OK;
+}
+
+int gd_ingest_finish(gd_ctx* c, int32_t tid, int32_t ref_id, const uint64_t* anchors, size_t n_anchors, uint64_t* n_records)
+{
+    if (!c || !anchors || n_anchors == 0) return GD_E_INVALID;
+    if (int r = set_device(c)) return r;
+    IngestState* g = c->ing;
+    if (!g) return fail(c, GD_E_STATE, "gd_ingest_begin has not been called");
+    struct Guard { gd_ctx* c; ~Guard() { (void)gd_ingest_abort(c); } } guard{c};   // buffers are released on every path
     if (tid < 0 || (size_t)tid >= c->contigs.size()) return fail(c, GD_E_RANGE, "tid %d out of range", tid);
     if (n_anchors > 0xfffffff0ull) return fail(c, GD_E_RANGE, "too many anchors");
-    const bool tm = getenv("GOLEFT_GD_TIMING") != nullptr;     // phase wall times on stderr (measurement only)
-    auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    double t_prev = now();
-    auto lap = [&](const char* what) {
-        if (!tm) return;
-        (void)hipStreamSynchronize(c->stream);
-        const double t = now();
-        fprintf(stderr, "gd_ingest_bgzf: %-22s %.4f s\n", what, t - t_prev);
-        t_prev = t;
-    };
-    // ---- the BGZF members of the range (SAMv1 4.1: gzip header with a BC extra subfield) -------
-    std::vector<uint64_t> m_coff, in_off, out_off;
-    std::vector<uint32_t> in_len, out_len, m_crc;
-    uint64_t total = 0;
-    for (size_t p = 0; p + 18 <= n_bytes;) {
-        const uint8_t* h = data + p;
-        if (h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4))
-            return fail(c, GD_E_INVALID, "not a BGZF member at byte %zu of the range", p);
-        const size_t xlen = (size_t)h[10] | ((size_t)h[11] << 8);
-        if (p + 12 + xlen > n_bytes) break;
-        size_t q = 12, bsize = 0;
-        while (q + 4 <= 12 + xlen) {
-            const size_t slen = (size_t)h[q + 2] | ((size_t)h[q + 3] << 8);
-            if (h[q] == 66 && h[q + 1] == 67 && slen == 2) bsize = ((size_t)h[q + 4] | ((size_t)h[q + 5] << 8)) + 1;
-            q += 4 + slen;
-        }
-        if (bsize < 12 + xlen + 8) return fail(c, GD_E_INVALID, "BGZF member without a BC subfield at byte %zu", p);
-        if (p + bsize > n_bytes) break;                     // a trailing partial member is ignored
-        const uint32_t isize = (uint32_t)h[bsize - 4] | ((uint32_t)h[bsize - 3] << 8) | ((uint32_t)h[bsize - 2] << 16) |
-                               ((uint32_t)h[bsize - 1] << 24);
-        m_crc.push_back((uint32_t)h[bsize - 8] | ((uint32_t)h[bsize - 7] << 8) | ((uint32_t)h[bsize - 6] << 16) |
-                        ((uint32_t)h[bsize - 5] << 24));
-        m_coff.push_back(base_coffset + p);
-        in_off.push_back(p + 12 + xlen);
-        in_len.push_back((uint32_t)(bsize - 12 - xlen - 8));
-        out_off.push_back(total);
-        out_len.push_back(isize);
-        total += isize;
-        p += bsize;
-    }
-    const size_t nm = m_coff.size();
-    if (nm == 0) return fail(c, GD_E_INVALID, "no complete BGZF member in the range");
+    if (g->next != g->nm) return fail(c, GD_E_STATE, "only %zu of %zu BGZF members were fed", g->next, g->nm);
+    const size_t nm = g->nm;
+    const uint64_t total = g->total;
     // ---- anchors (virtual offsets) -> byte offsets in the inflated range ----------------------
     std::vector<uint64_t> seg_beg(n_anchors), seg_end(n_anchors);
     for (size_t i = 0; i < n_anchors; ++i) {
         const uint64_t coff = anchors[i] >> 16, uoff = anchors[i] & 0xffffu;
-        const size_t k = (size_t)(std::lower_bound(m_coff.begin(), m_coff.end(), coff) - m_coff.begin());
-        if (k >= nm || m_coff[k] != coff || uoff > out_len[k])
+        const size_t k = (size_t)(std::lower_bound(g->m_coff.begin(), g->m_coff.end(), coff) - g->m_coff.begin());
+        if (k >= nm || g->m_coff[k] != coff || uoff > g->out_len[k])
             return fail(c, GD_E_INVALID, "anchor %zu (virtual offset %llu) is not inside a member of the range", i,
                         (unsigned long long)anchors[i]);
-        seg_beg[i] = out_off[k] + uoff;
+        seg_beg[i] = g->out_off[k] + uoff;
         if (i && seg_beg[i] <= seg_beg[i - 1]) return fail(c, GD_E_INVALID, "anchors must be strictly ascending");
         if (i) seg_end[i - 1] = seg_beg[i];
     }
     seg_end[n_anchors - 1] = total;
-    lap("member + anchor tables");
-
-    // ---- device: inflate ------------------------------------------------------------------------
-    DevBuf d_in, d_out, d_tab, d_seg;
-    const size_t tab_bytes = nm * (2 * sizeof(uint64_t) + 4 * sizeof(uint32_t));
-    const size_t seg_words = n_anchors * 5;                 // seg_beg, seg_end, rec_base, op_base, n_ops (uint64 each)
-    const size_t seg_bytes = seg_words * sizeof(uint64_t) + n_anchors * 4 * sizeof(uint32_t);
-    if (d_in.alloc(n_bytes) != hipSuccess || d_out.alloc(total) != hipSuccess || d_tab.alloc(tab_bytes) != hipSuccess ||
-        d_seg.alloc(seg_bytes) != hipSuccess)
-        return fail(c, GD_E_NOMEM, "device allocation for the BAM decode failed (%zu + %llu bytes)", n_bytes,
-                    (unsigned long long)total);
-    lap("device allocations");
-    uint64_t* t_in_off = d_tab.as<uint64_t>();
-    uint64_t* t_out_off = t_in_off + nm;
-    uint32_t* t_in_len = reinterpret_cast<uint32_t*>(t_out_off + nm);
-    uint32_t* t_out_len = t_in_len + nm;
-    uint32_t* t_status = t_out_len + nm;
-    uint32_t* t_crc = t_status + nm;
-    HIPCHK(c, hipMemcpyAsync(t_crc, m_crc.data(), nm * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(d_in.p, data, n_bytes, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(t_in_off, in_off.data(), nm * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(t_out_off, out_off.data(), nm * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(t_in_len, in_len.data(), nm * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(t_out_len, out_len.data(), nm * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-    lap("H2D compressed bytes");
-    gd::InflateJob ij{};
-    ij.comp = d_in.as<uint8_t>(); ij.in_off = t_in_off; ij.in_len = t_in_len; ij.out_off = t_out_off;
-    ij.out_len = t_out_len; ij.crc = t_crc; ij.out = d_out.as<uint8_t>(); ij.status = t_status; ij.n = (uint32_t)nm;
-    if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
-    hipLaunchKernelGGL(gd::gd_inflate_kernel, dim3((unsigned)((nm + gd::INF_LANES - 1) / gd::INF_LANES)),
-                       dim3(gd::INF_LANES), 0, c->stream, ij);
-    if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
-    lap("inflate kernel");
+    for (hipStream_t s : g->inf_stream) HIPCHK(c, hipStreamSynchronize(s));      // every member is inflated
     std::vector<uint32_t> status(nm);
-    HIPCHK(c, hipMemcpyAsync(status.data(), t_status, nm * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(status.data(), g->t_status, nm * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
 
-    // ---- device: count the records of every anchor segment -------------------------------------
+    // ---- count the records of every anchor segment ----------------------------------------------
+    DevBuf d_seg;
+    const size_t seg_bytes = n_anchors * 5 * sizeof(uint64_t) + n_anchors * 4 * sizeof(uint32_t);
+    if (d_seg.alloc(seg_bytes) != hipSuccess) return fail(c, GD_E_NOMEM, "device allocation for the record walk failed");
     uint64_t* s_beg = d_seg.as<uint64_t>();
     uint64_t* s_end = s_beg + n_anchors;
     uint64_t* s_rbase = s_end + n_anchors;
@@ -1512,7 +1589,7 @@ int gd_ingest_bgzf(gd_ctx* c, int32_t tid, int32_t ref_id, const uint8_t* data, 
     HIPCHK(c, hipMemcpyAsync(s_beg, seg_beg.data(), n_anchors * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(s_end, seg_end.data(), n_anchors * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
     gd::BamSegJob bj{};
-    bj.data = d_out.as<uint8_t>(); bj.n_bytes = total; bj.seg_beg = s_beg; bj.seg_end = s_end; bj.tid = ref_id;
+    bj.data = g->d_out.as<uint8_t>(); bj.n_bytes = total; bj.seg_beg = s_beg; bj.seg_end = s_end; bj.tid = ref_id;
     bj.n_seg = (uint32_t)n_anchors; bj.n_rec = s_nrec; bj.n_ops = s_nops; bj.first_pos = s_first; bj.last_pos = s_last;
     bj.flags = s_flags;
     const unsigned seg_grid = (unsigned)((n_anchors + 63) / 64);
@@ -1526,15 +1603,10 @@ int gd_ingest_bgzf(gd_ctx* c, int32_t tid, int32_t ref_id, const uint8_t* data, 
     HIPCHK(c, hipMemcpyAsync(lastp.data(), s_last, n_anchors * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(flags.data(), s_flags, n_anchors * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    lap("count walk + D2H");
-    if (c->profiling) {
-        float ms = 0;
-        if (hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) c->kernel_ms[GD_K_INFLATE] = ms;
-    }
     for (size_t m = 0; m < nm; ++m)
         if (status[m] != 0)
             return fail(c, GD_E_INVALID, "BGZF member at file offset %llu %s (decoder code %u)",
-                        (unsigned long long)m_coff[m], status[m] == 18 ? "fails its CRC32" : "does not inflate", status[m]);
+                        (unsigned long long)g->m_coff[m], status[m] == 18 ? "fails its CRC32" : "does not inflate", status[m]);
     std::vector<uint64_t> rbase(n_anchors), obase(n_anchors);
     uint64_t N = 0, M = 0;
     int32_t prev_last = -0x7fffffff;
@@ -1552,7 +1624,7 @@ int gd_ingest_bgzf(gd_ctx* c, int32_t tid, int32_t ref_id, const uint8_t* data, 
     if (M > 0xffffffffull) return fail(c, GD_E_RANGE, "more than 2^32 CIGAR ops on contig %d", tid);
     if (N >= kMaxReadsPerContig) return fail(c, GD_E_RANGE, "more than 2^30 records on contig %d", tid);
 
-    // ---- device: extract into the contig's SoA arrays -------------------------------------------
+    // ---- extract into the contig's SoA arrays ----------------------------------------------------
     HIPCHK(c, hipStreamSynchronize(c->copy_stream));
     ContigHost& h = c->contigs[tid];
     {
@@ -1578,13 +1650,66 @@ int gd_ingest_bgzf(gd_ctx* c, int32_t tid, int32_t ref_id, const uint8_t* data, 
         HIPCHK(c, hipMemcpyAsync(h.off + N, &m32, sizeof m32, hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
-    lap("alloc + extract walk");
     h.n_reads = (size_t)N;
     h.n_ops = (size_t)M;
     h.last_pos = prev_last;
     c->computed = false;
     if (n_records) *n_records = N;
     return GD_OK;
+}
+
+// The BGZF members of a byte range (SAMv1 4.1: gzip header with a BC extra subfield).
+int gd_bgzf_members(const uint8_t* data, size_t n_bytes, size_t cap, uint64_t* member_off, uint32_t* member_size,
+                    uint16_t* header_size, uint32_t* isize, uint32_t* crc, size_t* n_members)
+{
+    if (!data || !n_members) return GD_E_INVALID;
+    size_t nm = 0;
+    for (size_t p = 0; p + 18 <= n_bytes;) {
+        const uint8_t* h = data + p;
+        if (h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4)) return GD_E_INVALID;
+        const size_t xlen = (size_t)h[10] | ((size_t)h[11] << 8);
+        if (p + 12 + xlen > n_bytes) break;
+        size_t q = 12, bsize = 0;
+        while (q + 4 <= 12 + xlen) {
+            const size_t slen = (size_t)h[q + 2] | ((size_t)h[q + 3] << 8);
+            if (h[q] == 66 && h[q + 1] == 67 && slen == 2) bsize = ((size_t)h[q + 4] | ((size_t)h[q + 5] << 8)) + 1;
+            q += 4 + slen;
+        }
+        if (bsize < 12 + xlen + 8) return GD_E_INVALID;
+        if (p + bsize > n_bytes) break;                     // a trailing partial member is ignored
+        if (nm < cap) {
+            if (member_off) member_off[nm] = p;
+            if (member_size) member_size[nm] = (uint32_t)bsize;
+            if (header_size) header_size[nm] = (uint16_t)(12 + xlen);
+            if (isize) isize[nm] = (uint32_t)h[bsize - 4] | ((uint32_t)h[bsize - 3] << 8) | ((uint32_t)h[bsize - 2] << 16) |
+                                   ((uint32_t)h[bsize - 1] << 24);
+            if (crc) crc[nm] = (uint32_t)h[bsize - 8] | ((uint32_t)h[bsize - 7] << 8) | ((uint32_t)h[bsize - 6] << 16) |
+                               ((uint32_t)h[bsize - 5] << 24);
+        }
+        ++nm;
+        p += bsize;
+    }
+    *n_members = nm;
+    return nm > cap ? GD_E_CAPACITY : GD_OK;
+}
+
+int gd_ingest_bgzf(gd_ctx* c, int32_t tid, int32_t ref_id, const uint8_t* data, size_t n_bytes, uint64_t base_coffset,
+                   const uint64_t* anchors, size_t n_anchors, uint64_t* n_records)
+{
+    if (!c || !data || !anchors || n_anchors == 0) return GD_E_INVALID;
+    size_t nm = 0;
+    int rc = gd_bgzf_members(data, n_bytes, 0, nullptr, nullptr, nullptr, nullptr, nullptr, &nm);
+    if (rc != GD_OK && rc != GD_E_CAPACITY) return fail(c, GD_E_INVALID, "the range does not start with a BGZF member");
+    if (nm == 0) return fail(c, GD_E_INVALID, "no complete BGZF member in the range");
+    std::vector<uint64_t> moff(nm);
+    std::vector<uint32_t> msize(nm), misize(nm), mcrc(nm);
+    std::vector<uint16_t> mhdr(nm);
+    if (gd_bgzf_members(data, n_bytes, nm, moff.data(), msize.data(), mhdr.data(), misize.data(), mcrc.data(), &nm) != GD_OK)
+        return fail(c, GD_E_INVALID, "corrupt BGZF member table");
+    if (int r = gd_ingest_begin(c, n_bytes, base_coffset, nm, moff.data(), msize.data(), mhdr.data(), misize.data(), mcrc.data()))
+        return r;
+    if (int r = gd_ingest_feed(c, data, n_bytes)) { (void)gd_ingest_abort(c); return r; }
+    return gd_ingest_finish(c, tid, ref_id, anchors, n_anchors, n_records);
 }
 
 int gd_device_perbase(gd_ctx* c, int32_t tid, const int32_t** dptr, int64_t* len)

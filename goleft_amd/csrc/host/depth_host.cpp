@@ -415,18 +415,15 @@ int run(const DArgs& args)
         bool gpu_decode = !(gd_env && gd_env[0] == '0') && gdh::BamReader::linear_index(args.bam, &lin, &err) &&
                           lin.size() == contigs.size();
         if (gpu_decode) {
-            FILE* fb = fopen(args.bam.c_str(), "rb");
-            if (!fb) gpu_decode = false;
-            gdh::PinnedStage stage(ctx);
+            gdh::FileMap fm;
+            if (!fm.open(args.bam)) gpu_decode = false;
             for (size_t w = 0; gpu_decode && w < wanted.size(); ++w) {
                 uint64_t n = 0;
                 bool io_ok = true;
-                const int rc = gdh::ingest_reference_on_device(ctx, fb, lin, wanted[w], wanted[w], &stage, &n, &io_ok);
-                if (rc != GD_OK) { if (fb) fclose(fb); GDCHK(rc); }
+                GDCHK(gdh::ingest_reference_on_device(ctx, fm, lin, wanted[w], wanted[w], &n, &io_ok));
                 if (!io_ok) gpu_decode = false;
                 n_gpu_records += n;
             }
-            if (fb) fclose(fb);
             if (!gpu_decode) GDCHK(gd_reset(ctx));                    // fall back to the host decoder below
         }
         if (!gpu_decode) {

@@ -1,8 +1,13 @@
 // gpu_ingest.hpp -- host side of the device BAM read: which bytes of the file hold one
-// reference's records (from the .bai linear index), read them into page-locked memory and
-// hand them to gd_ingest_bgzf (include/goleft_depth.h), which inflates and decodes on the GPU.
+// reference's records (from the .bai linear index), and streaming them to the device decoder
+// (gd_ingest_begin / _feed / _finish, include/goleft_depth.h: inflate + record decode on the GPU).
 // Shared by `goleft depth` and `multidepth`.
 #pragma once
+
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include <cstdint>
 #include <cstdio>
@@ -13,34 +18,38 @@
 
 namespace gdh {
 
-// Page-locked staging buffer, grown as needed, released with the object.
-struct PinnedStage {
-    gd_ctx* ctx = nullptr;
-    uint8_t* p = nullptr;
-    size_t cap = 0;
-    explicit PinnedStage(gd_ctx* c) : ctx(c) {}
-    PinnedStage(const PinnedStage&) = delete;
-    PinnedStage& operator=(const PinnedStage&) = delete;
-    ~PinnedStage() { if (p) (void)gd_host_free(ctx, p); }
-    int reserve(size_t n)
+// A read-only mapping of a whole file.
+struct FileMap {
+    const uint8_t* p = nullptr;
+    size_t size = 0;
+    FileMap() = default;
+    FileMap(const FileMap&) = delete;
+    FileMap& operator=(const FileMap&) = delete;
+    ~FileMap() { if (p) munmap(const_cast<uint8_t*>(p), size); }
+    bool open(const std::string& path)
     {
-        if (n <= cap) return GD_OK;
-        if (p) { (void)gd_host_free(ctx, p); p = nullptr; cap = 0; }
-        void* q = nullptr;
-        const int rc = gd_host_alloc(ctx, n + n / 4, &q);
-        if (rc != GD_OK) return rc;
-        p = static_cast<uint8_t*>(q);
-        cap = n + n / 4;
-        return GD_OK;
+        const int fd = ::open(path.c_str(), O_RDONLY);
+        if (fd < 0) return false;
+        struct stat st;
+        if (fstat(fd, &st) != 0 || st.st_size <= 0) { ::close(fd); return false; }
+        void* m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+        ::close(fd);
+        if (m == MAP_FAILED) return false;
+        (void)madvise(m, (size_t)st.st_size, MADV_SEQUENTIAL);
+        p = static_cast<const uint8_t*>(m);
+        size = (size_t)st.st_size;
+        return true;
     }
 };
 
 // Records of BAM reference ref_id -> engine contig engine_tid, decoded on the device.
-// lin = BamReader::linear_index() of the file.  Returns GD_OK (with *io_ok = false when the file
-// could not be read as expected: the caller falls back to the host decoder) or a gd_* error.
-inline int ingest_reference_on_device(gd_ctx* ctx, FILE* fb, const std::vector<std::vector<uint64_t>>& lin,
-                                      int32_t ref_id, int32_t engine_tid, PinnedStage* stage, uint64_t* n_records,
-                                      bool* io_ok)
+// lin = BamReader::linear_index() of the file.  The reference's byte range is streamed: its
+// members are listed from the mapping (headers and trailers only), then the bytes are fed in
+// 32 MB pieces -- page-cache reads of the next piece overlap the upload and inflate of the
+// previous ones.  Returns GD_OK (with *io_ok = false when the file does not look as the index
+// says: the caller falls back to the host decoder) or a gd_* error.
+inline int ingest_reference_on_device(gd_ctx* ctx, const FileMap& fm, const std::vector<std::vector<uint64_t>>& lin,
+                                      int32_t ref_id, int32_t engine_tid, uint64_t* n_records, bool* io_ok)
 {
     *io_ok = true;
     *n_records = 0;
@@ -51,14 +60,29 @@ inline int ingest_reference_on_device(gd_ctx* ctx, FILE* fb, const std::vector<s
     uint64_t end = ~0ull;
     for (size_t u = (size_t)ref_id + 1; u < lin.size(); ++u)
         if (!lin[u].empty()) { end = (lin[u].front() >> 16) + 65536 + 26; break; }
-    if (fseeko(fb, 0, SEEK_END) != 0) { *io_ok = false; return GD_OK; }
-    const uint64_t fsize = (uint64_t)ftello(fb);
-    if (end > fsize) end = fsize;
-    if (beg >= end || fseeko(fb, (off_t)beg, SEEK_SET) != 0) { *io_ok = false; return GD_OK; }
+    if (end > fm.size) end = fm.size;
+    if (beg >= end) { *io_ok = false; return GD_OK; }
+    const uint8_t* base = fm.p + beg;
     const size_t nb = (size_t)(end - beg);
-    if (int rc = stage->reserve(nb)) return rc;
-    if (fread(stage->p, 1, nb, fb) != nb) { *io_ok = false; return GD_OK; }
-    return gd_ingest_bgzf(ctx, engine_tid, ref_id, stage->p, nb, beg, a.data(), a.size(), n_records);
+    size_t nm = 0;
+    int rc = gd_bgzf_members(base, nb, 0, nullptr, nullptr, nullptr, nullptr, nullptr, &nm);
+    if ((rc != GD_OK && rc != GD_E_CAPACITY) || nm == 0) { *io_ok = false; return GD_OK; }
+    std::vector<uint64_t> moff(nm);
+    std::vector<uint32_t> msize(nm), misize(nm), mcrc(nm);
+    std::vector<uint16_t> mhdr(nm);
+    if (gd_bgzf_members(base, nb, nm, moff.data(), msize.data(), mhdr.data(), misize.data(), mcrc.data(), &nm) != GD_OK) {
+        *io_ok = false;
+        return GD_OK;
+    }
+    const size_t used = (size_t)(moff[nm - 1] + msize[nm - 1]);   // a trailing partial member is not fed
+    rc = gd_ingest_begin(ctx, used, beg, nm, moff.data(), msize.data(), mhdr.data(), misize.data(), mcrc.data());
+    if (rc != GD_OK) return rc;
+    const size_t piece = 32u << 20;
+    for (size_t off = 0; off < used; off += piece) {
+        rc = gd_ingest_feed(ctx, base + off, used - off < piece ? used - off : piece);
+        if (rc != GD_OK) { (void)gd_ingest_abort(ctx); return rc; }
+    }
+    return gd_ingest_finish(ctx, engine_tid, ref_id, a.data(), a.size(), n_records);
 }
 
 }  // namespace gdh

@@ -297,14 +297,11 @@ int run(const MArgs& a, FILE* out)
         // with a .bai: the file's bytes of this reference are inflated and decoded on the device
         std::vector<std::vector<uint64_t>> lin;
         if (want_gpu && gdh::BamReader::linear_index(a.bams[(size_t)s], &lin, &err) && (size_t)want < lin.size()) {
-            FILE* fb = fopen(a.bams[(size_t)s].c_str(), "rb");
-            if (fb) {
-                gdh::PinnedStage stage(ctx);
+            gdh::FileMap fm;
+            if (fm.open(a.bams[(size_t)s])) {
                 uint64_t n = 0;
                 bool io_ok = true;
-                const int rc = gdh::ingest_reference_on_device(ctx, fb, lin, want, s, &stage, &n, &io_ok);
-                fclose(fb);
-                if (rc != GD_OK) MDCHK(rc);
+                MDCHK(gdh::ingest_reference_on_device(ctx, fm, lin, want, s, &n, &io_ok));
                 if (io_ok) continue;
             }
         }

@@ -306,6 +306,22 @@ int gd_inflate_bgzf(gd_ctx* ctx, const uint8_t* data, size_t n_bytes, size_t n_m
  * start), GD_E_UNSORTED. */
 int gd_ingest_bgzf(gd_ctx* ctx, int32_t tid, int32_t ref_id, const uint8_t* data, size_t n_bytes,
                    uint64_t base_coffset, const uint64_t* anchors, size_t n_anchors, uint64_t* n_records);
+/* The same read as a stream, so that file I/O overlaps the device work: list the range's
+ * members first (gd_bgzf_members, headers and trailers only), announce them
+ * (gd_ingest_begin: allocations), then feed the range's bytes in order in pieces of any
+ * size -- each piece is copied into page-locked staging (the pointer is not retained),
+ * uploaded asynchronously, and every member that is complete on the device is inflated
+ * behind the copy while the caller reads the next piece -- and finish with the anchors.
+ * gd_ingest_bgzf is begin + one feed + finish.  gd_ingest_abort drops an unfinished read. */
+int gd_bgzf_members(const uint8_t* data, size_t n_bytes, size_t cap, uint64_t* member_off, uint32_t* member_size,
+                    uint16_t* header_size, uint32_t* isize, uint32_t* crc, size_t* n_members);
+int gd_ingest_begin(gd_ctx* ctx, uint64_t n_bytes, uint64_t base_coffset, size_t n_members,
+                    const uint64_t* member_off, const uint32_t* member_size, const uint16_t* header_size,
+                    const uint32_t* isize, const uint32_t* crc);
+int gd_ingest_feed(gd_ctx* ctx, const uint8_t* bytes, size_t n);
+int gd_ingest_finish(gd_ctx* ctx, int32_t tid, int32_t ref_id, const uint64_t* anchors, size_t n_anchors,
+                     uint64_t* n_records);
+int gd_ingest_abort(gd_ctx* ctx);
 /* Page-locked host memory for the byte range handed to gd_ingest_bgzf (read the file
  * straight into it: the H2D copy then runs at PCIe speed instead of through a bounce
  * buffer).  Plain pageable memory works too, only slower. */

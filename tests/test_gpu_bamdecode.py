@@ -148,6 +148,25 @@ def test_ingest_many_anchors_and_long_cigars(tmp_path):
         assert eng.perbase(1).sum() == 0
 
 
+@pytest.mark.parametrize("piece", [1 << 30, 70_001, 4096, 333])
+def test_ingest_streamed_in_pieces(tmp_path, piece):
+    # the same read fed in pieces: members complete at arbitrary feed boundaries
+    from goleft_amd.engine import DepthEngine
+    contigs, reads, _ = H.load_golden_bam("t")
+    p = str(tmp_path / "a.bam")
+    bamio.write_bam(p, contigs, reads, unplaced=3, index=True)
+    data = open(p, "rb").read()
+    lin = bamio.read_bai_linear(p + ".bai")
+    with DepthEngine(0) as eng:
+        eng.set_params(window_size=100, min_mapq=1, min_cov=4)
+        eng.set_contigs([c[1] for c in contigs])
+        for tid in (0, 1):
+            assert eng.ingest_bgzf_stream(tid, data, 0, lin[tid], piece) == reads[tid].n
+        eng.compute()
+        for tid, (_, L) in enumerate(contigs):
+            assert np.array_equal(eng.perbase(tid), po.perbase_c(reads[tid], 1, 0, L))
+
+
 def test_ingest_rejects_stale_anchor_and_corrupt_data(tmp_path):
     from goleft_amd.engine import DepthEngine, GdError
     contigs, reads, _ = H.load_golden_bam("t")
