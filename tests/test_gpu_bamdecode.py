@@ -185,3 +185,43 @@ def test_ingest_rejects_stale_anchor_and_corrupt_data(tmp_path):
         with pytest.raises(GdError):
             eng.ingest_bgzf(1, bytes(bad), 0, anchors)
         assert eng.ingest_bgzf(1, data, 0, anchors) == reads[1].n     # the context is still usable
+
+
+def test_ingest_state_errors_and_pinned_alloc(tmp_path):
+    import ctypes as C
+    from goleft_amd import _lib
+    from goleft_amd.engine import DepthEngine, GdError
+    lib = _lib.load()
+    contigs, reads, _ = H.load_golden_bam("t")
+    p = str(tmp_path / "a.bam")
+    bamio.write_bam(p, contigs, reads, index=True)
+    data = open(p, "rb").read()
+    anchors = bamio.read_bai_linear(p + ".bai")[0]
+    with DepthEngine(0) as eng:
+        eng.set_contigs([c[1] for c in contigs])
+        raw = np.frombuffer(data, np.uint8)
+        assert lib.gd_ingest_feed(eng._ctx, raw.ctypes.data, 10) == -4            # GD_E_STATE: no begin
+        cnt = C.c_uint64()
+        a = np.ascontiguousarray(anchors, np.uint64)
+        assert lib.gd_ingest_finish(eng._ctx, 0, 0, a.ctypes.data, a.size, C.byref(cnt)) == -4
+        # begin, feed only half, finish -> refused, and the context recovers
+        nm = C.c_size_t()
+        lib.gd_bgzf_members(raw.ctypes.data, raw.size, 0, None, None, None, None, None, C.byref(nm))
+        n = nm.value
+        moff, msize, mhdr = np.zeros(n, np.uint64), np.zeros(n, np.uint32), np.zeros(n, np.uint16)
+        misz, mcrc = np.zeros(n, np.uint32), np.zeros(n, np.uint32)
+        assert lib.gd_bgzf_members(raw.ctypes.data, raw.size, n, moff.ctypes.data, msize.ctypes.data, mhdr.ctypes.data,
+                                   misz.ctypes.data, mcrc.ctypes.data, C.byref(nm)) == 0
+        used = int(moff[-1]) + int(msize[-1])
+        assert used == raw.size
+        assert lib.gd_ingest_begin(eng._ctx, used, 0, n, moff.ctypes.data, msize.ctypes.data, mhdr.ctypes.data,
+                                   misz.ctypes.data, mcrc.ctypes.data) == 0
+        assert lib.gd_ingest_feed(eng._ctx, raw.ctypes.data, used // 2) == 0
+        assert lib.gd_ingest_finish(eng._ctx, 0, 0, a.ctypes.data, a.size, C.byref(cnt)) == -4
+        assert lib.gd_ingest_feed(eng._ctx, raw.ctypes.data, 10) == -4            # finish released the read
+        assert eng.ingest_bgzf(0, data, 0, anchors) == reads[0].n
+        # page-locked staging for callers that read the file themselves
+        ptr = C.c_void_p()
+        assert lib.gd_host_alloc(eng._ctx, 1 << 20, C.byref(ptr)) == 0 and ptr.value
+        C.memset(ptr, 7, 1 << 20)
+        assert lib.gd_host_free(eng._ctx, ptr) == 0
