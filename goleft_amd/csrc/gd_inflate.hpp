@@ -231,8 +231,27 @@ __global__ __launch_bounds__(INF_LANES) void gd_inflate_kernel(InflateJob job)
         HuffCnt cl, cd;
         cl.load(hl);
         cd.load(hd);
+        // Short matches far enough back (the common case) are DEFERRED: their 16 source bytes are
+        // loaded now and stored only after the next symbol has been decoded, so the global load
+        // latency overlaps that decode instead of stalling the wave (with 64 lanes in 64 different
+        // places, nearly every step has some lane copying).  Bytes past the match length that the
+        // 16-byte store also writes are overwritten by the output that follows.
+        uint32_t pw0 = 0, pw1 = 0, pw2 = 0, pw3 = 0, pend_o = 0;
+        int pend_n = 0;
+        auto flush = [&]() {
+            if (pend_n == 0) return;
+            if (pend_o + 16u <= olen) {
+                __builtin_memcpy(out + pend_o, &pw0, 4); __builtin_memcpy(out + pend_o + 4, &pw1, 4);
+                __builtin_memcpy(out + pend_o + 8, &pw2, 4); __builtin_memcpy(out + pend_o + 12, &pw3, 4);
+            } else {                                       // next to the member's end: exactly the match
+                const uint32_t w[4] = {pw0, pw1, pw2, pw3};
+                for (int k = 0; k < pend_n; ++k) out[pend_o + k] = (uint8_t)(w[k >> 2] >> (8 * (k & 3)));
+            }
+            pend_n = 0;
+        };
         for (;;) {
             const int sym = huff_decode(br, hl, cl);
+            flush();
             if (sym < 0) { err = 13; break; }
             if (sym < 256) {
                 if (o >= olen) { err = 3; break; }
@@ -256,6 +275,15 @@ __global__ __launch_bounds__(INF_LANES) void gd_inflate_kernel(InflateJob job)
                 else { const int e = (ds >> 1) - 1; dist = 1u + ((2u + (uint32_t)(ds & 1)) << e) + br.bits(e); }
                 if (br.bad) { err = 1; break; }
                 if (dist > o || o + len > olen) { err = 16; break; }
+                if (dist >= 16 && len <= 16) {
+                    const uint8_t* src = out + o - dist;    // src + 16 <= out + o: only finished bytes are read
+                    __builtin_memcpy(&pw0, src, 4); __builtin_memcpy(&pw1, src + 4, 4);
+                    __builtin_memcpy(&pw2, src + 8, 4); __builtin_memcpy(&pw3, src + 12, 4);
+                    pend_o = o;
+                    pend_n = (int)len;
+                    o += len;
+                    continue;
+                }
                 uint32_t k = 0;
                 if (dist < 4) {
                     // run-length style matches (distance 1..3, up to 258 bytes): the pattern is read
@@ -299,6 +327,7 @@ __global__ __launch_bounds__(INF_LANES) void gd_inflate_kernel(InflateJob job)
                 for (; k < len; ++k, ++o) out[o] = out[o - dist];
             }
         }
+        flush();                                           // a match deferred by the block's last step
     }
     if (err == 0 && (o != olen || br.bad)) err = 17;
     if (err == 0 && job.crc) {
