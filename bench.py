@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--samples", type=int, default=200, help="cohort workload: number of chr1 samples")
     ap.add_argument("--wed-size", type=int, default=1000, help="cohort workload: depthwed -s")
+    ap.add_argument("--cohort-outputs", default="sums", choices=["sums", "windows"],
+                    help="cohort workload: window sums only (default; all depthwed needs) or sums + minima + class runs")
     ap.add_argument("--workload", default="wgs", choices=["wgs", "chr20", "ont", "ont-chr20", "cohort"],
                     help="wgs/chr20: 30x 150 bp short reads (headline); ont/ont-chr20: 20x long reads "
                          "(BASELINE.json config 5, chunk path)")
@@ -198,7 +200,9 @@ def run_case(args, scaling, world, rank, dev, local_rank, want_streams=False):
     eng = DepthEngine(local_rank)
     eng.set_params(window_size=W, min_mapq=Q, min_cov=mincov)
     if cohort:
-        eng.set_outputs(perbase=False)
+        # depthwed only needs window sums: GD_OUT_SUMS_ONLY (read/window overlaps, no per-base scan);
+        # --cohort-outputs windows keeps minima and class runs (the regular windows-only kernel)
+        eng.set_outputs(perbase=False, sums_only=args.cohort_outputs == "sums")
     eng.set_contigs(lengths)
     eng.select_contigs(mine)
     n_reads = n_ops = 0
@@ -331,8 +335,9 @@ def main():
 
     # PCIe-inclusive rate (results to host) -- reported, never `value`
     t1 = time.perf_counter()
+    sums_only = args.workload == "cohort" and args.cohort_outputs == "sums"
     for t in mine[:48]:
-        eng.windows(t)
+        eng.window_sums(t) if sums_only else eng.windows(t)
     d2h = (time.perf_counter() - t1) * (len(mine) / max(1, min(len(mine), 48)))
     d2h_matrix = None
     if args.workload == "cohort":
@@ -363,8 +368,9 @@ def main():
                    "sharding": ("single GPU" if world == 1 else
                                 "by sample (one genome per GPU, no exchange)" if args.scaling == "weak" else
                                 "by chromosome, LPT, RCCL gather of window sums/minima + class runs to rank 0"),
-                   "outputs": ("int32 per-base depth + " if r["perbase"] else "(windows-only) ") +
-                              "int64/int32 window sum/min + class runs" +
+                   "outputs": ("(sums-only) int64 window sums" if (args.workload == "cohort" and args.cohort_outputs == "sums") else
+                               ("int32 per-base depth + " if r["perbase"] else "(windows-only) ") +
+                               "int64/int32 window sum/min + class runs") +
                               (" + depthwed matrix %s" % r["wed_shape"] if r["wed_shape"] else ""),
                    "tile_positions": r["tile_positions"], "lookback": r["lookback"],
                    "device_path": "scatter" if scatter else "chunk" if chunk else "tile"},

@@ -78,6 +78,8 @@ struct gd_ctx {
     bool lookback_pinned = false;       // max_span_hint given: never shrink below it
     int path = GD_PATH_AUTO;            // gd_set_path / GOLEFT_GD_PATH
     bool keep_perbase = true;           // gd_set_outputs(GD_OUT_PERBASE)
+    bool sums_only = false;             // gd_set_outputs(GD_OUT_SUMS_ONLY): window sums, nothing else
+    bool ran_sums_only = false;         // what the last gd_compute produced
     bool scope_wg = false;              // debug: GOLEFT_GD_SCOPE=wg (wrong results, timing only)
     bool span_forces_long = false;      // AUTO: the tile path met a read too long for it
     unsigned long long* d_status = nullptr;  size_t cap_status = 0;   // scatter path look-back words
@@ -225,6 +227,10 @@ void launch_tile(gd_ctx* c, const gd::Job& job)
 {
     // 8 XCDs: the grid is 8 equal slices of the tile list (see the kernel)
     const unsigned grid = (unsigned)(((job.n_tiles + 7) / 8) * 8);
+    if (c->ran_sums_only) {                                 // decided by gd_compute for this run
+        hipLaunchKernelGGL((gd::v7::gd_tile_sums_kernel<4096, 256>), dim3(grid), dim3(256), 0, c->stream, job);
+        return;
+    }
     if (c->kernel_gen == 7 && T == 4096 && NT == 256) {     // v7 is built for the default shape only
         if (!c->keep_perbase)
             hipLaunchKernelGGL((gd::v7::gd_tile_kernel<4096, 256, 2>), dim3(grid), dim3(256), 0, c->stream, job);
@@ -454,8 +460,11 @@ int gd_set_path(gd_ctx* c, int path)
 int gd_set_outputs(gd_ctx* c, unsigned flags)
 {
     if (!c) return GD_E_INVALID;
-    if (flags & ~(unsigned)GD_OUT_PERBASE) return fail(c, GD_E_INVALID, "unknown output flags 0x%x", flags);
+    if (flags & ~(unsigned)(GD_OUT_PERBASE | GD_OUT_SUMS_ONLY)) return fail(c, GD_E_INVALID, "unknown output flags 0x%x", flags);
+    if ((flags & GD_OUT_PERBASE) && (flags & GD_OUT_SUMS_ONLY))
+        return fail(c, GD_E_INVALID, "GD_OUT_SUMS_ONLY excludes GD_OUT_PERBASE");
     c->keep_perbase = (flags & GD_OUT_PERBASE) != 0;
+    c->sums_only = (flags & GD_OUT_SUMS_ONLY) != 0;
     c->computed = false;
     return GD_OK;
 }
@@ -794,6 +803,7 @@ int gd_compute(gd_ctx* c)
         job.tile_status = c->d_status;
 
         // which device algorithm (include/goleft_depth.h GD_PATH_*)
+        c->ran_sums_only = false;
         const bool scatter = c->path == GD_PATH_SCATTER;
         const bool chunk = c->path == GD_PATH_CHUNK ||
                            (c->path == GD_PATH_AUTO && (c->span_forces_long || n_ops > 6 * n_reads));
@@ -835,6 +845,9 @@ int gd_compute(gd_ctx* c)
                                c->d_super_cnt, c->d_ordered, (int)c->n_tiles);
             if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
         } else if (!scatter) {
+            // sums-only: built for the default tile shape; W < 32 (more windows per tile than the
+            // LDS accumulators hold) keeps the regular windows-only kernel
+            c->ran_sums_only = c->sums_only && T == 4096 && c->tile_NT == 256 && P.window_size >= 32;
             if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
             switch (T) {
             case 8192: launch_prep<8192>(c, job); break;
@@ -851,9 +864,10 @@ int gd_compute(gd_ctx* c)
                 }
             }
             if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
-            hipLaunchKernelGGL(gd::gd_runs_order_kernel, dim3(runs_grid), dim3(gd::SUPER), 0,
-                               c->stream, c->d_chunks, job.run_cap, c->d_tile_cnt, c->d_tile_off,
-                               c->d_super_cnt, c->d_ordered, (int)c->n_tiles);
+            if (!c->ran_sums_only)                        // no class runs in sums-only mode
+                hipLaunchKernelGGL(gd::gd_runs_order_kernel, dim3(runs_grid), dim3(gd::SUPER), 0,
+                                   c->stream, c->d_chunks, job.run_cap, c->d_tile_cnt, c->d_tile_off,
+                                   c->d_super_cnt, c->d_ordered, (int)c->n_tiles);
             if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
         } else {
             if (int r = ensure_dev(c, &c->d_status, &c->cap_status, (size_t)c->n_tiles)) return r;
@@ -1018,6 +1032,7 @@ int gd_windows(gd_ctx* c, int32_t tid, int64_t* sums, int32_t* mins, size_t cap,
     *n = (size_t)h.n_win;
     if (h.n_win == 0) return GD_OK;
     if (cap < (size_t)h.n_win || !sums) return fail(c, GD_E_CAPACITY, "need room for %lld windows", (long long)h.n_win);
+    if (mins && c->ran_sums_only) return fail(c, GD_E_STATE, "window minima were not produced (GD_OUT_SUMS_ONLY)");
     HIPCHK(c, hipMemcpy(sums, c->d_wsum + h.win_off, (size_t)h.n_win * sizeof(int64_t), hipMemcpyDeviceToHost));
     if (mins)
         HIPCHK(c, hipMemcpy(mins, c->d_wmin + h.win_off, (size_t)h.n_win * sizeof(int32_t), hipMemcpyDeviceToHost));
@@ -1028,6 +1043,7 @@ int gd_callable(gd_ctx* c, int32_t tid, gd_run* out, size_t cap, size_t* n)
 {
     if (!c || !n) return GD_E_INVALID;
     if (int r = check_result_tid(c, tid)) return r;
+    if (c->ran_sums_only) return fail(c, GD_E_STATE, "coverage-class runs were not produced (GD_OUT_SUMS_ONLY)");
     const ContigHost& h = c->contigs[tid];
     const size_t k = h.run_end - h.run_beg;
     *n = k;

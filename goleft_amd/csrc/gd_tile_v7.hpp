@@ -33,10 +33,64 @@ __device__ __forceinline__ uint32_t div_magic(uint32_t x, uint32_t m, uint32_t s
     return (uint32_t)(((unsigned long long)x * (unsigned long long)m) >> s);
 }
 
-// Phase A for one wave, U = 4 reads per lane and batch of NT*4.
-template <int NT, bool STAGED>
+// ---- sums-only output (GD_OUT_SUMS_ONLY: what depth.bed means and the depthwed matrix need) ---
+// The sum of the depth over a window equals the sum over reads of their overlap with the window,
+// so no per-base vector has to exist at all: every counted interval adds its overlap lengths to
+// the (one or two) windows it touches, in 64-bit LDS accumulators of the tile.
+struct SumSink {
+    unsigned long long* acc;     // [T / 32 + 2] window accumulators of the tile (LDS)
+    uint32_t r0;                 // position of t0 inside its window
+    uint32_t W, w_magic, w_shift;
+    int tlen;
+};
+
+// counted interval [s, e) in tile-relative positions (may stick out on both sides)
+__device__ __forceinline__ void add_interval(const SumSink& S, int s, int e)
+{
+    const int cs = s > 0 ? s : 0, ce = e < S.tlen ? e : S.tlen;
+    if (ce <= cs) return;
+    const uint32_t a = (uint32_t)cs + S.r0, b = (uint32_t)(ce - 1) + S.r0;      // window-space offsets, < 2^31
+    const uint32_t ks = div_magic(a, S.w_magic, S.w_shift), ke = div_magic(b, S.w_magic, S.w_shift);
+    if (ks == ke) {
+        atomicAdd(&S.acc[ks], (unsigned long long)(uint32_t)(ce - cs));
+    } else {
+        for (uint32_t k = ks; k <= ke; ++k) {
+            const long long lo_w = (long long)k * S.W - S.r0, hi_w = lo_w + S.W;   // the window in tile positions
+            const int lo = lo_w > cs ? (int)lo_w : cs, hi = hi_w < ce ? (int)hi_w : ce;
+            atomicAdd(&S.acc[k], (unsigned long long)(uint32_t)(hi - lo));
+        }
+    }
+}
+
+// walk_cigar4 for the sums-only sink (ps4 is the read's start, tile relative, times 4)
+template <typename OpPtr>
+__device__ __forceinline__ uint32_t walk_cigar_sums(OpPtr ops, uint32_t n, int ps4, const SumSink& S)
+{
+    uint32_t span = 0;
+    const int ps = ps4 >> 2;
+    for (uint32_t k = 0; k < n; ++k) {
+        const uint32_t cg = ops[k];
+        const uint32_t op = cg & 0xf, len = cg >> 4;
+        const bool counted = (0x181u >> op) & 1u;     // M = X
+        const bool consumes = (0x18du >> op) & 1u;    // M D N = X
+        if (counted && len != 0 && span < SPAN_SAT) {
+            const long long s = (long long)ps + span;
+            if (s < S.tlen) {
+                const long long e = s + len;
+                add_interval(S, s < -1 ? -1 : (int)s, e > S.tlen ? S.tlen : (int)e);
+            }
+        }
+        if (consumes) { span += len; span = span < SPAN_SAT ? span : SPAN_SAT; }
+    }
+    return span;
+}
+
+// Phase A for one wave, U = 4 reads per lane and batch of NT*4.  SUMS: intervals go to a SumSink
+// (window accumulators) instead of +1/-1 marks.
+template <int NT, bool STAGED, bool SUMS = false>
 __device__ __forceinline__ uint32_t phase_a(const PhaseA& A, int32_t (&p)[4], uint32_t (&f)[4],
-                                            uint32_t (&mq)[4], uint32_t (&o0)[4], uint32_t (&o1)[4])
+                                            uint32_t (&mq)[4], uint32_t (&o0)[4], uint32_t (&o1)[4],
+                                            const SumSink* sink = nullptr)
 {
     constexpr int U = 4;
     const int tid = A.tid, lane = A.lane;
@@ -51,8 +105,12 @@ __device__ __forceinline__ uint32_t phase_a(const PhaseA& A, int32_t (&p)[4], ui
         if ((uint32_t)lane < cnt) {
             const int qp = (int)wq[lane];
             const uint32_t qo = wq[WAVE + lane], qk = wq[2 * WAVE + lane];
-            const uint32_t span = STAGED ? walk_cigar4(A.s_cig + (qo - A.clo), qk, qp, A.T4, A.s_diff)
-                                         : walk_cigar4(A.gcig + qo, qk, qp, A.T4, A.s_diff);
+            uint32_t span;
+            if constexpr (SUMS)
+                span = STAGED ? walk_cigar_sums(A.s_cig + (qo - A.clo), qk, qp, *sink) : walk_cigar_sums(A.gcig + qo, qk, qp, *sink);
+            else
+                span = STAGED ? walk_cigar4(A.s_cig + (qo - A.clo), qk, qp, A.T4, A.s_diff)
+                              : walk_cigar4(A.gcig + qo, qk, qp, A.T4, A.s_diff);
             smax = span > smax ? span : smax;
         }
         __builtin_amdgcn_wave_barrier();
@@ -104,7 +162,9 @@ __device__ __forceinline__ uint32_t phase_a(const PhaseA& A, int32_t (&p)[4], ui
             const uint32_t rs = simple ? r[u] : 0u;
             smax = rs > smax ? rs : smax;
             const int e4 = ps4[u] + (int)(r[u] << 2);
-            if (simple & (e4 >= 0)) {                             // reaches t0-1 or beyond
+            if constexpr (SUMS) {
+                if (simple & (e4 > 0)) add_interval(*sink, ps4[u] >> 2, e4 >> 2);   // overlaps [0, tlen)
+            } else if (simple & (e4 >= 0)) {                      // reaches t0-1 or beyond
                 const int cs4 = ps4[u] > -4 ? ps4[u] : -4;
                 atomicAdd(lds_at(A.s_diff, cs4), 1);
                 if (e4 < A.T4) atomicAdd(lds_at(A.s_diff, e4), -1);
@@ -520,6 +580,90 @@ __global__ __launch_bounds__(NT) void gd_tile_kernel(Job job)
 
     // ---- phase C: compact class boundaries of this tile -------------------
     phase_c<T, NT>(job, tile, t0, ti.ctg, tid, lane, wv, s_bmap, s_clo, s_chi, s_wcnt, &s_hasb, &s_base);
+}
+
+
+// K1s: the tile kernel for GD_OUT_SUMS_ONLY.  Same read selection, filter, staging and look-back
+// verification as gd_tile_kernel; phase A feeds window accumulators, phases B and C do not exist.
+template <int T, int NT>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void gd_tile_sums_kernel(Job job)
+{
+    constexpr int NW = NT / WAVE;
+    constexpr int CQ = (T * 3) / 8;
+    constexpr int U = 4;
+    constexpr int CCH = (CQ + NT - 1) / NT;
+    constexpr int NACC = T / 32 + 2;       // windows a tile can touch when W >= 32
+
+    __shared__ unsigned long long s_acc[NACC];
+    __shared__ uint32_t s_cig[CQ];
+    __shared__ uint32_t s_wq[NW * 3 * WAVE];
+
+    const int per = (job.n_tiles + 7) >> 3;
+    const int tile = (int)(blockIdx.x & 7u) * per + (int)(blockIdx.x >> 3);
+    if (tile >= job.n_tiles) return;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & (WAVE - 1);
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const TileInfo ti = job.tiles[tile];
+    const int seen0 = __hip_atomic_load(&job.counters->max_span, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int32_t t0 = ti.t0;
+    const int32_t tend = t0 + T < ti.length ? t0 + T : ti.length;
+    const int tlen = tend - t0;
+
+    const uint32_t nrd = ti.hi - ti.lo;
+    const uint32_t nst = ti.chi - ti.clo;
+    const bool staged = nst <= (uint32_t)CQ;
+    const rsrc_t r_pos = make_rsrc(ti.pos + ti.lo, nrd * 4u);
+    const rsrc_t r_flag = make_rsrc(ti.flag + ti.lo, nrd * 2u);
+    const rsrc_t r_mapq = make_rsrc(ti.mapq + ti.lo, nrd);
+    const rsrc_t r_off0 = make_rsrc(ti.off + ti.lo, nrd * 4u);
+    const rsrc_t r_off1 = make_rsrc(ti.off + ti.lo + 1, nrd * 4u);
+    const rsrc_t r_cig = make_rsrc(ti.cigar + ti.clo, staged ? nst * 4u : 0u);
+    const int tid4 = tid * 4, tid2 = tid * 2;
+    int32_t  p[U];
+    uint32_t f[U], mq[U], o0[U], o1[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        p[u]  = __builtin_amdgcn_raw_buffer_load_b32(r_pos, tid4 + u * NT * 4, 0, 0);
+        f[u]  = __builtin_amdgcn_raw_buffer_load_b16(r_flag, tid2 + u * NT * 2, 0, 0);
+        mq[u] = __builtin_amdgcn_raw_buffer_load_b8(r_mapq, tid + u * NT, 0, 0);
+        o0[u] = __builtin_amdgcn_raw_buffer_load_b32(r_off0, tid4 + u * NT * 4, 0, 0);
+        o1[u] = __builtin_amdgcn_raw_buffer_load_b32(r_off1, tid4 + u * NT * 4, 0, 0);
+    }
+    uint32_t cgv[CCH];
+#pragma unroll
+    for (int k = 0; k < CCH; ++k)
+        cgv[k] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r_cig, tid4 + k * NT * 4, 0, 0);
+    for (int i = tid; i < NACC; i += NT) s_acc[i] = 0ull;
+#pragma unroll
+    for (int k = 0; k < CCH; ++k)
+        if (k * NT + tid < CQ) s_cig[k * NT + tid] = cgv[k];
+    __syncthreads();
+
+    const uint32_t w_first = div_magic((uint32_t)t0, job.w_magic, job.w_shift);
+    SumSink S;
+    S.acc = s_acc; S.r0 = (uint32_t)t0 - w_first * (uint32_t)job.W; S.W = (uint32_t)job.W;
+    S.w_magic = job.w_magic; S.w_shift = job.w_shift; S.tlen = tlen;
+    if (nrd != 0) {
+        PhaseA A;
+        A.pos = ti.pos + ti.lo; A.flag = ti.flag + ti.lo; A.mapq = ti.mapq + ti.lo; A.off = ti.off + ti.lo;
+        A.s_diff = nullptr; A.s_cig = s_cig; A.wq = &s_wq[wv * (3 * WAVE)];
+        A.gcig = ti.cigar; A.clo = ti.clo; A.nrd = nrd;
+        A.neg4t0 = (int)(0u - ((uint32_t)t0 << 2));
+        A.T4 = tlen * 4; A.flag_mask = job.flag_mask; A.Q = job.Q; A.tid = tid; A.lane = lane;
+        const uint32_t smax = staged ? phase_a<NT, true, true>(A, p, f, mq, o0, o1, &S)
+                                     : phase_a<NT, false, true>(A, p, f, mq, o0, o1, &S);
+        if (smax > (uint32_t)seen0) atomicMax(&job.counters->max_span, (int32_t)smax);
+    }
+    __syncthreads();
+    // the tile's share of every window it touches
+    const uint32_t n_touch = div_magic((uint32_t)(tlen - 1) + S.r0, job.w_magic, job.w_shift) + 1u;
+    unsigned long long* const wsum = reinterpret_cast<unsigned long long*>(job.win_sum + ti.win_off) + w_first;
+    for (uint32_t k = (uint32_t)tid; k < n_touch && k < (uint32_t)NACC; k += NT) {
+        const unsigned long long v = s_acc[k];
+        if (v) atomicAdd(&wsum[k], v);
+    }
 }
 
 }  // namespace v7

@@ -73,9 +73,10 @@ class DepthEngine:
         """PATH_AUTO / PATH_TILE / PATH_SCATTER / PATH_CHUNK (include/goleft_depth.h GD_PATH_*)."""
         self._chk(self._lib.gd_set_path(self._ctx, int(path)))
 
-    def set_outputs(self, perbase: bool = True):
-        """perbase=False: windows + class runs only (no 4 B/base vector in HBM)."""
-        self._chk(self._lib.gd_set_outputs(self._ctx, 1 if perbase else 0))
+    def set_outputs(self, perbase: bool = True, sums_only: bool = False):
+        """perbase=False: windows + class runs only (no 4 B/base vector in HBM);
+        sums_only=True: window sums and nothing else (GD_OUT_SUMS_ONLY)."""
+        self._chk(self._lib.gd_set_outputs(self._ctx, 2 if sums_only else (1 if perbase else 0)))
 
     def set_contigs(self, lengths: Sequence[int]):
         a = np.asarray(lengths, dtype=np.int64)
@@ -149,6 +150,17 @@ class DepthEngine:
         out = np.empty(max(0, end - start), np.int32)
         self._chk(self._lib.gd_perbase(self._ctx, tid, start, end, out.ctypes.data))
         return out
+
+    def window_sums(self, tid: int) -> np.ndarray:
+        """int64 window sums only (works in every output mode)."""
+        n = C.c_size_t()
+        rc = self._lib.gd_windows(self._ctx, tid, None, None, 0, C.byref(n))
+        if rc not in (0, -8):
+            self._chk(rc)
+        sums = np.zeros(n.value, np.int64)
+        if n.value:
+            self._chk(self._lib.gd_windows(self._ctx, tid, sums.ctypes.data, None, n.value, C.byref(n)))
+        return sums
 
     def windows(self, tid: int):
         n = C.c_size_t()

@@ -159,7 +159,14 @@ int gd_set_path(gd_ctx* ctx, int path);
  * gd_device_perbase and the --bed region reductions.  Without it only window
  * sums/minima and class runs are produced -- all `goleft depth` prints for a whole
  * genome, and what a cohort (depthwed) needs; tile and chunk paths only. */
-enum { GD_OUT_PERBASE = 1 };
+enum { GD_OUT_PERBASE = 1,
+       /* Window sums ONLY (no per-base vector, no minima, no class runs): all that depth.bed's mean
+        * column and the depthwed matrix need.  The tile path then adds every read interval's overlap
+        * with the one or two windows it touches straight into per-tile accumulators -- no per-base
+        * scan at all (window_size >= 32; smaller windows and the long-read path silently run the
+        * regular windows-only kernels).  gd_callable and minima report GD_E_STATE.  Excludes
+        * GD_OUT_PERBASE. */
+       GD_OUT_SUMS_ONLY = 2 };
 int gd_set_outputs(gd_ctx* ctx, unsigned flags);
 
 /* Reference sequence table (@SQ LN of the BAM header / .fai lengths,
