@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--length", type=int, default=63025520)
+    ap.add_argument("--length", default="63025520", help="contig length, or several separated by commas")
     ap.add_argument("--coverage", type=float, default=30.0)
     ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("--window", type=int, default=1000)
@@ -27,7 +27,8 @@ def main():
     bam = os.path.join(d, "synth.bam")
     t0 = time.perf_counter()
     info = json.loads(subprocess.check_output([os.path.join(ROOT, "goleft_amd", "synth-bam"), bam, "chr20",
-                                               str(args.length), str(args.coverage), "20"]).decode())
+                                               args.length, str(args.coverage), "20"]).decode())
+    args.length = sum(int(x) for x in args.length.split(","))
     t_write = time.perf_counter() - t0
     out = {"scope": "BAM file -> depth.bed + callable.bed (goleft-depth CLI, process start to exit)",
            "ref_bases": args.length, "coverage": args.coverage, "reads": info["reads"],
@@ -50,7 +51,8 @@ def main():
             if best is None or dt < best[0]:
                 best = (dt, phases)
         dt, phases = best
-        beds[decoder] = open(os.path.join(d, "out_%s.depth.bed" % decoder)).read()
+        beds[decoder] = open(os.path.join(d, "out_%s.depth.bed" % decoder)).read() + \
+            open(os.path.join(d, "out_%s.callable.bed" % decoder)).read()
         out[decoder + "_decoder"] = {"wall_s": dt, "ref_bases_per_s": args.length / dt,
                                      "bam_MB_per_s": info["bam_bytes"] / 1e6 / dt, "phases": phases}
     out["outputs_identical"] = beds["device"] == beds["host"]

@@ -1,7 +1,8 @@
 // synth_bam.cpp -- writes a realistic single-contig BAM for the end-to-end timing
 // (SURVEY.md section 8d scope iii: BAM file -> BED).  MEASUREMENT TOOL, not product code.
 //
-//   synth-bam OUT.bam CONTIG LENGTH COVERAGE [SEED] [THREADS]
+//   synth-bam OUT.bam CONTIG LENGTH[,LENGTH...] COVERAGE [SEED] [THREADS]
+// (several comma-separated lengths: contigs CONTIG, CONTIG_2, CONTIG_3 ... in one coordinate-sorted file)
 //
 // 150 bp reads of the SURVEY 8d short-read model (92 % 150M, 5 % soft clip, 2 % one deletion,
 // 1 % one insertion; 5 % DUP, 0.3 % other filtered flags, 1 % MAPQ 0), coordinate sorted, WITH
@@ -67,36 +68,43 @@ static void bgzf_member(const uint8_t* data, size_t n, std::vector<uint8_t>* out
 int main(int argc, char** argv)
 {
     if (argc < 5) { fprintf(stderr, "usage: synth-bam OUT.bam CONTIG LENGTH COVERAGE [SEED] [THREADS]\n"); return 2; }
-    const std::string path = argv[1], contig = argv[2];
-    const int64_t L = atoll(argv[3]);
+    const std::string path = argv[1], contig0 = argv[2];
+    std::vector<int64_t> lens;
+    for (const char* q = argv[3]; *q;) { lens.push_back(atoll(q)); while (*q && *q != ',') ++q; if (*q == ',') ++q; }
+    std::vector<std::string> names;
+    for (size_t k = 0; k < lens.size(); ++k) names.push_back(k == 0 ? contig0 : contig0 + "_" + std::to_string(k + 1));
     const double cov = atof(argv[4]);
     const uint64_t seed = argc > 5 ? strtoull(argv[5], nullptr, 10) : 1;
     int threads = argc > 6 ? atoi(argv[6]) : (int)std::thread::hardware_concurrency();
     if (threads < 1) threads = 1;
     const int RL = 150;
-    const int64_t n = (int64_t)((double)L * cov / RL);
     FILE* f = fopen(path.c_str(), "wb");
     if (!f) { perror("open"); return 1; }
 
     std::vector<uint8_t> raw;                 // uncompressed BAM bytes of the current batch
     raw.reserve(300u << 20);
-    std::string text = "@HD\tVN:1.6\tSO:coordinate\n@SQ\tSN:" + contig + "\tLN:" + std::to_string(L) +
-                       "\n@RG\tID:rg1\tSM:synth\n";
+    std::string text = "@HD\tVN:1.6\tSO:coordinate\n";
+    for (size_t k = 0; k < lens.size(); ++k) text += "@SQ\tSN:" + names[k] + "\tLN:" + std::to_string(lens[k]) + "\n";
+    text += "@RG\tID:rg1\tSM:synth\n";
     raw.insert(raw.end(), {'B', 'A', 'M', 1});
     put32(raw, (uint32_t)text.size());
     raw.insert(raw.end(), text.begin(), text.end());
-    put32(raw, 1);
-    put32(raw, (uint32_t)contig.size() + 1);
-    raw.insert(raw.end(), contig.begin(), contig.end());
-    raw.push_back(0);
-    put32(raw, (uint32_t)L);
+    put32(raw, (uint32_t)lens.size());
+    for (size_t k = 0; k < lens.size(); ++k) {
+        put32(raw, (uint32_t)names[k].size() + 1);
+        raw.insert(raw.end(), names[k].begin(), names[k].end());
+        raw.push_back(0);
+        put32(raw, (uint32_t)lens[k]);
+    }
 
     const size_t BLK = 0xff00;
     uint64_t out_bytes = 0;
     std::vector<uint32_t> csize;               // compressed size of every data member, in file order
-    std::vector<uint64_t> lin((size_t)(L >> 14) + 1, ~0ull);   // uncompressed offset of the first record per 16 kb window
+    std::vector<std::vector<uint64_t>> lins(lens.size());      // per contig: uncompressed offset of the first record per 16 kb window
+    for (size_t k = 0; k < lens.size(); ++k) lins[k].assign((size_t)(lens[k] >> 14) + 1, ~0ull);
     uint64_t stream_off = 0;                   // uncompressed bytes written to `raw` so far (whole file)
-    uint64_t first_rec = ~0ull, after_last = 0;
+    std::vector<uint64_t> first_rec(lens.size(), ~0ull), after_last(lens.size(), 0);
+    int64_t n_total = 0;
     auto flush = [&](bool final) {
         const size_t nblk = raw.size() / BLK + ((final && raw.size() % BLK) ? 1 : 0);
         std::vector<std::vector<uint8_t>> comp(nblk);
@@ -115,9 +123,14 @@ int main(int argc, char** argv)
         stream_off += used;
     };
 
+    for (size_t ctg = 0; ctg < lens.size(); ++ctg) {
+    const int64_t L = lens[ctg];
+    const int64_t n = (int64_t)((double)L * cov / RL);
+    std::vector<uint64_t>& lin = lins[ctg];
+    n_total += n;
     const int64_t span = L - RL > 0 ? L - RL : 1;
     for (int64_t i = 0; i < n; ++i) {
-        const uint64_t h = mix(seed * 0x100000001b3ull + (uint64_t)i);
+        const uint64_t h = mix((seed + ctg * 7919) * 0x100000001b3ull + (uint64_t)i);
         const int64_t stride = span / n > 0 ? span / n : 1;
         int64_t pos = (int64_t)(((__int128)i * span) / n) + (int64_t)(h % (uint64_t)stride);
         if (pos > span) pos = span;
@@ -139,13 +152,13 @@ int main(int argc, char** argv)
         const uint32_t block = 32 + (uint32_t)ln + 4u * (uint32_t)nc + (RL + 1) / 2 + RL;
         {
             const uint64_t off = stream_off + raw.size();   // raw holds the not yet flushed tail of the stream
-            if (first_rec == ~0ull) first_rec = off;
-            after_last = off + 4 + block;
+            if (first_rec[ctg] == ~0ull) first_rec[ctg] = off;
+            after_last[ctg] = off + 4 + block;
             for (int64_t w = pos >> 14; w <= (pos + ref - 1) >> 14 && (size_t)w < lin.size(); ++w)
                 if (lin[(size_t)w] == ~0ull) lin[(size_t)w] = off;
         }
         put32(raw, block);
-        put32(raw, 0);                                   // refID
+        put32(raw, (uint32_t)ctg);                       // refID
         put32(raw, (uint32_t)pos);
         raw.push_back((uint8_t)ln);
         raw.push_back(mapq);
@@ -170,6 +183,7 @@ int main(int argc, char** argv)
         }
         if (raw.size() >= (256u << 20)) flush(false);
     }
+    }
     flush(true);
     static const uint8_t eof[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     fwrite(eof, 1, 28, f);
@@ -180,26 +194,32 @@ int main(int argc, char** argv)
         auto voff = [&](uint64_t o) { return (coff[o / BLK] << 16) | (o % BLK); };
         std::vector<uint8_t> b;
         b.insert(b.end(), {'B', 'A', 'I', 1});
-        put32(b, 1);
-        if (first_rec != ~0ull) {
-            put32(b, 1); put32(b, 0); put32(b, 1);                  // one bin (0) with one chunk
-            const uint64_t v0 = voff(first_rec), v1 = voff(after_last);
-            for (int i = 0; i < 8; ++i) b.push_back((uint8_t)(v0 >> (8 * i)));
-            for (int i = 0; i < 8; ++i) b.push_back((uint8_t)(v1 >> (8 * i)));
-        } else put32(b, 0);
-        size_t n_intv = lin.size();
-        while (n_intv && lin[n_intv - 1] == ~0ull) --n_intv;
-        put32(b, (uint32_t)n_intv);
-        uint64_t last = 0;
-        for (size_t w = 0; w < n_intv; ++w) {
-            if (lin[w] != ~0ull) last = voff(lin[w]);
-            for (int i = 0; i < 8; ++i) b.push_back((uint8_t)(last >> (8 * i)));
+        put32(b, (uint32_t)lens.size());
+        for (size_t ctg = 0; ctg < lens.size(); ++ctg) {
+            const std::vector<uint64_t>& lin = lins[ctg];
+            if (first_rec[ctg] != ~0ull) {
+                put32(b, 1); put32(b, 0); put32(b, 1);              // one bin (0) with one chunk
+                const uint64_t v0 = voff(first_rec[ctg]), v1 = voff(after_last[ctg]);
+                for (int i = 0; i < 8; ++i) b.push_back((uint8_t)(v0 >> (8 * i)));
+                for (int i = 0; i < 8; ++i) b.push_back((uint8_t)(v1 >> (8 * i)));
+            } else put32(b, 0);
+            size_t n_intv = lin.size();
+            while (n_intv && lin[n_intv - 1] == ~0ull) --n_intv;
+            put32(b, (uint32_t)n_intv);
+            uint64_t last = 0;
+            for (size_t w = 0; w < n_intv; ++w) {
+                if (lin[w] != ~0ull) last = voff(lin[w]);
+                for (int i = 0; i < 8; ++i) b.push_back((uint8_t)(last >> (8 * i)));
+            }
         }
         FILE* fb = fopen((path + ".bai").c_str(), "wb");
         if (fb) { fwrite(b.data(), 1, b.size(), fb); fclose(fb); }
     }
     FILE* fai = fopen((path.substr(0, path.size() - 4) + ".fa.fai").c_str(), "w");
-    if (fai) { fprintf(fai, "%s\t%lld\t6\t60\t61\n", contig.c_str(), (long long)L); fclose(fai); }
-    printf("{\"reads\": %lld, \"bam_bytes\": %llu}\n", (long long)n, (unsigned long long)(out_bytes + 28));
+    if (fai) {
+        for (size_t k = 0; k < lens.size(); ++k) fprintf(fai, "%s\t%lld\t6\t60\t61\n", names[k].c_str(), (long long)lens[k]);
+        fclose(fai);
+    }
+    printf("{\"reads\": %lld, \"bam_bytes\": %llu}\n", (long long)n_total, (unsigned long long)(out_bytes + 28));
     return 0;
 }
