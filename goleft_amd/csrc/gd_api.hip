@@ -39,6 +39,12 @@ struct ContigHost {
     size_t cap_reads = 0, cap_ops = 0;
     bool adopted = false;
     int32_t last_pos = -0x7fffffff;
+    // packed descriptors of the records (gd_tile_v8.hpp), always owned
+    uint2* desc = nullptr;
+    uint32_t* cxb = nullptr;
+    uint32_t* cxc = nullptr;
+    bool packed = false;               // desc/cxb/cxc describe the current records
+    bool packable = false;             // ... and the v8 kernels may use them
     // layout in the result arrays of the last compute (-1 = not computed)
     int64_t base_off = -1;
     int64_t win_off = -1;
@@ -72,7 +78,8 @@ struct gd_ctx {
 
     int tile_T = 4096;
     int tile_NT = 256;
-    int kernel_gen = 7;                 // debug: GOLEFT_GD_KERNEL=v6 selects the previous tile kernel
+    int kernel_gen = 8;                 // debug: GOLEFT_GD_KERNEL=v7 / v6 select the previous tile kernels
+    bool use_v8 = false;                // this gd_compute: every contig of the job is packed
     int tile_opt = 1;                   // bit 0: non-temporal per-base stores (2 % faster: the vector is
                                         // never re-read by the kernel); GOLEFT_GD_OPT=0 for plain stores
     bool lookback_pinned = false;       // max_span_hint given: never shrink below it
@@ -80,7 +87,6 @@ struct gd_ctx {
     bool keep_perbase = true;           // gd_set_outputs(GD_OUT_PERBASE)
     bool sums_only = false;             // gd_set_outputs(GD_OUT_SUMS_ONLY): window sums, nothing else
     bool ran_sums_only = false;         // what the last gd_compute produced
-    bool scope_wg = false;              // debug: GOLEFT_GD_SCOPE=wg (wrong results, timing only)
     bool span_forces_long = false;      // AUTO: the tile path met a read too long for it
     unsigned long long* d_status = nullptr;  size_t cap_status = 0;   // scatter path look-back words
     uint32_t* d_ck = nullptr;  size_t cap_ck = 0;      // chunk path: CIGAR checkpoints
@@ -168,8 +174,18 @@ int ensure_dev(gd_ctx* c, Tp** p, size_t* cap, size_t need, bool keep = false, s
     return GD_OK;
 }
 
+void drop_pack(ContigHost& h)
+{
+    if (h.desc) (void)hipFree(h.desc);
+    if (h.cxb) (void)hipFree(h.cxb);
+    if (h.cxc) (void)hipFree(h.cxc);
+    h.desc = nullptr; h.cxb = nullptr; h.cxc = nullptr;
+    h.packed = h.packable = false;
+}
+
 void free_contig(ContigHost& h)
 {
+    drop_pack(h);
     if (!h.adopted) {
         if (h.pos) (void)hipFree(h.pos);
         if (h.flag) (void)hipFree(h.flag);
@@ -228,10 +244,20 @@ void launch_tile(gd_ctx* c, const gd::Job& job)
     // 8 XCDs: the grid is 8 equal slices of the tile list (see the kernel)
     const unsigned grid = (unsigned)(((job.n_tiles + 7) / 8) * 8);
     if (c->ran_sums_only) {                                 // decided by gd_compute for this run
-        hipLaunchKernelGGL((gd::v7::gd_tile_sums_kernel<4096, 256>), dim3(grid), dim3(256), 0, c->stream, job);
+        if (c->use_v8) hipLaunchKernelGGL((gd::v8::gd_tile_sums_kernel<4096, 256>), dim3(grid), dim3(256), 0, c->stream, job);
+        else           hipLaunchKernelGGL((gd::v7::gd_tile_sums_kernel<4096, 256>), dim3(grid), dim3(256), 0, c->stream, job);
         return;
     }
-    if (c->kernel_gen == 7 && T == 4096 && NT == 256) {     // v7 is built for the default shape only
+    if (c->use_v8 && T == 4096 && NT == 256) {              // packed descriptors (default shape only)
+        if (!c->keep_perbase)
+            hipLaunchKernelGGL((gd::v8::gd_tile_kernel<4096, 256, 2>), dim3(grid), dim3(256), 0, c->stream, job);
+        else if (c->tile_opt & 1)
+            hipLaunchKernelGGL((gd::v8::gd_tile_kernel<4096, 256, 1>), dim3(grid), dim3(256), 0, c->stream, job);
+        else
+            hipLaunchKernelGGL((gd::v8::gd_tile_kernel<4096, 256, 0>), dim3(grid), dim3(256), 0, c->stream, job);
+        return;
+    }
+    if (c->kernel_gen >= 7 && T == 4096 && NT == 256) {     // v7 is built for the default shape only
         if (!c->keep_perbase)
             hipLaunchKernelGGL((gd::v7::gd_tile_kernel<4096, 256, 2>), dim3(grid), dim3(256), 0, c->stream, job);
         else if (c->tile_opt & 1)
@@ -263,6 +289,56 @@ void launch_ltile(gd_ctx* c, const gd::Job& job)
         hipLaunchKernelGGL((gd::gd_ltile2_kernel<T, NT, 2>), dim3(grid), dim3(NT), 0, c->stream, job);
     else
         hipLaunchKernelGGL((gd::gd_ltile2_kernel<T, NT, 0>), dim3(grid), dim3(NT), 0, c->stream, job);
+}
+
+// Builds the packed descriptors of one contig's records (gd_tile_v8.hpp) on the compute stream.
+// Afterwards h.packed is set; h.packable says whether the v8 kernels may use them.
+int pack_contig(gd_ctx* c, ContigHost& h)
+{
+    drop_pack(h);
+    h.packed = true;
+    if (h.n_reads >= (1ull << 29)) return GD_OK;           // descriptor byte offsets stay in 32 bits
+    const uint32_t n_reads = (uint32_t)h.n_reads, n_units = (n_reads + 63u) / 64u;
+    // records staged on the copy stream must have landed
+    HIPCHK(c, hipEventRecord(c->copy_done, c->copy_stream));
+    HIPCHK(c, hipStreamWaitEvent(c->stream, c->copy_done, 0));
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&h.desc), std::max<size_t>(n_reads, 1) * sizeof(uint2)));
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&h.cxb), ((size_t)n_units + 2) * sizeof(uint32_t)));   // + total, status
+    HIPCHK(c, hipMemsetAsync(h.cxb, 0, ((size_t)n_units + 2) * sizeof(uint32_t), c->stream));
+    gd::v8::PackJob j{};
+    j.pos = h.pos; j.flag = h.flag; j.mapq = h.mapq; j.off = h.off; j.cigar = h.cigar;
+    j.n_reads = n_reads; j.n_units = n_units; j.desc = h.desc; j.cx_base = h.cxb; j.status = h.cxb + n_units + 1;
+    uint32_t tail[2] = {0, 0};                              // grand total of compact ops, status bits
+    if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+    if (n_units) {
+        hipLaunchKernelGGL(gd::v8::gd_pack_desc_kernel, dim3((n_units + 3u) / 4u), dim3(256), 0, c->stream, j);
+        hipLaunchKernelGGL(gd::v8::gd_pack_scan_kernel, dim3(1), dim3(1024), 0, c->stream, h.cxb, n_units);
+        HIPCHK(c, hipMemcpyAsync(tail, h.cxb + n_units, sizeof tail, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&h.cxc), ((size_t)tail[0] + 4) * sizeof(uint32_t)));
+    if (tail[0]) {
+        j.cx_cigar = h.cxc;
+        hipLaunchKernelGGL(gd::v8::gd_pack_ops_kernel, dim3((n_units + 3u) / 4u), dim3(256), 0, c->stream, j);
+    }
+    HIPCHK(c, hipGetLastError());
+    if (c->profiling) {
+        float ms = 0;
+        HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+        HIPCHK(c, hipEventSynchronize(c->ev[1]));
+        HIPCHK(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
+        c->kernel_ms[GD_K_PACK] += ms;
+    }
+    h.packable = tail[1] == 0;
+    return GD_OK;
+}
+
+// The v8 kernels exist for the default tile shape; long-read data goes to the chunk path anyway.
+bool wants_pack(const gd_ctx* c, uint64_t n_reads, uint64_t n_ops)
+{
+    if (c->kernel_gen != 8 || c->tile_T != 4096 || c->tile_NT != 256) return false;
+    if (c->path == GD_PATH_TILE) return true;
+    return c->path == GD_PATH_AUTO && !c->span_forces_long && n_ops <= 6 * n_reads;
 }
 
 // RAII for the scratch device buffers of gd_ingest_bgzf
@@ -355,9 +431,9 @@ int gd_create(int device_id, gd_ctx** out)
         int t = atoi(e);
         if (t == 4096 || t == 8192) c->tile_T = t;
     }
-    if (const char* e = getenv("GOLEFT_GD_KERNEL")) c->kernel_gen = (e[0] == 'v' && e[1] == '6') ? 6 : 7;
+    if (const char* e = getenv("GOLEFT_GD_KERNEL"))
+        c->kernel_gen = (e[0] == 'v' && e[1] == '6') ? 6 : (e[0] == 'v' && e[1] == '7') ? 7 : 8;
     if (const char* e = getenv("GOLEFT_GD_OPT")) c->tile_opt = atoi(e) & 1;
-    if (const char* e = getenv("GOLEFT_GD_SCOPE")) c->scope_wg = e[0] == 'w';
     if (const char* e = getenv("GOLEFT_GD_PATH"))
         c->path = e[0] == 's' ? GD_PATH_SCATTER : e[0] == 't' ? GD_PATH_TILE : e[0] == 'c' ? GD_PATH_CHUNK : GD_PATH_AUTO;
     if (const char* e = getenv("GOLEFT_GD_THREADS")) {
@@ -592,6 +668,10 @@ int gd_commit(gd_ctx* c, const gd_batch* b, int32_t tid, size_t n_reads, size_t 
         HIPCHK(c, hipMemcpyAsync(h.cigar + h.n_ops, b->cigar, n_ops * sizeof(uint32_t), hipMemcpyHostToDevice, cs));
     HIPCHK(c, hipEventRecord(s.done, cs));
     s.busy = true;
+    if (h.packed) {                                     // the descriptors no longer cover the stream
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        drop_pack(h);
+    }
     h.n_reads += n_reads;
     h.n_ops += n_ops;
     h.last_pos = last;
@@ -655,6 +735,9 @@ int gd_adopt_device(gd_ctx* c, int32_t tid, const gd_batch* d, size_t n_reads, s
     h.n_reads = n_reads; h.n_ops = n_ops;
     h.adopted = true;
     c->computed = false;
+    // descriptors are part of taking the records in, not of gd_compute
+    if (n_reads && wants_pack(c, n_reads, n_ops))
+        if (int r = pack_contig(c, h)) return r;
     return GD_OK;
 }
 
@@ -688,6 +771,25 @@ int gd_compute(gd_ctx* c)
     std::vector<int32_t> tids = c->selected;
     if (tids.empty()) { tids.resize(c->contigs.size()); for (size_t i = 0; i < tids.size(); ++i) tids[i] = (int32_t)i; }
     for (auto& h : c->contigs) { h.base_off = h.win_off = -1; h.n_win = 0; h.run_beg = h.run_end = 0; }
+    {
+        // packed descriptors: built here only for records that arrived through gd_commit
+        // (gd_adopt_device and gd_ingest_finish build them on arrival)
+        const float pack_ms = c->kernel_ms[GD_K_PACK];
+        memset(c->kernel_ms, 0, sizeof c->kernel_ms);
+        c->kernel_ms[GD_K_PACK] = pack_ms;
+        uint64_t tr = 0, to = 0;
+        for (int32_t tid : tids)
+            if (c->contigs[tid].length > 0) { tr += c->contigs[tid].n_reads; to += c->contigs[tid].n_ops; }
+        bool v8 = wants_pack(c, tr, to);
+        for (size_t i = 0; v8 && i < tids.size(); ++i) {
+            ContigHost& h = c->contigs[tids[i]];
+            if (h.length <= 0) continue;
+            if (!h.packed)
+                if (int r = pack_contig(c, h)) return r;
+            v8 = h.packable;
+        }
+        c->use_v8 = v8;
+    }
     c->h_ctgs.clear();
     c->job_tids.clear();
     int64_t tile_beg = 0, base_off = 0, win_off = 0, bases = 0;
@@ -708,6 +810,7 @@ int gd_compute(gd_ctx* c)
         d.unit_beg = (uint32_t)n_units;
         d.ck_off = (int64_t)n_ck;
         d.read_off = (int64_t)n_reads;
+        if (c->use_v8) { d.desc = h.desc; d.cx_base = h.cxb; d.cx_cigar = h.cxc; }
         n_units += (h.n_reads + 63) / 64;
         n_ck += (h.n_ops >> 6) + h.n_reads + 1;   // gd_chunk.hpp: slots (off >> 6) + read
         h.base_off = base_off;
@@ -728,7 +831,6 @@ int gd_compute(gd_ctx* c)
     c->n_win_total = win_off;
     c->n_bases = bases;
     c->bounds.clear();
-    memset(c->kernel_ms, 0, sizeof c->kernel_ms);
     if (c->n_tiles == 0) { c->computed = true; return GD_OK; }
 
     // ---- allocations -------------------------------------------------------
@@ -884,10 +986,7 @@ int gd_compute(gd_ctx* c)
             if (n_units) {
                 const uint64_t groups = (n_units + 3) / 4;
                 const unsigned grid = (unsigned)(((groups + 7) / 8) * 8);
-                if (c->scope_wg)   // timing experiment only: not coherent across XCDs
-                    hipLaunchKernelGGL(gd::gd_expand_scatter_kernel<true>, dim3(grid), dim3(256), 0, c->stream, job);
-                else
-                    hipLaunchKernelGGL(gd::gd_expand_scatter_kernel<false>, dim3(grid), dim3(256), 0, c->stream, job);
+                hipLaunchKernelGGL(gd::gd_expand_scatter_kernel, dim3(grid), dim3(256), 0, c->stream, job);
             }
             if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
             if (T == 8192)
@@ -1671,6 +1770,8 @@ int gd_ingest_finish(gd_ctx* c, int32_t tid, int32_t ref_id, const uint64_t* anc
     h.last_pos = prev_last;
     c->computed = false;
     if (n_records) *n_records = N;
+    if (N && wants_pack(c, N, M))
+        if (int r = pack_contig(c, h)) return r;
     return GD_OK;
 }
 
@@ -1779,6 +1880,7 @@ int gd_set_profiling(gd_ctx* c, int on)
 {
     if (!c) return GD_E_INVALID;
     c->profiling = on != 0;
+    c->kernel_ms[GD_K_PACK] = 0;                        // accumulates over the contigs packed from now on
     return GD_OK;
 }
 

@@ -56,10 +56,13 @@ struct ContigDev {
     uint32_t unit_beg;        // first 64-read unit of this contig (scatter / chunk paths)
     int64_t  ck_off;          // chunk path: element offset of this contig's checkpoints in Job::ck
     int64_t  read_off;        // chunk path: element offset of this contig's reads in Job::rend
+    const uint2*    desc;     // packed read descriptors (gd_tile_v8.hpp), null when not packed
+    const uint32_t* cx_base;  // per 64-read unit: offset of its complex reads' ops in cx_cigar
+    const uint32_t* cx_cigar;
 };
 
-// Everything a workgroup needs for its tile in ONE 80-byte record (one scalar
-// load burst, no dependent contig-table lookup).  Written by gd_prep_kernel.
+// Everything a workgroup needs for its tile in ONE record (one scalar load
+// burst, no dependent contig-table lookup).  Written by gd_prep_kernel.
 struct __attribute__((aligned(16))) TileInfo {
     const int32_t*  pos;
     const uint16_t* flag;
@@ -75,6 +78,9 @@ struct __attribute__((aligned(16))) TileInfo {
     uint32_t n_reads;         // records of the contig (bounds for the vector loads)
     uint32_t n_ops;           // CIGAR ops of the contig
     uint32_t clo, chi;        // CIGAR op range [off[lo], off[hi]) of those reads
+    const uint2*    desc;     // packed descriptors of the contig (v8 kernels)
+    const uint32_t* cxb;
+    const uint32_t* cxc;
 };
 
 // Device-side counters, read back once per gd_compute.
@@ -206,6 +212,7 @@ __global__ void gd_prep_kernel(Job job)
     ti.pos = c.pos; ti.flag = c.flag; ti.mapq = c.mapq; ti.off = c.off; ti.cigar = c.cigar;
     ti.base_off = c.base_off; ti.win_off = c.win_off; ti.length = c.length;
     ti.n_reads = c.n_reads; ti.n_ops = c.n_ops;
+    ti.desc = c.desc; ti.cxb = c.cx_base; ti.cxc = c.cx_cigar;
     ti.ctg = lo;
     ti.t0 = (t - c.tile_beg) * T;
     int32_t tend = ti.t0 + T < c.length ? ti.t0 + T : c.length;
@@ -285,6 +292,7 @@ __device__ __forceinline__ int wave_min(int v)
 
 #include "gd_tile_v6.hpp"
 #include "gd_tile_v7.hpp"
+#include "gd_tile_v8.hpp"
 #include "gd_scatter.hpp"
 #include "gd_chunk.hpp"
 #include "gd_depthwed.hpp"

@@ -38,15 +38,11 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan_sat(uint32_t v)
     return v;
 }
 
-// One +-1 mark of the difference array.  SCOPE_WG (timing experiments only) uses
-// workgroup-scope atomics, which are NOT coherent across XCDs.
-template <bool SCOPE_WG>
+// One +-1 mark of the difference array: a device-scope atomic (units of different workgroups, on
+// different XCDs, mark the same cache lines; workgroup scope would not be coherent across XCDs).
 __device__ __forceinline__ void scatter_mark(int32_t* diff, uint32_t p, int v, uint32_t clen)
 {
-    if (p < clen) {
-        if (SCOPE_WG) __hip_atomic_fetch_add(&diff[p], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        else          __hip_atomic_fetch_add(&diff[p], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    if (p < clen) __hip_atomic_fetch_add(&diff[p], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // LK0: accumulators, counters, look-back status words.
@@ -75,7 +71,6 @@ __global__ void gd_linit_kernel(Job job)
 // length): insertions, clips and pads between two matches leave the intervals
 // adjacent, and adjacent intervals need no marks at the shared edge.  So a
 // read costs 2 x (number of deletions/skips + 1) atomics, not 2 per match op.
-template <bool SCOPE_WG>
 __global__ __launch_bounds__(256) void gd_expand_scatter_kernel(Job job)
 {
     // XCD-contiguous order (workgroup b runs on XCD b % 8): neighbouring units
@@ -122,12 +117,12 @@ __global__ __launch_bounds__(256) void gd_expand_scatter_kernel(Job job)
             const bool counted = (0x181u >> op) & 1u;     // M = X
             const bool consumes = (0x18du >> op) & 1u;    // M D N = X
             if (len != 0) {
-                if (counted && !open) { scatter_mark<SCOPE_WG>(diff, cur, 1, clen); open = true; }
-                if (consumes && !counted && open) { scatter_mark<SCOPE_WG>(diff, cur, -1, clen); open = false; }
+                if (counted && !open) { scatter_mark(diff, cur, 1, clen); open = true; }
+                if (consumes && !counted && open) { scatter_mark(diff, cur, -1, clen); open = false; }
                 if (consumes) { cur += len; cur = cur < POS_CAP ? cur : POS_CAP; }
             }
         }
-        if (open) scatter_mark<SCOPE_WG>(diff, cur, -1, clen);
+        if (open) scatter_mark(diff, cur, -1, clen);
     }
 
     // ---- long CIGARs: the wave expands one read at a time, 64 ops per round
@@ -160,8 +155,8 @@ __global__ __launch_bounds__(256) void gd_expand_scatter_kernel(Job job)
                 const bool prev_counted = pm != 0ull && ((cm >> (63 - __builtin_clzll(pm))) & 1ull);
                 const unsigned long long nm = nn & above;
                 const bool next_counted = nm != 0ull && ((cm >> (__builtin_ffsll((long long)nm) - 1)) & 1ull);
-                if (!prev_counted) scatter_mark<SCOPE_WG>(diff, s, 1, clen);
-                if (!next_counted) scatter_mark<SCOPE_WG>(diff, s + len, -1, clen);
+                if (!prev_counted) scatter_mark(diff, s, 1, clen);
+                if (!next_counted) scatter_mark(diff, s + len, -1, clen);
             }
             carry += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
             carry = carry < POS_CAP ? carry : POS_CAP;

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define GD_ABI_VERSION 6
+#define GD_ABI_VERSION 7
 
 typedef enum {
     GD_OK = 0,
@@ -118,7 +118,10 @@ enum { GD_K_PREP = 0, GD_K_TILE = 1, GD_K_RUNS = 2, GD_K_EXPAND = 3, GD_K_SCAN =
        GD_K_SEQSTATS = 6,   /* the kernel of the last gd_seq_stats */
        GD_K_MDFLAGS = 7,    /* the kernel of the last gd_md_flags */
        GD_K_INFLATE = 8,    /* the kernel of the last gd_inflate_bgzf */
-       GD_K_COUNT = 9 };
+       GD_K_PACK = 9,       /* packing records into read descriptors (gd_adopt_device, gd_ingest_finish,
+                               or the first gd_compute after gd_commit): summed over the contigs packed
+                               since gd_set_profiling was last called; not cleared by gd_compute */
+       GD_K_COUNT = 10 };
 
 /* Device algorithm of gd_compute.  All are bit exact; they differ in cost.
  *   TILE     one workgroup per 4096-position tile re-walks the CIGARs of the
