@@ -78,7 +78,8 @@ struct gd_ctx {
 
     int tile_T = 4096;
     int tile_NT = 256;
-    int kernel_gen = 8;                 // debug: GOLEFT_GD_KERNEL=v7 / v6 select the previous tile kernels
+    int kernel_gen = 7;                 // GOLEFT_GD_KERNEL=v8: packed read descriptors (gd_tile_v8.hpp, measured
+                                        // equal to v7: DESIGN.md section 4); v6: the previous tile kernel
     bool use_v8 = false;                // this gd_compute: every contig of the job is packed
     int tile_opt = 1;                   // bit 0: non-temporal per-base stores (2 % faster: the vector is
                                         // never re-read by the kernel); GOLEFT_GD_OPT=0 for plain stores
@@ -432,7 +433,7 @@ int gd_create(int device_id, gd_ctx** out)
         if (t == 4096 || t == 8192) c->tile_T = t;
     }
     if (const char* e = getenv("GOLEFT_GD_KERNEL"))
-        c->kernel_gen = (e[0] == 'v' && e[1] == '6') ? 6 : (e[0] == 'v' && e[1] == '7') ? 7 : 8;
+        c->kernel_gen = (e[0] == 'v' && e[1] == '6') ? 6 : (e[0] == 'v' && e[1] == '8') ? 8 : 7;
     if (const char* e = getenv("GOLEFT_GD_OPT")) c->tile_opt = atoi(e) & 1;
     if (const char* e = getenv("GOLEFT_GD_PATH"))
         c->path = e[0] == 's' ? GD_PATH_SCATTER : e[0] == 't' ? GD_PATH_TILE : e[0] == 'c' ? GD_PATH_CHUNK : GD_PATH_AUTO;

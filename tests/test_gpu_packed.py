@@ -1,5 +1,5 @@
-"""-m gpu: the packed-descriptor tile kernels (gd_tile_v8.hpp) vs the CPU oracle and vs the v7
-kernels on the same records -- every descriptor class (inlined single op, near complex, far
+"""-m gpu: the packed-descriptor tile kernels (gd_tile_v8.hpp, GOLEFT_GD_KERNEL=v8) vs the CPU oracle and
+vs the default v7 kernels on the same records -- every descriptor class (inlined single op, near complex, far
 complex, not packable), both ways the descriptors get built (first gd_compute after gd_commit,
 gd_adopt_device), bit exact."""
 import ctypes
@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 TILE = 1
 
 
-def _engine(kernel=None):
+def _engine(kernel="v8"):
     from goleft_amd.engine import DepthEngine
     old = os.environ.get("GOLEFT_GD_KERNEL")
     if kernel:
@@ -119,7 +119,7 @@ def test_packed_descriptors_against_oracle_and_v7(seed, p_complex, big):
     W = int(rng.choice([1, 13, 100, 250, 1000]))
     Q = int(rng.choice([0, 1, 20]))
     mincov, maxmean = int(rng.integers(1, 6)), int(rng.choice([0, 25]))
-    e8, e7 = _engine(), _engine("v7")
+    e8, e7 = _engine("v8"), _engine("v7")
     try:
         for e in (e8, e7):
             _run(e, contigs, reads, W, Q, mincov, maxmean)
