@@ -203,6 +203,8 @@ def run_case(args, scaling, world, rank, dev, local_rank, want_streams=False):
         # depthwed only needs window sums: GD_OUT_SUMS_ONLY (read/window overlaps, no per-base scan);
         # --cohort-outputs windows keeps minima and class runs (the regular windows-only kernel)
         eng.set_outputs(perbase=False, sums_only=args.cohort_outputs == "sums")
+    elif os.environ.get("GOLEFT_BENCH_OUTPUTS") == "windows":
+        eng.set_outputs(perbase=False)     # experiment only (profiles/r01h): the tile kernel without its store stream
     eng.set_contigs(lengths)
     eng.select_contigs(mine)
     n_reads = n_ops = 0
