@@ -116,6 +116,11 @@ struct gd_ctx {
     int64_t md_len = -1;                               // positions the bitmaps cover (-1: none yet)
     std::vector<int32_t> md_tids;                      // the samples they were built from
     IngestState* ing = nullptr;                        // gd_ingest_begin .. gd_ingest_finish
+    // staging of the device BAM read, created by the first gd_ingest_begin and kept until gd_destroy
+    // (page-locking 128 MB per contig would cost more than many contigs' whole decode)
+    uint8_t* ing_stage[2] = {nullptr, nullptr};
+    hipEvent_t ing_staged[2] = {nullptr, nullptr};
+    hipStream_t ing_stream[4] = {};
     uint8_t* d_seq = nullptr;  size_t cap_seq = 0;     // gd_seq_load: one contig's bases, zero padded
     int64_t seq_len = -1;
     uint32_t seq_padded = 0;
@@ -361,16 +366,14 @@ struct IngestState {
     DevBuf d_in, d_out, d_tab;
     uint64_t *t_in_off = nullptr, *t_out_off = nullptr;
     uint32_t *t_in_len = nullptr, *t_out_len = nullptr, *t_status = nullptr, *t_crc = nullptr;
-    uint8_t* stage[2] = {nullptr, nullptr};
-    hipEvent_t staged[2] = {nullptr, nullptr};
     bool stage_used[2] = {false, false};
     int cur = 0;
     // One lane inflates one member start to end (~0.1 s whatever the member count), so the members are
     // handed to the kernel in at most kBatches launches, each on its own stream: they overlap each other
     // and the upload of the bytes still to come.
     static constexpr int kBatches = 4;
-    hipStream_t inf_stream[kBatches] = {};
     int n_launch = 0;
+    bool inflated = false;                              // every member inflated and its status checked
 };
 
 extern "C" {
@@ -469,6 +472,11 @@ void gd_destroy(gd_ctx* c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
     (void)gd_ingest_abort(c);
+    for (int k = 0; k < 2; ++k) {
+        if (c->ing_stage[k]) (void)hipHostFree(c->ing_stage[k]);
+        if (c->ing_staged[k]) (void)hipEventDestroy(c->ing_staged[k]);
+    }
+    for (hipStream_t st : c->ing_stream) if (st) (void)hipStreamDestroy(st);
     for (auto& h : c->contigs) free_contig(h);
     for (auto& s : c->ring) {
         if (s.b.pos) (void)hipHostFree(s.b.pos);
@@ -1551,12 +1559,8 @@ int gd_ingest_abort(gd_ctx* c)
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->copy_stream);
     (void)hipStreamSynchronize(c->stream);
-    for (hipStream_t s : c->ing->inf_stream)
-        if (s) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
-    for (int k = 0; k < 2; ++k) {
-        if (c->ing->stage[k]) (void)hipHostFree(c->ing->stage[k]);
-        if (c->ing->staged[k]) (void)hipEventDestroy(c->ing->staged[k]);
-    }
+    for (hipStream_t s : c->ing_stream)
+        if (s) (void)hipStreamSynchronize(s);
     delete c->ing;
     c->ing = nullptr;
     return GD_OK;
@@ -1598,11 +1602,12 @@ int gd_ingest_begin(gd_ctx* c, uint64_t n_bytes, uint64_t base_coffset, size_t n
         g->d_tab.alloc(tab_bytes) != hipSuccess)
         return bail(GD_E_NOMEM, "device allocation for the BAM decode failed");
     for (int k = 0; k < 2; ++k)
-        if (hipHostMalloc(reinterpret_cast<void**>(&g->stage[k]), IngestState::kStage, hipHostMallocDefault) != hipSuccess ||
-            hipEventCreateWithFlags(&g->staged[k], hipEventDisableTiming) != hipSuccess)
+        if ((!c->ing_stage[k] &&
+             hipHostMalloc(reinterpret_cast<void**>(&c->ing_stage[k]), IngestState::kStage, hipHostMallocDefault) != hipSuccess) ||
+            (!c->ing_staged[k] && hipEventCreateWithFlags(&c->ing_staged[k], hipEventDisableTiming) != hipSuccess))
             return bail(GD_E_NOMEM, "cannot allocate the page-locked staging buffers");
-    for (hipStream_t& s : g->inf_stream)
-        if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return bail(GD_E_HIP, "cannot create a stream");
+    for (hipStream_t& s : c->ing_stream)
+        if (!s && hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return bail(GD_E_HIP, "cannot create a stream");
     g->t_in_off = g->d_tab.as<uint64_t>();
     g->t_out_off = g->t_in_off + n_members;
     g->t_in_len = reinterpret_cast<uint32_t*>(g->t_out_off + n_members);
@@ -1630,10 +1635,10 @@ int gd_ingest_feed(gd_ctx* c, const uint8_t* bytes, size_t n)
     while (done < n) {
         const size_t piece = std::min(n - done, IngestState::kStage);
         const int k = g->cur;
-        if (g->stage_used[k]) HIPCHK(c, hipEventSynchronize(g->staged[k]));       // its previous H2D has left the buffer
-        memcpy(g->stage[k], bytes + done, piece);                                // the caller's pointer is not retained
-        HIPCHK(c, hipMemcpyAsync(g->d_in.as<uint8_t>() + g->fed, g->stage[k], piece, hipMemcpyHostToDevice, c->copy_stream));
-        HIPCHK(c, hipEventRecord(g->staged[k], c->copy_stream));
+        if (g->stage_used[k]) HIPCHK(c, hipEventSynchronize(c->ing_staged[k]));   // its previous H2D has left the buffer
+        memcpy(c->ing_stage[k], bytes + done, piece);                            // the caller's pointer is not retained
+        HIPCHK(c, hipMemcpyAsync(g->d_in.as<uint8_t>() + g->fed, c->ing_stage[k], piece, hipMemcpyHostToDevice, c->copy_stream));
+        HIPCHK(c, hipEventRecord(c->ing_staged[k], c->copy_stream));
         g->stage_used[k] = true;
         g->cur ^= 1;
         g->fed += piece;
@@ -1644,8 +1649,8 @@ int gd_ingest_feed(gd_ctx* c, const uint8_t* bytes, size_t n)
         while (last < g->nm && g->m_end[last] <= g->fed) ++last;
         const size_t quota = std::max<size_t>((g->nm + IngestState::kBatches - 1) / IngestState::kBatches, 1);
         if (last > g->next && (last - g->next >= quota || last == g->nm) ) {
-            hipStream_t is = g->inf_stream[g->n_launch++ % IngestState::kBatches];
-            HIPCHK(c, hipStreamWaitEvent(is, g->staged[k], 0));
+            hipStream_t is = c->ing_stream[g->n_launch++ % IngestState::kBatches];
+            HIPCHK(c, hipStreamWaitEvent(is, c->ing_staged[k], 0));
             gd::InflateJob ij{};
             ij.comp = g->d_in.as<uint8_t>();
             ij.in_off = g->t_in_off + g->next; ij.in_len = g->t_in_len + g->next;
@@ -1660,13 +1665,15 @@ int gd_ingest_feed(gd_ctx* c, const uint8_t* bytes, size_t n)
     return GD_OK;
 }
 
-int gd_ingest_finish(gd_ctx* c, int32_t tid, int32_t ref_id, const uint64_t* anchors, size_t n_anchors, uint64_t* n_records)
+// One reference of the fed range -> contig tid.  release: the range is dropped afterwards (always on error).
+static int ingest_decode(gd_ctx* c, int32_t tid, int32_t ref_id, const uint64_t* anchors, size_t n_anchors,
+                         uint64_t* n_records, bool release)
 {
     if (!c || !anchors || n_anchors == 0) return GD_E_INVALID;
     if (int r = set_device(c)) return r;
     IngestState* g = c->ing;
     if (!g) return fail(c, GD_E_STATE, "gd_ingest_begin has not been called");
-    struct Guard { gd_ctx* c; ~Guard() { (void)gd_ingest_abort(c); } } guard{c};   // buffers are released on every path
+    struct Guard { gd_ctx* c; bool on; ~Guard() { if (on) (void)gd_ingest_abort(c); } } guard{c, true};   // released on every error path
     if (tid < 0 || (size_t)tid >= c->contigs.size()) return fail(c, GD_E_RANGE, "tid %d out of range", tid);
     if (n_anchors > 0xfffffff0ull) return fail(c, GD_E_RANGE, "too many anchors");
     if (g->next != g->nm) return fail(c, GD_E_STATE, "only %zu of %zu BGZF members were fed", g->next, g->nm);
@@ -1684,10 +1691,13 @@ int gd_ingest_finish(gd_ctx* c, int32_t tid, int32_t ref_id, const uint64_t* anc
         if (i && seg_beg[i] <= seg_beg[i - 1]) return fail(c, GD_E_INVALID, "anchors must be strictly ascending");
         if (i) seg_end[i - 1] = seg_beg[i];
     }
-    seg_end[n_anchors - 1] = total;
-    for (hipStream_t s : g->inf_stream) HIPCHK(c, hipStreamSynchronize(s));      // every member is inflated
-    std::vector<uint32_t> status(nm);
-    HIPCHK(c, hipMemcpyAsync(status.data(), g->t_status, nm * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    seg_end[n_anchors - 1] = total;                   // a record of another reference ends the last walk earlier
+    std::vector<uint32_t> status;
+    if (!g->inflated) {
+        for (hipStream_t s : c->ing_stream) HIPCHK(c, hipStreamSynchronize(s));  // every member is inflated
+        status.resize(nm);
+        HIPCHK(c, hipMemcpyAsync(status.data(), g->t_status, nm * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    }
 
     // ---- count the records of every anchor segment ----------------------------------------------
     DevBuf d_seg;
@@ -1719,10 +1729,11 @@ int gd_ingest_finish(gd_ctx* c, int32_t tid, int32_t ref_id, const uint64_t* anc
     HIPCHK(c, hipMemcpyAsync(lastp.data(), s_last, n_anchors * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(flags.data(), s_flags, n_anchors * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    for (size_t m = 0; m < nm; ++m)
+    for (size_t m = 0; m < status.size(); ++m)
         if (status[m] != 0)
             return fail(c, GD_E_INVALID, "BGZF member at file offset %llu %s (decoder code %u)",
                         (unsigned long long)g->m_coff[m], status[m] == 18 ? "fails its CRC32" : "does not inflate", status[m]);
+    g->inflated = true;
     std::vector<uint64_t> rbase(n_anchors), obase(n_anchors);
     uint64_t N = 0, M = 0;
     int32_t prev_last = -0x7fffffff;
@@ -1773,7 +1784,18 @@ int gd_ingest_finish(gd_ctx* c, int32_t tid, int32_t ref_id, const uint64_t* anc
     if (n_records) *n_records = N;
     if (N && wants_pack(c, N, M))
         if (int r = pack_contig(c, h)) return r;
+    guard.on = release;
     return GD_OK;
+}
+
+int gd_ingest_decode(gd_ctx* c, int32_t tid, int32_t ref_id, const uint64_t* anchors, size_t n_anchors, uint64_t* n_records)
+{
+    return ingest_decode(c, tid, ref_id, anchors, n_anchors, n_records, false);
+}
+
+int gd_ingest_finish(gd_ctx* c, int32_t tid, int32_t ref_id, const uint64_t* anchors, size_t n_anchors, uint64_t* n_records)
+{
+    return ingest_decode(c, tid, ref_id, anchors, n_anchors, n_records, true);
 }
 
 // The BGZF members of a byte range (SAMv1 4.1: gzip header with a BC extra subfield).

@@ -417,12 +417,10 @@ int run(const DArgs& args)
         if (gpu_decode) {
             gdh::FileMap fm;
             if (!fm.open(args.bam)) gpu_decode = false;
-            for (size_t w = 0; gpu_decode && w < wanted.size(); ++w) {
-                uint64_t n = 0;
+            if (gpu_decode) {
                 bool io_ok = true;
-                GDCHK(gdh::ingest_reference_on_device(ctx, fm, lin, wanted[w], wanted[w], &n, &io_ok));
-                if (!io_ok) gpu_decode = false;
-                n_gpu_records += n;
+                GDCHK(gdh::ingest_references_on_device(ctx, fm, lin, wanted, wanted, &n_gpu_records, &io_ok));
+                if (!io_ok) { gpu_decode = false; n_gpu_records = 0; }
             }
             if (!gpu_decode) GDCHK(gd_reset(ctx));                    // fall back to the host decoder below
         }

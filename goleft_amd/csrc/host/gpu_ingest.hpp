@@ -42,47 +42,87 @@ struct FileMap {
     }
 };
 
-// Records of BAM reference ref_id -> engine contig engine_tid, decoded on the device.
-// lin = BamReader::linear_index() of the file.  The reference's byte range is streamed: its
-// members are listed from the mapping (headers and trailers only), then the bytes are fed in
+// Records of the BAM references refs[0..n) (ascending reference ids that have records) -> engine
+// contigs tids[0..n), decoded on the device.  lin = BamReader::linear_index() of the file.
+// References that follow each other in the file share one pass while the pass stays under
+// `group_bytes` of BGZF: an inflate pass costs ~0.1 s however small it is, and an assembly with
+// thousands of small contigs would otherwise pay it per contig.  A pass streams its byte range:
+// the members are listed from the mapping (headers and trailers only), then the bytes are fed in
 // 32 MB pieces -- page-cache reads of the next piece overlap the upload and inflate of the
 // previous ones.  Returns GD_OK (with *io_ok = false when the file does not look as the index
 // says: the caller falls back to the host decoder) or a gd_* error.
-inline int ingest_reference_on_device(gd_ctx* ctx, const FileMap& fm, const std::vector<std::vector<uint64_t>>& lin,
-                                      int32_t ref_id, int32_t engine_tid, uint64_t* n_records, bool* io_ok)
+inline int ingest_references_on_device(gd_ctx* ctx, const FileMap& fm, const std::vector<std::vector<uint64_t>>& lin,
+                                       const std::vector<int32_t>& refs, const std::vector<int32_t>& tids,
+                                       uint64_t* n_records, bool* io_ok, uint64_t group_bytes = 512ull << 20)
 {
     *io_ok = true;
     *n_records = 0;
-    const std::vector<uint64_t>& a = lin[(size_t)ref_id];
-    if (a.empty()) return GD_OK;                                  // no records on this reference
-    const uint64_t beg = a.front() >> 16;
-    // up to the member in which the next reference with records starts (inclusive), or EOF
-    uint64_t end = ~0ull;
-    for (size_t u = (size_t)ref_id + 1; u < lin.size(); ++u)
-        if (!lin[u].empty()) { end = (lin[u].front() >> 16) + 65536 + 26; break; }
-    if (end > fm.size) end = fm.size;
-    if (beg >= end) { *io_ok = false; return GD_OK; }
-    const uint8_t* base = fm.p + beg;
-    const size_t nb = (size_t)(end - beg);
-    size_t nm = 0;
-    int rc = gd_bgzf_members(base, nb, 0, nullptr, nullptr, nullptr, nullptr, nullptr, &nm);
-    if ((rc != GD_OK && rc != GD_E_CAPACITY) || nm == 0) { *io_ok = false; return GD_OK; }
-    std::vector<uint64_t> moff(nm);
-    std::vector<uint32_t> msize(nm), misize(nm), mcrc(nm);
-    std::vector<uint16_t> mhdr(nm);
-    if (gd_bgzf_members(base, nb, nm, moff.data(), msize.data(), mhdr.data(), misize.data(), mcrc.data(), &nm) != GD_OK) {
-        *io_ok = false;
-        return GD_OK;
+    // the reference with records that follows r in the file (lin.size(): none)
+    auto next_with_records = [&](size_t r) {
+        size_t u = r + 1;
+        while (u < lin.size() && lin[u].empty()) ++u;
+        return u;
+    };
+    size_t i = 0;
+    while (i < refs.size()) {
+        if (lin[(size_t)refs[i]].empty()) { ++i; continue; }     // no records on this reference
+        const uint64_t beg = lin[(size_t)refs[i]].front() >> 16;
+        // extend the pass over wanted references that are neighbours in the file
+        size_t j = i;
+        for (;;) {
+            const size_t nx = next_with_records((size_t)refs[j]);
+            size_t k = j + 1;
+            while (k < refs.size() && lin[(size_t)refs[k]].empty()) ++k;
+            if (k >= refs.size() || (size_t)refs[k] != nx) break;
+            if ((lin[nx].front() >> 16) - beg > group_bytes) break;
+            j = k;
+        }
+        // up to the member in which the next reference with records starts (inclusive), or EOF
+        uint64_t end = ~0ull;
+        const size_t after = next_with_records((size_t)refs[j]);
+        if (after < lin.size()) end = (lin[after].front() >> 16) + 65536 + 26;
+        if (end > fm.size) end = fm.size;
+        if (beg >= end) { *io_ok = false; return GD_OK; }
+        const uint8_t* base = fm.p + beg;
+        const size_t nb = (size_t)(end - beg);
+        size_t nm = 0;
+        int rc = gd_bgzf_members(base, nb, 0, nullptr, nullptr, nullptr, nullptr, nullptr, &nm);
+        if ((rc != GD_OK && rc != GD_E_CAPACITY) || nm == 0) { *io_ok = false; return GD_OK; }
+        std::vector<uint64_t> moff(nm);
+        std::vector<uint32_t> msize(nm), misize(nm), mcrc(nm);
+        std::vector<uint16_t> mhdr(nm);
+        if (gd_bgzf_members(base, nb, nm, moff.data(), msize.data(), mhdr.data(), misize.data(), mcrc.data(), &nm) != GD_OK) {
+            *io_ok = false;
+            return GD_OK;
+        }
+        const size_t used = (size_t)(moff[nm - 1] + msize[nm - 1]);   // a trailing partial member is not fed
+        rc = gd_ingest_begin(ctx, used, beg, nm, moff.data(), msize.data(), mhdr.data(), misize.data(), mcrc.data());
+        if (rc != GD_OK) return rc;
+        const size_t piece = 32u << 20;
+        for (size_t off = 0; off < used; off += piece) {
+            rc = gd_ingest_feed(ctx, base + off, used - off < piece ? used - off : piece);
+            if (rc != GD_OK) { (void)gd_ingest_abort(ctx); return rc; }
+        }
+        for (size_t k = i; k <= j; ++k) {
+            const std::vector<uint64_t>& a = lin[(size_t)refs[k]];
+            if (a.empty()) continue;
+            uint64_t n = 0;
+            rc = gd_ingest_decode(ctx, tids[k], refs[k], a.data(), a.size(), &n);   // drops the range on error
+            if (rc != GD_OK) return rc;
+            *n_records += n;
+        }
+        (void)gd_ingest_abort(ctx);                                   // done with this range
+        i = j + 1;
     }
-    const size_t used = (size_t)(moff[nm - 1] + msize[nm - 1]);   // a trailing partial member is not fed
-    rc = gd_ingest_begin(ctx, used, beg, nm, moff.data(), msize.data(), mhdr.data(), misize.data(), mcrc.data());
-    if (rc != GD_OK) return rc;
-    const size_t piece = 32u << 20;
-    for (size_t off = 0; off < used; off += piece) {
-        rc = gd_ingest_feed(ctx, base + off, used - off < piece ? used - off : piece);
-        if (rc != GD_OK) { (void)gd_ingest_abort(ctx); return rc; }
-    }
-    return gd_ingest_finish(ctx, engine_tid, ref_id, a.data(), a.size(), n_records);
+    return GD_OK;
+}
+
+// One reference (multidepth: one contig of one BAM).
+inline int ingest_reference_on_device(gd_ctx* ctx, const FileMap& fm, const std::vector<std::vector<uint64_t>>& lin,
+                                      int32_t ref_id, int32_t engine_tid, uint64_t* n_records, bool* io_ok)
+{
+    return ingest_references_on_device(ctx, fm, lin, std::vector<int32_t>{ref_id}, std::vector<int32_t>{engine_tid},
+                                       n_records, io_ok);
 }
 
 }  // namespace gdh

@@ -344,6 +344,35 @@ class DepthEngine:
                                              C.byref(cnt)))
         return int(cnt.value)
 
+    def ingest_bgzf_refs(self, data: bytes, base_coffset: int, refs, piece: int = 32 << 20):
+        """One fed byte range that holds several references: refs = [(tid, ref_id, anchors), ...] in
+        file order (gd_ingest_begin / feed, then one gd_ingest_decode per reference).  Returns the
+        record counts."""
+        raw = np.frombuffer(data, np.uint8)
+        nm = C.c_size_t()
+        rc = self._lib.gd_bgzf_members(raw.ctypes.data, raw.size, 0, None, None, None, None, None, C.byref(nm))
+        if rc not in (0, -8):
+            self._chk(rc)
+        n = nm.value
+        moff, msize, mhdr = np.zeros(n, np.uint64), np.zeros(n, np.uint32), np.zeros(n, np.uint16)
+        misz, mcrc = np.zeros(n, np.uint32), np.zeros(n, np.uint32)
+        self._chk(self._lib.gd_bgzf_members(raw.ctypes.data, raw.size, n, moff.ctypes.data, msize.ctypes.data,
+                                            mhdr.ctypes.data, misz.ctypes.data, mcrc.ctypes.data, C.byref(nm)))
+        used = int(moff[-1]) + int(msize[-1])
+        self._chk(self._lib.gd_ingest_begin(self._ctx, used, base_coffset, n, moff.ctypes.data, msize.ctypes.data,
+                                            mhdr.ctypes.data, misz.ctypes.data, mcrc.ctypes.data))
+        for off in range(0, used, piece):
+            k = min(piece, used - off)
+            self._chk(self._lib.gd_ingest_feed(self._ctx, raw[off:off + k].ctypes.data, k))
+        counts = []
+        for tid, ref_id, anchors in refs:
+            a = np.ascontiguousarray(anchors, np.uint64)
+            cnt = C.c_uint64()
+            self._chk(self._lib.gd_ingest_decode(self._ctx, tid, ref_id, a.ctypes.data, a.size, C.byref(cnt)))
+            counts.append(int(cnt.value))
+        self._chk(self._lib.gd_ingest_abort(self._ctx))
+        return counts
+
     def device_windows(self):
         """(ptr_sums, ptr_mins, n_total) device views of the concatenated window arrays."""
         ps, pm, n = C.c_void_p(), C.c_void_p(), C.c_size_t()

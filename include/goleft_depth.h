@@ -322,7 +322,12 @@ int gd_ingest_bgzf(gd_ctx* ctx, int32_t tid, int32_t ref_id, const uint8_t* data
  * size -- each piece is copied into page-locked staging (the pointer is not retained),
  * uploaded asynchronously, and every member that is complete on the device is inflated
  * behind the copy while the caller reads the next piece -- and finish with the anchors.
- * gd_ingest_bgzf is begin + one feed + finish.  gd_ingest_abort drops an unfinished read. */
+ * gd_ingest_bgzf is begin + one feed + finish.  gd_ingest_abort drops an unfinished read.
+ * A fed range may hold several references (a BAM with thousands of small contigs: one inflate
+ * pass has a latency floor of ~0.1 s whatever its size): gd_ingest_decode is gd_ingest_finish
+ * without the release, so call it once per reference of the range (each with that reference's
+ * anchors and its own contig), then gd_ingest_abort -- or gd_ingest_finish for the last one.
+ * An error in any of them drops the range. */
 int gd_bgzf_members(const uint8_t* data, size_t n_bytes, size_t cap, uint64_t* member_off, uint32_t* member_size,
                     uint16_t* header_size, uint32_t* isize, uint32_t* crc, size_t* n_members);
 int gd_ingest_begin(gd_ctx* ctx, uint64_t n_bytes, uint64_t base_coffset, size_t n_members,
@@ -330,6 +335,8 @@ int gd_ingest_begin(gd_ctx* ctx, uint64_t n_bytes, uint64_t base_coffset, size_t
                     const uint32_t* isize, const uint32_t* crc);
 int gd_ingest_feed(gd_ctx* ctx, const uint8_t* bytes, size_t n);
 int gd_ingest_finish(gd_ctx* ctx, int32_t tid, int32_t ref_id, const uint64_t* anchors, size_t n_anchors,
+                     uint64_t* n_records);
+int gd_ingest_decode(gd_ctx* ctx, int32_t tid, int32_t ref_id, const uint64_t* anchors, size_t n_anchors,
                      uint64_t* n_records);
 int gd_ingest_abort(gd_ctx* ctx);
 /* Page-locked host memory for the byte range handed to gd_ingest_bgzf (read the file

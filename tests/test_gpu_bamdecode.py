@@ -125,6 +125,45 @@ def test_ingest_fixture_bam(tmp_path, name):
             assert np.array_equal(eng.perbase(tid), po.perbase_c(r, 1, 0, L))
 
 
+def test_ingest_several_references_in_one_pass(tmp_path):
+    """gd_ingest_decode: one fed byte range (the whole file), one decode per reference -- many small
+    contigs, one without records, tiny pieces; then the range is dropped and a second pass works."""
+    from goleft_amd.engine import DepthEngine, GdError
+    rng = np.random.default_rng(33)
+    lens = [40_000, 900, 120_000, 5_000, 2_500, 64_000, 1]
+    contigs = [("s%d" % i, l) for i, l in enumerate(lens)]
+    reads = {t: H.random_reads(rng, l, int(rng.integers(1, 3000)), max_len=100)
+             for t, l in enumerate(lens) if t not in (3, 6)}
+    p = str(tmp_path / "g.bam")
+    bamio.write_bam(p, contigs, reads, unplaced=4, index=True)
+    data = open(p, "rb").read()
+    lin = bamio.read_bai_linear(p + ".bai")
+    with DepthEngine(0) as eng:
+        eng.set_params(window_size=100, min_mapq=1, min_cov=4)
+        eng.set_contigs(lens)
+        refs = [(t, t, lin[t]) for t in range(len(lens)) if len(lin[t])]
+        assert [t for t, _, _ in refs] == sorted(reads)
+        counts = eng.ingest_bgzf_refs(data, 0, refs, piece=50_001)
+        assert counts == [reads[t].n for t, _, _ in refs]
+        eng.compute()
+        for t, l in enumerate(lens):
+            r = reads.get(t, H.empty_reads())
+            assert np.array_equal(eng.perbase(t), po.perbase_c(r, 1, 0, l))
+        # a second pass over a sub-range (from reference 2 on) replaces those contigs' records
+        beg = int(lin[2][0]) >> 16
+        sub = [(t, t, lin[t]) for t in (2, 4, 5)]
+        assert eng.ingest_bgzf_refs(data[beg:], beg, sub) == [reads[t].n for t in (2, 4, 5)]
+        eng.compute()
+        assert np.array_equal(eng.perbase(5), po.perbase_c(reads[5], 1, 0, lens[5]))
+        # an anchor outside every member is refused and drops the range; the next read starts clean
+        bogus = np.asarray([int(lin[2][0]) + (7 << 16)], np.uint64)
+        with pytest.raises(GdError):
+            eng.ingest_bgzf_refs(data, 0, [(0, 0, lin[0]), (2, 2, bogus)])
+        assert eng.ingest_bgzf(0, data, 0, lin[0]) == reads[0].n
+        # anchors of one reference decoded as another: its walk ends at the first record (no records, no error)
+        assert eng.ingest_bgzf_refs(data, 0, [(1, 2, lin[1])]) == [0]
+
+
 def test_ingest_many_anchors_and_long_cigars(tmp_path):
     # 43 anchors (700 kb contig), reads with up to 70000 ops (stored through the CG:B,I tag)
     from goleft_amd.engine import DepthEngine
