@@ -79,6 +79,7 @@ SYMBOLS = {
     "gd_ingest_feed": (C.c_int, [_P, _P, C.c_size_t]),
     "gd_ingest_finish": (C.c_int, [_P, C.c_int32, C.c_int32, _P, C.c_size_t, C.POINTER(C.c_uint64)]),
     "gd_ingest_decode": (C.c_int, [_P, C.c_int32, C.c_int32, _P, C.c_size_t, C.POINTER(C.c_uint64)]),
+    "gd_ingest_release": (C.c_int, [_P]),
     "gd_ingest_abort": (C.c_int, [_P]),
     "gd_host_alloc": (C.c_int, [_P, C.c_size_t, C.POINTER(_P)]),
     "gd_host_free": (C.c_int, [_P, _P]),

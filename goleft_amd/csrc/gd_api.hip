@@ -63,6 +63,31 @@ struct RingSlot {
 // State of a device BAM read between gd_ingest_begin and gd_ingest_finish.
 struct IngestState;
 
+// Device buffers of one pending range (compressed bytes, inflated bytes, member tables): grow-only and
+// kept by the context between ranges -- allocating and freeing gigabytes per range cost 0.1-0.2 s.
+struct IngestBufs {
+    void *in = nullptr, *out = nullptr, *tab = nullptr;
+    size_t cap_in = 0, cap_out = 0, cap_tab = 0;
+    bool busy = false;
+    static bool fit(void** p, size_t* cap, size_t need)
+    {
+        if (need <= *cap && *p) return true;
+        if (*p) { (void)hipFree(*p); *p = nullptr; *cap = 0; }
+        if (hipMalloc(p, need ? need : 1) != hipSuccess) { *p = nullptr; return false; }
+        *cap = need ? need : 1;
+        return true;
+    }
+    void drop()
+    {
+        if (in) (void)hipFree(in);
+        if (out) (void)hipFree(out);
+        if (tab) (void)hipFree(tab);
+        in = out = tab = nullptr;
+        cap_in = cap_out = cap_tab = 0;
+    }
+};
+
+
 struct gd_ctx {
     int device = 0;
     hipStream_t stream = nullptr;       // compute stream
@@ -115,12 +140,20 @@ struct gd_ctx {
     uint32_t* d_md_bits = nullptr; size_t cap_md = 0;  // gd_md_flags: `any` words then `suf` words
     int64_t md_len = -1;                               // positions the bitmaps cover (-1: none yet)
     std::vector<int32_t> md_tids;                      // the samples they were built from
-    IngestState* ing = nullptr;                        // gd_ingest_begin .. gd_ingest_finish
+    // gd_ingest_begin .. gd_ingest_finish.  Two ranges may be pending: ing_q[0] is the oldest (the one
+    // gd_ingest_decode / _finish / _release act on), the last one is being fed -- so the inflate tail of
+    // one range overlaps the upload of the next.
+    IngestState* ing_q[2] = {nullptr, nullptr};
+    int ing_n = 0;
+    bool ing_stage_used[2] = {false, false};
+    int ing_cur = 0;
+    IngestBufs ing_bufs[2];
     // staging of the device BAM read, created by the first gd_ingest_begin and kept until gd_destroy
     // (page-locking 128 MB per contig would cost more than many contigs' whole decode)
     uint8_t* ing_stage[2] = {nullptr, nullptr};
     hipEvent_t ing_staged[2] = {nullptr, nullptr};
     hipStream_t ing_stream[4] = {};
+    int ing_copy_threads = 1;                          // GOLEFT_GD_COPY_THREADS: threads filling the staging buffer
     uint8_t* d_seq = nullptr;  size_t cap_seq = 0;     // gd_seq_load: one contig's bases, zero padded
     int64_t seq_len = -1;
     uint32_t seq_padded = 0;
@@ -363,17 +396,22 @@ struct IngestState {
     size_t nm = 0, next = 0;                            // members, first member not yet handed to the inflate kernel
     std::vector<uint64_t> m_coff, m_end, out_off;       // file offset, end offset in the range, offset in the inflated bytes
     std::vector<uint32_t> out_len;
-    DevBuf d_in, d_out, d_tab;
+    IngestBufs* bufs = nullptr;                         // one of gd_ctx::ing_bufs
+    uint8_t *d_in = nullptr, *d_out = nullptr;
     uint64_t *t_in_off = nullptr, *t_out_off = nullptr;
     uint32_t *t_in_len = nullptr, *t_out_len = nullptr, *t_status = nullptr, *t_crc = nullptr;
-    bool stage_used[2] = {false, false};
-    int cur = 0;
     // One lane inflates one member start to end (~0.1 s whatever the member count), so the members are
     // handed to the kernel in at most kBatches launches, each on its own stream: they overlap each other
     // and the upload of the bytes still to come.
     static constexpr int kBatches = 4;
     int n_launch = 0;
+    std::vector<hipEvent_t> inf_done;                   // one per inflate launch of THIS range
     bool inflated = false;                              // every member inflated and its status checked
+    ~IngestState()
+    {
+        for (hipEvent_t e : inf_done) (void)hipEventDestroy(e);
+        if (bufs) bufs->busy = false;
+    }
 };
 
 extern "C" {
@@ -440,6 +478,7 @@ int gd_create(int device_id, gd_ctx** out)
     if (const char* e = getenv("GOLEFT_GD_OPT")) c->tile_opt = atoi(e) & 1;
     if (const char* e = getenv("GOLEFT_GD_PATH"))
         c->path = e[0] == 's' ? GD_PATH_SCATTER : e[0] == 't' ? GD_PATH_TILE : e[0] == 'c' ? GD_PATH_CHUNK : GD_PATH_AUTO;
+    if (const char* e = getenv("GOLEFT_GD_COPY_THREADS")) { const int t = atoi(e); if (t >= 1 && t <= 16) c->ing_copy_threads = t; }
     if (const char* e = getenv("GOLEFT_GD_THREADS")) {
         int t = atoi(e);
         if (t == 256 || t == 512) c->tile_NT = t;
@@ -477,6 +516,7 @@ void gd_destroy(gd_ctx* c)
         if (c->ing_staged[k]) (void)hipEventDestroy(c->ing_staged[k]);
     }
     for (hipStream_t st : c->ing_stream) if (st) (void)hipStreamDestroy(st);
+    for (auto& b : c->ing_bufs) b.drop();
     for (auto& h : c->contigs) free_contig(h);
     for (auto& s : c->ring) {
         if (s.b.pos) (void)hipHostFree(s.b.pos);
@@ -773,6 +813,8 @@ int gd_compute(gd_ctx* c)
     if (!c) return GD_E_INVALID;
     if (int r = set_device(c)) return r;
     if (c->contigs.empty()) return fail(c, GD_E_STATE, "gd_set_contigs has not been called");
+    if (c->ing_n == 0)                                   // the BAM read is over: its buffers go back to HBM
+        for (auto& b : c->ing_bufs) b.drop();
     const int T = c->tile_T;
     const gd_params& P = c->params;
 
@@ -1555,14 +1597,37 @@ int gd_host_free(gd_ctx* c, void* p)
 int gd_ingest_abort(gd_ctx* c)
 {
     if (!c) return GD_E_INVALID;
-    if (!c->ing) return GD_OK;
+    if (c->ing_n == 0) return GD_OK;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->copy_stream);
     (void)hipStreamSynchronize(c->stream);
     for (hipStream_t s : c->ing_stream)
         if (s) (void)hipStreamSynchronize(s);
-    delete c->ing;
-    c->ing = nullptr;
+    for (int i = 0; i < c->ing_n; ++i) { delete c->ing_q[i]; c->ing_q[i] = nullptr; }
+    c->ing_n = 0;
+    return GD_OK;
+}
+
+// Drops the oldest pending range (its device work must be complete: the caller decoded it).
+static void ingest_pop(gd_ctx* c)
+{
+    if (c->ing_n == 0) return;
+    (void)hipStreamSynchronize(c->stream);               // the record walks read its inflated bytes
+    delete c->ing_q[0];
+    c->ing_q[0] = c->ing_q[1];
+    c->ing_q[1] = nullptr;
+    --c->ing_n;
+}
+
+int gd_ingest_release(gd_ctx* c)
+{
+    if (!c) return GD_E_INVALID;
+    if (int r = set_device(c)) return r;
+    if (c->ing_n == 0) return fail(c, GD_E_STATE, "no fed range is pending");
+    IngestState* g = c->ing_q[0];
+    if (g->next != g->nm) return fail(c, GD_E_STATE, "the oldest range is still being fed (gd_ingest_abort drops it)");
+    for (hipEvent_t e : g->inf_done) HIPCHK(c, hipEventSynchronize(e));   // its inflate kernels write its buffers
+    ingest_pop(c);
     return GD_OK;
 }
 
@@ -1572,10 +1637,13 @@ int gd_ingest_begin(gd_ctx* c, uint64_t n_bytes, uint64_t base_coffset, size_t n
     if (!c || n_members == 0 || !member_off || !member_size || !header_size || !isize || !crc) return GD_E_INVALID;
     if (int r = set_device(c)) return r;
     if (n_members > 0xfffffff0ull) return fail(c, GD_E_RANGE, "too many BGZF members");
-    (void)gd_ingest_abort(c);
+    // a range that was not fed to its end is an abandoned read: start over.  A completely fed one may
+    // wait for its decode while this one is fed.
+    if (c->ing_n && c->ing_q[c->ing_n - 1]->next != c->ing_q[c->ing_n - 1]->nm) (void)gd_ingest_abort(c);
+    if (c->ing_n == 2) return fail(c, GD_E_STATE, "two fed ranges are pending: decode and release the oldest first");
     IngestState* g = new (std::nothrow) IngestState();
     if (!g) return GD_E_NOMEM;
-    c->ing = g;
+    c->ing_q[c->ing_n++] = g;
     auto bail = [&](int code, const char* msg) { (void)gd_ingest_abort(c); return fail(c, code, "%s", msg); };
     g->n_bytes = n_bytes;
     g->nm = n_members;
@@ -1598,9 +1666,14 @@ int gd_ingest_begin(gd_ctx* c, uint64_t n_bytes, uint64_t base_coffset, size_t n
     }
     g->total = total;
     const size_t tab_bytes = n_members * (2 * sizeof(uint64_t) + 4 * sizeof(uint32_t));
-    if (g->d_in.alloc((size_t)n_bytes) != hipSuccess || g->d_out.alloc((size_t)total) != hipSuccess ||
-        g->d_tab.alloc(tab_bytes) != hipSuccess)
+    g->bufs = c->ing_bufs[0].busy ? &c->ing_bufs[1] : &c->ing_bufs[0];
+    g->bufs->busy = true;
+    if (!IngestBufs::fit(&g->bufs->in, &g->bufs->cap_in, (size_t)n_bytes) ||
+        !IngestBufs::fit(&g->bufs->out, &g->bufs->cap_out, (size_t)total) ||
+        !IngestBufs::fit(&g->bufs->tab, &g->bufs->cap_tab, tab_bytes))
         return bail(GD_E_NOMEM, "device allocation for the BAM decode failed");
+    g->d_in = static_cast<uint8_t*>(g->bufs->in);
+    g->d_out = static_cast<uint8_t*>(g->bufs->out);
     for (int k = 0; k < 2; ++k)
         if ((!c->ing_stage[k] &&
              hipHostMalloc(reinterpret_cast<void**>(&c->ing_stage[k]), IngestState::kStage, hipHostMallocDefault) != hipSuccess) ||
@@ -1608,7 +1681,7 @@ int gd_ingest_begin(gd_ctx* c, uint64_t n_bytes, uint64_t base_coffset, size_t n
             return bail(GD_E_NOMEM, "cannot allocate the page-locked staging buffers");
     for (hipStream_t& s : c->ing_stream)
         if (!s && hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return bail(GD_E_HIP, "cannot create a stream");
-    g->t_in_off = g->d_tab.as<uint64_t>();
+    g->t_in_off = static_cast<uint64_t*>(g->bufs->tab);
     g->t_out_off = g->t_in_off + n_members;
     g->t_in_len = reinterpret_cast<uint32_t*>(g->t_out_off + n_members);
     g->t_out_len = g->t_in_len + n_members;
@@ -1628,19 +1701,32 @@ int gd_ingest_feed(gd_ctx* c, const uint8_t* bytes, size_t n)
 {
     if (!c || (n && !bytes)) return GD_E_INVALID;
     if (int r = set_device(c)) return r;
-    IngestState* g = c->ing;
+    IngestState* g = c->ing_n ? c->ing_q[c->ing_n - 1] : nullptr;
     if (!g) return fail(c, GD_E_STATE, "gd_ingest_begin has not been called");
     if (g->fed + n > g->n_bytes) return fail(c, GD_E_RANGE, "more bytes fed than announced");
     size_t done = 0;
     while (done < n) {
         const size_t piece = std::min(n - done, IngestState::kStage);
-        const int k = g->cur;
-        if (g->stage_used[k]) HIPCHK(c, hipEventSynchronize(c->ing_staged[k]));   // its previous H2D has left the buffer
-        memcpy(c->ing_stage[k], bytes + done, piece);                            // the caller's pointer is not retained
-        HIPCHK(c, hipMemcpyAsync(g->d_in.as<uint8_t>() + g->fed, c->ing_stage[k], piece, hipMemcpyHostToDevice, c->copy_stream));
+        const int k = c->ing_cur;
+        if (c->ing_stage_used[k]) HIPCHK(c, hipEventSynchronize(c->ing_staged[k]));   // its previous H2D has left the buffer
+        // the caller's pointer is not retained
+        if (c->ing_copy_threads > 1 && piece >= (8u << 20)) {
+            const int nt = c->ing_copy_threads;
+            const size_t slice = ((piece / (size_t)nt) + 4095) & ~(size_t)4095;
+            std::vector<std::thread> th;
+            for (int t = 1; t < nt; ++t) {
+                const size_t b = std::min(piece, slice * t), e = std::min(piece, slice * (t + 1));
+                if (e > b) th.emplace_back([=]() { memcpy(c->ing_stage[k] + b, bytes + done + b, e - b); });
+            }
+            memcpy(c->ing_stage[k], bytes + done, std::min(piece, slice));
+            for (auto& t : th) t.join();
+        } else {
+            memcpy(c->ing_stage[k], bytes + done, piece);
+        }
+        HIPCHK(c, hipMemcpyAsync(g->d_in + g->fed, c->ing_stage[k], piece, hipMemcpyHostToDevice, c->copy_stream));
         HIPCHK(c, hipEventRecord(c->ing_staged[k], c->copy_stream));
-        g->stage_used[k] = true;
-        g->cur ^= 1;
+        c->ing_stage_used[k] = true;
+        c->ing_cur ^= 1;
         g->fed += piece;
         done += piece;
         // inflate the members that are now completely on the device, behind the copy: a quarter of
@@ -1652,13 +1738,17 @@ int gd_ingest_feed(gd_ctx* c, const uint8_t* bytes, size_t n)
             hipStream_t is = c->ing_stream[g->n_launch++ % IngestState::kBatches];
             HIPCHK(c, hipStreamWaitEvent(is, c->ing_staged[k], 0));
             gd::InflateJob ij{};
-            ij.comp = g->d_in.as<uint8_t>();
+            ij.comp = g->d_in;
             ij.in_off = g->t_in_off + g->next; ij.in_len = g->t_in_len + g->next;
             ij.out_off = g->t_out_off + g->next; ij.out_len = g->t_out_len + g->next;
-            ij.crc = g->t_crc + g->next; ij.out = g->d_out.as<uint8_t>(); ij.status = g->t_status + g->next;
+            ij.crc = g->t_crc + g->next; ij.out = g->d_out; ij.status = g->t_status + g->next;
             ij.n = (uint32_t)(last - g->next);
             hipLaunchKernelGGL(gd::gd_inflate_kernel, dim3((unsigned)((ij.n + gd::INF_LANES - 1) / gd::INF_LANES)),
                                dim3(gd::INF_LANES), 0, is, ij);
+            hipEvent_t done = nullptr;
+            HIPCHK(c, hipEventCreateWithFlags(&done, hipEventDisableTiming));
+            g->inf_done.push_back(done);
+            HIPCHK(c, hipEventRecord(done, is));
             g->next = last;
         }
     }
@@ -1671,9 +1761,9 @@ static int ingest_decode(gd_ctx* c, int32_t tid, int32_t ref_id, const uint64_t*
 {
     if (!c || !anchors || n_anchors == 0) return GD_E_INVALID;
     if (int r = set_device(c)) return r;
-    IngestState* g = c->ing;
+    IngestState* g = c->ing_n ? c->ing_q[0] : nullptr;                // the oldest pending range
     if (!g) return fail(c, GD_E_STATE, "gd_ingest_begin has not been called");
-    struct Guard { gd_ctx* c; bool on; ~Guard() { if (on) (void)gd_ingest_abort(c); } } guard{c, true};   // released on every error path
+    struct Guard { gd_ctx* c; bool on; ~Guard() { if (on) (void)gd_ingest_abort(c); } } guard{c, true};   // everything pending is dropped on an error
     if (tid < 0 || (size_t)tid >= c->contigs.size()) return fail(c, GD_E_RANGE, "tid %d out of range", tid);
     if (n_anchors > 0xfffffff0ull) return fail(c, GD_E_RANGE, "too many anchors");
     if (g->next != g->nm) return fail(c, GD_E_STATE, "only %zu of %zu BGZF members were fed", g->next, g->nm);
@@ -1694,7 +1784,7 @@ static int ingest_decode(gd_ctx* c, int32_t tid, int32_t ref_id, const uint64_t*
     seg_end[n_anchors - 1] = total;                   // a record of another reference ends the last walk earlier
     std::vector<uint32_t> status;
     if (!g->inflated) {
-        for (hipStream_t s : c->ing_stream) HIPCHK(c, hipStreamSynchronize(s));  // every member is inflated
+        for (hipEvent_t e : g->inf_done) HIPCHK(c, hipEventSynchronize(e));      // every member of this range is inflated
         status.resize(nm);
         HIPCHK(c, hipMemcpyAsync(status.data(), g->t_status, nm * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     }
@@ -1715,7 +1805,7 @@ static int ingest_decode(gd_ctx* c, int32_t tid, int32_t ref_id, const uint64_t*
     HIPCHK(c, hipMemcpyAsync(s_beg, seg_beg.data(), n_anchors * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(s_end, seg_end.data(), n_anchors * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
     gd::BamSegJob bj{};
-    bj.data = g->d_out.as<uint8_t>(); bj.n_bytes = total; bj.seg_beg = s_beg; bj.seg_end = s_end; bj.tid = ref_id;
+    bj.data = g->d_out; bj.n_bytes = total; bj.seg_beg = s_beg; bj.seg_end = s_end; bj.tid = ref_id;
     bj.n_seg = (uint32_t)n_anchors; bj.n_rec = s_nrec; bj.n_ops = s_nops; bj.first_pos = s_first; bj.last_pos = s_last;
     bj.flags = s_flags;
     const unsigned seg_grid = (unsigned)((n_anchors + 63) / 64);
@@ -1784,7 +1874,8 @@ static int ingest_decode(gd_ctx* c, int32_t tid, int32_t ref_id, const uint64_t*
     if (n_records) *n_records = N;
     if (N && wants_pack(c, N, M))
         if (int r = pack_contig(c, h)) return r;
-    guard.on = release;
+    guard.on = false;
+    if (release) ingest_pop(c);
     return GD_OK;
 }
 
@@ -1837,6 +1928,7 @@ int gd_ingest_bgzf(gd_ctx* c, int32_t tid, int32_t ref_id, const uint8_t* data, 
                    const uint64_t* anchors, size_t n_anchors, uint64_t* n_records)
 {
     if (!c || !data || !anchors || n_anchors == 0) return GD_E_INVALID;
+    (void)gd_ingest_abort(c);                              // one-shot form: nothing else may be pending
     size_t nm = 0;
     int rc = gd_bgzf_members(data, n_bytes, 0, nullptr, nullptr, nullptr, nullptr, nullptr, &nm);
     if (rc != GD_OK && rc != GD_E_CAPACITY) return fail(c, GD_E_INVALID, "the range does not start with a BGZF member");

@@ -10,7 +10,9 @@
 #include <unistd.h>
 
 #include <cstdint>
+#include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -46,7 +48,8 @@ struct FileMap {
 // contigs tids[0..n), decoded on the device.  lin = BamReader::linear_index() of the file.
 // References that follow each other in the file share one pass while the pass stays under
 // `group_bytes` of BGZF: an inflate pass costs ~0.1 s however small it is, and an assembly with
-// thousands of small contigs would otherwise pay it per contig.  A pass streams its byte range:
+// thousands of small contigs would otherwise pay it per contig; and a pass is decoded only after the
+// NEXT one has been fed, so that its last inflate launches overlap that upload.  A pass streams its byte range:
 // the members are listed from the mapping (headers and trailers only), then the bytes are fed in
 // 32 MB pieces -- page-cache reads of the next piece overlap the upload and inflate of the
 // previous ones.  Returns GD_OK (with *io_ok = false when the file does not look as the index
@@ -63,6 +66,24 @@ inline int ingest_references_on_device(gd_ctx* ctx, const FileMap& fm, const std
         while (u < lin.size() && lin[u].empty()) ++u;
         return u;
     };
+    // decode + release of the oldest pending pass: references refs[a..b]
+    auto decode_pass = [&](size_t a, size_t b) -> int {
+        for (size_t k = a; k <= b; ++k) {
+            const std::vector<uint64_t>& an = lin[(size_t)refs[k]];
+            if (an.empty()) continue;
+            uint64_t n = 0;
+            const int rc = gd_ingest_decode(ctx, tids[k], refs[k], an.data(), an.size(), &n);   // drops everything on error
+            if (rc != GD_OK) return rc;
+            *n_records += n;
+        }
+        return gd_ingest_release(ctx);
+    };
+    // GOLEFT_INGEST_TIMING=1: where a pass spends its wall clock (stderr; measurement only)
+    const bool timing = getenv("GOLEFT_INGEST_TIMING") != nullptr;
+    auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_list = 0, t_begin = 0, t_feed = 0, t_decode = 0;
+    bool pending = false;                                  // a fed pass waits for its decode
+    size_t pa = 0, pb = 0;
     size_t i = 0;
     while (i < refs.size()) {
         if (lin[(size_t)refs[i]].empty()) { ++i; continue; }     // no records on this reference
@@ -82,39 +103,45 @@ inline int ingest_references_on_device(gd_ctx* ctx, const FileMap& fm, const std
         const size_t after = next_with_records((size_t)refs[j]);
         if (after < lin.size()) end = (lin[after].front() >> 16) + 65536 + 26;
         if (end > fm.size) end = fm.size;
-        if (beg >= end) { *io_ok = false; return GD_OK; }
+        auto bad_file = [&]() { (void)gd_ingest_abort(ctx); *io_ok = false; *n_records = 0; return GD_OK; };
+        if (beg >= end) return bad_file();
         const uint8_t* base = fm.p + beg;
         const size_t nb = (size_t)(end - beg);
         size_t nm = 0;
+        const double t0 = now();
         int rc = gd_bgzf_members(base, nb, 0, nullptr, nullptr, nullptr, nullptr, nullptr, &nm);
-        if ((rc != GD_OK && rc != GD_E_CAPACITY) || nm == 0) { *io_ok = false; return GD_OK; }
+        if ((rc != GD_OK && rc != GD_E_CAPACITY) || nm == 0) return bad_file();
         std::vector<uint64_t> moff(nm);
         std::vector<uint32_t> msize(nm), misize(nm), mcrc(nm);
         std::vector<uint16_t> mhdr(nm);
-        if (gd_bgzf_members(base, nb, nm, moff.data(), msize.data(), mhdr.data(), misize.data(), mcrc.data(), &nm) != GD_OK) {
-            *io_ok = false;
-            return GD_OK;
-        }
+        if (gd_bgzf_members(base, nb, nm, moff.data(), msize.data(), mhdr.data(), misize.data(), mcrc.data(), &nm) != GD_OK)
+            return bad_file();
         const size_t used = (size_t)(moff[nm - 1] + msize[nm - 1]);   // a trailing partial member is not fed
+        const double t1 = now();
         rc = gd_ingest_begin(ctx, used, beg, nm, moff.data(), msize.data(), mhdr.data(), misize.data(), mcrc.data());
-        if (rc != GD_OK) return rc;
+        if (rc != GD_OK) { (void)gd_ingest_abort(ctx); return rc; }
+        const double t2 = now();
         const size_t piece = 32u << 20;
         for (size_t off = 0; off < used; off += piece) {
             rc = gd_ingest_feed(ctx, base + off, used - off < piece ? used - off : piece);
             if (rc != GD_OK) { (void)gd_ingest_abort(ctx); return rc; }
         }
-        for (size_t k = i; k <= j; ++k) {
-            const std::vector<uint64_t>& a = lin[(size_t)refs[k]];
-            if (a.empty()) continue;
-            uint64_t n = 0;
-            rc = gd_ingest_decode(ctx, tids[k], refs[k], a.data(), a.size(), &n);   // drops the range on error
+        const double t3 = now();
+        // this pass is on its way (upload + inflate are asynchronous): now decode the one before it
+        if (pending) {
+            rc = decode_pass(pa, pb);
             if (rc != GD_OK) return rc;
-            *n_records += n;
         }
-        (void)gd_ingest_abort(ctx);                                   // done with this range
+        t_list += t1 - t0; t_begin += t2 - t1; t_feed += t3 - t2; t_decode += now() - t3;
+        pending = true; pa = i; pb = j;
         i = j + 1;
     }
-    return GD_OK;
+    int rc_last = GD_OK;
+    if (pending) { const double t = now(); rc_last = decode_pass(pa, pb); t_decode += now() - t; }
+    if (timing)
+        fprintf(stderr, "{\"ingest_list_members_s\": %.4f, \"begin_s\": %.4f, \"feed_s\": %.4f, \"decode_s\": %.4f}\n",
+                t_list, t_begin, t_feed, t_decode);
+    return rc_last;
 }
 
 // One reference (multidepth: one contig of one BAM).

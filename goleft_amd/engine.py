@@ -344,10 +344,8 @@ class DepthEngine:
                                              C.byref(cnt)))
         return int(cnt.value)
 
-    def ingest_bgzf_refs(self, data: bytes, base_coffset: int, refs, piece: int = 32 << 20):
-        """One fed byte range that holds several references: refs = [(tid, ref_id, anchors), ...] in
-        file order (gd_ingest_begin / feed, then one gd_ingest_decode per reference).  Returns the
-        record counts."""
+    def ingest_feed_range(self, data: bytes, base_coffset: int, piece: int = 32 << 20) -> None:
+        """gd_ingest_begin + gd_ingest_feed of one byte range (it then waits for ingest_decode)."""
         raw = np.frombuffer(data, np.uint8)
         nm = C.c_size_t()
         rc = self._lib.gd_bgzf_members(raw.ctypes.data, raw.size, 0, None, None, None, None, None, C.byref(nm))
@@ -364,13 +362,23 @@ class DepthEngine:
         for off in range(0, used, piece):
             k = min(piece, used - off)
             self._chk(self._lib.gd_ingest_feed(self._ctx, raw[off:off + k].ctypes.data, k))
-        counts = []
-        for tid, ref_id, anchors in refs:
-            a = np.ascontiguousarray(anchors, np.uint64)
-            cnt = C.c_uint64()
-            self._chk(self._lib.gd_ingest_decode(self._ctx, tid, ref_id, a.ctypes.data, a.size, C.byref(cnt)))
-            counts.append(int(cnt.value))
-        self._chk(self._lib.gd_ingest_abort(self._ctx))
+
+    def ingest_decode(self, tid: int, ref_id: int, anchors) -> int:
+        """One reference of the OLDEST pending range -> contig tid (gd_ingest_decode)."""
+        a = np.ascontiguousarray(anchors, np.uint64)
+        cnt = C.c_uint64()
+        self._chk(self._lib.gd_ingest_decode(self._ctx, tid, ref_id, a.ctypes.data, a.size, C.byref(cnt)))
+        return int(cnt.value)
+
+    def ingest_release(self) -> None:
+        self._chk(self._lib.gd_ingest_release(self._ctx))
+
+    def ingest_bgzf_refs(self, data: bytes, base_coffset: int, refs, piece: int = 32 << 20):
+        """One fed byte range that holds several references: refs = [(tid, ref_id, anchors), ...] in
+        file order.  Returns the record counts."""
+        self.ingest_feed_range(data, base_coffset, piece)
+        counts = [self.ingest_decode(tid, ref_id, anchors) for tid, ref_id, anchors in refs]
+        self.ingest_release()
         return counts
 
     def device_windows(self):

@@ -326,8 +326,14 @@ int gd_ingest_bgzf(gd_ctx* ctx, int32_t tid, int32_t ref_id, const uint8_t* data
  * A fed range may hold several references (a BAM with thousands of small contigs: one inflate
  * pass has a latency floor of ~0.1 s whatever its size): gd_ingest_decode is gd_ingest_finish
  * without the release, so call it once per reference of the range (each with that reference's
- * anchors and its own contig), then gd_ingest_abort -- or gd_ingest_finish for the last one.
- * An error in any of them drops the range. */
+ * anchors and its own contig), then gd_ingest_release -- or gd_ingest_finish for the last one.
+ * Two ranges may be pending at a time: once a range is completely fed, gd_ingest_begin / _feed of
+ * the NEXT range may run before the first is decoded, so that the last inflate launches of one
+ * range (latency bound) overlap the upload of the next; gd_ingest_decode, _finish and _release
+ * always act on the oldest pending range, gd_ingest_feed on the newest.  A third gd_ingest_begin is
+ * refused (GD_E_STATE, nothing changes); gd_ingest_begin while the newest range is only partly fed
+ * abandons what is pending, like gd_ingest_abort (which drops everything).  An error while feeding or
+ * decoding drops everything pending. */
 int gd_bgzf_members(const uint8_t* data, size_t n_bytes, size_t cap, uint64_t* member_off, uint32_t* member_size,
                     uint16_t* header_size, uint32_t* isize, uint32_t* crc, size_t* n_members);
 int gd_ingest_begin(gd_ctx* ctx, uint64_t n_bytes, uint64_t base_coffset, size_t n_members,
@@ -338,6 +344,7 @@ int gd_ingest_finish(gd_ctx* ctx, int32_t tid, int32_t ref_id, const uint64_t* a
                      uint64_t* n_records);
 int gd_ingest_decode(gd_ctx* ctx, int32_t tid, int32_t ref_id, const uint64_t* anchors, size_t n_anchors,
                      uint64_t* n_records);
+int gd_ingest_release(gd_ctx* ctx);
 int gd_ingest_abort(gd_ctx* ctx);
 /* Page-locked host memory for the byte range handed to gd_ingest_bgzf (read the file
  * straight into it: the H2D copy then runs at PCIe speed instead of through a bounce

@@ -164,6 +164,43 @@ def test_ingest_several_references_in_one_pass(tmp_path):
         assert eng.ingest_bgzf_refs(data, 0, [(1, 2, lin[1])]) == [0]
 
 
+def test_ingest_two_ranges_pending(tmp_path):
+    """The next range is fed before the previous one is decoded (what the CLI does so that the inflate
+    tail of one pass overlaps the next upload): decode / release act on the oldest, a third begin is
+    refused."""
+    from goleft_amd.engine import DepthEngine, GdError
+    rng = np.random.default_rng(44)
+    lens = [90_000, 30_000, 150_000, 700]
+    contigs = [("q%d" % i, l) for i, l in enumerate(lens)]
+    reads = {t: H.random_reads(rng, l, int(rng.integers(500, 6000)), max_len=100) for t, l in enumerate(lens)}
+    p = str(tmp_path / "q.bam")
+    bamio.write_bam(p, contigs, reads, unplaced=2, index=True)
+    data = open(p, "rb").read()
+    lin = bamio.read_bai_linear(p + ".bai")
+    start = [int(lin[t][0]) >> 16 for t in range(4)]
+    with DepthEngine(0) as eng:
+        eng.set_params(window_size=100, min_mapq=1, min_cov=4)
+        eng.set_contigs(lens)
+        eng.ingest_feed_range(data[:start[2] + 65536 + 26], 0, piece=40_000)       # references 0 and 1
+        eng.ingest_feed_range(data[start[2]:], start[2], piece=1 << 20)            # references 2 and 3
+        with pytest.raises(GdError):
+            eng.ingest_feed_range(data, 0)                                         # a third pending range: refused,
+        assert eng.ingest_decode(0, 0, lin[0]) == reads[0].n                       # nothing changed
+        assert eng.ingest_decode(1, 1, lin[1]) == reads[1].n
+        eng.ingest_release()
+        assert eng.ingest_decode(2, 2, lin[2]) == reads[2].n
+        assert eng.ingest_decode(3, 3, lin[3]) == reads[3].n
+        eng.ingest_release()
+        with pytest.raises(GdError):
+            eng.ingest_release()                                                   # nothing pending
+        eng.compute()
+        for t, l in enumerate(lens):
+            assert np.array_equal(eng.perbase(t), po.perbase_c(reads[t], 1, 0, l))
+        # a fed range nobody decodes is dropped by the one-shot form
+        eng.ingest_feed_range(data[:start[2] + 65536 + 26], 0)
+        assert eng.ingest_bgzf(3, data[start[3]:], start[3], lin[3]) == reads[3].n
+
+
 def test_ingest_many_anchors_and_long_cigars(tmp_path):
     # 43 anchors (700 kb contig), reads with up to 70000 ops (stored through the CG:B,I tag)
     from goleft_amd.engine import DepthEngine
