@@ -152,7 +152,8 @@ struct gd_ctx {
     // (page-locking 128 MB per contig would cost more than many contigs' whole decode)
     uint8_t* ing_stage[2] = {nullptr, nullptr};
     hipEvent_t ing_staged[2] = {nullptr, nullptr};
-    hipStream_t ing_stream[4] = {};
+    hipStream_t ing_stream[8] = {};                     // inflate launches rotate over these (two pending ranges x 4)
+    unsigned ing_launch_seq = 0;
     int ing_copy_threads = 1;                          // GOLEFT_GD_COPY_THREADS: threads filling the staging buffer
     uint8_t* d_seq = nullptr;  size_t cap_seq = 0;     // gd_seq_load: one contig's bases, zero padded
     int64_t seq_len = -1;
@@ -1735,7 +1736,8 @@ int gd_ingest_feed(gd_ctx* c, const uint8_t* bytes, size_t n)
         while (last < g->nm && g->m_end[last] <= g->fed) ++last;
         const size_t quota = std::max<size_t>((g->nm + IngestState::kBatches - 1) / IngestState::kBatches, 1);
         if (last > g->next && (last - g->next >= quota || last == g->nm) ) {
-            hipStream_t is = c->ing_stream[g->n_launch++ % IngestState::kBatches];
+            hipStream_t is = c->ing_stream[c->ing_launch_seq++ % 8u];
+            ++g->n_launch;
             HIPCHK(c, hipStreamWaitEvent(is, c->ing_staged[k], 0));
             gd::InflateJob ij{};
             ij.comp = g->d_in;

@@ -31,8 +31,13 @@ struct InflateJob {
 
 constexpr int INF_LANES = 64;      // lanes (= members in flight) per workgroup
 constexpr int INF_MAXL = 288, INF_MAXD = 30;
-// per-lane LDS tables, uint16: lencnt[16] lensym[288] distcnt[16] distsym[30]
-constexpr int INF_TBL = 16 + INF_MAXL + 16 + INF_MAXD;
+// Per-lane LDS tables, 384 bytes: cnt[16] (uint16, shared by the two builds: the counts live in
+// registers while a block is decoded), nlit[16] (uint16), litlen symbols [288] and distance symbols
+// [32] as BYTES.  A lit/len symbol needs 9 bits; the ninth is not stored: within one code length the
+// canonical order is ascending symbol value, so the first nlit[len] entries are literals (< 256) and
+// the rest are 256 + the stored byte.  (uint16 symbols were 700 bytes per lane = 3 workgroups per CU;
+// one lane inflates one member and is latency bound, so members in flight are the throughput.)
+constexpr int INF_TBL_BYTES = 32 + 32 + INF_MAXL + 32;
 
 struct BitReader {
     const uint8_t* p;              // next byte not yet fetched into `ahead`
@@ -77,16 +82,23 @@ struct BitReader {
 // Canonical Huffman tables of one lane in LDS: t[entry * INF_LANES + lane]
 struct HuffLds {
     uint16_t* cnt;                 // [16] codes of each length
-    uint16_t* sym;                 // symbols ordered by code
+    uint16_t* nlit;                // [16] of those, symbols below 256 (lit/len table only)
+    uint8_t* sym;                  // low 8 bits of the symbols, ordered by code
     __device__ __forceinline__ uint16_t& c(int i) const { return cnt[i * INF_LANES]; }
-    __device__ __forceinline__ uint16_t& s(int i) const { return sym[i * INF_LANES]; }
+    __device__ __forceinline__ uint16_t& nl(int i) const { return nlit[i * INF_LANES]; }
+    __device__ __forceinline__ uint8_t& s(int i) const { return sym[i * INF_LANES]; }
 };
 
 // Builds the tables from code lengths (puff.c construct()); returns false for an over-subscribed set.
+// LIT: also count the symbols below 256 per length (what restores the ninth symbol bit).
+template <bool LIT>
 __device__ __forceinline__ bool huff_build(const HuffLds& h, const uint8_t* lengths, int n)
 {
-    for (int l = 0; l <= 15; ++l) h.c(l) = 0;
-    for (int i = 0; i < n; ++i) h.c(lengths[i]) = (uint16_t)(h.c(lengths[i]) + 1);
+    for (int l = 0; l <= 15; ++l) { h.c(l) = 0; if (LIT) h.nl(l) = 0; }
+    for (int i = 0; i < n; ++i) {
+        h.c(lengths[i]) = (uint16_t)(h.c(lengths[i]) + 1);
+        if (LIT && i < 256) h.nl(lengths[i]) = (uint16_t)(h.nl(lengths[i]) + 1);
+    }
     int left = 1;
     for (int l = 1; l <= 15; ++l) {
         left <<= 1;
@@ -97,7 +109,7 @@ __device__ __forceinline__ bool huff_build(const HuffLds& h, const uint8_t* leng
     offs[1] = 0;
     for (int l = 1; l < 15; ++l) offs[l + 1] = (uint16_t)(offs[l] + h.c(l));
     for (int i = 0; i < n; ++i)
-        if (lengths[i] != 0) h.s(offs[lengths[i]]++) = (uint16_t)i;
+        if (lengths[i] != 0) h.s(offs[lengths[i]]++) = (uint8_t)i;
     return true;
 }
 
@@ -110,11 +122,18 @@ struct HuffCnt {
 #pragma unroll
         for (int k = 0; k < 8; ++k) w[k] = (uint32_t)h.c(2 * k) | ((uint32_t)h.c(2 * k + 1) << 16);
     }
+    __device__ __forceinline__ void load_nlit(const HuffLds& h)
+    {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) w[k] = (uint32_t)h.nl(2 * k) | ((uint32_t)h.nl(2 * k + 1) << 16);
+    }
     __device__ __forceinline__ int at(int len) const { return (int)((w[len >> 1] >> ((len & 1) * 16)) & 0xffffu); }
 };
 
-// One symbol (puff.c decode(), bit serial over the code lengths).
-__device__ __forceinline__ int huff_decode(BitReader& br, const HuffLds& h, const HuffCnt& hc)
+// One symbol (puff.c decode(), bit serial over the code lengths).  LIT: a lit/len table, nl holds its
+// per-length literal counts.
+template <bool LIT>
+__device__ __forceinline__ int huff_decode(BitReader& br, const HuffLds& h, const HuffCnt& hc, const HuffCnt& nl)
 {
     if (br.cnt < 15) br.refill();
     int code = 0, first = 0, index = 0;
@@ -128,7 +147,9 @@ __device__ __forceinline__ int huff_decode(BitReader& br, const HuffLds& h, cons
             if (br.cnt < len) { br.bad = true; return -1; }
             br.buf >>= len;
             br.cnt -= len;
-            return h.s(index + (code - first));
+            const int k = code - first;
+            const int v = h.s(index + k);
+            return LIT ? v | ((int)(k >= nl.at(len)) << 8) : v;
         }
         index += count;
         first += count;
@@ -141,7 +162,7 @@ __device__ __forceinline__ int huff_decode(BitReader& br, const HuffLds& h, cons
 
 __global__ __launch_bounds__(INF_LANES) void gd_inflate_kernel(InflateJob job)
 {
-    __shared__ uint16_t s_tbl[INF_TBL * INF_LANES];
+    __shared__ __attribute__((aligned(4))) uint8_t s_tbl[INF_TBL_BYTES * INF_LANES];
     __shared__ uint32_t s_crc[256];                        // CRC-32 (IEEE 802.3, reflected) byte table
     for (int i = threadIdx.x; i < 256; i += INF_LANES) {
         uint32_t c = (uint32_t)i;
@@ -153,10 +174,12 @@ __global__ __launch_bounds__(INF_LANES) void gd_inflate_kernel(InflateJob job)
     if (m >= job.n) return;
     const int lane = threadIdx.x;
     HuffLds hl, hd;
-    hl.cnt = s_tbl + lane;
-    hl.sym = s_tbl + 16 * INF_LANES + lane;
-    hd.cnt = s_tbl + (16 + INF_MAXL) * INF_LANES + lane;
-    hd.sym = s_tbl + (16 + INF_MAXL + 16) * INF_LANES + lane;
+    hl.cnt = reinterpret_cast<uint16_t*>(s_tbl) + lane;
+    hl.nlit = reinterpret_cast<uint16_t*>(s_tbl + 32 * INF_LANES) + lane;
+    hl.sym = s_tbl + 64 * INF_LANES + lane;
+    hd.cnt = hl.cnt;                                       // built after the lit/len counts are in registers
+    hd.nlit = nullptr;
+    hd.sym = s_tbl + (64 + INF_MAXL) * INF_LANES + lane;
 
     BitReader br;
     br.init(job.comp + job.in_off[m], job.comp + job.in_off[m] + job.in_len[m]);
@@ -187,27 +210,31 @@ __global__ __launch_bounds__(INF_LANES) void gd_inflate_kernel(InflateJob job)
         }
         if (type == 3) { err = 4; break; }
         uint8_t lengths[INF_MAXL + INF_MAXD + 2];
+        HuffCnt cl, cd, nl;
         if (type == 1) {                                   // fixed codes
             int s = 0;
             for (; s < 144; ++s) lengths[s] = 8;
             for (; s < 256; ++s) lengths[s] = 9;
             for (; s < 280; ++s) lengths[s] = 7;
             for (; s < 288; ++s) lengths[s] = 8;
-            huff_build(hl, lengths, 288);
+            huff_build<true>(hl, lengths, 288);
+            cl.load(hl);
+            nl.load_nlit(hl);
             for (s = 0; s < 30; ++s) lengths[s] = 5;
-            huff_build(hd, lengths, 30);
+            huff_build<false>(hd, lengths, 30);
+            cd.load(hd);
         } else {                                           // dynamic codes
             const int nlen = (int)br.bits(5) + 257, ndist = (int)br.bits(5) + 1, ncode = (int)br.bits(4) + 4;
             if (br.bad || nlen > INF_MAXL || ndist > INF_MAXD) { err = 5; break; }
             int idx = 0;
             for (; idx < ncode; ++idx) lengths[order[idx]] = (uint8_t)br.bits(3);
             for (; idx < 19; ++idx) lengths[order[idx]] = 0;
-            if (!huff_build(hl, lengths, 19)) { err = 6; break; }     // the code-length code borrows the lit/len table
+            if (!huff_build<false>(hl, lengths, 19)) { err = 6; break; }   // the code-length code borrows the lit/len table
             HuffCnt cc;
             cc.load(hl);
             idx = 0;
             while (idx < nlen + ndist) {
-                int sym = huff_decode(br, hl, cc);
+                int sym = huff_decode<false>(br, hl, cc, cc);
                 if (sym < 0) { err = 7; break; }
                 if (sym < 16) { lengths[idx++] = (uint8_t)sym; continue; }
                 int prev = 0, rep;
@@ -224,13 +251,13 @@ __global__ __launch_bounds__(INF_LANES) void gd_inflate_kernel(InflateJob job)
             if (lengths[256] == 0) { err = 10; break; }
             uint8_t dl[INF_MAXD];
             for (int k = 0; k < ndist; ++k) dl[k] = lengths[nlen + k];
-            if (!huff_build(hl, lengths, nlen)) { err = 11; break; }
-            if (!huff_build(hd, dl, ndist)) { err = 12; break; }
+            if (!huff_build<true>(hl, lengths, nlen)) { err = 11; break; }
+            cl.load(hl);
+            nl.load_nlit(hl);
+            if (!huff_build<false>(hd, dl, ndist)) { err = 12; break; }
+            cd.load(hd);
         }
         // ---- the block's symbols ---------------------------------------------
-        HuffCnt cl, cd;
-        cl.load(hl);
-        cd.load(hd);
         // Short matches far enough back (the common case) are DEFERRED: their 16 source bytes are
         // loaded now and stored only after the next symbol has been decoded, so the global load
         // latency overlaps that decode instead of stalling the wave (with 64 lanes in 64 different
@@ -250,7 +277,7 @@ __global__ __launch_bounds__(INF_LANES) void gd_inflate_kernel(InflateJob job)
             pend_n = 0;
         };
         for (;;) {
-            const int sym = huff_decode(br, hl, cl);
+            const int sym = huff_decode<true>(br, hl, cl, nl);
             flush();
             if (sym < 0) { err = 13; break; }
             if (sym < 256) {
@@ -268,7 +295,7 @@ __global__ __launch_bounds__(INF_LANES) void gd_inflate_kernel(InflateJob job)
                 if (ls < 8) len = 3u + (uint32_t)ls;
                 else if (ls == 28) len = 258u;
                 else { const int e = (ls >> 2) - 1; len = 3u + ((4u + (uint32_t)(ls & 3)) << e) + br.bits(e); }
-                const int ds = huff_decode(br, hd, cd);
+                const int ds = huff_decode<false>(br, hd, cd, cd);
                 if (ds < 0 || ds >= 30) { err = 15; break; }
                 uint32_t dist;
                 if (ds < 4) dist = 1u + (uint32_t)ds;
