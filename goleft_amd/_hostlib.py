@@ -24,6 +24,8 @@ SYMBOLS = {
     "gdh_depthwed_cells": (None, [_P, _P, C.c_size_t, _P]),
     "gdh_multidepth_main": (C.c_int, [C.c_int, C.POINTER(C.c_char_p)]),
     "gdh_multidepth_run": (C.c_int, [C.c_int, C.POINTER(C.c_char_p), C.c_char_p]),
+    "gdh_plan_ingest_passes": (C.c_size_t, [_P, _P, C.c_size_t, _P, C.c_size_t, C.c_uint64, C.c_uint64, C.c_size_t,
+                                            _P, _P, _P, _P]),
     "gdh_multidepth_blocks": (C.c_int64, [_P, _P, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
                                           _P, _P, C.c_int64]),
     "gdh_bam_open": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(_P)]),
@@ -173,3 +175,16 @@ def multidepth_blocks(any_mask, suf_mask, chunk, max_skip=10, min_size=15, windo
     load().gdh_multidepth_blocks(aw.ctypes.data, sw.ctypes.data, n, chunk, max_skip, min_size, window,
                                  st.ctypes.data, en.ctypes.data, cnt)
     return np.stack([st, en], 1)
+
+
+def plan_ingest_passes(start, has, wanted, file_size, group_bytes):
+    """[(first, last, beg, end)] -- how goleft-depth cuts a BAM into device passes (gdh_plan_ingest_passes)."""
+    import numpy as np
+    st = np.ascontiguousarray(start, np.uint64)
+    hs = np.ascontiguousarray(has, np.uint8)
+    w = np.ascontiguousarray(wanted, np.int32)
+    cap = max(1, len(w))
+    f, l, b, e = (np.zeros(cap, np.uint64) for _ in range(4))
+    n = load().gdh_plan_ingest_passes(st.ctypes.data, hs.ctypes.data, len(st), w.ctypes.data, len(w), file_size,
+                                      group_bytes, cap, f.ctypes.data, l.ctypes.data, b.ctypes.data, e.ctypes.data)
+    return [(int(f[k]), int(l[k]), int(b[k]), int(e[k])) for k in range(n)]

@@ -44,6 +44,51 @@ struct FileMap {
     }
 };
 
+// One device pass of the BAM read: references refs[first..last] (indices into the wanted list) and the
+// byte range [beg, end) of the file that holds all their records.
+struct IngestPass {
+    size_t first, last;
+    uint64_t beg, end;
+};
+
+// Plans the passes for the wanted references refs (ascending reference ids).  start[r] is the file offset
+// of the BGZF member in which reference r's first record lies (the first linear-index entry >> 16) and
+// has[r] whether r has records at all.  Wanted references that follow each other in the file -- nothing
+// with records between them -- share a pass while it stays under group_bytes; a pass ends with the member
+// in which the next reference with records starts (records may straddle it), or at the end of the file.
+inline std::vector<IngestPass> plan_ingest_passes(const std::vector<uint64_t>& start, const std::vector<char>& has,
+                                                  const std::vector<int32_t>& refs, uint64_t file_size,
+                                                  uint64_t group_bytes)
+{
+    std::vector<IngestPass> out;
+    auto next_with_records = [&](size_t r) {
+        size_t u = r + 1;
+        while (u < has.size() && !has[u]) ++u;
+        return u;
+    };
+    size_t i = 0;
+    while (i < refs.size()) {
+        if (!has[(size_t)refs[i]]) { ++i; continue; }
+        const uint64_t beg = start[(size_t)refs[i]];
+        size_t j = i;
+        for (;;) {
+            const size_t nx = next_with_records((size_t)refs[j]);
+            size_t k = j + 1;
+            while (k < refs.size() && !has[(size_t)refs[k]]) ++k;
+            if (k >= refs.size() || (size_t)refs[k] != nx) break;
+            if (start[nx] - beg > group_bytes) break;
+            j = k;
+        }
+        uint64_t end = ~0ull;
+        const size_t after = next_with_records((size_t)refs[j]);
+        if (after < has.size()) end = start[after] + 65536 + 26;
+        if (end > file_size) end = file_size;
+        out.push_back(IngestPass{i, j, beg, end});
+        i = j + 1;
+    }
+    return out;
+}
+
 // Records of the BAM references refs[0..n) (ascending reference ids that have records) -> engine
 // contigs tids[0..n), decoded on the device.  lin = BamReader::linear_index() of the file.
 // References that follow each other in the file share one pass while the pass stays under
@@ -60,12 +105,11 @@ inline int ingest_references_on_device(gd_ctx* ctx, const FileMap& fm, const std
 {
     *io_ok = true;
     *n_records = 0;
-    // the reference with records that follows r in the file (lin.size(): none)
-    auto next_with_records = [&](size_t r) {
-        size_t u = r + 1;
-        while (u < lin.size() && lin[u].empty()) ++u;
-        return u;
-    };
+    std::vector<uint64_t> start(lin.size(), 0);
+    std::vector<char> has(lin.size(), 0);
+    for (size_t r = 0; r < lin.size(); ++r)
+        if (!lin[r].empty()) { has[r] = 1; start[r] = lin[r].front() >> 16; }
+    const std::vector<IngestPass> passes = plan_ingest_passes(start, has, refs, fm.size, group_bytes);
     // decode + release of the oldest pending pass: references refs[a..b]
     auto decode_pass = [&](size_t a, size_t b) -> int {
         for (size_t k = a; k <= b; ++k) {
@@ -84,25 +128,9 @@ inline int ingest_references_on_device(gd_ctx* ctx, const FileMap& fm, const std
     double t_list = 0, t_begin = 0, t_feed = 0, t_decode = 0;
     bool pending = false;                                  // a fed pass waits for its decode
     size_t pa = 0, pb = 0;
-    size_t i = 0;
-    while (i < refs.size()) {
-        if (lin[(size_t)refs[i]].empty()) { ++i; continue; }     // no records on this reference
-        const uint64_t beg = lin[(size_t)refs[i]].front() >> 16;
-        // extend the pass over wanted references that are neighbours in the file
-        size_t j = i;
-        for (;;) {
-            const size_t nx = next_with_records((size_t)refs[j]);
-            size_t k = j + 1;
-            while (k < refs.size() && lin[(size_t)refs[k]].empty()) ++k;
-            if (k >= refs.size() || (size_t)refs[k] != nx) break;
-            if ((lin[nx].front() >> 16) - beg > group_bytes) break;
-            j = k;
-        }
-        // up to the member in which the next reference with records starts (inclusive), or EOF
-        uint64_t end = ~0ull;
-        const size_t after = next_with_records((size_t)refs[j]);
-        if (after < lin.size()) end = (lin[after].front() >> 16) + 65536 + 26;
-        if (end > fm.size) end = fm.size;
+    for (const IngestPass& ps : passes) {
+        const size_t i = ps.first, j = ps.last;
+        const uint64_t beg = ps.beg, end = ps.end;
         auto bad_file = [&]() { (void)gd_ingest_abort(ctx); *io_ok = false; *n_records = 0; return GD_OK; };
         if (beg >= end) return bad_file();
         const uint8_t* base = fm.p + beg;
@@ -134,7 +162,6 @@ inline int ingest_references_on_device(gd_ctx* ctx, const FileMap& fm, const std
         }
         t_list += t1 - t0; t_begin += t2 - t1; t_feed += t3 - t2; t_decode += now() - t3;
         pending = true; pa = i; pb = j;
-        i = j + 1;
     }
     int rc_last = GD_OK;
     if (pending) { const double t = now(); rc_last = decode_pass(pa, pb); t_decode += now() - t; }

@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "bam_reader.hpp"
+#include "gpu_ingest.hpp"
 
 struct gdh_bam {
     gdh::BamReader rd;
@@ -31,6 +32,26 @@ struct gdh_intervals {
 };
 
 extern "C" {
+
+size_t gdh_plan_ingest_passes(const uint64_t* start, const uint8_t* has, size_t n_refs, const int32_t* wanted,
+                              size_t n_wanted, uint64_t file_size, uint64_t group_bytes, size_t cap,
+                              uint64_t* first, uint64_t* last, uint64_t* beg, uint64_t* end)
+{
+    if ((n_refs && (!start || !has)) || (n_wanted && !wanted)) return 0;
+    for (size_t k = 0; k < n_wanted; ++k)
+        if (wanted[k] < 0 || (size_t)wanted[k] >= n_refs) return 0;
+    const std::vector<uint64_t> st(start, start + n_refs);
+    const std::vector<char> hs(has, has + n_refs);
+    const std::vector<int32_t> w(wanted, wanted + n_wanted);
+    const std::vector<gdh::IngestPass> ps = gdh::plan_ingest_passes(st, hs, w, file_size, group_bytes);
+    for (size_t k = 0; k < ps.size() && k < cap; ++k) {
+        if (first) first[k] = ps[k].first;
+        if (last) last[k] = ps[k].last;
+        if (beg) beg[k] = ps[k].beg;
+        if (end) end[k] = ps[k].end;
+    }
+    return ps.size();
+}
 
 int gdh_bam_open(const char* path, int threads, gdh_bam** out)
 {

@@ -74,6 +74,14 @@ int64_t gdh_multidepth_blocks(const uint32_t* any_bits, const uint32_t* suf_bits
                               int64_t* ends, int64_t cap);
 
 /* ---- BAM decode (replaces the read side of the samtools child) ---------- */
+/* How `goleft-depth` cuts a BAM into device passes (host/gpu_ingest.hpp; exported for tests):
+ * start[r] / has[r] describe the n_refs references of the file (offset of the BGZF member of r's first
+ * record; whether r has records), wanted[] the ascending reference ids to read.  Writes up to cap
+ * passes {first, last (indices into wanted), beg, end (file offsets)} and returns their number. */
+size_t gdh_plan_ingest_passes(const uint64_t* start, const uint8_t* has, size_t n_refs, const int32_t* wanted,
+                              size_t n_wanted, uint64_t file_size, uint64_t group_bytes, size_t cap,
+                              uint64_t* first, uint64_t* last, uint64_t* beg, uint64_t* end);
+
 typedef struct gdh_bam gdh_bam;
 int  gdh_bam_open(const char* path, int threads, gdh_bam** out);
 void gdh_bam_close(gdh_bam* b);

@@ -215,3 +215,44 @@ def test_intervals_readtree_overlaps(hostlib, tmp_path):
         e = s + int(rng.integers(0, 50))
         want = any(ie > s and is_ < e for is_, ie in ivs[c])   # intervals.go:16-19
         assert t.overlaps(c, s, e) == want
+
+
+@settings(max_examples=200, deadline=None)
+@given(st.integers(0, 2 ** 31), st.integers(1, 400), st.sampled_from([1 << 16, 1 << 22, 1 << 29]))
+def test_ingest_pass_plan(hostlib, seed, n_refs, group_bytes):
+    """How the CLI cuts a BAM into device passes (host/gpu_ingest.hpp): every wanted reference with
+    records is in exactly one pass, in order; a pass never spans an unwanted reference that has records;
+    it begins at its first reference's first member and ends one member past where the next reference
+    with records begins; several references share a pass only while it stays under group_bytes."""
+    rng = np.random.default_rng(seed)
+    has = (rng.random(n_refs) < rng.choice([0.2, 0.7, 1.0])).astype(np.uint8)
+    sizes = rng.choice([300, 70_000, 5_000_000, 900_000_000], size=n_refs, p=[0.5, 0.3, 0.15, 0.05])
+    start = np.zeros(n_refs, np.uint64)
+    off = 4096
+    for r in range(n_refs):
+        if has[r]:
+            start[r] = off
+            off += int(sizes[r])
+    file_size = off + 28
+    wanted = np.flatnonzero(rng.random(n_refs) < rng.choice([0.1, 0.6, 1.0])).astype(np.int32)
+    passes = hostlib.plan_ingest_passes(start, has, wanted, file_size, group_bytes)
+    with_records = [int(r) for r in range(n_refs) if has[r]]
+    covered = []
+    for first, last, beg, end in passes:
+        refs = [int(wanted[k]) for k in range(first, last + 1) if has[wanted[k]]]
+        assert refs and has[wanted[first]] and has[wanted[last]]
+        covered += refs
+        lo, hi = with_records.index(refs[0]), with_records.index(refs[-1])
+        assert with_records[lo:hi + 1] == refs                     # nothing with records skipped inside a pass
+        assert beg == int(start[refs[0]])
+        nxt = with_records[hi + 1] if hi + 1 < len(with_records) else None
+        assert end == (min(int(start[nxt]) + 65536 + 26, file_size) if nxt is not None else file_size)
+        assert beg < end
+        if len(refs) > 1:
+            assert int(start[refs[-1]]) - beg <= group_bytes
+    assert covered == [int(r) for r in wanted if has[r]]
+    # consecutive passes could not have been merged: a gap reference, or the size cap
+    for (f0, l0, b0, e0), (f1, l1, b1, e1) in zip(passes, passes[1:]):
+        a, b = int(wanted[l0]), int(wanted[f1])
+        gap = any(has[r] for r in range(a + 1, b))
+        assert gap or int(start[b]) - b0 > group_bytes
