@@ -246,7 +246,11 @@ bool BamReader::linear_index(const std::string& bam_path, std::vector<std::vecto
     std::vector<uint8_t> d;
     if (!load_bai(bam_path, &d)) return false;
     const int32_t n_ref = (int32_t)rd32(d.data() + 4);
-    per_ref->assign((size_t)std::max(n_ref, 0), std::vector<uint64_t>());
+    if (n_ref < 0 || (size_t)n_ref > (d.size() - 8) / 8) {     // every reference takes at least n_bin + n_intv
+        if (err) *err = "corrupt BAI";
+        return false;
+    }
+    per_ref->assign((size_t)n_ref, std::vector<uint64_t>());
     size_t p = 8;
     for (int32_t r = 0; r < n_ref; ++r) {
         if (p + 4 > d.size()) { if (err) *err = "truncated BAI"; return false; }
@@ -255,12 +259,13 @@ bool BamReader::linear_index(const std::string& bam_path, std::vector<std::vecto
         for (int32_t b = 0; b < n_bin; ++b) {
             if (p + 8 > d.size()) { if (err) *err = "truncated BAI"; return false; }
             const int32_t n_chunk = (int32_t)rd32(d.data() + p + 4);
+            if (n_chunk < 0 || (d.size() - p - 8) / 16 < (size_t)n_chunk) { if (err) *err = "corrupt BAI"; return false; }
             p += 8 + 16 * (size_t)n_chunk;
         }
         if (p + 4 > d.size()) { if (err) *err = "truncated BAI"; return false; }
         const int32_t n_intv = (int32_t)rd32(d.data() + p);
         p += 4;
-        if (p + 8 * (size_t)n_intv > d.size()) { if (err) *err = "truncated BAI"; return false; }
+        if (n_intv < 0 || (d.size() - p) / 8 < (size_t)n_intv) { if (err) *err = "truncated BAI"; return false; }
         std::vector<uint64_t>& v = (*per_ref)[(size_t)r];
         for (int32_t i = 0; i < n_intv; ++i) {
             const uint64_t x = rd64(d.data() + p + 8 * (size_t)i);
@@ -273,19 +278,8 @@ bool BamReader::linear_index(const std::string& bam_path, std::vector<std::vecto
 
 bool BamReader::seek_contig(int32_t tid, std::string* err)
 {
-    FILE* fi = fopen((path_ + ".bai").c_str(), "rb");
-    if (!fi) {
-        std::string alt = path_;
-        if (alt.size() > 4 && alt.substr(alt.size() - 4) == ".bam") alt = alt.substr(0, alt.size() - 4) + ".bai";
-        fi = fopen(alt.c_str(), "rb");
-        if (!fi) return false;
-    }
     std::vector<uint8_t> d;
-    uint8_t tmp[65536];
-    size_t g;
-    while ((g = fread(tmp, 1, sizeof tmp, fi)) > 0) d.insert(d.end(), tmp, tmp + g);
-    fclose(fi);
-    if (d.size() < 8 || memcmp(d.data(), "BAI\1", 4) != 0) { if (err) *err = "bad BAI magic"; return false; }
+    if (!load_bai(path_, &d)) return false;
     const int32_t n_ref = (int32_t)rd32(d.data() + 4);
     size_t p = 8;
     uint64_t best = ~0ull;
@@ -298,13 +292,14 @@ bool BamReader::seek_contig(int32_t tid, std::string* err)
             const uint32_t bin = rd32(d.data() + p);
             const int32_t n_chunk = (int32_t)rd32(d.data() + p + 4);
             p += 8;
-            if (p + 16ull * (size_t)n_chunk > d.size()) return false;
+            if (n_chunk < 0 || (d.size() - p) / 16 < (size_t)n_chunk) return false;
             if (r == tid && bin != 37450)
                 for (int32_t k = 0; k < n_chunk; ++k) best = std::min(best, rd64(d.data() + p + 16 * (size_t)k));
             p += 16 * (size_t)n_chunk;
         }
         if (p + 4 > d.size()) return false;
         const int32_t n_intv = (int32_t)rd32(d.data() + p);
+        if (n_intv < 0 || (d.size() - p - 4) / 8 < (size_t)n_intv) return false;
         p += 4 + 8 * (size_t)n_intv;
         if (r == tid) break;
     }
@@ -335,9 +330,10 @@ bool record_cigar(const uint8_t* r, uint32_t block_size, const uint8_t** cg_out,
     if (32 + l_read_name + 4ull * n_cigar > block_size) return false;
     const uint8_t* cg = r + 32 + l_read_name;
     const uint8_t* end = r + block_size;
-    if (n_cigar == 2 && (rd32(cg) & 0xf) == 4 && (rd32(cg) >> 4) == l_seq && (rd32(cg + 4) & 0xf) == 3) {
+    if (n_cigar == 2 && (rd32(cg) & 0xf) == 4 && (rd32(cg) >> 4) == l_seq && (rd32(cg + 4) & 0xf) == 3 &&
+        (uint64_t)(end - (cg + 8)) >= ((uint64_t)l_seq + 1) / 2 + (uint64_t)l_seq) {
         const uint8_t* t = cg + 8 + (l_seq + 1) / 2 + l_seq;
-        while (t + 3 <= end) {
+        while (end - t >= 3) {
             const uint8_t t0 = t[0], t1 = t[1], ty = t[2];
             t += 3;
             size_t sz = 0;
@@ -346,15 +342,17 @@ bool record_cigar(const uint8_t* r, uint32_t block_size, const uint8_t** cg_out,
             else if (ty == 'i' || ty == 'I' || ty == 'f') sz = 4;
             else if (ty == 'Z' || ty == 'H') { while (t < end && *t) ++t; ++t; continue; }
             else if (ty == 'B') {
-                if (t + 5 > end) break;
+                if (end - t < 5) break;
                 const uint8_t sub = t[0];
                 const uint32_t cnt = rd32(t + 1);
                 t += 5;
                 const size_t es = (sub == 'c' || sub == 'C') ? 1 : (sub == 's' || sub == 'S') ? 2 : 4;
-                if (t0 == 'C' && t1 == 'G' && sub == 'I' && t + 4ull * cnt <= end) { cg = t; n_cigar = cnt; break; }
+                if ((uint64_t)(end - t) < (uint64_t)es * cnt) break;          // the array runs past the record
+                if (t0 == 'C' && t1 == 'G' && sub == 'I') { cg = t; n_cigar = cnt; break; }
                 t += es * (size_t)cnt;
                 continue;
             } else break;
+            if ((size_t)(end - t) < sz) break;
             t += sz;
         }
     }

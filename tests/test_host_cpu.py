@@ -256,3 +256,33 @@ def test_ingest_pass_plan(hostlib, seed, n_refs, group_bytes):
         a, b = int(wanted[l0]), int(wanted[f1])
         gap = any(has[r] for r in range(a + 1, b))
         assert gap or int(start[b]) - b0 > group_bytes
+
+
+@settings(max_examples=60, deadline=None)
+@given(st.integers(0, 2 ** 31), st.integers(1, 12))
+def test_bam_reader_survives_corrupt_records_and_index(hostlib, seed, n_flips):
+    """Valid BGZF (CRCs recomputed) around a damaged record stream, and a damaged .bai: the host reader
+    reports an error or decodes something, it never reads outside its buffers (a crash would end the run)."""
+    rng = np.random.default_rng(seed)
+    contigs = [("f1", 30_000), ("f2", 9_000)]
+    reads = {0: H.random_reads(rng, 30_000, 300, max_len=80), 1: H.long_cigar_reads(rng, 9_000, [70_000, 3], max_step=2)}
+    with tempfile.TemporaryDirectory() as td:
+        p = os.path.join(td, "v.bam")
+        bamio.write_bam(p, contigs, reads, unplaced=1, index=True)
+        raw = bytearray(bamio.bgzf_decompress(open(p, "rb").read()))
+        hdr = 12 + int.from_bytes(raw[4:8], "little") + sum(8 + len(n) + 1 for n, _ in contigs)
+        for _ in range(n_flips):
+            k = int(rng.integers(hdr, len(raw)))
+            raw[k] = int(rng.integers(0, 256))
+        q = os.path.join(td, "c.bam")
+        open(q, "wb").write(bamio.bgzf_compress(bytes(raw)))
+        bai = bytearray(open(p + ".bai", "rb").read())
+        for _ in range(n_flips):
+            k = int(rng.integers(4, len(bai)))
+            bai[k] = int(rng.integers(0, 256))
+        open(q + ".bai", "wb").write(bytes(bai))
+        for seek in (None, 1):
+            try:
+                hostlib.read_bam(q, threads=2, max_reads=100, seek_tid=seek)
+            except OSError:
+                pass
