@@ -1905,7 +1905,8 @@ int gd_bgzf_members(const uint8_t* data, size_t n_bytes, size_t cap, uint64_t* m
         size_t q = 12, bsize = 0;
         while (q + 4 <= 12 + xlen) {
             const size_t slen = (size_t)h[q + 2] | ((size_t)h[q + 3] << 8);
-            if (h[q] == 66 && h[q + 1] == 67 && slen == 2) bsize = ((size_t)h[q + 4] | ((size_t)h[q + 5] << 8)) + 1;
+            if (h[q] == 66 && h[q + 1] == 67 && slen == 2 && q + 6 <= 12 + xlen)
+                bsize = ((size_t)h[q + 4] | ((size_t)h[q + 5] << 8)) + 1;
             q += 4 + slen;
         }
         if (bsize < 12 + xlen + 8) return GD_E_INVALID;

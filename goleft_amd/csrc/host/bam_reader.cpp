@@ -43,7 +43,7 @@ int parse_member(const std::vector<uint8_t>& raw, size_t off, Member* m)
     while (q + 4 <= 12 + xlen) {
         const uint8_t si1 = p[q], si2 = p[q + 1];
         const size_t slen = rd16(p + q + 2);
-        if (si1 == 66 && si2 == 67 && slen == 2) { bsize = rd16(p + q + 4); found = true; }
+        if (si1 == 66 && si2 == 67 && slen == 2 && q + 6 <= 12 + xlen) { bsize = rd16(p + q + 4); found = true; }
         q += 4 + slen;
     }
     if (!found) return -1;

@@ -286,3 +286,37 @@ def test_bam_reader_survives_corrupt_records_and_index(hostlib, seed, n_flips):
                 hostlib.read_bam(q, threads=2, max_reads=100, seek_tid=seek)
             except OSError:
                 pass
+
+
+@settings(max_examples=200, deadline=None)
+@given(st.integers(0, 2 ** 31))
+def test_bgzf_member_listing_on_damaged_bytes(seed):
+    """gd_bgzf_members (a host-side parser of the device library, no GPU involved): members of a valid
+    file are listed exactly; damaged or truncated bytes give an error or a shorter list, never a member
+    that reaches outside the buffer."""
+    import ctypes as C
+    from goleft_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(seed)
+    parts = [rng.integers(0, 256, int(rng.integers(0, 3000)), dtype=np.uint8).tobytes() for _ in range(int(rng.integers(1, 6)))]
+    sizes = []
+    data = bytearray(b"".join(bamio.bgzf_compress(x, sizes=sizes)[:-28] for x in parts) + bamio.bgzf_compress(b""))
+    good = bytes(data)
+    mode = int(rng.integers(0, 3))
+    if mode == 1:
+        for _ in range(int(rng.integers(1, 6))):
+            data[int(rng.integers(0, len(data)))] = int(rng.integers(0, 256))
+    elif mode == 2:
+        data = data[:int(rng.integers(0, len(data)))]
+    buf = (C.c_uint8 * max(1, len(data))).from_buffer_copy(bytes(data) or b"\0")
+    cap = 64
+    off, size, isz, crc = (C.c_uint64 * cap)(), (C.c_uint32 * cap)(), (C.c_uint32 * cap)(), (C.c_uint32 * cap)()
+    hdr = (C.c_uint16 * cap)()
+    n = C.c_size_t(0)
+    rc = lib.gd_bgzf_members(buf, len(data), cap, off, size, hdr, isz, crc, C.byref(n))
+    assert rc in (0, -1, -8)
+    for k in range(min(n.value, cap)):
+        assert off[k] + size[k] <= len(data) and hdr[k] + 8 <= size[k]
+    if mode == 0:
+        assert rc == 0 and n.value == len([s for s in sizes]) + 1 and bytes(data) == good
+        assert sum(isz[k] for k in range(n.value)) == sum(len(x) for x in parts)
