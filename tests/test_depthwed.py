@@ -129,3 +129,35 @@ def test_host_cli_unequal_records_is_an_error(tmp_path):
     assert rc != 0
     with pytest.raises(RuntimeError):
         po.depthwed_py([a.read_text(), b.read_text()], ["a", "b"], 250)
+
+
+from hypothesis import given, settings, strategies as st  # noqa: E402
+
+
+@settings(max_examples=150, deadline=None)
+@given(st.integers(0, 2 ** 31))
+def test_host_cli_survives_malformed_rows(seed):
+    """Garbage in the *.depth.bed inputs (missing columns, text for numbers, huge values, empty files,
+    binary bytes): gdh_depthwed_run returns an error or writes something, it never crashes."""
+    import tempfile
+    from goleft_amd import _hostlib
+    rng = np.random.default_rng(seed)
+    junk = [b"", b"\n", b"chr1\n", b"chr1\t0\n", b"chr1\t0\t250\n", b"chr1\tx\ty\tz\n", b"chr1\t0\t250\t1e400\n",
+            b"chr1\t-5\t99999999999999999999\tnan\n", b"\t\t\t\n", b"\x00\xff\x1f\x8b\n", b"chr1\t250\t0\t3\n",
+            b"c" * 5000 + b"\t0\t250\t1\n", b"chr2\t0\t250\t7.25\textra\tcols\n"]
+    with tempfile.TemporaryDirectory() as td:
+        paths = []
+        for i in range(int(rng.integers(1, 4))):
+            rows = []
+            for k in range(int(rng.integers(0, 30))):
+                if rng.random() < 0.3:
+                    rows.append(junk[int(rng.integers(0, len(junk)))])
+                else:
+                    rows.append(b"chr1\t%d\t%d\t%.4g\n" % (k * 250, k * 250 + 250, rng.random() * 60))
+            p = os.path.join(td, "s%d.depth.bed" % i)
+            open(p, "wb").write(b"".join(rows))
+            paths.append(p)
+        arr = (C.c_char_p * len(paths))(*[p.encode() for p in paths])
+        rc = _hostlib.load().gdh_depthwed_run(int(rng.choice([1, 250, 1000, 10 ** 9])), arr, len(paths),
+                                              os.path.join(td, "o.txt").encode())
+        assert isinstance(rc, int)
