@@ -1,0 +1,401 @@
+// gd_api_state.hpp -- what a gd_ctx holds and the helpers every part of the C ABI shares: per-contig
+// record streams, the pinned staging ring, the device job state, launch helpers of the tile kernels,
+// the descriptor packing (gd_tile_v8.hpp) and the state of a device BAM read.  Included by gd_api.hip
+// only (one translation unit: the kernels of gd_kernels.hpp are not inline).
+#pragma once
+
+namespace {
+
+constexpr int kRingSlots = 3;
+constexpr int kDefaultLookback = 512;
+constexpr uint64_t kMaxReadsPerContig = 1ull << 30;
+constexpr int kAutoLongSpan = 32768;      // GD_PATH_AUTO leaves the short-read tile path above this read span
+constexpr int kMaxSpan = 1 << 27;   // tile-relative byte offsets of the tile kernel stay in 32 bits
+
+struct ContigHost {
+    int64_t length = 0;
+    // device record stream (owned unless adopted)
+    int32_t*  pos = nullptr;
+    uint16_t* flag = nullptr;
+    uint8_t*  mapq = nullptr;
+    uint32_t* off = nullptr;
+    uint32_t* cigar = nullptr;
+    size_t n_reads = 0, n_ops = 0;
+    size_t cap_reads = 0, cap_ops = 0;
+    bool adopted = false;
+    int32_t last_pos = -0x7fffffff;
+    // packed descriptors of the records (gd_tile_v8.hpp), always owned
+    uint2* desc = nullptr;
+    uint32_t* cxb = nullptr;
+    uint32_t* cxc = nullptr;
+    bool packed = false;               // desc/cxb/cxc describe the current records
+    bool packable = false;             // ... and the v8 kernels may use them
+    // layout in the result arrays of the last compute (-1 = not computed)
+    int64_t base_off = -1;
+    int64_t win_off = -1;
+    int64_t n_win = 0;
+    size_t run_beg = 0, run_end = 0;   // slice of ctx->bounds
+};
+
+struct RingSlot {
+    gd_batch b{};
+    hipEvent_t done = nullptr;
+    bool busy = false;
+};
+
+}  // namespace
+
+// State of a device BAM read between gd_ingest_begin and gd_ingest_finish.
+struct IngestState;
+
+// Device buffers of one pending range (compressed bytes, inflated bytes, member tables): grow-only and
+// kept by the context between ranges -- allocating and freeing gigabytes per range cost 0.1-0.2 s.
+struct IngestBufs {
+    void *in = nullptr, *out = nullptr, *tab = nullptr;
+    size_t cap_in = 0, cap_out = 0, cap_tab = 0;
+    bool busy = false;
+    static bool fit(void** p, size_t* cap, size_t need)
+    {
+        if (need <= *cap && *p) return true;
+        if (*p) { (void)hipFree(*p); *p = nullptr; *cap = 0; }
+        if (hipMalloc(p, need ? need : 1) != hipSuccess) { *p = nullptr; return false; }
+        *cap = need ? need : 1;
+        return true;
+    }
+    void drop()
+    {
+        if (in) (void)hipFree(in);
+        if (out) (void)hipFree(out);
+        if (tab) (void)hipFree(tab);
+        in = out = tab = nullptr;
+        cap_in = cap_out = cap_tab = 0;
+    }
+};
+
+
+struct gd_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;       // compute stream
+    bool own_stream = true;
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t copy_done = nullptr;
+    gd_params params{};
+    std::vector<ContigHost> contigs;
+    std::vector<int32_t> selected;      // empty = all
+    RingSlot ring[kRingSlots];
+    int ring_next = 0;
+    std::string err;
+
+    int tile_T = 4096;
+    int tile_NT = 256;
+    int kernel_gen = 7;                 // GOLEFT_GD_KERNEL=v8: packed read descriptors (gd_tile_v8.hpp, measured
+                                        // equal to v7: DESIGN.md section 4); v6: the previous tile kernel
+    bool use_v8 = false;                // this gd_compute: every contig of the job is packed
+    int tile_opt = 1;                   // bit 0: non-temporal per-base stores (2 % faster: the vector is
+                                        // never re-read by the kernel); GOLEFT_GD_OPT=0 for plain stores
+    bool lookback_pinned = false;       // max_span_hint given: never shrink below it
+    int path = GD_PATH_AUTO;            // gd_set_path / GOLEFT_GD_PATH
+    bool keep_perbase = true;           // gd_set_outputs(GD_OUT_PERBASE)
+    bool sums_only = false;             // gd_set_outputs(GD_OUT_SUMS_ONLY): window sums, nothing else
+    bool ran_sums_only = false;         // what the last gd_compute produced
+    bool span_forces_long = false;      // AUTO: the tile path met a read too long for it
+    unsigned long long* d_status = nullptr;  size_t cap_status = 0;   // scatter path look-back words
+    uint32_t* d_ck = nullptr;  size_t cap_ck = 0;      // chunk path: CIGAR checkpoints
+    int32_t* d_rend = nullptr; size_t cap_rend = 0;    // chunk path: read end positions
+    int lookback = kDefaultLookback;
+
+    // device job state
+    gd::ContigDev* d_ctgs = nullptr;  size_t cap_ctgs = 0;
+    std::vector<gd::ContigDev> h_ctgs;
+    std::vector<int32_t> job_tids;      // contig table index -> tid
+    gd::TileInfo* d_tiles = nullptr;  size_t cap_tiles = 0;
+    int32_t* d_perbase = nullptr;     size_t cap_perbase = 0;
+    int64_t* d_wsum = nullptr;        size_t cap_win = 0;
+    int32_t* d_wmin = nullptr;
+    int2* d_chunks = nullptr;         size_t cap_runs = 0;
+    int2* d_ordered = nullptr;
+    uint32_t* d_tile_cnt = nullptr;
+    uint32_t* d_tile_off = nullptr;
+    uint32_t* d_super_cnt = nullptr;
+    gd::Counters* d_counters = nullptr;
+    gd::Counters* h_counters = nullptr;   // pinned
+    uint32_t* d_region_cursor = nullptr;
+
+    int64_t* d_wed = nullptr; size_t cap_wed = 0;      // gd_depthwed: tables + the sites x samples matrix
+    uint32_t* d_md_bits = nullptr; size_t cap_md = 0;  // gd_md_flags: `any` words then `suf` words
+    int64_t md_len = -1;                               // positions the bitmaps cover (-1: none yet)
+    std::vector<int32_t> md_tids;                      // the samples they were built from
+    // gd_ingest_begin .. gd_ingest_finish.  Two ranges may be pending: ing_q[0] is the oldest (the one
+    // gd_ingest_decode / _finish / _release act on), the last one is being fed -- so the inflate tail of
+    // one range overlaps the upload of the next.
+    IngestState* ing_q[2] = {nullptr, nullptr};
+    int ing_n = 0;
+    bool ing_stage_used[2] = {false, false};
+    int ing_cur = 0;
+    IngestBufs ing_bufs[2];
+    // staging of the device BAM read, created by the first gd_ingest_begin and kept until gd_destroy
+    // (page-locking 128 MB per contig would cost more than many contigs' whole decode)
+    uint8_t* ing_stage[2] = {nullptr, nullptr};
+    hipEvent_t ing_staged[2] = {nullptr, nullptr};
+    hipStream_t ing_stream[8] = {};                     // inflate launches rotate over these (two pending ranges x 4)
+    unsigned ing_launch_seq = 0;
+    int ing_copy_threads = 1;                          // GOLEFT_GD_COPY_THREADS: threads filling the staging buffer
+    uint8_t* d_seq = nullptr;  size_t cap_seq = 0;     // gd_seq_load: one contig's bases, zero padded
+    int64_t seq_len = -1;
+    uint32_t seq_padded = 0;
+
+    bool computed = false;
+    int64_t n_tiles = 0, n_win_total = 0, n_bases = 0;
+    std::vector<int2> bounds;             // ordered run boundaries of the last compute
+    gd_stats stats{};
+
+    bool profiling = false;
+    hipEvent_t ev[GD_K_COUNT + 1] = {};
+    float kernel_ms[GD_K_COUNT] = {};
+};
+
+namespace {
+
+int fail(gd_ctx* c, int code, const char* fmt, ...)
+{
+    if (c) {
+        char buf[512];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof buf, fmt, ap);
+        va_end(ap);
+        c->err = buf;
+    }
+    return code;
+}
+
+#define HIPCHK(ctx, call)                                                              \
+    do {                                                                               \
+        hipError_t e_ = (call);                                                        \
+        if (e_ != hipSuccess)                                                          \
+            return fail((ctx), e_ == hipErrorOutOfMemory ? GD_E_NOMEM : GD_E_HIP,      \
+                        "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_),         \
+                        __FILE__, __LINE__);                                           \
+    } while (0)
+
+template <typename Tp>
+int ensure_dev(gd_ctx* c, Tp** p, size_t* cap, size_t need, bool keep = false, size_t used = 0)
+{
+    if (need <= *cap && *p) return GD_OK;
+    size_t ncap = std::max(need, *cap + *cap / 2);
+    if (ncap == 0) ncap = 1;
+    Tp* np = nullptr;
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&np), ncap * sizeof(Tp)));
+    if (*p) {
+        if (keep && used)
+            HIPCHK(c, hipMemcpyAsync(np, *p, used * sizeof(Tp), hipMemcpyDeviceToDevice,
+                                     c->copy_stream));
+        HIPCHK(c, hipStreamSynchronize(c->copy_stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipFree(*p));
+    }
+    *p = np;
+    *cap = ncap;
+    return GD_OK;
+}
+
+void drop_pack(ContigHost& h)
+{
+    if (h.desc) (void)hipFree(h.desc);
+    if (h.cxb) (void)hipFree(h.cxb);
+    if (h.cxc) (void)hipFree(h.cxc);
+    h.desc = nullptr; h.cxb = nullptr; h.cxc = nullptr;
+    h.packed = h.packable = false;
+}
+
+void free_contig(ContigHost& h)
+{
+    drop_pack(h);
+    if (!h.adopted) {
+        if (h.pos) (void)hipFree(h.pos);
+        if (h.flag) (void)hipFree(h.flag);
+        if (h.mapq) (void)hipFree(h.mapq);
+        if (h.off) (void)hipFree(h.off);
+        if (h.cigar) (void)hipFree(h.cigar);
+    }
+    h.pos = nullptr; h.flag = nullptr; h.mapq = nullptr; h.off = nullptr; h.cigar = nullptr;
+    h.n_reads = h.n_ops = h.cap_reads = h.cap_ops = 0;
+    h.adopted = false;
+    h.last_pos = -0x7fffffff;
+    h.base_off = h.win_off = -1;
+    h.n_win = 0;
+    h.run_beg = h.run_end = 0;
+}
+
+int64_t derive_step(const gd_params& p)
+{
+    if (p.step > 0) return p.step;
+    // depth/depth.go:48,:132
+    int64_t s = 10000000 / p.window_size;
+    if (s < 1) s = 1;
+    return s * p.window_size;
+}
+
+// (m, s) with floor(x / d) == (x * m) >> s for every x < 2^31 (1 <= d < 2^31):
+// s = 31 + ceil(log2 d), m = ceil(2^s / d) < 2^32  (Granlund & Montgomery 1994, N = 31).
+void magic_u31(uint32_t d, uint32_t* m, uint32_t* s)
+{
+    if (d == 0) d = 1;
+    uint32_t l = 0;
+    while (l < 31 && (1u << l) < d) ++l;
+    const unsigned __int128 num = (unsigned __int128)1 << (31 + l);
+    *m = (uint32_t)((num + d - 1) / d);
+    *s = 31 + l;
+}
+
+int set_device(gd_ctx* c)
+{
+    HIPCHK(c, hipSetDevice(c->device));
+    return GD_OK;
+}
+
+template <int T>
+void launch_prep(gd_ctx* c, const gd::Job& job)
+{
+    int64_t work = std::max<int64_t>(job.n_tiles, std::min<int64_t>(job.n_win_total, 1 << 22));
+    int blocks = (int)((work + 255) / 256);
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(gd::gd_prep_kernel<T>, dim3(blocks), dim3(256), 0, c->stream, job);
+}
+
+template <int T, int NT>
+void launch_tile(gd_ctx* c, const gd::Job& job)
+{
+    // 8 XCDs: the grid is 8 equal slices of the tile list (see the kernel)
+    const unsigned grid = (unsigned)(((job.n_tiles + 7) / 8) * 8);
+    if (c->ran_sums_only) {                                 // decided by gd_compute for this run
+        if (c->use_v8) hipLaunchKernelGGL((gd::v8::gd_tile_sums_kernel<4096, 256>), dim3(grid), dim3(256), 0, c->stream, job);
+        else           hipLaunchKernelGGL((gd::v7::gd_tile_sums_kernel<4096, 256>), dim3(grid), dim3(256), 0, c->stream, job);
+        return;
+    }
+    if (c->use_v8 && T == 4096 && NT == 256) {              // packed descriptors (default shape only)
+        if (!c->keep_perbase)
+            hipLaunchKernelGGL((gd::v8::gd_tile_kernel<4096, 256, 2>), dim3(grid), dim3(256), 0, c->stream, job);
+        else if (c->tile_opt & 1)
+            hipLaunchKernelGGL((gd::v8::gd_tile_kernel<4096, 256, 1>), dim3(grid), dim3(256), 0, c->stream, job);
+        else
+            hipLaunchKernelGGL((gd::v8::gd_tile_kernel<4096, 256, 0>), dim3(grid), dim3(256), 0, c->stream, job);
+        return;
+    }
+    if (c->kernel_gen >= 7 && T == 4096 && NT == 256) {     // v7 is built for the default shape only
+        if (!c->keep_perbase)
+            hipLaunchKernelGGL((gd::v7::gd_tile_kernel<4096, 256, 2>), dim3(grid), dim3(256), 0, c->stream, job);
+        else if (c->tile_opt & 1)
+            hipLaunchKernelGGL((gd::v7::gd_tile_kernel<4096, 256, 1>), dim3(grid), dim3(256), 0, c->stream, job);
+        else
+            hipLaunchKernelGGL((gd::v7::gd_tile_kernel<4096, 256, 0>), dim3(grid), dim3(256), 0, c->stream, job);
+        return;
+    }
+    if (!c->keep_perbase)
+        hipLaunchKernelGGL((gd::gd_tile_kernel<T, NT, 2>), dim3(grid), dim3(NT), 0, c->stream, job);
+    else if (c->tile_opt & 1)
+        hipLaunchKernelGGL((gd::gd_tile_kernel<T, NT, 1>), dim3(grid), dim3(NT), 0, c->stream, job);
+    else
+        hipLaunchKernelGGL((gd::gd_tile_kernel<T, NT, 0>), dim3(grid), dim3(NT), 0, c->stream, job);
+}
+
+template <int T, int NT>
+void launch_ltile(gd_ctx* c, const gd::Job& job)
+{
+    const unsigned grid = (unsigned)(((job.n_tiles + 7) / 8) * 8);
+    if (c->kernel_gen == 6) {                              // GOLEFT_GD_KERNEL=v6: the first long-read kernel
+        if (!c->keep_perbase)
+            hipLaunchKernelGGL((gd::gd_ltile_kernel<T, NT, 2>), dim3(grid), dim3(NT), 0, c->stream, job);
+        else
+            hipLaunchKernelGGL((gd::gd_ltile_kernel<T, NT, 0>), dim3(grid), dim3(NT), 0, c->stream, job);
+        return;
+    }
+    if (!c->keep_perbase)
+        hipLaunchKernelGGL((gd::gd_ltile2_kernel<T, NT, 2>), dim3(grid), dim3(NT), 0, c->stream, job);
+    else
+        hipLaunchKernelGGL((gd::gd_ltile2_kernel<T, NT, 0>), dim3(grid), dim3(NT), 0, c->stream, job);
+}
+
+// Builds the packed descriptors of one contig's records (gd_tile_v8.hpp) on the compute stream.
+// Afterwards h.packed is set; h.packable says whether the v8 kernels may use them.
+int pack_contig(gd_ctx* c, ContigHost& h)
+{
+    drop_pack(h);
+    h.packed = true;
+    if (h.n_reads >= (1ull << 29)) return GD_OK;           // descriptor byte offsets stay in 32 bits
+    const uint32_t n_reads = (uint32_t)h.n_reads, n_units = (n_reads + 63u) / 64u;
+    // records staged on the copy stream must have landed
+    HIPCHK(c, hipEventRecord(c->copy_done, c->copy_stream));
+    HIPCHK(c, hipStreamWaitEvent(c->stream, c->copy_done, 0));
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&h.desc), std::max<size_t>(n_reads, 1) * sizeof(uint2)));
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&h.cxb), ((size_t)n_units + 2) * sizeof(uint32_t)));   // + total, status
+    HIPCHK(c, hipMemsetAsync(h.cxb, 0, ((size_t)n_units + 2) * sizeof(uint32_t), c->stream));
+    gd::v8::PackJob j{};
+    j.pos = h.pos; j.flag = h.flag; j.mapq = h.mapq; j.off = h.off; j.cigar = h.cigar;
+    j.n_reads = n_reads; j.n_units = n_units; j.desc = h.desc; j.cx_base = h.cxb; j.status = h.cxb + n_units + 1;
+    uint32_t tail[2] = {0, 0};                              // grand total of compact ops, status bits
+    if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+    if (n_units) {
+        hipLaunchKernelGGL(gd::v8::gd_pack_desc_kernel, dim3((n_units + 3u) / 4u), dim3(256), 0, c->stream, j);
+        hipLaunchKernelGGL(gd::v8::gd_pack_scan_kernel, dim3(1), dim3(1024), 0, c->stream, h.cxb, n_units);
+        HIPCHK(c, hipMemcpyAsync(tail, h.cxb + n_units, sizeof tail, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&h.cxc), ((size_t)tail[0] + 4) * sizeof(uint32_t)));
+    if (tail[0]) {
+        j.cx_cigar = h.cxc;
+        hipLaunchKernelGGL(gd::v8::gd_pack_ops_kernel, dim3((n_units + 3u) / 4u), dim3(256), 0, c->stream, j);
+    }
+    HIPCHK(c, hipGetLastError());
+    if (c->profiling) {
+        float ms = 0;
+        HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+        HIPCHK(c, hipEventSynchronize(c->ev[1]));
+        HIPCHK(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
+        c->kernel_ms[GD_K_PACK] += ms;
+    }
+    h.packable = tail[1] == 0;
+    return GD_OK;
+}
+
+// The v8 kernels exist for the default tile shape; long-read data goes to the chunk path anyway.
+bool wants_pack(const gd_ctx* c, uint64_t n_reads, uint64_t n_ops)
+{
+    if (c->kernel_gen != 8 || c->tile_T != 4096 || c->tile_NT != 256) return false;
+    if (c->path == GD_PATH_TILE) return true;
+    return c->path == GD_PATH_AUTO && !c->span_forces_long && n_ops <= 6 * n_reads;
+}
+
+// RAII for the scratch device buffers of gd_ingest_bgzf
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
+    template <typename T> T* as() const { return static_cast<T*>(p); }
+};
+
+}  // namespace
+
+struct IngestState {
+    static constexpr size_t kStage = 64u << 20;        // bytes per page-locked staging buffer
+    uint64_t n_bytes = 0, fed = 0, total = 0;           // compressed bytes announced / received, inflated bytes
+    size_t nm = 0, next = 0;                            // members, first member not yet handed to the inflate kernel
+    std::vector<uint64_t> m_coff, m_end, out_off;       // file offset, end offset in the range, offset in the inflated bytes
+    std::vector<uint32_t> out_len;
+    IngestBufs* bufs = nullptr;                         // one of gd_ctx::ing_bufs
+    uint8_t *d_in = nullptr, *d_out = nullptr;
+    uint64_t *t_in_off = nullptr, *t_out_off = nullptr;
+    uint32_t *t_in_len = nullptr, *t_out_len = nullptr, *t_status = nullptr, *t_crc = nullptr;
+    // One lane inflates one member start to end (~0.1 s whatever the member count), so the members are
+    // handed to the kernel in at most kBatches launches, each on its own stream: they overlap each other
+    // and the upload of the bytes still to come.
+    static constexpr int kBatches = 4;
+    int n_launch = 0;
+    std::vector<hipEvent_t> inf_done;                   // one per inflate launch of THIS range
+    bool inflated = false;                              // every member inflated and its status checked
+    ~IngestState()
+    {
+        for (hipEvent_t e : inf_done) (void)hipEventDestroy(e);
+        if (bufs) bufs->busy = false;
+    }
+};
