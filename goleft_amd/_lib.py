@@ -64,6 +64,7 @@ SYMBOLS = {
                                     C.POINTER(C.c_size_t)]),
     "gd_region_callable": (C.c_int, [_P, C.c_int32, C.c_int64, C.c_int64, _P, C.c_size_t,
                                      C.POINTER(C.c_size_t)]),
+    "gd_regions": (C.c_int, [_P, C.c_size_t, _P, _P, _P, _P, _P, C.c_size_t, _P, _P, C.c_size_t, _P]),
     "gd_depthwed": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int64, _P, _P, _P, _P, C.c_size_t,
                               C.POINTER(C.c_size_t)]),
     "gd_depthwed_device": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int64, C.POINTER(_P), C.POINTER(C.c_size_t)]),

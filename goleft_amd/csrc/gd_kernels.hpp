@@ -288,6 +288,76 @@ __device__ __forceinline__ int wave_min(int v)
     return v;
 }
 
+// ---- the same two reductions over MANY regions in one launch each (a --bed file with 10^5 rows) ----
+struct RegionTab {
+    const int32_t* depth;     // per-base vector of the region's contig
+    int64_t  clen, start, end;
+    int64_t  first_win;       // start / W
+    uint32_t win_off;         // first window of the region among the batch's windows
+    uint32_t chunk_off;       // first chunk of the region among the batch's chunks
+};
+constexpr int REGION_CHUNK = 4096;   // positions per workgroup of gd_regions_bounds_kernel
+
+// One workgroup per window of the batch (win_region[w] = its region).
+__global__ __launch_bounds__(256) void gd_regions_windows_kernel(const RegionTab* __restrict__ tab,
+                                                                 const uint32_t* __restrict__ win_region, int32_t W,
+                                                                 int64_t* __restrict__ sums, int32_t* __restrict__ mins)
+{
+    __shared__ long long s_sum[4];
+    __shared__ int s_min[4];
+    const uint32_t w = blockIdx.x;
+    const RegionTab t = tab[win_region[w]];
+    const int64_t k = t.first_win + (int64_t)(w - t.win_off);
+    int64_t ws = k * W, we = ws + W;
+    if (ws < t.start) ws = t.start;
+    if (we > t.end) we = t.end;
+    long long acc = 0;
+    int mn = 0x7fffffff;
+    for (int64_t p = ws + threadIdx.x; p < we; p += 256) {
+        const int d = p < t.clen ? t.depth[p] : 0;
+        acc += d;
+        mn = d < mn ? d : mn;
+    }
+    acc = wave_sum64(acc);
+    mn = wave_min(mn);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) { s_sum[wv] = acc; s_min[wv] = mn; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int m = s_min[0];
+        for (int i = 1; i < 4; ++i) m = s_min[i] < m ? s_min[i] : m;
+        sums[w] = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
+        mins[w] = m;
+    }
+}
+
+// One workgroup per chunk of REGION_CHUNK positions of a region: entries {p, class, region, 0} for
+// p == start or class(p) != class(p-1), appended unordered (the host sorts by region and position).
+__global__ __launch_bounds__(256) void gd_regions_bounds_kernel(const RegionTab* __restrict__ tab,
+                                                                const uint32_t* __restrict__ chunk_region, int mincov,
+                                                                int maxmean, int4* __restrict__ out, uint32_t cap,
+                                                                uint32_t* __restrict__ cursor)
+{
+    const uint32_t ch = blockIdx.x;
+    const uint32_t r = chunk_region[ch];
+    const RegionTab t = tab[r];
+    const int64_t p0 = t.start + (int64_t)(ch - t.chunk_off) * REGION_CHUNK;
+    const int64_t p1 = p0 + REGION_CHUNK < t.end ? p0 + REGION_CHUNK : t.end;
+    for (int64_t p = p0 + threadIdx.x; p < p1; p += 256) {
+        const int d = p < t.clen ? t.depth[p] : 0;
+        const int cl = cov_class(d, mincov, maxmean);
+        bool b = (p == t.start);
+        if (!b) {
+            const int dp = (p - 1) < t.clen ? t.depth[p - 1] : 0;
+            b = cov_class(dp, mincov, maxmean) != cl;
+        }
+        if (b) {
+            const uint32_t i = atomicAdd(cursor, 1u);
+            if (i < cap) out[i] = make_int4((int)p, cl, (int)r, 0);
+        }
+    }
+}
+
 }  // namespace gd
 
 #include "gd_tile_v6.hpp"

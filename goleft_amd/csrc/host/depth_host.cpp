@@ -500,9 +500,44 @@ int run(const DArgs& args)
         sp.collecting = false;
         format_region(&rows, chrom, rs, re, W, su, n_su, ru, n_ru, &sp);
     };
+    // Regions that need the region reductions (every --bed row, tiles cut by a disagreeing .fai) are
+    // collected and reduced in batches: one gd_regions call for up to kBatch of them instead of several
+    // launches, allocations and synchronisations per row.  Output order is the input order.
+    constexpr size_t kBatch = 4096;
+    std::vector<const Region*> batch;
+    auto flush_batch = [&]() -> int {
+        if (batch.empty()) return GD_OK;
+        const size_t nb = batch.size();
+        std::vector<int32_t> b_tid(nb);
+        std::vector<int64_t> b_start(nb), b_end(nb);
+        size_t nw = 0;
+        for (size_t k = 0; k < nb; ++k) {
+            b_tid[k] = batch[k]->tid; b_start[k] = batch[k]->start; b_end[k] = batch[k]->end;
+            nw += (size_t)((batch[k]->end - 1) / W - batch[k]->start / W + 1);
+        }
+        std::vector<size_t> woff(nb + 1), roff(nb + 1);
+        sums.resize(nw);
+        runs.resize(std::max<size_t>(runs.size(), 4 * nb + 1024));
+        int rc = gd_regions(ctx, nb, b_tid.data(), b_start.data(), b_end.data(), sums.data(), nullptr, nw, woff.data(),
+                            runs.data(), runs.size(), roff.data());
+        if (rc == GD_E_CAPACITY && woff[nb] <= nw && roff[nb] > runs.size()) {
+            runs.resize(roff[nb]);
+            rc = gd_regions(ctx, nb, b_tid.data(), b_start.data(), b_end.data(), sums.data(), nullptr, nw, woff.data(),
+                            runs.data(), runs.size(), roff.data());
+        }
+        if (rc != GD_OK) return rc;
+        for (size_t k = 0; k < nb; ++k) {
+            emit_region(batch[k]->chrom.c_str(), batch[k]->start, batch[k]->end, sums.data() + woff[k], woff[k + 1] - woff[k],
+                        runs.data() + roff[k], roff[k + 1] - roff[k]);
+            if (rows.hd.size() + rows.ca.size() > (8u << 20)) io_ok = flush_rows(&rows, fhd, fca) && io_ok;
+        }
+        batch.clear();
+        return GD_OK;
+    };
     for (const Region& r : regions) {
         if (stats_rc != GD_OK) GDCHK(stats_rc);
         if (r.tid < 0) {
+            GDCHK(flush_batch());
             // samtools would fail on an unknown reference name: the callback then sees an
             // empty stream (all-zero rows) and the exit code becomes non-zero (:395-399)
             fprintf(stderr, "ERROR with command: region %s:%" PRId64 "-%" PRId64 " not in the BAM header\n",
@@ -517,6 +552,7 @@ int run(const DArgs& args)
             const bool fused = args.bed.empty() && r.start % step == 0 &&
                                (r.end == clen || (r.end < clen && r.end % step == 0));
             if (fused) {
+                GDCHK(flush_batch());
                 if (cached_tid != r.tid) {
                     size_t n = 0;
                     csums.resize((size_t)((clen + W - 1) / W));
@@ -537,19 +573,13 @@ int run(const DArgs& args)
                             cruns.data() + run_cursor, e - run_cursor);
                 run_cursor = e;
             } else if (r.end > r.start) {
-                size_t n = 0;
-                const size_t nw = (size_t)((r.end - 1) / W - r.start / W + 1);
-                sums.resize(nw);
-                GDCHK(gd_region_windows(ctx, r.tid, r.start, r.end, sums.data(), nullptr, nw, &n));
-                int rc = gd_region_callable(ctx, r.tid, r.start, r.end, nullptr, 0, &n);
-                if (rc != GD_OK && rc != GD_E_CAPACITY) GDCHK(rc);
-                runs.resize(n);
-                if (n) GDCHK(gd_region_callable(ctx, r.tid, r.start, r.end, runs.data(), runs.size(), &n));
-                emit_region(r.chrom.c_str(), r.start, r.end, sums.data(), nw, runs.data(), n);
+                batch.push_back(&r);
+                if (batch.size() >= kBatch) GDCHK(flush_batch());
             }
         }
         if (rows.hd.size() + rows.ca.size() > (8u << 20)) io_ok = flush_rows(&rows, fhd, fca) && io_ok;
     }
+    GDCHK(flush_batch());
     if (stats_rc != GD_OK) GDCHK(stats_rc);
     io_ok = flush_rows(&rows, fhd, fca) && io_ok;
     gd_destroy(ctx);

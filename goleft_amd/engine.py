@@ -202,6 +202,35 @@ class DepthEngine:
     def region_callable(self, tid: int, start: int, end: int) -> np.ndarray:
         return self._runs(self._lib.gd_region_callable, tid, start, end)
 
+    def regions(self, tids, starts, ends):
+        """Many regions in one call (gd_regions): returns ([sums], [mins], [runs]) with one array per region."""
+        t = np.ascontiguousarray(tids, np.int32)
+        s = np.ascontiguousarray(starts, np.int64)
+        e = np.ascontiguousarray(ends, np.int64)
+        n = len(t)
+        W = int(self.params.window_size)
+        nw = int(sum((int(b) - 1) // W - int(a) // W + 1 for a, b in zip(s, e) if b > a))
+        sums, mins = np.zeros(max(nw, 1), np.int64), np.zeros(max(nw, 1), np.int32)
+        woff, roff = np.zeros(n + 1, np.uint64), np.zeros(n + 1, np.uint64)
+        cap = max(1024, 4 * n)
+        while True:
+            runs = (GdRun * cap)()
+            rc = self._lib.gd_regions(self._ctx, n, t.ctypes.data, s.ctypes.data, e.ctypes.data, sums.ctypes.data,
+                                      mins.ctypes.data, nw, woff.ctypes.data, runs, cap, roff.ctypes.data)
+            if rc == -8 and int(woff[n]) <= nw and int(roff[n]) > cap:      # GD_E_CAPACITY on the runs: retry
+                cap = int(roff[n])
+                continue
+            self._chk(rc)
+            break
+        allruns = np.frombuffer(runs, dtype=np.int32, count=3 * int(roff[n])).reshape(-1, 3)
+        out_s, out_m, out_r = [], [], []
+        for k in range(n):
+            a, b = int(woff[k]), int(woff[k + 1])
+            out_s.append(sums[a:b].copy())
+            out_m.append(mins[a:b].copy())
+            out_r.append(allruns[int(roff[k]):int(roff[k + 1])].copy())
+        return out_s, out_m, out_r
+
     def depthwed(self, tids, size: int):
         """Sites x samples matrix of `goleft depthwed -s size`.  tids: [n_samples][n_ctg]
         engine contigs.  Returns (cells int64 [rows, samples], row_ctg, row_start, row_end)."""

@@ -236,6 +236,16 @@ int gd_region_windows(gd_ctx* ctx, int32_t tid, int64_t start, int64_t end,
                       int64_t* sums, int32_t* mins, size_t cap, size_t* n);
 int gd_region_callable(gd_ctx* ctx, int32_t tid, int64_t start, int64_t end,
                        gd_run* out, size_t cap, size_t* n);
+/* The same two reductions for MANY regions in one call (a --bed file: one launch per reduction for
+ * the whole batch instead of several launches, allocations and synchronisations per row).  Region r
+ * is [start[r], end[r]) on contig tid[r].  Its W-anchored windows are sums/mins[win_off[r] ..
+ * win_off[r+1]) and its class runs runs[run_off[r] .. run_off[r+1]); win_off and run_off have
+ * n_regions + 1 entries and are written by the call.  mins may be NULL.  GD_E_CAPACITY when
+ * cap_windows or cap_runs is too small: win_off[n_regions] / run_off[n_regions] then hold what is
+ * needed (a windows shortfall is reported first, with run_off zeroed). */
+int gd_regions(gd_ctx* ctx, size_t n_regions, const int32_t* tid, const int64_t* start, const int64_t* end,
+               int64_t* sums, int32_t* mins, size_t cap_windows, size_t* win_off,
+               gd_run* runs, size_t cap_runs, size_t* run_off);
 
 /* ---- depthwed on device (depthwed/depthwed.go; BASELINE.json config 4) -----
  * A cohort is loaded as n_samples x n_ctg contigs of ONE context (tids[s*n_ctg+j]

@@ -413,3 +413,45 @@ def test_sums_only_small_windows_fall_back():
         want = po.perbase_c(r, 0, 0, L)
         assert np.array_equal(eng.window_sums(0), H.oracle_windows(want, 13)[0])
         assert len(eng.callable_runs(0)) > 0                 # W < 32: the regular windows-only kernel ran
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_regions_batch_equals_single_calls_and_oracle(auto_eng, seed):
+    """gd_regions (the --bed mode in one call): windows and class runs of many regions -- on several
+    contigs, one of length 0 and one without reads, empty regions, regions past the contig end, one
+    large region -- equal the single-region calls and the oracle's reductions of the per-base vector."""
+    eng = auto_eng
+    rng = np.random.default_rng(700 + seed)
+    lens = [50_000, 0, 20_000, 9_000]
+    contigs = [("r%d" % i, l) for i, l in enumerate(lens)]
+    reads = {0: H.random_reads(rng, lens[0], 4000), 3: H.random_reads(rng, lens[3], 900)}
+    W = int(rng.choice([1, 37, 250, 1000]))
+    mincov, maxmean = int(rng.integers(1, 6)), int(rng.choice([0, 12]))
+    run_engine(eng, contigs, reads, window_size=W, min_mapq=1, min_cov=mincov, max_mean_depth=maxmean)
+    tids, starts, ends = [], [], []
+    for _ in range(300):
+        t = int(rng.integers(0, 4))
+        a = int(rng.integers(0, max(1, lens[t]) + 50))
+        b = a + int(rng.choice([0, 1, 7, 120, 600, 5000]))
+        tids.append(t); starts.append(a); ends.append(b)
+    tids.append(0); starts.append(3); ends.append(lens[0] + 200)           # one large region
+    sums, mins, runs = eng.regions(tids, starts, ends)
+    assert len(sums) == len(tids)
+    per = {t: (po.perbase_c(reads.get(t, H.empty_reads()), 1, 0, l) if l else np.zeros(0, np.int32))
+           for t, l in enumerate(lens)}
+    for k, (t, a, b) in enumerate(zip(tids, starts, ends)):
+        if b == a:
+            assert len(sums[k]) == 0 and len(runs[k]) == 0
+            continue
+        d = np.zeros(b - a, np.int32)
+        hi = min(b, lens[t])
+        if hi > a:
+            d[:hi - a] = per[t][a:hi]
+        ws, wm = H.oracle_windows(d, W, a)
+        assert np.array_equal(sums[k], ws), (k, t, a, b)
+        assert np.array_equal(mins[k], wm if lens[t] else np.zeros(len(wm), np.int32)), (k, t, a, b)
+        assert np.array_equal(runs[k], H.oracle_runs(d, mincov, maxmean, 1 << 62, a)), (k, t, a, b)
+        if k % 17 == 0:                                                    # and the one-region API
+            s1, m1 = eng.region_windows(t, a, b)
+            assert np.array_equal(s1, sums[k]) and np.array_equal(m1, mins[k])
+            assert np.array_equal(eng.region_callable(t, a, b), runs[k])
