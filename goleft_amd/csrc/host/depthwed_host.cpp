@@ -224,6 +224,7 @@ int gdh_depthwed_main(int argc, const char* const* argv)
     }
     if (size < 0) { fprintf(stderr, "error: --size is required\n"); return 255; }
     if (beds.empty()) { fprintf(stderr, "error: beds is required\n"); return 255; }
+    if (size < 1) { fprintf(stderr, "error: --size must be >= 1\n"); return 255; }
     return gdh_depthwed_run(size, beds.data(), (int)beds.size(), nullptr);
 }
 
