@@ -1,0 +1,48 @@
+"""CPU: the bench line the driver parses.  The latest committed bench line (profiles/r*_bench_wgs_n1.json,
+written by bench.py on an MI355X) must carry every field of the contract, with BASELINE.json's metric."""
+import glob
+import json
+import os
+
+from tests import helpers as H
+
+
+def _latest(pattern):
+    files = sorted(glob.glob(os.path.join(H.ROOT, "profiles", pattern)))
+    assert files, pattern
+    return json.load(open(files[-1]))
+
+
+def test_wgs_bench_line_has_the_contract_fields():
+    d = _latest("r*_bench_wgs_n1.json")
+    base = json.load(open(os.path.join(H.ROOT, "BASELINE.json")))
+    assert d["metric"].split(",")[0] in base["metric"].replace("×", "x")
+    for k, t in (("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
+                 ("ms_per_step", float), ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str)):
+        assert isinstance(d[k], t), k
+    assert d["vs_baseline"] is None and base["published"] == {}          # no published number for this metric
+    assert d["n_gpus"] == 1 and d["higher_is_better"] is True and d["scaling"] in ("weak", "strong")
+    assert d["data"] == "synthetic" and d["dtype"] == "int32"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert r["traffic"] is None or r["traffic"] > 0
+    # achieved = algorithmic bytes per launch / average launch duration of the dominant kernel
+    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["avg_kernel_ms"] * 1e-3) / 1e9) / r["achieved"] < 1e-6
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == d["unit"] and c["sample"]
+    # whole-job throughput: the units of one step over its duration
+    assert abs(d["value"] - d["config"]["total_ref_bases"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
+    assert d["value"] >= 1e9                                            # BASELINE.json's target at one GPU
+
+
+def test_bench_defaults_are_the_contract_defaults():
+    import importlib.util
+    import sys
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(H.ROOT, "bench.py"))
+    src = open(os.path.join(H.ROOT, "bench.py")).read()
+    assert '"--gpus", type=int, default=1' in src and '"--steps"' in src and '"--warmup"' in src
+    assert spec is not None and "torch.cuda.synchronize" in src and "barrier" in src
+    assert "oracle" in src                                              # the cpu_baseline leg (and only that) uses it
+    assert sys.version_info >= (3, 8)
