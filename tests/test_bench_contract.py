@@ -46,3 +46,20 @@ def test_bench_defaults_are_the_contract_defaults():
     assert spec is not None and "torch.cuda.synchronize" in src and "barrier" in src
     assert "oracle" in src                                              # the cpu_baseline leg (and only that) uses it
     assert sys.version_info >= (3, 8)
+
+
+def test_product_never_uses_the_oracle():
+    """The oracle is test infrastructure: nothing under goleft_amd/ (Python, C++, HIP, Makefile) may import,
+    include, link or execute anything under oracle/ -- comments that cite it aside."""
+    import re
+    bad = []
+    for dirpath, _, files in os.walk(os.path.join(H.ROOT, "goleft_amd")):
+        for f in files:
+            if not f.endswith((".py", ".cpp", ".hpp", ".hip", ".inc", ".h")) and f != "Makefile":
+                continue
+            for n, line in enumerate(open(os.path.join(dirpath, f), errors="replace"), 1):
+                code = re.sub(r"(//|#(?!include)).*$", "", line) if not f.endswith(".py") else re.sub(r"#.*$", "", line)
+                if re.search(r"\boracle\b", code) and not code.lstrip().startswith(("*", '"""')):
+                    if re.search(r"import|include|dlopen|CDLL|-l|\.so|subprocess", code):
+                        bad.append("%s:%d: %s" % (os.path.relpath(os.path.join(dirpath, f), H.ROOT), n, line.strip()))
+    assert not bad, bad
