@@ -320,3 +320,20 @@ def test_bgzf_member_listing_on_damaged_bytes(seed):
     if mode == 0:
         assert rc == 0 and n.value == len([s for s in sizes]) + 1 and bytes(data) == good
         assert sum(isz[k] for k in range(n.value)) == sum(len(x) for x in parts)
+
+
+def test_headers_are_plain_c(tmp_path):
+    """cgo compiles include/*.h as C: both headers must be valid C99 (no C++ types, defaults or
+    references) and a C program must link against the device library's version symbol."""
+    import subprocess
+    src = tmp_path / "hc.c"
+    src.write_text('#include "goleft_depth.h"\n#include "goleft_depth_host.h"\n'
+                   "int main(void) { gd_params p; gd_run r; gd_batch b; gd_stats s; (void)p; (void)r; (void)b; (void)s;\n"
+                   "  return gd_abi_version() == GD_ABI_VERSION ? 0 : 1; }\n")
+    inc = os.path.join(ROOT, "include")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-I", inc, str(src)])
+    exe = tmp_path / "hc"
+    libdir = os.path.join(ROOT, "goleft_amd")
+    subprocess.check_call(["gcc", "-std=c99", "-I", inc, str(src), "-o", str(exe), "-L", libdir, "-lgoleft_depth",
+                           "-Wl,-rpath," + libdir])
+    assert subprocess.run([str(exe)]).returncode == 0
