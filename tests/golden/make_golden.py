@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
 """Regenerates tests/golden/*.npz and *.json from the reference's fixture BAMs.
 
-Run in the build container only (needs /root/reference):
+Runs anywhere (the fixture files are committed under tests/golden/ref/):
     python tests/golden/make_golden.py
 
 What is stored
   * the decoded record streams (pos/flag/mapq/cigar SoA per contig) of
     depth/test/{t,hla,t-empty}.bam -- derived data, decoded with
-    oracle/bamio.py; the BAM files themselves are not copied;
+    oracle/bamio.py (the files themselves: tests/golden/ref/);
   * the oracle's per-base depth and BED outputs for those streams.  These are
     REGRESSION vectors of the oracle, not reference-pinned truth (the reference
     has no golden outputs for this path);
@@ -24,8 +24,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 from oracle import bamio, pyoracle as po  # noqa: E402
 
-REF = "/root/reference/depth/test"
 OUT = os.path.dirname(os.path.abspath(__file__))
+REF = os.path.join(OUT, "ref")   # byte copies of /root/reference/depth/test/* (fixture DATA, not sources)
 
 
 def pack(contigs, reads):

@@ -13,7 +13,7 @@ from oracle import bamio, pyoracle as po
 from tests import helpers as H
 
 ROOT = H.ROOT
-REF_TEST = "/root/reference/depth/test"
+REF_TEST = os.path.join(H.GOLDEN, "ref")   # byte copies of the reference's depth/test fixtures
 
 
 @pytest.fixture(scope="module")
@@ -190,7 +190,6 @@ def test_bam_reader_rejects_garbage(hostlib, tmp_path):
         hostlib.read_bam(str(tmp_path / "missing.bam"))
 
 
-@pytest.mark.skipif(not os.path.isdir(REF_TEST), reason="reference fixtures only exist in the build container")
 @pytest.mark.parametrize("name,key", [("t", "t"), ("hla", "hla"), ("t-empty", "t_empty")])
 def test_bam_reader_on_reference_fixtures(hostlib, name, key):
     contigs, reads, z = H.load_golden_bam(key)
