@@ -59,47 +59,96 @@ def local_results(eng, device):
             device_view(pb, 2 * nb, torch.int32, device))
 
 
+class RootGather:
+    """The path's one exchange step (depth/depth.go:394-421: the merge loop owns the two BED files):
+    every rank's window sums / minima and ordered run boundaries to rank 0.
+
+    Built ONCE, outside any timed region: fixed-capacity send / receive buffers are allocated here
+    and reused by every step.  A step is then a few device-side copies into the packed send buffer
+    and ONE collective (`gather`; RCCL posts it as point-to-point sends to rank 0, each peer over its
+    own xGMI link) -- no `.item()`, no host synchronisation, no allocation.  The boundary count
+    travels inside the buffer (word 0), so no count exchange precedes the payload.
+
+    Packed layout per rank, int64 words:  [n_bounds][sums: max_w][mins: ceil(max_w / 2)][bounds: cap_b]
+    where a boundary is the engine's {int32 pos, int32 cls | local_contig_index << 2} pair.
+
+    `cap_b` (boundaries per rank) is agreed once by `reserve()` (an all_reduce MAX of the counts of
+    a first compute; data-dependent, like the reference's callable.bed row count).  A later step
+    with more boundaries than the capacity is detected on rank 0 by `result()` (`overflow`), never
+    silently truncated."""
+
+    def __init__(self, assignment: List[List[int]], lengths: Sequence[int], W: int, rank: int,
+                 world: int, device, bounds_cap: int = 1 << 16, group=None):
+        self.assignment, self.lengths, self.W = assignment, list(lengths), int(W)
+        self.rank, self.world, self.device, self.group = rank, world, device, group
+        self.nwin = [sum(n_windows(lengths[t], W) for t in assignment[r]) for r in range(world)]
+        self.max_w = max(self.nwin) if self.nwin else 0
+        self.words_m = (self.max_w + 1) // 2
+        self.cap_b = 0
+        self.send = self.recv = None
+        self._alloc(int(bounds_cap))
+
+    def _alloc(self, cap_b: int):
+        self.cap_b = cap_b
+        self.total = 1 + self.max_w + self.words_m + cap_b
+        self.send = torch.zeros(self.total, dtype=torch.int64, device=self.device)
+        if self.rank == 0:
+            self.recv = torch.zeros(self.world, self.total, dtype=torch.int64, device=self.device)
+            self._parts = list(self.recv.unbind(0))            # views of the one receive buffer
+
+    def reserve(self, n_bounds: int, slack: float = 1.25):
+        """Collective, setup time only: make every rank's boundary capacity cover the largest count
+        any rank has (times `slack`).  Returns the agreed capacity."""
+        t = torch.tensor([int(n_bounds)], dtype=torch.int64, device=self.device)
+        if self.world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        need = int(int(t.item()) * slack) + 1024
+        if need > self.cap_b:
+            self._alloc(need)
+        return self.cap_b
+
+    def step(self, sums: torch.Tensor, mins: torch.Tensor, bounds: torch.Tensor):
+        """Enqueue pack + gather on the current stream.  `bounds` is the flat int32 view (2 per
+        boundary); its length is host-known (gd_compute returns the count), so nothing here waits
+        for the device."""
+        k = sums.numel()
+        nb = bounds.numel() // 2
+        buf = self.send
+        buf[0:1].fill_(nb)
+        buf[1:1 + k].copy_(sums)
+        buf[1 + self.max_w:1 + self.max_w + self.words_m].view(torch.int32)[:k].copy_(mins)
+        m = min(nb, self.cap_b)
+        if m:
+            o = 1 + self.max_w + self.words_m
+            buf[o:o + m].copy_(bounds.view(torch.int64)[:m])
+        if self.world == 1:
+            self.recv[0].copy_(buf)
+        elif self.rank == 0:
+            dist.gather(buf, self._parts, dst=0, group=self.group)
+        else:
+            dist.gather(buf, None, dst=0, group=self.group)
+
+    def result(self):
+        """Rank 0: what the last step gathered, as the dict unpack_gathered() takes (one host
+        synchronisation, outside the exchange); other ranks: None."""
+        if self.rank != 0:
+            return None
+        counts = [int(c) for c in self.recv[:, 0].tolist()]
+        return {"parts": [p[1:] for p in self.recv.unbind(0)], "counts": [min(c, self.cap_b) for c in counts],
+                "overflow": any(c > self.cap_b for c in counts), "true_counts": counts,
+                "max_w": self.max_w, "words_m": self.words_m,
+                "assignment": self.assignment, "lengths": self.lengths, "W": self.W}
+
+
 def gather_to_root(sums: torch.Tensor, mins: torch.Tensor, bounds: torch.Tensor,
                    assignment: List[List[int]], lengths: Sequence[int], W: int,
                    rank: int, world: int, group=None):
-    """Gather per-rank results to rank 0.
-
-    Every rank passes its concatenated window sums/mins (contigs in ascending
-    tid order) and its ordered run boundaries {pos, cls | local_index << 2}.
-    Returns the gathered packed buffers on rank 0 (see unpack_gathered, which
-    yields tid -> {"sums": i64[n_win], "mins": i32[n_win], "bounds": i32[k,2]})
-    and None on the other ranks.
-    Two collectives: an all_gather of boundary counts (8 bytes per rank), then
-    one gather of a packed, padded int64 buffer."""
-    dev = sums.device
-    nwin = [sum(n_windows(lengths[t], W) for t in assignment[r]) for r in range(world)]
-    nb_local = torch.tensor([bounds.numel() // 2], dtype=torch.int64, device=dev)
-    if world == 1:
-        counts = [int(nb_local.item())]
-    else:
-        cl = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
-        dist.all_gather(cl, nb_local, group=group)
-        counts = [int(c.item()) for c in cl]
-    max_w, max_b = max(nwin), max(counts)
-    # packed layout (int64 words): [sums max_w][mins max_w as i32 pairs][bounds max_b]
-    words_m = (max_w + 1) // 2
-    total = max_w + words_m + max_b
-    buf = torch.zeros(total, dtype=torch.int64, device=dev)
-    k = sums.numel()
-    buf[:k] = sums
-    buf[max_w:max_w + words_m].view(torch.int32)[:k] = mins
-    buf[max_w + words_m:max_w + words_m + counts[rank]] = bounds.view(torch.int64) \
-        if bounds.numel() else bounds.new_zeros(0, dtype=torch.int64)
-    if world == 1:
-        parts = [buf]
-    elif rank == 0:
-        parts = [torch.empty_like(buf) for _ in range(world)]
-        dist.gather(buf, parts, dst=0, group=group)
-    else:
-        dist.gather(buf, None, dst=0, group=group)
-        return None
-    return {"parts": parts, "counts": counts, "max_w": max_w, "words_m": words_m,
-            "assignment": assignment, "lengths": list(lengths), "W": W}
+    """One-shot form (setup + one step + result): see RootGather.  Returns the gathered packed
+    buffers on rank 0 (unpack_gathered yields tid -> {"sums", "mins", "bounds"}), None elsewhere."""
+    g = RootGather(assignment, lengths, W, rank, world, sums.device, bounds_cap=0, group=group)
+    g.reserve(bounds.numel() // 2, slack=1.0)
+    g.step(sums, mins, bounds)
+    return g.result()
 
 
 def unpack_gathered(g) -> Dict[int, dict]:

@@ -105,3 +105,49 @@ def test_gather_single_rank_is_identity():
         nw = shard.n_windows(l, 100)
         assert np.array_equal(res[t]["sums"].numpy(), s[off:off + nw])
         off += nw
+
+
+def _worker_steps(rank, world, port, out_path):
+    """RootGather reused over several steps with CHANGING results (fixed buffers, one collective per
+    step), then a step whose boundary count exceeds the agreed capacity."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        lengths, reads = _make_case()
+        W, step = 250, 2500
+        assignment = shard.lpt_assign(lengths, world)
+        g = shard.RootGather(assignment, lengths, W, rank, world, torch.device("cpu"), bounds_cap=0)
+        s, m, b = _local(lengths, reads, assignment[rank], W, 4, step)
+        cap = g.reserve(len(b) // 2)
+        send_ptr = g.send.data_ptr()
+        ok = True
+        for mincov in (4, 2, 7, 4):                    # different class runs every step, same buffers
+            s, m, b = _local(lengths, reads, assignment[rank], W, mincov, step)
+            g.step(torch.from_numpy(s), torch.from_numpy(m), torch.from_numpy(b))
+            ok &= g.send.data_ptr() == send_ptr
+            if rank == 0:
+                gg = g.result()
+                ok &= not gg["overflow"]
+                res = shard.unpack_gathered(gg)
+                for t, l in enumerate(lengths):
+                    d = po.perbase_c(reads.get(t, H.empty_reads()), 1, 0, l)
+                    ws, wm = H.oracle_windows(d, W)
+                    wr = H.oracle_runs(d, mincov, 0, step)
+                    ok &= np.array_equal(res[t]["sums"].numpy(), ws) and np.array_equal(res[t]["mins"].numpy(), wm)
+                    ok &= np.array_equal(res[t]["bounds"].numpy(), wr[:, [0, 2]])
+        # more boundaries than the capacity: reported, never silently truncated
+        big = np.zeros(2 * (cap + 5), np.int32)
+        g.step(torch.from_numpy(s), torch.from_numpy(m), torch.from_numpy(big) if rank == world - 1 else torch.from_numpy(b))
+        if rank == 0:
+            gg = g.result()
+            ok &= gg["overflow"] and gg["true_counts"][world - 1] == cap + 5
+            open(out_path, "w").write("ok" if ok else "mismatch")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_root_gather_reused_over_steps(tmp_path):
+    out = str(tmp_path / "res.txt")
+    mp.spawn(_worker_steps, args=(2, _free_port(), out), nprocs=2, join=True)
+    assert open(out).read() == "ok"
