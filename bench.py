@@ -12,13 +12,17 @@ kernels, synchronous) over the rank's HBM-resident record streams, plus, when
 ONE genome is shared by N > 1 GPUs, the gather of window sums/minima and run
 boundaries to rank 0 over RCCL (the only exchange the path has):
 
-  --scaling weak   (default) N GPUs process a cohort of N 30x genomes, one
-                   whole genome per GPU (by sample): every rank owns its
-                   sample's outputs, as N independent `goleft depth` runs
-                   would, so no exchange step exists and none is timed;
-  --scaling strong N GPUs share ONE 3.1 Gb genome (BASELINE.json config 3);
-                   with N > 1 the weak run also times this case and reports
-                   it under "strong_scaling".
+  --scaling strong (default) BASELINE.json config 3: N GPUs share ONE 3.1 Gb
+                   genome, contigs assigned by LPT (goleft_amd/shard.py), every
+                   step ends with the gather to rank 0 INSIDE the timed region
+                   (one collective on a pre-allocated packed buffer the engine
+                   fills itself, gd_set_export); `value` = 3.1 Gb / step.  With
+                   N > 1 the line also carries the cohort case under
+                   "cohort_weak_scaling" and the compute / gather split;
+  --scaling weak   N GPUs process a cohort of N 30x genomes, one whole genome
+                   per GPU (by sample): every rank owns its sample's outputs,
+                   as N independent `goleft depth` runs would, so no exchange
+                   step exists and none is timed.
 
 Inputs are resident in HBM before the timed region starts.  Rank 0 prints one
 JSON line.
@@ -53,7 +57,7 @@ def parse():
                          "(BASELINE.json config 5, chunk path)")
     ap.add_argument("--coverage", type=float, default=None)
     ap.add_argument("--window", type=int, default=1000)
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--scaling", default="strong", choices=["weak", "strong"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-contigs", type=int, default=8)
     ap.add_argument("--no-host-stream", action="store_true",
@@ -228,6 +232,15 @@ def run_case(args, scaling, world, rank, dev, local_rank, want_streams=False):
     eng.set_profiling(True)
 
     wed = {}
+    gath = None
+    if exchange:
+        # set-up, outside the timed region: one compute to learn the boundary count, the ranks agree
+        # on a fixed capacity, buffers are allocated once and the engine is told to fill the send
+        # buffer itself (gd_set_export)
+        eng.compute()
+        gath = shard.RootGather(assignment, lengths, W, rank, world, dev, bounds_cap=0)
+        gath.reserve(eng.device_runs()[1])
+        gath.attach(eng)
 
     def step():
         eng.compute()
@@ -237,9 +250,7 @@ def run_case(args, scaling, world, rank, dev, local_rank, want_streams=False):
             tids = np.asarray(mine, np.int32).reshape(-1, 1)
             wed["shape"] = [eng.depthwed_device(tids, args.wed_size)[1], len(mine)]
         if exchange:
-            sums, mins, bounds = shard.local_results(eng, dev)
-            return shard.gather_to_root(sums, mins, bounds, assignment, lengths, W, rank, world)
-        return None
+            gath.step_exported()                    # ONE collective, no host sync, no allocation
 
     for _ in range(args.warmup):
         step()
@@ -265,6 +276,37 @@ def run_case(args, scaling, world, rank, dev, local_rank, want_streams=False):
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
+    split = None
+    if exchange:
+        # where a step goes, measured AFTER the timed loop with a synchronisation between the two
+        # halves (the timed loop itself has none): gd_compute wall, then the gather until it has landed
+        tc, tg = [], []
+        for _ in range(5):
+            dist.barrier()
+            torch.cuda.synchronize()
+            a = time.perf_counter()
+            eng.compute()
+            b = time.perf_counter()
+            gath.step_exported()
+            torch.cuda.synchronize()
+            c = time.perf_counter()
+            tc.append(b - a)
+            tg.append(c - b)
+        loads = [sum(lengths[t] for t in assignment[r]) for r in range(world)]
+        split = {"compute_ms_this_rank": float(np.median(tc)) * 1e3, "gather_ms_this_rank": float(np.median(tg)) * 1e3,
+                 "shard_ref_bases": loads, "lpt_imbalance": max(loads) / (sum(loads) / world),
+                 "lpt_speedup_ceiling": sum(loads) / max(loads),
+                 "gather_bytes_per_rank": int(gath.total * 8), "bounds_capacity": int(gath.cap_b)}
+        if rank == 0:
+            g = gath.result()
+            split["gather_overflow"] = bool(g["overflow"])
+            split["boundaries_per_rank"] = g["true_counts"]
+            # the gathered window sums are the whole genome's: one checksum the oracle side can repeat
+            tot = 0
+            for r_, p in enumerate(g["parts"]):
+                tot += int(p[:gath.nwin[r_]].sum().item())
+            split["gathered_sum_of_window_sums"] = tot
+
     st = eng.stats()
     my_bases = sum(lengths[t] for t in mine)
     my_windows = sum(shard.n_windows(lengths[t], W) for t in mine)
@@ -277,7 +319,7 @@ def run_case(args, scaling, world, rank, dev, local_rank, want_streams=False):
         "runs_ms": float(np.mean(runs_ms)), "tile_positions": st.tile_positions, "lookback": st.lookback,
         "expand_ms": float(np.mean(expand_ms)), "scan_ms": float(np.mean(scan_ms)), "path": int(st.path),
         "ckpt_ms": float(np.mean(ckpt_ms)),
-        "perbase": not cohort, "wed_shape": wed.get("shape"),
+        "perbase": not cohort, "wed_shape": wed.get("shape"), "split": split,
     }
     if not want_streams:
         streams.clear()
@@ -363,7 +405,9 @@ def main():
         "dtype": "int32",
         "data": "synthetic",
         "config": {"workload": r["wname"] + (" x %d samples (cohort, one genome per GPU)" % r["n_samples"]
-                                             if r["n_samples"] > 1 else ""),
+                                             if r["n_samples"] > 1 else
+                                             ", ONE genome sharded by chromosome (LPT) over %d GPUs, gather to rank 0 "
+                                             "inside the timed region" % world if world > 1 else ""),
                    "coverage": args.coverage, "window": W,
                    "min_mapq": Q, "min_cov": mincov, "total_ref_bases": r["total_bases"],
                    "reads_rank0": r["n_reads"], "cigar_ops_rank0": r["n_ops"],
@@ -389,6 +433,10 @@ def main():
                        if chunk else {"prep": r["prep_ms"], "tile": r["tile_ms"], "runs": r["runs_ms"]}),
         "with_d2h_windows_ref_bases_per_s": r["my_bases"] / (dt / args.steps + d2h) if world == 1 else None,
     }
+    if world == 1 and args.workload != "cohort":
+        from goleft_amd import shard as _sh
+        # checksum of checksums: equals "split.gathered_sum_of_window_sums" of an N > 1 run of the same workload
+        out["sum_of_window_sums"] = int(_sh.local_results(eng, dev)[0].sum().item())
     if d2h_matrix is not None:
         out["with_d2h_matrix_ref_bases_per_s"] = r["my_bases"] / (dt / args.steps + d2h_matrix)
     if traffic:
@@ -427,25 +475,28 @@ def main():
                                          "perbase_diff + callback, %d threads over 10 Mb tiles, %.1f s "
                                          "wall (%.0f core-seconds)"
                                          % ("+".join(s[0] for s in sample), b, cores, sec, sec * cores)}
+    r_split = r["split"]
     eng.close()
     streams.clear()
     del r
 
-    # N > 1, weak default: also time BASELINE.json's config 3 (one 3.1 Gb genome over N GPUs)
-    if world > 1 and args.scaling == "weak":
+    if r_split is not None:
+        out["split"] = r_split
+    # N > 1: the headline is ONE genome over N GPUs (BASELINE.json config 3); the cohort case (N genomes,
+    # one per GPU, no exchange) is reported next to it
+    if world > 1 and args.scaling == "strong" and args.workload in ("wgs", "ont"):
         try:
             torch.cuda.empty_cache()
-            r2 = run_case(args, "strong", world, rank, dev, local_rank)
-            out["strong_scaling"] = {"value": r2["total_bases"] * args.steps / r2["dt"], "unit": "ref-bases/s",
-                                     "ms_per_step": r2["dt"] / args.steps * 1e3,
-                                     "total_ref_bases": r2["total_bases"],
-                                     "workload": r2["wname"] + ", ONE genome sharded by chromosome (LPT) over %d GPUs, "
-                                                 "RCCL gather to rank 0 inside the timed region" % world,
-                                     "kernels_ms_rank0": {"prep": r2["prep_ms"], "tile": r2["tile_ms"],
-                                                          "runs": r2["runs_ms"]}}
+            r2 = run_case(args, "weak", world, rank, dev, local_rank)
+            out["cohort_weak_scaling"] = {"value": r2["total_bases"] * args.steps / r2["dt"], "unit": "ref-bases/s",
+                                          "ms_per_step": r2["dt"] / args.steps * 1e3,
+                                          "total_ref_bases": r2["total_bases"],
+                                          "workload": r2["wname"] + " x %d samples, one genome per GPU, no exchange" % world,
+                                          "kernels_ms_rank0": {"prep": r2["prep_ms"], "tile": r2["tile_ms"],
+                                                               "runs": r2["runs_ms"]}}
             r2["eng"].close()
         except Exception as e:                       # never lose the headline line to the secondary case
-            out["strong_scaling"] = {"error": "%s: %s" % (type(e).__name__, e)}
+            out["cohort_weak_scaling"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -460,6 +460,15 @@ int gd_device_runs(gd_ctx* c, const int32_t** d_bounds, size_t* n_bounds)
     return GD_OK;
 }
 
+int gd_set_export(gd_ctx* c, void* device_buf, int64_t max_windows, int64_t cap_bounds)
+{
+    if (!c || max_windows < 0 || cap_bounds < 0) return GD_E_INVALID;
+    c->export_buf = static_cast<int64_t*>(device_buf);
+    c->export_max_w = max_windows;
+    c->export_cap_b = cap_bounds;
+    return GD_OK;
+}
+
 int gd_get_stats(gd_ctx* c, gd_stats* out)
 {
     if (!c || !out) return GD_E_INVALID;

@@ -144,6 +144,9 @@ struct gd_ctx {
     int64_t seq_len = -1;
     uint32_t seq_padded = 0;
 
+    int64_t* export_buf = nullptr;     // gd_set_export: caller-owned device buffer, written by every gd_compute
+    int64_t export_max_w = 0, export_cap_b = 0;
+
     bool computed = false;
     int64_t n_tiles = 0, n_win_total = 0, n_bases = 0;
     std::vector<int2> bounds;             // ordered run boundaries of the last compute

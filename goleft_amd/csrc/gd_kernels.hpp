@@ -420,6 +420,29 @@ __global__ __launch_bounds__(SUPER) void gd_runs_order_kernel(const int2* __rest
 }
 
 // ---------------------------------------------------------------------------
+// K2b: packed export block (gd_set_export): the results a merge step needs -- what the
+// reference's merge loop (depth/depth.go:394-421) collects from its workers -- in ONE
+// caller-owned device buffer (an RCCL send buffer), written before gd_compute's single
+// synchronisation.  int64 words: [n_bounds][sums: max_w][mins: ceil(max_w/2)][bounds: cap_b].
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gd_export_kernel(const int64_t* __restrict__ wsum, const int32_t* __restrict__ wmin,
+                                                        int64_t n_win, const int2* __restrict__ ordered,
+                                                        const Counters* __restrict__ counters, int64_t* __restrict__ dst,
+                                                        int64_t max_w, int64_t cap_b)
+{
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    const uint32_t nb = counters->run_cursor;
+    if (gid == 0) dst[0] = (int64_t)nb;
+    int64_t* const d_sum = dst + 1;
+    int32_t* const d_min = reinterpret_cast<int32_t*>(dst + 1 + max_w);
+    int2* const d_bnd = reinterpret_cast<int2*>(dst + 1 + max_w + (max_w + 1) / 2);
+    for (int64_t w = gid; w < n_win; w += gsz) { d_sum[w] = wsum[w]; d_min[w] = wmin[w]; }
+    const int64_t m = (int64_t)nb < cap_b ? (int64_t)nb : cap_b;
+    for (int64_t k = gid; k < m; k += gsz) d_bnd[k] = ordered[k];
+}
+
+// ---------------------------------------------------------------------------
 // K3: --bed mode reductions over the resident per-base vector
 // ---------------------------------------------------------------------------
 // One workgroup per (clipped) window of the region: sum and min of

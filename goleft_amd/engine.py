@@ -426,6 +426,12 @@ class DepthEngine:
         self._chk(self._lib.gd_device_perbase(self._ctx, tid, C.byref(p), C.byref(n)))
         return p.value, n.value
 
+    def set_export(self, device_ptr: int, max_windows: int, cap_bounds: int):
+        """gd_set_export: every compute() also writes the packed block
+        [n_bounds][sums][mins][bounds] into caller-owned device memory (0 switches it off)."""
+        self._chk(self._lib.gd_set_export(self._ctx, C.c_void_p(device_ptr) if device_ptr else None,
+                                          int(max_windows), int(cap_bounds)))
+
     def window_offset(self, tid: int):
         o, n = C.c_size_t(), C.c_size_t()
         self._chk(self._lib.gd_window_offset(self._ctx, tid, C.byref(o), C.byref(n)))

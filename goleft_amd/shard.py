@@ -128,6 +128,23 @@ class RootGather:
         else:
             dist.gather(buf, None, dst=0, group=self.group)
 
+    def attach(self, eng):
+        """Let the engine fill the send buffer itself: gd_set_export makes every gd_compute write the
+        packed block (same layout) before its one synchronisation, so a step is compute + ONE
+        collective with no pack launches at all.  Call again after reserve() re-allocated."""
+        eng.set_export(self.send.data_ptr(), self.max_w, self.cap_b)
+        self._attached = self.send.data_ptr()
+
+    def step_exported(self):
+        """The exchange after a compute() of an attached engine (the block is already in `send`)."""
+        assert getattr(self, "_attached", None) == self.send.data_ptr(), "attach() after the last (re)allocation"
+        if self.world == 1:
+            self.recv[0].copy_(self.send)
+        elif self.rank == 0:
+            dist.gather(self.send, self._parts, dst=0, group=self.group)
+        else:
+            dist.gather(self.send, None, dst=0, group=self.group)
+
     def result(self):
         """Rank 0: what the last step gathered, as the dict unpack_gathered() takes (one host
         synchronisation, outside the exchange); other ranks: None."""

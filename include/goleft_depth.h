@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define GD_ABI_VERSION 7
+#define GD_ABI_VERSION 8
 
 typedef enum {
     GD_OK = 0,
@@ -371,6 +371,17 @@ int gd_device_windows(gd_ctx* ctx, const int64_t** d_sums, const int32_t** d_min
 int gd_window_offset(gd_ctx* ctx, int32_t tid, size_t* off, size_t* n);
 /* Ordered run boundaries {pos, cls | tid<<2} of all contigs. */
 int gd_device_runs(gd_ctx* ctx, const int32_t** d_bounds, size_t* n_bounds);
+
+/* Packed export block for a merge step (the reference's merge loop, depth/depth.go:394-421, run by
+ * one rank for N workers): when device_buf is not NULL, every gd_compute also writes -- before its
+ * single synchronisation, no extra launch latency -- the int64 words
+ *     [n_bounds][sums: max_windows][mins: ceil(max_windows / 2) words of int32 pairs][bounds: cap_bounds]
+ * into that caller-owned device buffer (e.g. an RCCL send buffer), so the exchange is one collective
+ * on one buffer with no host round trip for sizes.  n_bounds is the true boundary count (it may
+ * exceed cap_bounds: the receiver must check); the window arrays hold the computed contigs in
+ * ascending tid order; a boundary is {int32 pos, int32 cls | index_among_computed_contigs << 2}.
+ * GD_E_CAPACITY from gd_compute if the job has more windows than max_windows.  NULL switches it off. */
+int gd_set_export(gd_ctx* ctx, void* device_buf, int64_t max_windows, int64_t cap_bounds);
 
 /* ---- measurement ---------------------------------------------------------*/
 int gd_get_stats(gd_ctx* ctx, gd_stats* out);
