@@ -17,6 +17,7 @@ SYMBOLS = {
     "gdh_chrom_start_end": (C.c_int, [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t,
                                       C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "gdh_step": (C.c_int64, [C.c_int32]),
+    "gdh_lpt_assign": (C.c_int, [_P, C.c_size_t, _P, C.c_size_t, C.c_size_t, _P]),
     "gdh_format_region": (C.c_int, [C.c_char_p, C.c_int64, C.c_int64, C.c_int32, _P, C.c_size_t,
                                     _P, C.c_size_t, C.c_char_p, C.c_char_p]),
     "gdh_depthwed_main": (C.c_int, [C.c_int, C.POINTER(C.c_char_p)]),
@@ -71,6 +72,18 @@ def chrom_start_end(line: bytes):
     if load().gdh_chrom_start_end(line, len(line), chrom, 4096, C.byref(s), C.byref(e)) != 0:
         raise ValueError("couldn't get region from line %r" % line)
     return chrom.value.decode(), s.value, e.value
+
+
+def lpt_assign(tids, lengths, n_shards):
+    """gdh_lpt_assign: the shard (engine context / device) of every tid, as `goleft depth` assigns them."""
+    import numpy as np
+    t = np.ascontiguousarray(tids, np.int32)
+    l = np.ascontiguousarray(lengths, np.int64)
+    out = np.full(len(t), -1, np.int32)
+    rc = load().gdh_lpt_assign(t.ctypes.data, len(t), l.ctypes.data, len(l), int(n_shards), out.ctypes.data)
+    if rc != 0:
+        raise ValueError("gdh_lpt_assign: bad arguments")
+    return out
 
 
 def format_region(chrom, start, end, W, sums, runs, depth_path, callable_path):

@@ -241,7 +241,8 @@ bool load_bai(const std::string& bam_path, std::vector<uint8_t>* d)
 }
 }  // namespace
 
-bool BamReader::linear_index(const std::string& bam_path, std::vector<std::vector<uint64_t>>* per_ref, std::string* err)
+bool BamReader::linear_index(const std::string& bam_path, std::vector<std::vector<uint64_t>>* per_ref, std::string* err,
+                             std::vector<char>* has_chunks, std::vector<uint64_t>* chunk_end)
 {
     std::vector<uint8_t> d;
     if (!load_bai(bam_path, &d)) return false;
@@ -251,6 +252,8 @@ bool BamReader::linear_index(const std::string& bam_path, std::vector<std::vecto
         return false;
     }
     per_ref->assign((size_t)n_ref, std::vector<uint64_t>());
+    if (has_chunks) has_chunks->assign((size_t)n_ref, 0);
+    if (chunk_end) chunk_end->assign((size_t)n_ref, 0);
     size_t p = 8;
     for (int32_t r = 0; r < n_ref; ++r) {
         if (p + 4 > d.size()) { if (err) *err = "truncated BAI"; return false; }
@@ -258,8 +261,17 @@ bool BamReader::linear_index(const std::string& bam_path, std::vector<std::vecto
         p += 4;
         for (int32_t b = 0; b < n_bin; ++b) {
             if (p + 8 > d.size()) { if (err) *err = "truncated BAI"; return false; }
+            const uint32_t bin = rd32(d.data() + p);
             const int32_t n_chunk = (int32_t)rd32(d.data() + p + 4);
             if (n_chunk < 0 || (d.size() - p - 8) / 16 < (size_t)n_chunk) { if (err) *err = "corrupt BAI"; return false; }
+            if (bin != 37450 && n_chunk > 0) {                  // 37450: the metadata pseudo-bin (SAMv1 5.2)
+                if (has_chunks) (*has_chunks)[(size_t)r] = 1;
+                if (chunk_end)
+                    for (int32_t k = 0; k < n_chunk; ++k) {
+                        const uint64_t e = rd64(d.data() + p + 8 + 16 * (size_t)k + 8);
+                        if (e > (*chunk_end)[(size_t)r]) (*chunk_end)[(size_t)r] = e;
+                    }
+            }
             p += 8 + 16 * (size_t)n_chunk;
         }
         if (p + 4 > d.size()) { if (err) *err = "truncated BAI"; return false; }

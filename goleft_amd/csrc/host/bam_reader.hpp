@@ -57,8 +57,12 @@ public:
     // The .bai linear index (SAMv1 5.2): for every reference the sorted, distinct, non-zero
     // virtual offsets of record starts (one per 16 kb window that holds reads).  false when
     // there is no usable index next to the file.  Static: needs no open reader.
+    // Optional: has_chunks[r] = reference r has chunks in a real bin (so "no linear index" cannot mean
+    // "no records"), chunk_end[r] = the largest chunk end (virtual offset) of its bins: no record of r
+    // lies past the BGZF member that holds it.
     static bool linear_index(const std::string& bam_path, std::vector<std::vector<uint64_t>>* per_ref,
-                             std::string* err);
+                             std::string* err, std::vector<char>* has_chunks = nullptr,
+                             std::vector<uint64_t>* chunk_end = nullptr);
 
     // Fills `out` with up to max_reads records, all of one contig (a block ends
     // at a contig change).  Records with refID < 0 are skipped and counted.

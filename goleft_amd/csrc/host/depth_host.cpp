@@ -18,7 +18,9 @@
 #include <cstring>
 #include <map>
 #include <chrono>
+#include <functional>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "bam_reader.hpp"
@@ -57,7 +59,7 @@ bool parse_int(const char* s, int* out)
     char* end = nullptr;
     errno = 0;
     long v = strtol(s, &end, 10);
-    if (errno || end == s || *end) return false;
+    if (errno || end == s || *end || v < INT32_MIN || v > INT32_MAX) return false;
     *out = (int)v;
     return true;
 }
@@ -266,6 +268,7 @@ bool read_fai(const std::string& path, std::vector<FaiEntry>* out)
     size_t cap = 0;
     ssize_t n;
     while ((n = getline(&line, &cap, f)) > 0) {
+        if (line[n - 1] != '\n') break;          // quirk Q6 (depth/depth.go:137-140): an unterminated last .fai line is dropped
         std::string s(line, (size_t)n);
         const size_t t1 = s.find('\t');
         if (t1 == std::string::npos) continue;
@@ -279,13 +282,79 @@ bool read_fai(const std::string& path, std::vector<FaiEntry>* out)
     return true;
 }
 
-#define GDCHK(call)                                                                    \
+// One engine context per device ("shard"): the reference parallelises over tiles inside one process
+// (`-p`, depth/depth.go:392-394) and merges in :394-421; here the unit is a contig, assigned to a device.
+struct Shard {
+    gd_ctx* ctx = nullptr;
+    int device = 0;
+    std::vector<int32_t> wanted;        // the references this shard computes (ascending)
+    uint64_t n_gpu_records = 0;
+    int rc = GD_OK;                     // result of the shard's worker thread
+    bool io_ok = true;
+    std::string what;                   // the failing call
+};
+
+struct Shards {
+    std::vector<Shard> v;
+    ~Shards() { for (Shard& s : v) if (s.ctx) gd_destroy(s.ctx); }
+};
+
+// Longest-processing-time-first assignment of contigs (by length) to n shards; deterministic.
+std::vector<std::vector<int32_t>> lpt_assign(const std::vector<int32_t>& tids, const std::vector<int64_t>& lens, size_t n)
+{
+    std::vector<int32_t> order(tids);
+    std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return lens[(size_t)a] > lens[(size_t)b]; });
+    std::vector<std::vector<int32_t>> out(n);
+    std::vector<int64_t> load(n, 0);
+    for (int32_t t : order) {
+        size_t k = 0;
+        for (size_t i = 1; i < n; ++i) if (load[i] < load[k]) k = i;
+        out[k].push_back(t);
+        load[k] += lens[(size_t)t];
+    }
+    for (auto& o : out) std::sort(o.begin(), o.end());
+    return out;
+}
+
+// GOLEFT_DEVICES: "all", or a comma separated list of HIP device ids, one engine context each
+// (an id may repeat: several contexts on one device -- "virtual shards", how the multi-device path is
+// tested on a one-GPU box).  Unset: GOLEFT_DEVICE (default 0), one context.
+bool parse_devices(std::vector<int>* out, std::string* err)
+{
+    out->clear();
+    const char* e = getenv("GOLEFT_DEVICES");
+    if (!e || !*e) {
+        int d = 0;
+        if (const char* one = getenv("GOLEFT_DEVICE")) d = atoi(one);
+        out->push_back(d);
+        return true;
+    }
+    if (strcmp(e, "all") == 0) {
+        int n = 0;
+        if (gd_device_count(&n) != GD_OK || n < 1) { *err = "GOLEFT_DEVICES=all: no device"; return false; }
+        for (int i = 0; i < n; ++i) out->push_back(i);
+        return true;
+    }
+    const char* p = e;
+    while (*p) {
+        char* end = nullptr;
+        const long v = strtol(p, &end, 10);
+        if (end == p || v < 0 || v > 4095) { *err = std::string("GOLEFT_DEVICES: cannot parse '") + e + "'"; return false; }
+        out->push_back((int)v);
+        p = end;
+        if (*p == ',') ++p;
+        else if (*p) { *err = std::string("GOLEFT_DEVICES: cannot parse '") + e + "'"; return false; }
+    }
+    if (out->empty() || out->size() > 64) { *err = "GOLEFT_DEVICES: between 1 and 64 contexts"; return false; }
+    return true;
+}
+
+#define GDCHK_ON(cx_, call)                                                            \
     do {                                                                               \
         int rc_ = (call);                                                              \
         if (rc_ != GD_OK) {                                                            \
             fprintf(stderr, "goleft depth: %s failed: %s (%s)\n", #call, gd_strerror(rc_), \
-                    ctx ? gd_last_error(ctx) : "");                                    \
-            if (ctx) gd_destroy(ctx);                                                  \
+                    (cx_) ? gd_last_error(cx_) : "");                                  \
             return 1;                                                                  \
         }                                                                              \
     } while (0)
@@ -293,7 +362,6 @@ bool read_fai(const std::string& path, std::vector<FaiEntry>* out)
 int run(const DArgs& args)
 {
     int exit_code = 0;
-    gd_ctx* ctx = nullptr;
     std::string err;
     gdh::BamReader bam;
     if (!bam.open(args.bam, args.processes, &err)) {
@@ -315,6 +383,8 @@ int run(const DArgs& args)
         size_t cap = 0;
         ssize_t n;
         while ((n = getline(&line, &cap, f)) > 0) {
+            if (line[n - 1] != '\n') break;      // quirk Q6: ReadBytes returns the unterminated last line WITH io.EOF
+                                                 // and :108-110 breaks before using it -- the row is dropped
             Region r;
             if (!chrom_start_end(line, (size_t)n, &r.chrom, &r.start, &r.end)) {
                 fprintf(stderr, "couldn't get region from line%s", line);      // :78 log.Fatal
@@ -359,30 +429,38 @@ int run(const DArgs& args)
         if (fca) fclose(fca);
         return 1;
     }
-    auto close_all = [&]() { fclose(fca); fclose(fhd); };
+    struct Closer { FILE *a, *b; bool done = false; ~Closer() { if (!done) { fclose(a); fclose(b); } } } closer{fca, fhd};
 
     gdh::FastaStats fasta;
     gdh::FastaStats* fa = nullptr;
     if (args.stats) {                                                           // :244-252
         if (!fasta.open(args.reference, &err)) {
             fprintf(stderr, "goleft depth: %s\n", err.c_str());
-            close_all();
             return 1;
         }
         fa = &fasta;
     }
 
-    // ---- device engine ----------------------------------------------------------
-    int device = 0;
-    if (const char* e = getenv("GOLEFT_DEVICE")) device = atoi(e);
-    {
-        int rc = gd_create(device, &ctx);
-        if (rc != GD_OK) {
-            fprintf(stderr, "goleft depth: no usable MI355X device (%s); this build has no CPU path\n", gd_strerror(rc));
-            close_all();
-            return 1;
-        }
-    }
+    // ---- device engines: one context per device, contigs assigned by LPT -------------------
+    Shards S;                                                // destroys every context on any return
+    std::vector<int> devices;
+    if (!parse_devices(&devices, &err)) { fprintf(stderr, "goleft depth: %s\n", err.c_str()); return 1; }
+    std::vector<int64_t> lens(contigs.size());
+    for (size_t i = 0; i < contigs.size(); ++i) lens[i] = contigs[i].length;
+    const size_t n_shards = std::max<size_t>(1, std::min(devices.size(), std::max<size_t>(wanted.size(), 1)));
+    const std::vector<std::vector<int32_t>> assignment = lpt_assign(wanted, lens, n_shards);
+    std::vector<int> shard_of(contigs.size(), 0);
+    // fused device results are W/step aligned over the BAM contig length; a tile cut short by a
+    // disagreeing .fai length, and every --bed row, goes through the region reductions instead,
+    // which need the per-base vector; a whole-genome run with an agreeing .fai does not
+    auto is_fused = [&](const Region& r) {
+        if (r.tid < 0) return false;
+        const int64_t clen = contigs[(size_t)r.tid].length;
+        return args.bed.empty() && r.start % step == 0 && (r.end == clen || (r.end < clen && r.end % step == 0));
+    };
+    bool need_perbase = false;
+    for (const Region& r : regions)
+        if (r.tid >= 0 && r.end > r.start && !is_fused(r)) { need_perbase = true; break; }
     gd_params P;
     gd_default_params(&P);
     P.window_size = W;
@@ -390,11 +468,39 @@ int run(const DArgs& args)
     P.min_cov = args.min_cov;
     P.max_mean_depth = args.max_mean_depth;
     P.step = args.bed.empty() ? step : 0;
-    GDCHK(gd_set_params(ctx, &P));
-    std::vector<int64_t> lens(contigs.size());
-    for (size_t i = 0; i < contigs.size(); ++i) lens[i] = contigs[i].length;
-    GDCHK(gd_set_contigs(ctx, (int)lens.size(), lens.data()));
-    if (!contigs.empty()) GDCHK(gd_select_contigs(ctx, (int)wanted.size(), wanted.data()));
+    S.v.resize(n_shards);
+    for (size_t k = 0; k < n_shards; ++k) {
+        Shard& sh = S.v[k];
+        sh.device = devices[k];
+        sh.wanted = assignment[k];
+        for (int32_t t : sh.wanted) shard_of[(size_t)t] = (int)k;
+        const int rc = gd_create(sh.device, &sh.ctx);
+        if (rc != GD_OK) {
+            fprintf(stderr, "goleft depth: no usable MI355X device %d (%s); this build has no CPU path\n", sh.device, gd_strerror(rc));
+            return 1;
+        }
+        GDCHK_ON(sh.ctx, gd_set_params(sh.ctx, &P));
+        GDCHK_ON(sh.ctx, gd_set_contigs(sh.ctx, (int)lens.size(), lens.data()));
+        if (!need_perbase) GDCHK_ON(sh.ctx, gd_set_outputs(sh.ctx, 0));   // windows + class runs are all the rows need
+        if (!contigs.empty() && !sh.wanted.empty())
+            GDCHK_ON(sh.ctx, gd_select_contigs(sh.ctx, (int)sh.wanted.size(), sh.wanted.data()));
+    }
+    auto ctx_of = [&](int tid) -> gd_ctx* { return S.v[(size_t)shard_of[(size_t)tid]].ctx; };
+    // each worker runs on its own OS thread (every gd_* entry point re-issues hipSetDevice)
+    auto on_every_shard = [&](const char* what, const std::function<int(Shard&)>& fn) -> bool {
+        std::vector<std::thread> th;
+        for (size_t k = 1; k < S.v.size(); ++k)
+            th.emplace_back([&, k]() { S.v[k].rc = S.v[k].wanted.empty() ? GD_OK : fn(S.v[k]); });
+        S.v[0].rc = S.v[0].wanted.empty() ? GD_OK : fn(S.v[0]);
+        for (auto& t : th) t.join();
+        for (Shard& sh : S.v)
+            if (sh.rc != GD_OK) {
+                fprintf(stderr, "goleft depth: %s failed on device %d: %s (%s)\n", what, sh.device, gd_strerror(sh.rc),
+                        gd_last_error(sh.ctx));
+                return false;
+            }
+        return true;
+    };
 
     // GOLEFT_DEPTH_TIMING=1: wall-clock phases on stderr (measurement only, SURVEY.md 8d scope iii)
     const bool timing = getenv("GOLEFT_DEPTH_TIMING") != nullptr;
@@ -409,20 +515,35 @@ int run(const DArgs& args)
     // With a .bai next to the BAM (goleft depth needs one anyway: `samtools depth -r`), the whole
     // read happens on the device: the contig's byte range goes to gd_ingest_bgzf, which inflates
     // the BGZF members and decodes the records there (GOLEFT_GPU_DECODE=0 keeps the host decoder).
+    // Every shard reads its own contigs' byte ranges from the shared mapping.
     if (!wanted.empty()) {
         std::vector<std::vector<uint64_t>> lin;
+        std::vector<char> has_chunks;
+        std::vector<uint64_t> chunk_end;
         const char* gd_env = getenv("GOLEFT_GPU_DECODE");
-        bool gpu_decode = !(gd_env && gd_env[0] == '0') && gdh::BamReader::linear_index(args.bam, &lin, &err) &&
+        bool gpu_decode = !(gd_env && gd_env[0] == '0') && gdh::BamReader::linear_index(args.bam, &lin, &err, &has_chunks, &chunk_end) &&
                           lin.size() == contigs.size();
+        // a reference whose bins hold chunks but whose linear index is empty (a non-htslib indexer):
+        // the anchors cannot be trusted to mean "no records" -> host decoder
+        for (size_t r = 0; gpu_decode && r < lin.size(); ++r)
+            if (lin[r].empty() && r < has_chunks.size() && has_chunks[r]) gpu_decode = false;
         if (gpu_decode) {
             gdh::FileMap fm;
             if (!fm.open(args.bam)) gpu_decode = false;
             if (gpu_decode) {
-                bool io_ok = true;
-                GDCHK(gdh::ingest_references_on_device(ctx, fm, lin, wanted, wanted, &n_gpu_records, &io_ok));
-                if (!io_ok) { gpu_decode = false; n_gpu_records = 0; }
+                if (!on_every_shard("the device BAM read", [&](Shard& sh) {
+                        return gdh::ingest_references_on_device(sh.ctx, fm, lin, sh.wanted, sh.wanted, &sh.n_gpu_records, &sh.io_ok,
+                                                                512ull << 20, &chunk_end);
+                    }))
+                    return 1;
+                for (Shard& sh : S.v) {
+                    if (!sh.io_ok) gpu_decode = false;
+                    n_gpu_records += sh.n_gpu_records;
+                }
+                if (!gpu_decode) n_gpu_records = 0;
             }
-            if (!gpu_decode) GDCHK(gd_reset(ctx));                    // fall back to the host decoder below
+            if (!gpu_decode)
+                for (Shard& sh : S.v) GDCHK_ON(sh.ctx, gd_reset(sh.ctx));   // fall back to the host decoder below
         }
         if (!gpu_decode) {
         if (wanted.size() == 1) bam.seek_contig(wanted[0], &err);   // .bai shortcut for --chrom
@@ -434,25 +555,24 @@ int run(const DArgs& args)
             const int rc = bam.next_block(blk, 1u << 21, &err);
             if (rc < 0) {
                 fprintf(stderr, "goleft depth: %s\n", err.c_str());
-                gd_destroy(ctx);
-                close_all();
                 return 1;
             }
             if (rc == 0) break;
             if (blk.tid > last_wanted) break;                       // coordinate sorted: done
             if (blk.tid >= (int32_t)contigs.size() || !want[(size_t)blk.tid]) continue;
+            gd_ctx* const ctx = ctx_of(blk.tid);
             gd_batch b;
-            GDCHK(gd_acquire(ctx, blk.size(), blk.cigar.size(), &b));
+            GDCHK_ON(ctx, gd_acquire(ctx, blk.size(), blk.cigar.size(), &b));
             memcpy(b.pos, blk.pos.data(), blk.size() * sizeof(int32_t));
             memcpy(b.flag, blk.flag.data(), blk.size() * sizeof(uint16_t));
             memcpy(b.mapq, blk.mapq.data(), blk.size() * sizeof(uint8_t));
             memcpy(b.cigar_off, blk.cigar_off.data(), (blk.size() + 1) * sizeof(uint32_t));
             if (!blk.cigar.empty()) memcpy(b.cigar, blk.cigar.data(), blk.cigar.size() * sizeof(uint32_t));
-            GDCHK(gd_commit(ctx, &b, blk.tid, blk.size(), blk.cigar.size()));
+            GDCHK_ON(ctx, gd_commit(ctx, &b, blk.tid, blk.size(), blk.cigar.size()));
         }
         }
         t_ingested = now();
-        GDCHK(gd_compute(ctx));
+        if (!on_every_shard("gd_compute", [&](Shard& sh) { return gd_compute(sh.ctx); })) return 1;
         t_computed = now();
     }
 
@@ -470,6 +590,7 @@ int run(const DArgs& args)
     std::string seq_chrom, seq_bases;
     bool seq_known = false;
     int stats_rc = GD_OK;
+    gd_ctx* const seq_ctx = S.v[0].ctx;              // --stats: the FASTA windows are counted on the first device
     auto emit_region = [&](const char* chrom, int64_t rs, int64_t re, const int64_t* su, size_t n_su,
                            const gd_run* ru, size_t n_ru) {
         if (!fa) { format_region(&rows, chrom, rs, re, W, su, n_su, ru, n_ru, nullptr); return; }
@@ -480,14 +601,14 @@ int run(const DArgs& args)
             seq_chrom = chrom;
             seq_known = fa->contig_bases(chrom, &seq_bases);
             if (seq_known && stats_rc == GD_OK)
-                stats_rc = gd_seq_load(ctx, reinterpret_cast<const uint8_t*>(seq_bases.data()), (int64_t)seq_bases.size());
+                stats_rc = gd_seq_load(seq_ctx, reinterpret_cast<const uint8_t*>(seq_bases.data()), (int64_t)seq_bases.size());
             seq_bases.clear();
             seq_bases.shrink_to_fit();
         }
         const size_t n = sp.s.size();
         std::vector<uint32_t> gc(n, 0), cpg(n, 0), low(n, 0);
         if (seq_known && n && stats_rc == GD_OK)
-            stats_rc = gd_seq_stats(ctx, n, sp.s.data(), sp.e.data(), gc.data(), cpg.data(), low.data());
+            stats_rc = gd_seq_stats(seq_ctx, n, sp.s.data(), sp.e.data(), gc.data(), cpg.data(), low.data());
         sp.cols.resize(n);
         for (size_t k = 0; k < n; ++k) {
             const double tot = (double)(sp.e[k] - sp.s[k]);
@@ -504,9 +625,10 @@ int run(const DArgs& args)
     // collected and reduced in batches: one gd_regions call for up to kBatch of them instead of several
     // launches, allocations and synchronisations per row.  Output order is the input order.
     constexpr size_t kBatch = 4096;
-    std::vector<const Region*> batch;
+    std::vector<const Region*> batch;               // regions of ONE shard (flushed when the shard changes)
     auto flush_batch = [&]() -> int {
         if (batch.empty()) return GD_OK;
+        gd_ctx* const ctx = ctx_of(batch[0]->tid);
         const size_t nb = batch.size();
         std::vector<int32_t> b_tid(nb);
         std::vector<int64_t> b_start(nb), b_end(nb);
@@ -534,8 +656,11 @@ int run(const DArgs& args)
         batch.clear();
         return GD_OK;
     };
+    gd_ctx* ctx = seq_ctx;                          // the context GDCHK reports on
+#define GDCHK(call) GDCHK_ON(ctx, call)
     for (const Region& r : regions) {
-        if (stats_rc != GD_OK) GDCHK(stats_rc);
+        if (stats_rc != GD_OK) { ctx = seq_ctx; GDCHK(stats_rc); }
+        if (r.tid >= 0) ctx = ctx_of(r.tid);
         if (r.tid < 0) {
             GDCHK(flush_batch());
             // samtools would fail on an unknown reference name: the callback then sees an
@@ -547,10 +672,7 @@ int run(const DArgs& args)
             emit_region(r.chrom.c_str(), r.start, r.end, nullptr, 0, &nr, r.end > r.start ? 1 : 0);
         } else {
             const int64_t clen = contigs[(size_t)r.tid].length;
-            // fused device results are W/step aligned over the BAM contig length; a tile cut
-            // short by a disagreeing .fai length goes through the region reductions instead
-            const bool fused = args.bed.empty() && r.start % step == 0 &&
-                               (r.end == clen || (r.end < clen && r.end % step == 0));
+            const bool fused = is_fused(r);
             if (fused) {
                 GDCHK(flush_batch());
                 if (cached_tid != r.tid) {
@@ -573,6 +695,7 @@ int run(const DArgs& args)
                             cruns.data() + run_cursor, e - run_cursor);
                 run_cursor = e;
             } else if (r.end > r.start) {
+                if (!batch.empty() && shard_of[(size_t)batch[0]->tid] != shard_of[(size_t)r.tid]) GDCHK(flush_batch());
                 batch.push_back(&r);
                 if (batch.size() >= kBatch) GDCHK(flush_batch());
             }
@@ -580,10 +703,10 @@ int run(const DArgs& args)
         if (rows.hd.size() + rows.ca.size() > (8u << 20)) io_ok = flush_rows(&rows, fhd, fca) && io_ok;
     }
     GDCHK(flush_batch());
-    if (stats_rc != GD_OK) GDCHK(stats_rc);
+    if (stats_rc != GD_OK) { ctx = seq_ctx; GDCHK(stats_rc); }
+#undef GDCHK
     io_ok = flush_rows(&rows, fhd, fca) && io_ok;
-    gd_destroy(ctx);
-    ctx = nullptr;
+    closer.done = true;
     if (fclose(fca) != 0) io_ok = false;
     if (fclose(fhd) != 0) io_ok = false;
     if (!io_ok) { fprintf(stderr, "goleft depth: write error\n"); return 1; }
@@ -624,6 +747,22 @@ int gdh_chrom_start_end(const char* line, size_t len, char* chrom, size_t cap, i
 }
 
 int64_t gdh_step(int32_t window_size) { return window_size > 0 ? step_for(window_size) : 0; }
+
+int gdh_lpt_assign(const int32_t* tids, size_t n_tids, const int64_t* lengths, size_t n_contigs, size_t n_shards,
+                   int32_t* shard_of_tid)
+{
+    if ((n_tids && (!tids || !shard_of_tid)) || !lengths || n_shards == 0) return -1;
+    for (size_t i = 0; i < n_tids; ++i)
+        if (tids[i] < 0 || (size_t)tids[i] >= n_contigs) return -1;
+    const std::vector<int32_t> t(tids, tids + n_tids);
+    const std::vector<int64_t> l(lengths, lengths + n_contigs);
+    const auto a = lpt_assign(t, l, n_shards);
+    for (size_t k = 0; k < a.size(); ++k)
+        for (int32_t x : a[k])
+            for (size_t i = 0; i < n_tids; ++i)
+                if (tids[i] == x) shard_of_tid[i] = (int32_t)k;
+    return 0;
+}
 
 int gdh_format_region(const char* chrom, int64_t rs, int64_t re, int32_t W, const int64_t* sums,
                       size_t n_sums, const gd_run* runs, size_t n_runs, const char* depth_path,

@@ -56,9 +56,12 @@ struct IngestPass {
 // has[r] whether r has records at all.  Wanted references that follow each other in the file -- nothing
 // with records between them -- share a pass while it stays under group_bytes; a pass ends with the member
 // in which the next reference with records starts (records may straddle it), or at the end of the file.
+// ref_end (optional): the largest chunk end of every reference's .bai bins (virtual offsets).  The last
+// reference with records then ends one member past it instead of at the end of the file -- the unmapped
+// tail of a WGS BAM (often gigabytes) is neither uploaded nor inflated.
 inline std::vector<IngestPass> plan_ingest_passes(const std::vector<uint64_t>& start, const std::vector<char>& has,
                                                   const std::vector<int32_t>& refs, uint64_t file_size,
-                                                  uint64_t group_bytes)
+                                                  uint64_t group_bytes, const std::vector<uint64_t>* ref_end = nullptr)
 {
     std::vector<IngestPass> out;
     auto next_with_records = [&](size_t r) {
@@ -82,6 +85,8 @@ inline std::vector<IngestPass> plan_ingest_passes(const std::vector<uint64_t>& s
         uint64_t end = ~0ull;
         const size_t after = next_with_records((size_t)refs[j]);
         if (after < has.size()) end = start[after] + 65536 + 26;
+        else if (ref_end && (size_t)refs[j] < ref_end->size() && (*ref_end)[(size_t)refs[j]] != 0)
+            end = ((*ref_end)[(size_t)refs[j]] >> 16) + 2 * (65536 + 26);   // the member holding the last record's end, whole
         if (end > file_size) end = file_size;
         out.push_back(IngestPass{i, j, beg, end});
         i = j + 1;
@@ -101,7 +106,8 @@ inline std::vector<IngestPass> plan_ingest_passes(const std::vector<uint64_t>& s
 // says: the caller falls back to the host decoder) or a gd_* error.
 inline int ingest_references_on_device(gd_ctx* ctx, const FileMap& fm, const std::vector<std::vector<uint64_t>>& lin,
                                        const std::vector<int32_t>& refs, const std::vector<int32_t>& tids,
-                                       uint64_t* n_records, bool* io_ok, uint64_t group_bytes = 512ull << 20)
+                                       uint64_t* n_records, bool* io_ok, uint64_t group_bytes = 512ull << 20,
+                                       const std::vector<uint64_t>* ref_end = nullptr)
 {
     *io_ok = true;
     *n_records = 0;
@@ -109,7 +115,7 @@ inline int ingest_references_on_device(gd_ctx* ctx, const FileMap& fm, const std
     std::vector<char> has(lin.size(), 0);
     for (size_t r = 0; r < lin.size(); ++r)
         if (!lin[r].empty()) { has[r] = 1; start[r] = lin[r].front() >> 16; }
-    const std::vector<IngestPass> passes = plan_ingest_passes(start, has, refs, fm.size, group_bytes);
+    const std::vector<IngestPass> passes = plan_ingest_passes(start, has, refs, fm.size, group_bytes, ref_end);
     // decode + release of the oldest pending pass: references refs[a..b]
     auto decode_pass = [&](size_t a, size_t b) -> int {
         for (size_t k = a; k <= b; ++k) {

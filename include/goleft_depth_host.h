@@ -34,6 +34,14 @@ int gdh_chrom_start_end(const char* line, size_t len, char* chrom, size_t cap,
 /* depth/depth.go:48,:132: tile step for a window size. */
 int64_t gdh_step(int32_t window_size);
 
+/* How `goleft depth` spreads contigs over GOLEFT_DEVICES (one engine context per listed device, a
+ * worker thread each -- the in-process counterpart of the reference's `-p` pool, depth/depth.go:392-394;
+ * rows are still written by the main thread in input order, :394-421): longest-processing-time-first
+ * by contig length, ties to the lower shard, each shard's list ascending.  tids[i] (indices into
+ * lengths[n_contigs]) -> shard_of_tid[i] in [0, n_shards).  Returns 0, -1 on bad arguments. */
+int gdh_lpt_assign(const int32_t* tids, size_t n_tids, const int64_t* lengths, size_t n_contigs, size_t n_shards,
+                   int32_t* shard_of_tid);
+
 /* Rows of one region, formatted exactly like the reference's callback
  * (depth/depth.go:238-364) from integer results:
  *   sums[k]  sum of depth over the W-anchored window first_window+k clipped to

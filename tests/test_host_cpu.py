@@ -336,3 +336,22 @@ def test_headers_are_plain_c(tmp_path):
     subprocess.check_call(["gcc", "-std=c99", "-I", inc, str(src), "-o", str(exe), "-L", libdir, "-lgoleft_depth",
                            "-Wl,-rpath," + libdir])
     assert subprocess.run([str(exe)]).returncode == 0
+
+
+def test_host_lpt_assign_matches_the_bench_sharding(hostlib):
+    """The in-process multi-device host (GOLEFT_DEVICES) and the multi-process bench (goleft_amd/shard.py)
+    assign contigs identically: LPT by length (hg19 over 8 -> max shard 401 853 479)."""
+    from goleft_amd import shard, synth
+    L = list(synth.HG19_LENGTHS)
+    for n in (1, 2, 3, 4, 8, 30):
+        got = hostlib.lpt_assign(list(range(24)), L, n)
+        want = shard.lpt_assign(L, n)
+        for k, tids in enumerate(want):
+            assert all(got[t] == k for t in tids)
+    loads = np.bincount(hostlib.lpt_assign(list(range(24)), L, 8), weights=L, minlength=8)
+    assert int(loads.max()) == 401853479
+    # a subset (--chrom / --bed touching few contigs), ties broken towards the lower shard
+    sub = hostlib.lpt_assign([3, 7, 9], [5, 5, 5, 10, 5, 5, 5, 10, 5, 10], 2)
+    assert list(sub) == [0, 1, 0]
+    with pytest.raises(ValueError):
+        hostlib.lpt_assign([99], L, 2)
