@@ -88,6 +88,8 @@ SYMBOLS = {
     "gd_device_windows": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(C.c_size_t)]),
     "gd_window_offset": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "gd_device_runs": (C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_size_t)]),
+    "gd_set_option": (C.c_int, [_P, C.c_int, C.c_int64]),
+    "gd_canonical_cigars": (C.c_int, [_P, C.c_int32, _P, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
     "gd_set_export": (C.c_int, [_P, _P, C.c_int64, C.c_int64]),
     "gd_get_stats": (C.c_int, [_P, C.POINTER(GdStats)]),
     "gd_set_profiling": (C.c_int, [_P, C.c_int]),

@@ -76,20 +76,6 @@ int gd_create(int device_id, gd_ctx** out)
     if (!c) return GD_E_NOMEM;
     c->device = device_id;
     gd_default_params(&c->params);
-    if (const char* e = getenv("GOLEFT_GD_TILE")) {
-        int t = atoi(e);
-        if (t == 4096 || t == 8192) c->tile_T = t;
-    }
-    if (const char* e = getenv("GOLEFT_GD_KERNEL"))
-        c->kernel_gen = (e[0] == 'v' && e[1] == '6') ? 6 : (e[0] == 'v' && e[1] == '8') ? 8 : 7;
-    if (const char* e = getenv("GOLEFT_GD_OPT")) c->tile_opt = atoi(e) & 1;
-    if (const char* e = getenv("GOLEFT_GD_PATH"))
-        c->path = e[0] == 's' ? GD_PATH_SCATTER : e[0] == 't' ? GD_PATH_TILE : e[0] == 'c' ? GD_PATH_CHUNK : GD_PATH_AUTO;
-    if (const char* e = getenv("GOLEFT_GD_COPY_THREADS")) { const int t = atoi(e); if (t >= 1 && t <= 16) c->ing_copy_threads = t; }
-    if (const char* e = getenv("GOLEFT_GD_THREADS")) {
-        int t = atoi(e);
-        if (t == 256 || t == 512) c->tile_NT = t;
-    }
     auto bail = [&](hipError_t e) {
         (void)e;
         gd_destroy(c);
@@ -135,7 +121,7 @@ void gd_destroy(gd_ctx* c)
     }
     for (auto& ev : c->ev) if (ev) (void)hipEventDestroy(ev);
     if (c->copy_done) (void)hipEventDestroy(c->copy_done);
-    void* frees[] = {c->d_ctgs, c->d_tiles, c->d_perbase, c->d_wsum, c->d_wmin, c->d_chunks,
+    void* frees[] = {c->d_ctgs, c->d_tiles, c->d_ftiles, c->d_perbase, c->d_wsum, c->d_wmin, c->d_chunks,
                      c->d_ordered, c->d_tile_cnt, c->d_tile_off, c->d_super_cnt, c->d_counters,
                      c->d_region_cursor, c->d_status, c->d_ck, c->d_rend, c->d_seq, c->d_md_bits, c->d_wed};
     for (void* p : frees) if (p) (void)hipFree(p);
@@ -324,9 +310,9 @@ int gd_commit(gd_ctx* c, const gd_batch* b, int32_t tid, size_t n_reads, size_t 
         HIPCHK(c, hipMemcpyAsync(h.cigar + h.n_ops, b->cigar, n_ops * sizeof(uint32_t), hipMemcpyHostToDevice, cs));
     HIPCHK(c, hipEventRecord(s.done, cs));
     s.busy = true;
-    if (h.packed) {                                     // the descriptors no longer cover the stream
+    if (h.normed) {                                     // the canonical CIGARs no longer cover the stream
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        drop_pack(h);
+        drop_norm(h);
     }
     h.n_reads += n_reads;
     h.n_ops += n_ops;
@@ -391,9 +377,9 @@ int gd_adopt_device(gd_ctx* c, int32_t tid, const gd_batch* d, size_t n_reads, s
     h.n_reads = n_reads; h.n_ops = n_ops;
     h.adopted = true;
     c->computed = false;
-    // descriptors are part of taking the records in, not of gd_compute
-    if (n_reads && wants_pack(c, n_reads, n_ops))
-        if (int r = pack_contig(c, h)) return r;
+    // canonical CIGARs are part of taking the records in, not of gd_compute
+    if (n_reads && wants_norm(c, n_reads, n_ops))
+        if (int r = norm_contig(c, h)) return r;
     return GD_OK;
 }
 
@@ -469,6 +455,47 @@ int gd_set_export(gd_ctx* c, void* device_buf, int64_t max_windows, int64_t cap_
     return GD_OK;
 }
 
+int gd_set_option(gd_ctx* c, int option, int64_t value)
+{
+    if (!c) return GD_E_INVALID;
+    switch (option) {
+    case GD_OPT_TILE_POSITIONS:
+        if (value != 4096 && value != 8192) return fail(c, GD_E_INVALID, "tile positions: 4096 or 8192");
+        c->tile_T = (int)value;
+        break;
+    case GD_OPT_TILE_THREADS:
+        if (value != 256 && value != 512) return fail(c, GD_E_INVALID, "tile threads: 256 or 512");
+        c->tile_NT = (int)value;
+        break;
+    case GD_OPT_NT_STORES: c->tile_opt = value ? 1 : 0; break;
+    case GD_OPT_NORMALIZE: c->normalize = value != 0; break;
+    case GD_OPT_FAST_KERNEL: c->fast_kernel = value != 0; break;
+    case GD_OPT_COPY_THREADS:
+        if (value < 1 || value > 16) return fail(c, GD_E_INVALID, "copy threads: 1..16");
+        c->ing_copy_threads = (int)value;
+        break;
+    case 99: c->dbg = (uint32_t)value; break;
+    default: return fail(c, GD_E_INVALID, "unknown option %d", option);
+    }
+    c->computed = false;
+    return GD_OK;
+}
+
+int gd_canonical_cigars(gd_ctx* c, int32_t tid, uint32_t* cigar_off, uint32_t* cigar, size_t cap_ops, size_t* n_ops)
+{
+    if (!c || !n_ops) return GD_E_INVALID;
+    if (int r = set_device(c)) return r;
+    if (tid < 0 || (size_t)tid >= c->contigs.size()) return fail(c, GD_E_RANGE, "tid %d out of range", tid);
+    const ContigHost& h = c->contigs[tid];
+    if (!h.normed) return fail(c, GD_E_STATE, "contig %d has no canonical CIGARs (GD_OPT_NORMALIZE off, long-read data, or records committed since)", tid);
+    *n_ops = h.n_nops;
+    if (h.n_nops > cap_ops) return GD_E_CAPACITY;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (cigar_off) HIPCHK(c, hipMemcpy(cigar_off, h.noff, (h.n_reads + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (cigar && h.n_nops) HIPCHK(c, hipMemcpy(cigar, h.ncig, h.n_nops * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return GD_OK;
+}
+
 int gd_get_stats(gd_ctx* c, gd_stats* out)
 {
     if (!c || !out) return GD_E_INVALID;
@@ -480,7 +507,7 @@ int gd_set_profiling(gd_ctx* c, int on)
 {
     if (!c) return GD_E_INVALID;
     c->profiling = on != 0;
-    c->kernel_ms[GD_K_PACK] = 0;                        // accumulates over the contigs packed from now on
+    c->kernel_ms[GD_K_NORM] = 0;                        // accumulates over the contigs normalised from now on
     return GD_OK;
 }
 

@@ -1,6 +1,6 @@
 // gd_api_state.hpp -- what a gd_ctx holds and the helpers every part of the C ABI shares: per-contig
 // record streams, the pinned staging ring, the device job state, launch helpers of the tile kernels,
-// the descriptor packing (gd_tile_v8.hpp) and the state of a device BAM read.  Included by gd_api.hip
+// the CIGAR normalisation (gd_normalize.hpp) and the state of a device BAM read.  Included by gd_api.hip
 // only (one translation unit: the kernels of gd_kernels.hpp are not inline).
 #pragma once
 
@@ -24,12 +24,14 @@ struct ContigHost {
     size_t cap_reads = 0, cap_ops = 0;
     bool adopted = false;
     int32_t last_pos = -0x7fffffff;
-    // packed descriptors of the records (gd_tile_v8.hpp), always owned
-    uint2* desc = nullptr;
-    uint32_t* cxb = nullptr;
-    uint32_t* cxc = nullptr;
-    bool packed = false;               // desc/cxb/cxc describe the current records
-    bool packable = false;             // ... and the v8 kernels may use them
+    // canonical CIGARs of the records (gd_normalize.hpp), always owned
+    uint32_t* noff = nullptr;          // n_reads + 1 CSR offsets into ncig
+    uint32_t* ncig = nullptr;          // canonical ops (capacity n_ops)
+    uint32_t* nunit = nullptr;         // per 64-read unit: offset of its canonical ops; [n_units] = total, [n_units + 1] = status
+    uint32_t* nrec = nullptr;          // record words (flag | MAPQ | op count), n_reads + 4 (the kernel loads 16 bytes per lane)
+    bool rec_ok = false;               // every record fits its word: the straight-line kernel may run
+    size_t n_nops = 0;                 // canonical ops
+    bool normed = false;               // noff/ncig describe the current records
     // layout in the result arrays of the last compute (-1 = not computed)
     int64_t base_off = -1;
     int64_t win_off = -1;
@@ -86,13 +88,15 @@ struct gd_ctx {
     int ring_next = 0;
     std::string err;
 
+    // tuning knobs (gd_set_option; defaults are what the measurements of DESIGN.md section 4 chose)
     int tile_T = 4096;
     int tile_NT = 256;
-    int kernel_gen = 7;                 // GOLEFT_GD_KERNEL=v8: packed read descriptors (gd_tile_v8.hpp, measured
-                                        // equal to v7: DESIGN.md section 4); v6: the previous tile kernel
-    bool use_v8 = false;                // this gd_compute: every contig of the job is packed
+    bool fast_kernel = true;            // GD_OPT_FAST_KERNEL: the straight-line tile kernel (gd_tile_fast.hpp) for
+                                        // ordinary tiles, the generic one for the rest; 0 = generic for every tile
+    uint32_t dbg = 0;
+    bool normalize = true;              // GD_OPT_NORMALIZE: canonical CIGARs at arrival (gd_normalize.hpp)
     int tile_opt = 1;                   // bit 0: non-temporal per-base stores (2 % faster: the vector is
-                                        // never re-read by the kernel); GOLEFT_GD_OPT=0 for plain stores
+                                        // never re-read by the kernel)
     bool lookback_pinned = false;       // max_span_hint given: never shrink below it
     int path = GD_PATH_AUTO;            // gd_set_path / GOLEFT_GD_PATH
     bool keep_perbase = true;           // gd_set_outputs(GD_OUT_PERBASE)
@@ -109,6 +113,7 @@ struct gd_ctx {
     std::vector<gd::ContigDev> h_ctgs;
     std::vector<int32_t> job_tids;      // contig table index -> tid
     gd::TileInfo* d_tiles = nullptr;  size_t cap_tiles = 0;
+    gd::TileFast* d_ftiles = nullptr; size_t cap_ftiles = 0;
     int32_t* d_perbase = nullptr;     size_t cap_perbase = 0;
     int64_t* d_wsum = nullptr;        size_t cap_win = 0;
     int32_t* d_wmin = nullptr;
@@ -202,18 +207,21 @@ int ensure_dev(gd_ctx* c, Tp** p, size_t* cap, size_t need, bool keep = false, s
     return GD_OK;
 }
 
-void drop_pack(ContigHost& h)
+void drop_norm(ContigHost& h)
 {
-    if (h.desc) (void)hipFree(h.desc);
-    if (h.cxb) (void)hipFree(h.cxb);
-    if (h.cxc) (void)hipFree(h.cxc);
-    h.desc = nullptr; h.cxb = nullptr; h.cxc = nullptr;
-    h.packed = h.packable = false;
+    if (h.noff) (void)hipFree(h.noff);
+    if (h.ncig) (void)hipFree(h.ncig);
+    if (h.nunit) (void)hipFree(h.nunit);
+    if (h.nrec) (void)hipFree(h.nrec);
+    h.noff = nullptr; h.ncig = nullptr; h.nunit = nullptr; h.nrec = nullptr;
+    h.rec_ok = false;
+    h.n_nops = 0;
+    h.normed = false;
 }
 
 void free_contig(ContigHost& h)
 {
-    drop_pack(h);
+    drop_norm(h);
     if (!h.adopted) {
         if (h.pos) (void)hipFree(h.pos);
         if (h.flag) (void)hipFree(h.flag);
@@ -272,26 +280,25 @@ void launch_tile(gd_ctx* c, const gd::Job& job)
     // 8 XCDs: the grid is 8 equal slices of the tile list (see the kernel)
     const unsigned grid = (unsigned)(((job.n_tiles + 7) / 8) * 8);
     if (c->ran_sums_only) {                                 // decided by gd_compute for this run
-        if (c->use_v8) hipLaunchKernelGGL((gd::v8::gd_tile_sums_kernel<4096, 256>), dim3(grid), dim3(256), 0, c->stream, job);
-        else           hipLaunchKernelGGL((gd::v7::gd_tile_sums_kernel<4096, 256>), dim3(grid), dim3(256), 0, c->stream, job);
+        hipLaunchKernelGGL((gd::gd_tile_sums_kernel<4096, 256>), dim3(grid), dim3(256), 0, c->stream, job);
         return;
     }
-    if (c->use_v8 && T == 4096 && NT == 256) {              // packed descriptors (default shape only)
+    if (job.fast) {
+        // ordinary tiles: the straight-line kernel; the tiles gd_prep_kernel listed as `slow` (clipped at a
+        // contig end, deeper than one batch of reads, more ops than the staging area): the generic one
         if (!c->keep_perbase)
-            hipLaunchKernelGGL((gd::v8::gd_tile_kernel<4096, 256, 2>), dim3(grid), dim3(256), 0, c->stream, job);
+            hipLaunchKernelGGL((gd::fast::gd_tile_fast_kernel<2>), dim3(grid), dim3(256), 0, c->stream, job);
         else if (c->tile_opt & 1)
-            hipLaunchKernelGGL((gd::v8::gd_tile_kernel<4096, 256, 1>), dim3(grid), dim3(256), 0, c->stream, job);
+            hipLaunchKernelGGL((gd::fast::gd_tile_fast_kernel<1>), dim3(grid), dim3(256), 0, c->stream, job);
         else
-            hipLaunchKernelGGL((gd::v8::gd_tile_kernel<4096, 256, 0>), dim3(grid), dim3(256), 0, c->stream, job);
-        return;
-    }
-    if (c->kernel_gen >= 7 && T == 4096 && NT == 256) {     // v7 is built for the default shape only
+            hipLaunchKernelGGL((gd::fast::gd_tile_fast_kernel<0>), dim3(grid), dim3(256), 0, c->stream, job);
+        const unsigned sgrid = 2048;
         if (!c->keep_perbase)
-            hipLaunchKernelGGL((gd::v7::gd_tile_kernel<4096, 256, 2>), dim3(grid), dim3(256), 0, c->stream, job);
+            hipLaunchKernelGGL((gd::gd_tile_slow_kernel<4096, 256, 2>), dim3(sgrid), dim3(256), 0, c->stream, job);
         else if (c->tile_opt & 1)
-            hipLaunchKernelGGL((gd::v7::gd_tile_kernel<4096, 256, 1>), dim3(grid), dim3(256), 0, c->stream, job);
+            hipLaunchKernelGGL((gd::gd_tile_slow_kernel<4096, 256, 1>), dim3(sgrid), dim3(256), 0, c->stream, job);
         else
-            hipLaunchKernelGGL((gd::v7::gd_tile_kernel<4096, 256, 0>), dim3(grid), dim3(256), 0, c->stream, job);
+            hipLaunchKernelGGL((gd::gd_tile_slow_kernel<4096, 256, 0>), dim3(sgrid), dim3(256), 0, c->stream, job);
         return;
     }
     if (!c->keep_perbase)
@@ -306,65 +313,58 @@ template <int T, int NT>
 void launch_ltile(gd_ctx* c, const gd::Job& job)
 {
     const unsigned grid = (unsigned)(((job.n_tiles + 7) / 8) * 8);
-    if (c->kernel_gen == 6) {                              // GOLEFT_GD_KERNEL=v6: the first long-read kernel
-        if (!c->keep_perbase)
-            hipLaunchKernelGGL((gd::gd_ltile_kernel<T, NT, 2>), dim3(grid), dim3(NT), 0, c->stream, job);
-        else
-            hipLaunchKernelGGL((gd::gd_ltile_kernel<T, NT, 0>), dim3(grid), dim3(NT), 0, c->stream, job);
-        return;
-    }
     if (!c->keep_perbase)
         hipLaunchKernelGGL((gd::gd_ltile2_kernel<T, NT, 2>), dim3(grid), dim3(NT), 0, c->stream, job);
     else
         hipLaunchKernelGGL((gd::gd_ltile2_kernel<T, NT, 0>), dim3(grid), dim3(NT), 0, c->stream, job);
 }
 
-// Builds the packed descriptors of one contig's records (gd_tile_v8.hpp) on the compute stream.
-// Afterwards h.packed is set; h.packable says whether the v8 kernels may use them.
-int pack_contig(gd_ctx* c, ContigHost& h)
+// Builds the canonical CIGARs of one contig's records (gd_normalize.hpp) on the compute stream.
+// Afterwards h.normed is set.
+int norm_contig(gd_ctx* c, ContigHost& h)
 {
-    drop_pack(h);
-    h.packed = true;
-    if (h.n_reads >= (1ull << 29)) return GD_OK;           // descriptor byte offsets stay in 32 bits
+    drop_norm(h);
     const uint32_t n_reads = (uint32_t)h.n_reads, n_units = (n_reads + 63u) / 64u;
     // records staged on the copy stream must have landed
     HIPCHK(c, hipEventRecord(c->copy_done, c->copy_stream));
     HIPCHK(c, hipStreamWaitEvent(c->stream, c->copy_done, 0));
-    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&h.desc), std::max<size_t>(n_reads, 1) * sizeof(uint2)));
-    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&h.cxb), ((size_t)n_units + 2) * sizeof(uint32_t)));   // + total, status
-    HIPCHK(c, hipMemsetAsync(h.cxb, 0, ((size_t)n_units + 2) * sizeof(uint32_t), c->stream));
-    gd::v8::PackJob j{};
-    j.pos = h.pos; j.flag = h.flag; j.mapq = h.mapq; j.off = h.off; j.cigar = h.cigar;
-    j.n_reads = n_reads; j.n_units = n_units; j.desc = h.desc; j.cx_base = h.cxb; j.status = h.cxb + n_units + 1;
-    uint32_t tail[2] = {0, 0};                              // grand total of compact ops, status bits
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&h.noff), ((size_t)n_reads + 1) * sizeof(uint32_t)));
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&h.ncig), std::max<size_t>(h.n_ops, 1) * sizeof(uint32_t)));
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&h.nunit), ((size_t)n_units + 2) * sizeof(uint32_t)));
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&h.nrec), ((size_t)n_reads + 4) * sizeof(uint32_t)));
+    HIPCHK(c, hipMemsetAsync(h.noff + n_reads, 0, sizeof(uint32_t), c->stream));         // n_reads == 0: noff[0] = 0
+    HIPCHK(c, hipMemsetAsync(h.nunit + n_units, 0, 2 * sizeof(uint32_t), c->stream));
+    HIPCHK(c, hipMemsetAsync(h.nrec + n_reads, 0, 4 * sizeof(uint32_t), c->stream));
+    gd::norm::NormJob j{};
+    j.off = h.off; j.cigar = h.cigar; j.n_reads = n_reads; j.n_units = n_units;
+    j.noff = h.noff; j.unit = h.nunit; j.ncig = h.ncig;
+    j.flag = h.flag; j.mapq = h.mapq; j.rec = h.nrec; j.status = h.nunit + n_units + 1;
+    uint32_t total[2] = {0, 0};                              // canonical ops, status bits
     if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
     if (n_units) {
-        hipLaunchKernelGGL(gd::v8::gd_pack_desc_kernel, dim3((n_units + 3u) / 4u), dim3(256), 0, c->stream, j);
-        hipLaunchKernelGGL(gd::v8::gd_pack_scan_kernel, dim3(1), dim3(1024), 0, c->stream, h.cxb, n_units);
-        HIPCHK(c, hipMemcpyAsync(tail, h.cxb + n_units, sizeof tail, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-    }
-    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&h.cxc), ((size_t)tail[0] + 4) * sizeof(uint32_t)));
-    if (tail[0]) {
-        j.cx_cigar = h.cxc;
-        hipLaunchKernelGGL(gd::v8::gd_pack_ops_kernel, dim3((n_units + 3u) / 4u), dim3(256), 0, c->stream, j);
+        hipLaunchKernelGGL(gd::norm::gd_norm_count_kernel, dim3((n_units + 3u) / 4u), dim3(256), 0, c->stream, j);
+        hipLaunchKernelGGL(gd::norm::gd_unit_scan_kernel, dim3(1), dim3(1024), 0, c->stream, h.nunit, n_units);
+        hipLaunchKernelGGL(gd::norm::gd_norm_write_kernel, dim3((n_units + 3u) / 4u), dim3(256), 0, c->stream, j);
+        HIPCHK(c, hipMemcpyAsync(total, h.nunit + n_units, sizeof total, hipMemcpyDeviceToHost, c->stream));
     }
     HIPCHK(c, hipGetLastError());
+    if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->profiling) {
         float ms = 0;
-        HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
-        HIPCHK(c, hipEventSynchronize(c->ev[1]));
         HIPCHK(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
-        c->kernel_ms[GD_K_PACK] += ms;
+        c->kernel_ms[GD_K_NORM] += ms;
     }
-    h.packable = tail[1] == 0;
+    h.n_nops = total[0];
+    h.rec_ok = total[1] == 0;
+    h.normed = true;
     return GD_OK;
 }
 
-// The v8 kernels exist for the default tile shape; long-read data goes to the chunk path anyway.
-bool wants_pack(const gd_ctx* c, uint64_t n_reads, uint64_t n_ops)
+// Canonical CIGARs serve the tile path; long-read data goes to the chunk path (original ops).
+bool wants_norm(const gd_ctx* c, uint64_t n_reads, uint64_t n_ops)
 {
-    if (c->kernel_gen != 8 || c->tile_T != 4096 || c->tile_NT != 256) return false;
+    if (!c->normalize) return false;
     if (c->path == GD_PATH_TILE) return true;
     return c->path == GD_PATH_AUTO && !c->span_forces_long && n_ops <= 6 * n_reads;
 }

@@ -14,15 +14,12 @@
 //       4 bytes per 64 ops), the read's end position, and the largest span.
 //       Checkpoint slots need no prefix sum: read r with CSR offset o uses slots
 //       (o >> 6) + r ... which never overlap (ceil(n/64) <= (n >> 6) + 1).
-//   LT  gd_ltile_kernel  per tile: the candidate reads (start within one maximum
-//       span before the tile; 8 bytes each: start, end) are tested lane-parallel;
-//       for each overlapping read the wave loads its checkpoints (one coalesced
-//       load for up to 4096 ops), picks the chunks that reach the tile and
-//       expands only those: 64 ops per wave round, coalesced, a saturating DPP
-//       scan of the reference-consuming lengths seeded with the checkpoint, and
-//       one LDS +1/-1 pair per run of counted ops (M/=/X; `samtools depth`
-//       semantics, /root/reference/depth/depth.go:45).  Then the tile kernel's
-//       phase B/C (depth/depth.go:293-323).
+//   LT2 gd_ltile2_kernel per tile: the candidate reads (start within one maximum
+//       span before the tile; 8 bytes each: start, end) are tested lane-parallel
+//       and contribute one +1/-1 pair; the 64-op chunks that reach the tile are
+//       expanded for their D/N ops only (`samtools depth` semantics,
+//       /root/reference/depth/depth.go:45; details at the kernel).  Then the tile
+//       kernel's phase B/C (depth/depth.go:293-323).
 #pragma once
 
 namespace gd {
@@ -146,213 +143,12 @@ __global__ __launch_bounds__(256) void gd_ckpt_kernel(Job job)
     if (lane == 0 && smax > (uint32_t)seen0) atomicMax(&job.counters->max_span, (int32_t)smax);
 }
 
-// +-1 at absolute position `abs` (<= POS_CAP) of the tile [t0, t0+tlen); marks
-// before the tile collapse onto LDS index -1 (the depth at t0-1), marks at or
-// past the tile end are dropped.
-__device__ __forceinline__ void lmark(int32_t* s_diff, uint32_t abs, int t0, int tlen, int v)
-{
-    const int rel = (int)abs - t0;
-    if (rel < tlen) atomicAdd(&s_diff[rel > -1 ? rel : -1], v);
-}
-
-// One chunk of <= 64 ops (lane k holds op k; 0 = nothing) whose first op starts
-// at reference position `start`: every maximal run of counted ops not interrupted
-// by a reference-consuming uncounted op (D/N) is one interval.  A run cut by the
-// chunk end is closed there; its continuation re-opens at the same position and
-// the two marks cancel.
-__device__ __forceinline__ void expand_chunk_lds(uint32_t cg, uint32_t start, int t0, int tlen,
-                                                 int32_t* s_diff, unsigned long long below,
-                                                 unsigned long long above)
-{
-    const uint32_t op = cg & 0xf, len = cg >> 4;
-    const bool counted = ((0x181u >> op) & 1u) && len != 0;
-    const bool consumes = ((0x18du >> op) & 1u) && len != 0;
-    const uint32_t cons = consumes ? len : 0u;
-    const uint32_t incl = wave_inclusive_scan_sat(cons);
-    const uint32_t s = sat_pos(start + (incl - cons));
-    const unsigned long long cm = __ballot(counted);
-    const unsigned long long nn = cm | __ballot(consumes);
-    if (counted) {
-        const unsigned long long pm = nn & below;
-        const bool prev_counted = pm != 0ull && ((cm >> (63 - __builtin_clzll(pm))) & 1ull);
-        const unsigned long long nm = nn & above;
-        const bool next_counted = nm != 0ull && ((cm >> (__builtin_ffsll((long long)nm) - 1)) & 1ull);
-        if (!prev_counted) lmark(s_diff, s, t0, tlen, 1);
-        if (!next_counted) lmark(s_diff, sat_pos(s + len), t0, tlen, -1);
-    }
-}
-
-// LT: one workgroup per tile.  OPT as in gd_tile_kernel (per-base stores 0 plain,
-// 1 non-temporal, 2 none).
-template <int T, int NT, int OPT>
-__global__ __launch_bounds__(NT) void gd_ltile_kernel(Job job)
-{
-    constexpr int NW = NT / WAVE;
-    constexpr int CHUNK = T / NW;
-    constexpr int ROWS = CHUNK / 256;
-    constexpr int NWORDS = T / 32;
-    constexpr int U = 4;                   // candidate reads per lane in flight
-    static_assert(CHUNK % 256 == 0, "wave chunk must be whole rows");
-
-    __shared__ __attribute__((aligned(16))) int32_t s_diffp[T + 4];  // [3] = index -1
-    __shared__ uint32_t s_bmap[NWORDS];
-    __shared__ uint32_t s_clo[NWORDS];
-    __shared__ uint32_t s_chi[NWORDS];
-    __shared__ int32_t  s_wtot[NW];
-    __shared__ uint32_t s_wcnt[NW];
-    __shared__ uint32_t s_hasb;
-    __shared__ uint32_t s_base;
-    int32_t* const s_diff = s_diffp + 4;
-
-    const int per = (job.n_tiles + 7) >> 3;                // XCD-contiguous tile order
-    const int tile = (int)(blockIdx.x & 7u) * per + (int)(blockIdx.x >> 3);
-    if (tile >= job.n_tiles) return;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & (WAVE - 1);
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const TileInfo ti = job.tiles[tile];
-    const ContigDev& c = job.ctgs[ti.ctg];
-    const uint32_t* const ck = job.ck + c.ck_off;
-    const int32_t t0 = ti.t0;
-    const int32_t tend = t0 + T < ti.length ? t0 + T : ti.length;
-    const int tlen = tend - t0;
-
-    const uint32_t nrd = ti.hi - ti.lo;
-    const int32_t* const gpos = ti.pos + ti.lo;
-    const int32_t* const gend = job.rend + c.read_off + ti.lo;
-    const uint32_t* const goff = ti.off + ti.lo;
-    const uint32_t* const cigar = ti.cigar;
-
-    {
-        const int4 z = make_int4(0, 0, 0, 0);
-        int4* d4 = reinterpret_cast<int4*>(s_diffp);
-#pragma unroll
-        for (int i = tid; i < T / 4 + 1; i += NT) d4[i] = z;
-        for (int i = tid; i < NWORDS; i += NT) { s_bmap[i] = 0; s_clo[i] = 0; s_chi[i] = 0; }
-        if (tid == 0) s_hasb = 0;
-    }
-    __syncthreads();
-
-    // ---- phase A: candidate reads -> overlapping chunks -> LDS +1/-1 --------
-    const unsigned long long below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
-    const unsigned long long above = lane == 63 ? 0ull : (~0ull << (lane + 1));
-    for (uint32_t base = 0; base < nrd; base += (uint32_t)(NT * U)) {
-        // candidate i of a batch belongs to wave i % NW: the overlapping reads (mostly
-        // the latest starters) spread evenly over the waves
-        uint32_t idx[U], o0[U], n[U];
-        int32_t e[U];
-        bool hit[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            idx[u] = base + (uint32_t)((u * WAVE + lane) * NW + wv);
-            const bool inb = idx[u] < nrd;
-            const int32_t p = inb ? gpos[idx[u]] : 0x7fffffff;
-            e[u] = inb ? gend[idx[u]] : -1;
-            hit[u] = e[u] >= t0 && p < tend;              // reaches t0-1 or beyond
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            o0[u] = 0; n[u] = 0;
-            if (hit[u]) { o0[u] = goff[idx[u]]; n[u] = goff[idx[u] + 1] - o0[u]; }
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            unsigned long long m = __ballot(hit[u]);
-            while (m != 0ull) {
-                const int j = __ffsll((long long)m) - 1;
-                m &= m - 1ull;
-                const uint32_t oj = (uint32_t)__builtin_amdgcn_readlane((int)o0[u], j);
-                const uint32_t nj = (uint32_t)__builtin_amdgcn_readlane((int)n[u], j);
-                const uint32_t ej = (uint32_t)__builtin_amdgcn_readlane(e[u], j);
-                const uint32_t rj = ti.lo + (uint32_t)__builtin_amdgcn_readlane((int)idx[u], j);
-                const uint32_t nch = (nj + CK_OPS - 1u) >> 6;
-                const uint32_t* const ckj = ck + ((oj >> 6) + rj);
-                uint32_t cb = 0;
-                if (nch > 64u) {
-                    // more than 4096 ops: a strided probe of the (monotone) checkpoints
-                    // finds the block of 64 chunks where the tile begins
-                    const uint32_t stride = (nch + 63u) >> 6;
-                    const uint32_t q = (uint32_t)lane * stride;
-                    const uint32_t v = q < nch ? ckj[q] : POS_CAP;
-                    // chunks before the last probe that starts before t0 end before t0
-                    const int cnt = __popcll(__ballot(q < nch && (int)v < t0));
-                    cb = cnt > 1 ? (uint32_t)(cnt - 1) * stride : 0u;
-                }
-                for (; cb < nch; cb += 64u) {
-                    const uint32_t q = cb + (uint32_t)lane;
-                    const uint32_t c0 = q < nch ? ckj[q] : POS_CAP;
-                    const uint32_t c1 = q + 1u < nch ? ckj[q + 1u] : ej;
-                    unsigned long long cm = __ballot(q < nch && (int)c0 < tend && (int)c1 >= t0);
-                    uint32_t nxt = 0;
-                    if (cm != 0ull) {
-                        const uint32_t k = cb + (uint32_t)(__ffsll((long long)cm) - 1);
-                        const uint32_t a = k * CK_OPS + (uint32_t)lane;
-                        nxt = a < nj ? cigar[oj + a] : 0u;
-                    }
-                    while (cm != 0ull) {
-                        const int kk = __ffsll((long long)cm) - 1;
-                        cm &= cm - 1ull;
-                        const uint32_t cg = nxt;
-                        if (cm != 0ull) {                  // next chunk's ops are in flight while this one expands
-                            const uint32_t k2 = cb + (uint32_t)(__ffsll((long long)cm) - 1);
-                            const uint32_t a2 = k2 * CK_OPS + (uint32_t)lane;
-                            nxt = a2 < nj ? cigar[oj + a2] : 0u;
-                        }
-                        const uint32_t start = (uint32_t)__builtin_amdgcn_readlane((int)c0, kk);
-                        expand_chunk_lds(cg, start, t0, tlen, s_diff, below, above);
-                    }
-                    // checkpoints only grow: nothing past a chunk that starts at or after the tile end
-                    if ((int)(uint32_t)__builtin_amdgcn_readlane((int)c0, 63) >= tend) break;
-                }
-            }
-        }
-    }
-    __syncthreads();
-
-    // ---- phase B pass 1: wave chunk totals -------------------------------
-    const int chunk0 = wv * CHUNK;
-    {
-        int tot = 0;
-#pragma unroll
-        for (int r = 0; r < ROWS; ++r) {
-            const int4 v = *reinterpret_cast<const int4*>(&s_diff[chunk0 + r * 256 + lane * 4]);
-            tot += v.x + v.y + v.z + v.w;
-        }
-        tot = wave_total(tot);
-        if (lane == 0) s_wtot[wv] = tot;
-    }
-    __syncthreads();
-
-    // ---- phase B pass 2: scan, store, window reduce, class boundaries ----
-    {
-        PhaseB B;
-        B.s_diff = s_diff; B.s_bmap = s_bmap; B.s_clo = s_clo; B.s_chi = s_chi; B.s_hasb = &s_hasb;
-        B.out = job.perbase + ti.base_off + t0;
-        B.wsum = job.win_sum + ti.win_off;
-        B.wmin = job.win_min + ti.win_off;
-        B.t0 = t0; B.tlen = tlen; B.chunk0 = chunk0; B.lane = lane;
-        B.W = job.W; B.mincov = job.mincov; B.maxmean = job.maxmean; B.step = job.step;
-        int carry = s_diff[-1];                            // depth at t0-1
-#pragma unroll
-        for (int v = 0; v < NW - 1; ++v) carry += v < wv ? s_wtot[v] : 0;
-        B.carry = carry;
-        // a read covers a position at most once: depth <= candidate reads
-        const bool wide = nrd >= (1u << 22);
-        if (tlen == T && !wide) phase_b_rows<ROWS, true, false, OPT>(B);
-        else                    phase_b_rows<ROWS, false, true, OPT>(B);
-    }
-    __syncthreads();
-
-    phase_c<T, NT>(job, tile, t0, ti.ctg, tid, lane, wv, s_bmap, s_clo, s_chi, s_wcnt, &s_hasb, &s_base);
-}
-
 // ---------------------------------------------------------------------------
-// LT2: the long-read tile kernel, generation 2.
+// LT2: the long-read tile kernel.
 //
-// gd_ltile_kernel (above) walks one overlapping read at a time per wave and
-// spends ~120 wave-instructions per 64 CIGAR ops; at ONT shape (4.8e9 ops,
-// every chunk expanded ~1.2 times) it is instruction-issue bound.  Here:
+// Its predecessor walked one overlapping read at a time per wave, marking M runs, and
+// spent ~120 wave-instructions per 64 CIGAR ops; at ONT shape (4.8e9 ops,
+// every chunk expanded ~1.2 times) that was instruction-issue bound.  Here:
 //   * depth of a read = [pos <= x < end] - [x inside one of its D/N ops]
 //     (every reference-consuming op is either counted, M/=/X, or a D/N): the
 //     read contributes ONE +1/-1 pair per tile (lane-parallel, from the start /
@@ -372,7 +168,7 @@ __global__ __launch_bounds__(NT) void gd_ltile_kernel(Job job)
 // Reference positions use plain 32-bit scans whenever every op of the four
 // items consumes <= 2^24 bases (64 * 2^24 + 2^31 < 2^32: no wrap); items with
 // a longer D/N op take a saturating scan.  Integer adds commute, so the
-// per-base result equals the M-run marking of gd_ltile_kernel bit for bit.
+// per-base result equals M-run marking bit for bit.
 // ---------------------------------------------------------------------------
 constexpr int LQ_CAP = 128;                   // queue items per wave: one round of 4 slots pushes <= 4 * 32
 constexpr uint32_t LQ_OPS = 2 * CK_OPS;       // ops per item
@@ -659,7 +455,7 @@ __global__ __launch_bounds__(NT) void gd_ltile2_kernel(Job job)
         // a read covers a position at most once: depth <= candidate reads
         const bool wide = nrd >= (1u << 22);
         if (tlen == T && !wide) {
-            if constexpr (ROWS == 4) v7::phase_b_rows<ROWS, OPT>(B, job.w_magic, job.w_shift, job.s_magic, job.s_shift);
+            if constexpr (ROWS == 4) phase_b_rows_full<ROWS, OPT>(B, job.w_magic, job.w_shift, job.s_magic, job.s_shift);
             else                     phase_b_rows<ROWS, true, false, OPT>(B);
         } else {
             phase_b_rows<ROWS, false, true, OPT>(B);

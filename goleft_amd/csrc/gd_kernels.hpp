@@ -56,9 +56,7 @@ struct ContigDev {
     uint32_t unit_beg;        // first 64-read unit of this contig (scatter / chunk paths)
     int64_t  ck_off;          // chunk path: element offset of this contig's checkpoints in Job::ck
     int64_t  read_off;        // chunk path: element offset of this contig's reads in Job::rend
-    const uint2*    desc;     // packed read descriptors (gd_tile_v8.hpp), null when not packed
-    const uint32_t* cx_base;  // per 64-read unit: offset of its complex reads' ops in cx_cigar
-    const uint32_t* cx_cigar;
+    const uint32_t* rec;      // record words (gd_normalize.hpp) of the canonical records, null otherwise
 };
 
 // Everything a workgroup needs for its tile in ONE record (one scalar load
@@ -78,10 +76,34 @@ struct __attribute__((aligned(16))) TileInfo {
     uint32_t n_reads;         // records of the contig (bounds for the vector loads)
     uint32_t n_ops;           // CIGAR ops of the contig
     uint32_t clo, chi;        // CIGAR op range [off[lo], off[hi]) of those reads
-    const uint2*    desc;     // packed descriptors of the contig (v8 kernels)
-    const uint32_t* cxb;
-    const uint32_t* cxc;
+    int32_t  tile;            // global tile id (the slow list of a fast run is compacted)
+    int32_t  pad_[3];
 };
+
+// The same for gd_tile_fast_kernel: one record per ORDINARY tile (full, at most one batch of reads, ops
+// fit the staging area), everything resolved -- pointers at the tile's first read / op, window and
+// run-break state of each wave's quarter -- so the kernel derives nothing on the scalar unit.
+// nrd == 0xffffffff: the tile is on the slow list (job.tiles[0 .. n_slow)) instead.
+struct __attribute__((aligned(16))) TileFast {
+    const int32_t*  pos;      // at read lo
+    const uint32_t* rec;      // record words (flag | MAPQ | op count), at read lo
+    const uint32_t* cig;      // canonical ops, at op clo
+    const void*     pad0_[2];
+    int32_t*  out;            // per-base output at t0 (null: windows-only)
+    int64_t*  wsum;           // the contig's window sums
+    int32_t*  wmin;
+    int32_t   t0;
+    uint32_t  nrd;            // reads [lo, hi) that can touch the tile
+    uint32_t  nst;            // their ops [clo, chi)
+    uint32_t  clo;
+    int32_t   ctg;
+    int32_t   pad_[3];
+    uint32_t  win0[4];        // per wave quarter (1024 positions): window of its first position,
+    int32_t   wleft[4];       //   positions from there to the next window boundary (1..W; BIG: never),
+    int32_t   sleft[4];       //   positions to the next forced run break (0: at the first position; BIG: never)
+};
+constexpr int FAST_BIG = 0x3fffffff;
+constexpr int FAST_FAR = FAST_BIG - 65536;
 
 // Device-side counters, read back once per gd_compute.
 struct Counters {
@@ -89,6 +111,8 @@ struct Counters {
     uint32_t run_cursor;      // boundary entries allocated (may exceed capacity)
     uint32_t pad0;            // scatter path: tile ticket of gd_scan_kernel
     uint32_t pad1;            // scatter path: 1 if a look-back ever timed out
+    uint32_t n_slow;          // fast run: tiles gd_prep_kernel put on the slow list (zeroed before the launch)
+    uint32_t pad2[3];
 };
 
 struct Job {
@@ -121,6 +145,9 @@ struct Job {
     int32_t   lookback_dev;   // chunk path: look-back = counters->max_span (written by gd_ckpt_kernel)
     uint32_t  w_magic, w_shift;   // floor(x / W)    = (x * w_magic) >> w_shift for x < 2^31
     uint32_t  s_magic, s_shift;   // floor(x / step) likewise (step clamped to 2^31-1)
+    uint32_t  fast;               // 1: ordinary tiles get a TileFast record, the rest go to the slow list
+    TileFast* ftiles;             // n_tiles records (fast run)
+    uint32_t  dbg;                // experiments only (GD_OPT 99)
 };
 
 __device__ __forceinline__ int cov_class(int d, int mincov, int maxmean)
@@ -212,15 +239,45 @@ __global__ void gd_prep_kernel(Job job)
     ti.pos = c.pos; ti.flag = c.flag; ti.mapq = c.mapq; ti.off = c.off; ti.cigar = c.cigar;
     ti.base_off = c.base_off; ti.win_off = c.win_off; ti.length = c.length;
     ti.n_reads = c.n_reads; ti.n_ops = c.n_ops;
-    ti.desc = c.desc; ti.cxb = c.cx_base; ti.cxc = c.cx_cigar;
     ti.ctg = lo;
+    ti.tile = t;
+    ti.pad_[0] = ti.pad_[1] = ti.pad_[2] = 0;
     ti.t0 = (t - c.tile_beg) * T;
     int32_t tend = ti.t0 + T < c.length ? ti.t0 + T : c.length;
     int32_t from = ti.t0 > lookback ? ti.t0 - lookback : 0;
     lower_bound_pair(c.pos, c.n_reads, from, tend, ti.lo, ti.hi);
     ti.clo = c.n_reads ? c.off[ti.lo] : 0u;
     ti.chi = c.n_reads ? c.off[ti.hi] : 0u;
-    job.tiles[t] = ti;
+    if (!job.fast) { job.tiles[t] = ti; return; }
+    // fast run: an ordinary tile gets its resolved record; anything else joins the slow list
+    TileFast tf;
+    const uint32_t nrd = ti.hi - ti.lo, nst = ti.chi - ti.clo;
+    const bool ordinary = tend - ti.t0 == T && nrd <= 1024u && nst <= 1024u;
+    tf.nrd = 0xffffffffu;
+    if (ordinary) {
+        tf.pos = c.pos + ti.lo; tf.rec = c.rec + ti.lo; tf.cig = c.cigar + ti.clo;
+        tf.pad0_[0] = tf.pad0_[1] = nullptr;
+        tf.out = job.perbase ? job.perbase + c.base_off + ti.t0 : nullptr;
+        tf.wsum = job.win_sum + c.win_off;
+        tf.wmin = job.win_min + c.win_off;
+        tf.t0 = ti.t0; tf.nrd = nrd; tf.nst = nst; tf.clo = ti.clo; tf.ctg = lo;
+        tf.pad_[0] = tf.pad_[1] = tf.pad_[2] = 0;
+        const uint32_t W = (uint32_t)job.W;
+        const uint32_t stepc = job.step > 0x7fffffffLL ? 0x7fffffffu : (uint32_t)job.step;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const uint32_t cpos0 = (uint32_t)ti.t0 + (uint32_t)(w * (T / 4));
+            const uint32_t cw = cpos0 / W, wleft = W - (cpos0 - cw * W);
+            const uint32_t srem = cpos0 % stepc, sleft = srem == 0u ? 0u : stepc - srem;
+            tf.win0[w] = cw;
+            tf.wleft[w] = wleft > (uint32_t)FAST_FAR ? FAST_BIG : (int32_t)wleft;
+            tf.sleft[w] = sleft > (uint32_t)FAST_FAR ? FAST_BIG : (int32_t)sleft;
+        }
+    } else {
+        const uint32_t slot = atomicAdd(&job.counters->n_slow, 1u);
+        job.tiles[slot] = ti;
+    }
+    job.ftiles[t] = tf;
 }
 
 // ---------------------------------------------------------------------------
@@ -360,9 +417,10 @@ __global__ __launch_bounds__(256) void gd_regions_bounds_kernel(const RegionTab*
 
 }  // namespace gd
 
-#include "gd_tile_v6.hpp"
-#include "gd_tile_v7.hpp"
-#include "gd_tile_v8.hpp"
+#include "gd_normalize.hpp"
+#include "gd_tile_common.hpp"
+#include "gd_tile_generic.hpp"
+#include "gd_tile_fast.hpp"
 #include "gd_scatter.hpp"
 #include "gd_chunk.hpp"
 #include "gd_depthwed.hpp"

@@ -1,27 +1,23 @@
-// gd_tile_v6.hpp -- K1, the tile kernel (short-read path) of the per-base depth engine.
+// gd_tile_common.hpp -- what the tile kernels of the per-base depth engine share: buffer descriptors,
+// wavefront primitives, the generic CIGAR walk, the generic (any tile shape, clipped tiles, any depth,
+// any window size) phase B and phase C.
 //
-// One workgroup (NT threads, NW = NT/64 waves) per tile of T reference
-// positions.  Replaces, for the reads of one tile, the per-read CIGAR walk and
-// per-position counting that `samtools depth` performs
-// (/root/reference/depth/depth.go:45) and the per-line window / class
-// reductions of the callback (depth/depth.go:293-323).
+// One workgroup (NT threads, NW = NT/64 waves) handles one tile of T reference positions.  Replaces, for
+// the reads of one tile, the per-read CIGAR walk and per-position counting that `samtools depth`
+// performs (/root/reference/depth/depth.go:45) and the per-line window / class reductions of the
+// callback (depth/depth.go:293-323).
 //
-// Instruction-lean by construction (the previous generation was VALU-issue
-// bound at ~3200 wave-instructions per tile):
-//   * record fields come through raw buffer loads: the descriptors are bound
-//     to the tile's read range [lo,hi), so out-of-range lanes read 0 (n_ops = 0
-//     => dropped) and no index clamping / 64-bit address arithmetic is issued;
-//     the 4 slots of a lane share one VGPR offset (immediate offsets);
-//   * all interval arithmetic is tile relative and pre-multiplied by 4 (LDS
-//     byte addresses); the depth at t0-1 (needed for the class boundary at the
-//     tile start) lives at LDS index -1: reads that start before the tile are
-//     clipped to -1, so the scan's carry-in IS that depth and no separate
+//   * record fields come through raw buffer loads: the descriptors are bound to the tile's read range
+//     [lo,hi), so out-of-range lanes read 0 (n_ops = 0 => dropped) and no index clamping / 64-bit
+//     address arithmetic is issued; the 4 slots of a lane share one VGPR offset (immediate offsets);
+//   * all interval arithmetic is tile relative and pre-multiplied by 4 (LDS byte addresses); the depth
+//     at t0-1 (needed for the class boundary at the tile start) lives at LDS index -1: reads that start
+//     before the tile are clipped to -1, so the scan's carry-in IS that depth and no separate
 //     "covers t0-1" counting exists;
-//   * phase B keeps the depth in registers: per row of 256 positions one
-//     ds_read_b128, a 6-step DPP scan, one global_store_dwordx4, v_add3/v_min3
-//     window accumulation in 32 bits (exact: depth <= reads of the tile
-//     < 2^22, else the 64-bit path runs), DPP wave reductions at window
-//     boundaries, and a one-compare "row is all CALLABLE" shortcut.
+//   * phase B keeps the depth in registers: per row of 256 positions one ds_read_b128, a 6-step DPP
+//     scan, one global_store_dwordx4, v_add3/v_min3 window accumulation in 32 bits (exact: depth <=
+//     reads of the tile < 2^22, else the 64-bit path runs), DPP wave reductions at window boundaries,
+//     and a one-compare "row is all CALLABLE" shortcut.
 #pragma once
 
 #include <type_traits>
@@ -114,91 +110,6 @@ struct PhaseA {
     uint32_t flag_mask;
     int Q, tid, lane;
 };
-
-// Phase A for one wave: every lane owns U reads per batch of NT*U.
-// Single-M reads (the bulk of short-read data) are marked straight away.
-// Other reads are compacted into a per-wave queue and walked with dense lanes
-// when the queue fills and at the end.  STAGED: the tile's CIGAR ops sit in
-// LDS; otherwise (very deep tiles) they are read from global memory.
-// Returns the lane's largest (saturated) reference span among kept reads.
-template <int NT, int U, bool STAGED>
-__device__ __forceinline__ uint32_t phase_a(const PhaseA& A, int32_t (&p)[U], uint32_t (&f)[U],
-                                            uint32_t (&mq)[U], uint32_t (&o0)[U], uint32_t (&o1)[U])
-{
-    const int tid = A.tid, lane = A.lane;
-    const int tid4 = tid * 4, tid2 = tid * 2;
-    uint32_t smax = 0;
-    uint32_t qn = 0;                              // entries queued (wave uniform)
-    uint32_t* const wq = A.wq;
-
-    auto drain = [&](uint32_t cnt) {
-        __builtin_amdgcn_wave_barrier();
-        if ((uint32_t)lane < cnt) {
-            const int qp = (int)wq[lane];
-            const uint32_t qo = wq[WAVE + lane], qk = wq[2 * WAVE + lane];
-            const uint32_t span = STAGED ? walk_cigar4(A.s_cig + (qo - A.clo), qk, qp, A.T4, A.s_diff)
-                                         : walk_cigar4(A.gcig + qo, qk, qp, A.T4, A.s_diff);
-            smax = span > smax ? span : smax;
-        }
-        __builtin_amdgcn_wave_barrier();
-    };
-
-    for (uint32_t base = 0; base < A.nrd; base += NT * U) {
-        if (base != 0) {                          // further batches (deep tiles)
-            // fresh descriptors over the remaining reads: the range check covers
-            // voffset + immediate only, so the batch base goes into the descriptor
-            const uint32_t rem = A.nrd - base;
-            const rsrc_t r_pos = make_rsrc(A.pos + base, rem * 4u);
-            const rsrc_t r_flag = make_rsrc(A.flag + base, rem * 2u);
-            const rsrc_t r_mapq = make_rsrc(A.mapq + base, rem);
-            const rsrc_t r_off0 = make_rsrc(A.off + base, rem * 4u);
-            const rsrc_t r_off1 = make_rsrc(A.off + base + 1, rem * 4u);
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                p[u]  = __builtin_amdgcn_raw_buffer_load_b32(r_pos, tid4 + u * NT * 4, 0, 0);
-                f[u]  = __builtin_amdgcn_raw_buffer_load_b16(r_flag, tid2 + u * NT * 2, 0, 0);
-                mq[u] = __builtin_amdgcn_raw_buffer_load_b8(r_mapq, tid + u * NT, 0, 0);
-                o0[u] = __builtin_amdgcn_raw_buffer_load_b32(r_off0, tid4 + u * NT * 4, 0, 0);
-                o1[u] = __builtin_amdgcn_raw_buffer_load_b32(r_off1, tid4 + u * NT * 4, 0, 0);
-            }
-        }
-        // filter + first op of every slot first (one LDS round trip for all U)
-        uint32_t n[U], r[U];
-        bool keep[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            n[u] = o1[u] - o0[u];                                 // 0 for lanes past the range
-            keep[u] = (f[u] & A.flag_mask) == 0 && (int)mq[u] >= A.Q && n[u] != 0;
-            uint32_t cg = 0;
-            if (keep[u]) cg = STAGED ? A.s_cig[o0[u] - A.clo] : A.gcig[o0[u]];
-            r[u] = __builtin_rotateright32(cg, 4);                // op<<28 | len
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if (base + (uint32_t)(u * NT) >= A.nrd) break;        // uniform: slot past the range
-            const bool simple = keep[u] && n[u] == 1u && (r[u] - 1u) < 0x0fffffffu;   // one M op, len >= 1
-            const int ps4 = (int)(((uint32_t)p[u] << 2) + (uint32_t)A.neg4t0);
-            if (simple) {
-                smax = r[u] > smax ? r[u] : smax;
-                mark4(A.s_diff, ps4, ps4 + (int)(r[u] << 2), A.T4);
-            }
-            const bool cx = keep[u] && !simple;
-            const unsigned long long m = __ballot(cx);
-            if (m != 0ull) {                      // wave uniform
-                const uint32_t cnt = (uint32_t)__popcll(m);
-                if (qn + cnt > (uint32_t)WAVE) { drain(qn); qn = 0; }
-                if (cx) {
-                    const uint32_t rk = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32),
-                                                 __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                    wq[rk] = (uint32_t)ps4; wq[WAVE + rk] = o0[u]; wq[2 * WAVE + rk] = n[u];
-                }
-                qn += cnt;
-            }
-        }
-    }
-    if (qn != 0) drain(qn);
-    return smax;
-}
 
 // Scalars shared by the phase-B instantiations.
 struct PhaseB {
@@ -456,148 +367,6 @@ __device__ __forceinline__ void phase_c(const Job& job, int tile, int32_t t0, in
             ++dst;
         }
     }
-}
-
-// OPT: per-base stores 0 plain, 1 non-temporal, 2 none (gd_set_outputs without GD_OUT_PERBASE).
-template <int T, int NT, int OPT>
-__global__ __launch_bounds__(NT) void gd_tile_kernel(Job job)
-{
-    constexpr int NW = NT / WAVE;          // waves per workgroup
-    constexpr int CHUNK = T / NW;          // positions per wave
-    constexpr int ROWS = CHUNK / 256;      // rows of 256 positions per wave
-    constexpr int NWORDS = T / 32;         // bitmap words
-    constexpr int CQ = (T * 3) / 8;        // staged CIGAR ops (30x/150 bp needs ~T/4)
-    constexpr int U = 4;                   // reads per lane in flight
-    constexpr int CCH = (CQ + NT - 1) / NT;   // staged ops per thread
-    constexpr int ST = OPT;
-    static_assert(CHUNK % 256 == 0, "wave chunk must be whole rows");
-
-    __shared__ __attribute__((aligned(16))) int32_t s_diffp[T + 4];  // [3] = index -1
-    __shared__ uint32_t s_bmap[NWORDS];    // boundary bit per position
-    __shared__ uint32_t s_clo[NWORDS];     // class bit 0 at boundary positions
-    __shared__ uint32_t s_chi[NWORDS];     // class bit 1 at boundary positions
-    __shared__ uint32_t s_cig[CQ];         // staged CIGAR ops of the tile's reads
-    __shared__ uint32_t s_wq[NW * 3 * WAVE];  // per-wave queues of multi-op reads
-    __shared__ int32_t  s_wtot[NW];
-    __shared__ uint32_t s_wcnt[NW];
-    __shared__ uint32_t s_hasb;
-    __shared__ uint32_t s_base;
-    int32_t* const s_diff = s_diffp + 4;
-
-    // XCD-aware order: workgroup b runs on XCD b % 8; give every XCD a
-    // contiguous eighth of the genome so the look-back reads of neighbouring
-    // tiles hit the same L2.
-    const int per = (job.n_tiles + 7) >> 3;
-    const int tile = (int)(blockIdx.x & 7u) * per + (int)(blockIdx.x >> 3);
-    if (tile >= job.n_tiles) return;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & (WAVE - 1);
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const TileInfo ti = job.tiles[tile];
-    const int seen0 = __hip_atomic_load(&job.counters->max_span, __ATOMIC_RELAXED,
-                                        __HIP_MEMORY_SCOPE_AGENT);
-    const int32_t t0 = ti.t0;
-    const int32_t tend = t0 + T < ti.length ? t0 + T : ti.length;   // clipped tile end
-    const int tlen = tend - t0;                                      // valid positions, 1..T
-    const int T4 = tlen * 4;
-
-    // ---- loads first: record fields of the first batch + the tile's CIGAR range
-    const uint32_t nrd = ti.hi - ti.lo;
-    const uint32_t nst = ti.chi - ti.clo;
-    const bool staged = nst <= (uint32_t)CQ;
-    const rsrc_t r_pos = make_rsrc(ti.pos + ti.lo, nrd * 4u);
-    const rsrc_t r_flag = make_rsrc(ti.flag + ti.lo, nrd * 2u);
-    const rsrc_t r_mapq = make_rsrc(ti.mapq + ti.lo, nrd);
-    const rsrc_t r_off0 = make_rsrc(ti.off + ti.lo, nrd * 4u);
-    const rsrc_t r_off1 = make_rsrc(ti.off + ti.lo + 1, nrd * 4u);
-    const rsrc_t r_cig = make_rsrc(ti.cigar + ti.clo, staged ? nst * 4u : 0u);
-    const int tid4 = tid * 4, tid2 = tid * 2;
-    int32_t  p[U];
-    uint32_t f[U], mq[U], o0[U], o1[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-        p[u]  = __builtin_amdgcn_raw_buffer_load_b32(r_pos, tid4 + u * NT * 4, 0, 0);
-        f[u]  = __builtin_amdgcn_raw_buffer_load_b16(r_flag, tid2 + u * NT * 2, 0, 0);
-        mq[u] = __builtin_amdgcn_raw_buffer_load_b8(r_mapq, tid + u * NT, 0, 0);
-        o0[u] = __builtin_amdgcn_raw_buffer_load_b32(r_off0, tid4 + u * NT * 4, 0, 0);
-        o1[u] = __builtin_amdgcn_raw_buffer_load_b32(r_off1, tid4 + u * NT * 4, 0, 0);
-    }
-    uint32_t cgv[CCH];
-#pragma unroll
-    for (int k = 0; k < CCH; ++k)
-        cgv[k] = (uint32_t)(k * NT) < (staged ? nst : 0u)
-                     ? (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r_cig, tid4 + k * NT * 4, 0, 0)
-                     : 0u;
-
-    // ---- zero LDS (overlaps the loads above) -----------------------------
-    {
-        const int4 z = make_int4(0, 0, 0, 0);
-        int4* d4 = reinterpret_cast<int4*>(s_diffp);
-#pragma unroll
-        for (int i = tid; i < T / 4 + 1; i += NT) d4[i] = z;
-        for (int i = tid; i < NWORDS; i += NT) { s_bmap[i] = 0; s_clo[i] = 0; s_chi[i] = 0; }
-        if (tid == 0) s_hasb = 0;
-#pragma unroll
-        for (int k = 0; k < CCH; ++k)
-            if ((uint32_t)(k * NT) < (staged ? nst : 0u) && k * NT + tid < CQ) s_cig[k * NT + tid] = cgv[k];
-    }
-    __syncthreads();
-
-    // ---- phase A: reads -> clipped intervals -> LDS +1/-1 -----------------
-    if (nrd != 0) {
-        PhaseA A;
-        A.pos = ti.pos + ti.lo; A.flag = ti.flag + ti.lo; A.mapq = ti.mapq + ti.lo; A.off = ti.off + ti.lo;
-        A.s_diff = s_diff; A.s_cig = s_cig; A.wq = &s_wq[wv * (3 * WAVE)];
-        A.gcig = ti.cigar; A.clo = ti.clo; A.nrd = nrd;
-        A.neg4t0 = (int)(0u - ((uint32_t)t0 << 2));       // (p<<2) + neg4t0 = 4*(p - t0)
-        A.T4 = T4; A.flag_mask = job.flag_mask; A.Q = job.Q; A.tid = tid; A.lane = lane;
-        const uint32_t smax = staged ? phase_a<NT, U, true>(A, p, f, mq, o0, o1)
-                                     : phase_a<NT, U, false>(A, p, f, mq, o0, o1);
-        // publish the largest span seen: the host re-runs when it exceeds the
-        // look-back and shrinks the look-back when it is far below.  Gated on
-        // the value read at kernel entry, so only record holders pay an atomic.
-        if (smax > (uint32_t)seen0) atomicMax(&job.counters->max_span, (int32_t)smax);
-    }
-    __syncthreads();
-
-    // ---- phase B pass 1: wave chunk totals -------------------------------
-    const int chunk0 = wv * CHUNK;
-    {
-        int tot = 0;
-#pragma unroll
-        for (int r = 0; r < ROWS; ++r) {
-            const int4 v = *reinterpret_cast<const int4*>(&s_diff[chunk0 + r * 256 + lane * 4]);
-            tot += v.x + v.y + v.z + v.w;
-        }
-        tot = wave_total(tot);
-        if (lane == 0) s_wtot[wv] = tot;
-    }
-    __syncthreads();
-
-    // ---- phase B pass 2: scan, store, window reduce, class boundaries ----
-    {
-        PhaseB B;
-        B.s_diff = s_diff; B.s_bmap = s_bmap; B.s_clo = s_clo; B.s_chi = s_chi; B.s_hasb = &s_hasb;
-        B.out = job.perbase + ti.base_off + t0;
-        B.wsum = job.win_sum + ti.win_off;
-        B.wmin = job.win_min + ti.win_off;
-        B.t0 = t0; B.tlen = tlen; B.chunk0 = chunk0; B.lane = lane;
-        B.W = job.W; B.mincov = job.mincov; B.maxmean = job.maxmean; B.step = job.step;
-        int carry = s_diff[-1];                            // depth at t0-1
-#pragma unroll
-        for (int v = 0; v < NW - 1; ++v) carry += v < wv ? s_wtot[v] : 0;
-        B.carry = carry;
-        // depth <= reads examined for the tile: below 2^22 the 32-bit window
-        // accumulation is exact (1024 positions x depth < 2^32)
-        const bool wide = nrd >= (1u << 22);
-        if (tlen == T && !wide) phase_b_rows<ROWS, true, false, ST>(B);
-        else                    phase_b_rows<ROWS, false, true, ST>(B);   // clipped or very deep tiles
-    }
-    __syncthreads();
-
-    // ---- phase C: compact class boundaries of this tile -------------------
-    phase_c<T, NT>(job, tile, t0, ti.ctg, tid, lane, wv, s_bmap, s_clo, s_chi, s_wcnt, &s_hasb, &s_base);
 }
 
 }  // namespace gd

@@ -1,30 +1,22 @@
-// gd_tile_v7.hpp -- K1, the tile kernel (short-read path), generation 7.
+// gd_tile_generic.hpp -- K1, the generic tile kernel (short-read path): any tile shape (T, NT), tiles
+// clipped at a contig end, tiles deeper than one batch of reads, CIGARs in any form (canonical or not),
+// any window size.  It runs every tile when the straight-line kernel is switched off
+// (GD_OPT_FAST_KERNEL = 0), the tiles gd_prep_kernel lists as `slow` otherwise, and -- as
+// gd_tile_sums_kernel -- the sums-only output.  Same algorithm and results as gd_tile_fast.hpp: phase A
+// marks +1/-1 per counted interval in an LDS difference array, phase B scans, stores and reduces,
+// phase C compacts class boundaries; it replaces the per-read CIGAR walk of `samtools depth`
+// (/root/reference/depth/depth.go:45) and the per-line window / class reductions of the callback
+// (depth/depth.go:293-323).
 //
-// Same algorithm, LDS layout and results as gd_tile_v6.hpp (one workgroup per
-// tile of T reference positions; phase A marks +1/-1 per counted interval,
-// phase B scans, stores and reduces; phase C compacts class boundaries) --
-// replaces, like it, the per-read CIGAR walk of `samtools depth`
-// (/root/reference/depth/depth.go:45) and the per-line window / class
-// reductions of the callback (depth/depth.go:293-323).
-//
-// What changed, from the v6 ISA (the kernel issued ~560 SALU and ~470 VALU
-// wave-instructions per wave and tile; on CDNA the scalar unit is shared by
-// the four SIMDs of a CU, so the SALU stream was the larger issue bound):
-//   * phase A is branch-free up to the LDS atomics: the record filter is mask
-//     arithmetic, the first CIGAR op of all four slots is fetched with one
-//     LDS round trip (the compiler had serialised four short-circuit branches,
-//     each with its own ds_read + wait), the two marks of a read share one
-//     EXEC region, and the multi-op reads of a whole batch are queued with one
-//     test instead of one per slot;
-//   * phase B scans the four rows of a wave in one basic block (four
-//     independent DPP chains interleave, no hazard no-ops, one LDS wait),
-//     decides "no class boundary in this quarter tile" with ONE ballot, and
-//     gets its window / step indices from host-computed multiplicative
-//     inverses (two udiv expansions per wave were ~120 scalar instructions).
+//   * phase A is branch-free up to the LDS atomics: the record filter is mask arithmetic, the first
+//     CIGAR op of all four slots is fetched with one LDS round trip, the two marks of a read share one
+//     EXEC region, and the multi-op reads of a whole batch are queued with one test;
+//   * phase B scans the four rows of a wave in one basic block (four independent DPP chains
+//     interleave, no hazard no-ops, one LDS wait), decides "no class boundary in this quarter tile"
+//     with ONE ballot, and gets its window / step indices from host-computed multiplicative inverses.
 #pragma once
 
 namespace gd {
-namespace v7 {
 
 // floor(x / d) for x < 2^31 with the (m, s) pair of magic_u31() (host side):
 // m = ceil(2^s / d), s = 31 + ceil(log2 d)  (Granlund & Montgomery, N = 31).
@@ -235,7 +227,7 @@ __device__ __forceinline__ uint32_t phase_a(const PhaseA& A, int32_t (&p)[4], ui
 // exact).  Other tiles take gd_tile_v6.hpp's generic phase_b_rows.
 //   ST    per-base stores: 0 plain, 1 non-temporal, 2 none (windows-only output)
 template <int ROWS, int ST>
-__device__ __forceinline__ void phase_b_rows(const PhaseB& B, uint32_t w_magic, uint32_t w_shift,
+__device__ __forceinline__ void phase_b_rows_full(const PhaseB& B, uint32_t w_magic, uint32_t w_shift,
                                              uint32_t s_magic, uint32_t s_shift)
 {
     constexpr int BIG = 0x3fffffff;
@@ -445,9 +437,10 @@ __device__ __forceinline__ void phase_b_rows(const PhaseB& B, uint32_t w_magic, 
     }
 }
 
-// OPT: per-base stores 0 plain, 1 non-temporal, 2 none (gd_set_outputs without GD_OUT_PERBASE).
+// One tile.  OPT: per-base stores 0 plain, 1 non-temporal, 2 none (gd_set_outputs without GD_OUT_PERBASE).
+// Called by every thread of the workgroup.
 template <int T, int NT, int OPT>
-__global__ __launch_bounds__(NT) void gd_tile_kernel(Job job)
+__device__ __forceinline__ void tile_body(const Job& job, const TileInfo& ti, const int tile)
 {
     constexpr int NW = NT / WAVE;          // waves per workgroup
     constexpr int CHUNK = T / NW;          // positions per wave
@@ -470,16 +463,9 @@ __global__ __launch_bounds__(NT) void gd_tile_kernel(Job job)
     __shared__ uint32_t s_base;
     int32_t* const s_diff = s_diffp + 4;
 
-    // XCD-aware order: workgroup b runs on XCD b % 8; every XCD gets a contiguous
-    // eighth of the genome so the look-back reads of neighbouring tiles hit the same L2.
-    const int per = (job.n_tiles + 7) >> 3;
-    const int tile = (int)(blockIdx.x & 7u) * per + (int)(blockIdx.x >> 3);
-    if (tile >= job.n_tiles) return;
-
     const int tid = threadIdx.x;
     const int lane = tid & (WAVE - 1);
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const TileInfo ti = job.tiles[tile];
     const int seen0 = __hip_atomic_load(&job.counters->max_span, __ATOMIC_RELAXED,
                                         __HIP_MEMORY_SCOPE_AGENT);
     const int32_t t0 = ti.t0;
@@ -573,13 +559,44 @@ __global__ __launch_bounds__(NT) void gd_tile_kernel(Job job)
         // depth <= reads examined for the tile: below 2^22 the 32-bit window
         // accumulation is exact (1024 positions x depth < 2^32)
         const bool wide = nrd >= (1u << 22);
-        if (tlen == T && !wide) v7::phase_b_rows<ROWS, OPT>(B, job.w_magic, job.w_shift, job.s_magic, job.s_shift);
-        else                    gd::phase_b_rows<ROWS, false, true, OPT>(B);   // clipped or very deep tiles
+        if constexpr (ROWS == 4) {
+            if (tlen == T && !wide) phase_b_rows_full<ROWS, OPT>(B, job.w_magic, job.w_shift, job.s_magic, job.s_shift);
+            else                    phase_b_rows<ROWS, false, true, OPT>(B);   // clipped or very deep tiles
+        } else {
+            if (tlen == T && !wide) phase_b_rows<ROWS, true, false, OPT>(B);   // other tile shapes: row by row
+            else                    phase_b_rows<ROWS, false, true, OPT>(B);
+        }
     }
     __syncthreads();
 
     // ---- phase C: compact class boundaries of this tile -------------------
     phase_c<T, NT>(job, tile, t0, ti.ctg, tid, lane, wv, s_bmap, s_clo, s_chi, s_wcnt, &s_hasb, &s_base);
+}
+
+// Every tile, one workgroup each (GD_OPT_FAST_KERNEL = 0, or a tile shape other than 4096 x 256).
+template <int T, int NT, int OPT>
+__global__ __launch_bounds__(NT) void gd_tile_kernel(Job job)
+{
+    // XCD-aware order: workgroup b runs on XCD b % 8; every XCD gets a contiguous
+    // eighth of the genome so the look-back reads of neighbouring tiles hit the same L2.
+    const int per = (job.n_tiles + 7) >> 3;
+    const int tile = (int)(blockIdx.x & 7u) * per + (int)(blockIdx.x >> 3);
+    if (tile >= job.n_tiles) return;
+    const TileInfo ti = job.tiles[tile];
+    tile_body<T, NT, OPT>(job, ti, tile);
+}
+
+// The `slow` tiles of a fast run: gd_prep_kernel compacted their descriptors to the front of job.tiles
+// (tile id in TileInfo::tile) and counted them in Counters::n_slow; a fixed grid strides over the list.
+template <int T, int NT, int OPT>
+__global__ __launch_bounds__(NT) void gd_tile_slow_kernel(Job job)
+{
+    const uint32_t n = __hip_atomic_load(&job.counters->n_slow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
+        const TileInfo ti = job.tiles[i];
+        tile_body<T, NT, OPT>(job, ti, ti.tile);
+        __syncthreads();                       // the next tile reuses the LDS arrays
+    }
 }
 
 
@@ -666,5 +683,4 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     }
 }
 
-}  // namespace v7
 }  // namespace gd

@@ -14,7 +14,9 @@ from . import _lib
 from ._lib import GdBatch, GdParams, GdRun, GdStats
 
 CLASS_NAMES = ("NO_COVERAGE", "LOW_COVERAGE", "CALLABLE", "EXCESSIVE_COVERAGE")
-K_PREP, K_TILE, K_RUNS, K_EXPAND, K_SCAN, K_CKPT, K_SEQSTATS, K_MDFLAGS, K_INFLATE, K_PACK = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9
+K_PREP, K_TILE, K_RUNS, K_EXPAND, K_SCAN, K_CKPT, K_SEQSTATS, K_MDFLAGS, K_INFLATE, K_NORM = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9
+# gd_set_option keys (include/goleft_depth.h)
+OPT_TILE_POSITIONS, OPT_TILE_THREADS, OPT_NT_STORES, OPT_NORMALIZE, OPT_FAST_KERNEL, OPT_COPY_THREADS = 1, 2, 3, 4, 5, 6
 PATH_AUTO, PATH_TILE, PATH_SCATTER, PATH_CHUNK = 0, 1, 2, 3
 
 
@@ -425,6 +427,22 @@ class DepthEngine:
         p, n = C.c_void_p(), C.c_int64()
         self._chk(self._lib.gd_device_perbase(self._ctx, tid, C.byref(p), C.byref(n)))
         return p.value, n.value
+
+    def set_option(self, option: int, value: int):
+        """gd_set_option (OPT_* above): tuning / diagnostic switches; results never change."""
+        self._chk(self._lib.gd_set_option(self._ctx, int(option), int(value)))
+
+    def canonical_cigars(self, tid: int, n_reads: int):
+        """(cigar_off u32[n_reads + 1], cigar u32[n_ops]) of the canonical CIGARs of the contig's n_reads
+        records (diagnostic)."""
+        n = C.c_size_t(0)
+        rc = self._lib.gd_canonical_cigars(self._ctx, tid, None, None, 0, C.byref(n))
+        if rc not in (0, -8):
+            self._chk(rc)
+        off = np.zeros(int(n_reads) + 1, np.uint32)
+        cig = np.zeros(max(1, n.value), np.uint32)
+        self._chk(self._lib.gd_canonical_cigars(self._ctx, tid, off.ctypes.data, cig.ctypes.data, len(cig), C.byref(n)))
+        return off, cig[:n.value]
 
     def set_export(self, device_ptr: int, max_windows: int, cap_bounds: int):
         """gd_set_export: every compute() also writes the packed block

@@ -107,7 +107,7 @@ typedef struct {
     int32_t  max_span_seen;  /* largest reference span among kept reads */
     int32_t  reruns;         /* times the last gd_compute re-ran (span / run capacity) */
     int32_t  path;           /* GD_PATH_TILE / _SCATTER / _CHUNK: what the last gd_compute ran */
-    int32_t  reserved;
+    int32_t  reserved;       /* tile path with GD_OPT_FAST_KERNEL: tiles that took the generic kernel instead */
 } gd_stats;
 
 /* Kernel ids for gd_kernel_ms.  Tile path: PREP, TILE, RUNS.  Chunk path: CKPT
@@ -118,9 +118,9 @@ enum { GD_K_PREP = 0, GD_K_TILE = 1, GD_K_RUNS = 2, GD_K_EXPAND = 3, GD_K_SCAN =
        GD_K_SEQSTATS = 6,   /* the kernel of the last gd_seq_stats */
        GD_K_MDFLAGS = 7,    /* the kernel of the last gd_md_flags */
        GD_K_INFLATE = 8,    /* the kernel of the last gd_inflate_bgzf */
-       GD_K_PACK = 9,       /* packing records into read descriptors (gd_adopt_device, gd_ingest_finish,
-                               or the first gd_compute after gd_commit): summed over the contigs packed
-                               since gd_set_profiling was last called; not cleared by gd_compute */
+       GD_K_NORM = 9,       /* CIGAR normalisation (gd_adopt_device, gd_ingest_finish, or the first gd_compute
+                               after gd_commit): summed over the contigs normalised since gd_set_profiling
+                               was last called; not cleared by gd_compute */
        GD_K_COUNT = 10 };
 
 /* Device algorithm of gd_compute.  All are bit exact; they differ in cost.
@@ -156,6 +156,26 @@ int gd_set_params(gd_ctx* ctx, const gd_params* p);
 int gd_default_params(gd_params* p);
 /* Choose the device algorithm (GD_PATH_*); default GD_PATH_AUTO. */
 int gd_set_path(gd_ctx* ctx, int path);
+
+/* Tuning / diagnostic switches (defaults are what the measurements in DESIGN.md chose; results are bit
+ * identical under every setting).  A C library behind cgo takes no behaviour from the process
+ * environment: these are calls. */
+enum { GD_OPT_TILE_POSITIONS = 1,   /* reference positions per LDS tile: 4096 (default) or 8192 */
+       GD_OPT_TILE_THREADS = 2,     /* threads per tile workgroup: 256 (default) or 512 */
+       GD_OPT_NT_STORES = 3,        /* 1 (default): non-temporal per-base stores; 0: plain */
+       GD_OPT_NORMALIZE = 4,        /* 1 (default): canonical CIGARs are built when records arrive (I/S/H/P and
+                                       zero-length ops dropped, neighbouring M/=/X merged, neighbouring D/N
+                                       merged -- exactly what `samtools depth` without -J distinguishes); 0: the
+                                       kernels walk the CIGARs as given (generic tile kernel) */
+       GD_OPT_FAST_KERNEL = 5,      /* 1 (default): ordinary tiles run the straight-line tile kernel, the rest the
+                                       generic one; 0: the generic kernel for every tile */
+       GD_OPT_COPY_THREADS = 6 };   /* host threads filling the staging buffer of gd_ingest_feed: 1 (default) .. 16 */
+int gd_set_option(gd_ctx* ctx, int option, int64_t value);
+
+/* Diagnostic: the canonical CIGARs of contig tid (GD_OPT_NORMALIZE) as CSR offsets (n_reads + 1) and ops
+ * (BAM encoding, op 0 = M or 3 = N) into host memory.  *n_ops receives the op count; GD_E_CAPACITY if cap_ops
+ * is too small; GD_E_STATE if the contig's records have not been normalised (yet). */
+int gd_canonical_cigars(gd_ctx* ctx, int32_t tid, uint32_t* cigar_off, uint32_t* cigar, size_t cap_ops, size_t* n_ops);
 
 /* Which results gd_compute materialises in HBM.  GD_OUT_PERBASE (default): the
  * int32 per-base vector (12.4 GB for a human genome), needed by gd_perbase,

@@ -1,0 +1,122 @@
+"""-m gpu: canonical CIGARs (csrc/gd_normalize.hpp, built when records arrive) against the op-by-op
+Python restatement, and the two tile kernels (straight-line for ordinary tiles + generic for the rest,
+vs generic for every tile, vs no normalisation at all) against each other and the oracle, bit for bit."""
+import numpy as np
+import pytest
+
+from oracle import pyoracle as po
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine(lengths, reads, fast=1, norm=1, **params):
+    from goleft_amd import engine as E
+    eng = E.DepthEngine(0)
+    eng.set_option(E.OPT_NORMALIZE, norm)
+    eng.set_option(E.OPT_FAST_KERNEL, fast)
+    eng.set_params(**params)
+    eng.set_path(1)                                      # GD_PATH_TILE
+    eng.set_contigs(lengths)
+    for t, r in reads.items():
+        eng.push(t, r.pos, r.flag, r.mapq, r.cigar_off, r.cigar)
+    return eng
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_canonical_cigars_equal_restatement(seed):
+    rng = np.random.default_rng(seed)
+    L = 200_000
+    r = H.random_reads(rng, L, 30_000, max_ops=9, max_len=120)
+    with _engine([L], {0: r}, window_size=100) as eng:
+        eng.compute()
+        off, cig = eng.canonical_cigars(0, r.n)
+    woff, wcig = po.canonical_cigars(r)
+    assert np.array_equal(off, woff)
+    assert np.array_equal(cig, wcig)
+    assert set(np.unique(cig & 0xf)) <= {0, 3} and (cig >> 4).min() >= 1
+    # a read is its M runs: never two neighbouring ops of one kind, never a trailing N
+    last = cig[off[1:][off[1:] > off[:-1]] - 1]
+    assert (last & 0xf == 0).all()
+
+
+def test_canonical_overflow_and_degenerate_reads():
+    """Merged lengths past the 28-bit field split off full-length ops; reads of only D/N/I/S ops have none."""
+    M, D, N, I, S = 0, 2, 3, 1, 4
+    big = 0x0fffffff
+    cig = lambda *ops: [(ln << 4) | op for op, ln in ops]
+    reads = [cig((M, big), (M, 5), (I, 3), (M, big)),            # M run of 2 * big + 5
+             cig((M, 10), (D, big), (N, big), (D, 7), (M, 1)),   # N run of 2 * big + 7 between two Ms
+             cig((D, 5), (N, 5)), cig((S, 5), (I, 2)), [],      # nothing counted
+             cig((D, 3), (M, 4), (D, 9)),                        # leading N kept, trailing N dropped
+             cig((M, 0), (M, 7), (D, 0), (M, 2))]               # zero-length ops vanish
+    off = np.cumsum([0] + [len(x) for x in reads]).astype(np.uint32)
+    flat = np.asarray([x for rd in reads for x in rd], np.uint32)
+    n = len(reads)
+    r = po.Reads(np.arange(n, dtype=np.int32) * 3, np.zeros(n, np.uint16), np.full(n, 60, np.uint8), off, flat)
+    with _engine([1000], {0: r}, window_size=100) as eng:
+        eng.set_path(0)
+        got = eng.canonical_cigars(0, n) if False else None
+    from goleft_amd import engine as E
+    with E.DepthEngine(0) as eng:
+        eng.set_params(window_size=100)
+        eng.set_path(1)
+        eng.set_contigs([1000])
+        eng.push(0, r.pos, r.flag, r.mapq, r.cigar_off, r.cigar)
+        try:
+            eng.compute()                                        # spans beyond the tile path's limit: refused ...
+        except E.GdError:
+            pass
+        goff, gcig = eng.canonical_cigars(0, n)                  # ... but the canonical form is there
+    woff, wcig = po.canonical_cigars(r)
+    assert np.array_equal(goff, woff) and np.array_equal(gcig, wcig)
+    assert list(np.diff(woff)) == [3, 5, 0, 0, 0, 2, 1]
+    assert wcig[-1] == (9 << 4)
+
+
+@pytest.mark.parametrize("W,mincov,maxmean,step", [(100, 4, 0, 0), (1000, 4, 0, 0), (37, 2, 25, 3700), (5000, 1, 0, 0)])
+def test_fast_kernel_equals_generic_and_oracle(W, mincov, maxmean, step):
+    """Several contigs incl. clipped last tiles, an exactly-T contig, a deep pile-up (more than one batch of
+    reads per tile -> slow list), a tile with more ops than the staging area, multi-op reads past the queue."""
+    rng = np.random.default_rng(99)
+    lengths = [4096 * 9 + 1234, 4096, 4096 * 3, 50_000, 1, 30_000]
+    reads = {0: H.random_reads(rng, lengths[0], 9000, max_ops=5, max_len=150),
+             1: H.random_reads(rng, lengths[1], 700, max_ops=2, max_len=200),
+             2: H.random_reads(rng, 2000, 6000, max_ops=3, max_len=100),          # pile-up in the first tile
+             3: H.random_reads(rng, lengths[3], 8000, max_ops=9, max_len=60),     # many multi-op reads, many ops
+             5: H.random_reads(rng, lengths[5], 3000, max_ops=1, max_len=300)}
+    res = {}
+    for key, (fast, norm) in {"fast": (1, 1), "generic": (0, 1), "raw": (0, 0)}.items():
+        with _engine(lengths, reads, fast=fast, norm=norm, window_size=W, min_mapq=1, min_cov=mincov,
+                     max_mean_depth=maxmean, step=step) as eng:
+            eng.compute()
+            res[key] = [(eng.perbase(t), eng.windows(t), eng.callable_runs(t)) for t in range(len(lengths))]
+    for t, L in enumerate(lengths):
+        d = po.perbase_c(reads.get(t, H.empty_reads()), 1, 0, L)
+        ws, wm = H.oracle_windows(d, W)
+        for key in res:
+            pb, (s, m), runs = res[key][t]
+            assert np.array_equal(pb, d), (key, t)
+            assert np.array_equal(s, ws) and np.array_equal(m, wm), (key, t)
+            assert np.array_equal(runs, res["raw"][t][2]), (key, t)
+
+
+def test_normalisation_is_ingest_time_not_compute_time():
+    from goleft_amd import engine as E, synth
+    L = 3_000_000
+    r = po.Reads(*synth.short_reads_numpy(L, synth.n_reads_for(L), 5))
+    with E.DepthEngine(0) as eng:
+        eng.set_profiling(True)
+        eng.set_params(window_size=1000)
+        eng.set_contigs([L])
+        eng.push(0, r.pos, r.flag, r.mapq, r.cigar_off, r.cigar)
+        eng.compute()                                   # committed records: normalised by the first compute
+        first = eng.kernel_ms(E.K_NORM)
+        assert first > 0.0
+        eng.compute()
+        assert eng.kernel_ms(E.K_NORM) == first         # ... and not again
+        off, cig = eng.canonical_cigars(0, r.n)
+        single = float((np.diff(off) == 1).mean())
+        raw_single = float((np.diff(r.cigar_off) == 1).mean())
+        assert single > raw_single + 0.04               # soft clips and insertions became single-op reads
+        assert np.array_equal(eng.perbase(0), po.perbase_c(r, 1, 0, L))

@@ -176,9 +176,10 @@ def test_read_span_limit_is_an_error(eng):
     """Reference spans of 2^27 bases or more are rejected, not mis-counted."""
     from goleft_amd.engine import GdError
     L = 1 << 20
-    off = np.array([0, 9], np.uint32)
-    cigar = np.full(9, (((1 << 24) - 1) << 4) | 3, np.uint32)   # nine N skips of ~16.7 Mb
-    cigar[0] = (100 << 4) | 0
+    off = np.array([0, 10], np.uint32)
+    cigar = np.full(10, (((1 << 24) - 1) << 4) | 3, np.uint32)  # eight N skips of ~16.7 Mb between two M ops
+    cigar[0] = (100 << 4) | 0                                   # (skips AFTER the last M would be dropped by the
+    cigar[9] = (5 << 4) | 0                                     # normalisation: they cover nothing that is counted)
     r = po.Reads(np.array([10], np.int32), np.zeros(1, np.uint16), np.full(1, 60, np.uint8), off, cigar)
     eng.set_params(window_size=1000, min_mapq=1, min_cov=4)
     eng.set_contigs([L])
