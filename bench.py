@@ -136,21 +136,23 @@ def host_stream_scope(local_rank, W, Q, mincov, reps=3):
             "host_to_device_GBps": nbytes / best / 1e9}
 
 
-def load_traffic(tag="wgs"):
-    """HBM bytes per launch of the dominant kernel(s) from the committed rocprofv3
-    PMC passes (profiles/*_<tag>_traffic.json: FETCH_SIZE / WRITE_SIZE collected in
-    separate --pmc runs of this very command, tools/gpu_round_r.sh)."""
+def load_traffic(tag, kernel):
+    """HBM bytes per launch of the dominant kernel(s) from the committed rocprofv3 PMC passes
+    (profiles/*_<tag>_traffic.json: FETCH_SIZE / WRITE_SIZE collected in separate --pmc runs of this
+    very command, tools/prof.sh + tools/traffic_from_pmc.py).  Only a file measured on the SAME
+    kernel(s) this run timed is accepted: counter evidence of another kernel generation says nothing
+    about this one."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_traffic.json" % tag)))
-    if not files:
-        return None
-    try:
-        with open(files[-1]) as fh:          # the latest round's measurement
-            d = json.load(fh)
-        d["file"] = os.path.relpath(files[-1], ROOT)
-        return d
-    except (OSError, ValueError):
-        return None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_traffic.json" % tag)), reverse=True):
+        try:
+            with open(path) as fh:
+                d = json.load(fh)
+        except (OSError, ValueError):
+            continue
+        if d.get("kernel") == kernel:               # the latest round's measurement of this kernel
+            d["file"] = os.path.relpath(path, ROOT)
+            return d
+    return None
 
 
 def run_case(args, scaling, world, rank, dev, local_rank, want_streams=False):
@@ -159,7 +161,7 @@ def run_case(args, scaling, world, rank, dev, local_rank, want_streams=False):
     import torch
     import torch.distributed as dist
     from goleft_amd import shard, synth
-    from goleft_amd.engine import DepthEngine, K_PREP, K_TILE, K_RUNS, K_EXPAND, K_SCAN, K_CKPT
+    from goleft_amd.engine import DepthEngine, K_PREP, K_TILE, K_RUNS, K_EXPAND, K_SCAN, K_CKPT, K_NORM
 
     ont = args.workload.startswith("ont")
     cohort = args.workload == "cohort"
@@ -211,6 +213,7 @@ def run_case(args, scaling, world, rank, dev, local_rank, want_streams=False):
         eng.set_outputs(perbase=False)     # experiment only (profiles/r01h): the tile kernel without its store stream
     eng.set_contigs(lengths)
     eng.select_contigs(mine)
+    eng.set_profiling(True)               # before the records arrive: the ingest-time normalisation is timed too
     n_reads = n_ops = 0
     streams = {}
     for t in mine:
@@ -229,7 +232,8 @@ def run_case(args, scaling, world, rank, dev, local_rank, want_streams=False):
         n_reads += n
         n_ops += int(s[4].shape[0])
     torch.cuda.synchronize()
-    eng.set_profiling(True)
+    norm_ms = eng.kernel_ms(K_NORM)       # ingest-time CIGAR normalisation of this rank's contigs (not part of a step)
+    eng.set_profiling(False)              # the timed loop runs without kernel events (4 event records cost ~25 us a step)
 
     wed = {}
     gath = None
@@ -254,11 +258,19 @@ def run_case(args, scaling, world, rank, dev, local_rank, want_streams=False):
 
     for _ in range(args.warmup):
         step()
-    tile_ms, prep_ms, runs_ms, expand_ms, scan_ms, ckpt_ms = [], [], [], [], [], []
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    # kernel durations (HIP events on the engine's stream): the same steps again, profiled, after the timed region
+    tile_ms, prep_ms, runs_ms, expand_ms, scan_ms, ckpt_ms = [], [], [], [], [], []
+    eng.set_profiling(True)
     for _ in range(args.steps):
         step()
         tile_ms.append(eng.kernel_ms(K_TILE))
@@ -267,10 +279,8 @@ def run_case(args, scaling, world, rank, dev, local_rank, want_streams=False):
         expand_ms.append(eng.kernel_ms(K_EXPAND))
         scan_ms.append(eng.kernel_ms(K_SCAN))
         ckpt_ms.append(eng.kernel_ms(K_CKPT))
+    eng.set_profiling(False)
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -318,7 +328,8 @@ def run_case(args, scaling, world, rank, dev, local_rank, want_streams=False):
         "tile_ms": float(np.mean(tile_ms)), "prep_ms": float(np.mean(prep_ms)),
         "runs_ms": float(np.mean(runs_ms)), "tile_positions": st.tile_positions, "lookback": st.lookback,
         "expand_ms": float(np.mean(expand_ms)), "scan_ms": float(np.mean(scan_ms)), "path": int(st.path),
-        "ckpt_ms": float(np.mean(ckpt_ms)),
+        "ckpt_ms": float(np.mean(ckpt_ms)), "norm_ms": norm_ms,
+        "n_canonical_ops": int(st.n_canonical_ops), "n_slow_tiles": int(st.n_slow_tiles),
         "perbase": not cohort, "wed_shape": wed.get("shape"), "split": split,
     }
     if not want_streams:
@@ -359,7 +370,10 @@ def main():
     dt, W, Q, mincov = r["dt"], r["W"], r["Q"], r["mincov"]
     value = r["total_bases"] * args.steps / dt
     # roofline of the dominant kernel (gd_tile_kernel), this rank's launch
-    alg_bytes = synth.algorithmic_bytes(r["n_reads"], r["n_ops"], r["my_bases"] if r["perbase"] else 0,
+    # 4 B/read (pos) + 4 B/read (the record word that stands where the CSR offset stood: flag |
+    # MAPQ | op count) + 4 B per CIGAR op the kernel reads (the canonical ops on the tile path) + 4 B/base + 8 B/window
+    ops_read = r["n_canonical_ops"] if r["n_canonical_ops"] else r["n_ops"]
+    alg_bytes = synth.algorithmic_bytes(r["n_reads"], ops_read, r["my_bases"] if r["perbase"] else 0,
                                         r["my_windows"])   # windows-only: no 4 B/base write
     scatter = r["path"] == 2
     chunk = r["path"] == 3
@@ -370,10 +384,14 @@ def main():
     achieved = alg_bytes / avg_tile_s / 1e9
     traffic = None
     tr = None
+    fast = r["path"] == 1 and r["n_canonical_ops"] > 0 and args.workload != "cohort"
+    kname = ("gd_expand_scatter_kernel+gd_scan_kernel" if scatter else "gd_ckpt_kernel+gd_ltile2_kernel" if chunk else
+             "gd_tile_sums_kernel" if (args.workload == "cohort" and args.cohort_outputs == "sums") else
+             "gd_tile_fast_kernel" if fast else "gd_tile_kernel")
     if world == 1 and args.workload == "wgs" and args.coverage == 30.0 and r["path"] == 1:
-        tr = load_traffic("wgs")
+        tr = load_traffic("wgs", kname)
     elif world == 1 and args.workload == "ont" and args.coverage == 20.0 and chunk:
-        tr = load_traffic("ont")
+        tr = load_traffic("ont", kname)
     if tr:
         traffic = tr.get("hbm_bytes_per_launch")   # measured on this exact launch shape
 
@@ -411,6 +429,8 @@ def main():
                    "coverage": args.coverage, "window": W,
                    "min_mapq": Q, "min_cov": mincov, "total_ref_bases": r["total_bases"],
                    "reads_rank0": r["n_reads"], "cigar_ops_rank0": r["n_ops"],
+                   "canonical_cigar_ops_rank0": r["n_canonical_ops"], "tiles_on_the_generic_kernel": r["n_slow_tiles"],
+                   "ingest_normalise_ms_rank0": r["norm_ms"],
                    "sharding": ("single GPU" if world == 1 else
                                 "by sample (one genome per GPU, no exchange)" if args.scaling == "weak" else
                                 "by chromosome, LPT, RCCL gather of window sums/minima + class runs to rank 0"),
@@ -422,8 +442,7 @@ def main():
                    "device_path": "scatter" if scatter else "chunk" if chunk else "tile"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                     "kernel": ("gd_expand_scatter_kernel+gd_scan_kernel" if scatter else
-                                "gd_ckpt_kernel+gd_ltile2_kernel" if chunk else "gd_tile_kernel"),
+                     "kernel": kname,
                      "avg_kernel_ms": avg_tile_s * 1e3,
                      "algorithmic_bytes_per_launch": alg_bytes,
                      "bytes_per_ref_base": alg_bytes / r["my_bases"]},

@@ -32,7 +32,7 @@ class GdStats(C.Structure):
                 ("n_windows", C.c_uint64), ("n_tiles", C.c_uint64), ("n_runs", C.c_uint64),
                 ("tile_positions", C.c_int32), ("lookback", C.c_int32),
                 ("max_span_seen", C.c_int32), ("reruns", C.c_int32),
-                ("path", C.c_int32), ("reserved", C.c_int32)]
+                ("path", C.c_int32), ("n_slow_tiles", C.c_int32), ("n_canonical_ops", C.c_uint64)]
 
 
 # every symbol include/goleft_depth.h declares: (restype, argtypes)

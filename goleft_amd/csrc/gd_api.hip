@@ -93,6 +93,8 @@ int gd_create(int device_id, gd_ctx** out)
     if ((e = hipMalloc(reinterpret_cast<void**>(&c->d_counters), sizeof(gd::Counters))) != hipSuccess) return bail(e);
     if ((e = hipMalloc(reinterpret_cast<void**>(&c->d_region_cursor), sizeof(uint32_t))) != hipSuccess) return bail(e);
     if ((e = hipHostMalloc(reinterpret_cast<void**>(&c->h_counters), sizeof(gd::Counters), hipHostMallocDefault)) != hipSuccess) return bail(e);
+    if ((e = hipHostMalloc(reinterpret_cast<void**>(&c->h_bounds), kSpecBounds * sizeof(int2), hipHostMallocDefault)) != hipSuccess) return bail(e);
+    if ((e = hipMemset(c->d_counters, 0, sizeof(gd::Counters))) != hipSuccess) return bail(e);
     *out = c;
     return GD_OK;
 }
@@ -126,6 +128,7 @@ void gd_destroy(gd_ctx* c)
                      c->d_region_cursor, c->d_status, c->d_ck, c->d_rend, c->d_seq, c->d_md_bits, c->d_wed};
     for (void* p : frees) if (p) (void)hipFree(p);
     if (c->h_counters) (void)hipHostFree(c->h_counters);
+    if (c->h_bounds) (void)hipHostFree(c->h_bounds);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     delete c;
@@ -367,8 +370,10 @@ int gd_adopt_device(gd_ctx* c, int32_t tid, const gd_batch* d, size_t n_reads, s
     if (n_ops > 0xffffffffull) return fail(c, GD_E_RANGE, "more than 2^32 CIGAR ops");
     // depth <= records of the contig; the window reduction adds four depths in 32 bits
     if (n_reads >= kMaxReadsPerContig) return fail(c, GD_E_RANGE, "more than 2^30 records on one contig");
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->copy_stream));
+    // The canonical CIGARs are built from the arrays right away, on this context's stream: whatever
+    // stream of the caller produced them must have finished.  A device-wide wait makes that true for
+    // any producer (a few microseconds per contig, at ingest time).
+    HIPCHK(c, hipDeviceSynchronize());
     ContigHost& h = c->contigs[tid];
     int64_t len = h.length;
     free_contig(h);
@@ -474,7 +479,6 @@ int gd_set_option(gd_ctx* c, int option, int64_t value)
         if (value < 1 || value > 16) return fail(c, GD_E_INVALID, "copy threads: 1..16");
         c->ing_copy_threads = (int)value;
         break;
-    case 99: c->dbg = (uint32_t)value; break;
     default: return fail(c, GD_E_INVALID, "unknown option %d", option);
     }
     c->computed = false;

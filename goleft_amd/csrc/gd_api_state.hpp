@@ -7,6 +7,7 @@
 namespace {
 
 constexpr int kRingSlots = 3;
+constexpr size_t kSpecBounds = 4096;     // boundaries copied to the host before their count is known (one synchronisation)
 constexpr int kDefaultLookback = 512;
 constexpr uint64_t kMaxReadsPerContig = 1ull << 30;
 constexpr int kAutoLongSpan = 32768;      // GD_PATH_AUTO leaves the short-read tile path above this read span
@@ -93,7 +94,6 @@ struct gd_ctx {
     int tile_NT = 256;
     bool fast_kernel = true;            // GD_OPT_FAST_KERNEL: the straight-line tile kernel (gd_tile_fast.hpp) for
                                         // ordinary tiles, the generic one for the rest; 0 = generic for every tile
-    uint32_t dbg = 0;
     bool normalize = true;              // GD_OPT_NORMALIZE: canonical CIGARs at arrival (gd_normalize.hpp)
     int tile_opt = 1;                   // bit 0: non-temporal per-base stores (2 % faster: the vector is
                                         // never re-read by the kernel)
@@ -111,6 +111,9 @@ struct gd_ctx {
     // device job state
     gd::ContigDev* d_ctgs = nullptr;  size_t cap_ctgs = 0;
     std::vector<gd::ContigDev> h_ctgs;
+    std::vector<gd::ContigDev> up_ctgs;   // what d_ctgs holds
+    gd::ContigDev* up_ctgs_dev = nullptr;
+    uint32_t slow_grid = 64;             // workgroups of gd_tile_slow_kernel
     std::vector<int32_t> job_tids;      // contig table index -> tid
     gd::TileInfo* d_tiles = nullptr;  size_t cap_tiles = 0;
     gd::TileFast* d_ftiles = nullptr; size_t cap_ftiles = 0;
@@ -124,6 +127,8 @@ struct gd_ctx {
     uint32_t* d_super_cnt = nullptr;
     gd::Counters* d_counters = nullptr;
     gd::Counters* h_counters = nullptr;   // pinned
+    int2* h_bounds = nullptr;             // pinned: the first kSpecBounds ordered boundaries travel with the counters
+    uint32_t parity = 0;                  // Counters::n_slow in use (alternates per compute)
     uint32_t* d_region_cursor = nullptr;
 
     int64_t* d_wed = nullptr; size_t cap_wed = 0;      // gd_depthwed: tables + the sites x samples matrix
@@ -292,7 +297,7 @@ void launch_tile(gd_ctx* c, const gd::Job& job)
             hipLaunchKernelGGL((gd::fast::gd_tile_fast_kernel<1>), dim3(grid), dim3(256), 0, c->stream, job);
         else
             hipLaunchKernelGGL((gd::fast::gd_tile_fast_kernel<0>), dim3(grid), dim3(256), 0, c->stream, job);
-        const unsigned sgrid = 2048;
+        const unsigned sgrid = c->slow_grid;                 // strides over the slow list (usually one tile per contig)
         if (!c->keep_perbase)
             hipLaunchKernelGGL((gd::gd_tile_slow_kernel<4096, 256, 2>), dim3(sgrid), dim3(256), 0, c->stream, job);
         else if (c->tile_opt & 1)

@@ -111,8 +111,10 @@ struct Counters {
     uint32_t run_cursor;      // boundary entries allocated (may exceed capacity)
     uint32_t pad0;            // scatter path: tile ticket of gd_scan_kernel
     uint32_t pad1;            // scatter path: 1 if a look-back ever timed out
-    uint32_t n_slow;          // fast run: tiles gd_prep_kernel put on the slow list (zeroed before the launch)
-    uint32_t pad2[3];
+    uint32_t n_slow[2];       // fast run: tiles gd_prep_kernel put on the slow list.  Two counters, used
+                              // alternately: the prep kernel of compute k counts in [k & 1] and zeroes the
+                              // other one for compute k + 1 -- no memset launch between computes
+    uint32_t pad2[2];
 };
 
 struct Job {
@@ -146,8 +148,8 @@ struct Job {
     uint32_t  w_magic, w_shift;   // floor(x / W)    = (x * w_magic) >> w_shift for x < 2^31
     uint32_t  s_magic, s_shift;   // floor(x / step) likewise (step clamped to 2^31-1)
     uint32_t  fast;               // 1: ordinary tiles get a TileFast record, the rest go to the slow list
+    uint32_t  parity;             // which Counters::n_slow this compute uses
     TileFast* ftiles;             // n_tiles records (fast run)
-    uint32_t  dbg;                // experiments only (GD_OPT 99)
 };
 
 __device__ __forceinline__ int cov_class(int d, int mincov, int maxmean)
@@ -225,6 +227,7 @@ __global__ void gd_prep_kernel(Job job)
     if (gid == 0) {
         if (!job.lookback_dev) job.counters->max_span = 0;
         job.counters->run_cursor = 0;
+        job.counters->n_slow[job.parity ^ 1u] = 0;
     }
     if (gid >= job.n_tiles) return;
     const int t = (int)gid;
@@ -274,7 +277,7 @@ __global__ void gd_prep_kernel(Job job)
             tf.sleft[w] = sleft > (uint32_t)FAST_FAR ? FAST_BIG : (int32_t)sleft;
         }
     } else {
-        const uint32_t slot = atomicAdd(&job.counters->n_slow, 1u);
+        const uint32_t slot = atomicAdd(&job.counters->n_slow[job.parity], 1u);
         job.tiles[slot] = ti;
     }
     job.ftiles[t] = tf;

@@ -57,6 +57,32 @@ __device__ __forceinline__ int wave_min_dpp(int v)
     return __builtin_amdgcn_readlane(v, 63);
 }
 
+// Wave maximum via DPP, valid in every lane.
+__device__ __forceinline__ uint32_t wave_max_dpp(uint32_t v)
+{
+    uint32_t o;
+    o = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x111, 0xf, 0xf, false); v = o > v ? o : v;  // row_shr:1
+    o = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x112, 0xf, 0xf, false); v = o > v ? o : v;  // row_shr:2
+    o = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x114, 0xf, 0xf, false); v = o > v ? o : v;  // row_shr:4
+    o = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x118, 0xf, 0xf, false); v = o > v ? o : v;  // row_shr:8
+    o = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x142, 0xa, 0xf, false); v = o > v ? o : v;  // row_bcast:15
+    o = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x143, 0xc, 0xf, false); v = o > v ? o : v;  // row_bcast:31
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// Publishes the largest reference span a wave has seen (the host re-runs when it exceeds the look-back
+// and tightens the look-back when it is far below).  Gated on the value read at kernel entry: once any
+// wave has published the data set's typical span, ONE compare + ballot per wave is all that is left; and a
+// wave that does publish sends one atomic, not one per lane -- at kernel start thousands of workgroups
+// find max_span == 0, and a quarter of a million same-address atomics was ~0.1 ms of every launch.
+__device__ __forceinline__ void publish_span(int32_t* max_span, uint32_t smax, int seen0, int lane)
+{
+    if (__builtin_amdgcn_ballot_w64(smax > (uint32_t)seen0) != 0ull) {
+        const uint32_t m = wave_max_dpp(smax);
+        if (lane == 0) atomicMax(max_span, (int32_t)m);
+    }
+}
+
 // LDS word at byte offset `b4` from `base` (b4 is already a multiple of 4).
 __device__ __forceinline__ int32_t* lds_at(int32_t* base, int b4)
 {

@@ -21,6 +21,10 @@
 //     and C) + 1.5 KB queue = 22 KB => 7 workgroups (28 waves) per CU instead of 5.
 #pragma once
 
+#ifndef GD_LOAD_AUX
+#define GD_LOAD_AUX 0
+#endif
+
 namespace gd {
 namespace fast {
 
@@ -86,12 +90,12 @@ __global__ __launch_bounds__(NT) void gd_tile_fast_kernel(Job job)
     const rsrc_t r_cig = make_rsrc(tf.cig, tf.nst * 4u);
     const int tid4 = tid * 4;
     typedef unsigned int v4u __attribute__((ext_vector_type(4)));
-    const v4u pv = __builtin_amdgcn_raw_buffer_load_b128(r_pos, tid * 16, 0, 0);
-    const v4u rv = __builtin_amdgcn_raw_buffer_load_b128(r_rec, tid * 16, 0, 0);
+    const v4u pv = __builtin_amdgcn_raw_buffer_load_b128(r_pos, tid * 16, 0, GD_LOAD_AUX);
+    const v4u rv = __builtin_amdgcn_raw_buffer_load_b128(r_rec, tid * 16, 0, GD_LOAD_AUX);
     uint32_t cgv[CQ / NT];
 #pragma unroll
     for (int k = 0; k < CQ / NT; ++k)
-        cgv[k] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r_cig, tid4 + k * NT * 4, 0, 0);
+        cgv[k] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r_cig, tid4 + k * NT * 4, 0, GD_LOAD_AUX);
 
     // ---- zero the difference array (overlaps the loads) -----------------------------------------
     {
@@ -144,7 +148,7 @@ __global__ __launch_bounds__(NT) void gd_tile_fast_kernel(Job job)
             const uint32_t rs = simple ? len : 0u;
             smax = rs > smax ? rs : smax;
             const int e4 = ps4[u] + (int)(len << 2);
-            if (simple & (e4 >= 0) & !(job.dbg & 1u)) {                              // reaches t0-1 or beyond
+            if (simple & (e4 >= 0)) {                              // reaches t0-1 or beyond
                 const int cs4 = ps4[u] > -4 ? ps4[u] : -4;
                 atomicAdd(lds_at(s_diff, cs4), 1);
                 if (e4 < T4) atomicAdd(lds_at(s_diff, e4), -1);
@@ -156,7 +160,7 @@ __global__ __launch_bounds__(NT) void gd_tile_fast_kernel(Job job)
 #pragma unroll
         for (int u = 0; u < U; ++u) { m[u] = __builtin_amdgcn_ballot_w64(cx[u]); cnt[u] = (uint32_t)__popcll(m[u]); }
         const uint32_t tot = cnt[0] + cnt[1] + cnt[2] + cnt[3];
-        if (tot != 0u && !(job.dbg & 4u)) {                                           // wave uniform
+        if (tot != 0u) {                                           // wave uniform
             uint32_t b = 0;
             if (lane == 0) b = atomicAdd(&s_qn, tot);
             b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
@@ -188,9 +192,7 @@ __global__ __launch_bounds__(NT) void gd_tile_fast_kernel(Job job)
                 smax = sp > smax ? sp : smax;
             }
         }
-        // publish the largest span seen: the host re-runs when it exceeds the look-back.  Gated on the
-        // value read at kernel entry, so only record holders pay an atomic.
-        if (smax > (uint32_t)seen0) atomicMax(&job.counters->max_span, (int32_t)smax);
+        publish_span(&job.counters->max_span, smax, seen0, lane);
     }
     __syncthreads();
 
@@ -287,7 +289,6 @@ __global__ __launch_bounds__(NT) void gd_tile_fast_kernel(Job job)
             any_noisy = any_noisy || carry < lo_thr || carry >= hi_thr || nf < chunk0 + ROWS * 256;
         }
 
-        if (!(job.dbg & 2u))
 #pragma unroll
         for (int r = 0; r < ROWS; ++r) {
             const int rb = chunk0 + r * 256;                       // row start (rel)

@@ -524,8 +524,8 @@ __device__ __forceinline__ void tile_body(const Job& job, const TileInfo& ti, co
         A.T4 = T4; A.flag_mask = job.flag_mask; A.Q = job.Q; A.tid = tid; A.lane = lane;
         const uint32_t smax = staged ? phase_a<NT, true>(A, p, f, mq, o0, o1)
                                      : phase_a<NT, false>(A, p, f, mq, o0, o1);
-        // publish the largest span seen (see gd_tile_v6.hpp)
-        if (smax > (uint32_t)seen0) atomicMax(&job.counters->max_span, (int32_t)smax);
+        // publish the largest span seen
+        publish_span(&job.counters->max_span, smax, seen0, lane);
     }
     __syncthreads();
 
@@ -587,11 +587,11 @@ __global__ __launch_bounds__(NT) void gd_tile_kernel(Job job)
 }
 
 // The `slow` tiles of a fast run: gd_prep_kernel compacted their descriptors to the front of job.tiles
-// (tile id in TileInfo::tile) and counted them in Counters::n_slow; a fixed grid strides over the list.
+// (tile id in TileInfo::tile) and counted them in Counters::n_slow[job.parity]; a fixed grid strides over the list.
 template <int T, int NT, int OPT>
 __global__ __launch_bounds__(NT) void gd_tile_slow_kernel(Job job)
 {
-    const uint32_t n = __hip_atomic_load(&job.counters->n_slow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t n = __hip_atomic_load(&job.counters->n_slow[job.parity], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
         const TileInfo ti = job.tiles[i];
         tile_body<T, NT, OPT>(job, ti, ti.tile);
@@ -671,7 +671,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
         A.T4 = tlen * 4; A.flag_mask = job.flag_mask; A.Q = job.Q; A.tid = tid; A.lane = lane;
         const uint32_t smax = staged ? phase_a<NT, true, true>(A, p, f, mq, o0, o1, &S)
                                      : phase_a<NT, false, true>(A, p, f, mq, o0, o1, &S);
-        if (smax > (uint32_t)seen0) atomicMax(&job.counters->max_span, (int32_t)smax);
+        publish_span(&job.counters->max_span, smax, seen0, lane);
     }
     __syncthreads();
     // the tile's share of every window it touches

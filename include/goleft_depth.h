@@ -107,7 +107,8 @@ typedef struct {
     int32_t  max_span_seen;  /* largest reference span among kept reads */
     int32_t  reruns;         /* times the last gd_compute re-ran (span / run capacity) */
     int32_t  path;           /* GD_PATH_TILE / _SCATTER / _CHUNK: what the last gd_compute ran */
-    int32_t  reserved;       /* tile path with GD_OPT_FAST_KERNEL: tiles that took the generic kernel instead */
+    int32_t  n_slow_tiles;   /* tile path with GD_OPT_FAST_KERNEL: tiles that took the generic kernel instead */
+    uint64_t n_canonical_ops; /* ops of the canonical CIGARs the tile path read (0: it read the original ones) */
 } gd_stats;
 
 /* Kernel ids for gd_kernel_ms.  Tile path: PREP, TILE, RUNS.  Chunk path: CKPT
@@ -220,7 +221,8 @@ int gd_push(gd_ctx* ctx, int32_t tid, const int32_t* pos, const uint16_t* flag,
             size_t n_reads, size_t n_ops);
 
 /* Use records already resident in HBM (zero copy).  Replaces any records of
- * that contig. */
+ * that contig.  The call waits for the device (whatever stream produced the
+ * arrays) and builds the contig's canonical CIGARs from them right away. */
 int gd_adopt_device(gd_ctx* ctx, int32_t tid, const gd_batch* dev, size_t n_reads, size_t n_ops);
 
 /* Drop records and results, keep contigs/params/allocations. */

@@ -24,4 +24,4 @@ with E.DepthEngine(0) as eng:
         ms = []
         for i in range(5):
             eng.compute(); ms.append(eng.kernel_ms(E.K_TILE))
-        print('fast %d perbase %d dbg %d: tile ms min %.3f mean %.3f' % (fast, pb, dbg, min(ms[1:]), np.mean(ms[1:])), flush=True)
+        print('fast %d perbase %d dbg %d: tile ms min %.3f mean %.3f  (slow tiles %d)' % (fast, pb, dbg, min(ms[1:]), np.mean(ms[1:]), eng.stats().n_slow_tiles), flush=True)

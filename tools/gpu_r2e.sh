@@ -23,9 +23,9 @@ with E.DepthEngine(0) as eng:
     eng.set_params(window_size=1000)
     eng.set_contigs([L]); eng.adopt_device(0,*s); eng.set_profiling(True)
     for i in range(3):
-        eng.compute(); st=eng.stats(); print('slow tiles', st.reserved, 'tiles', st.n_tiles, 'lookback', st.lookback, 'tile ms', eng.kernel_ms(E.K_TILE))
+        eng.compute(); st=eng.stats(); print('slow tiles', st.n_slow_tiles, 'tiles', st.n_tiles, 'lookback', st.lookback, 'tile ms', eng.kernel_ms(E.K_TILE))
     eng.set_option(E.OPT_FAST_KERNEL,0)
     for i in range(2):
-        eng.compute(); st=eng.stats(); print('generic: slow', st.reserved, 'tile ms', eng.kernel_ms(E.K_TILE))
+        eng.compute(); st=eng.stats(); print('generic: slow', st.n_slow_tiles, 'tile ms', eng.kernel_ms(E.K_TILE))
 P
 find gpurun_out/prof_r2e -name "*.csv" -size +2M -delete

@@ -22,5 +22,5 @@ with E.DepthEngine(0) as eng:
         for i in range(6):
             eng.compute(); ms.append(eng.kernel_ms(E.K_TILE))
         st=eng.stats()
-        print('fast',fast,'slow tiles',st.reserved,'lookback',st.lookback,'tile ms min %.3f mean %.3f'%(min(ms[1:]),np.mean(ms[1:])), 'prep %.3f'%eng.kernel_ms(E.K_PREP))
+        print('fast',fast,'slow tiles',st.n_slow_tiles,'lookback',st.lookback,'tile ms min %.3f mean %.3f'%(min(ms[1:]),np.mean(ms[1:])), 'prep %.3f'%eng.kernel_ms(E.K_PREP))
 P

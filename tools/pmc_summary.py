@@ -3,6 +3,7 @@
 import csv
 import glob
 import os
+import re
 import sys
 from collections import defaultdict
 
@@ -10,11 +11,9 @@ root = sys.argv[1]
 
 
 def short(name):
-    for k in ("gd_tile_kernel", "gd_ltile2_kernel", "gd_ltile_kernel", "gd_ckpt_kernel", "gd_prep_kernel", "gd_runs_order_kernel",
-              "gd_expand_scatter_kernel", "gd_scan_kernel", "gd_depthwed", "gd_inflate_kernel", "gd_bam_walk_kernel", "gd_region", "gd_"):
-        if k in name:
-            return k + (name[name.index("<"):name.index(">") + 1] if "<" in name else "")
-    return name[:60]
+    """gd::fast::gd_tile_fast_kernel<1>(gd::Job) -> gd_tile_fast_kernel<1>"""
+    m = re.search(r"(gd_[A-Za-z0-9_]+)(<[^>(]*>)?", name)
+    return (m.group(1) + (m.group(2) or "")) if m else name[:60]
 
 
 for f in glob.glob(os.path.join(root, "trace", "**", "*kernel_stats.csv"), recursive=True):
