@@ -1,0 +1,22 @@
+#!/bin/bash
+# HEAD verification: GPU suite, smoke, bench lines (HIP events) and rocprofv3 kernel-trace of the same commands
+cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
+T=${1:-j}
+mkdir -p gpurun_out/prof_$T
+R=$PWD
+{
+echo "== pytest gpu"; timeout 1200 python -m pytest tests -m gpu -x -q 2>&1 | tail -6
+echo "== smoke"; timeout 300 python __graft_entry__.py smoke 2>&1 | tail -1
+echo "== bench wgs"; timeout 600 python bench.py --verify 2>gpurun_out/${T}_wgs.err | tail -1 | tee gpurun_out/${T}_bench_wgs.json | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['kernels_ms'], d['ms_per_step'], d['value'], d['roofline']['frac'], d['roofline']['traffic'], d.get('verified_bit_exact'))"
+echo "== bench chr20"; timeout 600 python bench.py --workload chr20 --steps 50 --verify --no-cpu-baseline --no-host-stream 2>gpurun_out/${T}_chr20.err | tail -1 | tee gpurun_out/${T}_bench_chr20.json | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['kernels_ms'], d['ms_per_step'], d['value'], d['roofline']['frac'], d.get('verified_bit_exact'))"
+echo "== bench ont"; timeout 600 python bench.py --workload ont --steps 5 --warmup 2 --verify --no-cpu-baseline 2>gpurun_out/${T}_ont.err | tail -1 | tee gpurun_out/${T}_bench_ont.json | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['kernels_ms'], d['ms_per_step'], d['value'], d['roofline']['frac'], d['roofline']['traffic'], d.get('verified_bit_exact'))"
+cd /tmp && export TMPDIR=/tmp
+for w in wgs ont; do
+  extra=""; [ $w = ont ] && extra="--workload ont"
+  timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$T/$w/trace -- python $R/bench.py $extra --no-cpu-baseline --no-host-stream --steps 5 --warmup 2 > $R/gpurun_out/prof_$T/${w}_trace.log 2>&1
+done
+cd $R
+for w in wgs ont; do echo "-- rocprofv3 $w"; python tools/pmc_summary.py gpurun_out/prof_$T/$w 2>&1 | grep -v "^ *$" | head -10; done
+find gpurun_out/prof_$T -name "*.csv" -size +2M -delete
+} > gpurun_out/round_$T.log 2>&1
+cat gpurun_out/round_$T.log
