@@ -125,7 +125,7 @@ void gd_destroy(gd_ctx* c)
     if (c->copy_done) (void)hipEventDestroy(c->copy_done);
     void* frees[] = {c->d_ctgs, c->d_tiles, c->d_ftiles, c->d_perbase, c->d_wsum, c->d_wmin, c->d_chunks,
                      c->d_ordered, c->d_tile_cnt, c->d_tile_off, c->d_super_cnt, c->d_counters,
-                     c->d_region_cursor, c->d_status, c->d_ck, c->d_rend, c->d_seq, c->d_md_bits, c->d_wed};
+                     c->d_region_cursor, c->d_status, c->d_seq, c->d_md_bits, c->d_wed};
     for (void* p : frees) if (p) (void)hipFree(p);
     if (c->h_counters) (void)hipHostFree(c->h_counters);
     if (c->h_bounds) (void)hipHostFree(c->h_bounds);
@@ -313,7 +313,7 @@ int gd_commit(gd_ctx* c, const gd_batch* b, int32_t tid, size_t n_reads, size_t 
         HIPCHK(c, hipMemcpyAsync(h.cigar + h.n_ops, b->cigar, n_ops * sizeof(uint32_t), hipMemcpyHostToDevice, cs));
     HIPCHK(c, hipEventRecord(s.done, cs));
     s.busy = true;
-    if (h.normed) {                                     // the canonical CIGARs no longer cover the stream
+    if (h.normed || h.ck_ok) {                          // the canonical CIGARs / checkpoints no longer cover the stream
         HIPCHK(c, hipStreamSynchronize(c->stream));
         drop_norm(h);
     }
@@ -511,7 +511,8 @@ int gd_set_profiling(gd_ctx* c, int on)
 {
     if (!c) return GD_E_INVALID;
     c->profiling = on != 0;
-    c->kernel_ms[GD_K_NORM] = 0;                        // accumulates over the contigs normalised from now on
+    c->kernel_ms[GD_K_NORM] = 0;                        // accumulate over the contigs normalised / checkpointed
+    c->kernel_ms[GD_K_CKPT] = 0;                        // from now on
     return GD_OK;
 }
 

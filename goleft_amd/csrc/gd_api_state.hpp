@@ -33,6 +33,12 @@ struct ContigHost {
     bool rec_ok = false;               // every record fits its word: the straight-line kernel may run
     size_t n_nops = 0;                 // canonical ops
     bool normed = false;               // noff/ncig describe the current records
+    uint32_t* pidx = nullptr;          // position index: pidx[k] = first read with pos >= 64 k, k = 0 .. (length >> 6) + 1
+    // long-read path (gd_chunk.hpp): checkpoints of the CIGARs above (the canonical ones when normed), read ends
+    uint32_t* ck = nullptr;            // (ops >> 6) + n_reads + 1 slots
+    int32_t*  rend = nullptr;          // n_reads + 1: end position per read; [n_reads] = the largest span
+    int32_t   max_span = 0;
+    bool ck_ok = false;                // ck / rend describe the current records
     // layout in the result arrays of the last compute (-1 = not computed)
     int64_t base_off = -1;
     int64_t win_off = -1;
@@ -104,8 +110,6 @@ struct gd_ctx {
     bool ran_sums_only = false;         // what the last gd_compute produced
     bool span_forces_long = false;      // AUTO: the tile path met a read too long for it
     unsigned long long* d_status = nullptr;  size_t cap_status = 0;   // scatter path look-back words
-    uint32_t* d_ck = nullptr;  size_t cap_ck = 0;      // chunk path: CIGAR checkpoints
-    int32_t* d_rend = nullptr; size_t cap_rend = 0;    // chunk path: read end positions
     int lookback = kDefaultLookback;
 
     // device job state
@@ -212,13 +216,24 @@ int ensure_dev(gd_ctx* c, Tp** p, size_t* cap, size_t need, bool keep = false, s
     return GD_OK;
 }
 
+void drop_ck(ContigHost& h)
+{
+    if (h.ck) (void)hipFree(h.ck);
+    if (h.rend) (void)hipFree(h.rend);
+    h.ck = nullptr; h.rend = nullptr;
+    h.max_span = 0;
+    h.ck_ok = false;
+}
+
 void drop_norm(ContigHost& h)
 {
+    drop_ck(h);                        // built from the canonical arrays
     if (h.noff) (void)hipFree(h.noff);
     if (h.ncig) (void)hipFree(h.ncig);
     if (h.nunit) (void)hipFree(h.nunit);
     if (h.nrec) (void)hipFree(h.nrec);
-    h.noff = nullptr; h.ncig = nullptr; h.nunit = nullptr; h.nrec = nullptr;
+    if (h.pidx) (void)hipFree(h.pidx);
+    h.noff = nullptr; h.ncig = nullptr; h.nunit = nullptr; h.nrec = nullptr; h.pidx = nullptr;
     h.rec_ok = false;
     h.n_nops = 0;
     h.normed = false;
@@ -234,6 +249,7 @@ void free_contig(ContigHost& h)
         if (h.off) (void)hipFree(h.off);
         if (h.cigar) (void)hipFree(h.cigar);
     }
+    drop_ck(h);
     h.pos = nullptr; h.flag = nullptr; h.mapq = nullptr; h.off = nullptr; h.cigar = nullptr;
     h.n_reads = h.n_ops = h.cap_reads = h.cap_ops = 0;
     h.adopted = false;
@@ -291,12 +307,10 @@ void launch_tile(gd_ctx* c, const gd::Job& job)
     if (job.fast) {
         // ordinary tiles: the straight-line kernel; the tiles gd_prep_kernel listed as `slow` (clipped at a
         // contig end, deeper than one batch of reads, more ops than the staging area): the generic one
-        if (!c->keep_perbase)
-            hipLaunchKernelGGL((gd::fast::gd_tile_fast_kernel<2>), dim3(grid), dim3(256), 0, c->stream, job);
-        else if (c->tile_opt & 1)
-            hipLaunchKernelGGL((gd::fast::gd_tile_fast_kernel<1>), dim3(grid), dim3(256), 0, c->stream, job);
-        else
-            hipLaunchKernelGGL((gd::fast::gd_tile_fast_kernel<0>), dim3(grid), dim3(256), 0, c->stream, job);
+        // The slow list (a few dozen workgroups of a large, cold kernel) goes FIRST: launched after the
+        // straight-line kernel it took ~0.1 ms -- as long as all of chr20's ordinary tiles -- behind the
+        // write-back of that kernel's per-base stores; in front of it, it costs a few microseconds
+        // (profiles/r02d_slow_first.txt; a side stream next to the straight-line kernel bought nothing).
         const unsigned sgrid = c->slow_grid;                 // strides over the slow list (usually one tile per contig)
         if (!c->keep_perbase)
             hipLaunchKernelGGL((gd::gd_tile_slow_kernel<4096, 256, 2>), dim3(sgrid), dim3(256), 0, c->stream, job);
@@ -304,6 +318,12 @@ void launch_tile(gd_ctx* c, const gd::Job& job)
             hipLaunchKernelGGL((gd::gd_tile_slow_kernel<4096, 256, 1>), dim3(sgrid), dim3(256), 0, c->stream, job);
         else
             hipLaunchKernelGGL((gd::gd_tile_slow_kernel<4096, 256, 0>), dim3(sgrid), dim3(256), 0, c->stream, job);
+        if (!c->keep_perbase)
+            hipLaunchKernelGGL((gd::fast::gd_tile_fast_kernel<2>), dim3(grid), dim3(256), 0, c->stream, job);
+        else if (c->tile_opt & 1)
+            hipLaunchKernelGGL((gd::fast::gd_tile_fast_kernel<1>), dim3(grid), dim3(256), 0, c->stream, job);
+        else
+            hipLaunchKernelGGL((gd::fast::gd_tile_fast_kernel<0>), dim3(grid), dim3(256), 0, c->stream, job);
         return;
     }
     if (!c->keep_perbase)
@@ -324,8 +344,42 @@ void launch_ltile(gd_ctx* c, const gd::Job& job)
         hipLaunchKernelGGL((gd::gd_ltile2_kernel<T, NT, 0>), dim3(grid), dim3(NT), 0, c->stream, job);
 }
 
-// Builds the canonical CIGARs of one contig's records (gd_normalize.hpp) on the compute stream.
-// Afterwards h.normed is set.
+// Long-read path: checkpoints + read ends of one contig's CIGARs (gd_ckpt_kernel), from the canonical arrays
+// when the contig has them.  Part of taking the records in (or of the first gd_compute that needs them), kept
+// until the records change.
+int build_ck(gd_ctx* c, ContigHost& h)
+{
+    drop_ck(h);
+    const uint32_t n_reads = (uint32_t)h.n_reads, n_units = (n_reads + 63u) / 64u;
+    const size_t n_ops = h.normed ? h.n_nops : h.n_ops;
+    HIPCHK(c, hipEventRecord(c->copy_done, c->copy_stream));
+    HIPCHK(c, hipStreamWaitEvent(c->stream, c->copy_done, 0));
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&h.ck), ((n_ops >> 6) + (size_t)n_reads + 1) * sizeof(uint32_t)));
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&h.rend), ((size_t)n_reads + 1) * sizeof(int32_t)));
+    HIPCHK(c, hipMemsetAsync(h.rend + n_reads, 0, sizeof(int32_t), c->stream));
+    gd::CkJob j{};
+    j.pos = h.pos; j.off = h.normed ? h.noff : h.off; j.cigar = h.normed ? h.ncig : h.cigar;
+    j.n_reads = n_reads; j.n_units = n_units;
+    j.ck = h.ck; j.rend = h.rend; j.max_span = h.rend + n_reads;
+    if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+    if (n_units) hipLaunchKernelGGL(gd::gd_ckpt_kernel, dim3((n_units + 3u) / 4u), dim3(256), 0, c->stream, j);
+    HIPCHK(c, hipGetLastError());
+    if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+    int32_t span = 0;
+    HIPCHK(c, hipMemcpyAsync(&span, h.rend + n_reads, sizeof span, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->profiling) {
+        float ms = 0;
+        HIPCHK(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
+        c->kernel_ms[GD_K_CKPT] += ms;
+    }
+    h.max_span = span;
+    h.ck_ok = true;
+    return GD_OK;
+}
+
+// Builds the canonical CIGARs of one contig's records (gd_normalize.hpp) and its position index on the compute
+// stream; long-read shaped contigs also get their checkpoints (build_ck).  Afterwards h.normed is set.
 int norm_contig(gd_ctx* c, ContigHost& h)
 {
     drop_norm(h);
@@ -334,24 +388,32 @@ int norm_contig(gd_ctx* c, ContigHost& h)
     HIPCHK(c, hipEventRecord(c->copy_done, c->copy_stream));
     HIPCHK(c, hipStreamWaitEvent(c->stream, c->copy_done, 0));
     HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&h.noff), ((size_t)n_reads + 1) * sizeof(uint32_t)));
-    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&h.ncig), std::max<size_t>(h.n_ops, 1) * sizeof(uint32_t)));
     HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&h.nunit), ((size_t)n_units + 2) * sizeof(uint32_t)));
     HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&h.nrec), ((size_t)n_reads + 4) * sizeof(uint32_t)));
     HIPCHK(c, hipMemsetAsync(h.noff + n_reads, 0, sizeof(uint32_t), c->stream));         // n_reads == 0: noff[0] = 0
     HIPCHK(c, hipMemsetAsync(h.nunit + n_units, 0, 2 * sizeof(uint32_t), c->stream));
     HIPCHK(c, hipMemsetAsync(h.nrec + n_reads, 0, 4 * sizeof(uint32_t), c->stream));
+    const uint32_t n_idx = (uint32_t)(h.length >> 6) + 2u;
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&h.pidx), (size_t)n_idx * sizeof(uint32_t)));
     gd::norm::NormJob j{};
     j.off = h.off; j.cigar = h.cigar; j.n_reads = n_reads; j.n_units = n_units;
-    j.noff = h.noff; j.unit = h.nunit; j.ncig = h.ncig;
+    j.noff = h.noff; j.unit = h.nunit; j.ncig = nullptr;
     j.flag = h.flag; j.mapq = h.mapq; j.rec = h.nrec; j.status = h.nunit + n_units + 1;
     uint32_t total[2] = {0, 0};                              // canonical ops, status bits
     if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
     if (n_units) {
         hipLaunchKernelGGL(gd::norm::gd_norm_count_kernel, dim3((n_units + 3u) / 4u), dim3(256), 0, c->stream, j);
         hipLaunchKernelGGL(gd::norm::gd_unit_scan_kernel, dim3(1), dim3(1024), 0, c->stream, h.nunit, n_units);
-        hipLaunchKernelGGL(gd::norm::gd_norm_write_kernel, dim3((n_units + 3u) / 4u), dim3(256), 0, c->stream, j);
         HIPCHK(c, hipMemcpyAsync(total, h.nunit + n_units, sizeof total, hipMemcpyDeviceToHost, c->stream));
     }
+    hipLaunchKernelGGL(gd::norm::gd_pidx_kernel, dim3((n_idx + 255u) / 256u), dim3(256), 0, c->stream,
+                       h.pos, n_reads, h.pidx, n_idx);                                // no reads: all zero
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));              // the canonical array is allocated at its exact size
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&h.ncig), std::max<size_t>(total[0], 1) * sizeof(uint32_t)));
+    j.ncig = h.ncig;
+    if (n_units)
+        hipLaunchKernelGGL(gd::norm::gd_norm_write_kernel, dim3((n_units + 3u) / 4u), dim3(256), 0, c->stream, j);
     HIPCHK(c, hipGetLastError());
     if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -363,15 +425,16 @@ int norm_contig(gd_ctx* c, ContigHost& h)
     h.n_nops = total[0];
     h.rec_ok = total[1] == 0;
     h.normed = true;
+    if (h.n_ops > 6 * h.n_reads)                             // what GD_PATH_AUTO sends to the long-read path
+        if (int r = build_ck(c, h)) return r;
     return GD_OK;
 }
 
-// Canonical CIGARs serve the tile path; long-read data goes to the chunk path (original ops).
-bool wants_norm(const gd_ctx* c, uint64_t n_reads, uint64_t n_ops)
+// Canonical CIGARs serve the tile and the long-read paths; the scatter path reads the original ops (it stays
+// an independent cross-check of the normalisation).
+bool wants_norm(const gd_ctx* c, uint64_t, uint64_t)
 {
-    if (!c->normalize) return false;
-    if (c->path == GD_PATH_TILE) return true;
-    return c->path == GD_PATH_AUTO && !c->span_forces_long && n_ops <= 6 * n_reads;
+    return c->normalize && c->path != GD_PATH_SCATTER;
 }
 
 // RAII for the scratch device buffers of gd_ingest_bgzf

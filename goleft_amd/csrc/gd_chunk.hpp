@@ -9,11 +9,14 @@
 // / window / class reductions, every per-base value written to HBM exactly once
 // -- and makes a read's CIGAR addressable by reference position:
 //
-//   CK  gd_ckpt_kernel   one pass over all CIGARs: for every chunk of 64 ops of
-//       a read, the reference position at which the chunk starts (a checkpoint,
-//       4 bytes per 64 ops), the read's end position, and the largest span.
-//       Checkpoint slots need no prefix sum: read r with CSR offset o uses slots
-//       (o >> 6) + r ... which never overlap (ceil(n/64) <= (n >> 6) + 1).
+//   CK  gd_ckpt_kernel   one pass over a contig's CIGARs WHEN ITS RECORDS ARRIVE (with the
+//       canonical CIGARs of gd_normalize.hpp, which it reads: about half the ops of an
+//       ONT-like read; not part of gd_compute): for every chunk of 64 ops of a read, the
+//       reference position at which the chunk starts (a checkpoint, 4 bytes per 64 ops), the
+//       read's end position, and the largest span.  Independent of the read filter (-Q, flag
+//       mask), which the tile kernel applies.  Checkpoint slots need no prefix sum: read r
+//       with CSR offset o uses slots (o >> 6) + r ... which never overlap
+//       (ceil(n/64) <= (n >> 6) + 1).
 //   LT2 gd_ltile2_kernel per tile: the candidate reads (start within one maximum
 //       span before the tile; 8 bytes each: start, end) are tested lane-parallel
 //       and contribute one +1/-1 pair; the 64-op chunks that reach the tile are
@@ -39,39 +42,36 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
     return v;
 }
 
-// CK: one wave per unit of 64 consecutive reads of one contig.
-__global__ __launch_bounds__(256) void gd_ckpt_kernel(Job job)
+// CK: one wave per unit of 64 consecutive reads of ONE contig.
+struct CkJob {
+    const int32_t*  pos;
+    const uint32_t* off;      // CSR offsets of `cigar` (the canonical arrays when the contig has them)
+    const uint32_t* cigar;
+    uint32_t  n_reads;
+    uint32_t  n_units;        // ceil(n_reads / 64)
+    uint32_t* ck;             // (n_ops >> 6) + n_reads + 1 slots
+    int32_t*  rend;           // n_reads: reference position after the last op (== pos: no ops)
+    int32_t*  max_span;       // atomicMax of end - pos
+};
+
+__global__ __launch_bounds__(256) void gd_ckpt_kernel(CkJob job)
 {
-    const uint32_t n_groups = (job.n_units + 3u) >> 2;
-    const uint32_t per = (n_groups + 7u) >> 3;
-    const uint32_t grp = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
     const int lane = threadIdx.x & 63;
-    const uint32_t unit = grp * 4u + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    if (grp >= n_groups || unit >= job.n_units) return;
+    const uint32_t unit = blockIdx.x * 4u + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (unit >= job.n_units) return;
+    const uint32_t n_reads = job.n_reads;
+    const uint32_t* const cigar = job.cigar;
+    uint32_t* const ck = job.ck;
 
-    int lo = 0, hi = job.n_ctgs;
-    while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (job.ctgs[mid].unit_beg <= unit) lo = mid; else hi = mid;
-    }
-    const ContigDev& c = job.ctgs[lo];
-    const uint32_t n_reads = c.n_reads;
-    const uint32_t* const cigar = c.cigar;
-    uint32_t* const ck = job.ck + c.ck_off;
-    int32_t* const rend = job.rend + c.read_off;
-    const int seen0 = __hip_atomic_load(&job.counters->max_span, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-
-    const uint32_t r = (unit - c.unit_beg) * 64u + (uint32_t)lane;
+    const uint32_t r = unit * 64u + (uint32_t)lane;
     const bool valid = r < n_reads;
     uint32_t p = 0, o0 = 0, n = 0;
-    bool keep = false;
     if (valid) {
-        p = (uint32_t)c.pos[r];
-        const uint32_t f = c.flag[r], mq = c.mapq[r];
-        o0 = c.off[r];
-        n = c.off[r + 1] - o0;
-        keep = (f & job.flag_mask) == 0 && (int)mq >= job.Q && n != 0;
+        p = (uint32_t)job.pos[r];
+        o0 = job.off[r];
+        n = job.off[r + 1] - o0;
     }
+    const bool keep = n != 0u;
     uint32_t endp = p;                                    // reference position after the last op
 
     // short CIGARs: lane serial, a single chunk
@@ -138,9 +138,9 @@ __global__ __launch_bounds__(256) void gd_ckpt_kernel(Job job)
         }
         if (lane == j) endp = run;
     }
-    if (valid) rend[r] = keep ? (int32_t)endp : -1;       // -1: dropped by the read filter
+    if (valid) job.rend[r] = (int32_t)endp;
     const uint32_t smax = wave_max_u32(keep ? endp - p : 0u);
-    if (lane == 0 && smax > (uint32_t)seen0) atomicMax(&job.counters->max_span, (int32_t)smax);
+    if (lane == 0 && smax != 0u) atomicMax(job.max_span, (int32_t)smax);
 }
 
 // ---------------------------------------------------------------------------
@@ -160,13 +160,15 @@ __global__ __launch_bounds__(256) void gd_ckpt_kernel(Job job)
 //     (two consecutive 64-op checkpoint chunks): the checkpoints of up to four
 //     overlapping reads are fetched in one round trip, lanes whose chunk pair
 //     reaches the tile push an item (ballot + mbcnt, no atomics); items are
-//     expanded four at a time, lane k holding op k of each of the item's two
-//     chunks (two coalesced 256-byte loads, no alignment cases), eight loads in
-//     flight while the previous four items expand, and the eight wave scans of
-//     the reference-consuming lengths interleave (scan4 twice), each seeded
-//     with its own chunk's checkpoint.
+//     expanded four at a time, lane k holding the PAIR of ops 2k, 2k+1 of the item (one
+//     8-byte load; 512 bytes per item and wave instruction), the next four items' loads
+//     in flight while the current ones expand, and ONE wave scan per item over the pairs'
+//     reference-consuming lengths (four interleave in scan4), seeded with the item's
+//     checkpoint.  Canonical CIGARs alternate M and N, so a pair holds exactly one D/N op:
+//     every lane has one mark to make, none idles on an M (a pair of two D/N ops -- only
+//     when normalisation is off -- takes a second, wave-uniformly skipped, mark).
 // Reference positions use plain 32-bit scans whenever every op of the four
-// items consumes <= 2^24 bases (64 * 2^24 + 2^31 < 2^32: no wrap); items with
+// items consumes <= 2^23 bases (64 * 2^24 + 2^31 < 2^32: no wrap); items with
 // a longer D/N op take a saturating scan.  Integer adds commute, so the
 // per-base result equals M-run marking bit for bit.
 // ---------------------------------------------------------------------------
@@ -188,7 +190,7 @@ __device__ __forceinline__ void del_mark(int32_t* s_diff, bool del, uint32_t s, 
     }
 }
 
-// Reference positions of the ops of four chunks (lane k = op k; cons = bases the op consumes).
+// Reference positions of the op pairs of four items (lane k = ops 2k, 2k+1; cons = bases the pair consumes).
 __device__ __forceinline__ void chunk_pos4(const uint32_t (&cons)[4], const uint32_t (&st)[4], bool big,
                                            uint32_t (&pos)[4])
 {
@@ -209,32 +211,38 @@ __device__ __forceinline__ void chunk_pos4(const uint32_t (&cons)[4], const uint
     }
 }
 
-// Four items: lane k holds op k of the item's first chunk (a) and of its second chunk (b);
-// 0 = nothing.  sa / sb: reference position of op 0 of each chunk.
+// Four items: lane k holds ops 2k (a) and 2k+1 (b) of each; 0 = nothing.  sa: reference position of op 0.
 __device__ __forceinline__ void expand4_lds(const uint32_t (&a)[4], const uint32_t (&b)[4],
-                                            const uint32_t (&sa)[4], const uint32_t (&sb)[4],
-                                            int t0, int tlen, int32_t* s_diff)
+                                            const uint32_t (&sa)[4], int t0, int tlen, int32_t* s_diff)
 {
-    uint32_t la[4], lb[4], ca[4], cb[4], pa[4], pb[4];
+    uint32_t la[4], lb[4], ca[4], cp[4], pa[4];
     bool da[4], db[4];
     uint32_t mx = 0;
+    bool two = false;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         const uint32_t oa = a[g] & 0xf, ob = b[g] & 0xf;
         la[g] = a[g] >> 4; lb[g] = b[g] >> 4;
         ca[g] = ((0x18du >> oa) & 1u) ? la[g] : 0u;                       // M D N = X
-        cb[g] = ((0x18du >> ob) & 1u) ? lb[g] : 0u;
+        const uint32_t cb = ((0x18du >> ob) & 1u) ? lb[g] : 0u;
         da[g] = ((0xcu >> oa) & 1u) && la[g] != 0;                        // D N
         db[g] = ((0xcu >> ob) & 1u) && lb[g] != 0;
-        mx |= ca[g] | cb[g];
+        mx |= ca[g] | cb;
+        cp[g] = sat_pos(ca[g]) + sat_pos(cb);                             // < 2^32
+        two = two || (da[g] && db[g]);
     }
-    const bool big = __builtin_amdgcn_ballot_w64(mx > (1u << 24)) != 0ull;   // wave uniform
-    chunk_pos4(ca, sa, big, pa);
-    chunk_pos4(cb, sb, big, pb);
+    const bool big = __builtin_amdgcn_ballot_w64(mx > (1u << 23)) != 0ull;   // wave uniform
+    chunk_pos4(cp, sa, big, pa);
+    // one mark per pair: the pair's D/N op (canonical CIGARs alternate, so there is exactly one)
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-        del_mark(s_diff, da[g], pa[g], la[g], t0, tlen);
-        del_mark(s_diff, db[g], pb[g], lb[g], t0, tlen);
+        const uint32_t ps = da[g] ? pa[g] : sat_pos(pa[g] + ca[g]);
+        del_mark(s_diff, da[g] | db[g], ps, da[g] ? la[g] : lb[g], t0, tlen);
+    }
+    if (__builtin_amdgcn_ballot_w64(two) != 0ull) {                      // original CIGARs only: D next to N
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            del_mark(s_diff, da[g] && db[g], sat_pos(pa[g] + ca[g]), lb[g], t0, tlen);
     }
 }
 
@@ -268,14 +276,16 @@ __global__ __launch_bounds__(NT) void gd_ltile2_kernel(Job job)
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const TileInfo ti = job.tiles[tile];
     const ContigDev& c = job.ctgs[ti.ctg];
-    const uint32_t* const ck = job.ck + c.ck_off;
+    const uint32_t* const ck = c.ck;
     const int32_t t0 = ti.t0;
     const int32_t tend = t0 + T < ti.length ? t0 + T : ti.length;
     const int tlen = tend - t0;
 
     const uint32_t nrd = ti.hi - ti.lo;
     const int32_t* const gpos = ti.pos + ti.lo;
-    const int32_t* const gend = job.rend + c.read_off + ti.lo;
+    const int32_t* const gend = c.rend + ti.lo;
+    const uint16_t* const gflag = ti.flag + ti.lo;
+    const uint8_t* const gmapq = ti.mapq + ti.lo;
     const uint32_t* const goff = ti.off + ti.lo;
     const uint32_t* const cigar = ti.cigar;
 
@@ -292,34 +302,37 @@ __global__ __launch_bounds__(NT) void gd_ltile2_kernel(Job job)
     LItem* const Q = &s_q[wv * LQ_CAP];
     uint32_t qn = 0;                                       // items queued (wave uniform)
 
-    // four queued items: op k of each chunk in lane k (0 past the item) and the chunks' start positions
-    auto fetch4 = [&](uint32_t i, uint32_t cnt, uint32_t (&a)[4], uint32_t (&b)[4], uint32_t (&sa)[4],
-                      uint32_t (&sb)[4]) {
+    // four queued items: ops 2k, 2k+1 of each in lane k (0 past the item) and the items' start positions
+    typedef uint32_t __attribute__((ext_vector_type(2), aligned(4))) pair_u;   // a read's ops start at any dword
+    auto fetch4 = [&](uint32_t i, uint32_t cnt, uint32_t (&a)[4], uint32_t (&b)[4], uint32_t (&sa)[4]) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            a[g] = 0; b[g] = 0; sa[g] = POS_CAP; sb[g] = POS_CAP;
+            a[g] = 0; b[g] = 0; sa[g] = POS_CAP;
             if (i + (uint32_t)g < cnt) {                   // wave uniform
                 const LItem it = Q[i + g];                 // same address in every lane: one broadcast read
                 const uint32_t ci = (uint32_t)__builtin_amdgcn_readfirstlane((int)it.x);
                 const uint32_t no = (uint32_t)__builtin_amdgcn_readfirstlane((int)it.w);
                 sa[g] = (uint32_t)__builtin_amdgcn_readfirstlane((int)it.y);
-                sb[g] = (uint32_t)__builtin_amdgcn_readfirstlane((int)it.z);
-                const uint32_t* src = cigar + ci + (uint32_t)lane;
-                if ((uint32_t)lane < no) a[g] = src[0];
-                if ((uint32_t)lane + CK_OPS < no) b[g] = src[CK_OPS];
+                const uint32_t* src = cigar + ci + 2u * (uint32_t)lane;
+                if (2u * (uint32_t)lane + 1u < no) {
+                    const pair_u v = *reinterpret_cast<const pair_u*>(src);
+                    a[g] = v.x; b[g] = v.y;
+                } else if (2u * (uint32_t)lane < no) {
+                    a[g] = src[0];
+                }
             }
         }
     };
     auto drain = [&](uint32_t cnt) {
         __builtin_amdgcn_wave_barrier();
-        uint32_t aA[4], bA[4], saA[4], sbA[4];
-        fetch4(0, cnt, aA, bA, saA, sbA);
+        uint32_t aA[4], bA[4], saA[4];
+        fetch4(0, cnt, aA, bA, saA);
         for (uint32_t i = 0; i < cnt; i += 4u) {
-            uint32_t aB[4], bB[4], saB[4], sbB[4];
-            fetch4(i + 4u, cnt, aB, bB, saB, sbB);         // next four are in flight while these expand
-            expand4_lds(aA, bA, saA, sbA, t0, tlen, s_diff);
+            uint32_t aB[4], bB[4], saB[4];
+            fetch4(i + 4u, cnt, aB, bB, saB);              // next four are in flight while these expand
+            expand4_lds(aA, bA, saA, t0, tlen, s_diff);
 #pragma unroll
-            for (int g = 0; g < 4; ++g) { aA[g] = aB[g]; bA[g] = bB[g]; saA[g] = saB[g]; sbA[g] = sbB[g]; }
+            for (int g = 0; g < 4; ++g) { aA[g] = aB[g]; bA[g] = bB[g]; saA[g] = saB[g]; }
         }
         __builtin_amdgcn_wave_barrier();
     };
@@ -334,7 +347,9 @@ __global__ __launch_bounds__(NT) void gd_ltile2_kernel(Job job)
         const bool inb = idx < nrd;
         const int32_t p = inb ? gpos[idx] : 0x7fffffff;
         const int32_t e = inb ? gend[idx] : -1;
-        const bool hit = e >= t0 && p < tend;                 // reaches t0-1 or beyond
+        bool hit = e >= t0 && p < tend;                       // reaches t0-1 or beyond
+        if (hit)                                              // the read filter of `samtools depth` (few lanes get here)
+            hit = ((uint32_t)gflag[idx] & job.flag_mask) == 0u && (int)gmapq[idx] >= job.Q;
         uint32_t o0 = 0, n = 0;
         if (hit) {
             o0 = goff[idx]; n = goff[idx + 1] - o0;

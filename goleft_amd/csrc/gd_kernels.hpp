@@ -53,10 +53,11 @@ struct ContigDev {
     int64_t  base_off;        // element offset of this contig in the per-base array
     int64_t  win_off;         // element offset in the window arrays
     int32_t  tid;             // reference id in the BAM header
-    uint32_t unit_beg;        // first 64-read unit of this contig (scatter / chunk paths)
-    int64_t  ck_off;          // chunk path: element offset of this contig's checkpoints in Job::ck
-    int64_t  read_off;        // chunk path: element offset of this contig's reads in Job::rend
+    uint32_t unit_beg;        // first 64-read unit of this contig (scatter path)
+    const uint32_t* ck;       // long-read path: checkpoints of `cigar` (gd_ckpt_kernel), built when the records arrive
+    const int32_t*  rend;     // long-read path: end position of every read
     const uint32_t* rec;      // record words (gd_normalize.hpp) of the canonical records, null otherwise
+    const uint32_t* pidx;     // position index (gd_pidx_kernel): first read with pos >= 64 k; null: search `pos`
 };
 
 // Everything a workgroup needs for its tile in ONE record (one scalar load
@@ -142,9 +143,6 @@ struct Job {
     int64_t   step;
     uint32_t  n_units;        // scatter path: 64-read units over all contigs
     unsigned long long* tile_status;   // scatter path: look-back status word per tile
-    uint32_t* ck;             // chunk path: reference position at every 64th CIGAR op of a read
-    int32_t*  rend;           // chunk path: end position of every read (-1: filtered out)
-    int32_t   lookback_dev;   // chunk path: look-back = counters->max_span (written by gd_ckpt_kernel)
     uint32_t  w_magic, w_shift;   // floor(x / W)    = (x * w_magic) >> w_shift for x < 2^31
     uint32_t  s_magic, s_shift;   // floor(x / step) likewise (step clamped to 2^31-1)
     uint32_t  fast;               // 1: ordinary tiles get a TileFast record, the rest go to the slow list
@@ -220,12 +218,9 @@ __global__ void gd_prep_kernel(Job job)
         job.win_min[w] = 0x7fffffff;
     }
     for (int64_t g = gid; g < (job.n_tiles + SUPER - 1) / SUPER; g += gsz) job.super_cnt[g] = 0;
-    // chunk path: the exact maximum span is already on the device (no host round trip)
-    const int32_t lookback = job.lookback_dev
-        ? __hip_atomic_load(&job.counters->max_span, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-        : job.lookback;
+    const int32_t lookback = job.lookback;   // long-read path: the exact maximum span, known since the records arrived
     if (gid == 0) {
-        if (!job.lookback_dev) job.counters->max_span = 0;
+        job.counters->max_span = 0;
         job.counters->run_cursor = 0;
         job.counters->n_slow[job.parity ^ 1u] = 0;
     }
@@ -248,7 +243,17 @@ __global__ void gd_prep_kernel(Job job)
     ti.t0 = (t - c.tile_beg) * T;
     int32_t tend = ti.t0 + T < c.length ? ti.t0 + T : c.length;
     int32_t from = ti.t0 > lookback ? ti.t0 - lookback : 0;
-    lower_bound_pair(c.pos, c.n_reads, from, tend, ti.lo, ti.hi);
+    if (c.pidx) {
+        // the index answers both searches: the look-back start rounded DOWN to a multiple of 64 (a few more
+        // reads examined, never fewer), the tile end exactly (T is a multiple of 64; the clipped last tile of a
+        // contig searches the one 64-position bucket its end lies in)
+        ti.lo = c.pidx[from >> 6];
+        const uint32_t k = (uint32_t)tend >> 6;
+        const uint32_t a = c.pidx[k];
+        ti.hi = (tend & 63) == 0 ? a : a + lower_bound_i32(c.pos + a, c.pidx[k + 1] - a, tend);
+    } else {
+        lower_bound_pair(c.pos, c.n_reads, from, tend, ti.lo, ti.hi);
+    }
     ti.clo = c.n_reads ? c.off[ti.lo] : 0u;
     ti.chi = c.n_reads ? c.off[ti.hi] : 0u;
     if (!job.fast) { job.tiles[t] = ti; return; }

@@ -90,6 +90,72 @@ __device__ __forceinline__ uint32_t canonical_walk(const uint32_t* __restrict__ 
     return cnt;
 }
 
+
+// The same canonical form, built by a whole WAVE for one read: lane k takes op b + k of every group of 64
+// ops.  Long reads (ONT / PacBio: 10^3..10^5 ops) make the one-lane walk above serial and uncoalesced;
+// here the kept ops (reference consuming, length >= 1) of a group are classified in parallel, a lane
+// whose kind differs from the kept op before it (the open run carried in for the first one) is the HEAD
+// of a new run and closes the run before it; run lengths are differences of one wave prefix sum.  Trailing
+// N runs are never closed by a head, i.e. dropped, as canonical_walk drops them.
+// Returns the number of canonical ops (wave uniform); WRITE: stores them at out[0 ..).  `overflow` is set
+// (and the result is meaningless) when a merged run would not fit the 28-bit length field or an op is
+// longer than 2^22 bases -- input no aligner writes; the caller then walks that read with canonical_walk,
+// which splits such runs.  Count and write passes take the same decision, both depend on the ops only.
+template <bool WRITE>
+__device__ __forceinline__ uint32_t wave_canonical(const uint32_t* __restrict__ ops, uint32_t n, int lane,
+                                                   uint32_t* __restrict__ out, bool& overflow)
+{
+    uint32_t open_kind = 2u, open_len = 0u, w = 0u;            // wave uniform: the run still open, runs closed
+    overflow = false;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    for (uint32_t b = 0; b < n; b += 64u) {
+        const uint32_t k = b + (uint32_t)lane;
+        const uint32_t cg = k < n ? ops[k] : 0u;
+        const uint32_t op = cg & 0xfu, len = cg >> 4;
+        const bool kept = ((0x18du >> op) & 1u) && len != 0u;    // M D N = X, not empty
+        const uint32_t kind = ((0x181u >> op) & 1u) ? 0u : 1u;   // 0: counted (M = X), 1: skipped (D N)
+        const unsigned long long km = __builtin_amdgcn_ballot_w64(kept);
+        if (km == 0ull) continue;
+        if (__builtin_amdgcn_ballot_w64(kept && len > (1u << 22)) != 0ull) { overflow = true; return 0u; }
+        const unsigned long long nm = __builtin_amdgcn_ballot_w64(kept && kind == 1u);
+        const unsigned long long pm = km & below;                // kept lanes before this one
+        uint32_t pk = open_kind;
+        if (pm != 0ull) pk = (uint32_t)((nm >> (63 - __clzll((long long)pm))) & 1ull);
+        const bool head = kept && kind != pk;
+        const unsigned long long hm = __builtin_amdgcn_ballot_w64(head);
+        const uint32_t kl = kept ? len : 0u;
+        const uint32_t S = (uint32_t)wave_inclusive_scan((int)kl);   // <= 64 * 2^22
+        const uint32_t E = S - kl;
+        const uint32_t gtot = (uint32_t)__builtin_amdgcn_readlane((int)S, 63);
+        if (hm == 0ull) {                                        // the open run goes on
+            open_len += gtot;                                    // both <= 2^28: no wrap
+            if (open_len > LEN_MAX) { overflow = true; return 0u; }
+            continue;
+        }
+        const bool open_exists = open_kind != 2u;
+        const unsigned long long hb = hm & below;                // heads before this lane
+        const uint32_t q = (uint32_t)__popcll(hb);
+        const int ph = hb != 0ull ? 63 - __clzll((long long)hb) : 0;
+        const uint32_t Eph = (uint32_t)__shfl((int)E, ph, 64);   // where the run this head closes began
+        const uint32_t tot = q == 0u ? open_len + E : E - Eph;
+        const bool closes = head && (q != 0u || open_exists);
+        if (__builtin_amdgcn_ballot_w64(closes && tot > LEN_MAX) != 0ull) { overflow = true; return 0u; }
+        if (WRITE && closes)                                     // kinds alternate: the closed run is of the other kind
+            out[w + q - (open_exists ? 0u : 1u)] = (tot << 4) | (kind == 0u ? 3u : 0u);
+        const int lh = __builtin_amdgcn_readfirstlane(63 - __clzll((long long)hm));
+        open_kind = (uint32_t)__builtin_amdgcn_readlane((int)kind, lh);
+        open_len = gtot - (uint32_t)__builtin_amdgcn_readlane((int)E, lh);
+        w += (uint32_t)__popcll(hm) - (open_exists ? 0u : 1u);
+    }
+    if (open_kind == 0u) {                                       // a trailing N run is dropped
+        if (WRITE && lane == 0) out[w] = open_len << 4;
+        ++w;
+    }
+    return w;
+}
+
+constexpr uint32_t WAVE_WALK_MIN = 24;     // reads with more ops than this are walked by the whole wave
+
 // N1: count.  One wave per unit of 64 consecutive reads.
 __global__ __launch_bounds__(256) void gd_norm_count_kernel(NormJob j)
 {
@@ -97,11 +163,20 @@ __global__ __launch_bounds__(256) void gd_norm_count_kernel(NormJob j)
     const uint32_t unit = blockIdx.x * 4u + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (unit >= j.n_units) return;
     const uint32_t r = unit * 64u + (uint32_t)lane;
-    uint32_t cnt = 0;
-    if (r < j.n_reads) {
-        const uint32_t o0 = j.off[r], n = j.off[r + 1] - o0;
-        cnt = canonical_walk(j.cigar + o0, n, [](uint32_t, uint32_t) {});
+    uint32_t cnt = 0, o0 = 0, n = 0;
+    if (r < j.n_reads) { o0 = j.off[r]; n = j.off[r + 1] - o0; }
+    bool serial = n <= WAVE_WALK_MIN;
+    unsigned long long todo = __builtin_amdgcn_ballot_w64(!serial);
+    while (todo != 0ull) {                                    // long reads: the wave walks one at a time
+        const int jl = __ffsll((long long)todo) - 1;
+        todo &= todo - 1ull;
+        const uint32_t oj = (uint32_t)__builtin_amdgcn_readlane((int)o0, jl);
+        const uint32_t nj = (uint32_t)__builtin_amdgcn_readlane((int)n, jl);
+        bool ovf;
+        const uint32_t cw = wave_canonical<false>(j.cigar + oj, nj, lane, nullptr, ovf);
+        if (lane == jl) { cnt = cw; serial = ovf; }
     }
+    if (serial && n != 0u) cnt = canonical_walk(j.cigar + o0, n, [](uint32_t, uint32_t) {});
     const uint32_t incl = (uint32_t)wave_inclusive_scan((int)cnt);
     if (r < j.n_reads) {
         j.noff[r] = incl - cnt;                             // offset inside the unit, completed by N3
@@ -144,14 +219,51 @@ __global__ __launch_bounds__(256) void gd_norm_write_kernel(NormJob j)
     const uint32_t unit = blockIdx.x * 4u + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (unit >= j.n_units) return;
     const uint32_t r = unit * 64u + (uint32_t)lane;
-    if (r >= j.n_reads) return;
-    const uint32_t dst0 = j.unit[unit] + j.noff[r];
-    j.noff[r] = dst0;
-    if (r + 1u == j.n_reads) j.noff[j.n_reads] = j.unit[j.n_units];
-    const uint32_t o0 = j.off[r], n = j.off[r + 1] - o0;
-    uint32_t* out = j.ncig + dst0;
-    uint32_t w = 0;
-    canonical_walk(j.cigar + o0, n, [&](uint32_t op, uint32_t len) { out[w++] = (len << 4) | op; });
+    const bool valid = r < j.n_reads;
+    uint32_t dst0 = 0, o0 = 0, n = 0;
+    if (valid) {
+        dst0 = j.unit[unit] + j.noff[r];
+        j.noff[r] = dst0;
+        if (r + 1u == j.n_reads) j.noff[j.n_reads] = j.unit[j.n_units];
+        o0 = j.off[r]; n = j.off[r + 1] - o0;
+    }
+    bool serial = n <= WAVE_WALK_MIN;
+    unsigned long long todo = __builtin_amdgcn_ballot_w64(!serial);
+    while (todo != 0ull) {
+        const int jl = __ffsll((long long)todo) - 1;
+        todo &= todo - 1ull;
+        const uint32_t oj = (uint32_t)__builtin_amdgcn_readlane((int)o0, jl);
+        const uint32_t nj = (uint32_t)__builtin_amdgcn_readlane((int)n, jl);
+        const uint32_t dj = (uint32_t)__builtin_amdgcn_readlane((int)dst0, jl);
+        bool ovf;
+        (void)wave_canonical<true>(j.cigar + oj, nj, lane, j.ncig + dj, ovf);
+        if (lane == jl) serial = ovf;                         // (what it wrote before noticing is overwritten below)
+    }
+    if (serial && n != 0u) {
+        uint32_t* out = j.ncig + dst0;
+        uint32_t w = 0;
+        canonical_walk(j.cigar + o0, n, [&](uint32_t op, uint32_t len) { out[w++] = (len << 4) | op; });
+    }
+}
+
+// P: the position index of a contig's (coordinate sorted) records, built with the canonical CIGARs when the
+// records arrive: pidx[k] = first read with pos >= 64 k, for k = 0 .. (length >> 6) + 1.  gd_prep_kernel
+// looks a tile's read range up in it instead of searching `pos` (two dependent chains of ~15 loads per tile,
+// 0.29 ms per genome: 7 % of a step).  4 bytes per 64 reference positions (194 MB for hg19).  One thread per
+// entry, a plain binary search each: latency bound, but wide, and paid once per ingest.
+__global__ __launch_bounds__(256) void gd_pidx_kernel(const int32_t* __restrict__ pos, uint32_t n_reads,
+                                                      uint32_t* __restrict__ pidx, uint32_t n_idx)
+{
+    const uint32_t k = blockIdx.x * 256u + threadIdx.x;
+    if (k >= n_idx) return;
+    const uint64_t key = (uint64_t)k << 6;
+    uint32_t lo = 0, hi = n_reads;
+    if (key > 0x7fffffffull) lo = n_reads;              // every position is below it
+    while (lo < hi) {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        if (pos[mid] < (int32_t)key) lo = mid + 1; else hi = mid;
+    }
+    pidx[k] = lo;
 }
 
 }  // namespace norm

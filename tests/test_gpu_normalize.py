@@ -120,3 +120,40 @@ def test_normalisation_is_ingest_time_not_compute_time():
         raw_single = float((np.diff(r.cigar_off) == 1).mean())
         assert single > raw_single + 0.04               # soft clips and insertions became single-op reads
         assert np.array_equal(eng.perbase(0), po.perbase_c(r, 1, 0, L))
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_wave_walked_canonical_cigars_equal_restatement(seed):
+    """Reads with more than 24 ops are normalised by a whole wave (runs spanning the 64-op groups, leading and
+    trailing D/N runs, zero-length ops, a long N skip); shorter ones in the same 64-read unit by one lane."""
+    rng = np.random.default_rng(100 + seed)
+    L = 4_000_000
+    n_ops = [int(x) for x in rng.choice([0, 1, 7, 24, 25, 63, 64, 65, 127, 128, 129, 500, 4097, 9000], size=150)]
+    r = H.long_cigar_reads(rng, L, n_ops, max_step=25, skip_every=7)
+    # a read of D/N ops only, one that starts and ends with deletions, a pure-M run across three groups
+    cig = r.cigar.copy()
+    o = r.cigar_off
+    for i, n in enumerate(n_ops):
+        if n >= 129 and i % 3 == 0:
+            cig[o[i]:o[i] + 3] = [(5 << 4) | 2, (6 << 4) | 3, (0 << 4) | 2]
+            cig[o[i + 1] - 2:o[i + 1]] = [(9 << 4) | 2, (4 << 4) | 3]
+        if n == 500 and i % 2 == 0:
+            cig[o[i]:o[i + 1]] = (rng.integers(1, 30, size=n).astype(np.uint32) << 4) | rng.choice([0, 7, 8, 1], size=n).astype(np.uint32)
+        if n == 127:
+            cig[o[i]:o[i + 1]] = (rng.integers(0, 30, size=n).astype(np.uint32) << 4) | rng.choice([2, 3, 1, 4], size=n).astype(np.uint32)
+    r = po.Reads(r.pos, r.flag, r.mapq, r.cigar_off, cig)
+    from goleft_amd import engine as E
+    with E.DepthEngine(0) as eng:
+        eng.set_params(window_size=1000)
+        eng.set_path(3)                                      # GD_PATH_CHUNK
+        eng.set_contigs([L])
+        eng.push(0, r.pos, r.flag, r.mapq, r.cigar_off, r.cigar)
+        eng.compute()
+        off, cig_got = eng.canonical_cigars(0, r.n)
+        st = eng.stats()
+        got = eng.perbase(0)
+    woff, wcig = po.canonical_cigars(r)
+    assert np.array_equal(off, woff)
+    assert np.array_equal(cig_got, wcig)
+    assert st.path == 3 and st.n_canonical_ops == len(wcig)
+    assert np.array_equal(got, po.perbase_c(r, 1, 0, L))
