@@ -62,6 +62,8 @@ def parse():
     ap.add_argument("--cpu-sample-contigs", type=int, default=8)
     ap.add_argument("--no-host-stream", action="store_true",
                     help="skip the PCIe-inclusive scope (host records -> pinned ring -> results on host)")
+    ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE",
+                    help="experiments only: gd_set_option(KEY, VALUE) on the engine (include/goleft_depth.h GD_OPT_*)")
     ap.add_argument("--verify", action="store_true",
                     help="check one contig against the CPU oracle after timing")
     return ap.parse_args()
@@ -205,6 +207,9 @@ def run_case(args, scaling, world, rank, dev, local_rank, want_streams=False):
     # ---- synthetic record streams, generated on device, adopted zero-copy ----
     eng = DepthEngine(local_rank)
     eng.set_params(window_size=W, min_mapq=Q, min_cov=mincov)
+    for kv in args.opt:
+        k, v = kv.split("=")
+        eng.set_option(int(k), int(v))
     if cohort:
         # depthwed only needs window sums: GD_OUT_SUMS_ONLY (read/window overlaps, no per-base scan);
         # --cohort-outputs windows keeps minima and class runs (the regular windows-only kernel)

@@ -44,7 +44,15 @@ SYMBOLS = {
     "gdh_intervals_free": (None, [_P]),
     "gdh_intervals_overlaps": (C.c_int, [_P, C.c_char_p, C.c_int64, C.c_int64]),
     "gdh_intervals_count": (C.c_size_t, [_P, C.c_char_p]),
+    "gdh_set_stats_contract": (C.c_int, [C.c_int]),
+    "gdh_get_stats_contract": (C.c_int, []),
+    "gdh_format_stats": (C.c_int, [C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_uint32, C.c_uint32, C.c_uint32,
+                                   C.c_uint32, C.c_uint32, C.c_char_p, C.c_size_t]),
 }
+
+# the forks of the `--stats` contract (include/goleft_depth_host.h)
+STATS_DENOM_ACGT, STATS_MASKED_ACGT, STATS_CPG_CLAMP, STATS_CPG_RAW_LINES = 1, 2, 4, 8
+STATS_WINDOW, STATS_FAIDX = 0, 15
 
 _LIB = None
 
@@ -63,6 +71,23 @@ def load():
         fn.argtypes = args
     _LIB = lib
     return lib
+
+
+def set_stats_contract(contract: int) -> None:
+    """gdh_set_stats_contract: which reading of faidx.Stats `goleft depth --stats` prints (STATS_* above)."""
+    if load().gdh_set_stats_contract(int(contract)) != 0:
+        raise ValueError("stats contract %r" % (contract,))
+
+
+def get_stats_contract() -> int:
+    return int(load().gdh_get_stats_contract())
+
+
+def format_stats(contract, known, start, end, n_gc, n_cpg, n_masked, n_acgt, n_masked_acgt) -> str:
+    buf = C.create_string_buffer(128)
+    load().gdh_format_stats(int(contract), int(known), int(start), int(end), int(n_gc), int(n_cpg), int(n_masked),
+                            int(n_acgt), int(n_masked_acgt), buf, 128)
+    return buf.value.decode()
 
 
 def chrom_start_end(line: bytes):

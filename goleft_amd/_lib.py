@@ -70,6 +70,7 @@ SYMBOLS = {
     "gd_depthwed_device": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int64, C.POINTER(_P), C.POINTER(C.c_size_t)]),
     "gd_seq_load": (C.c_int, [_P, _P, C.c_int64]),
     "gd_seq_stats": (C.c_int, [_P, C.c_size_t, _P, _P, _P, _P, _P]),
+    "gd_seq_stats_ex": (C.c_int, [_P, C.c_size_t, _P, _P, C.c_int32, _P, _P, _P, _P, _P]),
     "gd_md_flags": (C.c_int, [_P, C.c_int, _P, C.c_int32, C.c_int32, _P, _P, C.c_size_t]),
     "gd_md_sums": (C.c_int, [_P, C.c_size_t, _P, _P, _P]),
     "gd_inflate_bgzf": (C.c_int, [_P, _P, C.c_size_t, C.c_size_t, _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),

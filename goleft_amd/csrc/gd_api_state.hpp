@@ -36,7 +36,7 @@ struct ContigHost {
     uint32_t* pidx = nullptr;          // position index: pidx[k] = first read with pos >= 64 k, k = 0 .. (length >> 6) + 1
     // long-read path (gd_chunk.hpp): checkpoints of the CIGARs above (the canonical ones when normed), read ends
     uint32_t* ck = nullptr;            // (ops >> 6) + n_reads + 1 slots
-    int32_t*  rend = nullptr;          // n_reads + 1: end position per read; [n_reads] = the largest span
+    uint4*    lrec = nullptr;          // n_reads + 2 long-read records {pos, end, off, flag << 8 | MAPQ}; [n_reads + 1].x = the largest span
     int32_t   max_span = 0;
     bool ck_ok = false;                // ck / rend describe the current records
     // layout in the result arrays of the last compute (-1 = not computed)
@@ -219,8 +219,8 @@ int ensure_dev(gd_ctx* c, Tp** p, size_t* cap, size_t need, bool keep = false, s
 void drop_ck(ContigHost& h)
 {
     if (h.ck) (void)hipFree(h.ck);
-    if (h.rend) (void)hipFree(h.rend);
-    h.ck = nullptr; h.rend = nullptr;
+    if (h.lrec) (void)hipFree(h.lrec);
+    h.ck = nullptr; h.lrec = nullptr;
     h.max_span = 0;
     h.ck_ok = false;
 }
@@ -355,18 +355,19 @@ int build_ck(gd_ctx* c, ContigHost& h)
     HIPCHK(c, hipEventRecord(c->copy_done, c->copy_stream));
     HIPCHK(c, hipStreamWaitEvent(c->stream, c->copy_done, 0));
     HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&h.ck), ((n_ops >> 6) + (size_t)n_reads + 1) * sizeof(uint32_t)));
-    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&h.rend), ((size_t)n_reads + 1) * sizeof(int32_t)));
-    HIPCHK(c, hipMemsetAsync(h.rend + n_reads, 0, sizeof(int32_t), c->stream));
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&h.lrec), ((size_t)n_reads + 2) * sizeof(uint4)));
+    HIPCHK(c, hipMemsetAsync(h.lrec + n_reads, 0, 2 * sizeof(uint4), c->stream));
     gd::CkJob j{};
     j.pos = h.pos; j.off = h.normed ? h.noff : h.off; j.cigar = h.normed ? h.ncig : h.cigar;
     j.n_reads = n_reads; j.n_units = n_units;
-    j.ck = h.ck; j.rend = h.rend; j.max_span = h.rend + n_reads;
+    j.flag = h.flag; j.mapq = h.mapq;
+    j.ck = h.ck; j.lrec = h.lrec; j.max_span = reinterpret_cast<int32_t*>(h.lrec + n_reads + 1);
     if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
     if (n_units) hipLaunchKernelGGL(gd::gd_ckpt_kernel, dim3((n_units + 3u) / 4u), dim3(256), 0, c->stream, j);
     HIPCHK(c, hipGetLastError());
     if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
     int32_t span = 0;
-    HIPCHK(c, hipMemcpyAsync(&span, h.rend + n_reads, sizeof span, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(&span, h.lrec + n_reads + 1, sizeof span, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->profiling) {
         float ms = 0;

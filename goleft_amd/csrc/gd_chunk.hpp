@@ -49,8 +49,12 @@ struct CkJob {
     const uint32_t* cigar;
     uint32_t  n_reads;
     uint32_t  n_units;        // ceil(n_reads / 64)
+    const uint16_t* flag;
+    const uint8_t*  mapq;
     uint32_t* ck;             // (n_ops >> 6) + n_reads + 1 slots
-    int32_t*  rend;           // n_reads: reference position after the last op (== pos: no ops)
+    uint4*    lrec;           // n_reads + 1 long-read records {pos, end, off, flag << 8 | MAPQ}: everything the
+                              // tile kernel asks about a candidate read in ONE 16-byte load (end = reference
+                              // position after the last op, == pos without ops; [n_reads] = {0, 0, n_ops, 0})
     int32_t*  max_span;       // atomicMax of end - pos
 };
 
@@ -65,11 +69,12 @@ __global__ __launch_bounds__(256) void gd_ckpt_kernel(CkJob job)
 
     const uint32_t r = unit * 64u + (uint32_t)lane;
     const bool valid = r < n_reads;
-    uint32_t p = 0, o0 = 0, n = 0;
+    uint32_t p = 0, o0 = 0, n = 0, fq = 0;
     if (valid) {
         p = (uint32_t)job.pos[r];
         o0 = job.off[r];
         n = job.off[r + 1] - o0;
+        fq = ((uint32_t)job.flag[r] << 8) | (uint32_t)job.mapq[r];
     }
     const bool keep = n != 0u;
     uint32_t endp = p;                                    // reference position after the last op
@@ -138,7 +143,10 @@ __global__ __launch_bounds__(256) void gd_ckpt_kernel(CkJob job)
         }
         if (lane == j) endp = run;
     }
-    if (valid) job.rend[r] = (int32_t)endp;
+    if (valid) {
+        job.lrec[r] = make_uint4(p, endp, o0, fq);
+        if (r + 1u == n_reads) job.lrec[n_reads] = make_uint4(0u, 0u, o0 + n, 0u);
+    }
     const uint32_t smax = wave_max_u32(keep ? endp - p : 0u);
     if (lane == 0 && smax != 0u) atomicMax(job.max_span, (int32_t)smax);
 }
@@ -275,18 +283,13 @@ __global__ __launch_bounds__(NT) void gd_ltile2_kernel(Job job)
     const int lane = tid & (WAVE - 1);
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const TileInfo ti = job.tiles[tile];
-    const ContigDev& c = job.ctgs[ti.ctg];
-    const uint32_t* const ck = c.ck;
+    const uint32_t* const ck = ti.ck;
     const int32_t t0 = ti.t0;
     const int32_t tend = t0 + T < ti.length ? t0 + T : ti.length;
     const int tlen = tend - t0;
 
     const uint32_t nrd = ti.hi - ti.lo;
-    const int32_t* const gpos = ti.pos + ti.lo;
-    const int32_t* const gend = c.rend + ti.lo;
-    const uint16_t* const gflag = ti.flag + ti.lo;
-    const uint8_t* const gmapq = ti.mapq + ti.lo;
-    const uint32_t* const goff = ti.off + ti.lo;
+    const uint4* const grec = ti.lrec + ti.lo;
     const uint32_t* const cigar = ti.cigar;
 
     {
@@ -345,14 +348,17 @@ __global__ __launch_bounds__(NT) void gd_ltile2_kernel(Job job)
     for (uint32_t base = 0; base < nrd; base += (uint32_t)NT) {
         const uint32_t idx = base + (uint32_t)(lane * NW + wv);
         const bool inb = idx < nrd;
-        const int32_t p = inb ? gpos[idx] : 0x7fffffff;
-        const int32_t e = inb ? gend[idx] : -1;
-        bool hit = e >= t0 && p < tend;                       // reaches t0-1 or beyond
-        if (hit)                                              // the read filter of `samtools depth` (few lanes get here)
-            hit = ((uint32_t)gflag[idx] & job.flag_mask) == 0u && (int)gmapq[idx] >= job.Q;
+        // one round trip per candidate: its record and the next one's CIGAR offset
+        uint4 rc = make_uint4(0x7fffffffu, 0u, 0u, 0u);
+        uint32_t o1 = 0;
+        if (inb) { rc = grec[idx]; o1 = grec[idx + 1u].z; }
+        const int32_t p = (int32_t)rc.x;
+        const int32_t e = inb ? (int32_t)rc.y : -1;
+        // reaches t0-1 or beyond, and passes the read filter of `samtools depth`
+        const bool hit = e >= t0 && p < tend && ((rc.w >> 8) & job.flag_mask) == 0u && (int)(rc.w & 0xffu) >= job.Q;
         uint32_t o0 = 0, n = 0;
         if (hit) {
-            o0 = goff[idx]; n = goff[idx + 1] - o0;
+            o0 = rc.z; n = o1 - o0;
             // the read's own +1 / -1 (its D/N ops subtract below)
             const int rs = p - t0;
             atomicAdd(&s_diff[rs > -1 ? rs : -1], 1);

@@ -11,8 +11,13 @@
 //   gc     = #{i in [s,e) : seq[i] in "GCgc"}
 //   masked = #{i in [s,e) : 'a' <= seq[i] <= 'z'}
 //   cpg    = #{i in [s,e) : seq[i] in "Cc" and i+1 < len and seq[i+1] in "Gg"}
-// with [s,e) clipped to the contig.  The kernel returns the three integer
-// counts; the three divisions by (e - s) and the %.3g stay on the host.
+// with [s,e) clipped to the contig.  Because the contract is a restatement from memory, the kernel also
+// returns what the OTHER plausible reading of faidx.Stats needs (include/goleft_depth_host.h, GDH_STATS_*):
+//   acgt        = #{i : seq[i] in "ACGTacgt"}            (a denominator that skips N and IUPAC codes)
+//   masked_acgt = #{i : seq[i] in "acgt"}
+// and can ignore a CpG whose C is the last base of a FASTA line (line_bases > 0): a scan of the raw, line
+// broken file -- which is what a memory-mapped faidx does -- sees "C\nG" there, not "CG".
+// The kernel returns integer counts; the divisions and the %.3g stay on the host.
 //
 // One wave per window.  HBM-bound: 1 byte per reference base read once, 12 bytes
 // per window written.  Lanes read aligned 32-bit words through a buffer
@@ -31,7 +36,10 @@ struct SeqStatsJob {
     uint32_t* gc;              // [n_win]
     uint32_t* cpg;
     uint32_t* masked;
+    uint32_t* acgt;            // null: not wanted
+    uint32_t* masked_acgt;     // null: not wanted
     int64_t  n_win;
+    uint32_t line_bases;       // > 0: bases per FASTA line; a C at the end of a line never starts a CpG
 };
 
 // bit 7 of every byte of x that is zero (exact: no carries between bytes)
@@ -58,7 +66,8 @@ __global__ __launch_bounds__(256) void gd_seq_stats_kernel(SeqStatsJob job)
     int64_t s = job.win_start[w], e = job.win_end[w];
     s = s < 0 ? 0 : s;
     e = e > job.len ? job.len : e;
-    uint32_t n_gc = 0, n_cpg = 0, n_low = 0;
+    uint32_t n_gc = 0, n_cpg = 0, n_low = 0, n_acgt = 0, n_lacgt = 0;
+    const uint32_t lb = job.line_bases;
     if (e > s) {
         // bytes past the contig are 0 (never a base), so the look-ahead at the contig end
         // needs no special case
@@ -80,15 +89,32 @@ __global__ __launch_bounds__(256) void gd_seq_stats_kernel(SeqStatsJob job)
             const uint32_t ge_a = (x7 + 0x1f1f1f1fu) & 0x80808080u;                  // low 7 bits >= 'a'
             const uint32_t gt_z = (x7 + 0x05050505u) & 0x80808080u;                  // low 7 bits >  'z'
             const uint32_t low = ge_a & ~gt_z & ~x;                                  // and bit 7 clear
+            const uint32_t is_at = zero_bytes(y ^ 0x61616161u) | zero_bytes(y ^ 0x74747474u);
+            const uint32_t acgt = (is_c | is_g | is_at) & in;
+            uint32_t not_eol = 0x80808080u;                                          // bases that are not the last of a line
+            if (lb != 0u) {
+                const uint32_t r0 = (uint32_t)(p0 % (int64_t)lb);                    // column of byte 0
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if ((r0 + (uint32_t)j) % lb == lb - 1u) not_eol &= ~(0x80u << (8 * j));
+            }
             n_gc += __popc((is_c | is_g) & in);
-            n_cpg += __popc(is_c & g_next & in);
+            n_cpg += __popc(is_c & g_next & in & not_eol);
             n_low += __popc(low & in);
+            n_acgt += __popc(acgt);
+            n_lacgt += __popc(acgt & ((x & 0x20202020u) << 2));                      // bit 5: lower case
         }
     }
     n_gc = (uint32_t)wave_total((int)n_gc);
     n_cpg = (uint32_t)wave_total((int)n_cpg);
     n_low = (uint32_t)wave_total((int)n_low);
-    if (lane == 0) { job.gc[w] = n_gc; job.cpg[w] = n_cpg; job.masked[w] = n_low; }
+    n_acgt = (uint32_t)wave_total((int)n_acgt);
+    n_lacgt = (uint32_t)wave_total((int)n_lacgt);
+    if (lane == 0) {
+        job.gc[w] = n_gc; job.cpg[w] = n_cpg; job.masked[w] = n_low;
+        if (job.acgt) job.acgt[w] = n_acgt;
+        if (job.masked_acgt) job.masked_acgt[w] = n_lacgt;
+    }
 }
 
 }  // namespace gd

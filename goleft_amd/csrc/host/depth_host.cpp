@@ -589,6 +589,8 @@ int run(const DArgs& args)
     // gd_seq_stats call counts GC / CpG / lower-case bases of every emitted window
     std::string seq_chrom, seq_bases;
     bool seq_known = false;
+    int64_t seq_line_bases = 0;
+    const int stats_contract = gdh_get_stats_contract();
     int stats_rc = GD_OK;
     gd_ctx* const seq_ctx = S.v[0].ctx;              // --stats: the FASTA windows are counted on the first device
     auto emit_region = [&](const char* chrom, int64_t rs, int64_t re, const int64_t* su, size_t n_su,
@@ -599,23 +601,24 @@ int run(const DArgs& args)
         format_region(&probe, chrom, rs, re, W, su, n_su, ru, n_ru, &sp);
         if (seq_chrom != chrom || seq_chrom.empty()) {
             seq_chrom = chrom;
-            seq_known = fa->contig_bases(chrom, &seq_bases);
+            seq_known = fa->contig_bases(chrom, &seq_bases, &seq_line_bases);
             if (seq_known && stats_rc == GD_OK)
                 stats_rc = gd_seq_load(seq_ctx, reinterpret_cast<const uint8_t*>(seq_bases.data()), (int64_t)seq_bases.size());
             seq_bases.clear();
             seq_bases.shrink_to_fit();
         }
         const size_t n = sp.s.size();
-        std::vector<uint32_t> gc(n, 0), cpg(n, 0), low(n, 0);
-        if (seq_known && n && stats_rc == GD_OK)
-            stats_rc = gd_seq_stats(seq_ctx, n, sp.s.data(), sp.e.data(), gc.data(), cpg.data(), low.data());
+        std::vector<uint32_t> gc(n, 0), cpg(n, 0), low(n, 0), acgt(n, 0), lacgt(n, 0);
+        if (seq_known && n && stats_rc == GD_OK) {
+            const bool raw = (stats_contract & GDH_STATS_CPG_RAW_LINES) && seq_line_bases > 0 && seq_line_bases < 0x7fffffff;
+            stats_rc = gd_seq_stats_ex(seq_ctx, n, sp.s.data(), sp.e.data(), raw ? (int32_t)seq_line_bases : 0,
+                                       gc.data(), cpg.data(), low.data(), acgt.data(), lacgt.data());
+        }
         sp.cols.resize(n);
         for (size_t k = 0; k < n; ++k) {
-            const double tot = (double)(sp.e[k] - sp.s[k]);
-            const bool ok = seq_known && sp.e[k] > sp.s[k];
             char buf[96];
-            snprintf(buf, sizeof buf, "\t%.3g\t%.3g\t%.3g", ok ? gc[k] / tot : 0.0, ok ? 2.0 * cpg[k] / tot : 0.0,
-                     ok ? low[k] / tot : 0.0);                               // :199
+            gdh_format_stats(stats_contract, seq_known ? 1 : 0, sp.s[k], sp.e[k], gc[k], cpg[k], low[k], acgt[k], lacgt[k],
+                             buf, sizeof buf);                               // :199
             sp.cols[k] = buf;
         }
         sp.collecting = false;

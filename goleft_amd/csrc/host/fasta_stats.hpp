@@ -37,12 +37,14 @@ public:
     }
 
     // All bases of one contig, line breaks removed; false when the contig is not in the .fai.
-    bool contig_bases(const std::string& chrom, std::string* out)
+    // line_bases (optional): the .fai LINEBASES column of the contig.
+    bool contig_bases(const std::string& chrom, std::string* out, int64_t* line_bases = nullptr)
     {
         out->clear();
         auto it = idx_.find(chrom);
         if (it == idx_.end()) return false;
         fetch(it->second, 0, it->second.len, out);
+        if (line_bases) *line_bases = it->second.lb;
         return true;
     }
 

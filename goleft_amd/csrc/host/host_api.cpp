@@ -31,7 +31,55 @@ struct gdh_intervals {
     std::map<std::string, Set> by_chrom;
 };
 
+namespace {
+// the `--stats` contract of this process (include/goleft_depth_host.h GDH_STATS_*): GOLEFT_STATS_CONTRACT
+// at first use, gdh_set_stats_contract afterwards
+int g_stats_contract = -1;
+int stats_contract_from_env()
+{
+    const char* e = getenv("GOLEFT_STATS_CONTRACT");
+    if (!e || !*e || !strcmp(e, "faidx")) return GDH_STATS_FAIDX;
+    if (!strcmp(e, "window")) return GDH_STATS_WINDOW;
+    char* end = nullptr;
+    const long v = strtol(e, &end, 0);
+    if (end == e || *end || v < 0 || (v & ~(long)GDH_STATS_FAIDX)) {
+        fprintf(stderr, "goleft-depth: GOLEFT_STATS_CONTRACT=%s is not faidx, window or a mask of 0..%d; using faidx\n",
+                e, GDH_STATS_FAIDX);
+        return GDH_STATS_FAIDX;
+    }
+    return (int)v;
+}
+}  // namespace
+
 extern "C" {
+
+int gdh_set_stats_contract(int contract)
+{
+    if (contract < 0 || (contract & ~GDH_STATS_FAIDX)) return -1;
+    g_stats_contract = contract;
+    return 0;
+}
+
+int gdh_get_stats_contract(void)
+{
+    if (g_stats_contract < 0) g_stats_contract = stats_contract_from_env();
+    return g_stats_contract;
+}
+
+int gdh_format_stats(int contract, int known, int64_t start, int64_t end, uint32_t n_gc, uint32_t n_cpg,
+                     uint32_t n_masked, uint32_t n_acgt, uint32_t n_masked_acgt, char* out, size_t cap)
+{
+    // depth/depth.go:191-200; the forks are the named switches of goleft_depth_host.h
+    const double tot = (contract & GDH_STATS_DENOM_ACGT) ? (double)n_acgt : (double)(end - start);
+    double gc = 0, cpg = 0, masked = 0;
+    if (known && end > start && tot > 0) {
+        gc = n_gc / tot;
+        cpg = 2.0 * n_cpg / tot;
+        if ((contract & GDH_STATS_CPG_CLAMP) && cpg > 1.0) cpg = 1.0;
+        masked = ((contract & GDH_STATS_MASKED_ACGT) ? n_masked_acgt : n_masked) / tot;
+    }
+    return snprintf(out, cap, "\t%.3g\t%.3g\t%.3g", gc, cpg, masked);
+}
 
 size_t gdh_plan_ingest_passes(const uint64_t* start, const uint8_t* has, size_t n_refs, const int32_t* wanted,
                               size_t n_wanted, uint64_t file_size, uint64_t group_bytes, size_t cap,

@@ -280,6 +280,17 @@ class DepthEngine:
                                          gc.ctypes.data, cpg.ctypes.data, low.ctypes.data))
         return gc, cpg, low
 
+    def seq_stats_ex(self, starts, ends, line_bases: int = 0):
+        """gd_seq_stats_ex: (n_gc, n_cpg, n_masked, n_acgt, n_masked_acgt) per window; line_bases > 0: a C at the
+        end of a FASTA line starts no CpG (include/goleft_depth_host.h GDH_STATS_CPG_RAW_LINES)."""
+        s = np.ascontiguousarray(starts, np.int64)
+        e = np.ascontiguousarray(ends, np.int64)
+        assert s.shape == e.shape and s.ndim == 1
+        out = [np.empty(s.size, np.uint32) for _ in range(5)]
+        self._chk(self._lib.gd_seq_stats_ex(self._ctx, s.size, s.ctypes.data, e.ctypes.data, int(line_bases),
+                                            *[a.ctypes.data for a in out]))
+        return tuple(out)
+
     def md_flags(self, tids, min_cov: int, min_samples: int):
         """multidepth: (any, suf) boolean arrays over the samples' common contig
         (multidepth/multidepth.go:163-171; bit x of word x // 32 on the wire)."""

@@ -302,6 +302,13 @@ int gd_depthwed_device(gd_ctx* ctx, int n_samples, int n_ctg, const int32_t* tid
 int gd_seq_load(gd_ctx* ctx, const uint8_t* seq, int64_t len);
 int gd_seq_stats(gd_ctx* ctx, size_t n_windows, const int64_t* start, const int64_t* end,
                  uint32_t* n_gc, uint32_t* n_cpg, uint32_t* n_masked);
+/* The same plus what the other plausible reading of faidx.Stats needs (goleft_depth_host.h GDH_STATS_*; the
+ * caller picks the contract, the library only counts): n_acgt = bases in "ACGTacgt" (a denominator that
+ * skips N and IUPAC codes), n_masked_acgt = bases in "acgt"; either may be NULL.  line_bases > 0 (bases per
+ * FASTA line, the .fai LINEBASES column): a C that is the last base of a line does not start a CpG -- what
+ * a scan of the raw, line-broken file sees; 0: the sequence is one line. */
+int gd_seq_stats_ex(gd_ctx* ctx, size_t n_windows, const int64_t* start, const int64_t* end, int32_t line_bases,
+                    uint32_t* n_gc, uint32_t* n_cpg, uint32_t* n_masked, uint32_t* n_acgt, uint32_t* n_masked_acgt);
 
 /* ---- multidepth on device (multidepth/multidepth.go) ----------------------------
  * The S samples are S equally long contigs tids[0..S) of ONE context, computed by

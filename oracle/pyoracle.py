@@ -248,6 +248,34 @@ def seq_stats(seq: bytes, start: int, end: int):
     return gc, cpg, low
 
 
+# the forks of the `--stats` contract (include/goleft_depth_host.h GDH_STATS_*)
+STATS_DENOM_ACGT, STATS_MASKED_ACGT, STATS_CPG_CLAMP, STATS_CPG_RAW_LINES = 1, 2, 4, 8
+STATS_WINDOW, STATS_FAIDX = 0, 15
+
+
+def seq_counts(seq: bytes, start: int, end: int, line_bases: int = 0):
+    """(n_gc, n_cpg, n_masked, n_acgt, n_masked_acgt) of seq[start:end] clipped to the contig -- seq_stats plus
+    what the other reading of faidx.Stats needs: A/C/G/T bases of either case, lower-case a/c/g/t; with
+    line_bases > 0 a C that is the last base of a FASTA line (position % line_bases == line_bases - 1) starts
+    no CpG.  Pure Python, byte by byte; the contract of gd_seq_stats_ex."""
+    s, e = max(0, start), min(end, len(seq))
+    gc = cpg = low = acgt = lacgt = 0
+    for i in range(s, e):
+        c = seq[i]
+        if c in b"GCgc":
+            gc += 1
+        if 0x61 <= c <= 0x7a:
+            low += 1
+        if c in b"ACGTacgt":
+            acgt += 1
+            if c in b"acgt":
+                lacgt += 1
+        eol = line_bases > 0 and i % line_bases == line_bases - 1
+        if c in b"Cc" and not eol and i + 1 < len(seq) and seq[i + 1] in b"Gg":
+            cpg += 1
+    return gc, cpg, low, acgt, lacgt
+
+
 def fmt_g3(x: float) -> str:
     """Go's %.3g for the magnitudes --stats prints (fractions in [0, 2])."""
     t = "%.3g" % x
@@ -257,13 +285,18 @@ def fmt_g3(x: float) -> str:
     return t
 
 
-def stats_columns(seq: bytes, start: int, end: int) -> str:
-    """"\tGC\tCpG\tMasked" as getStats formats them (depth/depth.go:199)."""
-    gc, cpg, low = seq_stats(seq, start, end)
-    tot = float(end - start)
-    if start >= len(seq) or end <= start:
+def stats_columns(seq: bytes, start: int, end: int, contract: int = STATS_FAIDX, line_bases: int = 0) -> str:
+    """"\tGC\tCpG\tMasked" as getStats formats them (depth/depth.go:199) under one of the contracts of
+    include/goleft_depth_host.h (gdh_format_stats is the product's twin of this function)."""
+    gc, cpg, low, acgt, lacgt = seq_counts(seq, start, end, line_bases if contract & STATS_CPG_RAW_LINES else 0)
+    tot = float(acgt) if contract & STATS_DENOM_ACGT else float(end - start)
+    if start >= len(seq) or end <= start or tot == 0:
         return "\t0\t0\t0"
-    return "\t%s\t%s\t%s" % (fmt_g3(gc / tot), fmt_g3(2.0 * cpg / tot), fmt_g3(low / tot))
+    c = 2.0 * cpg / tot
+    if contract & STATS_CPG_CLAMP:
+        c = min(1.0, c)
+    m = (lacgt if contract & STATS_MASKED_ACGT else low) / tot
+    return "\t%s\t%s\t%s" % (fmt_g3(gc / tot), fmt_g3(c), fmt_g3(m))
 
 
 # ---------------------------------------------------------------------------

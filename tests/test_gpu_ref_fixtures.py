@@ -56,10 +56,12 @@ def oracle_beds(bam_key, fai, W, regions=None, stats_fa=None, **kw):
         hd, ca = po.depth_run_oracle(contigs, reads, W=W, regions=regions, **kw)
     if stats_fa:
         seqs = fasta(stats_fa)
+        width = {l.split("\t")[0]: int(l.split("\t")[3]) for l in open(stats_fa + ".fai") if l.strip()}
         rows = []
         for line in hd.splitlines():
             chrom, s, e, _ = line.split("\t")
-            rows.append(line + po.stats_columns(seqs[chrom], int(s), int(e)) + "\n")
+            # the default contract (GDH_STATS_FAIDX), line breaks as the FASTA has them
+            rows.append(line + po.stats_columns(seqs[chrom], int(s), int(e), po.STATS_FAIDX, width[chrom]) + "\n")
         hd = "".join(rows)
     return hd, ca
 
