@@ -375,9 +375,9 @@ def main():
     eng, streams, names, lengths, mine = r["eng"], r["streams"], r["names"], r["lengths"], r["mine"]
     dt, W, Q, mincov = r["dt"], r["W"], r["Q"], r["mincov"]
     value = r["total_bases"] * args.steps / dt
-    # roofline of the dominant kernel (gd_tile_kernel), this rank's launch
-    # 4 B/read (pos) + 4 B/read (the record word that stands where the CSR offset stood: flag |
-    # MAPQ | op count) + 4 B per CIGAR op the kernel reads (the canonical ops on the tile path) + 4 B/base + 8 B/window
+    # roofline of the dominant kernel, this rank's launch.  SURVEY.md 8(d): 4 B/read (pos) + 4 B/read (the record
+    # word that stands where the CSR offset stood: flag | MAPQ | op count) + 4 B per CIGAR op the kernel reads (the
+    # canonical ops on the tile and long-read paths) + 4 B/base + 8 B/window
     ops_read = r["n_canonical_ops"] if r["n_canonical_ops"] else r["n_ops"]
     alg_bytes = synth.algorithmic_bytes(r["n_reads"], ops_read, r["my_bases"] if r["perbase"] else 0,
                                         r["my_windows"])   # windows-only: no 4 B/base write
@@ -451,7 +451,8 @@ def main():
                      "kernel": kname,
                      "avg_kernel_ms": avg_tile_s * 1e3,
                      "algorithmic_bytes_per_launch": alg_bytes,
-                     "bytes_per_ref_base": alg_bytes / r["my_bases"]},
+                     "bytes_per_ref_base": alg_bytes / r["my_bases"],
+                     "cigar_ops_counted": ops_read},
         "kernels_ms": ({"prep": r["prep_ms"], "expand": r["expand_ms"], "scan": r["scan_ms"], "runs": r["runs_ms"]}
                        if scatter else
                        {"prep": r["prep_ms"], "ltile": r["tile_ms"], "runs": r["runs_ms"]}

@@ -34,9 +34,11 @@ struct ContigHost {
     size_t n_nops = 0;                 // canonical ops
     bool normed = false;               // noff/ncig describe the current records
     uint32_t* pidx = nullptr;          // position index: pidx[k] = first read with pos >= 64 k, k = 0 .. (length >> 6) + 1
-    // long-read path (gd_chunk.hpp): checkpoints of the CIGARs above (the canonical ones when normed), read ends
-    uint32_t* ck = nullptr;            // (ops >> 6) + n_reads + 1 slots
-    uint4*    lrec = nullptr;          // n_reads + 2 long-read records {pos, end, off, flag << 8 | MAPQ}; [n_reads + 1].x = the largest span
+    // long-read path (gd_chunk.hpp): deletion lists of the canonical CIGARs above, their checkpoints, read records
+    uint4*    lrec = nullptr;          // n_reads + 2 long-read records {pos, end, list offset, deletions}; [n_reads + 1].x = the largest span
+    uint32_t* lfq = nullptr;           // n_reads: flag << 8 | MAPQ
+    uint2*    dl = nullptr;            // (canonical ops >> 1) + n_reads + 1 deletions {start, length}
+    uint32_t* dck = nullptr;           // (entries of dl >> 6) + n_reads + 1 checkpoints
     int32_t   max_span = 0;
     bool ck_ok = false;                // ck / rend describe the current records
     // layout in the result arrays of the last compute (-1 = not computed)
@@ -218,9 +220,11 @@ int ensure_dev(gd_ctx* c, Tp** p, size_t* cap, size_t need, bool keep = false, s
 
 void drop_ck(ContigHost& h)
 {
-    if (h.ck) (void)hipFree(h.ck);
     if (h.lrec) (void)hipFree(h.lrec);
-    h.ck = nullptr; h.lrec = nullptr;
+    if (h.lfq) (void)hipFree(h.lfq);
+    if (h.dl) (void)hipFree(h.dl);
+    if (h.dck) (void)hipFree(h.dck);
+    h.lrec = nullptr; h.lfq = nullptr; h.dl = nullptr; h.dck = nullptr;
     h.max_span = 0;
     h.ck_ok = false;
 }
@@ -344,26 +348,30 @@ void launch_ltile(gd_ctx* c, const gd::Job& job)
         hipLaunchKernelGGL((gd::gd_ltile2_kernel<T, NT, 0>), dim3(grid), dim3(NT), 0, c->stream, job);
 }
 
-// Long-read path: checkpoints + read ends of one contig's CIGARs (gd_ckpt_kernel), from the canonical arrays
-// when the contig has them.  Part of taking the records in (or of the first gd_compute that needs them), kept
-// until the records change.
+// Long-read path: deletion lists, their checkpoints and the read records of one contig (gd_dels_kernel), from
+// its canonical CIGARs.  Part of taking the records in (or of the first gd_compute that needs them), kept until
+// the records change.
 int build_ck(gd_ctx* c, ContigHost& h)
 {
     drop_ck(h);
+    if (!h.normed) return fail(c, GD_E_STATE, "long-read path: the contig has no canonical CIGARs (internal error)");
     const uint32_t n_reads = (uint32_t)h.n_reads, n_units = (n_reads + 63u) / 64u;
-    const size_t n_ops = h.normed ? h.n_nops : h.n_ops;
+    const size_t n_dl = (h.n_nops >> 1) + (size_t)n_reads + 1;
+    if (n_dl > 0xffffffffull) return fail(c, GD_E_RANGE, "too many deletions on one contig");
     HIPCHK(c, hipEventRecord(c->copy_done, c->copy_stream));
     HIPCHK(c, hipStreamWaitEvent(c->stream, c->copy_done, 0));
-    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&h.ck), ((n_ops >> 6) + (size_t)n_reads + 1) * sizeof(uint32_t)));
     HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&h.lrec), ((size_t)n_reads + 2) * sizeof(uint4)));
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&h.lfq), ((size_t)n_reads + 1) * sizeof(uint32_t)));
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&h.dl), n_dl * sizeof(uint2)));
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&h.dck), ((n_dl >> 6) + (size_t)n_reads + 1) * sizeof(uint32_t)));
     HIPCHK(c, hipMemsetAsync(h.lrec + n_reads, 0, 2 * sizeof(uint4), c->stream));
-    gd::CkJob j{};
-    j.pos = h.pos; j.off = h.normed ? h.noff : h.off; j.cigar = h.normed ? h.ncig : h.cigar;
+    gd::DelJob j{};
+    j.pos = h.pos; j.off = h.noff; j.cigar = h.ncig; j.flag = h.flag; j.mapq = h.mapq;
     j.n_reads = n_reads; j.n_units = n_units;
-    j.flag = h.flag; j.mapq = h.mapq;
-    j.ck = h.ck; j.lrec = h.lrec; j.max_span = reinterpret_cast<int32_t*>(h.lrec + n_reads + 1);
+    j.lrec = h.lrec; j.lfq = h.lfq; j.dl = h.dl; j.dck = h.dck;
+    j.max_span = reinterpret_cast<int32_t*>(h.lrec + n_reads + 1);
     if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
-    if (n_units) hipLaunchKernelGGL(gd::gd_ckpt_kernel, dim3((n_units + 3u) / 4u), dim3(256), 0, c->stream, j);
+    if (n_units) hipLaunchKernelGGL(gd::gd_dels_kernel, dim3((n_units + 3u) / 4u), dim3(256), 0, c->stream, j);
     HIPCHK(c, hipGetLastError());
     if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
     int32_t span = 0;

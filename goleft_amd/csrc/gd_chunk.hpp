@@ -7,28 +7,39 @@
 // read.  This path keeps the tile kernel's shape -- one workgroup per tile of T
 // reference positions, +-1 marks in an LDS difference array, fused scan / store
 // / window / class reductions, every per-base value written to HBM exactly once
-// -- and makes a read's CIGAR addressable by reference position:
+// -- and uses
+//     depth(read, x) = [pos <= x < end] - [x inside one of the read's D/N ops]
+// (every reference-consuming op is either counted, M/=/X, or a D/N;
+// `samtools depth` semantics, /root/reference/depth/depth.go:45): per tile a read
+// contributes ONE +1/-1 pair plus one -1/+1 pair per deletion or skip that reaches
+// the tile.  What the tile kernel needs is therefore not the CIGAR but the read's
+// DELETION LIST in reference coordinates:
 //
-//   CK  gd_ckpt_kernel   one pass over a contig's CIGARs WHEN ITS RECORDS ARRIVE (with the
-//       canonical CIGARs of gd_normalize.hpp, which it reads: about half the ops of an
-//       ONT-like read; not part of gd_compute): for every chunk of 64 ops of a read, the
-//       reference position at which the chunk starts (a checkpoint, 4 bytes per 64 ops), the
-//       read's end position, and the largest span.  Independent of the read filter (-Q, flag
-//       mask), which the tile kernel applies.  Checkpoint slots need no prefix sum: read r
-//       with CSR offset o uses slots (o >> 6) + r ... which never overlap
-//       (ceil(n/64) <= (n >> 6) + 1).
-//   LT2 gd_ltile2_kernel per tile: the candidate reads (start within one maximum
-//       span before the tile; 8 bytes each: start, end) are tested lane-parallel
-//       and contribute one +1/-1 pair; the 64-op chunks that reach the tile are
-//       expanded for their D/N ops only (`samtools depth` semantics,
-//       /root/reference/depth/depth.go:45; details at the kernel).  Then the tile
-//       kernel's phase B/C (depth/depth.go:293-323).
+//   DL  gd_dels_kernel   one pass over a contig's canonical CIGARs (gd_normalize.hpp: M and N
+//       alternate) WHEN ITS RECORDS ARRIVE, not in gd_compute: every N op becomes {start, length}
+//       (8 bytes -- what the (M, N) op pair took) at a dense per-read offset, every 64th start
+//       is also a checkpoint (4 bytes per 64 deletions), and each read gets one 16-byte record
+//       {pos, end, offset of its list, its length}.  Independent of the read filter (-Q, flag
+//       mask), which the tile kernel applies.  Offsets need no prefix sum: the canonical CSR
+//       offset o of read r gives list offset (o >> 1) + r and checkpoint offset
+//       (list offset >> 6) + r, neither of which ever overlaps the next read's.
+//   LT2 gd_ltile2_kernel per tile: the candidate reads (start within one maximum span before
+//       the tile) are tested lane-parallel from their records; the checkpoints of up to four
+//       overlapping reads are fetched in one round trip and the 64-deletion chunks that reach
+//       the tile queued; lanes then load one deletion each (8 bytes, 512 bytes per chunk and
+//       wave instruction) and mark it -- no op decode, no position scan, no alignment waste.
+//       Then the tile kernel's phase B/C (depth/depth.go:293-323).
+//
+// History: walking M runs (19.7 ms on the 20x ONT genome) -> deletions of
+// 64-op chunks with a checkpoint pass per gd_compute (15.4 ms) -> canonical op pairs, checkpoints at
+// ingest (11.0 ms; PMC: 4.0e9 VALU + 2.9e9 SALU wave-instructions per launch, issue bound, two
+// thirds of them decoding and scanning ops) -> deletion lists.
 #pragma once
 
 namespace gd {
 
-constexpr uint32_t CK_OPS = 64;               // CIGAR ops per checkpoint chunk
-constexpr int CK_UNROLL = 8;                  // chunks in flight per wave in gd_ckpt_kernel
+constexpr uint32_t DL_CHUNK = 64;             // deletions per checkpoint
+constexpr int DL_UNROLL = 4;                  // 64-op groups in flight per wave in gd_dels_kernel
 
 __device__ __forceinline__ uint32_t sat_pos(uint32_t v) { return v < POS_CAP ? v : POS_CAP; }
 
@@ -42,30 +53,31 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
     return v;
 }
 
-// CK: one wave per unit of 64 consecutive reads of ONE contig.
-struct CkJob {
+// DL: one wave per unit of 64 consecutive reads of ONE contig.
+struct DelJob {
     const int32_t*  pos;
-    const uint32_t* off;      // CSR offsets of `cigar` (the canonical arrays when the contig has them)
-    const uint32_t* cigar;
-    uint32_t  n_reads;
-    uint32_t  n_units;        // ceil(n_reads / 64)
+    const uint32_t* off;      // CSR offsets of the CANONICAL ops (gd_normalize.hpp)
+    const uint32_t* cigar;    // canonical ops: M (0) and N (3) alternate, lengths >= 1, the last one is an M
     const uint16_t* flag;
     const uint8_t*  mapq;
-    uint32_t* ck;             // (n_ops >> 6) + n_reads + 1 slots
-    uint4*    lrec;           // n_reads + 1 long-read records {pos, end, off, flag << 8 | MAPQ}: everything the
-                              // tile kernel asks about a candidate read in ONE 16-byte load (end = reference
-                              // position after the last op, == pos without ops; [n_reads] = {0, 0, n_ops, 0})
+    uint32_t  n_reads;
+    uint32_t  n_units;        // ceil(n_reads / 64)
+    uint4*    lrec;           // n_reads + 1 long-read records {pos, end, list offset, deletions}: everything the
+                              // tile kernel asks about a candidate read's geometry in ONE 16-byte load
+                              // (end = reference position after the last op, == pos without ops)
+    uint32_t* lfq;            // n_reads: flag << 8 | MAPQ (the filter is applied per tile)
+    uint2*    dl;             // deletion lists {start, length}: (n_ops >> 1) + n_reads + 1 entries
+    uint32_t* dck;            // start of every 64th deletion of a read: (entries of dl >> 6) + n_reads + 1
     int32_t*  max_span;       // atomicMax of end - pos
 };
 
-__global__ __launch_bounds__(256) void gd_ckpt_kernel(CkJob job)
+__global__ __launch_bounds__(256) void gd_dels_kernel(DelJob job)
 {
     const int lane = threadIdx.x & 63;
     const uint32_t unit = blockIdx.x * 4u + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (unit >= job.n_units) return;
     const uint32_t n_reads = job.n_reads;
     const uint32_t* const cigar = job.cigar;
-    uint32_t* const ck = job.ck;
 
     const uint32_t r = unit * 64u + (uint32_t)lane;
     const bool valid = r < n_reads;
@@ -76,116 +88,95 @@ __global__ __launch_bounds__(256) void gd_ckpt_kernel(CkJob job)
         n = job.off[r + 1] - o0;
         fq = ((uint32_t)job.flag[r] << 8) | (uint32_t)job.mapq[r];
     }
-    const bool keep = n != 0u;
+    const uint32_t doff = (o0 >> 1) + r;                  // this read's deletion list ...
+    const uint32_t koff = (doff >> 6) + r;                // ... and its checkpoints
     uint32_t endp = p;                                    // reference position after the last op
 
-    // short CIGARs: lane serial, a single chunk
-    if (keep && n <= SHORT_OPS) {
+    // short CIGARs: lane serial
+    if (n != 0u && n <= SHORT_OPS) {
         for (uint32_t k = 0; k < n; ++k) {
             const uint32_t cg = cigar[o0 + k];
-            const uint32_t op = cg & 0xf, len = cg >> 4;
-            if ((0x18du >> op) & 1u) endp = sat_pos(endp + len);      // M D N = X
+            const uint32_t len = cg >> 4;
+            if ((cg & 0xfu) != 0u) {                      // N: deletion number k >> 1
+                job.dl[doff + (k >> 1)] = make_uint2(endp, len);
+                if ((k >> 1) == 0u) job.dck[koff] = endp;
+            }
+            endp = sat_pos(endp + len);
         }
     }
-    if (keep) ck[(o0 >> 6) + r] = p;                      // chunk 0 starts at POS
 
-    // long CIGARs: the wave walks one read at a time, CK_UNROLL chunks in flight
-    unsigned long long todo = __ballot(keep && n > SHORT_OPS);
+    // long CIGARs: the wave walks one read at a time, DL_UNROLL groups of 64 ops in flight
+    unsigned long long todo = __ballot(n > SHORT_OPS);
     while (todo != 0ull) {
         const int j = __ffsll((long long)todo) - 1;
         todo &= todo - 1ull;
         const uint32_t pj = (uint32_t)__builtin_amdgcn_readlane((int)p, j);
         const uint32_t oj = (uint32_t)__builtin_amdgcn_readlane((int)o0, j);
         const uint32_t nj = (uint32_t)__builtin_amdgcn_readlane((int)n, j);
-        const uint32_t rj = (uint32_t)__builtin_amdgcn_readlane((int)r, j);
-        uint32_t* const ckj = ck + ((oj >> 6) + rj);
-        uint32_t run = pj;
-        for (uint32_t b = 0; b < nj; b += CK_UNROLL * CK_OPS) {
-            uint32_t cg[CK_UNROLL];
+        const uint32_t dj = (uint32_t)__builtin_amdgcn_readlane((int)doff, j);
+        const uint32_t kj = (uint32_t)__builtin_amdgcn_readlane((int)koff, j);
+        uint32_t run = pj;                                // reference position at the start of the group
+        for (uint32_t b = 0; b < nj; b += DL_UNROLL * 64u) {
+            uint32_t cg[DL_UNROLL];
 #pragma unroll
-            for (int u = 0; u < CK_UNROLL; ++u) {
-                const uint32_t k = b + (uint32_t)u * CK_OPS + (uint32_t)lane;
+            for (int u = 0; u < DL_UNROLL; ++u) {
+                const uint32_t k = b + (uint32_t)u * 64u + (uint32_t)lane;
                 cg[u] = k < nj ? cigar[oj + k] : 0u;
             }
-            // reference bases each op consumes; the chunk totals come from eight interleaved plain
-            // 32-bit scans (scan4 twice) unless an op consumes more than 2^24 bases (64 * 2^24 <
-            // 2^31: no wrap), then from saturating scans
-            uint32_t cons[CK_UNROLL];
-            uint32_t mx = 0;
+            uint32_t len[DL_UNROLL], mx = 0;
 #pragma unroll
-            for (int u = 0; u < CK_UNROLL; ++u) {
-                const uint32_t op = cg[u] & 0xf, len = cg[u] >> 4;
-                cons[u] = ((0x18du >> op) & 1u) ? len : 0u;
-                mx |= cons[u];
-            }
-            uint32_t tot[CK_UNROLL];
+            for (int u = 0; u < DL_UNROLL; ++u) { len[u] = cg[u] >> 4; mx |= len[u]; }
+            // where each op starts: four interleaved plain 32-bit scans unless an op consumes more than
+            // 2^24 bases (64 * 2^24 < 2^31: no wrap), then saturating scans
+            uint32_t excl[DL_UNROLL], tot[DL_UNROLL];
             if (__builtin_amdgcn_ballot_w64(mx > (1u << 24)) == 0ull) {
-                int t[CK_UNROLL];
+                int t[DL_UNROLL];
 #pragma unroll
-                for (int u = 0; u < CK_UNROLL; ++u) t[u] = (int)cons[u];
-                static_assert(CK_UNROLL == 8, "two scan4 groups");
+                for (int u = 0; u < DL_UNROLL; ++u) t[u] = (int)len[u];
+                static_assert(DL_UNROLL == 4, "one scan4 group");
                 scan4(t[0], t[1], t[2], t[3]);
-                scan4(t[4], t[5], t[6], t[7]);
 #pragma unroll
-                for (int u = 0; u < CK_UNROLL; ++u) tot[u] = (uint32_t)__builtin_amdgcn_readlane(t[u], 63);
+                for (int u = 0; u < DL_UNROLL; ++u) {
+                    excl[u] = (uint32_t)t[u] - len[u];
+                    tot[u] = (uint32_t)__builtin_amdgcn_readlane(t[u], 63);
+                }
             } else {
 #pragma unroll
-                for (int u = 0; u < CK_UNROLL; ++u)
-                    tot[u] = (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_scan_sat(sat_pos(cons[u])), 63);
+                for (int u = 0; u < DL_UNROLL; ++u) {
+                    const uint32_t inc = wave_inclusive_scan_sat(sat_pos(len[u]));
+                    excl[u] = (uint32_t)wave_prev_lane((int)inc, 0);
+                    tot[u] = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+                }
             }
 #pragma unroll
-            for (int u = 0; u < CK_UNROLL; ++u) {
-                if (b + (uint32_t)u * CK_OPS >= nj) break;            // uniform
+            for (int u = 0; u < DL_UNROLL; ++u) {
+                const uint32_t k = b + (uint32_t)u * 64u + (uint32_t)lane;
+                if (k < nj && (cg[u] & 0xfu) != 0u) {     // N: deletion number k >> 1 (M and N alternate)
+                    const uint32_t s = sat_pos(run + excl[u]);
+                    const uint32_t di = k >> 1;
+                    job.dl[dj + di] = make_uint2(s, len[u]);
+                    if ((di & (DL_CHUNK - 1u)) == 0u) job.dck[kj + (di >> 6)] = s;
+                }
                 run = sat_pos(run + tot[u]);
-                const uint32_t nxt = (b >> 6) + (uint32_t)u + 1u;     // the chunk that starts here
-                if (nxt * CK_OPS < nj && lane == 0) ckj[nxt] = run;
             }
         }
         if (lane == j) endp = run;
     }
     if (valid) {
-        job.lrec[r] = make_uint4(p, endp, o0, fq);
-        if (r + 1u == n_reads) job.lrec[n_reads] = make_uint4(0u, 0u, o0 + n, 0u);
+        job.lrec[r] = make_uint4(p, endp, doff, n >> 1);  // M and N alternate and the last op is an M: n >> 1 deletions
+        job.lfq[r] = fq;
     }
-    const uint32_t smax = wave_max_u32(keep ? endp - p : 0u);
+    const uint32_t smax = wave_max_u32(n != 0u ? endp - p : 0u);
     if (lane == 0 && smax != 0u) atomicMax(job.max_span, (int32_t)smax);
 }
 
 // ---------------------------------------------------------------------------
 // LT2: the long-read tile kernel.
-//
-// Its predecessor walked one overlapping read at a time per wave, marking M runs, and
-// spent ~120 wave-instructions per 64 CIGAR ops; at ONT shape (4.8e9 ops,
-// every chunk expanded ~1.2 times) that was instruction-issue bound.  Here:
-//   * depth of a read = [pos <= x < end] - [x inside one of its D/N ops]
-//     (every reference-consuming op is either counted, M/=/X, or a D/N): the
-//     read contributes ONE +1/-1 pair per tile (lane-parallel, from the start /
-//     end arrays the checkpoint pass wrote) and each D/N op one -1/+1 pair.
-//     Only a quarter of ONT-like ops are deletions, the M runs need no marks at
-//     all, and no neighbour-op logic is left;
-//   * work is split into producing and consuming a per-wave queue of ITEMS
-//     {first op index, reference position of the first op, op count <= 128}
-//     (two consecutive 64-op checkpoint chunks): the checkpoints of up to four
-//     overlapping reads are fetched in one round trip, lanes whose chunk pair
-//     reaches the tile push an item (ballot + mbcnt, no atomics); items are
-//     expanded four at a time, lane k holding the PAIR of ops 2k, 2k+1 of the item (one
-//     8-byte load; 512 bytes per item and wave instruction), the next four items' loads
-//     in flight while the current ones expand, and ONE wave scan per item over the pairs'
-//     reference-consuming lengths (four interleave in scan4), seeded with the item's
-//     checkpoint.  Canonical CIGARs alternate M and N, so a pair holds exactly one D/N op:
-//     every lane has one mark to make, none idles on an M (a pair of two D/N ops -- only
-//     when normalisation is off -- takes a second, wave-uniformly skipped, mark).
-// Reference positions use plain 32-bit scans whenever every op of the four
-// items consumes <= 2^23 bases (64 * 2^24 + 2^31 < 2^32: no wrap); items with
-// a longer D/N op take a saturating scan.  Integer adds commute, so the
-// per-base result equals M-run marking bit for bit.
 // ---------------------------------------------------------------------------
-constexpr int LQ_CAP = 128;                   // queue items per wave: one round of 4 slots pushes <= 4 * 32
-constexpr uint32_t LQ_OPS = 2 * CK_OPS;       // ops per item
+constexpr int LQ_CAP = 128;                   // queue items per wave (a read pushes at most T / 128 + 2 per round)
 
-// One queue item: {index of the first op in the contig's CIGAR array, reference position
-// of op 0, reference position of op 64, ops in the item (1..128)}
-typedef uint4 LItem;
+// One queue item: {index of the chunk's first deletion in the contig's list, deletions in it (1..64)}
+typedef uint2 LItem;
 
 // -1 over [s, s+len) of a D/N op (absolute, saturated positions)
 __device__ __forceinline__ void del_mark(int32_t* s_diff, bool del, uint32_t s, uint32_t len, int t0, int tlen)
@@ -198,62 +189,6 @@ __device__ __forceinline__ void del_mark(int32_t* s_diff, bool del, uint32_t s, 
     }
 }
 
-// Reference positions of the op pairs of four items (lane k = ops 2k, 2k+1; cons = bases the pair consumes).
-__device__ __forceinline__ void chunk_pos4(const uint32_t (&cons)[4], const uint32_t (&st)[4], bool big,
-                                           uint32_t (&pos)[4])
-{
-    if (!big) {
-        int incl[4];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) incl[g] = (int)cons[g];
-        scan4(incl[0], incl[1], incl[2], incl[3]);
-#pragma unroll
-        for (int g = 0; g < 4; ++g) pos[g] = sat_pos(st[g] + ((uint32_t)incl[g] - cons[g]));
-    } else {
-        // rare: saturating scans (positions stay exact up to POS_CAP, then stick there)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const uint32_t inc = wave_inclusive_scan_sat(sat_pos(cons[g]));
-            pos[g] = sat_pos(st[g] + (uint32_t)wave_prev_lane((int)inc, 0));
-        }
-    }
-}
-
-// Four items: lane k holds ops 2k (a) and 2k+1 (b) of each; 0 = nothing.  sa: reference position of op 0.
-__device__ __forceinline__ void expand4_lds(const uint32_t (&a)[4], const uint32_t (&b)[4],
-                                            const uint32_t (&sa)[4], int t0, int tlen, int32_t* s_diff)
-{
-    uint32_t la[4], lb[4], ca[4], cp[4], pa[4];
-    bool da[4], db[4];
-    uint32_t mx = 0;
-    bool two = false;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const uint32_t oa = a[g] & 0xf, ob = b[g] & 0xf;
-        la[g] = a[g] >> 4; lb[g] = b[g] >> 4;
-        ca[g] = ((0x18du >> oa) & 1u) ? la[g] : 0u;                       // M D N = X
-        const uint32_t cb = ((0x18du >> ob) & 1u) ? lb[g] : 0u;
-        da[g] = ((0xcu >> oa) & 1u) && la[g] != 0;                        // D N
-        db[g] = ((0xcu >> ob) & 1u) && lb[g] != 0;
-        mx |= ca[g] | cb;
-        cp[g] = sat_pos(ca[g]) + sat_pos(cb);                             // < 2^32
-        two = two || (da[g] && db[g]);
-    }
-    const bool big = __builtin_amdgcn_ballot_w64(mx > (1u << 23)) != 0ull;   // wave uniform
-    chunk_pos4(cp, sa, big, pa);
-    // one mark per pair: the pair's D/N op (canonical CIGARs alternate, so there is exactly one)
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const uint32_t ps = da[g] ? pa[g] : sat_pos(pa[g] + ca[g]);
-        del_mark(s_diff, da[g] | db[g], ps, da[g] ? la[g] : lb[g], t0, tlen);
-    }
-    if (__builtin_amdgcn_ballot_w64(two) != 0ull) {                      // original CIGARs only: D next to N
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-            del_mark(s_diff, da[g] && db[g], sat_pos(pa[g] + ca[g]), lb[g], t0, tlen);
-    }
-}
-
 template <int T, int NT, int OPT>
 __global__ __launch_bounds__(NT) void gd_ltile2_kernel(Job job)
 {
@@ -263,12 +198,13 @@ __global__ __launch_bounds__(NT) void gd_ltile2_kernel(Job job)
     constexpr int NWORDS = T / 32;
     constexpr int G = 4;                   // overlapping reads whose checkpoints are fetched together
     static_assert(CHUNK % 256 == 0, "wave chunk must be whole rows");
+    static_assert(T / 128 + 2 <= LQ_CAP, "one read's chunks of a round fit the queue");
 
     __shared__ __attribute__((aligned(16))) int32_t s_diffp[T + 4];  // [3] = index -1
     __shared__ uint32_t s_bmap[NWORDS];
     __shared__ uint32_t s_clo[NWORDS];
     __shared__ uint32_t s_chi[NWORDS];
-    __shared__ __attribute__((aligned(16))) LItem s_q[NW * LQ_CAP];
+    __shared__ __attribute__((aligned(8))) LItem s_q[NW * LQ_CAP];
     __shared__ int32_t  s_wtot[NW];
     __shared__ uint32_t s_wcnt[NW];
     __shared__ uint32_t s_hasb;
@@ -283,14 +219,15 @@ __global__ __launch_bounds__(NT) void gd_ltile2_kernel(Job job)
     const int lane = tid & (WAVE - 1);
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const TileInfo ti = job.tiles[tile];
-    const uint32_t* const ck = ti.ck;
     const int32_t t0 = ti.t0;
     const int32_t tend = t0 + T < ti.length ? t0 + T : ti.length;
     const int tlen = tend - t0;
 
     const uint32_t nrd = ti.hi - ti.lo;
     const uint4* const grec = ti.lrec + ti.lo;
-    const uint32_t* const cigar = ti.cigar;
+    const uint32_t* const gfq = ti.lfq + ti.lo;
+    const uint2* const dl = ti.dl;
+    const uint32_t* const dck = ti.dck;
 
     {
         const int4 z = make_int4(0, 0, 0, 0);
@@ -305,72 +242,63 @@ __global__ __launch_bounds__(NT) void gd_ltile2_kernel(Job job)
     LItem* const Q = &s_q[wv * LQ_CAP];
     uint32_t qn = 0;                                       // items queued (wave uniform)
 
-    // four queued items: ops 2k, 2k+1 of each in lane k (0 past the item) and the items' start positions
-    typedef uint32_t __attribute__((ext_vector_type(2), aligned(4))) pair_u;   // a read's ops start at any dword
-    auto fetch4 = [&](uint32_t i, uint32_t cnt, uint32_t (&a)[4], uint32_t (&b)[4], uint32_t (&sa)[4]) {
+    // four queued chunks: deletion k of each in lane k ({0, 0} past the chunk)
+    auto fetch4 = [&](uint32_t i, uint32_t cnt, uint2 (&d)[4]) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            a[g] = 0; b[g] = 0; sa[g] = POS_CAP;
+            d[g] = make_uint2(0u, 0u);
             if (i + (uint32_t)g < cnt) {                   // wave uniform
                 const LItem it = Q[i + g];                 // same address in every lane: one broadcast read
                 const uint32_t ci = (uint32_t)__builtin_amdgcn_readfirstlane((int)it.x);
-                const uint32_t no = (uint32_t)__builtin_amdgcn_readfirstlane((int)it.w);
-                sa[g] = (uint32_t)__builtin_amdgcn_readfirstlane((int)it.y);
-                const uint32_t* src = cigar + ci + 2u * (uint32_t)lane;
-                if (2u * (uint32_t)lane + 1u < no) {
-                    const pair_u v = *reinterpret_cast<const pair_u*>(src);
-                    a[g] = v.x; b[g] = v.y;
-                } else if (2u * (uint32_t)lane < no) {
-                    a[g] = src[0];
-                }
+                const uint32_t no = (uint32_t)__builtin_amdgcn_readfirstlane((int)it.y);
+                if ((uint32_t)lane < no) d[g] = dl[ci + (uint32_t)lane];
             }
         }
     };
     auto drain = [&](uint32_t cnt) {
         __builtin_amdgcn_wave_barrier();
-        uint32_t aA[4], bA[4], saA[4];
-        fetch4(0, cnt, aA, bA, saA);
+        uint2 dA[4];
+        fetch4(0, cnt, dA);
         for (uint32_t i = 0; i < cnt; i += 4u) {
-            uint32_t aB[4], bB[4], saB[4];
-            fetch4(i + 4u, cnt, aB, bB, saB);              // next four are in flight while these expand
-            expand4_lds(aA, bA, saA, t0, tlen, s_diff);
+            uint2 dB[4];
+            fetch4(i + 4u, cnt, dB);                       // next four are in flight while these are marked
 #pragma unroll
-            for (int g = 0; g < 4; ++g) { aA[g] = aB[g]; bA[g] = bB[g]; saA[g] = saB[g]; }
+            for (int g = 0; g < 4; ++g) del_mark(s_diff, dA[g].y != 0u, dA[g].x, dA[g].y, t0, tlen);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) dA[g] = dB[g];
         }
         __builtin_amdgcn_wave_barrier();
     };
 
-    // ---- phase A: candidate reads -> chunk items -> LDS +1/-1 ----------------
+    // ---- phase A: candidate reads -> deletion chunks -> LDS +1/-1 -------------
     // Candidate i of a batch of NT belongs to wave i % NW: the overlapping reads (mostly
     // the latest starters) spread evenly over the waves.  G "slots" each hold one
     // overlapping read and the block of 64 chunks under examination; a read with more
-    // than 64 chunks keeps its slot until its chunks pass the tile end.
+    // than 64 chunks (4096 deletions) keeps its slot until its chunks pass the tile end.
     for (uint32_t base = 0; base < nrd; base += (uint32_t)NT) {
         const uint32_t idx = base + (uint32_t)(lane * NW + wv);
         const bool inb = idx < nrd;
-        // one round trip per candidate: its record and the next one's CIGAR offset
+        // one round trip per candidate: its record and its filter word
         uint4 rc = make_uint4(0x7fffffffu, 0u, 0u, 0u);
-        uint32_t o1 = 0;
-        if (inb) { rc = grec[idx]; o1 = grec[idx + 1u].z; }
+        uint32_t fq = 0;
+        if (inb) { rc = grec[idx]; fq = gfq[idx]; }
         const int32_t p = (int32_t)rc.x;
         const int32_t e = inb ? (int32_t)rc.y : -1;
         // reaches t0-1 or beyond, and passes the read filter of `samtools depth`
-        const bool hit = e >= t0 && p < tend && ((rc.w >> 8) & job.flag_mask) == 0u && (int)(rc.w & 0xffu) >= job.Q;
-        uint32_t o0 = 0, n = 0;
+        const bool hit = e >= t0 && p < tend && ((fq >> 8) & job.flag_mask) == 0u && (int)(fq & 0xffu) >= job.Q;
         if (hit) {
-            o0 = rc.z; n = o1 - o0;
             // the read's own +1 / -1 (its D/N ops subtract below)
             const int rs = p - t0;
             atomicAdd(&s_diff[rs > -1 ? rs : -1], 1);
             if (e < tend) atomicAdd(&s_diff[e - t0], -1);
         }
-        unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
+        unsigned long long m = __builtin_amdgcn_ballot_w64(hit && rc.w != 0u);   // reads with deletions
 
         bool act[G];
-        uint32_t oj[G], nj[G], ej[G], nch[G], cb[G];
+        uint32_t dj[G], nj[G], ej[G], nch[G], cb[G];
         const uint32_t* ckj[G];
 #pragma unroll
-        for (int g = 0; g < G; ++g) { act[g] = false; oj[g] = nj[g] = ej[g] = nch[g] = cb[g] = 0; ckj[g] = ck; }
+        for (int g = 0; g < G; ++g) { act[g] = false; dj[g] = nj[g] = ej[g] = nch[g] = cb[g] = 0; ckj[g] = dck; }
         bool any = false;
         while (m != 0ull || any) {
             // free slots take the next overlapping reads
@@ -379,16 +307,16 @@ __global__ __launch_bounds__(NT) void gd_ltile2_kernel(Job job)
                 if (act[g] || m == 0ull) continue;            // wave uniform
                 const int j = __ffsll((long long)m) - 1;
                 m &= m - 1ull;
-                oj[g] = (uint32_t)__builtin_amdgcn_readlane((int)o0, j);
-                nj[g] = (uint32_t)__builtin_amdgcn_readlane((int)n, j);
+                dj[g] = (uint32_t)__builtin_amdgcn_readlane((int)rc.z, j);
+                nj[g] = (uint32_t)__builtin_amdgcn_readlane((int)rc.w, j);
                 ej[g] = (uint32_t)__builtin_amdgcn_readlane(e, j);
                 const uint32_t rj = ti.lo + (uint32_t)__builtin_amdgcn_readlane((int)idx, j);
-                nch[g] = (nj[g] + CK_OPS - 1u) >> 6;
-                ckj[g] = ck + ((oj[g] >> 6) + rj);
+                nch[g] = (nj[g] + DL_CHUNK - 1u) >> 6;
+                ckj[g] = dck + ((dj[g] >> 6) + rj);
                 cb[g] = 0;
                 act[g] = true;
                 if (nch[g] > 64u) {
-                    // more than 4096 ops: a strided probe of the (monotone) checkpoints finds
+                    // more than 4096 deletions: a strided probe of the (monotone) checkpoints finds
                     // the block of 64 chunks where the tile begins
                     const uint32_t stride = (nch[g] + 63u) >> 6;
                     const uint32_t pq = (uint32_t)lane * stride;
@@ -398,38 +326,36 @@ __global__ __launch_bounds__(NT) void gd_ltile2_kernel(Job job)
                     cb[g] = pc > 1 ? (uint32_t)(pc - 1) * stride : 0u;
                 }
             }
-            // the checkpoints of all slots in one round trip; even lanes own the pair of
-            // chunks (q, q+1): c0 = where it starts, c2 = where it ends
-            uint32_t c0[G], c1[G], c2[G];
+            // the checkpoints of all slots in one round trip: lane q owns chunk cb + q, which starts at
+            // c0 and whose deletions all end before c1 = the start of the next chunk (or the read's end)
+            uint32_t c0[G], c1[G];
 #pragma unroll
             for (int g = 0; g < G; ++g) {
                 const uint32_t q = cb[g] + (uint32_t)lane;
                 c0[g] = (act[g] && q < nch[g]) ? ckj[g][q] : POS_CAP;
-                c2[g] = (act[g] && q + 2u < nch[g]) ? ckj[g][q + 2u] : ej[g];
             }
 #pragma unroll
-            for (int g = 0; g < G; ++g)                    // start of chunk q+1 = c0 of the next lane (wave_shl:1)
-                c1[g] = (uint32_t)__builtin_amdgcn_update_dpp((int)POS_CAP, (int)c0[g], 0x130, 0xf, 0xf, false);
-            unsigned long long cm[G];
-            uint32_t cnt[G], tot = 0;
+            for (int g = 0; g < G; ++g) {                  // c0 of the next lane (wave_shl:1); lane 63: the chunk after
+                const uint32_t q = cb[g] + (uint32_t)lane;
+                uint32_t nx = (uint32_t)__builtin_amdgcn_update_dpp((int)POS_CAP, (int)c0[g], 0x130, 0xf, 0xf, false);
+                if (lane == 63) nx = (act[g] && q + 1u < nch[g]) ? ckj[g][q + 1u] : POS_CAP;
+                c1[g] = (q + 1u < nch[g]) ? nx : ej[g];
+            }
 #pragma unroll
             for (int g = 0; g < G; ++g) {
                 const uint32_t q = cb[g] + (uint32_t)lane;
-                cm[g] = __builtin_amdgcn_ballot_w64(act[g] && (lane & 1) == 0 && q < nch[g] &&
-                                                    (int)c0[g] < tend && (int)c2[g] >= t0);
-                cnt[g] = (uint32_t)__popcll(cm[g]);
-                tot += cnt[g];
-            }
-            if (qn + tot > (uint32_t)LQ_CAP) { drain(qn); qn = 0; }   // tot <= 4 * 32 = LQ_CAP
-#pragma unroll
-            for (int g = 0; g < G; ++g) {
-                if ((cm[g] >> lane) & 1ull) {
-                    const uint32_t rk = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(cm[g] >> 32),
-                                                 __builtin_amdgcn_mbcnt_lo((uint32_t)cm[g], 0u));
-                    const uint32_t first = (cb[g] + (uint32_t)lane) * CK_OPS, left = nj[g] - first;
-                    Q[rk] = make_uint4(oj[g] + first, c0[g], c1[g], left < LQ_OPS ? left : LQ_OPS);
+                const unsigned long long cm = __builtin_amdgcn_ballot_w64(act[g] && q < nch[g] &&
+                                                                          (int)c0[g] < tend && (int)c1[g] >= t0);
+                const uint32_t cnt = (uint32_t)__popcll(cm);
+                if (cnt == 0u) continue;                     // wave uniform
+                if (qn + cnt > (uint32_t)LQ_CAP) { drain(qn); qn = 0; }
+                if ((cm >> lane) & 1ull) {
+                    const uint32_t rk = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(cm >> 32),
+                                                 __builtin_amdgcn_mbcnt_lo((uint32_t)cm, 0u));
+                    const uint32_t first = q * DL_CHUNK, left = nj[g] - first;
+                    Q[rk] = make_uint2(dj[g] + first, left < DL_CHUNK ? left : DL_CHUNK);
                 }
-                qn += cnt[g];
+                qn += cnt;
             }
             // a slot is done when its chunks are exhausted or start at/after the tile end
             // (checkpoints only grow)

@@ -54,8 +54,11 @@ struct ContigDev {
     int64_t  win_off;         // element offset in the window arrays
     int32_t  tid;             // reference id in the BAM header
     uint32_t unit_beg;        // first 64-read unit of this contig (scatter path)
-    const uint32_t* ck;       // long-read path: checkpoints of `cigar` (gd_ckpt_kernel), built when the records arrive
-    const uint4*    lrec;     // long-read path: {pos, end, off, flag << 8 | MAPQ} per read
+    // long-read path (gd_chunk.hpp), built when the records arrive:
+    const uint4*    lrec;     // {pos, end, offset of the deletion list, deletions} per read
+    const uint32_t* lfq;      // flag << 8 | MAPQ per read
+    const uint2*    dl;       // deletion lists {start, length}
+    const uint32_t* dck;      // start of every 64th deletion of a read
     const uint32_t* rec;      // record words (gd_normalize.hpp) of the canonical records, null otherwise
     const uint32_t* pidx;     // position index (gd_pidx_kernel): first read with pos >= 64 k; null: search `pos`
 };
@@ -79,8 +82,10 @@ struct __attribute__((aligned(16))) TileInfo {
     uint32_t clo, chi;        // CIGAR op range [off[lo], off[hi]) of those reads
     int32_t  tile;            // global tile id (the slow list of a fast run is compacted)
     int32_t  pad_[3];
-    const uint32_t* ck;       // long-read path (ContigDev::ck, ::lrec)
-    const uint4*    lrec;
+    const uint4*    lrec;     // long-read path (ContigDev::lrec, ::lfq, ::dl, ::dck)
+    const uint32_t* lfq;
+    const uint2*    dl;
+    const uint32_t* dck;
 };
 
 // The same for gd_tile_fast_kernel: one record per ORDINARY tile (full, at most one batch of reads, ops
@@ -242,7 +247,7 @@ __global__ void gd_prep_kernel(Job job)
     ti.ctg = lo;
     ti.tile = t;
     ti.pad_[0] = ti.pad_[1] = ti.pad_[2] = 0;
-    ti.ck = c.ck; ti.lrec = c.lrec;
+    ti.lrec = c.lrec; ti.lfq = c.lfq; ti.dl = c.dl; ti.dck = c.dck;
     ti.t0 = (t - c.tile_beg) * T;
     int32_t tend = ti.t0 + T < c.length ? ti.t0 + T : c.length;
     int32_t from = ti.t0 > lookback ? ti.t0 - lookback : 0;

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define GD_ABI_VERSION 8
+#define GD_ABI_VERSION 9
 
 typedef enum {
     GD_OK = 0,
@@ -108,7 +108,7 @@ typedef struct {
     int32_t  reruns;         /* times the last gd_compute re-ran (span / run capacity) */
     int32_t  path;           /* GD_PATH_TILE / _SCATTER / _CHUNK: what the last gd_compute ran */
     int32_t  n_slow_tiles;   /* tile path with GD_OPT_FAST_KERNEL: tiles that took the generic kernel instead */
-    uint64_t n_canonical_ops; /* ops of the canonical CIGARs the tile path read (0: it read the original ones) */
+    uint64_t n_canonical_ops; /* ops of the canonical CIGARs the tile / long-read path read (0: it read the original ones) */
 } gd_stats;
 
 /* Kernel ids for gd_kernel_ms.  Tile path: PREP, TILE, RUNS.  Chunk path: CKPT

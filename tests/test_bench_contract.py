@@ -37,17 +37,6 @@ def test_wgs_bench_line_has_the_contract_fields():
     assert d["value"] >= 1e9                                            # BASELINE.json's target at one GPU
 
 
-def test_bench_defaults_are_the_contract_defaults():
-    import importlib.util
-    import sys
-    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(H.ROOT, "bench.py"))
-    src = open(os.path.join(H.ROOT, "bench.py")).read()
-    assert '"--gpus", type=int, default=1' in src and '"--steps"' in src and '"--warmup"' in src
-    assert spec is not None and "torch.cuda.synchronize" in src and "barrier" in src
-    assert "oracle" in src                                              # the cpu_baseline leg (and only that) uses it
-    assert sys.version_info >= (3, 8)
-
-
 def test_product_never_uses_the_oracle():
     """The oracle is test infrastructure: nothing under goleft_amd/ (Python, C++, HIP, Makefile) may import,
     include, link or execute anything under oracle/ -- comments that cite it aside."""

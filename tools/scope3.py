@@ -22,15 +22,23 @@ def main():
     ap.add_argument("--coverage", type=float, default=30.0)
     ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("--window", type=int, default=1000)
+    ap.add_argument("--name", default="chr20", help="contig name in the synthetic BAM")
+    ap.add_argument("--paper", action="store_true",
+                    help="the one invocation the reference itself times (indexcov/paper/cmp.sh:6): "
+                         "`goleft depth --chrom <name> -p 20 -o -w 16384`")
     args = ap.parse_args()
     d = tempfile.mkdtemp(prefix="gd_scope3_", dir="/tmp")
     bam = os.path.join(d, "synth.bam")
     t0 = time.perf_counter()
-    info = json.loads(subprocess.check_output([os.path.join(ROOT, "goleft_amd", "synth-bam"), bam, "chr20",
+    if args.paper:
+        args.window, args.threads = 16384, 20
+    info = json.loads(subprocess.check_output([os.path.join(ROOT, "goleft_amd", "synth-bam"), bam, args.name,
                                                args.length, str(args.coverage), "20"]).decode())
     args.length = sum(int(x) for x in args.length.split(","))
     t_write = time.perf_counter() - t0
+    extra = ["--chrom", args.name, "-o"] if args.paper else []
     out = {"scope": "BAM file -> depth.bed + callable.bed (goleft-depth CLI, process start to exit)",
+           "invocation": "goleft-depth depth -w %d -p %d %s--prefix OUT synth.bam" % (args.window, args.threads, " ".join(extra) + (" " if extra else "")),
            "ref_bases": args.length, "coverage": args.coverage, "reads": info["reads"],
            "bam_MB": info["bam_bytes"] / 1e6, "host_cores": os.cpu_count(), "bam_write_s": t_write}
     beds = {}
@@ -43,7 +51,7 @@ def main():
         for rep in range(3):                               # the file is in the page cache after the write
             t0 = time.perf_counter()
             p = subprocess.run([os.path.join(ROOT, "goleft_amd", "goleft-depth"), "depth", "-w", str(args.window),
-                                "-p", str(args.threads), "-r", os.path.join(d, "synth.fa"), "--prefix",
+                                "-p", str(args.threads)] + extra + ["-r", os.path.join(d, "synth.fa"), "--prefix",
                                 os.path.join(d, "out_" + decoder), bam],
                                env=dict(os.environ, GOLEFT_DEPTH_TIMING="1", **env), stderr=subprocess.PIPE)
             dt = time.perf_counter() - t0
