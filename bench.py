@@ -501,6 +501,11 @@ def main():
                                          "perbase_diff + callback, %d threads over 10 Mb tiles, %.1f s "
                                          "wall (%.0f core-seconds)"
                                          % ("+".join(s[0] for s in sample), b, cores, sec, sec * cores)}
+        # the same port on ONE thread, on the last contig of the sample
+        v1, b1, sec1 = cpu_baseline(sample[-1:], W, mincov, 1)
+        out["cpu_baseline"]["single_thread"] = {
+            "value": v1, "unit": "ref-bases/s", "cores": 1,
+            "sample": "%s (%d ref bases), one thread, %.1f s" % (sample[-1][0], b1, sec1)}
     r_split = r["split"]
     eng.close()
     streams.clear()

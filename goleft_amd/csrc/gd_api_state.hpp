@@ -38,7 +38,7 @@ struct ContigHost {
     uint4*    lrec = nullptr;          // n_reads + 2 long-read records {pos, end, list offset, deletions}; [n_reads + 1].x = the largest span
     uint32_t* lfq = nullptr;           // n_reads: flag << 8 | MAPQ
     uint2*    dl = nullptr;            // (canonical ops >> 1) + n_reads + 1 deletions {start, length}
-    uint32_t* dck = nullptr;           // (entries of dl >> 6) + n_reads + 1 checkpoints
+    uint32_t* pck = nullptr;           // tile indexes (gd_ptile_fill_kernel)
     int32_t   max_span = 0;
     bool ck_ok = false;                // ck / rend describe the current records
     // layout in the result arrays of the last compute (-1 = not computed)
@@ -223,8 +223,8 @@ void drop_ck(ContigHost& h)
     if (h.lrec) (void)hipFree(h.lrec);
     if (h.lfq) (void)hipFree(h.lfq);
     if (h.dl) (void)hipFree(h.dl);
-    if (h.dck) (void)hipFree(h.dck);
-    h.lrec = nullptr; h.lfq = nullptr; h.dl = nullptr; h.dck = nullptr;
+    if (h.pck) (void)hipFree(h.pck);
+    h.lrec = nullptr; h.lfq = nullptr; h.dl = nullptr; h.pck = nullptr;
     h.max_span = 0;
     h.ck_ok = false;
 }
@@ -363,19 +363,41 @@ int build_ck(gd_ctx* c, ContigHost& h)
     HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&h.lrec), ((size_t)n_reads + 2) * sizeof(uint4)));
     HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&h.lfq), ((size_t)n_reads + 1) * sizeof(uint32_t)));
     HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&h.dl), n_dl * sizeof(uint2)));
-    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&h.dck), ((n_dl >> 6) + (size_t)n_reads + 1) * sizeof(uint32_t)));
     HIPCHK(c, hipMemsetAsync(h.lrec + n_reads, 0, 2 * sizeof(uint4), c->stream));
     gd::DelJob j{};
     j.pos = h.pos; j.off = h.noff; j.cigar = h.ncig; j.flag = h.flag; j.mapq = h.mapq;
     j.n_reads = n_reads; j.n_units = n_units;
-    j.lrec = h.lrec; j.lfq = h.lfq; j.dl = h.dl; j.dck = h.dck;
+    j.lrec = h.lrec; j.lfq = h.lfq; j.dl = h.dl;
     j.max_span = reinterpret_cast<int32_t*>(h.lrec + n_reads + 1);
     if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
-    if (n_units) hipLaunchKernelGGL(gd::gd_dels_kernel, dim3((n_units + 3u) / 4u), dim3(256), 0, c->stream, j);
-    HIPCHK(c, hipGetLastError());
-    if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+    // the tile index: entries per read -> offsets (one scan over the 64-read units) -> filled
+    uint32_t* unit = nullptr;
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&unit), ((size_t)n_units + 2) * sizeof(uint32_t)));
+    struct UnitGuard { uint32_t* p; ~UnitGuard() { if (p) (void)hipFree(p); } } unit_guard{unit};
+    HIPCHK(c, hipMemsetAsync(unit + n_units, 0, 2 * sizeof(uint32_t), c->stream));
+    gd::PtJob pj{};
+    pj.noff = h.noff; pj.lrec = h.lrec; pj.dl = h.dl; pj.n_reads = n_reads; pj.n_units = n_units; pj.unit = unit;
+    uint32_t n_pck = 0;
+    if (n_units) {
+        hipLaunchKernelGGL(gd::gd_dels_kernel, dim3((n_units + 3u) / 4u), dim3(256), 0, c->stream, j);
+        hipLaunchKernelGGL(gd::gd_ptile_count_kernel, dim3((n_units + 3u) / 4u), dim3(256), 0, c->stream, pj);
+        hipLaunchKernelGGL(gd::norm::gd_unit_scan_kernel, dim3(1), dim3(1024), 0, c->stream, unit, n_units);
+        HIPCHK(c, hipMemcpyAsync(&n_pck, unit + n_units, sizeof n_pck, hipMemcpyDeviceToHost, c->stream));
+    }
     int32_t span = 0;
     HIPCHK(c, hipMemcpyAsync(&span, h.lrec + n_reads + 1, sizeof span, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));              // the index is allocated at its exact size
+    // its 32-bit offsets cannot have wrapped if even this bound fits
+    if ((uint64_t)n_reads * (((uint64_t)(uint32_t)span >> gd::PT_SHIFT) + 2) > 0xffffffffull)
+        return fail(c, GD_E_RANGE, "long-read path: %u reads spanning up to %d bases -- the tile index would not fit 2^32 entries",
+                    n_reads, span);
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&h.pck), ((size_t)n_pck + 1) * sizeof(uint32_t)));
+    pj.pck = h.pck;
+    if (n_reads)
+        hipLaunchKernelGGL(gd::gd_ptile_fill_kernel, dim3((n_reads + 255u) / 256u), dim3(256), 0, c->stream, pj);
+    HIPCHK(c, hipGetLastError());
+    if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->profiling) {
         float ms = 0;

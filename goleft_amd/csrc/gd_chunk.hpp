@@ -17,28 +17,33 @@
 //
 //   DL  gd_dels_kernel   one pass over a contig's canonical CIGARs (gd_normalize.hpp: M and N
 //       alternate) WHEN ITS RECORDS ARRIVE, not in gd_compute: every N op becomes {start, length}
-//       (8 bytes -- what the (M, N) op pair took) at a dense per-read offset, every 64th start
-//       is also a checkpoint (4 bytes per 64 deletions), and each read gets one 16-byte record
-//       {pos, end, offset of its list, its length}.  Independent of the read filter (-Q, flag
-//       mask), which the tile kernel applies.  Offsets need no prefix sum: the canonical CSR
-//       offset o of read r gives list offset (o >> 1) + r and checkpoint offset
-//       (list offset >> 6) + r, neither of which ever overlaps the next read's.
+//       (8 bytes -- what the (M, N) op pair took) at a dense per-read offset, and each read gets
+//       one 16-byte record {pos, end, offset of its list, offset of its tile index}.  Independent
+//       of the read filter (-Q, flag mask), which the tile kernel applies.  List offsets need no
+//       prefix sum: the canonical CSR offset o of read r gives (o >> 1) + r, which never overlaps
+//       the next read's.
+//   PT  gd_ptile_count_kernel / gd_ptile_fill_kernel   the read's TILE INDEX: for every 4096-base
+//       boundary b the read spans (from the one at or before pos to the one after end), the number
+//       of its deletions that start before b -- 4 bytes per (read, 4 kb of reference), 80 MB for a
+//       20x ONT genome.  A tile finds the deletions of an overlapping read that can touch it with
+//       TWO lookups (no checkpoint search, no chunk that merely brushes the tile).
 //   LT2 gd_ltile2_kernel per tile: the candidate reads (start within one maximum span before
-//       the tile) are tested lane-parallel from their records; the checkpoints of up to four
-//       overlapping reads are fetched in one round trip and the 64-deletion chunks that reach
-//       the tile queued; lanes then load one deletion each (8 bytes, 512 bytes per chunk and
-//       wave instruction) and mark it -- no op decode, no position scan, no alignment waste.
-//       Then the tile kernel's phase B/C (depth/depth.go:293-323).
+//       the tile) are tested lane-parallel from their records; a lane whose read overlaps looks
+//       its deletion range up and queues it in pieces of 64; lanes then load one deletion each
+//       (8 bytes, 512 bytes per piece and wave instruction) and mark it -- no op decode, no
+//       position scan.  Then the tile kernel's phase B/C (depth/depth.go:293-323).
 //
 // History: walking M runs (19.7 ms on the 20x ONT genome) -> deletions of
 // 64-op chunks with a checkpoint pass per gd_compute (15.4 ms) -> canonical op pairs, checkpoints at
 // ingest (11.0 ms; PMC: 4.0e9 VALU + 2.9e9 SALU wave-instructions per launch, issue bound, two
-// thirds of them decoding and scanning ops) -> deletion lists.
+// thirds of them decoding and scanning ops) -> deletion lists found through 64-deletion checkpoints
+// (9.4 ms) -> deletion lists found through the per-read tile index.
 #pragma once
 
 namespace gd {
 
-constexpr uint32_t DL_CHUNK = 64;             // deletions per checkpoint
+constexpr uint32_t DL_CHUNK = 64;             // deletions per queued piece
+constexpr int PT_SHIFT = 12;                  // the tile index has one entry per 4096 reference positions
 constexpr int DL_UNROLL = 4;                  // 64-op groups in flight per wave in gd_dels_kernel
 
 __device__ __forceinline__ uint32_t sat_pos(uint32_t v) { return v < POS_CAP ? v : POS_CAP; }
@@ -62,14 +67,15 @@ struct DelJob {
     const uint8_t*  mapq;
     uint32_t  n_reads;
     uint32_t  n_units;        // ceil(n_reads / 64)
-    uint4*    lrec;           // n_reads + 1 long-read records {pos, end, list offset, deletions}: everything the
-                              // tile kernel asks about a candidate read's geometry in ONE 16-byte load
-                              // (end = reference position after the last op, == pos without ops)
+    uint4*    lrec;           // n_reads + 1 long-read records {pos, end, list offset, tile index offset}: everything
+                              // the tile kernel asks about a candidate read's geometry in ONE 16-byte load
+                              // (end = reference position after the last op, == pos without ops; the last field
+                              // is filled by gd_ptile_fill_kernel, PT_NONE: the read has no deletion)
     uint32_t* lfq;            // n_reads: flag << 8 | MAPQ (the filter is applied per tile)
     uint2*    dl;             // deletion lists {start, length}: (n_ops >> 1) + n_reads + 1 entries
-    uint32_t* dck;            // start of every 64th deletion of a read: (entries of dl >> 6) + n_reads + 1
     int32_t*  max_span;       // atomicMax of end - pos
 };
+constexpr uint32_t PT_NONE = 0xffffffffu;
 
 __global__ __launch_bounds__(256) void gd_dels_kernel(DelJob job)
 {
@@ -88,8 +94,7 @@ __global__ __launch_bounds__(256) void gd_dels_kernel(DelJob job)
         n = job.off[r + 1] - o0;
         fq = ((uint32_t)job.flag[r] << 8) | (uint32_t)job.mapq[r];
     }
-    const uint32_t doff = (o0 >> 1) + r;                  // this read's deletion list ...
-    const uint32_t koff = (doff >> 6) + r;                // ... and its checkpoints
+    const uint32_t doff = (o0 >> 1) + r;                  // this read's deletion list
     uint32_t endp = p;                                    // reference position after the last op
 
     // short CIGARs: lane serial
@@ -97,10 +102,7 @@ __global__ __launch_bounds__(256) void gd_dels_kernel(DelJob job)
         for (uint32_t k = 0; k < n; ++k) {
             const uint32_t cg = cigar[o0 + k];
             const uint32_t len = cg >> 4;
-            if ((cg & 0xfu) != 0u) {                      // N: deletion number k >> 1
-                job.dl[doff + (k >> 1)] = make_uint2(endp, len);
-                if ((k >> 1) == 0u) job.dck[koff] = endp;
-            }
+            if ((cg & 0xfu) != 0u) job.dl[doff + (k >> 1)] = make_uint2(endp, len);   // N: deletion number k >> 1
             endp = sat_pos(endp + len);
         }
     }
@@ -114,7 +116,6 @@ __global__ __launch_bounds__(256) void gd_dels_kernel(DelJob job)
         const uint32_t oj = (uint32_t)__builtin_amdgcn_readlane((int)o0, j);
         const uint32_t nj = (uint32_t)__builtin_amdgcn_readlane((int)n, j);
         const uint32_t dj = (uint32_t)__builtin_amdgcn_readlane((int)doff, j);
-        const uint32_t kj = (uint32_t)__builtin_amdgcn_readlane((int)koff, j);
         uint32_t run = pj;                                // reference position at the start of the group
         for (uint32_t b = 0; b < nj; b += DL_UNROLL * 64u) {
             uint32_t cg[DL_UNROLL];
@@ -152,10 +153,7 @@ __global__ __launch_bounds__(256) void gd_dels_kernel(DelJob job)
             for (int u = 0; u < DL_UNROLL; ++u) {
                 const uint32_t k = b + (uint32_t)u * 64u + (uint32_t)lane;
                 if (k < nj && (cg[u] & 0xfu) != 0u) {     // N: deletion number k >> 1 (M and N alternate)
-                    const uint32_t s = sat_pos(run + excl[u]);
-                    const uint32_t di = k >> 1;
-                    job.dl[dj + di] = make_uint2(s, len[u]);
-                    if ((di & (DL_CHUNK - 1u)) == 0u) job.dck[kj + (di >> 6)] = s;
+                    job.dl[dj + (k >> 1)] = make_uint2(sat_pos(run + excl[u]), len[u]);
                 }
                 run = sat_pos(run + tot[u]);
             }
@@ -163,19 +161,79 @@ __global__ __launch_bounds__(256) void gd_dels_kernel(DelJob job)
         if (lane == j) endp = run;
     }
     if (valid) {
-        job.lrec[r] = make_uint4(p, endp, doff, n >> 1);  // M and N alternate and the last op is an M: n >> 1 deletions
+        job.lrec[r] = make_uint4(p, endp, doff, PT_NONE);
         job.lfq[r] = fq;
     }
     const uint32_t smax = wave_max_u32(n != 0u ? endp - p : 0u);
     if (lane == 0 && smax != 0u) atomicMax(job.max_span, (int32_t)smax);
 }
 
+// PT: the tile index.  Entries of read r: boundaries b_k = ((pos >> 12) + k) << 12 for k = 0 .. K - 1 with
+// K = (end >> 12) - (pos >> 12) + 2 (reads without deletions have none); entry k = number of the read's
+// deletions that start before b_k.  (M and N alternate and the last op is an M: a read of n canonical ops has
+// n >> 1 deletions.)
+struct PtJob {
+    const uint32_t* noff;     // canonical CSR offsets
+    uint4*    lrec;
+    const uint2* dl;
+    uint32_t  n_reads;
+    uint32_t  n_units;
+    uint32_t* unit;           // n_units + 1: entries per 64-read unit, then (gd_unit_scan_kernel) offsets; [n_units] = total
+    uint32_t* pck;            // the index
+};
+
+__device__ __forceinline__ uint32_t pt_entries(uint32_t p, uint32_t e, uint32_t n_del)
+{
+    return (n_del != 0u && e >= p) ? (e >> PT_SHIFT) - (p >> PT_SHIFT) + 2u : 0u;   // (e < p: a negative POS)
+}
+
+// PT1: entries per read -> offsets inside the unit (parked in lrec.w) and unit totals.
+__global__ __launch_bounds__(256) void gd_ptile_count_kernel(PtJob job)
+{
+    const int lane = threadIdx.x & 63;
+    const uint32_t unit = blockIdx.x * 4u + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (unit >= job.n_units) return;
+    const uint32_t r = unit * 64u + (uint32_t)lane;
+    uint32_t K = 0;
+    if (r < job.n_reads) {
+        const uint4 rc = job.lrec[r];
+        K = pt_entries(rc.x, rc.y, (job.noff[r + 1] - job.noff[r]) >> 1);
+    }
+    const uint32_t incl = (uint32_t)wave_inclusive_scan((int)K);
+    if (r < job.n_reads) job.lrec[r].w = K != 0u ? incl - K : PT_NONE;
+    if (lane == 63) job.unit[unit] = incl;
+}
+
+// PT2: one lane per read fills its entries (a binary search of its own, sorted, deletion list per boundary).
+__global__ __launch_bounds__(256) void gd_ptile_fill_kernel(PtJob job)
+{
+    const uint32_t r = blockIdx.x * 256u + threadIdx.x;
+    if (r >= job.n_reads) return;
+    const uint4 rc = job.lrec[r];
+    if (rc.w == PT_NONE) return;
+    const uint32_t n_del = (job.noff[r + 1] - job.noff[r]) >> 1;
+    const uint32_t K = pt_entries(rc.x, rc.y, n_del);
+    const uint32_t pb = job.unit[r >> 6] + rc.w;
+    job.lrec[r].w = pb;
+    const uint2* const d = job.dl + rc.z;
+    uint32_t lo = 0;                                       // boundaries grow: the previous answer is a lower bound
+    for (uint32_t k = 0; k < K; ++k) {
+        const uint64_t b = (uint64_t)((rc.x >> PT_SHIFT) + k) << PT_SHIFT;
+        uint32_t hi = n_del;
+        while (lo < hi) {
+            const uint32_t mid = lo + ((hi - lo) >> 1);
+            if ((uint64_t)d[mid].x < b) lo = mid + 1; else hi = mid;
+        }
+        job.pck[pb + k] = lo;
+    }
+}
+
 // ---------------------------------------------------------------------------
 // LT2: the long-read tile kernel.
 // ---------------------------------------------------------------------------
-constexpr int LQ_CAP = 128;                   // queue items per wave (a read pushes at most T / 128 + 2 per round)
+constexpr int LQ_CAP = 128;                   // queue items per wave (every lane pushes at most one per round)
 
-// One queue item: {index of the chunk's first deletion in the contig's list, deletions in it (1..64)}
+// One queue item: {index of the piece's first deletion in the contig's list, deletions in it (1..64)}
 typedef uint2 LItem;
 
 // -1 over [s, s+len) of a D/N op (absolute, saturated positions)
@@ -196,9 +254,8 @@ __global__ __launch_bounds__(NT) void gd_ltile2_kernel(Job job)
     constexpr int CHUNK = T / NW;
     constexpr int ROWS = CHUNK / 256;
     constexpr int NWORDS = T / 32;
-    constexpr int G = 4;                   // overlapping reads whose checkpoints are fetched together
     static_assert(CHUNK % 256 == 0, "wave chunk must be whole rows");
-    static_assert(T / 128 + 2 <= LQ_CAP, "one read's chunks of a round fit the queue");
+    static_assert(T % (1 << PT_SHIFT) == 0 && WAVE <= LQ_CAP, "tiles start on index boundaries; a round fits the queue");
 
     __shared__ __attribute__((aligned(16))) int32_t s_diffp[T + 4];  // [3] = index -1
     __shared__ uint32_t s_bmap[NWORDS];
@@ -227,7 +284,7 @@ __global__ __launch_bounds__(NT) void gd_ltile2_kernel(Job job)
     const uint4* const grec = ti.lrec + ti.lo;
     const uint32_t* const gfq = ti.lfq + ti.lo;
     const uint2* const dl = ti.dl;
-    const uint32_t* const dck = ti.dck;
+    const uint32_t* const pck = ti.pck;
 
     {
         const int4 z = make_int4(0, 0, 0, 0);
@@ -270,103 +327,54 @@ __global__ __launch_bounds__(NT) void gd_ltile2_kernel(Job job)
         __builtin_amdgcn_wave_barrier();
     };
 
-    // ---- phase A: candidate reads -> deletion chunks -> LDS +1/-1 -------------
+    // ---- phase A: candidate reads -> their deletions in this tile -> LDS +1/-1 -------------
     // Candidate i of a batch of NT belongs to wave i % NW: the overlapping reads (mostly
-    // the latest starters) spread evenly over the waves.  G "slots" each hold one
-    // overlapping read and the block of 64 chunks under examination; a read with more
-    // than 64 chunks (4096 deletions) keeps its slot until its chunks pass the tile end.
+    // the latest starters) spread evenly over the waves.
     for (uint32_t base = 0; base < nrd; base += (uint32_t)NT) {
         const uint32_t idx = base + (uint32_t)(lane * NW + wv);
         const bool inb = idx < nrd;
         // one round trip per candidate: its record and its filter word
-        uint4 rc = make_uint4(0x7fffffffu, 0u, 0u, 0u);
+        uint4 rc = make_uint4(0x7fffffffu, 0u, 0u, PT_NONE);
         uint32_t fq = 0;
         if (inb) { rc = grec[idx]; fq = gfq[idx]; }
         const int32_t p = (int32_t)rc.x;
         const int32_t e = inb ? (int32_t)rc.y : -1;
         // reaches t0-1 or beyond, and passes the read filter of `samtools depth`
         const bool hit = e >= t0 && p < tend && ((fq >> 8) & job.flag_mask) == 0u && (int)(fq & 0xffu) >= job.Q;
+        uint32_t cur = 0, rem = 0;                            // this lane's deletions still to queue
         if (hit) {
             // the read's own +1 / -1 (its D/N ops subtract below)
             const int rs = p - t0;
             atomicAdd(&s_diff[rs > -1 ? rs : -1], 1);
             if (e < tend) atomicAdd(&s_diff[e - t0], -1);
+            if (rc.w != PT_NONE) {
+                // deletions that can touch the tile: the last one starting before t0 (it may reach in) up to the
+                // last one starting before the tile's end -- two entries of the read's tile index
+                const uint32_t pk = rc.x >> PT_SHIFT;
+                const uint32_t K = (rc.y >> PT_SHIFT) - pk + 2u;
+                const uint32_t k0 = (uint32_t)t0 > rc.x ? ((uint32_t)t0 >> PT_SHIFT) - pk : 0u;   // t0 <= end: k0 <= K - 2
+                uint32_t k1 = k0 + (uint32_t)(T >> PT_SHIFT);
+                k1 = k1 < K - 1u ? k1 : K - 1u;
+                const uint32_t a = pck[rc.w + k0], b = pck[rc.w + k1];
+                const uint32_t j0 = a != 0u ? a - 1u : 0u;
+                cur = rc.z + j0;
+                rem = b - j0;
+            }
         }
-        unsigned long long m = __builtin_amdgcn_ballot_w64(hit && rc.w != 0u);   // reads with deletions
-
-        bool act[G];
-        uint32_t dj[G], nj[G], ej[G], nch[G], cb[G];
-        const uint32_t* ckj[G];
-#pragma unroll
-        for (int g = 0; g < G; ++g) { act[g] = false; dj[g] = nj[g] = ej[g] = nch[g] = cb[g] = 0; ckj[g] = dck; }
-        bool any = false;
-        while (m != 0ull || any) {
-            // free slots take the next overlapping reads
-#pragma unroll
-            for (int g = 0; g < G; ++g) {
-                if (act[g] || m == 0ull) continue;            // wave uniform
-                const int j = __ffsll((long long)m) - 1;
-                m &= m - 1ull;
-                dj[g] = (uint32_t)__builtin_amdgcn_readlane((int)rc.z, j);
-                nj[g] = (uint32_t)__builtin_amdgcn_readlane((int)rc.w, j);
-                ej[g] = (uint32_t)__builtin_amdgcn_readlane(e, j);
-                const uint32_t rj = ti.lo + (uint32_t)__builtin_amdgcn_readlane((int)idx, j);
-                nch[g] = (nj[g] + DL_CHUNK - 1u) >> 6;
-                ckj[g] = dck + ((dj[g] >> 6) + rj);
-                cb[g] = 0;
-                act[g] = true;
-                if (nch[g] > 64u) {
-                    // more than 4096 deletions: a strided probe of the (monotone) checkpoints finds
-                    // the block of 64 chunks where the tile begins
-                    const uint32_t stride = (nch[g] + 63u) >> 6;
-                    const uint32_t pq = (uint32_t)lane * stride;
-                    const uint32_t pv = pq < nch[g] ? ckj[g][pq] : POS_CAP;
-                    // chunks before the last probe that starts before t0 end before t0
-                    const int pc = __popcll(__builtin_amdgcn_ballot_w64(pq < nch[g] && (int)pv < t0));
-                    cb[g] = pc > 1 ? (uint32_t)(pc - 1) * stride : 0u;
-                }
+        // queue them in pieces of 64, one piece per lane and round
+        for (;;) {
+            const unsigned long long pm = __builtin_amdgcn_ballot_w64(rem != 0u);
+            if (pm == 0ull) break;
+            const uint32_t np = (uint32_t)__popcll(pm);
+            if (qn + np > (uint32_t)LQ_CAP) { drain(qn); qn = 0; }
+            if (rem != 0u) {
+                const uint32_t rk = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32),
+                                             __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0u));
+                const uint32_t c = rem < DL_CHUNK ? rem : DL_CHUNK;
+                Q[rk] = make_uint2(cur, c);
+                cur += c; rem -= c;
             }
-            // the checkpoints of all slots in one round trip: lane q owns chunk cb + q, which starts at
-            // c0 and whose deletions all end before c1 = the start of the next chunk (or the read's end)
-            uint32_t c0[G], c1[G];
-#pragma unroll
-            for (int g = 0; g < G; ++g) {
-                const uint32_t q = cb[g] + (uint32_t)lane;
-                c0[g] = (act[g] && q < nch[g]) ? ckj[g][q] : POS_CAP;
-            }
-#pragma unroll
-            for (int g = 0; g < G; ++g) {                  // c0 of the next lane (wave_shl:1); lane 63: the chunk after
-                const uint32_t q = cb[g] + (uint32_t)lane;
-                uint32_t nx = (uint32_t)__builtin_amdgcn_update_dpp((int)POS_CAP, (int)c0[g], 0x130, 0xf, 0xf, false);
-                if (lane == 63) nx = (act[g] && q + 1u < nch[g]) ? ckj[g][q + 1u] : POS_CAP;
-                c1[g] = (q + 1u < nch[g]) ? nx : ej[g];
-            }
-#pragma unroll
-            for (int g = 0; g < G; ++g) {
-                const uint32_t q = cb[g] + (uint32_t)lane;
-                const unsigned long long cm = __builtin_amdgcn_ballot_w64(act[g] && q < nch[g] &&
-                                                                          (int)c0[g] < tend && (int)c1[g] >= t0);
-                const uint32_t cnt = (uint32_t)__popcll(cm);
-                if (cnt == 0u) continue;                     // wave uniform
-                if (qn + cnt > (uint32_t)LQ_CAP) { drain(qn); qn = 0; }
-                if ((cm >> lane) & 1ull) {
-                    const uint32_t rk = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(cm >> 32),
-                                                 __builtin_amdgcn_mbcnt_lo((uint32_t)cm, 0u));
-                    const uint32_t first = q * DL_CHUNK, left = nj[g] - first;
-                    Q[rk] = make_uint2(dj[g] + first, left < DL_CHUNK ? left : DL_CHUNK);
-                }
-                qn += cnt;
-            }
-            // a slot is done when its chunks are exhausted or start at/after the tile end
-            // (checkpoints only grow)
-            any = false;
-#pragma unroll
-            for (int g = 0; g < G; ++g) {
-                if (!act[g]) continue;
-                const bool past = (int)(uint32_t)__builtin_amdgcn_readlane((int)c0[g], 63) >= tend;
-                if (cb[g] + 64u >= nch[g] || past) act[g] = false;
-                else { cb[g] += 64u; any = true; }
-            }
+            qn += np;
         }
     }
     if (qn != 0u) drain(qn);

@@ -55,10 +55,10 @@ struct ContigDev {
     int32_t  tid;             // reference id in the BAM header
     uint32_t unit_beg;        // first 64-read unit of this contig (scatter path)
     // long-read path (gd_chunk.hpp), built when the records arrive:
-    const uint4*    lrec;     // {pos, end, offset of the deletion list, deletions} per read
+    const uint4*    lrec;     // {pos, end, offset of the deletion list, offset of the tile index} per read
     const uint32_t* lfq;      // flag << 8 | MAPQ per read
     const uint2*    dl;       // deletion lists {start, length}
-    const uint32_t* dck;      // start of every 64th deletion of a read
+    const uint32_t* pck;      // tile indexes: deletions starting before every 4096-base boundary a read spans
     const uint32_t* rec;      // record words (gd_normalize.hpp) of the canonical records, null otherwise
     const uint32_t* pidx;     // position index (gd_pidx_kernel): first read with pos >= 64 k; null: search `pos`
 };
@@ -82,10 +82,10 @@ struct __attribute__((aligned(16))) TileInfo {
     uint32_t clo, chi;        // CIGAR op range [off[lo], off[hi]) of those reads
     int32_t  tile;            // global tile id (the slow list of a fast run is compacted)
     int32_t  pad_[3];
-    const uint4*    lrec;     // long-read path (ContigDev::lrec, ::lfq, ::dl, ::dck)
+    const uint4*    lrec;     // long-read path (ContigDev::lrec, ::lfq, ::dl, ::pck)
     const uint32_t* lfq;
     const uint2*    dl;
-    const uint32_t* dck;
+    const uint32_t* pck;
 };
 
 // The same for gd_tile_fast_kernel: one record per ORDINARY tile (full, at most one batch of reads, ops
@@ -247,7 +247,7 @@ __global__ void gd_prep_kernel(Job job)
     ti.ctg = lo;
     ti.tile = t;
     ti.pad_[0] = ti.pad_[1] = ti.pad_[2] = 0;
-    ti.lrec = c.lrec; ti.lfq = c.lfq; ti.dl = c.dl; ti.dck = c.dck;
+    ti.lrec = c.lrec; ti.lfq = c.lfq; ti.dl = c.dl; ti.pck = c.pck;
     ti.t0 = (t - c.tile_beg) * T;
     int32_t tend = ti.t0 + T < c.length ? ti.t0 + T : c.length;
     int32_t from = ti.t0 > lookback ? ti.t0 - lookback : 0;
