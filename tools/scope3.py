@@ -63,8 +63,8 @@ def main():
             if best is None or dt < best[0]:
                 best = (dt, phases)
         dt, phases = best
-        beds[decoder] = open(os.path.join(d, "out_%s.depth.bed" % decoder)).read() + \
-            open(os.path.join(d, "out_%s.callable.bed" % decoder)).read()
+        stem = os.path.join(d, "out_" + decoder) + ((".%s" % args.name) if args.paper else "")   # depth/depth.go:382-388
+        beds[decoder] = open(stem + ".depth.bed").read() + open(stem + ".callable.bed").read()
         out[decoder + "_decoder" + (("_%d" % vi) if len(variants) > 2 else "")] = {"env": env, "wall_s": dt, "ref_bases_per_s": args.length / dt,
                                      "bam_MB_per_s": info["bam_bytes"] / 1e6 / dt, "phases": phases}
     out["outputs_identical"] = beds["device"] == beds["host"] if "host" in beds else None
