@@ -197,7 +197,8 @@ class Intervals:
 
 def multidepth_blocks(any_mask, suf_mask, chunk, max_skip=10, min_size=15, window=10000000):
     """The multidepth block state machine (multidepth/multidepth.go:188-268) over boolean
-    site masks; returns an int64 array [n_blocks, 2] of {start, end}.  No GPU needed."""
+    site masks, found on the device (gd_md_load_flags + gd_md_blocks); returns an int64 array
+    [n_blocks, 2] of {start, end}."""
     import numpy as np
     a = np.asarray(any_mask, bool)
     s = np.asarray(suf_mask, bool)
@@ -207,7 +208,7 @@ def multidepth_blocks(any_mask, suf_mask, chunk, max_skip=10, min_size=15, windo
     cnt = load().gdh_multidepth_blocks(aw.ctypes.data, sw.ctypes.data, n, chunk, max_skip, min_size, window,
                                        None, None, 0)
     if cnt < 0:
-        raise ValueError("gdh_multidepth_blocks: bad arguments")
+        raise ValueError("gdh_multidepth_blocks: bad arguments" if cnt == -1 else "gdh_multidepth_blocks: no usable device")
     st = np.zeros(cnt, np.int64)
     en = np.zeros(cnt, np.int64)
     load().gdh_multidepth_blocks(aw.ctypes.data, sw.ctypes.data, n, chunk, max_skip, min_size, window,

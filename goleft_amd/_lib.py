@@ -72,6 +72,12 @@ SYMBOLS = {
     "gd_seq_stats": (C.c_int, [_P, C.c_size_t, _P, _P, _P, _P, _P]),
     "gd_seq_stats_ex": (C.c_int, [_P, C.c_size_t, _P, _P, C.c_int32, _P, _P, _P, _P, _P]),
     "gd_md_flags": (C.c_int, [_P, C.c_int, _P, C.c_int32, C.c_int32, _P, _P, C.c_size_t]),
+    "gd_md_begin": (C.c_int, [_P, C.c_int64]),
+    "gd_md_accumulate": (C.c_int, [_P, C.c_int, _P, C.c_int32]),
+    "gd_md_finish": (C.c_int, [_P, C.c_int32, _P, _P, C.c_size_t]),
+    "gd_md_load_flags": (C.c_int, [_P, _P, _P, C.c_int64]),
+    "gd_md_blocks": (C.c_int, [_P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, _P, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "gd_md_sums_group": (C.c_int, [_P, C.c_int, _P, C.c_size_t, _P, _P, _P]),
     "gd_md_sums": (C.c_int, [_P, C.c_size_t, _P, _P, _P]),
     "gd_inflate_bgzf": (C.c_int, [_P, _P, C.c_size_t, C.c_size_t, _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),
     "gd_ingest_bgzf": (C.c_int, [_P, C.c_int32, C.c_int32, _P, C.c_size_t, C.c_uint64, _P, C.c_size_t,

@@ -139,6 +139,9 @@ struct gd_ctx {
 
     int64_t* d_wed = nullptr; size_t cap_wed = 0;      // gd_depthwed: tables + the sites x samples matrix
     uint32_t* d_md_bits = nullptr; size_t cap_md = 0;  // gd_md_flags: `any` words then `suf` words
+    uint16_t* d_md_cnt = nullptr; size_t cap_md_cnt = 0;   // gd_md_begin .. gd_md_finish: samples >= min_cov per position
+    int64_t md_acc_len = -1;                           // gd_md_begin's length (-1: not begun)
+    int64_t md_acc_samples = 0;
     int64_t md_len = -1;                               // positions the bitmaps cover (-1: none yet)
     std::vector<int32_t> md_tids;                      // the samples they were built from
     // gd_ingest_begin .. gd_ingest_finish.  Two ranges may be pending: ing_q[0] is the oldest (the one

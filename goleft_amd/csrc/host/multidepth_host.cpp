@@ -140,91 +140,7 @@ bool short_name(const std::string& path, const std::string& header, std::string*
     return true;
 }
 
-// ---- bitmaps (bit x of word x / 32) ------------------------------------------
-struct Bits {
-    const uint32_t* w;
-    int64_t len;
-    bool get(int64_t p) const { return (w[p >> 5] >> (p & 31)) & 1u; }
-    // first set bit at or after `from` (len if none); with `andnot`: first bit set here and clear there
-    int64_t next_set(int64_t from, const uint32_t* andnot = nullptr) const
-    {
-        if (from >= len) return len;
-        int64_t k = from >> 5;
-        const int64_t nw = (len + 31) >> 5;
-        uint32_t cur = (andnot ? w[k] & ~andnot[k] : w[k]) & (~0u << (from & 31));
-        for (;;) {
-            if (cur) { const int64_t p = (k << 5) + __builtin_ctz(cur); return p < len ? p : len; }
-            if (++k >= nw) return len;
-            cur = andnot ? w[k] & ~andnot[k] : w[k];
-        }
-    }
-    // last set bit at or before `from` (-1 if none)
-    int64_t prev_set(int64_t from) const
-    {
-        if (from < 0) return -1;
-        if (from >= len) from = len - 1;
-        int64_t k = from >> 5;
-        uint32_t cur = w[k] & (~0u >> (31 - (from & 31)));
-        for (;;) {
-            if (cur) return (k << 5) + 31 - __builtin_clz(cur);
-            if (--k < 0) return -1;
-            cur = w[k];
-        }
-    }
-};
-
 struct Block { int64_t start, end; };        // 0-based start, 1-based end (:175-180)
-
-// splitBlocks (:188-201) over the sufficient sites first..last of one flushed cache
-void split_blocks(const Bits& suf, int64_t first, int64_t last, int64_t window, std::vector<Block>* out)
-{
-    int64_t s = first;
-    while (s <= last) {
-        const int64_t lim = window > 0 && s + window - 1 < last ? s + window - 1 : last;   // pos0 - start < Window
-        int64_t e = window > 0 ? suf.prev_set(lim) : s;
-        if (e < s) e = s;
-        out->push_back(Block{s, e + 1});
-        s = suf.next_set(e + 1);
-    }
-}
-
-// aggregate (:203-268) for the chunk whose 0-based start is i
-void aggregate(const Bits& any, const Bits& suf, int64_t i, int64_t chunk, const MArgs& a, std::vector<Block>* out)
-{
-    const int64_t L = any.len, rstart = i + 1;
-    int64_t first = -1, last = -1, count = 0;               // the cache: only its ends and size matter
-    bool seen0 = false;
-    // nothing happens before the first printed site that is NOT sufficient (:229-246)
-    int64_t p = any.next_set(i, suf.w);
-    while (p < L) {
-        // 32 consecutive sufficient sites extend a live cache in one step
-        if (seen0 && count > 0 && (p & 31) == 0 && p + 32 <= L && any.w[p >> 5] == ~0u && suf.w[p >> 5] == ~0u &&
-            p - (last + 1) <= a.max_skip) {
-            count += 32;
-            last = p + 31;
-            p = any.next_set(p + 32);
-            continue;
-        }
-        const bool s = suf.get(p);
-        if (!s) {
-            seen0 = true;
-            if (p > rstart + chunk && (count == 0 || p - last >= a.max_skip)) break;    // :232-240 (samtools killed)
-        }
-        if (seen0) {
-            if ((count == 0 || p - (last + 1) <= a.max_skip) && s) {                     // :247-248
-                if (count == 0) first = p;
-                last = p;
-                ++count;
-            } else if (count > 0 && p - (last + 1) > a.max_skip) {                       // :249-259
-                if (count >= a.min_size) split_blocks(suf, first, last, a.window, out);
-                count = 0;
-                if (s) { first = last = p; count = 1; }
-            }
-        }
-        p = any.next_set(p + 1);
-    }
-    if (count > 0) split_blocks(suf, first, last, a.window, out);                          // :261-266 (no MinSize test)
-}
 
 #define MDCHK(call)                                                                     \
     do {                                                                                \
@@ -324,24 +240,52 @@ int run(const MArgs& a, FILE* out)
             MDCHK(gd_commit(ctx, &b, s, blk.size(), blk.cigar.size()));
         }
     }
-    MDCHK(gd_compute(ctx));
-
     // ---- bitmaps, blocks, means ---------------------------------------------------
-    std::vector<int32_t> tids((size_t)S);
-    for (int s = 0; s < S; ++s) tids[(size_t)s] = s;
-    const size_t nw = (size_t)((L + 31) / 32);
-    std::vector<uint32_t> anyw(nw), sufw(nw);
+    // The records of all S samples stay in HBM (15 bytes per read); their per-base vectors (4 bytes per
+    // position and sample) exist for ONE GROUP of samples at a time: gd_select_contigs + gd_compute per
+    // group, twice -- once to accumulate the per-position counts behind the two bitmaps, once (the blocks
+    // known) for the block means.  The reference bounds memory with 5 Mb position chunks (:114,126); a
+    // group of samples over the whole chromosome does the same job and keeps every launch large.
+    int group = 16;                                                                      // 16 x 4 x L bytes resident
+    if (const char* e = getenv("GOLEFT_MD_GROUP")) group = std::max(1, atoi(e));
     const int need = (int)(0.5 + a.min_samples * (double)S);                              // :66
-    MDCHK(gd_md_flags(ctx, S, tids.data(), a.min_cov, need, anyw.data(), sufw.data(), nw));
-    const Bits any{anyw.data(), L}, suf{sufw.data(), L};
+    MDCHK(gd_md_begin(ctx, L));
+    std::vector<int32_t> tids;
+    for (int g0 = 0; g0 < S; g0 += group) {
+        tids.clear();
+        for (int s = g0; s < std::min(S, g0 + group); ++s) tids.push_back(s);
+        MDCHK(gd_select_contigs(ctx, (int)tids.size(), tids.data()));
+        MDCHK(gd_compute(ctx));
+        MDCHK(gd_md_accumulate(ctx, (int)tids.size(), tids.data(), a.min_cov));
+    }
+    MDCHK(gd_md_finish(ctx, need, nullptr, nullptr, 0));
     int64_t chunk = 5000000;                                                             // :119
     if (S > 50) chunk /= 5;                                                              // :62-64
-    std::vector<Block> blocks;
-    for (int64_t i = 0; i < L; i += chunk) aggregate(any, suf, i, chunk, a, &blocks);   // genRegions :130-141
-    std::vector<int64_t> bs(blocks.size()), be(blocks.size());
-    for (size_t k = 0; k < blocks.size(); ++k) { bs[k] = blocks[k].start; be[k] = blocks[k].end; }
+    // aggregate + splitBlocks of every chunk (:188-268, genRegions :130-141), on the device
+    size_t nb = 0;
+    std::vector<int64_t> bs, be;
+    {
+        int rc = gd_md_blocks(ctx, chunk, a.max_skip, a.min_size, a.window, nullptr, nullptr, 0, &nb);
+        if (rc != GD_OK && rc != GD_E_CAPACITY) MDCHK(rc);
+        bs.resize(nb); be.resize(nb);
+        if (nb) MDCHK(gd_md_blocks(ctx, chunk, a.max_skip, a.min_size, a.window, bs.data(), be.data(), nb, &nb));
+    }
+    std::vector<Block> blocks(nb);
+    for (size_t k = 0; k < nb; ++k) blocks[k] = Block{bs[k], be[k]};
     std::vector<double> sums(blocks.size() * (size_t)S);
-    MDCHK(gd_md_sums(ctx, blocks.size(), bs.data(), be.data(), sums.data()));
+    std::vector<double> gsum;
+    for (int g0 = 0; g0 < S && nb; g0 += group) {
+        tids.clear();
+        for (int s = g0; s < std::min(S, g0 + group); ++s) tids.push_back(s);
+        if (S > group) {                                                                 // one group: its vectors are still there
+            MDCHK(gd_select_contigs(ctx, (int)tids.size(), tids.data()));
+            MDCHK(gd_compute(ctx));
+        }
+        gsum.assign(nb * tids.size(), 0.0);
+        MDCHK(gd_md_sums_group(ctx, (int)tids.size(), tids.data(), nb, bs.data(), be.data(), gsum.data()));
+        for (size_t k = 0; k < nb; ++k)
+            for (size_t t = 0; t < tids.size(); ++t) sums[k * (size_t)S + (size_t)tids[t]] = gsum[k * tids.size() + t];
+    }
     gd_destroy(ctx);
     ctx = nullptr;
     for (size_t k = 0; k < blocks.size(); ++k) {
@@ -376,23 +320,37 @@ int gdh_multidepth_run(int argc, const char* const* argv, const char* out_path)
 
 int gdh_multidepth_main(int argc, const char* const* argv) { return gdh_multidepth_run(argc, argv, nullptr); }
 
-// The block state machine alone, over caller-provided bitmaps (tests drive it without a GPU).
-// Returns the number of blocks; fills up to cap {start, end} pairs.
+// The block state machine alone, over caller-provided bitmaps: they are uploaded (gd_md_load_flags) and the
+// device finds the blocks (gd_md_blocks) -- there is no host state machine any more.  Returns the number of
+// blocks (fills up to cap {start, end} pairs), -1 on bad arguments, -2 without a usable device.
 int64_t gdh_multidepth_blocks(const uint32_t* any_bits, const uint32_t* suf_bits, int64_t len, int64_t chunk,
                               int32_t max_skip, int32_t min_size, int32_t window, int64_t* starts, int64_t* ends,
                               int64_t cap)
 {
-    if (len < 0 || chunk < 1 || (len && (!any_bits || !suf_bits))) return -1;
-    MArgs a;
-    a.max_skip = max_skip; a.min_size = min_size; a.window = window;
-    const Bits any{any_bits, len}, suf{suf_bits, len};
-    std::vector<Block> blocks;
-    for (int64_t i = 0; i < len; i += chunk) aggregate(any, suf, i, chunk, a, &blocks);
-    for (size_t k = 0; k < blocks.size() && (int64_t)k < cap; ++k) {
-        if (starts) starts[k] = blocks[k].start;
-        if (ends) ends[k] = blocks[k].end;
+    if (len < 0 || chunk < 1 || max_skip < 0 || (len && (!any_bits || !suf_bits))) return -1;
+    int device = 0;
+    if (const char* e = getenv("GOLEFT_DEVICE")) device = atoi(e);
+    gd_ctx* ctx = nullptr;
+    if (gd_create(device, &ctx) != GD_OK) return -2;
+    size_t nb = 0;
+    int rc = gd_md_load_flags(ctx, any_bits, suf_bits, len);
+    std::vector<int64_t> bs, be;
+    if (rc == GD_OK) {
+        rc = gd_md_blocks(ctx, chunk, max_skip, min_size, window, nullptr, nullptr, 0, &nb);
+        if (rc == GD_E_CAPACITY) rc = GD_OK;
+        if (rc == GD_OK && nb) {
+            bs.resize(nb); be.resize(nb);
+            rc = gd_md_blocks(ctx, chunk, max_skip, min_size, window, bs.data(), be.data(), nb, &nb);
+        }
     }
-    return (int64_t)blocks.size();
+    if (rc != GD_OK) fprintf(stderr, "multidepth: %s (%s)\n", gd_strerror(rc), gd_last_error(ctx));
+    gd_destroy(ctx);
+    if (rc != GD_OK) return -2;
+    for (size_t k = 0; k < nb && (int64_t)k < cap; ++k) {
+        if (starts) starts[k] = bs[k];
+        if (ends) ends[k] = be[k];
+    }
+    return (int64_t)nb;
 }
 
 }  // extern "C"

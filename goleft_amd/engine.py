@@ -304,6 +304,57 @@ class DepthEngine:
         unpack = lambda w: np.unpackbits(w.view(np.uint8), bitorder="little")[:length].astype(bool)
         return unpack(a), unpack(s)
 
+    def md_begin(self, length: int):
+        """multidepth with the samples in groups: zero the per-position accumulators."""
+        self._chk(self._lib.gd_md_begin(self._ctx, int(length)))
+        self._md_len = int(length)
+
+    def md_accumulate(self, tids, min_cov: int):
+        t = np.ascontiguousarray(tids, np.int32)
+        self._chk(self._lib.gd_md_accumulate(self._ctx, t.size, t.ctypes.data, int(min_cov)))
+
+    def md_finish(self, min_samples: int):
+        """-> (any, suf) boolean arrays; they become the bitmaps of md_blocks / md_sums_group."""
+        length = self._md_len
+        nw = (length + 31) // 32
+        a = np.zeros(max(nw, 1), np.uint32)
+        s = np.zeros(max(nw, 1), np.uint32)
+        self._chk(self._lib.gd_md_finish(self._ctx, int(min_samples), a.ctypes.data, s.ctypes.data, nw))
+        unpack = lambda w: np.unpackbits(w.view(np.uint8), bitorder="little")[:length].astype(bool)
+        return unpack(a), unpack(s)
+
+    def md_load_flags(self, any_mask, suf_mask):
+        a = np.asarray(any_mask, bool)
+        s = np.asarray(suf_mask, bool)
+        n = a.size
+        pack = lambda m: np.ascontiguousarray(np.packbits(np.concatenate([m, np.zeros((-n) % 32, bool)]),
+                                                          bitorder="little").view(np.uint32))
+        aw, sw = pack(a), pack(s)
+        self._chk(self._lib.gd_md_load_flags(self._ctx, aw.ctypes.data if n else None, sw.ctypes.data if n else None, n))
+
+    def md_blocks(self, chunk: int, max_skip: int = 10, min_size: int = 15, window: int = 10000000) -> np.ndarray:
+        """The block state machine of multidepth.go:188-268 on the device over the current bitmaps:
+        int64 [n_blocks, 2] of {start, end}."""
+        n = C.c_size_t(0)
+        rc = self._lib.gd_md_blocks(self._ctx, int(chunk), int(max_skip), int(min_size), int(window), None, None, 0, C.byref(n))
+        if rc not in (0, -8):
+            self._chk(rc)
+        st = np.zeros(max(1, n.value), np.int64)
+        en = np.zeros(max(1, n.value), np.int64)
+        if n.value:
+            self._chk(self._lib.gd_md_blocks(self._ctx, int(chunk), int(max_skip), int(min_size), int(window),
+                                             st.ctypes.data, en.ctypes.data, n.value, C.byref(n)))
+        return np.stack([st[:n.value], en[:n.value]], 1)
+
+    def md_sums_group(self, tids, starts, ends) -> np.ndarray:
+        t = np.ascontiguousarray(tids, np.int32)
+        s = np.ascontiguousarray(starts, np.int64)
+        e = np.ascontiguousarray(ends, np.int64)
+        out = np.zeros((s.size, t.size), np.float64)
+        self._chk(self._lib.gd_md_sums_group(self._ctx, t.size, t.ctypes.data, s.size, s.ctypes.data, e.ctypes.data,
+                                             out.ctypes.data))
+        return out
+
     def md_sums(self, starts, ends, n_samples: int) -> np.ndarray:
         """multidepth: float64 [n_blocks, n_samples] running sums of depth / 1000 over the suf
         sites of each block, in position order (multidepth.go:270-277)."""

@@ -326,6 +326,26 @@ int gd_seq_stats_ex(gd_ctx* ctx, size_t n_windows, const int64_t* start, const i
 int gd_md_flags(gd_ctx* ctx, int n_samples, const int32_t* tids, int32_t min_cov, int32_t min_samples,
                 uint32_t* any_bits, uint32_t* suf_bits, size_t n_words);
 int gd_md_sums(gd_ctx* ctx, size_t n_blocks, const int64_t* start, const int64_t* end, double* sums);
+/* The same bitmaps with the samples brought in GROUPS, so that only one group's per-base vectors have to be
+ * resident (gd_select_contigs + gd_compute per group; the reference bounds memory with 5 Mb position chunks,
+ * :114,126): gd_md_begin(len) zeroes the per-position accumulators, gd_md_accumulate adds a group (the tids of
+ * the last gd_compute), gd_md_finish turns them into `any` / `suf` (copied out when the pointers are non-NULL)
+ * and makes them the bitmaps gd_md_blocks and gd_md_sums_group use.  At most 65535 samples. */
+int gd_md_begin(gd_ctx* ctx, int64_t len);
+int gd_md_accumulate(gd_ctx* ctx, int n_samples, const int32_t* tids, int32_t min_cov);
+int gd_md_finish(gd_ctx* ctx, int32_t min_samples, uint32_t* any_bits, uint32_t* suf_bits, size_t n_words);
+/* Bitmaps made elsewhere become the current ones (tests; a host with its own depth source). */
+int gd_md_load_flags(gd_ctx* ctx, const uint32_t* any_bits, const uint32_t* suf_bits, int64_t len);
+/* The block state machine on the device (aggregate + splitBlocks, multidepth.go:188-268, for every chunk of
+ * `chunk` positions, in chunk order -- what `multidepth -p 1` prints): blocks [start, end) over the current
+ * bitmaps.  *n_blocks receives their number; GD_E_CAPACITY (with *n_blocks set) when cap is too small.  The
+ * quirks of the reference are kept: nothing is reported before a chunk's first insufficient site, the last
+ * cache of a chunk skips the min_size test, neighbouring chunks may report overlapping blocks. */
+int gd_md_blocks(gd_ctx* ctx, int64_t chunk, int32_t max_skip, int32_t min_size, int32_t window,
+                 int64_t* starts, int64_t* ends, size_t cap, size_t* n_blocks);
+/* gd_md_sums for the samples tids[0..n_samples) of the last gd_compute (one group): sums is [n_blocks][n_samples]. */
+int gd_md_sums_group(gd_ctx* ctx, int n_samples, const int32_t* tids, size_t n_blocks, const int64_t* start,
+                     const int64_t* end, double* sums);
 
 /* ---- BGZF inflate on device (the first stage of the BAM read of depth/depth.go:45) ----
  * A BGZF file is a sequence of independent <= 64 KiB DEFLATE streams ("members").  The

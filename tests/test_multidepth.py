@@ -1,6 +1,6 @@
 """`multidepth` (/root/reference/multidepth/multidepth.go): the
-host block state machine and the device kernels against the oracle's line-by-line
-restatement.  The reference ships no test for this tool and its arithmetic front end is an
+device kernels -- bitmaps, the block state machine restated as set operations (gd_md_blocks), block
+means, samples in groups -- against the oracle's line-by-line restatement.  The reference ships no test for this tool and its arithmetic front end is an
 external `samtools depth` over several BAMs: PARITY UNPINNED, the restatement
 (oracle/pyoracle.py::multidepth_py) is the contract."""
 import numpy as np
@@ -47,10 +47,15 @@ def test_oracle_hand_case():
         po.md_short_name("a.bam", ["S1", "S2"])
 
 
+@pytest.mark.gpu
 @pytest.mark.parametrize("seed", range(12))
-def test_host_state_machine_equals_oracle(seed):
-    from goleft_amd import _hostlib as hl
+def test_device_block_finder_equals_oracle(seed):
+    """aggregate + splitBlocks (multidepth.go:188-268) as the device finds them over uploaded bitmaps, against
+    the sequential restatement: small chunks (streams that run far past their chunk, overlapping blocks of
+    neighbouring chunks), max_skip 0, min_size on flushed caches only, window splits."""
+    from goleft_amd.engine import DepthEngine
     rng = np.random.default_rng(1000 + seed)
+    eng = DepthEngine(0)
     for _ in range(25):
         L, S = int(rng.integers(1, 5000)), int(rng.integers(1, 6))
         D = random_depths(rng, L, S)
@@ -64,12 +69,16 @@ def test_host_state_machine_equals_oracle(seed):
                                 min_samples=ms, chunk_size=chunk)
         A = np.stack(D)
         any_, suf = (A > 0).any(0), (A >= mincov).sum(0) > int(0.5 + ms * S)
-        got = hl.multidepth_blocks(any_, suf, chunk, maxskip, minsize, window)
-        assert [tuple(map(int, l.split("\t")[1:3])) for l in want] == [tuple(map(int, r)) for r in got]
+        eng.md_load_flags(any_, suf)
+        got = eng.md_blocks(chunk, maxskip, minsize, window)
+        assert [tuple(map(int, l.split("\t")[1:3])) for l in want] == [tuple(map(int, r)) for r in got], \
+            (L, S, mincov, maxskip, minsize, window, chunk, ms)
+    eng.close()
 
 
-def test_host_state_machine_dense_words():
-    # long all-sufficient stretches take the 32-sites-at-once path; results must not change
+@pytest.mark.gpu
+def test_device_block_finder_dense_words_and_host_entry():
+    # long all-sufficient stretches (whole words of set bits), through the host library's entry point
     from goleft_amd import _hostlib as hl
     rng = np.random.default_rng(9)
     L = 20000
@@ -107,6 +116,21 @@ def test_device_flags_and_sums(S, L):
         en = np.minimum(L, st + rng.integers(0, 3000, 40))
         st = np.append(st, [0, L]); en = np.append(en, [L, L])
         got = eng.md_sums(st, en, S)
+        # the same with the samples brought in groups of two: only a group's per-base vectors are resident
+        eng.md_begin(L)
+        groups = [list(range(g, min(S, g + 2))) for g in range(0, S, 2)]
+        for g in groups:
+            eng.select_contigs(g)
+            eng.compute()
+            eng.md_accumulate(g, mincov)
+        any_g, suf_g = eng.md_finish(need)
+        assert np.array_equal(any_g, any_) and np.array_equal(suf_g, suf)
+        got_g = np.zeros_like(got)
+        for g in groups:
+            eng.select_contigs(g)
+            eng.compute()
+            got_g[:, g] = eng.md_sums_group(g, st, en)
+        assert np.array_equal(got_g, got)
     for k in range(len(st)):
         for s in range(S):
             acc = 0.0
@@ -117,8 +141,11 @@ def test_device_flags_and_sums(S, L):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("opts", [dict(), dict(mincov=2, maxskip=3, minsize=4, window=500, q=1, minsamples=0.3)])
-def test_cli_matches_oracle(tmp_path, opts):
+@pytest.mark.parametrize("opts", [dict(), dict(mincov=2, maxskip=3, minsize=4, window=500, q=1, minsamples=0.3),
+                                  dict(group=3), dict(group=1, mincov=2, maxskip=0, minsize=2, window=50)])
+def test_cli_matches_oracle(tmp_path, opts, monkeypatch):
+    if "group" in opts:
+        monkeypatch.setenv("GOLEFT_MD_GROUP", str(opts["group"]))   # samples per resident group (default 16)
     # four "samples": the fixture's reads thinned differently
     from goleft_amd import multidepth
     contigs, reads, _ = H.load_golden_bam("t")
