@@ -106,7 +106,7 @@ struct gd_ctx {
     int tile_opt = 1;                   // bit 0: non-temporal per-base stores (2 % faster: the vector is
                                         // never re-read by the kernel)
     bool lookback_pinned = false;       // max_span_hint given: never shrink below it
-    int path = GD_PATH_AUTO;            // gd_set_path / GOLEFT_GD_PATH
+    int path = GD_PATH_AUTO;            // gd_set_path
     bool keep_perbase = true;           // gd_set_outputs(GD_OUT_PERBASE)
     bool sums_only = false;             // gd_set_outputs(GD_OUT_SUMS_ONLY): window sums, nothing else
     bool ran_sums_only = false;         // what the last gd_compute produced
@@ -158,7 +158,7 @@ struct gd_ctx {
     hipEvent_t ing_staged[2] = {nullptr, nullptr};
     hipStream_t ing_stream[8] = {};                     // inflate launches rotate over these (two pending ranges x 4)
     unsigned ing_launch_seq = 0;
-    int ing_copy_threads = 1;                          // GOLEFT_GD_COPY_THREADS: threads filling the staging buffer
+    int ing_copy_threads = 1;                          // GD_OPT_COPY_THREADS: threads filling the staging buffer
     uint8_t* d_seq = nullptr;  size_t cap_seq = 0;     // gd_seq_load: one contig's bases, zero padded
     int64_t seq_len = -1;
     uint32_t seq_padded = 0;
