@@ -392,6 +392,7 @@ def main():
     tr = None
     fast = r["path"] == 1 and r["n_canonical_ops"] > 0 and args.workload != "cohort"
     kname = ("gd_expand_scatter_kernel+gd_scan_kernel" if scatter else "gd_ltile2_kernel" if chunk else
+             "gd_sums_stream_kernel" if (args.workload == "cohort" and args.cohort_outputs == "sums" and "5=0" not in args.opt) else
              "gd_tile_sums_kernel" if (args.workload == "cohort" and args.cohort_outputs == "sums") else
              "gd_tile_fast_kernel" if fast else "gd_tile_kernel")
     if world == 1 and args.workload == "wgs" and args.coverage == 30.0 and r["path"] == 1:

@@ -380,21 +380,8 @@ __global__ __launch_bounds__(NT) void gd_ltile2_kernel(Job job)
     if (qn != 0u) drain(qn);
     __syncthreads();
 
-    // ---- phase B pass 1: wave chunk totals -------------------------------
+    // ---- phase B: scan the wave's quarter, publish its total, then carry / store / reduce ----
     const int chunk0 = wv * CHUNK;
-    {
-        int tot = 0;
-#pragma unroll
-        for (int r = 0; r < ROWS; ++r) {
-            const int4 v = *reinterpret_cast<const int4*>(&s_diff[chunk0 + r * 256 + lane * 4]);
-            tot += v.x + v.y + v.z + v.w;
-        }
-        tot = wave_total(tot);
-        if (lane == 0) s_wtot[wv] = tot;
-    }
-    __syncthreads();
-
-    // ---- phase B pass 2: scan, store, window reduce, class boundaries ----
     {
         PhaseB B;
         B.s_diff = s_diff; B.s_bmap = s_bmap; B.s_clo = s_clo; B.s_chi = s_chi; B.s_hasb = &s_hasb;
@@ -403,18 +390,42 @@ __global__ __launch_bounds__(NT) void gd_ltile2_kernel(Job job)
         B.wmin = job.win_min + ti.win_off;
         B.t0 = t0; B.tlen = tlen; B.chunk0 = chunk0; B.lane = lane;
         B.W = job.W; B.mincov = job.mincov; B.maxmean = job.maxmean; B.step = job.step;
+        // a read covers a position at most once: depth <= candidate reads
+        const bool wide = nrd >= (1u << 22);
+        if constexpr (ROWS == 4) {
+            if (tlen == T && !wide) {                     // workgroup uniform: the single-pass form
+                PhaseBRows R;
+                const int tot = phase_b_scan<ROWS>(B, R);
+                if (lane == 0) s_wtot[wv] = tot;
+                __syncthreads();
+                int carry = s_diff[-1];                    // depth at t0-1
+#pragma unroll
+                for (int v = 0; v < NW - 1; ++v) carry += v < wv ? s_wtot[v] : 0;
+                B.carry = carry;
+                phase_b_finish<ROWS, OPT>(B, R, job.w_magic, job.w_shift, job.s_magic, job.s_shift);
+                __syncthreads();
+                phase_c<T, NT>(job, tile, t0, ti.ctg, tid, lane, wv, s_bmap, s_clo, s_chi, s_wcnt, &s_hasb, &s_base);
+                return;
+            }
+        }
+        // clipped / very deep tiles and other tile shapes: totals pass, then row by row
+        {
+            int tot = 0;
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) {
+                const int4 v = *reinterpret_cast<const int4*>(&s_diff[chunk0 + r * 256 + lane * 4]);
+                tot += v.x + v.y + v.z + v.w;
+            }
+            tot = wave_total(tot);
+            if (lane == 0) s_wtot[wv] = tot;
+        }
+        __syncthreads();
         int carry = s_diff[-1];                            // depth at t0-1
 #pragma unroll
         for (int v = 0; v < NW - 1; ++v) carry += v < wv ? s_wtot[v] : 0;
         B.carry = carry;
-        // a read covers a position at most once: depth <= candidate reads
-        const bool wide = nrd >= (1u << 22);
-        if (tlen == T && !wide) {
-            if constexpr (ROWS == 4) phase_b_rows_full<ROWS, OPT>(B, job.w_magic, job.w_shift, job.s_magic, job.s_shift);
-            else                     phase_b_rows<ROWS, true, false, OPT>(B);
-        } else {
-            phase_b_rows<ROWS, false, true, OPT>(B);
-        }
+        if (tlen == T && !wide) phase_b_rows<ROWS, true, false, OPT>(B);
+        else                    phase_b_rows<ROWS, false, true, OPT>(B);
     }
     __syncthreads();
 

@@ -54,6 +54,7 @@ struct ContigDev {
     int64_t  win_off;         // element offset in the window arrays
     int32_t  tid;             // reference id in the BAM header
     uint32_t unit_beg;        // first 64-read unit of this contig (scatter path)
+    uint32_t grp_beg;         // first 4096-read unit of this contig (gd_sums_stream_kernel)
     // long-read path (gd_chunk.hpp), built when the records arrive:
     const uint4*    lrec;     // {pos, end, offset of the deletion list, offset of the tile index} per read
     const uint32_t* lfq;      // flag << 8 | MAPQ per read
@@ -149,6 +150,7 @@ struct Job {
     int32_t   reserved0;
     int64_t   step;
     uint32_t  n_units;        // scatter path: 64-read units over all contigs
+    uint32_t  n_groups;       // sums-only stream: 4096-read units over all contigs
     unsigned long long* tile_status;   // scatter path: look-back status word per tile
     uint32_t  w_magic, w_shift;   // floor(x / W)    = (x * w_magic) >> w_shift for x < 2^31
     uint32_t  s_magic, s_shift;   // floor(x / step) likewise (step clamped to 2^31-1)
@@ -437,6 +439,7 @@ __global__ __launch_bounds__(256) void gd_regions_bounds_kernel(const RegionTab*
 #include "gd_tile_common.hpp"
 #include "gd_tile_generic.hpp"
 #include "gd_tile_fast.hpp"
+#include "gd_sums_stream.hpp"
 #include "gd_scatter.hpp"
 #include "gd_chunk.hpp"
 #include "gd_depthwed.hpp"

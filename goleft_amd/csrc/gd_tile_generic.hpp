@@ -226,28 +226,62 @@ __device__ __forceinline__ uint32_t phase_a(const PhaseA& A, int32_t (&p)[4], ui
 // tile inside the contig, depths below 2^22 (32-bit window accumulation is
 // exact).  Other tiles take gd_tile_v6.hpp's generic phase_b_rows.
 //   ST    per-base stores: 0 plain, 1 non-temporal, 2 none (windows-only output)
+// The rows of a wave's quarter after their scans: what phase_b_scan leaves in registers for phase_b_finish.
+struct PhaseBRows {
+    int4 v[4];
+    int x1[4], x2[4], x3[4], incl[4];
+};
+
+// First half: load the wave's four rows of 256 positions and run the four wave scans.  Returns the quarter's
+// total (wave uniform): a kernel without a separate totals pass publishes it, waits for the other waves and
+// passes the carry to phase_b_finish in B.carry.
+template <int ROWS>
+__device__ __forceinline__ int phase_b_scan(const PhaseB& B, PhaseBRows& R)
+{
+    static_assert(ROWS == 4, "scan4 interleaves exactly four rows");
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r)
+        R.v[r] = *reinterpret_cast<const int4*>(&B.s_diff[B.chunk0 + r * 256 + B.lane * 4]);
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+        R.x1[r] = R.v[r].x + R.v[r].y; R.x2[r] = R.x1[r] + R.v[r].z; R.x3[r] = R.x2[r] + R.v[r].w;
+        R.incl[r] = R.x3[r];
+    }
+    scan4(R.incl[0], R.incl[1], R.incl[2], R.incl[3]);
+    int tot = 0;
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) tot += __builtin_amdgcn_readlane(R.incl[r], 63);
+    return tot;
+}
+
+template <int ROWS, int ST>
+__device__ __forceinline__ void phase_b_finish(const PhaseB& B, const PhaseBRows& R, uint32_t w_magic, uint32_t w_shift,
+                                               uint32_t s_magic, uint32_t s_shift);
+
 template <int ROWS, int ST>
 __device__ __forceinline__ void phase_b_rows_full(const PhaseB& B, uint32_t w_magic, uint32_t w_shift,
                                              uint32_t s_magic, uint32_t s_shift)
+{
+    PhaseBRows R;
+    (void)phase_b_scan<ROWS>(B, R);
+    phase_b_finish<ROWS, ST>(B, R, w_magic, w_shift, s_magic, s_shift);
+}
+
+template <int ROWS, int ST>
+__device__ __forceinline__ void phase_b_finish(const PhaseB& B, const PhaseBRows& R, uint32_t w_magic, uint32_t w_shift,
+                                               uint32_t s_magic, uint32_t s_shift)
 {
     constexpr int BIG = 0x3fffffff;
     constexpr int FAR = BIG - 65536;                     // anything at or past this is "never"
     const int lane = B.lane, t0 = B.t0, chunk0 = B.chunk0;
     const int W = B.W;
+    const int4 (&v)[4] = R.v;
+    const int (&x1)[4] = R.x1;
+    const int (&x2)[4] = R.x2;
+    const int (&x3)[4] = R.x3;
+    const int (&incl)[4] = R.incl;
 
-    // ---- stage 1: all rows of this wave: scan, store -------------------------
-    int4 v[ROWS];
-#pragma unroll
-    for (int r = 0; r < ROWS; ++r)
-        v[r] = *reinterpret_cast<const int4*>(&B.s_diff[chunk0 + r * 256 + lane * 4]);
-    int x1[ROWS], x2[ROWS], x3[ROWS], incl[ROWS];
-#pragma unroll
-    for (int r = 0; r < ROWS; ++r) {
-        x1[r] = v[r].x + v[r].y; x2[r] = x1[r] + v[r].z; x3[r] = x2[r] + v[r].w;
-        incl[r] = x3[r];
-    }
-    static_assert(ROWS == 4, "scan4 interleaves exactly four rows");
-    scan4(incl[0], incl[1], incl[2], incl[3]);
+    // ---- stage 1: all rows of this wave: carry in, store ----------------------
     int cin[ROWS + 1];                                    // depth just before each row
     cin[0] = B.carry;
 #pragma unroll

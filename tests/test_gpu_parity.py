@@ -361,13 +361,15 @@ def test_windows_only_output(auto_eng):
     assert np.array_equal(eng.perbase(0), want)
 
 
+@pytest.mark.parametrize("stream", [1, 0])
 @pytest.mark.parametrize("W", [32, 100, 250, 1000, 4096, 5000, 1 << 20])
-def test_sums_only_output(W):
-    """gd_set_outputs(GD_OUT_SUMS_ONLY): window sums from read/window overlaps, no per-base scan
-    (tile path); they equal the sums of the regular path; minima, class runs and the per-base
-    vector report GD_E_STATE; the depthwed matrix is unchanged."""
+def test_sums_only_output(W, stream):
+    """gd_set_outputs(GD_OUT_SUMS_ONLY): window sums from read/window overlaps, no per-base scan -- the
+    streaming kernel over the canonical records (gd_sums_stream.hpp; stream=1, the default) and the tile
+    kernel it replaces (GD_OPT_FAST_KERNEL = 0); they equal the sums of the regular path; minima, class runs
+    and the per-base vector report GD_E_STATE; the depthwed matrix is unchanged."""
     from goleft_amd import synth
-    from goleft_amd.engine import DepthEngine, GdError, PATH_TILE
+    from goleft_amd.engine import DepthEngine, GdError, PATH_TILE, OPT_FAST_KERNEL
     rng = np.random.default_rng(W)
     lengths = [300_001, 1, 4096, 70_000, 12_289]
     reads = {0: po.Reads(*synth.short_reads_numpy(lengths[0], synth.n_reads_for(lengths[0]), 3)),
@@ -375,6 +377,7 @@ def test_sums_only_output(W):
              3: H.random_reads(rng, lengths[3], 6000, max_len=90, long_reads=True),
              4: H.random_reads(rng, lengths[4], 20000, max_len=60)}     # deep: several record batches per tile
     with DepthEngine(0) as eng:
+        eng.set_option(OPT_FAST_KERNEL, stream)
         eng.set_params(window_size=W, min_mapq=1, min_cov=4)
         eng.set_path(PATH_TILE)
         eng.set_outputs(sums_only=True)
