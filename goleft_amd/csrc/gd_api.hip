@@ -125,7 +125,7 @@ void gd_destroy(gd_ctx* c)
     if (c->copy_done) (void)hipEventDestroy(c->copy_done);
     void* frees[] = {c->d_ctgs, c->d_tiles, c->d_ftiles, c->d_perbase, c->d_wsum, c->d_wmin, c->d_chunks,
                      c->d_ordered, c->d_tile_cnt, c->d_tile_off, c->d_super_cnt, c->d_counters,
-                     c->d_region_cursor, c->d_status, c->d_seq, c->d_md_bits, c->d_md_cnt, c->d_wed};
+                     c->d_region_cursor, c->d_status, c->d_seq, c->d_md_bits, c->d_md_cnt, c->d_wed, c->d_scan_tmp};
     for (void* p : frees) if (p) (void)hipFree(p);
     if (c->h_counters) (void)hipHostFree(c->h_counters);
     if (c->h_bounds) (void)hipHostFree(c->h_bounds);

@@ -159,6 +159,7 @@ struct gd_ctx {
     hipStream_t ing_stream[8] = {};                     // inflate launches rotate over these (two pending ranges x 4)
     unsigned ing_launch_seq = 0;
     int ing_copy_threads = 1;                          // GD_OPT_COPY_THREADS: threads filling the staging buffer
+    uint32_t* d_scan_tmp = nullptr; size_t cap_scan_tmp = 0;   // launch_scan: block totals
     uint8_t* d_seq = nullptr;  size_t cap_seq = 0;     // gd_seq_load: one contig's bases, zero padded
     int64_t seq_len = -1;
     uint32_t seq_padded = 0;
@@ -351,6 +352,21 @@ void launch_ltile(gd_ctx* c, const gd::Job& job)
         hipLaunchKernelGGL((gd::gd_ltile2_kernel<T, NT, 0>), dim3(grid), dim3(NT), 0, c->stream, job);
 }
 
+// In-place exclusive scan of v[0..n) on the compute stream, v[n] = total (v has n + 1 elements).
+int launch_scan(gd_ctx* c, uint32_t* v, uint32_t n)
+{
+    if (n <= 4u * gd::norm::SCAN_BLOCK) {
+        hipLaunchKernelGGL(gd::norm::gd_unit_scan_kernel, dim3(1), dim3(1024), 0, c->stream, v, n);
+        return GD_OK;
+    }
+    const uint32_t nb = (n + gd::norm::SCAN_BLOCK - 1u) / gd::norm::SCAN_BLOCK;
+    if (int r = ensure_dev(c, &c->d_scan_tmp, &c->cap_scan_tmp, (size_t)nb + 1)) return r;
+    hipLaunchKernelGGL(gd::norm::gd_scan_totals_kernel, dim3(nb), dim3(256), 0, c->stream, v, n, c->d_scan_tmp);
+    hipLaunchKernelGGL(gd::norm::gd_unit_scan_kernel, dim3(1), dim3(1024), 0, c->stream, c->d_scan_tmp, nb);
+    hipLaunchKernelGGL(gd::norm::gd_scan_apply_kernel, dim3(nb), dim3(256), 0, c->stream, v, n, c->d_scan_tmp, nb);
+    return GD_OK;
+}
+
 // Long-read path: deletion lists, their checkpoints and the read records of one contig (gd_dels_kernel), from
 // its canonical CIGARs.  Part of taking the records in (or of the first gd_compute that needs them), kept until
 // the records change.
@@ -384,7 +400,7 @@ int build_ck(gd_ctx* c, ContigHost& h)
     if (n_units) {
         hipLaunchKernelGGL(gd::gd_dels_kernel, dim3((n_units + 3u) / 4u), dim3(256), 0, c->stream, j);
         hipLaunchKernelGGL(gd::gd_ptile_count_kernel, dim3((n_units + 3u) / 4u), dim3(256), 0, c->stream, pj);
-        hipLaunchKernelGGL(gd::norm::gd_unit_scan_kernel, dim3(1), dim3(1024), 0, c->stream, unit, n_units);
+        if (int r = launch_scan(c, unit, n_units)) return r;
         HIPCHK(c, hipMemcpyAsync(&n_pck, unit + n_units, sizeof n_pck, hipMemcpyDeviceToHost, c->stream));
     }
     int32_t span = 0;
@@ -437,7 +453,7 @@ int norm_contig(gd_ctx* c, ContigHost& h)
     if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
     if (n_units) {
         hipLaunchKernelGGL(gd::norm::gd_norm_count_kernel, dim3((n_units + 3u) / 4u), dim3(256), 0, c->stream, j);
-        hipLaunchKernelGGL(gd::norm::gd_unit_scan_kernel, dim3(1), dim3(1024), 0, c->stream, h.nunit, n_units);
+        if (int r = launch_scan(c, h.nunit, n_units)) return r;
         HIPCHK(c, hipMemcpyAsync(total, h.nunit + n_units, sizeof total, hipMemcpyDeviceToHost, c->stream));
     }
     hipLaunchKernelGGL(gd::norm::gd_pidx_kernel, dim3((n_idx + 255u) / 256u), dim3(256), 0, c->stream,

@@ -75,7 +75,13 @@ class RootGather:
     `cap_b` (boundaries per rank) is agreed once by `reserve()` (an all_reduce MAX of the counts of
     a first compute; data-dependent, like the reference's callable.bed row count).  A later step
     with more boundaries than the capacity is detected on rank 0 by `result()` (`overflow`), never
-    silently truncated."""
+    silently truncated.
+
+    The buffers are DOUBLE: the collective of step k is asynchronous and reads send buffer k % 2 while
+    the compute of step k + 1 already fills the other one (`gd_set_export` is re-pointed every step), so
+    the exchange of one step runs under the kernels of the next -- and nothing is ever written into a
+    buffer a collective may still be reading: before buffer k % 2 is handed out again (step k + 2) the
+    collective of step k is waited for (two steps later it has long finished)."""
 
     def __init__(self, assignment: List[List[int]], lengths: Sequence[int], W: int, rank: int,
                  world: int, device, bounds_cap: int = 1 << 16, group=None):
@@ -86,15 +92,53 @@ class RootGather:
         self.words_m = (self.max_w + 1) // 2
         self.cap_b = 0
         self.send = self.recv = None
+        self._eng = None
         self._alloc(int(bounds_cap))
 
     def _alloc(self, cap_b: int):
+        self.drain()
         self.cap_b = cap_b
         self.total = 1 + self.max_w + self.words_m + cap_b
-        self.send = torch.zeros(self.total, dtype=torch.int64, device=self.device)
+        self._sends = [torch.zeros(self.total, dtype=torch.int64, device=self.device) for _ in range(2)]
+        self._recvs, self._partss = [None, None], [None, None]
         if self.rank == 0:
-            self.recv = torch.zeros(self.world, self.total, dtype=torch.int64, device=self.device)
-            self._parts = list(self.recv.unbind(0))            # views of the one receive buffer
+            self._recvs = [torch.zeros(self.world, self.total, dtype=torch.int64, device=self.device) for _ in range(2)]
+            self._partss = [list(r.unbind(0)) for r in self._recvs]   # views of the receive buffers
+        self._works = [None, None]
+        self._cur = 0                                           # the buffer pair the NEXT step uses
+        self._last = 0                                          # the pair the last step used
+        self.send, self.recv = self._sends[0], self._recvs[0]
+
+    def _wait(self, k: int):
+        """The collective that last used buffer pair k has finished (host side)."""
+        w = self._works[k] if getattr(self, "_works", None) else None
+        if w is not None:
+            w.wait()
+            if self.device is not None and torch.device(self.device).type == "cuda":
+                torch.cuda.current_stream(self.device).synchronize()   # NCCL's wait() only orders the stream
+            self._works[k] = None
+
+    def drain(self):
+        """Every collective issued so far has finished (host side)."""
+        for k in (0, 1):
+            self._wait(k)
+
+    def _exchange(self):
+        """ONE collective on the current buffer pair, asynchronous; then hand out the other pair."""
+        k = self._cur
+        buf = self._sends[k]
+        if self.world == 1:
+            self._recvs[k][0].copy_(buf)
+        elif self.rank == 0:
+            self._works[k] = dist.gather(buf, self._partss[k], dst=0, group=self.group, async_op=True)
+        else:
+            self._works[k] = dist.gather(buf, None, dst=0, group=self.group, async_op=True)
+        self._last = k
+        self._cur = k ^ 1
+        self._wait(self._cur)                                   # its collective (two steps ago) must be over
+        self.send, self.recv = self._sends[self._cur], self._recvs[self._last]
+        if self._eng is not None:
+            self._eng.set_export(self.send.data_ptr(), self.max_w, self.cap_b)
 
     def reserve(self, n_bounds: int, slack: float = 1.25):
         """Collective, setup time only: make every rank's boundary capacity cover the largest count
@@ -113,7 +157,7 @@ class RootGather:
         for the device."""
         k = sums.numel()
         nb = bounds.numel() // 2
-        buf = self.send
+        buf = self._sends[self._cur]
         buf[0:1].fill_(nb)
         buf[1:1 + k].copy_(sums)
         buf[1 + self.max_w:1 + self.max_w + self.words_m].view(torch.int32)[:k].copy_(mins)
@@ -121,37 +165,31 @@ class RootGather:
         if m:
             o = 1 + self.max_w + self.words_m
             buf[o:o + m].copy_(bounds.view(torch.int64)[:m])
-        if self.world == 1:
-            self.recv[0].copy_(buf)
-        elif self.rank == 0:
-            dist.gather(buf, self._parts, dst=0, group=self.group)
-        else:
-            dist.gather(buf, None, dst=0, group=self.group)
+        self._exchange()
 
     def attach(self, eng):
         """Let the engine fill the send buffer itself: gd_set_export makes every gd_compute write the
         packed block (same layout) before its one synchronisation, so a step is compute + ONE
         collective with no pack launches at all.  Call again after reserve() re-allocated."""
-        eng.set_export(self.send.data_ptr(), self.max_w, self.cap_b)
-        self._attached = self.send.data_ptr()
+        self._eng = eng
+        eng.set_export(self._sends[self._cur].data_ptr(), self.max_w, self.cap_b)
+        self._attached = id(self._sends)
 
     def step_exported(self):
-        """The exchange after a compute() of an attached engine (the block is already in `send`)."""
-        assert getattr(self, "_attached", None) == self.send.data_ptr(), "attach() after the last (re)allocation"
-        if self.world == 1:
-            self.recv[0].copy_(self.send)
-        elif self.rank == 0:
-            dist.gather(self.send, self._parts, dst=0, group=self.group)
-        else:
-            dist.gather(self.send, None, dst=0, group=self.group)
+        """The exchange after a compute() of an attached engine (the block is already in the current send
+        buffer); the engine's next compute exports into the other one."""
+        assert getattr(self, "_attached", None) == id(self._sends), "attach() after the last (re)allocation"
+        self._exchange()
 
     def result(self):
         """Rank 0: what the last step gathered, as the dict unpack_gathered() takes (one host
         synchronisation, outside the exchange); other ranks: None."""
+        self._wait(self._last)
         if self.rank != 0:
             return None
-        counts = [int(c) for c in self.recv[:, 0].tolist()]
-        return {"parts": [p[1:] for p in self.recv.unbind(0)], "counts": [min(c, self.cap_b) for c in counts],
+        recv = self._recvs[self._last]
+        counts = [int(c) for c in recv[:, 0].tolist()]
+        return {"parts": [p[1:] for p in recv.unbind(0)], "counts": [min(c, self.cap_b) for c in counts],
                 "overflow": any(c > self.cap_b for c in counts), "true_counts": counts,
                 "max_w": self.max_w, "words_m": self.words_m,
                 "assignment": self.assignment, "lengths": self.lengths, "W": self.W}

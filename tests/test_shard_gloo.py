@@ -108,8 +108,8 @@ def test_gather_single_rank_is_identity():
 
 
 def _worker_steps(rank, world, port, out_path):
-    """RootGather reused over several steps with CHANGING results (fixed buffers, one collective per
-    step), then a step whose boundary count exceeds the agreed capacity."""
+    """RootGather reused over several steps with CHANGING results (two fixed buffer pairs used alternately,
+    one asynchronous collective per step), then a step whose boundary count exceeds the agreed capacity."""
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -120,12 +120,12 @@ def _worker_steps(rank, world, port, out_path):
         g = shard.RootGather(assignment, lengths, W, rank, world, torch.device("cpu"), bounds_cap=0)
         s, m, b = _local(lengths, reads, assignment[rank], W, 4, step)
         cap = g.reserve(len(b) // 2)
-        send_ptr = g.send.data_ptr()
+        send_ptrs = {b.data_ptr() for b in g._sends}   # two fixed send buffers, used alternately
         ok = True
         for mincov in (4, 2, 7, 4):                    # different class runs every step, same buffers
             s, m, b = _local(lengths, reads, assignment[rank], W, mincov, step)
             g.step(torch.from_numpy(s), torch.from_numpy(m), torch.from_numpy(b))
-            ok &= g.send.data_ptr() == send_ptr
+            ok &= g.send.data_ptr() in send_ptrs and {b.data_ptr() for b in g._sends} == send_ptrs   # never re-allocated
             if rank == 0:
                 gg = g.result()
                 ok &= not gg["overflow"]
