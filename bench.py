@@ -522,7 +522,8 @@ def main():
         out["split"] = r_split
     # N > 1: the headline is ONE genome over N GPUs (BASELINE.json config 3); the cohort case (N genomes,
     # one per GPU, no exchange) is reported next to it
-    if world > 1 and args.scaling == "strong" and args.workload in ("wgs", "ont"):
+    if world > 1 and args.scaling == "strong" and args.workload in ("wgs", "ont") and \
+            not os.environ.get("GOLEFT_BENCH_SKIP_COHORT"):     # (dry runs on the 1-GPU box skip the side case)
         try:
             torch.cuda.empty_cache()
             r2 = run_case(args, "weak", world, rank, dev, local_rank)
