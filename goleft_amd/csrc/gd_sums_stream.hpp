@@ -126,43 +126,65 @@ __global__ __launch_bounds__(256) void gd_sums_stream_kernel(Job job)
         const bool inb = g0 + (uint32_t)lane * U < r_end;
         const uint32_t kb = inb ? div_magic((uint32_t)(p[0] > 0 ? p[0] : 0), wm, ws) : 0xffffffffu;
         uint32_t a0 = 0, a1 = 0, a2 = 0;
+        uint32_t s_[U], e_[U];
+        uint32_t odd = 0;                                          // bit u: read u of this lane goes the long way
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            if (!keep[u]) continue;
             const uint32_t len = cg[u] >> 4;
-            if (n[u] == 1u) {
-                // canonical: a single op is an M of 1 <= len < 2^28.  [s, e) clipped to the contig, in 32 bits
-                // (a negative POS -- no aligner writes one -- counts from 0 like everywhere else)
-                const uint32_t s = p[u] > 0 ? (uint32_t)p[u] : 0u;
-                const uint32_t eu = p[u] >= 0 ? s + len : ((int)len > -p[u] ? len - (uint32_t)(-p[u]) : 0u);   // < 2^31 + 2^28
-                const uint32_t e = eu < length ? eu : length;
-                if (e > s) {
-                    const uint32_t k1 = div_magic(s, wm, ws);
-                    const uint32_t room = (k1 + 1u) * W - s;       // positions left in the start window
-                    const uint32_t tot = e - s;
-                    const uint32_t ca = tot < room ? tot : room, cb = tot - ca;
-                    const uint32_t d = k1 - kb;
-                    if (cb > W || d > 1u + (cb == 0u ? 1u : 0u)) {
-                        add_interval_direct(wsum, nwin, W, wm, ws, s, e);   // longer than two windows, or too far from kb
-                    } else {
-                        a0 += d == 0u ? ca : 0u;
-                        a1 += (d == 1u ? ca : 0u) + (d == 0u ? cb : 0u);
-                        a2 += (d == 2u ? ca : 0u) + (d == 1u ? cb : 0u);
-                    }
+            // canonical: a single op is an M of 1 <= len < 2^28.  [s, e) clipped to the contig, in 32 bits
+            // (a negative POS -- no aligner writes one -- counts from 0 like everywhere else)
+            const uint32_t s = p[u] > 0 ? (uint32_t)p[u] : 0u;
+            const uint32_t eu = p[u] >= 0 ? s + len : ((int)len > -p[u] ? len - (uint32_t)(-p[u]) : 0u);   // < 2^31 + 2^28
+            const uint32_t e = eu < length ? eu : length;
+            s_[u] = s; e_[u] = e;
+            if (keep[u] & (n[u] == 1u) & (e > s)) {
+                const uint32_t k1 = div_magic(s, wm, ws);
+                const uint32_t room = (k1 + 1u) * W - s;           // positions left in the start window
+                const uint32_t tot = e - s;
+                const uint32_t ca = tot < room ? tot : room, cb = tot - ca;
+                const uint32_t d = k1 - kb;
+                if (cb > W || d > 1u + (cb == 0u ? 1u : 0u)) {
+                    odd |= 1u << u;                                // longer than two windows, or too far from kb
+                } else {
+                    a0 += d == 0u ? ca : 0u;
+                    a1 += (d == 1u ? ca : 0u) + (d == 0u ? cb : 0u);
+                    a2 += (d == 2u ? ca : 0u) + (d == 1u ? cb : 0u);
                 }
-            } else {
-                // multi-op: walk the canonical ops, M (0) counted, N (3) skipped, every M interval on its own
-                const uint32_t* ops = cig + obase + ex[u];
-                long long x = p[u];
-                for (uint32_t k = 0; k < n[u]; ++k) {
-                    const uint32_t o = k == 0u ? cg[u] : k == 1u ? cg1[u] : k == 2u ? cg2[u] : ops[k], ol = o >> 4;
-                    if ((o & 0xfu) == 0u) {
-                        const long long e64 = x + (long long)ol;
-                        const uint32_t s = x > 0 ? (x < (long long)length ? (uint32_t)x : length) : 0u;
-                        const uint32_t e = e64 < (long long)length ? (e64 > 0 ? (uint32_t)e64 : 0u) : length;
-                        if (e > s) add_interval_direct(wsum, nwin, W, wm, ws, s, e);
+            }
+            odd |= (keep[u] & (n[u] > 1u)) ? 1u << u : 0u;         // multi-op (2 % of short reads)
+        }
+        // The long way, ONE instance of the code for all four slots: nearly every group of 256 reads has a few
+        // multi-op reads, in different slots of different lanes -- a block per slot ran three of the four blocks
+        // with a handful of lanes each (PMC: more than half of this kernel's vector instructions).  Every lane
+        // takes its next flagged read (a select over the four slots); usually one round.
+        while (__builtin_amdgcn_ballot_w64(odd != 0u) != 0ull) {
+            if (odd != 0u) {
+                const int u = __ffs((int)odd) - 1;
+                odd &= odd - 1u;
+                const int32_t pu = u == 0 ? p[0] : u == 1 ? p[1] : u == 2 ? p[2] : p[3];
+                const uint32_t nu = u == 0 ? n[0] : u == 1 ? n[1] : u == 2 ? n[2] : n[3];
+                if (nu == 1u) {
+                    const uint32_t su = u == 0 ? s_[0] : u == 1 ? s_[1] : u == 2 ? s_[2] : s_[3];
+                    const uint32_t eu = u == 0 ? e_[0] : u == 1 ? e_[1] : u == 2 ? e_[2] : e_[3];
+                    add_interval_direct(wsum, nwin, W, wm, ws, su, eu);
+                } else {
+                    // walk the canonical ops: M (0) counted, N (3) skipped, every M interval on its own
+                    const uint32_t c0 = u == 0 ? cg[0] : u == 1 ? cg[1] : u == 2 ? cg[2] : cg[3];
+                    const uint32_t c1 = u == 0 ? cg1[0] : u == 1 ? cg1[1] : u == 2 ? cg1[2] : cg1[3];
+                    const uint32_t c2 = u == 0 ? cg2[0] : u == 1 ? cg2[1] : u == 2 ? cg2[2] : cg2[3];
+                    const uint32_t xu = u == 0 ? ex[0] : u == 1 ? ex[1] : u == 2 ? ex[2] : ex[3];
+                    const uint32_t* ops = cig + obase + xu;
+                    long long x = pu;
+                    for (uint32_t k = 0; k < nu; ++k) {
+                        const uint32_t o = k == 0u ? c0 : k == 1u ? c1 : k == 2u ? c2 : ops[k], ol = o >> 4;
+                        if ((o & 0xfu) == 0u) {
+                            const long long e64 = x + (long long)ol;
+                            const uint32_t s = x > 0 ? (x < (long long)length ? (uint32_t)x : length) : 0u;
+                            const uint32_t e = e64 < (long long)length ? (e64 > 0 ? (uint32_t)e64 : 0u) : length;
+                            if (e > s) add_interval_direct(wsum, nwin, W, wm, ws, s, e);
+                        }
+                        x += (long long)ol;
                     }
-                    x += (long long)ol;
                 }
             }
         }

@@ -111,8 +111,9 @@ typedef struct {
     uint64_t n_canonical_ops; /* ops of the canonical CIGARs the tile / long-read path read (0: it read the original ones) */
 } gd_stats;
 
-/* Kernel ids for gd_kernel_ms.  Tile path: PREP, TILE, RUNS.  Chunk path: CKPT
- * (CIGAR checkpoints + read ends), PREP, TILE (the long-read tile kernel), RUNS.
+/* Kernel ids for gd_kernel_ms.  Tile path: PREP, TILE, RUNS.  Long-read path: PREP, TILE (the long-read tile
+ * kernel), RUNS; CKPT = its deletion lists + tile indexes, built when the records arrive (like NORM: summed over
+ * the contigs since gd_set_profiling was last called, not cleared by gd_compute).
  * Scatter path: PREP (zero-fill + init), EXPAND (CIGAR expand + scatter), SCAN
  * (in-place scan + window / class reductions), RUNS. */
 enum { GD_K_PREP = 0, GD_K_TILE = 1, GD_K_RUNS = 2, GD_K_EXPAND = 3, GD_K_SCAN = 4, GD_K_CKPT = 5,
@@ -185,9 +186,9 @@ int gd_canonical_cigars(gd_ctx* ctx, int32_t tid, uint32_t* cigar_off, uint32_t*
  * genome, and what a cohort (depthwed) needs; tile and chunk paths only. */
 enum { GD_OUT_PERBASE = 1,
        /* Window sums ONLY (no per-base vector, no minima, no class runs): all that depth.bed's mean
-        * column and the depthwed matrix need.  The tile path then adds every read interval's overlap
-        * with the one or two windows it touches straight into per-tile accumulators -- no per-base
-        * scan at all (window_size >= 32; smaller windows and the long-read path silently run the
+        * column and the depthwed matrix need.  The short-read path then makes ONE streaming pass over the
+        * canonical records, every read adding its overlap with the one or two windows it touches -- no tiles,
+        * no per-base scan at all (window_size >= 32; smaller windows and the long-read path silently run the
         * regular windows-only kernels).  gd_callable and minima report GD_E_STATE.  Excludes
         * GD_OUT_PERBASE. */
        GD_OUT_SUMS_ONLY = 2 };
