@@ -44,6 +44,8 @@ SYMBOLS = {
     "gdh_intervals_free": (None, [_P]),
     "gdh_intervals_overlaps": (C.c_int, [_P, C.c_char_p, C.c_int64, C.c_int64]),
     "gdh_intervals_count": (C.c_size_t, [_P, C.c_char_p]),
+    "gdh_list_members": (C.c_int64, [_P, C.c_size_t, C.c_uint64, _P, C.c_size_t, C.c_uint, C.c_size_t, C.c_size_t,
+                                     _P, _P, _P, _P, _P]),
     "gdh_set_stats_contract": (C.c_int, [C.c_int]),
     "gdh_get_stats_contract": (C.c_int, []),
     "gdh_format_stats": (C.c_int, [C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_uint32, C.c_uint32, C.c_uint32,
@@ -214,6 +216,22 @@ def multidepth_blocks(any_mask, suf_mask, chunk, max_skip=10, min_size=15, windo
     load().gdh_multidepth_blocks(aw.ctypes.data, sw.ctypes.data, n, chunk, max_skip, min_size, window,
                                  st.ctypes.data, en.ctypes.data, cnt)
     return np.stack([st, en], 1)
+
+
+def list_members(data: bytes, beg: int, member_starts, threads: int = 16, min_bytes: int = 64 << 20):
+    """gdh_list_members: (off u64[n], size u32[n], hdr u16[n], isize u32[n], crc u32[n]) of the complete BGZF members
+    of `data` (file offset `beg`), the walk cut at .bai-known member starts and run by `threads` threads."""
+    import numpy as np
+    raw = np.frombuffer(data, np.uint8)
+    st = np.ascontiguousarray(member_starts, np.uint64)
+    args = (raw.ctypes.data, raw.size, int(beg), st.ctypes.data if st.size else None, st.size, int(threads), int(min_bytes))
+    n = load().gdh_list_members(*args, 0, None, None, None, None, None)
+    if n < 0:
+        raise ValueError("not a BGZF range")
+    off = np.zeros(n, np.uint64); size = np.zeros(n, np.uint32); hdr = np.zeros(n, np.uint16)
+    isize = np.zeros(n, np.uint32); crc = np.zeros(n, np.uint32)
+    load().gdh_list_members(*args, n, off.ctypes.data, size.ctypes.data, hdr.ctypes.data, isize.ctypes.data, crc.ctypes.data)
+    return off, size, hdr, isize, crc
 
 
 def plan_ingest_passes(start, has, wanted, file_size, group_bytes):

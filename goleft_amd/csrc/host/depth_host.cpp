@@ -480,6 +480,7 @@ int run(const DArgs& args)
             return 1;
         }
         GDCHK_ON(sh.ctx, gd_set_params(sh.ctx, &P));
+        GDCHK_ON(sh.ctx, gd_set_option(sh.ctx, GD_OPT_COPY_THREADS, 4));   // staging copies of the device BAM read (8 % on a 3 GB file)
         GDCHK_ON(sh.ctx, gd_set_contigs(sh.ctx, (int)lens.size(), lens.data()));
         if (!need_perbase) GDCHK_ON(sh.ctx, gd_set_outputs(sh.ctx, 0));   // windows + class runs are all the rows need
         if (!contigs.empty() && !sh.wanted.empty())

@@ -13,7 +13,9 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../../include/goleft_depth.h"
@@ -94,6 +96,90 @@ inline std::vector<IngestPass> plan_ingest_passes(const std::vector<uint64_t>& s
     return out;
 }
 
+// The BGZF members of a byte range: offsets (relative to the range), sizes, header sizes, ISIZE and CRC of every
+// complete member.  A member's header says where the next one starts, so the walk is serial -- 0.2 s for the
+// 230 k members of a 3.7 GB chromosome, a quarter of that file's whole read.  The .bai breaks the chain: the
+// upper 48 bits of every linear-index entry are the file offset of a member, so the range is cut at ~16 of them
+// and the pieces are walked by as many threads (each must end exactly where the next begins; anything else --
+// a stale index -- falls back to the serial walk).
+struct MemberTable {
+    std::vector<uint64_t> off;
+    std::vector<uint32_t> size, isize, crc;
+    std::vector<uint16_t> hdr;
+    size_t n = 0;
+};
+
+inline bool list_members_serial(const uint8_t* base, size_t nb, MemberTable* t, size_t guess)
+{
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        t->off.resize(guess); t->size.resize(guess); t->isize.resize(guess); t->crc.resize(guess); t->hdr.resize(guess);
+        size_t nm = 0;
+        const int rc = gd_bgzf_members(base, nb, guess, t->off.data(), t->size.data(), t->hdr.data(), t->isize.data(),
+                                       t->crc.data(), &nm);
+        if (rc == GD_OK) {
+            t->n = nm;
+            t->off.resize(nm); t->size.resize(nm); t->isize.resize(nm); t->crc.resize(nm); t->hdr.resize(nm);
+            return true;
+        }
+        if (rc != GD_E_CAPACITY) return false;
+        guess = nm;                                          // the exact count: second walk
+    }
+    return false;
+}
+
+inline bool list_members(const uint8_t* base, size_t nb, uint64_t beg, const std::vector<uint64_t>& member_starts,
+                         MemberTable* out, unsigned max_threads = 16, size_t kMin = 64u << 20)
+{
+    // (ranges under kMin bytes: not worth the threads)
+    std::vector<uint64_t> cuts;                              // range-relative member starts, strictly inside the range
+    if (nb >= kMin && max_threads > 1) {
+        std::vector<uint64_t> c;
+        for (uint64_t m : member_starts)
+            if (m > beg && m - beg < nb) c.push_back(m - beg);
+        std::sort(c.begin(), c.end());
+        c.erase(std::unique(c.begin(), c.end()), c.end());
+        const unsigned pieces = (unsigned)std::min<size_t>(max_threads, nb / std::max<size_t>(kMin / 4, 1));
+        for (unsigned k = 1; k < pieces && !c.empty(); ++k) {
+            const uint64_t target = (uint64_t)((unsigned __int128)nb * k / pieces);
+            auto it = std::lower_bound(c.begin(), c.end(), target);
+            if (it == c.end()) break;
+            if (cuts.empty() || *it > cuts.back()) cuts.push_back(*it);
+        }
+    }
+    if (cuts.empty()) return list_members_serial(base, nb, out, nb / 12000 + 64);
+    std::vector<uint64_t> seg_beg{0};
+    seg_beg.insert(seg_beg.end(), cuts.begin(), cuts.end());
+    const size_t ns = seg_beg.size();
+    std::vector<MemberTable> part(ns);
+    std::vector<char> ok(ns, 0);
+    std::vector<std::thread> th;
+    for (size_t k = 0; k < ns; ++k)
+        th.emplace_back([&, k]() {
+            const uint64_t b = seg_beg[k], e = k + 1 < ns ? seg_beg[k + 1] : (uint64_t)nb;
+            ok[k] = list_members_serial(base + b, (size_t)(e - b), &part[k], (size_t)((e - b) / 12000 + 64));
+            if (ok[k] && k + 1 < ns) {                         // an inner piece must be tiled exactly by its members
+                const MemberTable& p = part[k];
+                ok[k] = p.n != 0 && p.off[p.n - 1] + p.size[p.n - 1] == e - b;
+            }
+        });
+    for (auto& t : th) t.join();
+    for (size_t k = 0; k < ns; ++k)
+        if (!ok[k]) return list_members_serial(base, nb, out, nb / 12000 + 64);   // the index lied: walk the chain
+    size_t total = 0;
+    for (const MemberTable& p : part) total += p.n;
+    out->off.resize(total); out->size.resize(total); out->isize.resize(total); out->crc.resize(total); out->hdr.resize(total);
+    size_t w = 0;
+    for (size_t k = 0; k < ns; ++k) {
+        const MemberTable& p = part[k];
+        for (size_t i = 0; i < p.n; ++i, ++w) {
+            out->off[w] = p.off[i] + seg_beg[k]; out->size[w] = p.size[i]; out->isize[w] = p.isize[i];
+            out->crc[w] = p.crc[i]; out->hdr[w] = p.hdr[i];
+        }
+    }
+    out->n = total;
+    return true;
+}
+
 // Records of the BAM references refs[0..n) (ascending reference ids that have records) -> engine
 // contigs tids[0..n), decoded on the device.  lin = BamReader::linear_index() of the file.
 // References that follow each other in the file share one pass while the pass stays under
@@ -141,15 +227,17 @@ inline int ingest_references_on_device(gd_ctx* ctx, const FileMap& fm, const std
         if (beg >= end) return bad_file();
         const uint8_t* base = fm.p + beg;
         const size_t nb = (size_t)(end - beg);
-        size_t nm = 0;
         const double t0 = now();
-        int rc = gd_bgzf_members(base, nb, 0, nullptr, nullptr, nullptr, nullptr, nullptr, &nm);
-        if ((rc != GD_OK && rc != GD_E_CAPACITY) || nm == 0) return bad_file();
-        std::vector<uint64_t> moff(nm);
-        std::vector<uint32_t> msize(nm), misize(nm), mcrc(nm);
-        std::vector<uint16_t> mhdr(nm);
-        if (gd_bgzf_members(base, nb, nm, moff.data(), msize.data(), mhdr.data(), misize.data(), mcrc.data(), &nm) != GD_OK)
-            return bad_file();
+        std::vector<uint64_t> member_starts;                   // what the .bai knows about where members begin
+        for (size_t k = i; k <= j; ++k)
+            for (uint64_t v : lin[(size_t)refs[k]]) member_starts.push_back(v >> 16);
+        MemberTable mt;
+        if (!list_members(base, nb, beg, member_starts, &mt) || mt.n == 0) return bad_file();
+        const size_t nm = mt.n;
+        std::vector<uint64_t>& moff = mt.off;
+        std::vector<uint32_t>&msize = mt.size, &misize = mt.isize, &mcrc = mt.crc;
+        std::vector<uint16_t>& mhdr = mt.hdr;
+        int rc = GD_OK;
         const size_t used = (size_t)(moff[nm - 1] + msize[nm - 1]);   // a trailing partial member is not fed
         const double t1 = now();
         rc = gd_ingest_begin(ctx, used, beg, nm, moff.data(), msize.data(), mhdr.data(), misize.data(), mcrc.data());

@@ -53,6 +53,16 @@ int gdh_format_region(const char* chrom, int64_t region_start, int64_t region_en
                       const gd_run* runs, size_t n_runs,
                       const char* depth_path, const char* callable_path);
 
+/* The BGZF members of a byte range of a BAM (what gd_ingest_begin wants), listed in parallel: a member's header
+ * says where the next one starts, so the walk is serial -- unless somebody knows member starts inside the range.
+ * The .bai does: the upper 48 bits of every linear-index entry.  member_starts[] are absolute file offsets, `beg`
+ * the file offset of data[0]; the range is cut at up to `threads` of them (ranges under min_bytes: one walk) and
+ * every piece must end exactly where the next begins, else (a stale index) the serial walk decides.  Offsets
+ * returned are relative to data.  Returns the member count (fills up to cap), -1 for a range that is not BGZF. */
+int64_t gdh_list_members(const uint8_t* data, size_t n_bytes, uint64_t beg, const uint64_t* member_starts, size_t n_starts,
+                         unsigned threads, size_t min_bytes, size_t cap, uint64_t* off, uint32_t* size, uint16_t* hdr,
+                         uint32_t* isize, uint32_t* crc);
+
 /* ---- the contract of the `--stats` columns ------------------------------------------------------------
  * depth/depth.go:191-200 prints "%.3g" of faidx.Stats(chrom, start, end).GC / .CpG / .Masked.  faidx is an
  * external module (github.com/brentp/faidx @c39eb85, go.mod:12) that is not under /root/reference, and no

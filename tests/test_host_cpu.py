@@ -355,3 +355,31 @@ def test_host_lpt_assign_matches_the_bench_sharding(hostlib):
     assert list(sub) == [0, 1, 0]
     with pytest.raises(ValueError):
         hostlib.lpt_assign([99], L, 2)
+
+
+def test_parallel_member_listing_equals_the_serial_walk(tmp_path):
+    """gdh_list_members: the BGZF member table of a BAM range walked in pieces cut at .bai-known member starts equals
+    the serial walk -- also when a "known start" is not a member start (stale index: the serial walk decides), when
+    there are no usable cut points, and for a range that ends inside a member."""
+    from goleft_amd import _hostlib as hl
+    from oracle import bamio
+    rng = np.random.default_rng(3)
+    contigs = [("c1", 400_000)]
+    reads = {0: H.random_reads(rng, 400_000, 60_000, max_len=120)}
+    path = str(tmp_path / "x.bam")
+    bamio.write_bam(path, contigs, reads)
+    data = open(path, "rb").read()
+    ser = hl.list_members(data, 0, [], threads=1)
+    n = len(ser[0])
+    assert n > 40 and int(ser[0][-1] + ser[1][-1]) == len(data)          # the walk tiles the whole file
+    starts = ser[0][3::5] + 1000                                            # absolute offsets: the range begins at file offset 1000
+    for th, extra in ((16, []), (4, []), (16, [int(ser[0][7]) + 1000 + 13]), (16, [5]), (2, list(starts[:1]))):
+        got = hl.list_members(data, 1000, list(starts) + extra, threads=th, min_bytes=1)
+        for a, b in zip(got, ser):
+            assert np.array_equal(a, b), (th, extra)
+    # a range that stops in the middle of a member: the partial one is not listed
+    cut = int(ser[0][n // 2]) + 7
+    got = hl.list_members(data[:cut], 0, list(ser[0][2::3]), threads=8, min_bytes=1)
+    assert len(got[0]) == n // 2 and np.array_equal(got[0], ser[0][:n // 2])
+    with pytest.raises(ValueError):
+        hl.list_members(b"not bgzf at all, definitely" * 4, 0, [], threads=4, min_bytes=1)
