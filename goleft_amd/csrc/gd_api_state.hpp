@@ -297,7 +297,9 @@ int set_device(gd_ctx* c)
 template <int T>
 void launch_prep(gd_ctx* c, const gd::Job& job)
 {
-    int64_t work = std::max<int64_t>(job.n_tiles, std::min<int64_t>(job.n_win_total, 1 << 22));
+    // one thread per tile; the same threads grid-stride over the window arrays (a thread per window made a 30x
+    // genome's launch six rounds of workgroups, five of them doing 12 bytes of work per thread)
+    int64_t work = std::max<int64_t>(job.n_tiles, std::min<int64_t>(job.n_win_total / 8, 1 << 20));
     int blocks = (int)((work + 255) / 256);
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(gd::gd_prep_kernel<T>, dim3(blocks), dim3(256), 0, c->stream, job);
