@@ -82,3 +82,102 @@ def test_ont_chr20_full_size_chunk_path():
         got = eng.perbase(0)
         check_properties(eng, r, Q, got)
     assert np.array_equal(got, po.perbase_c(r, Q, 0, L, diff=True))
+
+
+# ---------------------------------------------------------------------------------------------------------
+# BASELINE.json's FULL sizes (config 3: 30x WGS, 3.1 Gb; config 5: 20x ONT-like WGS), checked through
+# size-independent properties computed ON THE DEVICE with torch from the record streams and the engine's own
+# per-base vector -- no oracle can walk 3.1 Gb in seconds, these can:
+#   * conservation: every contig's per-base vector adds up to the M/=/X bases of its kept reads that fall inside
+#     the contig (computed from the records alone, independent of any engine structure);
+#   * window sums / minima equal reductions of the per-base vector;
+#   * class runs tile every contig, with breaks exactly at class changes and at multiples of the step.
+# ---------------------------------------------------------------------------------------------------------
+def _counted_bases_torch(torch, pos, flag, mapq, off, cig, q, length, flag_mask=0x704):
+    keep = ((flag.to(torch.int32) & flag_mask) == 0) & (mapq.to(torch.int32) >= q)
+    op = (cig & 0xF).to(torch.int64)
+    ln = ((cig.to(torch.int64) & 0xFFFFFFFF) >> 4)
+    consumes = (op == 0) | (op == 2) | (op == 3) | (op == 7) | (op == 8)
+    counted = (op == 0) | (op == 7) | (op == 8)
+    o = off.to(torch.int64) & 0xFFFFFFFF
+    nops = o[1:] - o[:-1]
+    read_of = torch.repeat_interleave(torch.arange(nops.numel(), device=pos.device), nops)
+    cons = torch.where(consumes, ln, torch.zeros_like(ln))
+    before = torch.cumsum(cons, 0) - cons
+    first = torch.clamp(o[:-1], max=max(0, cig.numel() - 1))
+    base = torch.where(nops > 0, before[first], torch.zeros_like(first))
+    start = pos.to(torch.int64)[read_of] + before - base[read_of]
+    end = torch.clamp(start + ln, max=length)
+    c = torch.where(counted & keep[read_of], torch.clamp(end - torch.clamp(start, min=0), min=0), torch.zeros_like(ln))
+    return int(c.sum().item())
+
+
+def _check_genome_properties(torch, eng, dev, lengths, streams, step):
+    from goleft_amd import shard
+    ps, pm, nwt = eng.device_windows()
+    sums_all = shard.device_view(ps, nwt, torch.int64, dev)
+    mins_all = shard.device_view(pm, nwt, torch.int32, dev)
+    pb, nb = eng.device_runs()
+    bounds = shard.device_view(pb, 2 * nb, torch.int32, dev).view(-1, 2)
+    ctg_of = bounds[:, 1] >> 2
+    for t, Lt in enumerate(lengths):
+        p, n = eng.device_perbase(t)
+        d = shard.device_view(p, n, torch.int32, dev)
+        assert n == Lt and int(d.min().item()) >= 0
+        total = int(d.sum(dtype=torch.int64).item())
+        assert total == _counted_bases_torch(torch, *streams[t], Q, Lt), t          # conservation
+        o, nw = eng.window_offset(t)
+        pad = (-Lt) % W
+        dd = torch.cat([d.to(torch.int64), torch.zeros(pad, dtype=torch.int64, device=dev)]).view(-1, W)
+        assert torch.equal(sums_all[o:o + nw], dd.sum(1)), t
+        dm = torch.cat([d, torch.full((pad,), 2 ** 31 - 1, dtype=torch.int32, device=dev)]).view(-1, W)
+        assert torch.equal(mins_all[o:o + nw], dm.min(1).values), t
+        del dd, dm
+        cls = torch.where(d == 0, 0, torch.where(d < MINCOV, 1, 2)).to(torch.int8)
+        ar = torch.arange(1, Lt, device=dev)
+        brk = torch.nonzero((cls[1:] != cls[:-1]) | (ar % step == 0)).flatten() + 1
+        b = bounds[ctg_of == t]
+        assert int(b[0, 0].item()) == 0                                              # the first run starts the contig
+        assert torch.equal(b[1:, 0].to(torch.int64), brk), t                         # breaks exactly there, nowhere else
+        assert torch.equal((b[:, 1] & 3).to(torch.int8), cls[b[:, 0].to(torch.int64)]), t
+        del cls, ar, brk
+
+
+def test_config3_wgs_full_size_properties():
+    """30x WGS, hg19 contig lengths, 619 M reads: the configuration bench.py's headline is quoted on."""
+    import torch
+    from goleft_amd.engine import DepthEngine
+    dev = torch.device("cuda", 0)
+    lengths = list(synth.HG19_LENGTHS)
+    assert sum(lengths) == 3_095_677_412
+    with DepthEngine(0) as eng:
+        eng.set_params(window_size=W, min_mapq=Q, min_cov=MINCOV)
+        eng.set_contigs(lengths)
+        streams = []
+        for t, Lt in enumerate(lengths):
+            s = synth.short_reads_torch(Lt, synth.n_reads_for(Lt), t + 1, dev)
+            streams.append(s)
+            eng.adopt_device(t, *s)
+        eng.compute()
+        st = eng.stats()
+        assert st.n_reads == 619_135_482 and st.path == 1 and st.reruns == 0
+        _check_genome_properties(torch, eng, dev, lengths, streams, po.step_for(W))
+
+
+def test_config5_ont_wgs_full_size_properties():
+    """20x ONT-like WGS (4.8e9 CIGAR ops): the long-read path at BASELINE.json's config-5 size."""
+    import torch
+    from goleft_amd.engine import DepthEngine
+    dev = torch.device("cuda", 0)
+    lengths = list(synth.HG19_LENGTHS)
+    with DepthEngine(0) as eng:
+        eng.set_params(window_size=W, min_mapq=Q, min_cov=MINCOV)
+        eng.set_contigs(lengths)
+        streams = []
+        for t, Lt in enumerate(lengths):
+            s = synth.ont_reads_torch(Lt, synth.n_ont_reads_for(Lt, 20.0), t + 1, dev)
+            streams.append(s)
+            eng.adopt_device(t, *s)
+        eng.compute()
+        assert eng.stats().path == 3                                                 # GD_PATH_CHUNK chosen by AUTO
+        _check_genome_properties(torch, eng, dev, lengths, streams, po.step_for(W))
