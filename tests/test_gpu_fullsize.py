@@ -181,3 +181,38 @@ def test_config5_ont_wgs_full_size_properties():
         eng.compute()
         assert eng.stats().path == 3                                                 # GD_PATH_CHUNK chosen by AUTO
         _check_genome_properties(torch, eng, dev, lengths, streams, po.step_for(W))
+
+
+def test_config4_cohort_full_size_properties():
+    """200 samples x chr1 (BASELINE.json config 4), window sums only (what the depthwed matrix is made of), through
+    the streaming sums kernel: every sample's window sums add up to the M/=/X bases of its kept reads inside the
+    contig (from the records alone), and a sample drawn at random equals the sums of the per-base path."""
+    import torch
+    from goleft_amd.engine import DepthEngine
+    dev = torch.device("cuda", 0)
+    L1, S, Wc = synth.HG19_LENGTHS[0], 200, 250
+    with DepthEngine(0) as eng:
+        eng.set_params(window_size=Wc, min_mapq=Q, min_cov=MINCOV)
+        eng.set_outputs(sums_only=True)
+        eng.set_contigs([L1] * S)
+        want = []
+        keep = {}
+        for s in range(S):
+            st = synth.short_reads_torch(L1, synth.n_reads_for(L1), 1000 + s, dev)
+            eng.adopt_device(s, *st)
+            want.append(_counted_bases_torch(torch, *st, Q, L1))
+            keep[s] = st                                       # adopted, not copied: the engine reads these tensors
+        eng.compute()
+        from goleft_amd import shard
+        ps, _, nwt = eng.device_windows()
+        sums_all = shard.device_view(ps, nwt, torch.int64, dev)
+        nw = (L1 + Wc - 1) // Wc
+        got = sums_all.view(S, nw).sum(1).tolist()
+        assert got == want
+        one = sums_all.view(S, nw)[137].clone()
+    with DepthEngine(0) as eng:                                # the same sample through the per-base path
+        eng.set_params(window_size=Wc, min_mapq=Q, min_cov=MINCOV)
+        eng.set_contigs([L1])
+        eng.adopt_device(0, *keep[137])
+        eng.compute()
+        assert np.array_equal(eng.windows(0)[0], one.cpu().numpy())
