@@ -40,7 +40,7 @@ struct ContigHost {
     uint2*    dl = nullptr;            // (canonical ops >> 1) + n_reads + 1 deletions {start, length}
     uint32_t* pck = nullptr;           // tile indexes (gd_ptile_fill_kernel)
     int32_t   max_span = 0;
-    bool ck_ok = false;                // ck / rend describe the current records
+    bool ck_ok = false;                // lrec / lfq / dl / pck describe the current records
     // layout in the result arrays of the last compute (-1 = not computed)
     int64_t base_off = -1;
     int64_t win_off = -1;
