@@ -263,14 +263,33 @@ def run_case(args, scaling, world, rank, dev, local_rank, want_streams=False):
             gath.step_exported()                    # ONE asynchronous collective on the buffer this compute filled;
                                                     # the next compute fills the other one (no allocation)
 
-    for _ in range(args.warmup):
-        step()
+    def run_steps(n):
+        if not exchange or n < 1:
+            for _ in range(n):
+                step()
+            return
+        # ONE genome over N GPUs: the steps are pipelined -- while the kernels of step k run, the host verifies
+        # nothing (compute_finish(k - 1) already did), re-points the export block and issues the (asynchronous)
+        # gather of step k - 1.  Every step is still a complete compute + gather; all of them have landed before
+        # the clock stops (drain + synchronize below).
+        eng.compute_launch()
+        for _ in range(n - 1):
+            eng.compute_finish()
+            gath.flip()
+            eng.compute_launch()
+            gath.post()
+        eng.compute_finish()
+        gath.flip()
+        gath.post()
+
+    run_steps(args.warmup)
+    if exchange:
+        gath.drain()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    run_steps(args.steps)
     if exchange:
         gath.drain()                                # the last steps' collectives have landed on rank 0
     torch.cuda.synchronize()
@@ -317,8 +336,9 @@ def run_case(args, scaling, world, rank, dev, local_rank, want_streams=False):
                  "shard_ref_bases": loads, "lpt_imbalance": max(loads) / (sum(loads) / world),
                  "lpt_speedup_ceiling": sum(loads) / max(loads),
                  "gather_bytes_per_rank": int(gath.total * 8), "bounds_capacity": int(gath.cap_b),
-                 "pipelined": "in the timed loop the gather of step k is asynchronous (double-buffered) and runs under "
-                              "the kernels of step k + 1; compute_ms / gather_ms here are measured one after the other"}
+                 "pipelined": "in the timed loop a step is finish(k-1); flip(); launch(k); post(): the asynchronous, "
+                              "double-buffered gather of step k-1 and its host-side cost run under the kernels of step k; "
+                              "compute_ms / gather_ms here are measured one after the other"}
         if rank == 0:
             g = gath.result()
             split["gather_overflow"] = bool(g["overflow"])

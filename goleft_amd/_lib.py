@@ -57,6 +57,8 @@ SYMBOLS = {
     "gd_adopt_device": (C.c_int, [_P, C.c_int32, C.POINTER(GdBatch), C.c_size_t, C.c_size_t]),
     "gd_reset": (C.c_int, [_P]),
     "gd_compute": (C.c_int, [_P]),
+    "gd_compute_launch": (C.c_int, [_P]),
+    "gd_compute_finish": (C.c_int, [_P]),
     "gd_perbase": (C.c_int, [_P, C.c_int32, C.c_int64, C.c_int64, _P]),
     "gd_windows": (C.c_int, [_P, C.c_int32, _P, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
     "gd_callable": (C.c_int, [_P, C.c_int32, _P, C.c_size_t, C.POINTER(C.c_size_t)]),

@@ -84,6 +84,21 @@ struct IngestBufs {
 };
 
 
+// What gd_compute carries from its launch to its finish (gd_api_compute.inc).
+struct ComputeState {
+    std::vector<int32_t> tids;          // contigs of the job
+    uint64_t n_reads = 0, n_ops = 0, n_units = 0, n_groups = 0;
+    int64_t tile_beg = 0, base_off = 0, win_off = 0, bases = 0;
+    bool all_normed = true;
+    int reruns = 0, used_lookback = 0;
+    bool used_scatter = false, used_chunk = false;
+    int32_t chunk_span = 0;
+    bool it_scatter = false, it_chunk = false;   // the attempt in flight
+    size_t spec = 0;                             // boundaries copied speculatively with the counters
+    bool pending = false;               // launched, not finished
+    bool nothing = false;               // ... a job without tiles
+};
+
 struct gd_ctx {
     int device = 0;
     hipStream_t stream = nullptr;       // compute stream
@@ -167,6 +182,7 @@ struct gd_ctx {
     int64_t* export_buf = nullptr;     // gd_set_export: caller-owned device buffer, written by every gd_compute
     int64_t export_max_w = 0, export_cap_b = 0;
 
+    ComputeState cs;
     bool computed = false;
     int64_t n_tiles = 0, n_win_total = 0, n_bases = 0;
     std::vector<int2> bounds;             // ordered run boundaries of the last compute

@@ -132,6 +132,13 @@ class DepthEngine:
     def compute(self):
         self._chk(self._lib.gd_compute(self._ctx))
 
+    def compute_launch(self):
+        """gd_compute_launch: enqueue a compute, do not wait (compute_finish does)."""
+        self._chk(self._lib.gd_compute_launch(self._ctx))
+
+    def compute_finish(self):
+        self._chk(self._lib.gd_compute_finish(self._ctx))
+
     def set_profiling(self, on: bool):
         self._chk(self._lib.gd_set_profiling(self._ctx, int(on)))
 

@@ -81,7 +81,9 @@ class RootGather:
     the compute of step k + 1 already fills the other one (`gd_set_export` is re-pointed every step), so
     the exchange of one step runs under the kernels of the next -- and nothing is ever written into a
     buffer a collective may still be reading: before buffer k % 2 is handed out again (step k + 2) the
-    collective of step k is waited for (two steps later it has long finished)."""
+    collective of step k is waited for (two steps later it has long finished).  A pipelined caller (bench.py)
+    orders a step as  compute_finish(k - 1); flip(); compute_launch(k); post()  -- the collective's host-side
+    cost falls under the kernels of step k too; step_exported() is flip() + post() for a synchronous compute."""
 
     def __init__(self, assignment: List[List[int]], lengths: Sequence[int], W: int, rank: int,
                  world: int, device, bounds_cap: int = 1 << 16, group=None):
@@ -123,9 +125,19 @@ class RootGather:
         for k in (0, 1):
             self._wait(k)
 
-    def _exchange(self):
-        """ONE collective on the current buffer pair, asynchronous; then hand out the other pair."""
-        k = self._cur
+    def flip(self):
+        """The current send buffer is complete (the compute that filled it has FINISHED): hand out the other pair.
+        Its collective (two steps ago) must be over before anything writes into it again."""
+        self._last = self._cur
+        self._cur ^= 1
+        self._wait(self._cur)
+        self.send, self.recv = self._sends[self._cur], self._recvs[self._last]
+        if self._eng is not None:
+            self._eng.set_export(self.send.data_ptr(), self.max_w, self.cap_b)
+
+    def post(self):
+        """ONE collective on the buffer pair flip() retired, asynchronous."""
+        k = self._last
         buf = self._sends[k]
         if self.world == 1:
             self._recvs[k][0].copy_(buf)
@@ -133,12 +145,10 @@ class RootGather:
             self._works[k] = dist.gather(buf, self._partss[k], dst=0, group=self.group, async_op=True)
         else:
             self._works[k] = dist.gather(buf, None, dst=0, group=self.group, async_op=True)
-        self._last = k
-        self._cur = k ^ 1
-        self._wait(self._cur)                                   # its collective (two steps ago) must be over
-        self.send, self.recv = self._sends[self._cur], self._recvs[self._last]
-        if self._eng is not None:
-            self._eng.set_export(self.send.data_ptr(), self.max_w, self.cap_b)
+
+    def _exchange(self):
+        self.flip()
+        self.post()
 
     def reserve(self, n_bounds: int, slack: float = 1.25):
         """Collective, setup time only: make every rank's boundary capacity cover the largest count

@@ -236,6 +236,13 @@ int gd_reset(gd_ctx* ctx);
  * `samtools depth` + callback compute per tile).  Synchronous: returns when
  * results are ready. */
 int gd_compute(gd_ctx* ctx);
+/* The same in two halves: gd_compute_launch enqueues every kernel and the read-back copies on the context's
+ * stream and returns without waiting; gd_compute_finish waits, verifies (re-running synchronously when the
+ * look-back / capacity checks ask for it) and publishes the results.  Between the two the host is free -- e.g.
+ * to issue the collective of the PREVIOUS step while this one's kernels run (bench.py --gpus N).  Exactly one
+ * compute may be in flight per context; result calls before gd_compute_finish see the previous compute. */
+int gd_compute_launch(gd_ctx* ctx);
+int gd_compute_finish(gd_ctx* ctx);
 
 /* ---- results -------------------------------------------------------------*/
 

@@ -1,0 +1,76 @@
+"""-m gpu: gd_compute in two halves (gd_compute_launch / gd_compute_finish) -- what bench.py's multi-GPU loop uses
+to issue the previous step's collective while this step's kernels run.  Same results as gd_compute, including the
+attempts that finish() has to repeat (a read longer than the look-back; AUTO leaving the tile path), and the call
+order is enforced."""
+import numpy as np
+import pytest
+
+from oracle import pyoracle as po
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def _results(eng, lengths):
+    out = []
+    for t in range(len(lengths)):
+        s, m = eng.windows(t)
+        out.append((eng.perbase(t), s, m, eng.callable_runs(t)))
+    return out
+
+
+@pytest.mark.parametrize("path", [0, 1, 3])                   # AUTO, TILE, CHUNK
+def test_launch_finish_equals_compute(path):
+    from goleft_amd.engine import DepthEngine
+    rng = np.random.default_rng(11 + path)
+    lengths = [150_000, 4096, 1, 70_001]
+    reads = {0: H.random_reads(rng, lengths[0], 20000, max_len=150),
+             1: H.random_reads(rng, lengths[1], 500, max_len=90),
+             3: H.random_reads(rng, lengths[3], 3000, max_len=300, long_reads=(path != 1))}
+    res = []
+    for split in (False, True):
+        with DepthEngine(0) as eng:
+            eng.set_params(window_size=100, min_mapq=1, min_cov=4)
+            eng.set_path(path)
+            eng.set_contigs(lengths)
+            for t, r in reads.items():
+                eng.push(t, r.pos, r.flag, r.mapq, r.cigar_off, r.cigar)
+            for _ in range(3):                                 # several steps: the second launch reuses every buffer
+                if split:
+                    eng.compute_launch()
+                    eng.compute_finish()
+                else:
+                    eng.compute()
+            res.append((_results(eng, lengths), eng.stats().reruns, eng.stats().path))
+    for a, b in zip(res[0][0], res[1][0]):
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y)
+    assert res[0][1:] == res[1][1:]
+    for t, L in enumerate(lengths):
+        want = po.perbase_c(reads.get(t, H.empty_reads()), 1, 0, L)
+        assert np.array_equal(res[1][0][t][0], want)
+
+
+def test_finish_repeats_a_failed_attempt_and_the_order_is_enforced():
+    from goleft_amd.engine import DepthEngine, GdError
+    L = 50_000
+    # one read of 1500 bases: longer than the default look-back of 512 -> the first attempt is repeated inside finish()
+    pos = np.array([100, 200, 30000], np.int32)
+    cig = np.array([(50 << 4), (1500 << 4), (80 << 4)], np.uint32)
+    r = po.Reads(pos, np.zeros(3, np.uint16), np.full(3, 60, np.uint8), np.arange(4, dtype=np.uint32), cig)
+    with DepthEngine(0) as eng:
+        eng.set_params(window_size=250, min_mapq=1, min_cov=1)
+        eng.set_path(1)
+        eng.set_contigs([L])
+        eng.push(0, r.pos, r.flag, r.mapq, r.cigar_off, r.cigar)
+        with pytest.raises(GdError):
+            eng.compute_finish()                               # nothing launched
+        eng.compute_launch()
+        with pytest.raises(GdError):
+            eng.compute_launch()                               # one in flight
+        eng.compute_finish()
+        st = eng.stats()
+        assert st.reruns == 1 and st.max_span_seen == 1500
+        assert np.array_equal(eng.perbase(0), po.perbase_c(r, 1, 0, L))
+        eng.compute()                                          # and the synchronous form still works afterwards
+        assert eng.stats().reruns == 0
