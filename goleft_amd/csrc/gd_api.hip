@@ -156,6 +156,7 @@ int gd_set_stream(gd_ctx* c, void* s)
 
 int gd_set_params(gd_ctx* c, const gd_params* p)
 {
+    if (c && c->cs.pending) return fail(c, GD_E_STATE, "a compute is in flight: gd_compute_finish first");
     if (!c || !p) return GD_E_INVALID;
     if (p->window_size < 1) return fail(c, GD_E_INVALID, "window_size must be >= 1");
     if (p->step < 0) return fail(c, GD_E_INVALID, "step must be >= 0");
@@ -170,6 +171,7 @@ int gd_set_params(gd_ctx* c, const gd_params* p)
 
 int gd_set_path(gd_ctx* c, int path)
 {
+    if (c && c->cs.pending) return fail(c, GD_E_STATE, "a compute is in flight: gd_compute_finish first");
     if (!c) return GD_E_INVALID;
     if (path != GD_PATH_AUTO && path != GD_PATH_TILE && path != GD_PATH_SCATTER && path != GD_PATH_CHUNK)
         return fail(c, GD_E_INVALID, "unknown path %d", path);
@@ -180,6 +182,7 @@ int gd_set_path(gd_ctx* c, int path)
 
 int gd_set_outputs(gd_ctx* c, unsigned flags)
 {
+    if (c && c->cs.pending) return fail(c, GD_E_STATE, "a compute is in flight: gd_compute_finish first");
     if (!c) return GD_E_INVALID;
     if (flags & ~(unsigned)(GD_OUT_PERBASE | GD_OUT_SUMS_ONLY)) return fail(c, GD_E_INVALID, "unknown output flags 0x%x", flags);
     if ((flags & GD_OUT_PERBASE) && (flags & GD_OUT_SUMS_ONLY))
@@ -192,6 +195,7 @@ int gd_set_outputs(gd_ctx* c, unsigned flags)
 
 int gd_set_contigs(gd_ctx* c, int n, const int64_t* lengths)
 {
+    if (c && c->cs.pending) return fail(c, GD_E_STATE, "a compute is in flight: gd_compute_finish first");
     if (!c || n < 0 || (n > 0 && !lengths)) return GD_E_INVALID;
     if (int r = set_device(c)) return r;
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -213,6 +217,7 @@ int gd_set_contigs(gd_ctx* c, int n, const int64_t* lengths)
 
 int gd_select_contigs(gd_ctx* c, int n, const int32_t* tids)
 {
+    if (c && c->cs.pending) return fail(c, GD_E_STATE, "a compute is in flight: gd_compute_finish first");
     if (!c || n < 0 || (n > 0 && !tids)) return GD_E_INVALID;
     std::vector<int32_t> s(tids, tids + n);
     for (int32_t t : s)
@@ -260,6 +265,7 @@ int gd_acquire(gd_ctx* c, size_t reads_cap, size_t ops_cap, gd_batch* out)
 
 int gd_commit(gd_ctx* c, const gd_batch* b, int32_t tid, size_t n_reads, size_t n_ops)
 {
+    if (c && c->cs.pending) return fail(c, GD_E_STATE, "a compute is in flight: gd_compute_finish first");
     if (!c || !b) return GD_E_INVALID;
     if (int r = set_device(c)) return r;
     if (b->slot < 0 || b->slot >= kRingSlots || c->ring[b->slot].b.pos != b->pos)
@@ -363,6 +369,7 @@ int gd_push(gd_ctx* c, int32_t tid, const int32_t* pos, const uint16_t* flag, co
 
 int gd_adopt_device(gd_ctx* c, int32_t tid, const gd_batch* d, size_t n_reads, size_t n_ops)
 {
+    if (c && c->cs.pending) return fail(c, GD_E_STATE, "a compute is in flight: gd_compute_finish first");
     if (!c || !d) return GD_E_INVALID;
     if (int r = set_device(c)) return r;
     if (tid < 0 || (size_t)tid >= c->contigs.size()) return fail(c, GD_E_RANGE, "tid %d out of range", tid);
@@ -390,6 +397,7 @@ int gd_adopt_device(gd_ctx* c, int32_t tid, const gd_batch* d, size_t n_reads, s
 
 int gd_reset(gd_ctx* c)
 {
+    if (c && c->cs.pending) return fail(c, GD_E_STATE, "a compute is in flight: gd_compute_finish first");
     if (!c) return GD_E_INVALID;
     if (int r = set_device(c)) return r;
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -462,6 +470,7 @@ int gd_set_export(gd_ctx* c, void* device_buf, int64_t max_windows, int64_t cap_
 
 int gd_set_option(gd_ctx* c, int option, int64_t value)
 {
+    if (c && c->cs.pending) return fail(c, GD_E_STATE, "a compute is in flight: gd_compute_finish first");
     if (!c) return GD_E_INVALID;
     switch (option) {
     case GD_OPT_TILE_POSITIONS:

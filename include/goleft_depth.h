@@ -240,7 +240,8 @@ int gd_compute(gd_ctx* ctx);
  * stream and returns without waiting; gd_compute_finish waits, verifies (re-running synchronously when the
  * look-back / capacity checks ask for it) and publishes the results.  Between the two the host is free -- e.g.
  * to issue the collective of the PREVIOUS step while this one's kernels run (bench.py --gpus N).  Exactly one
- * compute may be in flight per context; result calls before gd_compute_finish see the previous compute. */
+ * compute may be in flight per context; result calls before gd_compute_finish see the previous compute, and calls
+ * that change the job (records, contigs, parameters, path, outputs, options) are refused with GD_E_STATE. */
 int gd_compute_launch(gd_ctx* ctx);
 int gd_compute_finish(gd_ctx* ctx);
 

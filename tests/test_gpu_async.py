@@ -68,6 +68,10 @@ def test_finish_repeats_a_failed_attempt_and_the_order_is_enforced():
         eng.compute_launch()
         with pytest.raises(GdError):
             eng.compute_launch()                               # one in flight
+        with pytest.raises(GdError):
+            eng.set_params(window_size=100)                    # the job may not change under it
+        with pytest.raises(GdError):
+            eng.push(0, r.pos, r.flag, r.mapq, r.cigar_off, r.cigar)
         eng.compute_finish()
         st = eng.stats()
         assert st.reruns == 1 and st.max_span_seen == 1500
