@@ -27,16 +27,17 @@ __device__ __forceinline__ void add_win(int64_t* wsum, uint32_t nwin, uint32_t k
     if (v != 0u && k < nwin) atomicAdd(reinterpret_cast<unsigned long long*>(&wsum[k]), (unsigned long long)v);
 }
 
-// a counted interval [s, e) of contig positions -> every window it touches, one atomic each
+// a counted interval [s, e) of contig positions (e <= contig length < 2^31) -> every window it touches, one atomic
+// each.  32-bit throughout: the next boundary nb = (k + 1) W <= s + W < 2^32, and it only advances while nb < e.
 __device__ __forceinline__ void add_interval_direct(int64_t* wsum, uint32_t nwin, uint32_t W, uint32_t wm, uint32_t ws,
                                                     uint32_t s, uint32_t e)
 {
     uint32_t k = div_magic(s, wm, ws);
+    uint32_t nb = (k + 1u) * W;
     while (s < e) {
-        const unsigned long long nb = (unsigned long long)(k + 1u) * W;
-        const uint32_t c = nb < (unsigned long long)e ? (uint32_t)nb - s : e - s;
+        const uint32_t c = (nb < e ? nb : e) - s;
         add_win(wsum, nwin, k, c);
-        s += c; ++k;
+        s += c; ++k; nb += W;
     }
 }
 
@@ -174,16 +175,27 @@ __global__ __launch_bounds__(256) void gd_sums_stream_kernel(Job job)
                     const uint32_t c2 = u == 0 ? cg2[0] : u == 1 ? cg2[1] : u == 2 ? cg2[2] : cg2[3];
                     const uint32_t xu = u == 0 ? ex[0] : u == 1 ? ex[1] : u == 2 ? ex[2] : ex[3];
                     const uint32_t* ops = cig + obase + xu;
-                    long long x = pu;
-                    for (uint32_t k = 0; k < nu; ++k) {
-                        const uint32_t o = k == 0u ? c0 : k == 1u ? c1 : k == 2u ? c2 : ops[k], ol = o >> 4;
-                        if ((o & 0xfu) == 0u) {
-                            const long long e64 = x + (long long)ol;
-                            const uint32_t s = x > 0 ? (x < (long long)length ? (uint32_t)x : length) : 0u;
-                            const uint32_t e = e64 < (long long)length ? (e64 > 0 ? (uint32_t)e64 : 0u) : length;
-                            if (e > s) add_interval_direct(wsum, nwin, W, wm, ws, s, e);
+                    if (pu >= 0) {
+                        // 32 bits: x stays below the contig length (the walk stops there), an op is < 2^28
+                        uint32_t x = (uint32_t)pu;
+                        for (uint32_t k = 0; k < nu && x < length; ++k) {
+                            const uint32_t o = k == 0u ? c0 : k == 1u ? c1 : k == 2u ? c2 : ops[k], ol = o >> 4;
+                            const uint32_t xe = x + ol;
+                            if ((o & 0xfu) == 0u) add_interval_direct(wsum, nwin, W, wm, ws, x, xe < length ? xe : length);
+                            x = xe;
                         }
-                        x += (long long)ol;
+                    } else {
+                        long long x = pu;                      // a negative POS (no aligner writes one): the long form
+                        for (uint32_t k = 0; k < nu; ++k) {
+                            const uint32_t o = k == 0u ? c0 : k == 1u ? c1 : k == 2u ? c2 : ops[k], ol = o >> 4;
+                            if ((o & 0xfu) == 0u) {
+                                const long long e64 = x + (long long)ol;
+                                const uint32_t s = x > 0 ? (x < (long long)length ? (uint32_t)x : length) : 0u;
+                                const uint32_t e = e64 < (long long)length ? (e64 > 0 ? (uint32_t)e64 : 0u) : length;
+                                if (e > s) add_interval_direct(wsum, nwin, W, wm, ws, s, e);
+                            }
+                            x += (long long)ol;
+                        }
                     }
                 }
             }
