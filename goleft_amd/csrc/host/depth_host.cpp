@@ -296,7 +296,11 @@ struct Shard {
 
 struct Shards {
     std::vector<Shard> v;
-    ~Shards() { for (Shard& s : v) if (s.ctx) gd_destroy(s.ctx); }
+    ~Shards()
+    {
+        if (gdh_get_fast_exit()) return;                     // the process is about to exit (main.cpp)
+        for (Shard& s : v) if (s.ctx) gd_destroy(s.ctx);
+    }
 };
 
 // Longest-processing-time-first assignment of contigs (by length) to n shards; deterministic.

@@ -53,6 +53,10 @@ int stats_contract_from_env()
 
 extern "C" {
 
+static int g_fast_exit = 0;
+int gdh_set_fast_exit(int on) { g_fast_exit = on != 0; return 0; }
+int gdh_get_fast_exit(void) { return g_fast_exit; }
+
 int gdh_set_stats_contract(int contract)
 {
     if (contract < 0 || (contract & ~GDH_STATS_FAIDX)) return -1;

@@ -286,7 +286,7 @@ int run(const MArgs& a, FILE* out)
         for (size_t k = 0; k < nb; ++k)
             for (size_t t = 0; t < tids.size(); ++t) sums[k * (size_t)S + (size_t)tids[t]] = gsum[k * tids.size() + t];
     }
-    gd_destroy(ctx);
+    if (!gdh_get_fast_exit()) gd_destroy(ctx);             // (goleft-depth exits right after: main.cpp)
     ctx = nullptr;
     for (size_t k = 0; k < blocks.size(); ++k) {
         fprintf(out, "%s\t%" PRId64 "\t%" PRId64, a.chrom.c_str(), blocks[k].start, blocks[k].end);   // :182-184

@@ -25,6 +25,12 @@ extern "C" {
  * (depth/depth.go:174, :398).  Needs an MI355X: there is no CPU path. */
 int gdh_depth_main(int argc, const char* const* argv);
 
+/* For an executable that exits right after gdh_*_main returns (goleft-depth does): the engines are then NOT torn
+ * down at the end of the run -- freeing tens of gigabytes of HBM and unloading the runtime is work the operating
+ * system does for an exiting process anyway.  Off by default: a host that lives on must get its memory back. */
+int gdh_set_fast_exit(int on);
+int gdh_get_fast_exit(void);
+
 /* depth/depth.go:73-94 chromStartEndFromLine: `chr:s-e` (1-based inclusive) or
  * `chr\ts\te` (BED) -> chrom, 0-based start, end.  Returns 0, or -1 when the
  * line does not match (the reference calls log.Fatal there). */
