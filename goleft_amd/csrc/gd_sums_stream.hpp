@@ -126,33 +126,31 @@ __global__ __launch_bounds__(256) void gd_sums_stream_kernel(Job job)
         // lanes; lanes past the contig's last read sort last and add nothing)
         const bool inb = g0 + (uint32_t)lane * U < r_end;
         const uint32_t kb = inb ? div_magic((uint32_t)(p[0] > 0 ? p[0] : 0), wm, ws) : 0xffffffffu;
+        // the lane's three windows [kb W, nb0), [nb0, nb1), [nb1, nb2): a read's share of each is an interval overlap
+        // (min, max, subtract) -- no division, no multiplication, no case analysis per read
+        const uint32_t nb0 = inb ? (kb + 1u) * W : 0u;             // <= start of the lane's first read + W < 2^32
+        const uint32_t nb1 = nb0 + W >= nb0 ? nb0 + W : 0xffffffffu;
+        const uint32_t nb2 = nb1 + W >= nb1 ? nb1 + W : 0xffffffffu;
         uint32_t a0 = 0, a1 = 0, a2 = 0;
         uint32_t s_[U], e_[U];
         uint32_t odd = 0;                                          // bit u: read u of this lane goes the long way
 #pragma unroll
         for (int u = 0; u < U; ++u) {
+            // canonical: a single op is an M of 1 <= len < 2^28.  [s, e) clipped to the contig, in 32 bits; everything
+            // that is not a kept single-op read at a non-negative POS is an EMPTY interval here
             const uint32_t len = cg[u] >> 4;
-            // canonical: a single op is an M of 1 <= len < 2^28.  [s, e) clipped to the contig, in 32 bits
-            // (a negative POS -- no aligner writes one -- counts from 0 like everywhere else)
+            const bool one = keep[u] & (n[u] == 1u);
             const uint32_t s = p[u] > 0 ? (uint32_t)p[u] : 0u;
-            const uint32_t eu = p[u] >= 0 ? s + len : ((int)len > -p[u] ? len - (uint32_t)(-p[u]) : 0u);   // < 2^31 + 2^28
-            const uint32_t e = eu < length ? eu : length;
-            s_[u] = s; e_[u] = e;
-            if (keep[u] & (n[u] == 1u) & (e > s)) {
-                const uint32_t k1 = div_magic(s, wm, ws);
-                const uint32_t room = (k1 + 1u) * W - s;           // positions left in the start window
-                const uint32_t tot = e - s;
-                const uint32_t ca = tot < room ? tot : room, cb = tot - ca;
-                const uint32_t d = k1 - kb;
-                if (cb > W || d > 1u + (cb == 0u ? 1u : 0u)) {
-                    odd |= 1u << u;                                // longer than two windows, or too far from kb
-                } else {
-                    a0 += d == 0u ? ca : 0u;
-                    a1 += (d == 1u ? ca : 0u) + (d == 0u ? cb : 0u);
-                    a2 += (d == 2u ? ca : 0u) + (d == 1u ? cb : 0u);
-                }
-            }
-            odd |= (keep[u] & (n[u] > 1u)) ? 1u << u : 0u;         // multi-op (2 % of short reads)
+            const uint32_t eu = s + len;                           // < 2^31 + 2^28
+            const uint32_t e = (one & (p[u] >= 0)) ? (eu < length ? eu : length) : s;
+            const uint32_t l1 = s > nb0 ? s : nb0, l2 = s > nb1 ? s : nb1;
+            const uint32_t h0 = e < nb0 ? e : nb0, h1 = e < nb1 ? e : nb1, h2 = e < nb2 ? e : nb2;
+            a0 += (h0 > s ? h0 : s) - s;
+            a1 += (h1 > l1 ? h1 : l1) - l1;
+            a2 += (h2 > l2 ? h2 : l2) - l2;
+            // what sticks out past the third window (a long read, sparse reads), a negative POS, several ops: the long way
+            s_[u] = s > nb2 ? s : nb2; e_[u] = e;
+            odd |= ((one & (e > nb2)) | (keep[u] & (n[u] > 1u)) | (one & (p[u] < 0))) ? 1u << u : 0u;
         }
         // The long way, ONE instance of the code for all four slots: nearly every group of 256 reads has a few
         // multi-op reads, in different slots of different lanes -- a block per slot ran three of the four blocks
@@ -164,10 +162,11 @@ __global__ __launch_bounds__(256) void gd_sums_stream_kernel(Job job)
                 odd &= odd - 1u;
                 const int32_t pu = u == 0 ? p[0] : u == 1 ? p[1] : u == 2 ? p[2] : p[3];
                 const uint32_t nu = u == 0 ? n[0] : u == 1 ? n[1] : u == 2 ? n[2] : n[3];
-                if (nu == 1u) {
+                if (nu == 1u && pu >= 0) {
+                    // the part of a single-op read past the lane's third window
                     const uint32_t su = u == 0 ? s_[0] : u == 1 ? s_[1] : u == 2 ? s_[2] : s_[3];
                     const uint32_t eu = u == 0 ? e_[0] : u == 1 ? e_[1] : u == 2 ? e_[2] : e_[3];
-                    add_interval_direct(wsum, nwin, W, wm, ws, su, eu);
+                    if (eu > su) add_interval_direct(wsum, nwin, W, wm, ws, su, eu);
                 } else {
                     // walk the canonical ops: M (0) counted, N (3) skipped, every M interval on its own
                     const uint32_t c0 = u == 0 ? cg[0] : u == 1 ? cg[1] : u == 2 ? cg[2] : cg[3];
