@@ -150,6 +150,7 @@ struct gd_ctx {
     gd::Counters* h_counters = nullptr;   // pinned
     int2* h_bounds = nullptr;             // pinned: the first kSpecBounds ordered boundaries travel with the counters
     uint32_t parity = 0;                  // Counters::n_slow in use (alternates per compute)
+    bool slow_counter_clean = false;      // the last enqueue ran gd_prep_kernel, which zeroed the other counter
     uint32_t* d_region_cursor = nullptr;
 
     int64_t* d_wed = nullptr; size_t cap_wed = 0;      // gd_depthwed: tables + the sites x samples matrix

@@ -459,3 +459,42 @@ def test_regions_batch_equals_single_calls_and_oracle(auto_eng, seed):
             s1, m1 = eng.region_windows(t, a, b)
             assert np.array_equal(s1, sums[k]) and np.array_equal(m1, mins[k])
             assert np.array_equal(eng.region_callable(t, a, b), runs[k])
+
+
+def test_slow_list_counter_survives_jobs_without_a_tile_table(auto_eng):
+    """The straight-line tile kernel's slow list is counted in one of two alternating device counters, each
+    zeroed by the tile-table kernel of the PREVIOUS compute; a compute in between that builds no tile table
+    (scatter path, streaming sums) must not leave the counter -- and with it stale tiles of an earlier job --
+    behind (found by tests/test_gpu_soak.py: a memory fault two jobs later)."""
+    from goleft_amd.engine import PATH_AUTO, PATH_TILE, PATH_SCATTER
+    eng = auto_eng
+    rng = np.random.default_rng(77)
+    try:
+        for between in ("scatter", "sums"):
+            a = {0: H.random_reads(rng, 12289, 3000), 1: H.random_reads(rng, 4097, 800)}
+            eng.set_path(PATH_TILE)
+            run_engine(eng, [("a", 12289), ("b", 4097)], a, window_size=1000, min_mapq=1, min_cov=4)
+            assert eng.stats().n_slow_tiles >= 2
+            lens = [4097, 4096, 64, 8192, 63]
+            b = {t: H.random_reads(rng, L, 500) for t, L in enumerate(lens)}
+            if between == "scatter":
+                eng.set_path(PATH_SCATTER)
+            else:
+                eng.set_outputs(sums_only=True)
+            run_engine(eng, [("c%d" % t, L) for t, L in enumerate(lens)], b, window_size=64, min_mapq=1, min_cov=4)
+            eng.set_outputs(perbase=False)
+            eng.set_path(PATH_AUTO)
+            lens = [1, 12289, 12289, 0, 12289]
+            c = {t: H.random_reads(rng, L, 600) for t, L in enumerate(lens) if L}
+            contigs = [("d%d" % t, L) for t, L in enumerate(lens)]
+            run_engine(eng, contigs, c, window_size=250, min_mapq=4, min_cov=4)
+            assert eng.stats().n_slow_tiles == 4                    # the clipped last tile of each non-empty contig
+            for t, L in enumerate(lens):
+                want = po.perbase_c(c.get(t, H.empty_reads()), 4, 0, L) if L else np.zeros(0, np.int32)
+                ws, wm = H.oracle_windows(want, 250)
+                gs, gm = eng.windows(t)
+                assert np.array_equal(gs, ws) and np.array_equal(gm, wm)
+                assert np.array_equal(eng.callable_runs(t), H.oracle_runs(want, 4, 0, po.step_for(250)))
+    finally:
+        eng.set_outputs(perbase=True)
+        eng.set_path(PATH_AUTO)
