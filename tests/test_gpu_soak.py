@@ -17,16 +17,16 @@ from oracle import pyoracle as po
 pytestmark = pytest.mark.gpu
 
 JOBS = int(os.environ.get("GOLEFT_SOAK_JOBS", "10"))
-# GOLEFT_SOAK_ONLY="13,14": replay a seed's job sequence but hand only these jobs to the engine
+# GOLEFT_SOAK_ONLY="13,14": run only these jobs of each seed (every job draws from its own generator)
 ONLY = [int(x) for x in os.environ.get("GOLEFT_SOAK_ONLY", "").split(",") if x]
 
 
-def _split_push(eng, rng, tid, r, live=True):
+def _split_push(eng, rng, tid, r):
     """Push a contig's records in 1..3 consecutive batches."""
     n = len(r.pos)
     cuts = sorted(set([0, n] + [int(x) for x in rng.integers(0, n + 1, size=int(rng.integers(0, 3)))]))
     for a, b in zip(cuts[:-1], cuts[1:]):
-        if a == b or not live:
+        if a == b:
             continue
         o0, o1 = int(r.cigar_off[a]), int(r.cigar_off[b])
         eng.push(tid, r.pos[a:b], r.flag[a:b], r.mapq[a:b], (r.cigar_off[a:b + 1] - o0).astype(np.uint32),
@@ -82,13 +82,30 @@ def _contig_reads(rng, L):
                     np.full(n, (int(rng.integers(1, 400)) << 4), np.uint32))
 
 
+
+def _adopt(eng, torch, tid, r):
+    dev = torch.device("cuda", 0)
+    eng.adopt_device(tid, torch.from_numpy(r.pos).to(dev), torch.from_numpy(r.flag.view(np.int16)).to(dev),
+                     torch.from_numpy(r.mapq).to(dev), torch.from_numpy(r.cigar_off.view(np.int32)).to(dev),
+                     torch.from_numpy(r.cigar.view(np.int32)).to(dev))
+
+
+def _concat(a, b):
+    return po.Reads(np.concatenate([a.pos, b.pos]), np.concatenate([a.flag, b.flag]), np.concatenate([a.mapq, b.mapq]),
+                    np.concatenate([a.cigar_off, b.cigar_off[1:] + a.cigar_off[-1]]).astype(np.uint32),
+                    np.concatenate([a.cigar, b.cigar]))
+
+
 @pytest.mark.parametrize("seed", range(int(os.environ.get("GOLEFT_SOAK_SEEDS", "4"))))
 def test_soak_one_context_many_jobs(seed):
+    import torch
     from goleft_amd.engine import (DepthEngine, GdError, PATH_AUTO, PATH_TILE, PATH_SCATTER, PATH_CHUNK,
                                    OPT_NT_STORES, OPT_NORMALIZE, OPT_FAST_KERNEL)
-    rng = np.random.default_rng(9000 + seed)
     with DepthEngine(0) as eng:
         for job in range(JOBS):
+            if ONLY and job not in ONLY:
+                continue
+            rng = np.random.default_rng([9000 + seed, job])
             n_ctg = int(rng.integers(1, 6))
             lens = [int(rng.choice([0, 1, 63, 64, 4095, 4096, 4097, 8192, 12289, int(rng.integers(1, 300000)),
                                     int(rng.integers(1, 300000))])) for _ in range(n_ctg)]
@@ -107,15 +124,8 @@ def test_soak_one_context_many_jobs(seed):
             if path == PATH_SCATTER:
                 mode = "full"            # the scatter path needs the per-base vector (GD_E_INVAL otherwise)
             opts = (int(rng.integers(0, 2)), int(rng.random() < 0.8), int(rng.random() < 0.8))
-            live = not ONLY or job in ONLY
-            if not live:                                     # keep the generator in step, skip the engine
-                for t, r in reads.items():
-                    _split_push(eng, rng, t, r, live=False)
-                rng.integers(1, 3)
-                for t, L in enumerate(lens):
-                    if mode == "full" and L > 2 and rng.random() < 0.5:
-                        rng.integers(int(rng.integers(0, L)), L + 1)
-                continue
+            adopt = bool(rng.random() < 0.3)
+            split = bool(rng.random() < 0.3)
             eng.set_option(OPT_NT_STORES, opts[0])
             eng.set_option(OPT_NORMALIZE, opts[1])
             eng.set_option(OPT_FAST_KERNEL, opts[2])
@@ -124,17 +134,41 @@ def test_soak_one_context_many_jobs(seed):
             eng.set_params(window_size=W, min_mapq=Q, min_cov=mincov, max_mean_depth=maxmean, step=step)
             eng.set_contigs(lens)
             for t, r in reads.items():
-                _split_push(eng, rng, t, r)
-            n_compute = int(rng.integers(1, 3))
+                if adopt:
+                    _adopt(eng, torch, t, r)
+                else:
+                    _split_push(eng, rng, t, r)
+            selected = list(range(n_ctg))
+            if n_ctg > 1 and rng.random() < 0.25:            # a job over some of the contigs
+                selected = sorted(int(x) for x in rng.choice(n_ctg, size=int(rng.integers(1, n_ctg)), replace=False))
+                eng.select_contigs(selected)
+            n_compute = int(rng.integers(1, 4))
             if os.environ.get("GOLEFT_SOAK_VERBOSE"):
-                print("soak", seed, job, "path", path, mode, "W", W, "Q", Q, "opts", opts, "lens", lens, "x%d" % n_compute,
+                print("soak", seed, job, "path", path, mode, "W", W, "Q", Q, "opts", opts, "adopt", adopt, "split", split,
+                      "lens", lens, "sel", selected, "x%d" % n_compute,
                       {t: (len(r.pos), len(r.cigar)) for t, r in reads.items()}, flush=True)
-            for _ in range(n_compute):                                   # a second pass over resident records
-                eng.compute()
+            for k in range(n_compute):
+                if k and not adopt and rng.random() < 0.5:   # more records arrive between two computes
+                    t = int(rng.integers(0, n_ctg))
+                    last = int(reads[t].pos[-1]) if t in reads and len(reads[t].pos) else 0
+                    if lens[t] - last > 1:
+                        more = H.random_reads(rng, lens[t] - last, int(rng.integers(1, 800)),
+                                              long_reads=bool(rng.random() < 0.3))
+                        more = po.Reads((more.pos + last).astype(np.int32), more.flag, more.mapq, more.cigar_off, more.cigar)
+                        eng.push(t, more.pos, more.flag, more.mapq, more.cigar_off, more.cigar)
+                        reads[t] = _concat(reads[t], more) if t in reads else more
+                if split:
+                    eng.compute_launch()
+                    eng.compute_finish()
+                else:
+                    eng.compute()
             eff_step = step if step else po.step_for(W)
             tag = (seed, job, path, mode, W, Q, mincov, maxmean, step, lens)
-            for t, L in enumerate(lens):
+            per = {}
+            for t in selected:
+                L = lens[t]
                 want = po.perbase_c(reads.get(t, H.empty_reads()), Q, 0, L) if L else np.zeros(0, np.int32)
+                per[t] = want
                 ws, wm = H.oracle_windows(want, W)
                 if mode == "sums":
                     assert np.array_equal(eng.window_sums(t), ws), tag + (t,)    # (minima / runs: only when the
@@ -146,11 +180,27 @@ def test_soak_one_context_many_jobs(seed):
                 if mode == "full":
                     got = eng.perbase(t)
                     assert np.array_equal(got, want), tag + (t, "perbase")
-                    if L > 2 and rng.random() < 0.5:
-                        a = int(rng.integers(0, L)); b = int(rng.integers(a, L + 1))
-                        s1, m1 = eng.region_windows(t, a, b)
-                        rs, rm = H.oracle_windows(want[a:b], W, a)
-                        assert np.array_equal(s1, rs) and np.array_equal(m1, rm), tag + (t, a, b)
                 elif L:
                     with pytest.raises(GdError):
                         eng.perbase(t)
+            if mode == "full" and rng.random() < 0.5:        # the --bed reductions, many regions in one call
+                rt, rs, re_ = [], [], []
+                for _ in range(int(rng.integers(1, 60))):
+                    t = int(rng.choice(selected))
+                    a = int(rng.integers(0, max(1, lens[t]) + 20))
+                    rt.append(t); rs.append(a); re_.append(a + int(rng.choice([0, 1, 9, 300, 5000, 400000])))
+                sums, mins, runs = eng.regions(rt, rs, re_)
+                for k, (t, a, b) in enumerate(zip(rt, rs, re_)):
+                    if b == a:
+                        assert len(sums[k]) == 0 and len(runs[k]) == 0
+                        continue
+                    d = np.zeros(b - a, np.int32)
+                    hi = min(b, lens[t])
+                    if hi > a:
+                        d[:hi - a] = per[t][a:hi]
+                    ws, wm = H.oracle_windows(d, W, a)
+                    assert np.array_equal(sums[k], ws), tag + ("region", t, a, b)
+                    assert np.array_equal(mins[k], wm if lens[t] else np.zeros(len(wm), np.int32)), tag + ("region", t, a, b)
+                    assert np.array_equal(runs[k], H.oracle_runs(d, mincov, maxmean, 1 << 62, a)), tag + ("region", t, a, b)
+            if len(selected) != n_ctg:
+                eng.select_contigs([])
