@@ -203,7 +203,7 @@ int gd_set_contigs(gd_ctx* c, int n, const int64_t* lengths)
     for (auto& h : c->contigs) free_contig(h);
     c->contigs.assign(n, ContigHost());
     for (int i = 0; i < n; ++i) {
-        if (lengths[i] < 0 || lengths[i] > 0x7fffffffLL)
+        if (lengths[i] < 0 || lengths[i] > GD_MAX_CONTIG_LENGTH)
             return fail(c, GD_E_RANGE, "contig %d length %lld out of range", i, (long long)lengths[i]);
         c->contigs[i].length = lengths[i];
     }

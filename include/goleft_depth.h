@@ -195,7 +195,10 @@ enum { GD_OUT_PERBASE = 1,
 int gd_set_outputs(gd_ctx* ctx, unsigned flags);
 
 /* Reference sequence table (@SQ LN of the BAM header / .fai lengths,
- * depth/depth.go:134-149).  Drops all records and results. */
+ * depth/depth.go:134-149).  Drops all records and results.  Lengths are 0 .. GD_MAX_CONTIG_LENGTH (BAM itself
+ * stops at 2^31 - 1; the last 64 Ki positions are given up so that tile arithmetic stays in 32 bits), else
+ * GD_E_RANGE. */
+#define GD_MAX_CONTIG_LENGTH 0x7fff0000LL
 int gd_set_contigs(gd_ctx* ctx, int n_contigs, const int64_t* lengths);
 
 /* Restrict computation to a subset of contigs (--chrom, depth/depth.go:145).

@@ -216,3 +216,76 @@ def test_config4_cohort_full_size_properties():
         eng.adopt_device(0, *keep[137])
         eng.compute()
         assert np.array_equal(eng.windows(0)[0], one.cpu().numpy())
+
+
+@pytest.mark.parametrize("path,mode", [(1, "full"), (1, "windows"), (1, "sums"), (3, "full"), (3, "windows"),
+                                       (2, "full"), (0, "full")])
+def test_maximum_contig_length(path, mode):
+    """GD_MAX_CONTIG_LENGTH (0x7fff0000 positions: 524 272 tiles, an 8.6 GB per-base vector): records at the
+    start, across the tile boundary in the middle, and at the very end -- reads that hang over the contig end,
+    a deletion and a skip that run past it, a read at the last position -- on every device algorithm and
+    output mode.  Per-base values and window reductions of the three busy stretches against the oracle,
+    everything else zero / NO_COVERAGE, and one position past the limit is GD_E_RANGE."""
+    from goleft_amd.engine import DepthEngine, GdError
+    from tests import helpers as H
+    LMAX = 0x7fff0000
+    rng = np.random.default_rng(8)
+    spots = [0, LMAX // 2 - 20000, LMAX - 70000]
+    parts = []
+    for s0 in spots:
+        r = H.random_reads(rng, 60000, 3000, max_len=400, long_reads=(path != 1))
+        parts.append((r.pos.astype(np.int64) + s0, r))
+    pos = np.concatenate([p for p, _ in parts] + [[LMAX - 5000, LMAX - 300, LMAX - 1, LMAX - 1]])
+    tail_cig = np.array([(3000 << 4) | 0, (900 << 4) | 2, (2000 << 4) | 0,          # M D M over the end
+                         (100 << 4) | 0, (50000 << 4) | 3, (10 << 4) | 0,           # M N(past the end) M
+                         (1 << 4) | 0, (77 << 4) | 0], np.uint32)
+    tail_off = np.array([3, 6, 7, 8])
+    flag = np.concatenate([r.flag for _, r in parts] + [np.zeros(4, np.uint16)])
+    mapq = np.concatenate([r.mapq for _, r in parts] + [np.full(4, 60, np.uint8)])
+    offs, cigs, base = [np.zeros(1, np.int64)], [], 0
+    for _, r in parts:
+        offs.append(r.cigar_off[1:].astype(np.int64) + base)
+        cigs.append(r.cigar)
+        base += int(r.cigar_off[-1])
+    offs.append(tail_off + base)
+    cigs.append(tail_cig)
+    order = np.argsort(pos, kind="stable")                    # (the tail records already sort last)
+    assert np.array_equal(order, np.arange(len(pos)))
+    r = po.Reads(pos.astype(np.int32), flag.astype(np.uint16), mapq.astype(np.uint8),
+                 np.concatenate(offs).astype(np.uint32), np.concatenate(cigs).astype(np.uint32))
+    Wm, step = 1000, po.step_for(1000)
+    with DepthEngine(0) as eng:
+        with pytest.raises(GdError) as ei:
+            eng.set_contigs([LMAX + 1])
+        assert ei.value.status == -5
+        eng.set_path(path)
+        eng.set_outputs(perbase=(mode == "full"), sums_only=(mode == "sums"))
+        eng.set_params(window_size=Wm, min_mapq=Q, min_cov=MINCOV)
+        eng.set_contigs([LMAX])
+        eng.push(0, r.pos, r.flag, r.mapq, r.cigar_off, r.cigar)
+        eng.compute()
+        sums = eng.window_sums(0)
+        assert len(sums) == (LMAX + Wm - 1) // Wm
+        busy = np.zeros(len(sums), bool)
+        total = 0
+        for s0 in spots:
+            a, b = (s0 // Wm) * Wm, min(LMAX, ((s0 + 200000) // Wm + 1) * Wm)
+            want = po.perbase_c(r, Q, a, b)
+            total += int(want.sum(dtype=np.int64))
+            ws, wm = H.oracle_windows(want, Wm, a)
+            k0, k1 = a // Wm, a // Wm + len(ws)
+            busy[k0:k1] = True
+            assert np.array_equal(sums[k0:k1], ws), (s0, "sums")
+            if mode == "sums":
+                continue
+            assert np.array_equal(eng.windows(0)[1][k0:k1], wm), (s0, "mins")
+            if mode == "full":
+                assert np.array_equal(eng.perbase(0, a, b), want), (s0, "perbase")
+                assert np.array_equal(eng.region_callable(0, a, b), H.oracle_runs(want, MINCOV, 0, 1 << 62, a))
+        assert not sums[~busy].any() and int(sums.sum()) == total == counted_bases(r, Q, LMAX)
+        if mode != "sums":
+            runs = eng.callable_runs(0)
+            assert runs[0, 0] == 0 and runs[-1, 1] == LMAX and np.array_equal(runs[1:, 0], runs[:-1, 1])
+            assert (np.diff(runs[:, 0] // step) <= 1).all()                   # no run crosses a step boundary
+            far = (runs[:, 1] <= spots[1] - 40000) & (runs[:, 0] >= 250000)   # between the first two stretches
+            assert far.any() and (runs[far, 2] == 0).all()
