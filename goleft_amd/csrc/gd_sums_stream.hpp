@@ -13,45 +13,124 @@
 //     reads into three consecutive windows kb, kb+1, kb+2 in registers;
 //   * the lanes' kb are non-decreasing, so a window's total over the wave is a difference of ONE plain wave
 //     prefix sum at the segment ends (ballot of "my kb differs from the next lane's" + one bpermute): about
-//     six 64-bit global atomics per accumulator and wave instead of ~330 contended LDS atomics;
-//   * whatever does not fit that shape (multi-op reads: 2 %; a read longer than two windows; reads so sparse
-//     that a lane spans more than three windows) adds its intervals with direct global atomics.
+//     six adds per accumulator and group instead of ~330 contended ones -- into the wave's own LDS accumulators
+//     (the 256 windows from its first read's on), which go to memory with one 64-bit atomic each at its end;
+//   * whatever does not fit that shape (multi-op reads: 2 %; a read that ends past the lane's third window --
+//     long or sparse reads) is parked in a per-wave LDS queue and walked 64 reads at a time, its intervals
+//     added with direct global atomics.
 // Integer adds commute: the result is bit-identical to the per-base sums.
 #pragma once
 
 namespace gd {
 namespace sums {
 
-__device__ __forceinline__ void add_win(int64_t* wsum, uint32_t nwin, uint32_t k, uint32_t v)
+constexpr uint32_t NACC = 256;             // LDS window accumulators per wave
+
+// Where a wave's sums go.  Global 64-bit atomics are the expensive ingredient of this kernel (tools/probe/
+// stream_mix.hip: a read-only stream of this shape runs at 6.4 TB/s, with ~24 lane-atomics per KB of records at
+// 4.8): every one is an L2 request, and the sorted records of a wave keep hitting the same ~80 windows.  So a
+// wave accumulates the NACC windows from its first read's on in LDS and adds them to memory ONCE at its end;
+// only a window outside that range (sparse records, tiny windows) goes to memory directly.
+struct Acc {
+    unsigned long long* lds;               // NACC accumulators of this wave
+    uint32_t kw0;                          // window of accumulator 0
+    int64_t* wsum;
+    uint32_t nwin;
+};
+
+__device__ __forceinline__ void add_win(const Acc& A, uint32_t k, uint32_t v)
 {
-    if (v != 0u && k < nwin) atomicAdd(reinterpret_cast<unsigned long long*>(&wsum[k]), (unsigned long long)v);
+    if (v != 0u && k < A.nwin) {
+        const uint32_t rel = k - A.kw0;
+        if (rel < NACC) atomicAdd(&A.lds[rel], (unsigned long long)v);
+        else atomicAdd(reinterpret_cast<unsigned long long*>(&A.wsum[k]), (unsigned long long)v);
+    }
 }
 
-// a counted interval [s, e) of contig positions (e <= contig length < 2^31) -> every window it touches, one atomic
+// a counted interval [s, e) of contig positions (e <= contig length < 2^31) -> every window it touches, one add
 // each.  32-bit throughout: the next boundary nb = (k + 1) W <= s + W < 2^32, and it only advances while nb < e.
-__device__ __forceinline__ void add_interval_direct(int64_t* wsum, uint32_t nwin, uint32_t W, uint32_t wm, uint32_t ws,
-                                                    uint32_t s, uint32_t e)
+__device__ __forceinline__ void add_interval_direct(const Acc& A, uint32_t W, uint32_t wm, uint32_t ws, uint32_t s, uint32_t e)
 {
     uint32_t k = div_magic(s, wm, ws);
     uint32_t nb = (k + 1u) * W;
     while (s < e) {
         const uint32_t c = (nb < e ? nb : e) - s;
-        add_win(wsum, nwin, k, c);
+        add_win(A, k, c);
         s += c; ++k; nb += W;
     }
 }
 
 constexpr int U = 4;                       // reads per lane and group
 constexpr uint32_t GROUP = 64u * U;        // reads per group: one pass of a wave
-constexpr uint32_t GPW = 16;               // consecutive groups per wave: 4096 reads
+#ifndef GD_GPW
+#define GD_GPW 16
+#endif
+constexpr uint32_t GPW = GD_GPW;           // consecutive groups per wave
+constexpr int SQ_CAP = 256;                // queued odd reads per wave (a round adds at most 64)
+
+// pointers read from the contig table are generic to the compiler; as GLOBAL ones their loads return in order with
+// the buffer loads and the waits between pipeline stages can be partial (one FLAT load outstanding forces every
+// wait to vmcnt(0))
+typedef const __attribute__((address_space(1))) uint32_t* gptr_u32;
+
+// The wave's queue of odd reads {POS, index of the first canonical op, op count}, 64 at a time: walk the canonical
+// ops, M (0) counted, N (3) skipped, every M interval on its own.  (Inlined, at its one call site and the final one: as a
+// function call it cost the kernel 25 vector registers, one resident wave per SIMD in six and a tenth of its speed.)
+__device__ __forceinline__ void drain_queue(const uint4* Q, uint32_t cnt, int lane, gptr_u32 cigar, uint32_t length,
+                                         Acc acc, uint32_t W, uint32_t wm, uint32_t ws)
+{
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t i = (uint32_t)lane; i < cnt; i += 64u) {
+        const uint4 it = Q[i];
+        const int32_t pu = (int32_t)it.x;
+        const gptr_u32 ops = cigar + it.y;
+        const uint32_t nu = it.z;
+        if (pu >= 0) {
+            // 32 bits: x stays below the contig length (the walk stops there), an op is < 2^28
+            uint32_t x = (uint32_t)pu;
+            for (uint32_t k = 0; k < nu && x < length; ++k) {
+                const uint32_t o = ops[k], ol = o >> 4;
+                const uint32_t xe = x + ol;
+                if ((o & 0xfu) == 0u) add_interval_direct(acc, W, wm, ws, x, xe < length ? xe : length);
+                x = xe;
+            }
+        } else {
+            long long x = pu;                                  // a negative POS (no aligner writes one): the long form
+            for (uint32_t k = 0; k < nu; ++k) {
+                const uint32_t o = ops[k], ol = o >> 4;
+                if ((o & 0xfu) == 0u) {
+                    const long long e64 = x + (long long)ol;
+                    const uint32_t s = x > 0 ? (x < (long long)length ? (uint32_t)x : length) : 0u;
+                    const uint32_t e = e64 < (long long)length ? (e64 > 0 ? (uint32_t)e64 : 0u) : length;
+                    if (e > s) add_interval_direct(acc, W, wm, ws, s, e);
+                }
+                x += (long long)ol;
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+// one group of 256 reads on its way through the wave's pipeline
+struct Stage {
+    typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+    v4u pv, rv;            // POS and record words of the lane's four reads
+    uint32_t ob;           // first canonical op of the group (wave uniform)
+    uint32_t obase;        // ops of the lanes before this one
+    uint32_t cg[U];        // first op of each read
+};
 
 // A wave that took one group per launch slot spent its life in dependent round trips (which contig? its
 // pointers? the group's first op? the records? the ops? -- a dozen for 3 KB of records, 2 TB/s at full
 // occupancy).  So: a wave takes GPW consecutive groups of one contig, finds its contig with ONE vector load of
-// the group table (64 contigs per ballot), and has the next group's records and op offset in flight while it
-// works on the current one -- per group only the op fetch (which needs the record words) is exposed.
+// the group table (64 contigs per ballot), and runs them through a three-stage pipeline: while group g is
+// worked on, the first ops of group g+1 (their addresses need that group's record words) and the records of
+// group g+2 are in flight.  The loop is unrolled three times so that a stage's registers are never copied while
+// their loads are outstanding (a copy is a wait).
 __global__ __launch_bounds__(256) void gd_sums_stream_kernel(Job job)
 {
+    __shared__ uint4 s_q[4 * SQ_CAP];
+    __shared__ unsigned long long s_acc[4 * NACC];
     const int lane = threadIdx.x & 63;
     const uint32_t unit = blockIdx.x * 4u + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (unit >= job.n_groups) return;
@@ -71,56 +150,65 @@ __global__ __launch_bounds__(256) void gd_sums_stream_kernel(Job job)
     const uint32_t W = (uint32_t)job.W, wm = job.w_magic, ws = job.w_shift;
     const uint32_t nwin = div_magic(length - 1u, wm, ws) + 1u;     // length >= 1: a contig with reads
     int64_t* const wsum = job.win_sum + c.win_off;
-    const uint32_t* const off = c.off;
-    const uint32_t* const cigar = c.cigar;
+    const gptr_u32 off = (gptr_u32)c.off;
+    const gptr_u32 cigar = (gptr_u32)c.cigar;
     const uint32_t fmask = job.flag_mask << 20;
+    const int Q_ = job.Q;
 
     const uint32_t r_first = (unit - c.grp_beg) * (GROUP * GPW);   // first read of this wave
     uint32_t r_end = r_first + GROUP * GPW;
     r_end = r_end < n_reads ? r_end : n_reads;
     // one descriptor pair for the wave's whole range: reads past it load 0 = no ops
-    typedef unsigned int v4u __attribute__((ext_vector_type(4)));
     const rsrc_t r_pos = make_rsrc(c.pos + r_first, (r_end - r_first) * 4u);
     const rsrc_t r_rec = make_rsrc(c.rec + r_first, (r_end - r_first) * 4u);
 
-    v4u pv = __builtin_amdgcn_raw_buffer_load_b128(r_pos, lane * 16, 0, 0);
-    v4u rv = __builtin_amdgcn_raw_buffer_load_b128(r_rec, lane * 16, 0, 0);
-    uint32_t ob = off[r_first];                                  // first canonical op of the group (uniform)
-    for (uint32_t g0 = r_first; g0 < r_end; g0 += GROUP) {
-        // the next group's records and op offset: in flight while this one is processed
-        const uint32_t gn = g0 + GROUP;
-        v4u pvn = pv, rvn = rv;
-        uint32_t obn = ob;
-        if (gn < r_end) {
-            pvn = __builtin_amdgcn_raw_buffer_load_b128(r_pos, (int)(gn - r_first) * 4 + lane * 16, 0, 0);
-            rvn = __builtin_amdgcn_raw_buffer_load_b128(r_rec, (int)(gn - r_first) * 4 + lane * 16, 0, 0);
-            obn = off[gn];
-        }
-        const uint32_t* const cig = cigar + ob;                    // canonical ops of this group's reads, in read order
-        const int32_t p[U] = {(int32_t)pv.x, (int32_t)pv.y, (int32_t)pv.z, (int32_t)pv.w};
-        const uint32_t rec[U] = {rv.x, rv.y, rv.z, rv.w};
+    uint4* const Q = &s_q[(threadIdx.x >> 6) * SQ_CAP];
+    uint32_t qn = 0;                                             // queued odd reads (wave uniform)
+    // the wave's LDS accumulators: the NACC windows from its first read's on (sorted records: nothing before it;
+    // kw0 is set when the first records have arrived)
+    Acc acc;
+    acc.lds = &s_acc[(threadIdx.x >> 6) * NACC];
+    acc.kw0 = 0;
+    acc.wsum = wsum;
+    acc.nwin = nwin;
+#pragma unroll
+    for (uint32_t i = 0; i < NACC; i += 64u) acc.lds[i + (uint32_t)lane] = 0ull;
 
-        // where each read's ops are: prefix sum of the op counts
+    // stage 1: the records of group g (nothing past the wave's range: zeros = reads without ops)
+    auto load_records = [&](Stage& S, uint32_t g) {
+        S.pv = __builtin_amdgcn_raw_buffer_load_b128(r_pos, (int)(g - r_first) * 4 + lane * 16, 0, 0);
+        S.rv = __builtin_amdgcn_raw_buffer_load_b128(r_rec, (int)(g - r_first) * 4 + lane * 16, 0, 0);
+        S.ob = g < r_end ? off[g] : 0u;
+    };
+    // stage 2: where the group's ops are -- a prefix sum of the op counts in the record words -- and the first op
+    // of each read (the only one of 98 % of short reads)
+    auto fetch_ops = [&](Stage& S) {
+        const uint32_t rec[U] = {S.rv.x, S.rv.y, S.rv.z, S.rv.w};
         uint32_t n[U], ex[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) n[u] = rec[u] & norm::REC_NMAX;
         ex[0] = 0; ex[1] = n[0]; ex[2] = ex[1] + n[1]; ex[3] = ex[2] + n[2];
         const uint32_t ltot = ex[3] + n[3];
-        const uint32_t obase = (uint32_t)wave_inclusive_scan((int)ltot) - ltot;
-
-        // the first op of every read (the only one of 98 % of short reads) and, for the few multi-op reads, the two
-        // after it (a deletion is M N M) -- ONE round trip: a lane walking its ops load by load held the whole wave
-        // for three more
-        bool keep[U];
-        uint32_t cg[U], cg1[U], cg2[U];
+        S.obase = (uint32_t)wave_inclusive_scan((int)ltot) - ltot;
+        const gptr_u32 cig = cigar + S.ob;                         // canonical ops of this group's reads, in read order
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            keep[u] = ((rec[u] & fmask) == 0) & ((int)((rec[u] >> 12) & 0xffu) >= job.Q) & (n[u] != 0u);
-            const uint32_t* q = cig + obase + ex[u];
-            cg[u] = keep[u] ? q[0] : 0u;
-            cg1[u] = (keep[u] & (n[u] > 1u)) ? q[1] : 0u;
-            cg2[u] = (keep[u] & (n[u] > 2u)) ? q[2] : 0u;
+            const bool keep = ((rec[u] & fmask) == 0) & ((int)((rec[u] >> 12) & 0xffu) >= Q_) & (n[u] != 0u);
+            S.cg[u] = keep ? cig[S.obase + ex[u]] : 0u;
         }
+    };
+    // stage 3: the group's reads onto their windows
+    auto work = [&](const Stage& S, uint32_t g0) {
+        const int32_t p[U] = {(int32_t)S.pv.x, (int32_t)S.pv.y, (int32_t)S.pv.z, (int32_t)S.pv.w};
+        const uint32_t rec[U] = {S.rv.x, S.rv.y, S.rv.z, S.rv.w};
+        uint32_t n[U], ex[U];
+        bool keep[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            n[u] = rec[u] & norm::REC_NMAX;
+            keep[u] = ((rec[u] & fmask) == 0) & ((int)((rec[u] >> 12) & 0xffu) >= Q_) & (n[u] != 0u);
+        }
+        ex[0] = 0; ex[1] = n[0]; ex[2] = ex[1] + n[1]; ex[3] = ex[2] + n[2];
 
         // this lane's window base: the start window of its first read (sorted records: non-decreasing over the
         // lanes; lanes past the contig's last read sort last and add nothing)
@@ -132,72 +220,47 @@ __global__ __launch_bounds__(256) void gd_sums_stream_kernel(Job job)
         const uint32_t nb1 = nb0 + W >= nb0 ? nb0 + W : 0xffffffffu;
         const uint32_t nb2 = nb1 + W >= nb1 ? nb1 + W : 0xffffffffu;
         uint32_t a0 = 0, a1 = 0, a2 = 0;
-        uint32_t s_[U], e_[U];
-        uint32_t odd = 0;                                          // bit u: read u of this lane goes the long way
+        uint32_t odd = 0;                                          // bit u: read u of this lane is queued
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            // canonical: a single op is an M of 1 <= len < 2^28.  [s, e) clipped to the contig, in 32 bits; everything
-            // that is not a kept single-op read at a non-negative POS is an EMPTY interval here
-            const uint32_t len = cg[u] >> 4;
-            const bool one = keep[u] & (n[u] == 1u);
+            // canonical: a single op is an M of 1 <= len < 2^28.  [s, e) clipped to the contig, in 32 bits.  A kept
+            // read FITS when it is one M of fewer than 2^22 bases (the wave's prefix sums stay below 2^32 whatever
+            // the window) at a non-negative POS that ends inside the lane's three windows; every other read --
+            // several ops, a long or sparse read, a negative POS -- is an EMPTY interval here and goes to the queue
+            const uint32_t len = S.cg[u] >> 4;
             const uint32_t s = p[u] > 0 ? (uint32_t)p[u] : 0u;
             const uint32_t eu = s + len;                           // < 2^31 + 2^28
-            const uint32_t e = (one & (p[u] >= 0)) ? (eu < length ? eu : length) : s;
+            const uint32_t ec = eu < length ? eu : length;
+            const bool fits = keep[u] & (n[u] == 1u) & (len < (1u << 22)) & (p[u] >= 0) & (ec <= nb2);
+            const uint32_t e = fits ? ec : s;
             const uint32_t l1 = s > nb0 ? s : nb0, l2 = s > nb1 ? s : nb1;
-            const uint32_t h0 = e < nb0 ? e : nb0, h1 = e < nb1 ? e : nb1, h2 = e < nb2 ? e : nb2;
+            const uint32_t h0 = e < nb0 ? e : nb0, h1 = e < nb1 ? e : nb1;
             a0 += (h0 > s ? h0 : s) - s;
             a1 += (h1 > l1 ? h1 : l1) - l1;
-            a2 += (h2 > l2 ? h2 : l2) - l2;
-            // what sticks out past the third window (a long read, sparse reads), a negative POS, several ops: the long way
-            s_[u] = s > nb2 ? s : nb2; e_[u] = e;
-            odd |= ((one & (e > nb2)) | (keep[u] & (n[u] > 1u)) | (one & (p[u] < 0))) ? 1u << u : 0u;
+            a2 += (e > l2 ? e : l2) - l2;
+            odd |= (keep[u] & !fits) ? 1u << u : 0u;
         }
-        // The long way, ONE instance of the code for all four slots: nearly every group of 256 reads has a few
-        // multi-op reads, in different slots of different lanes -- a block per slot ran three of the four blocks
-        // with a handful of lanes each (PMC: more than half of this kernel's vector instructions).  Every lane
-        // takes its next flagged read (a select over the four slots); usually one round.
+        // Odd reads (2 % of a short-read sample) do not interrupt the stream: they are parked in the wave's queue and
+        // walked 64 at a time.  Walked where they occur -- a loop per group, a handful of lanes each round -- they
+        // were a quarter of this kernel's vector instructions (PMC, profiles/r02l_cohort_pmc.txt).
+        // (one queue slot per lane and round: every lane parks its next flagged read, a select over the four slots --
+        // ONE instance of the insertion code and of the drain)
         while (__builtin_amdgcn_ballot_w64(odd != 0u) != 0ull) {
-            if (odd != 0u) {
-                const int u = __ffs((int)odd) - 1;
-                odd &= odd - 1u;
+            const bool mine = odd != 0u;
+            const int u = mine ? __ffs((int)odd) - 1 : 0;
+            odd &= odd - 1u;
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(mine);
+            const uint32_t np = (uint32_t)__popcll(m);
+            if (qn + np > (uint32_t)SQ_CAP) { drain_queue(Q, qn, lane, cigar, length, acc, W, wm, ws); qn = 0; }
+            if (mine) {
+                const uint32_t rk = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32),
+                                             __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
                 const int32_t pu = u == 0 ? p[0] : u == 1 ? p[1] : u == 2 ? p[2] : p[3];
                 const uint32_t nu = u == 0 ? n[0] : u == 1 ? n[1] : u == 2 ? n[2] : n[3];
-                if (nu == 1u && pu >= 0) {
-                    // the part of a single-op read past the lane's third window
-                    const uint32_t su = u == 0 ? s_[0] : u == 1 ? s_[1] : u == 2 ? s_[2] : s_[3];
-                    const uint32_t eu = u == 0 ? e_[0] : u == 1 ? e_[1] : u == 2 ? e_[2] : e_[3];
-                    if (eu > su) add_interval_direct(wsum, nwin, W, wm, ws, su, eu);
-                } else {
-                    // walk the canonical ops: M (0) counted, N (3) skipped, every M interval on its own
-                    const uint32_t c0 = u == 0 ? cg[0] : u == 1 ? cg[1] : u == 2 ? cg[2] : cg[3];
-                    const uint32_t c1 = u == 0 ? cg1[0] : u == 1 ? cg1[1] : u == 2 ? cg1[2] : cg1[3];
-                    const uint32_t c2 = u == 0 ? cg2[0] : u == 1 ? cg2[1] : u == 2 ? cg2[2] : cg2[3];
-                    const uint32_t xu = u == 0 ? ex[0] : u == 1 ? ex[1] : u == 2 ? ex[2] : ex[3];
-                    const uint32_t* ops = cig + obase + xu;
-                    if (pu >= 0) {
-                        // 32 bits: x stays below the contig length (the walk stops there), an op is < 2^28
-                        uint32_t x = (uint32_t)pu;
-                        for (uint32_t k = 0; k < nu && x < length; ++k) {
-                            const uint32_t o = k == 0u ? c0 : k == 1u ? c1 : k == 2u ? c2 : ops[k], ol = o >> 4;
-                            const uint32_t xe = x + ol;
-                            if ((o & 0xfu) == 0u) add_interval_direct(wsum, nwin, W, wm, ws, x, xe < length ? xe : length);
-                            x = xe;
-                        }
-                    } else {
-                        long long x = pu;                      // a negative POS (no aligner writes one): the long form
-                        for (uint32_t k = 0; k < nu; ++k) {
-                            const uint32_t o = k == 0u ? c0 : k == 1u ? c1 : k == 2u ? c2 : ops[k], ol = o >> 4;
-                            if ((o & 0xfu) == 0u) {
-                                const long long e64 = x + (long long)ol;
-                                const uint32_t s = x > 0 ? (x < (long long)length ? (uint32_t)x : length) : 0u;
-                                const uint32_t e = e64 < (long long)length ? (e64 > 0 ? (uint32_t)e64 : 0u) : length;
-                                if (e > s) add_interval_direct(wsum, nwin, W, wm, ws, s, e);
-                            }
-                            x += (long long)ol;
-                        }
-                    }
-                }
+                const uint32_t xu = u == 0 ? ex[0] : u == 1 ? ex[1] : u == 2 ? ex[2] : ex[3];
+                Q[rk] = make_uint4((uint32_t)pu, S.ob + S.obase + xu, nu, 0u);
             }
+            qn += np;
         }
 
         // segment totals: kb is non-decreasing over the lanes, so a window's total is a difference of one plain
@@ -215,11 +278,35 @@ __global__ __launch_bounds__(256) void gd_sums_stream_kernel(Job job)
         const uint32_t q2 = (uint32_t)__shfl((int)s2, pt, 64);
         if (tail) {
             const bool first = before == 0ull;
-            add_win(wsum, nwin, kb, s0 - (first ? 0u : q0));
-            add_win(wsum, nwin, kb + 1u, s1 - (first ? 0u : q1));
-            add_win(wsum, nwin, kb + 2u, s2 - (first ? 0u : q2));
+            add_win(acc, kb, s0 - (first ? 0u : q0));
+            add_win(acc, kb + 1u, s1 - (first ? 0u : q1));
+            add_win(acc, kb + 2u, s2 - (first ? 0u : q2));
         }
-        pv = pvn; rv = rvn; ob = obn;
+    };
+
+    Stage A, B, C;
+    load_records(A, r_first);
+    load_records(B, r_first + GROUP);
+    {
+        const int32_t p0 = __builtin_amdgcn_readfirstlane((int)A.pv.x);
+        acc.kw0 = div_magic((uint32_t)(p0 > 0 ? p0 : 0), wm, ws);
+    }
+    fetch_ops(A);
+    for (uint32_t g = r_first; g < r_end; g += 3u * GROUP) {
+        load_records(C, g + 2u * GROUP); fetch_ops(B); work(A, g);
+        if (g + GROUP >= r_end) break;
+        load_records(A, g + 3u * GROUP); fetch_ops(C); work(B, g + GROUP);
+        if (g + 2u * GROUP >= r_end) break;
+        load_records(B, g + 4u * GROUP); fetch_ops(A); work(C, g + 2u * GROUP);
+    }
+    if (qn != 0u) drain_queue(Q, qn, lane, cigar, length, acc, W, wm, ws);
+    // the wave's accumulators -> memory, once
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (uint32_t i = 0; i < NACC; i += 64u) {
+        const unsigned long long v = acc.lds[i + (uint32_t)lane];
+        const uint32_t k = acc.kw0 + i + (uint32_t)lane;
+        if (v != 0ull && k < nwin) atomicAdd(reinterpret_cast<unsigned long long*>(&wsum[k]), v);
     }
 }
 
