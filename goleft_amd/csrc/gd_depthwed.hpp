@@ -6,7 +6,7 @@
 // (/root/reference/depthwed/depthwed.go:117-157, :103).  Here the N samples are
 // N sets of contigs of one engine (their integer window sums are already in
 // HBM), the text round trip is replaced by gd_depthwed_cell (gd_round4g.hpp)
-// and one thread produces one (row, sample) cell.
+// and one lane produces one (row, sample) cell.
 #pragma once
 
 #include "gd_round4g.hpp"
@@ -25,28 +25,57 @@ struct WedJob {
     int64_t W, group;           // windows per group = ceil(size / W)
 };
 
+// One workgroup per tile of 64 matrix rows x 64 samples.  The window sums are sample-major (a sample's windows
+// are contiguous) and the matrix is row-major (a row's samples are contiguous): a thread per cell in matrix order
+// read 32 bytes here and 32 bytes a whole sample further on (half of every line fetched for nothing, two 64-bit
+// divisions per cell to find out where it was).  Here a wave takes 16 of the tile's samples, its lanes are the 64
+// rows -- together they read one contiguous stretch of that sample's sums -- and the tile goes through LDS so that
+// the stores are whole rows of 64 cells.
+constexpr int WED_TILE = 64;
+
 __global__ __launch_bounds__(256) void gd_depthwed_kernel(WedJob j)
 {
-    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= j.n_rows * j.n_samples) return;
-    const int64_t row = gid / j.n_samples;
-    const int s = (int)(gid - row * j.n_samples);
-    int lo = 0, hi = j.n_ctg;                       // contig of this row
-    while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (j.row_beg[mid] <= row) lo = mid; else hi = mid;
+    __shared__ int64_t s_tile[WED_TILE][WED_TILE + 1];
+    const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;
+    const int64_t row0 = (int64_t)blockIdx.x * WED_TILE;
+    const int s0 = (int)blockIdx.y * WED_TILE;
+    const int64_t row = row0 + lane;
+    const bool in_rows = row < j.n_rows;
+    int lo = 0;
+    int64_t w0 = 0, w1 = 0, L = 0;
+    if (in_rows) {
+        int hi = j.n_ctg;                           // contig of this row
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (j.row_beg[mid] <= row) lo = mid; else hi = mid;
+        }
+        w0 = (row - j.row_beg[lo]) * j.group;
+        w1 = w0 + j.group < j.nwin[lo] ? w0 + j.group : j.nwin[lo];
+        L = j.clen[lo];
     }
-    const int64_t r = row - j.row_beg[lo];
-    const int64_t w0 = r * j.group;
-    const int64_t w1 = w0 + j.group < j.nwin[lo] ? w0 + j.group : j.nwin[lo];
-    const int64_t* ws = j.win_sum + j.off[(int64_t)s * j.n_ctg + lo];
-    const int64_t L = j.clen[lo];
-    int64_t cell = 0;
-    for (int64_t w = w0; w < w1; ++w) {
-        const int64_t e = (w + 1) * j.W < L ? (w + 1) * j.W : L;
-        cell += gd_depthwed_cell(ws[w], e - w * j.W);
+    for (int k = 0; k < WED_TILE / 4; ++k) {
+        const int sl = wv * (WED_TILE / 4) + k;     // sample of the tile
+        const int s = s0 + sl;
+        if (s >= j.n_samples) break;                // wave uniform
+        int64_t cell = 0;
+        if (in_rows) {
+            const int64_t* ws = j.win_sum + j.off[(int64_t)s * j.n_ctg + lo];
+            for (int64_t w = w0; w < w1; ++w) {
+                const int64_t e = (w + 1) * j.W < L ? (w + 1) * j.W : L;
+                cell += gd_depthwed_cell(ws[w], e - w * j.W);
+            }
+        }
+        s_tile[lane][sl] = cell;
     }
-    j.cells[gid] = cell;
+    __syncthreads();
+    const int s = s0 + lane;
+    if (s < j.n_samples)
+        for (int k = 0; k < WED_TILE / 4; ++k) {
+            const int rl = wv * (WED_TILE / 4) + k;
+            if (row0 + rl >= j.n_rows) break;
+            j.cells[(row0 + rl) * j.n_samples + s] = s_tile[rl][lane];
+        }
 }
 
 }  // namespace gd
