@@ -191,10 +191,24 @@ __global__ __launch_bounds__(256) void gd_sums_stream_kernel(Job job)
         const uint32_t ltot = ex[3] + n[3];
         S.obase = (uint32_t)wave_inclusive_scan((int)ltot) - ltot;
         const gptr_u32 cig = cigar + S.ob;                         // canonical ops of this group's reads, in read order
+        // a lane whose four reads have one op each (nearly all lanes of a short-read sample) finds them side by side:
+        // ONE 16-byte load; the others gather theirs read by read
+        typedef unsigned int v4u_t __attribute__((ext_vector_type(4)));
+        typedef const __attribute__((address_space(1))) v4u_t* gptr_v4;
+        const bool four = ((n[0] & n[1] & n[2] & n[3]) == 1u) & ((n[0] | n[1] | n[2] | n[3]) == 1u);
+        v4u_t o4 = {0u, 0u, 0u, 0u};
+        if (four) o4 = *(gptr_v4)(cig + S.obase);
+        const uint32_t o[U] = {o4.x, o4.y, o4.z, o4.w};
+        bool keep[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const bool keep = ((rec[u] & fmask) == 0) & ((int)((rec[u] >> 12) & 0xffu) >= Q_) & (n[u] != 0u);
-            S.cg[u] = keep ? cig[S.obase + ex[u]] : 0u;
+            keep[u] = ((rec[u] & fmask) == 0) & ((int)((rec[u] >> 12) & 0xffu) >= Q_) & (n[u] != 0u);
+            S.cg[u] = keep[u] ? o[u] : 0u;
+        }
+        if (__builtin_amdgcn_ballot_w64(!four & (ltot != 0u)) != 0ull) {
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (!four & keep[u]) S.cg[u] = cig[S.obase + ex[u]];
         }
     };
     // stage 3: the group's reads onto their windows
