@@ -8,7 +8,7 @@
 // atomics onto the 16 window accumulators of a tile -- 64 lanes hitting 2-3 addresses.  Nothing here is
 // positional except the window index, and the records are coordinate sorted, so:
 //   * one wave takes 256 CONSECUTIVE reads of one contig (4 per lane: 16 bytes of `pos`, 16 bytes of record
-//     words, the reads' first canonical op each), every read exactly once: no tiles, no look-back, no LDS;
+//     words, the reads' first canonical op each), every read exactly once: no tiles, no look-back;
 //   * a read adds to its start window and -- when it crosses the boundary -- the next; a lane folds its four
 //     reads into three consecutive windows kb, kb+1, kb+2 in registers;
 //   * the lanes' kb are non-decreasing, so a window's total over the wave is a difference of ONE plain wave
@@ -16,8 +16,8 @@
 //     six adds per accumulator and group instead of ~330 contended ones -- into the wave's own LDS accumulators
 //     (the 256 windows from its first read's on), which go to memory with one 64-bit atomic each at its end;
 //   * whatever does not fit that shape (multi-op reads: 2 %; a read that ends past the lane's third window --
-//     long or sparse reads) is parked in a per-wave LDS queue and walked 64 reads at a time, its intervals
-//     added with direct global atomics.
+//     long or sparse reads) is parked in a per-wave LDS queue and walked 64 reads at a time, one add per
+//     (interval, window) into the same accumulators.
 // Integer adds commute: the result is bit-identical to the per-base sums.
 #pragma once
 
@@ -62,10 +62,7 @@ __device__ __forceinline__ void add_interval_direct(const Acc& A, uint32_t W, ui
 
 constexpr int U = 4;                       // reads per lane and group
 constexpr uint32_t GROUP = 64u * U;        // reads per group: one pass of a wave
-#ifndef GD_GPW
-#define GD_GPW 16
-#endif
-constexpr uint32_t GPW = GD_GPW;           // consecutive groups per wave
+constexpr uint32_t GPW = 16;               // consecutive groups per wave: 4096 reads (64 or 256: slower, r02o)
 constexpr int SQ_CAP = 256;                // queued odd reads per wave (a round adds at most 64)
 
 // pointers read from the contig table are generic to the compiler; as GLOBAL ones their loads return in order with
