@@ -383,3 +383,40 @@ def test_parallel_member_listing_equals_the_serial_walk(tmp_path):
     assert len(got[0]) == n // 2 and np.array_equal(got[0], ser[0][:n // 2])
     with pytest.raises(ValueError):
         hl.list_members(b"not bgzf at all, definitely" * 4, 0, [], threads=4, min_bytes=1)
+
+
+def test_member_listing_on_damaged_ranges_agrees_with_the_serial_walk(tmp_path):
+    """gdh_list_members on damaged input: random bytes of a BGZF range overwritten (headers included), cut points
+    that are no member starts, ranges cut anywhere -- the threaded walk returns what the serial walk returns (the
+    same table or the same refusal), never more, and never reads outside the range."""
+    from goleft_amd import _hostlib as hl
+    from oracle import bamio
+    rng = np.random.default_rng(12)
+    path = str(tmp_path / "y.bam")
+    bamio.write_bam(path, [("c1", 90_000)], {0: H.random_reads(rng, 90_000, 15_000, max_len=100)})
+    good = open(path, "rb").read()
+    ser0 = hl.list_members(good, 0, [], threads=1)
+    assert len(ser0[0]) > 8
+
+    def listing(data, starts, threads):
+        try:
+            return hl.list_members(data, 0, starts, threads=threads, min_bytes=1)
+        except ValueError:
+            return None
+
+    for case in range(150):
+        data = bytearray(good)
+        for _ in range(int(rng.integers(0, 6))):
+            data[int(rng.integers(0, len(data)))] = int(rng.integers(0, 256))
+        if case % 3 == 0:                                                   # hit a member header for sure
+            k = int(rng.integers(0, len(ser0[0])))
+            data[int(ser0[0][k]) + int(rng.integers(0, 18))] = int(rng.integers(0, 256))
+        data = bytes(data[:int(rng.integers(1, len(data) + 1))] if case % 4 == 1 else data)
+        true_starts = [int(x) for x in ser0[0][1::int(rng.integers(1, 5))] if x < len(data)]
+        bogus = [int(x) for x in rng.integers(0, len(data), size=int(rng.integers(0, 4)))]
+        want = listing(data, [], 1)
+        got = listing(data, sorted(true_starts + bogus), int(rng.integers(2, 17)))
+        assert (want is None) == (got is None), case
+        if want is not None:
+            for a, b in zip(got, want):
+                assert np.array_equal(a, b), case
