@@ -381,6 +381,18 @@ int gd_adopt_device(gd_ctx* c, int32_t tid, const gd_batch* d, size_t n_reads, s
     // stream of the caller produced them must have finished.  A device-wide wait makes that true for
     // any producer (a few microseconds per contig, at ingest time).
     HIPCHK(c, hipDeviceSynchronize());
+    if (n_reads) {
+        // what gd_commit checks on a host block, here in one pass over pos / cigar_off on the device
+        if (int r = ensure_dev(c, &c->d_scan_tmp, &c->cap_scan_tmp, 1)) return r;
+        uint32_t bad = 0;
+        HIPCHK(c, hipMemsetAsync(c->d_scan_tmp, 0, sizeof(uint32_t), c->stream));
+        hipLaunchKernelGGL(gd::norm::gd_check_records_kernel, dim3((unsigned)((n_reads + 255) / 256)), dim3(256), 0, c->stream,
+                           d->pos, d->cigar_off, (uint32_t)n_reads, (uint32_t)n_ops, c->d_scan_tmp);
+        HIPCHK(c, hipMemcpyAsync(&bad, c->d_scan_tmp, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (bad & 1u) return fail(c, GD_E_UNSORTED, "contig %d: device records not coordinate sorted", tid);
+        if (bad & 2u) return fail(c, GD_E_INVALID, "contig %d: CSR offsets of the device records are not a non-decreasing sequence from 0 to at most %zu", tid, n_ops);
+    }
     ContigHost& h = c->contigs[tid];
     int64_t len = h.length;
     free_contig(h);

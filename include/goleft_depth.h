@@ -226,7 +226,10 @@ int gd_push(gd_ctx* ctx, int32_t tid, const int32_t* pos, const uint16_t* flag,
 
 /* Use records already resident in HBM (zero copy).  Replaces any records of
  * that contig.  The call waits for the device (whatever stream produced the
- * arrays) and builds the contig's canonical CIGARs from them right away. */
+ * arrays), checks them the way gd_commit checks a host block -- positions in
+ * coordinate order (GD_E_UNSORTED), CSR offsets non-decreasing from 0 and ending
+ * inside the op array (GD_E_INVALID); one pass over pos / cigar_off -- and builds
+ * the contig's canonical CIGARs from them right away. */
 int gd_adopt_device(gd_ctx* ctx, int32_t tid, const gd_batch* dev, size_t n_reads, size_t n_ops);
 
 /* Drop records and results, keep contigs/params/allocations. */

@@ -498,3 +498,44 @@ def test_slow_list_counter_survives_jobs_without_a_tile_table(auto_eng):
     finally:
         eng.set_outputs(perbase=True)
         eng.set_path(PATH_AUTO)
+
+
+def test_adopted_device_records_are_checked():
+    """gd_adopt_device gives device arrays the check gd_commit gives a host block: positions out of order are
+    GD_E_UNSORTED, CSR offsets that decrease, do not start at 0 or end past the op array GD_E_INVALID -- before
+    any kernel indexes with them; well-formed arrays (also with equal positions and reads without ops) pass."""
+    import torch
+    from goleft_amd.engine import DepthEngine, GdError
+    from tests.test_gpu_soak import _adopt
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(41)
+    L = 50_000
+    r = H.random_reads(rng, L, 3000)
+
+    def adopt(eng, pos, off, cigar=None):
+        t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a).view(dt)).to(dev)
+        eng.adopt_device(0, t(pos.astype(np.int32), np.int32), t(r.flag, np.int16), t(r.mapq, np.uint8),
+                         t(off.astype(np.uint32), np.int32), t(r.cigar if cigar is None else cigar, np.int32))
+
+    with DepthEngine(0) as eng:
+        eng.set_params(window_size=100, min_mapq=1, min_cov=4)
+        eng.set_contigs([L])
+        bad_pos = r.pos.copy(); bad_pos[1500], bad_pos[1501] = r.pos[-1], r.pos[0]
+        with pytest.raises(GdError) as ei:
+            adopt(eng, bad_pos, r.cigar_off)
+        assert ei.value.status == -7
+        for mutate in ("decreasing", "start", "end"):
+            off = r.cigar_off.astype(np.int64).copy()
+            if mutate == "decreasing":
+                off[2000] = off[1999] - 1 if off[1999] > 0 else off[2001] + 5
+                off[2000] = max(off[2000], off[2001] + 1)
+            elif mutate == "start":
+                off[0] = 1
+            else:
+                off[-1] = len(r.cigar) + 7
+            with pytest.raises(GdError) as ei:
+                adopt(eng, r.pos, off)
+            assert ei.value.status == -1, mutate
+        _adopt(eng, torch, 0, r)                                             # the well-formed arrays
+        eng.compute()
+        assert np.array_equal(eng.perbase(0), po.perbase_c(r, 1, 0, L))
