@@ -290,7 +290,8 @@ __global__ __launch_bounds__(NT) void gd_ltile2_kernel(Job job)
         const int4 z = make_int4(0, 0, 0, 0);
         int4* d4 = reinterpret_cast<int4*>(s_diffp);
 #pragma unroll
-        for (int i = tid; i < T / 4 + 1; i += NT) d4[i] = z;
+        for (int i = 0; i < T / 4 / NT; ++i) d4[tid + i * NT] = z;       // (T / 4 is a multiple of NT)
+        if (tid == 0) d4[T / 4] = z;
         for (int i = tid; i < NWORDS; i += NT) { s_bmap[i] = 0; s_clo[i] = 0; s_chi[i] = 0; }
         if (tid == 0) s_hasb = 0;
     }
