@@ -485,14 +485,6 @@ int gd_set_option(gd_ctx* c, int option, int64_t value)
     if (c && c->cs.pending) return fail(c, GD_E_STATE, "a compute is in flight: gd_compute_finish first");
     if (!c) return GD_E_INVALID;
     switch (option) {
-    case GD_OPT_TILE_POSITIONS:
-        if (value != 4096 && value != 8192) return fail(c, GD_E_INVALID, "tile positions: 4096 or 8192");
-        c->tile_T = (int)value;
-        break;
-    case GD_OPT_TILE_THREADS:
-        if (value != 256 && value != 512) return fail(c, GD_E_INVALID, "tile threads: 256 or 512");
-        c->tile_NT = (int)value;
-        break;
     case GD_OPT_NT_STORES: c->tile_opt = value ? 1 : 0; break;
     case GD_OPT_NORMALIZE: c->normalize = value != 0; break;
     case GD_OPT_FAST_KERNEL: c->fast_kernel = value != 0; break;

@@ -10,6 +10,8 @@ constexpr int kRingSlots = 3;
 constexpr size_t kSpecBounds = 4096;     // boundaries copied to the host before their count is known (one synchronisation)
 constexpr int kDefaultLookback = 512;
 constexpr uint64_t kMaxReadsPerContig = 1ull << 30;
+constexpr int kTileT = 4096;              // reference positions per tile, 256 threads each: the one shape that is built (8192
+                                           // positions and 512 threads were measured slower on every workload and retired)
 constexpr int kAutoLongSpan = 32768;      // GD_PATH_AUTO leaves the short-read tile path above this read span
 constexpr int kMaxSpan = 1 << 27;   // tile-relative byte offsets of the tile kernel stay in 32 bits
 
@@ -113,8 +115,6 @@ struct gd_ctx {
     std::string err;
 
     // tuning knobs (gd_set_option; defaults are what the measurements of DESIGN.md section 4 chose)
-    int tile_T = 4096;
-    int tile_NT = 256;
     bool fast_kernel = true;            // GD_OPT_FAST_KERNEL: the straight-line tile kernel (gd_tile_fast.hpp) for
                                         // ordinary tiles, the generic one for the rest; 0 = generic for every tile
     bool normalize = true;              // GD_OPT_NORMALIZE: canonical CIGARs at arrival (gd_normalize.hpp)

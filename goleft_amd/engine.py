@@ -16,7 +16,7 @@ from ._lib import GdBatch, GdParams, GdRun, GdStats
 CLASS_NAMES = ("NO_COVERAGE", "LOW_COVERAGE", "CALLABLE", "EXCESSIVE_COVERAGE")
 K_PREP, K_TILE, K_RUNS, K_EXPAND, K_SCAN, K_CKPT, K_SEQSTATS, K_MDFLAGS, K_INFLATE, K_NORM = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9
 # gd_set_option keys (include/goleft_depth.h)
-OPT_TILE_POSITIONS, OPT_TILE_THREADS, OPT_NT_STORES, OPT_NORMALIZE, OPT_FAST_KERNEL, OPT_COPY_THREADS = 1, 2, 3, 4, 5, 6
+OPT_NT_STORES, OPT_NORMALIZE, OPT_FAST_KERNEL, OPT_COPY_THREADS = 3, 4, 5, 6
 PATH_AUTO, PATH_TILE, PATH_SCATTER, PATH_CHUNK = 0, 1, 2, 3
 
 

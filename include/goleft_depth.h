@@ -162,8 +162,7 @@ int gd_set_path(gd_ctx* ctx, int path);
 /* Tuning / diagnostic switches (defaults are what the measurements in DESIGN.md chose; results are bit
  * identical under every setting).  A C library behind cgo takes no behaviour from the process
  * environment: these are calls. */
-enum { GD_OPT_TILE_POSITIONS = 1,   /* reference positions per LDS tile: 4096 (default) or 8192 */
-       GD_OPT_TILE_THREADS = 2,     /* threads per tile workgroup: 256 (default) or 512 */
+enum { /* (1, 2: tile shapes other than 4096 positions x 256 threads -- measured slower everywhere, retired) */
        GD_OPT_NT_STORES = 3,        /* 1 (default): non-temporal per-base stores; 0: plain */
        GD_OPT_NORMALIZE = 4,        /* 1 (default): canonical CIGARs are built when records arrive (I/S/H/P and
                                        zero-length ops dropped, neighbouring M/=/X merged, neighbouring D/N
