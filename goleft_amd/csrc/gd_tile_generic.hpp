@@ -608,7 +608,7 @@ __device__ __forceinline__ void tile_body(const Job& job, const TileInfo& ti, co
     phase_c<T, NT>(job, tile, t0, ti.ctg, tid, lane, wv, s_bmap, s_clo, s_chi, s_wcnt, &s_hasb, &s_base);
 }
 
-// Every tile, one workgroup each (GD_OPT_FAST_KERNEL = 0, or a tile shape other than 4096 x 256).
+// Every tile, one workgroup each (GD_OPT_FAST_KERNEL = 0, or records without canonical CIGARs / record words).
 template <int T, int NT, int OPT>
 __global__ __launch_bounds__(NT) void gd_tile_kernel(Job job)
 {
