@@ -286,6 +286,7 @@ int gd_commit(gd_ctx* c, const gd_batch* b, int32_t tid, size_t n_reads, size_t 
     // coordinate order (BAM SO:coordinate) is what makes the tile search valid
     int32_t last = h.last_pos;
     for (size_t i = 0; i < n_reads; ++i) {
+        if (b->pos[i] < 0) return fail(c, GD_E_RANGE, "contig %d record %zu: negative position %d (a placed BAM record has POS >= 0)", tid, h.n_reads + i, b->pos[i]);
         if (b->pos[i] < last) return fail(c, GD_E_UNSORTED, "contig %d record %zu: pos %d < %d", tid, h.n_reads + i, b->pos[i], last);
         if (b->cigar_off[i + 1] < b->cigar_off[i]) return fail(c, GD_E_INVALID, "cigar_off not monotone");
         last = b->pos[i];
@@ -390,6 +391,7 @@ int gd_adopt_device(gd_ctx* c, int32_t tid, const gd_batch* d, size_t n_reads, s
                            d->pos, d->cigar_off, (uint32_t)n_reads, (uint32_t)n_ops, c->d_scan_tmp);
         HIPCHK(c, hipMemcpyAsync(&bad, c->d_scan_tmp, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (bad & 4u) return fail(c, GD_E_RANGE, "contig %d: a device record has a negative position (a placed BAM record has POS >= 0)", tid);
         if (bad & 1u) return fail(c, GD_E_UNSORTED, "contig %d: device records not coordinate sorted", tid);
         if (bad & 2u) return fail(c, GD_E_INVALID, "contig %d: CSR offsets of the device records are not a non-decreasing sequence from 0 to at most %zu", tid, n_ops);
     }

@@ -306,7 +306,8 @@ __global__ __launch_bounds__(256) void gd_pidx_kernel(const int32_t* __restrict_
 }
 
 // gd_adopt_device: the arrays come from the caller's own kernels -- the one check a host block gets in gd_commit.
-// flags: bit 0 positions out of order, bit 1 CSR offsets decreasing / not starting at 0 / ending past the ops.
+// flags: bit 0 positions out of order, bit 1 CSR offsets decreasing / not starting at 0 / ending past the ops,
+// bit 2 a negative position.
 __global__ __launch_bounds__(256) void gd_check_records_kernel(const int32_t* __restrict__ pos, const uint32_t* __restrict__ off,
                                                                uint32_t n_reads, uint32_t n_ops, uint32_t* __restrict__ flags)
 {
@@ -314,11 +315,13 @@ __global__ __launch_bounds__(256) void gd_check_records_kernel(const int32_t* __
     uint32_t bad = 0;
     if (r < n_reads) {
         if (r + 1u < n_reads && pos[r] > pos[r + 1u]) bad |= 1u;
+        if (r == 0u && pos[0] < 0) bad |= 4u;                  // (sorted: the first position is the smallest)
         const uint32_t a = off[r], b = off[r + 1u];
         if (a > b || (r == 0u && a != 0u) || (r + 1u == n_reads && b > n_ops)) bad |= 2u;
     }
     const uint32_t any = (__builtin_amdgcn_ballot_w64((bad & 1u) != 0u) != 0ull ? 1u : 0u) |
-                         (__builtin_amdgcn_ballot_w64((bad & 2u) != 0u) != 0ull ? 2u : 0u);
+                         (__builtin_amdgcn_ballot_w64((bad & 2u) != 0u) != 0ull ? 2u : 0u) |
+                         (__builtin_amdgcn_ballot_w64((bad & 4u) != 0u) != 0ull ? 4u : 0u);
     if (any != 0u && (threadIdx.x & 63u) == 0u) atomicOr(flags, any);
 }
 

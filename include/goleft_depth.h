@@ -214,7 +214,8 @@ int gd_acquire(gd_ctx* ctx, size_t reads_cap, size_t ops_cap, gd_batch* out);
 /* Append n_reads records (n_ops ops) of contig tid from a block obtained from
  * gd_acquire; the H2D copy is asynchronous on the copy stream and the block
  * returns to the ring when it completes.  Records of one contig must be
- * committed in coordinate order. */
+ * committed in coordinate order (GD_E_UNSORTED); a negative position is
+ * GD_E_RANGE (a placed BAM record has POS >= 0). */
 int gd_commit(gd_ctx* ctx, const gd_batch* b, int32_t tid, size_t n_reads, size_t n_ops);
 
 /* Convenience: copy records from ordinary host memory (copies before
@@ -226,7 +227,7 @@ int gd_push(gd_ctx* ctx, int32_t tid, const int32_t* pos, const uint16_t* flag,
 /* Use records already resident in HBM (zero copy).  Replaces any records of
  * that contig.  The call waits for the device (whatever stream produced the
  * arrays), checks them the way gd_commit checks a host block -- positions in
- * coordinate order (GD_E_UNSORTED), CSR offsets non-decreasing from 0 and ending
+ * coordinate order (GD_E_UNSORTED) and not negative (GD_E_RANGE), CSR offsets non-decreasing from 0 and ending
  * inside the op array (GD_E_INVALID); one pass over pos / cigar_off -- and builds
  * the contig's canonical CIGARs from them right away. */
 int gd_adopt_device(gd_ctx* ctx, int32_t tid, const gd_batch* dev, size_t n_reads, size_t n_ops);

@@ -539,3 +539,42 @@ def test_adopted_device_records_are_checked():
         _adopt(eng, torch, 0, r)                                             # the well-formed arrays
         eng.compute()
         assert np.array_equal(eng.perbase(0), po.perbase_c(r, 1, 0, L))
+
+
+def test_negative_positions_are_refused_at_the_boundary():
+    """A placed BAM record has POS >= 0 (-1 means "no position"): gd_push / gd_commit and gd_adopt_device answer
+    GD_E_RANGE instead of counting from a position that does not exist; the same records without the bad one pass."""
+    import torch
+    from goleft_amd.engine import DepthEngine, GdError
+    L = 20000
+    rng = np.random.default_rng(1)
+    good = H.random_reads(rng, L, 500)
+    bad = po.Reads(np.concatenate([[-3], good.pos]).astype(np.int32), np.concatenate([[0], good.flag]).astype(np.uint16),
+                   np.concatenate([[60], good.mapq]).astype(np.uint8),
+                   np.concatenate([[0], good.cigar_off + 1]).astype(np.uint32),
+                   np.concatenate([[(10 << 4)], good.cigar]).astype(np.uint32))
+    dev = torch.device("cuda", 0)
+    t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a).view(dt)).to(dev)
+
+    def adopt(e, r):
+        e.adopt_device(0, t(r.pos, np.int32), t(r.flag, np.int16), t(r.mapq, np.uint8), t(r.cigar_off, np.int32),
+                       t(r.cigar, np.int32))
+
+    with DepthEngine(0) as e:
+        e.set_params(window_size=100, min_mapq=1, min_cov=1)
+        e.set_contigs([L])
+        with pytest.raises(GdError) as ei:
+            e.push(0, bad.pos, bad.flag, bad.mapq, bad.cigar_off, bad.cigar)
+        assert ei.value.status == -5
+        with pytest.raises(GdError) as ei:
+            adopt(e, bad)
+        assert ei.value.status == -5
+        want = po.perbase_c(good, 1, 0, L)
+        e.set_contigs([L])
+        e.push(0, good.pos, good.flag, good.mapq, good.cigar_off, good.cigar)
+        e.compute()
+        assert np.array_equal(e.perbase(0), want)
+        e.set_contigs([L])
+        adopt(e, good)
+        e.compute()
+        assert np.array_equal(e.perbase(0), want)
