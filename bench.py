@@ -7,10 +7,18 @@ decoded-record stream, 150 bp reads, hg19 contig lengths (3 095 677 412 bp).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload wgs|chr20]
 
-A step = one pass of the hot path (gd_compute: prep + tile + run-ordering
-kernels, synchronous) over the rank's HBM-resident record streams, plus, when
-ONE genome is shared by N > 1 GPUs, the gather of window sums/minima and run
-boundaries to rank 0 over RCCL (the only exchange the path has):
+A step = one pass of the hot path over the rank's HBM-resident record streams AS
+THEY CROSSED THE C ABI (pos / flag / MAPQ / CSR offsets / BAM-encoded CIGAR ops,
+nothing derived): gd_compute (prep + tile + run-ordering kernels, synchronous)
+-- the short-read tile kernel reads those records directly -- and, where the
+path needs derived structures (long reads: canonical CIGARs, deletion lists,
+tile indexes; the cohort's streaming sums: canonical records), their
+construction (gd_normalize(force)) INSIDE every step: what one `goleft depth`
+run pays per input.  "compute_only" in the line is the same step with the
+derived structures kept from step to step (what round 2 reported as `value`).
+When ONE genome is shared by N > 1 GPUs a step also holds the gather of window
+sums/minima and run boundaries to rank 0 over RCCL (the only exchange the path
+has):
 
   --scaling strong (default) BASELINE.json config 3: N GPUs share ONE 3.1 Gb
                    genome, contigs assigned by LPT (goleft_amd/shard.py), every
@@ -163,7 +171,7 @@ def run_case(args, scaling, world, rank, dev, local_rank, want_streams=False):
     import torch
     import torch.distributed as dist
     from goleft_amd import shard, synth
-    from goleft_amd.engine import DepthEngine, K_PREP, K_TILE, K_RUNS, K_EXPAND, K_SCAN, K_CKPT, K_NORM
+    from goleft_amd.engine import DepthEngine, K_PREP, K_TILE, K_RUNS, K_EXPAND, K_SCAN, K_CKPT, K_NORM, TK_NAMES
 
     ont = args.workload.startswith("ont")
     cohort = args.workload == "cohort"
@@ -218,7 +226,6 @@ def run_case(args, scaling, world, rank, dev, local_rank, want_streams=False):
         eng.set_outputs(perbase=False)     # experiment only (profiles/r01h): the tile kernel without its store stream
     eng.set_contigs(lengths)
     eng.select_contigs(mine)
-    eng.set_profiling(True)               # before the records arrive: the ingest-time normalisation is timed too
     n_reads = n_ops = 0
     streams = {}
     for t in mine:
@@ -237,9 +244,9 @@ def run_case(args, scaling, world, rank, dev, local_rank, want_streams=False):
         n_reads += n
         n_ops += int(s[4].shape[0])
     torch.cuda.synchronize()
-    norm_ms = eng.kernel_ms(K_NORM)       # ingest-time CIGAR normalisation of this rank's contigs (not part of a step)
-    ingest_ck_ms = eng.kernel_ms(K_CKPT)  # ingest-time CIGAR checkpoints of long-read contigs (not part of a step)
-    eng.set_profiling(False)              # the timed loop runs without kernel events (4 event records cost ~25 us a step)
+    # derived structures (canonical records, deletion lists, tile indexes) are part of EVERY step where the path
+    # needs them; the short-read tile path needs none
+    derive = ont or cohort
 
     wed = {}
     gath = None
@@ -247,12 +254,16 @@ def run_case(args, scaling, world, rank, dev, local_rank, want_streams=False):
         # set-up, outside the timed region: one compute to learn the boundary count, the ranks agree
         # on a fixed capacity, buffers are allocated once and the engine is told to fill the send
         # buffer itself (gd_set_export)
+        if derive:
+            eng.normalize(True)
         eng.compute()
         gath = shard.RootGather(assignment, lengths, W, rank, world, dev, bounds_cap=0)
         gath.reserve(eng.device_runs()[1])
         gath.attach(eng)
 
-    def step():
+    def step(inclusive=True):
+        if derive and inclusive:
+            eng.normalize(True)                     # rebuilt from the records as they arrived, every step
         eng.compute()
         if cohort:
             # the sites x samples matrix of this rank's samples, left in HBM for its consumer
@@ -272,10 +283,14 @@ def run_case(args, scaling, world, rank, dev, local_rank, want_streams=False):
         # nothing (compute_finish(k - 1) already did), re-points the export block and issues the (asynchronous)
         # gather of step k - 1.  Every step is still a complete compute + gather; all of them have landed before
         # the clock stops (drain + synchronize below).
+        if derive:
+            eng.normalize(True)
         eng.compute_launch()
         for _ in range(n - 1):
             eng.compute_finish()
             gath.flip()
+            if derive:
+                eng.normalize(True)
             eng.compute_launch()
             gath.post()
         eng.compute_finish()
@@ -297,9 +312,9 @@ def run_case(args, scaling, world, rank, dev, local_rank, want_streams=False):
         dist.barrier()
     dt = time.perf_counter() - t0
     # kernel durations (HIP events on the engine's stream): the same steps again, profiled, after the timed region
-    tile_ms, prep_ms, runs_ms, expand_ms, scan_ms, ckpt_ms = [], [], [], [], [], []
-    eng.set_profiling(True)
+    tile_ms, prep_ms, runs_ms, expand_ms, scan_ms, ckpt_ms, norm_ms = [], [], [], [], [], [], []
     for _ in range(args.steps):
+        eng.set_profiling(True)                     # (also clears the accumulating NORM / CKPT timers)
         step()
         tile_ms.append(eng.kernel_ms(K_TILE))
         prep_ms.append(eng.kernel_ms(K_PREP))
@@ -307,8 +322,46 @@ def run_case(args, scaling, world, rank, dev, local_rank, want_streams=False):
         expand_ms.append(eng.kernel_ms(K_EXPAND))
         scan_ms.append(eng.kernel_ms(K_SCAN))
         ckpt_ms.append(eng.kernel_ms(K_CKPT))
+        norm_ms.append(eng.kernel_ms(K_NORM))
     eng.set_profiling(False)
     torch.cuda.synchronize()
+    st_incl = eng.stats()
+    incl_kernel, incl_canon, incl_slow = int(st_incl.tile_kernel), int(st_incl.n_canonical_ops), int(st_incl.n_slow_tiles)
+
+    # ---- the same step with the derived structures KEPT from step to step (round 2's `value`) --------------
+    only = None
+    if world == 1:
+        eng.set_profiling(True)
+        t1 = time.perf_counter()
+        eng.normalize(True)                         # one batch: one allocation, one launch set, one synchronisation
+        torch.cuda.synchronize()
+        wall_first = time.perf_counter() - t1
+        eng.set_profiling(True)
+        t1 = time.perf_counter()
+        eng.normalize(True)                         # again, into the block it already holds
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t1
+        nk, ck = eng.kernel_ms(K_NORM), eng.kernel_ms(K_CKPT)
+        eng.set_profiling(False)
+        for _ in range(args.warmup):
+            step(False)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step(False)
+        torch.cuda.synchronize()
+        dt_only = time.perf_counter() - t1
+        k_only = []
+        eng.set_profiling(True)
+        for _ in range(args.steps):
+            step(False)
+            k_only.append(eng.kernel_ms(K_TILE) + eng.kernel_ms(K_EXPAND) + eng.kernel_ms(K_SCAN))
+        eng.set_profiling(False)
+        sto = eng.stats()
+        only = {"dt": dt_only, "tile_ms": float(np.mean(k_only)), "kernel": TK_NAMES[int(sto.tile_kernel)],
+                "n_canonical_ops": int(sto.n_canonical_ops), "normalise_wall_ms": wall * 1e3,
+                "normalise_wall_first_ms": wall_first * 1e3, "normalise_kernels_ms": nk, "checkpoint_kernels_ms": ck}
+
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -360,8 +413,8 @@ def run_case(args, scaling, world, rank, dev, local_rank, want_streams=False):
         "tile_ms": float(np.mean(tile_ms)), "prep_ms": float(np.mean(prep_ms)),
         "runs_ms": float(np.mean(runs_ms)), "tile_positions": st.tile_positions, "lookback": st.lookback,
         "expand_ms": float(np.mean(expand_ms)), "scan_ms": float(np.mean(scan_ms)), "path": int(st.path),
-        "ckpt_ms": float(np.mean(ckpt_ms)), "norm_ms": norm_ms, "ingest_ck_ms": ingest_ck_ms,
-        "n_canonical_ops": int(st.n_canonical_ops), "n_slow_tiles": int(st.n_slow_tiles),
+        "ckpt_ms": float(np.mean(ckpt_ms)), "norm_ms": float(np.mean(norm_ms)), "only": only, "derive": derive,
+        "n_canonical_ops": incl_canon, "n_slow_tiles": incl_slow, "kernel": TK_NAMES[incl_kernel],
         "perbase": not cohort, "wed_shape": wed.get("shape"), "split": split,
     }
     if not want_streams:
@@ -404,9 +457,11 @@ def main():
     # roofline of the dominant kernel, this rank's launch.  SURVEY.md 8(d): 4 B/read (pos) + 4 B/read (the record
     # word that stands where the CSR offset stood: flag | MAPQ | op count) + 4 B per CIGAR op the kernel reads (the
     # canonical ops on the tile and long-read paths) + 4 B/base + 8 B/window
+    # (the raw straight-line kernel reads flag 2 + MAPQ 1 per read too and the ops as they arrived)
     ops_read = r["n_canonical_ops"] if r["n_canonical_ops"] else r["n_ops"]
+    raw_records = r["kernel"] == "gd_tile_fast_kernel<raw>"
     alg_bytes = synth.algorithmic_bytes(r["n_reads"], ops_read, r["my_bases"] if r["perbase"] else 0,
-                                        r["my_windows"])   # windows-only: no 4 B/base write
+                                        r["my_windows"], raw=raw_records)   # windows-only: no 4 B/base write
     scatter = r["path"] == 2
     chunk = r["path"] == 3
     # tile path: gd_tile_kernel does all the arithmetic; chunk path: the long-read tile kernel (the CIGAR
@@ -416,11 +471,7 @@ def main():
     achieved = alg_bytes / avg_tile_s / 1e9
     traffic = None
     tr = None
-    fast = r["path"] == 1 and r["n_canonical_ops"] > 0 and args.workload != "cohort"
-    kname = ("gd_expand_scatter_kernel+gd_scan_kernel" if scatter else "gd_ltile2_kernel" if chunk else
-             "gd_sums_stream_kernel" if (args.workload == "cohort" and args.cohort_outputs == "sums" and "5=0" not in args.opt) else
-             "gd_tile_sums_kernel" if (args.workload == "cohort" and args.cohort_outputs == "sums") else
-             "gd_tile_fast_kernel" if fast else "gd_tile_kernel")
+    kname = r["kernel"]                             # gd_stats.tile_kernel: what did the per-base arithmetic
     if world == 1 and args.workload == "wgs" and args.coverage == 30.0 and r["path"] == 1:
         tr = load_traffic("wgs", kname)
     elif world == 1 and args.workload == "ont" and args.coverage == 20.0 and chunk:
@@ -464,8 +515,12 @@ def main():
                    "coverage": args.coverage, "window": W,
                    "min_mapq": Q, "min_cov": mincov, "total_ref_bases": r["total_bases"],
                    "reads_rank0": r["n_reads"], "cigar_ops_rank0": r["n_ops"],
-                   "canonical_cigar_ops_rank0": r["n_canonical_ops"], "ingest_checkpoint_ms_rank0": r["ingest_ck_ms"], "tiles_on_the_generic_kernel": r["n_slow_tiles"],
-                   "ingest_normalise_ms_rank0": r["norm_ms"],
+                   "canonical_cigar_ops_rank0": r["n_canonical_ops"], "tiles_on_the_generic_kernel": r["n_slow_tiles"],
+                   "step": ("gd_normalize(force) [canonical records" + (", deletion lists, tile indexes" if chunk else "") +
+                            " rebuilt from the records as they arrived] + gd_compute" if r["derive"] else
+                            "gd_compute on the records as they arrived (nothing derived exists)" if raw_records else
+                            "gd_compute") + (" + gd_depthwed_device" if args.workload == "cohort" else ""),
+                   "in_step_normalise_kernels_ms_rank0": r["norm_ms"], "in_step_checkpoint_kernels_ms_rank0": r["ckpt_ms"],
                    "sharding": ("single GPU" if world == 1 else
                                 "by sample (one genome per GPU, no exchange)" if args.scaling == "weak" else
                                 "by chromosome, LPT, RCCL gather of window sums/minima + class runs to rank 0"),
@@ -488,6 +543,28 @@ def main():
                        if chunk else {"prep": r["prep_ms"], "tile": r["tile_ms"], "runs": r["runs_ms"]}),
         "with_d2h_windows_ref_bases_per_s": r["my_bases"] / (dt / args.steps + d2h) if world == 1 else None,
     }
+    o = r["only"]
+    if o is not None:
+        # the step with the derived structures kept (round 2's headline), and what building them costs
+        ops_o = o["n_canonical_ops"] if o["n_canonical_ops"] else r["n_ops"]
+        alg_o = synth.algorithmic_bytes(r["n_reads"], ops_o, r["my_bases"] if r["perbase"] else 0, r["my_windows"],
+                                        raw=o["kernel"] == "gd_tile_fast_kernel<raw>")
+        out["compute_only"] = {
+            "value": r["total_bases"] * args.steps / o["dt"], "unit": "ref-bases/s", "ms_per_step": o["dt"] / args.steps * 1e3,
+            "what": "the same step with canonical records / long-read structures kept from step to step",
+            "roofline": {"bound": "hbm", "achieved": alg_o / (o["tile_ms"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": alg_o / (o["tile_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, "kernel": o["kernel"],
+                         "avg_kernel_ms": o["tile_ms"], "algorithmic_bytes_per_launch": alg_o}}
+        nb = synth.normalise_bytes(r["n_reads"], r["n_ops"], ops_o, r["my_bases"])
+        out["roofline_ingest"] = {
+            "what": "gd_normalize: canonical CIGARs + record words + position index of every contig, ONE batch "
+                    "(one allocation, one launch set, one synchronisation)",
+            "bound": "hbm", "achieved": nb / (o["normalise_kernels_ms"] * 1e-3) / 1e9 if o["normalise_kernels_ms"] else None,
+            "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": nb / (o["normalise_kernels_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS if o["normalise_kernels_ms"] else None,
+            "kernels_ms": o["normalise_kernels_ms"], "wall_ms": o["normalise_wall_ms"],
+            "wall_ms_first_call_with_allocation": o["normalise_wall_first_ms"],
+            "long_read_structures_kernels_ms": o["checkpoint_kernels_ms"], "algorithmic_bytes": nb}
     if world == 1 and args.workload != "cohort":
         from goleft_amd import shard as _sh
         # checksum of checksums: equals "split.gathered_sum_of_window_sums" of an N > 1 run of the same workload

@@ -32,7 +32,8 @@ class GdStats(C.Structure):
                 ("n_windows", C.c_uint64), ("n_tiles", C.c_uint64), ("n_runs", C.c_uint64),
                 ("tile_positions", C.c_int32), ("lookback", C.c_int32),
                 ("max_span_seen", C.c_int32), ("reruns", C.c_int32),
-                ("path", C.c_int32), ("n_slow_tiles", C.c_int32), ("n_canonical_ops", C.c_uint64)]
+                ("path", C.c_int32), ("n_slow_tiles", C.c_int32), ("n_canonical_ops", C.c_uint64),
+                ("tile_kernel", C.c_int32), ("reserved_", C.c_int32)]
 
 
 # every symbol include/goleft_depth.h declares: (restype, argtypes)
@@ -98,6 +99,8 @@ SYMBOLS = {
     "gd_window_offset": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "gd_device_runs": (C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_size_t)]),
     "gd_set_option": (C.c_int, [_P, C.c_int, C.c_int64]),
+    "gd_normalize": (C.c_int, [_P, C.c_int]),
+    "gd_drop_derived": (C.c_int, [_P]),
     "gd_canonical_cigars": (C.c_int, [_P, C.c_int32, _P, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
     "gd_set_export": (C.c_int, [_P, _P, C.c_int64, C.c_int64]),
     "gd_get_stats": (C.c_int, [_P, C.POINTER(GdStats)]),

@@ -129,6 +129,7 @@ void gd_destroy(gd_ctx* c)
     for (void* p : frees) if (p) (void)hipFree(p);
     if (c->h_counters) (void)hipHostFree(c->h_counters);
     if (c->h_bounds) (void)hipHostFree(c->h_bounds);
+    if (c->h_batch) (void)hipHostFree(c->h_batch);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     delete c;
@@ -403,9 +404,9 @@ int gd_adopt_device(gd_ctx* c, int32_t tid, const gd_batch* d, size_t n_reads, s
     h.n_reads = n_reads; h.n_ops = n_ops;
     h.adopted = true;
     c->computed = false;
-    // canonical CIGARs are part of taking the records in, not of gd_compute
+    // GD_OPT_NORMALIZE = 1: canonical records are built as part of taking the records in
     if (n_reads && wants_norm(c, n_reads, n_ops))
-        if (int r = norm_contig(c, h)) return r;
+        if (int r = norm_tids(c, std::vector<int32_t>{tid}, false, false)) return r;
     return GD_OK;
 }
 
@@ -488,7 +489,10 @@ int gd_set_option(gd_ctx* c, int option, int64_t value)
     if (!c) return GD_E_INVALID;
     switch (option) {
     case GD_OPT_NT_STORES: c->tile_opt = value ? 1 : 0; break;
-    case GD_OPT_NORMALIZE: c->normalize = value != 0; break;
+    case GD_OPT_NORMALIZE:
+        if (value < 0 || value > 2) return fail(c, GD_E_INVALID, "GD_OPT_NORMALIZE: 0, 1 or 2");
+        c->normalize = (int)value;
+        break;
     case GD_OPT_FAST_KERNEL: c->fast_kernel = value != 0; break;
     case GD_OPT_COPY_THREADS:
         if (value < 1 || value > 16) return fail(c, GD_E_INVALID, "copy threads: 1..16");

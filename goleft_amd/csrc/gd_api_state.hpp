@@ -4,6 +4,8 @@
 // only (one translation unit: the kernels of gd_kernels.hpp are not inline).
 #pragma once
 
+#include <memory>
+
 namespace {
 
 constexpr int kRingSlots = 3;
@@ -14,6 +16,16 @@ constexpr int kTileT = 4096;              // reference positions per tile, 256 t
                                            // positions and 512 threads were measured slower on every workload and retired)
 constexpr int kAutoLongSpan = 32768;      // GD_PATH_AUTO leaves the short-read tile path above this read span
 constexpr int kMaxSpan = 1 << 27;   // tile-relative byte offsets of the tile kernel stay in 32 bits
+
+// One device allocation shared by the derived arrays of a batch of contigs (canonical records, position
+// indexes, long-read structures): a batch is built with one hipMalloc and no per-contig host round trip; the
+// block goes back to HBM when the last contig that points into it drops its share.
+struct DevBlock {
+    void* p = nullptr;
+    size_t bytes = 0;
+    ~DevBlock() { if (p) (void)hipFree(p); }
+};
+typedef std::shared_ptr<DevBlock> BlockRef;
 
 struct ContigHost {
     int64_t length = 0;
@@ -27,16 +39,17 @@ struct ContigHost {
     size_t cap_reads = 0, cap_ops = 0;
     bool adopted = false;
     int32_t last_pos = -0x7fffffff;
-    // canonical CIGARs of the records (gd_normalize.hpp), always owned
+    // canonical CIGARs of the records (gd_normalize.hpp): slices of norm_blk
+    BlockRef norm_blk, ck_blk, pck_blk;
     uint32_t* noff = nullptr;          // n_reads + 1 CSR offsets into ncig
     uint32_t* ncig = nullptr;          // canonical ops (capacity n_ops)
-    uint32_t* nunit = nullptr;         // per 64-read unit: offset of its canonical ops; [n_units] = total, [n_units + 1] = status
     uint32_t* nrec = nullptr;          // record words (flag | MAPQ | op count), n_reads + 4 (the kernel loads 16 bytes per lane)
     bool rec_ok = false;               // every record fits its word: the straight-line kernel may run
     size_t n_nops = 0;                 // canonical ops
     bool normed = false;               // noff/ncig describe the current records
     uint32_t* pidx = nullptr;          // position index: pidx[k] = first read with pos >= 64 k, k = 0 .. (length >> 6) + 1
-    // long-read path (gd_chunk.hpp): deletion lists of the canonical CIGARs above, their checkpoints, read records
+    // long-read path (gd_chunk.hpp): deletion lists of the canonical CIGARs above, read records (slices of ck_blk), the
+    // tile indexes (a slice of pck_blk)
     uint4*    lrec = nullptr;          // n_reads + 2 long-read records {pos, end, list offset, deletions}; [n_reads + 1].x = the largest span
     uint32_t* lfq = nullptr;           // n_reads: flag << 8 | MAPQ
     uint2*    dl = nullptr;            // (canonical ops >> 1) + n_reads + 1 deletions {start, length}
@@ -91,7 +104,9 @@ struct ComputeState {
     std::vector<int32_t> tids;          // contigs of the job
     uint64_t n_reads = 0, n_ops = 0, n_units = 0, n_groups = 0;
     int64_t tile_beg = 0, base_off = 0, win_off = 0, bases = 0;
-    bool all_normed = true;
+    bool all_normed = true;             // every contig of the job has canonical records whose word fits
+    bool raw_aligned = true;            // ... arrays aligned for the raw straight-line kernel's vector loads
+    int32_t it_kernel = 0;              // GD_TK_*: the kernel of the attempt in flight
     int reruns = 0, used_lookback = 0;
     bool used_scatter = false, used_chunk = false;
     int32_t chunk_span = 0;
@@ -117,7 +132,10 @@ struct gd_ctx {
     // tuning knobs (gd_set_option; defaults are what the measurements of DESIGN.md section 4 chose)
     bool fast_kernel = true;            // GD_OPT_FAST_KERNEL: the straight-line tile kernel (gd_tile_fast.hpp) for
                                         // ordinary tiles, the generic one for the rest; 0 = generic for every tile
-    bool normalize = true;              // GD_OPT_NORMALIZE: canonical CIGARs at arrival (gd_normalize.hpp)
+    int normalize = 2;                  // GD_OPT_NORMALIZE: canonical records (gd_normalize.hpp) 0 never for the tile path,
+                                        // 1 when records arrive, 2 only for what needs them (long-read path, streaming sums)
+    std::vector<uint8_t> batch_tab, batch_tab_ck;   // host copies of the job tables of the last norm_batch / ck batch
+    uint32_t* h_batch = nullptr; size_t cap_h_batch = 0;   // pinned: per-contig totals / status words coming back
     int tile_opt = 1;                   // bit 0: non-temporal per-base stores (2 % faster: the vector is
                                         // never re-read by the kernel)
     bool lookback_pinned = false;       // max_span_hint given: never shrink below it
@@ -241,10 +259,8 @@ int ensure_dev(gd_ctx* c, Tp** p, size_t* cap, size_t need, bool keep = false, s
 
 void drop_ck(ContigHost& h)
 {
-    if (h.lrec) (void)hipFree(h.lrec);
-    if (h.lfq) (void)hipFree(h.lfq);
-    if (h.dl) (void)hipFree(h.dl);
-    if (h.pck) (void)hipFree(h.pck);
+    h.ck_blk.reset();                  // (hipFree of the block, when this was its last user, waits for the device)
+    h.pck_blk.reset();
     h.lrec = nullptr; h.lfq = nullptr; h.dl = nullptr; h.pck = nullptr;
     h.max_span = 0;
     h.ck_ok = false;
@@ -253,12 +269,8 @@ void drop_ck(ContigHost& h)
 void drop_norm(ContigHost& h)
 {
     drop_ck(h);                        // built from the canonical arrays
-    if (h.noff) (void)hipFree(h.noff);
-    if (h.ncig) (void)hipFree(h.ncig);
-    if (h.nunit) (void)hipFree(h.nunit);
-    if (h.nrec) (void)hipFree(h.nrec);
-    if (h.pidx) (void)hipFree(h.pidx);
-    h.noff = nullptr; h.ncig = nullptr; h.nunit = nullptr; h.nrec = nullptr; h.pidx = nullptr;
+    h.norm_blk.reset();
+    h.noff = nullptr; h.ncig = nullptr; h.nrec = nullptr; h.pidx = nullptr;
     h.rec_ok = false;
     h.n_nops = 0;
     h.normed = false;
@@ -345,6 +357,15 @@ void launch_tile(gd_ctx* c, const gd::Job& job)
             hipLaunchKernelGGL((gd::gd_tile_slow_kernel<4096, 256, 1>), dim3(sgrid), dim3(256), 0, c->stream, job);
         else
             hipLaunchKernelGGL((gd::gd_tile_slow_kernel<4096, 256, 0>), dim3(sgrid), dim3(256), 0, c->stream, job);
+        if (job.fast == 2u) {                                // the records as they arrived
+            if (!c->keep_perbase)
+                hipLaunchKernelGGL((gd::fast::gd_tile_fast_kernel<2, true>), dim3(grid), dim3(256), 0, c->stream, job);
+            else if (c->tile_opt & 1)
+                hipLaunchKernelGGL((gd::fast::gd_tile_fast_kernel<1, true>), dim3(grid), dim3(256), 0, c->stream, job);
+            else
+                hipLaunchKernelGGL((gd::fast::gd_tile_fast_kernel<0, true>), dim3(grid), dim3(256), 0, c->stream, job);
+            return;
+        }
         if (!c->keep_perbase)
             hipLaunchKernelGGL((gd::fast::gd_tile_fast_kernel<2>), dim3(grid), dim3(256), 0, c->stream, job);
         else if (c->tile_opt & 1)
@@ -386,116 +407,306 @@ int launch_scan(gd_ctx* c, uint32_t* v, uint32_t n)
     return GD_OK;
 }
 
-// Long-read path: deletion lists, their checkpoints and the read records of one contig (gd_dels_kernel), from
-// its canonical CIGARs.  Part of taking the records in (or of the first gd_compute that needs them), kept until
-// the records change.
-int build_ck(gd_ctx* c, ContigHost& h)
+// ---- derived record arrays, built per BATCH of contigs ----------------------------------------------------
+// Bump allocation inside one DevBlock: every array starts on a 256-byte boundary.
+struct Carve {
+    size_t at = 0;
+    size_t take(size_t bytes) { const size_t o = at; at += (bytes + 255) & ~(size_t)255; return o; }
+};
+
+// A block of at least `need` bytes: `keep` (what the batch's contigs held before) when nobody else uses it and it
+// is large enough -- a re-normalisation of the same contigs allocates nothing -- else a new allocation.
+int batch_block(gd_ctx* c, BlockRef keep, size_t need, BlockRef* out)
 {
-    drop_ck(h);
-    if (!h.normed) return fail(c, GD_E_STATE, "long-read path: the contig has no canonical CIGARs (internal error)");
-    const uint32_t n_reads = (uint32_t)h.n_reads, n_units = (n_reads + 63u) / 64u;
-    const size_t n_dl = (h.n_nops >> 1) + (size_t)n_reads + 1;
-    if (n_dl > 0xffffffffull) return fail(c, GD_E_RANGE, "too many deletions on one contig");
-    HIPCHK(c, hipEventRecord(c->copy_done, c->copy_stream));
-    HIPCHK(c, hipStreamWaitEvent(c->stream, c->copy_done, 0));
-    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&h.lrec), ((size_t)n_reads + 2) * sizeof(uint4)));
-    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&h.lfq), ((size_t)n_reads + 1) * sizeof(uint32_t)));
-    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&h.dl), n_dl * sizeof(uint2)));
-    HIPCHK(c, hipMemsetAsync(h.lrec + n_reads, 0, 2 * sizeof(uint4), c->stream));
-    gd::DelJob j{};
-    j.pos = h.pos; j.off = h.noff; j.cigar = h.ncig; j.flag = h.flag; j.mapq = h.mapq;
-    j.n_reads = n_reads; j.n_units = n_units;
-    j.lrec = h.lrec; j.lfq = h.lfq; j.dl = h.dl;
-    j.max_span = reinterpret_cast<int32_t*>(h.lrec + n_reads + 1);
-    if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
-    // the tile index: entries per read -> offsets (one scan over the 64-read units) -> filled
-    uint32_t* unit = nullptr;
-    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&unit), ((size_t)n_units + 2) * sizeof(uint32_t)));
-    struct UnitGuard { uint32_t* p; ~UnitGuard() { if (p) (void)hipFree(p); } } unit_guard{unit};
-    HIPCHK(c, hipMemsetAsync(unit + n_units, 0, 2 * sizeof(uint32_t), c->stream));
-    gd::PtJob pj{};
-    pj.noff = h.noff; pj.lrec = h.lrec; pj.dl = h.dl; pj.n_reads = n_reads; pj.n_units = n_units; pj.unit = unit;
-    uint32_t n_pck = 0;
-    if (n_units) {
-        hipLaunchKernelGGL(gd::gd_dels_kernel, dim3((n_units + 3u) / 4u), dim3(256), 0, c->stream, j);
-        hipLaunchKernelGGL(gd::gd_ptile_count_kernel, dim3((n_units + 3u) / 4u), dim3(256), 0, c->stream, pj);
-        if (int r = launch_scan(c, unit, n_units)) return r;
-        HIPCHK(c, hipMemcpyAsync(&n_pck, unit + n_units, sizeof n_pck, hipMemcpyDeviceToHost, c->stream));
-    }
-    int32_t span = 0;
-    HIPCHK(c, hipMemcpyAsync(&span, h.lrec + n_reads + 1, sizeof span, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipStreamSynchronize(c->stream));              // the index is allocated at its exact size
-    // its 32-bit offsets cannot have wrapped if even this bound fits
-    if ((uint64_t)n_reads * (((uint64_t)(uint32_t)span >> gd::PT_SHIFT) + 2) > 0xffffffffull)
-        return fail(c, GD_E_RANGE, "long-read path: %u reads spanning up to %d bases -- the tile index would not fit 2^32 entries",
-                    n_reads, span);
-    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&h.pck), ((size_t)n_pck + 1) * sizeof(uint32_t)));
-    pj.pck = h.pck;
-    if (n_reads)
-        hipLaunchKernelGGL(gd::gd_ptile_fill_kernel, dim3((n_reads + 255u) / 256u), dim3(256), 0, c->stream, pj);
-    HIPCHK(c, hipGetLastError());
-    if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (c->profiling) {
-        float ms = 0;
-        HIPCHK(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
-        c->kernel_ms[GD_K_CKPT] += ms;
-    }
-    h.max_span = span;
-    h.ck_ok = true;
+    if (keep && keep.use_count() == 1 && keep->bytes >= need) { *out = std::move(keep); return GD_OK; }
+    keep.reset();
+    BlockRef b = std::make_shared<DevBlock>();
+    HIPCHK(c, hipMalloc(&b->p, need ? need : 1));
+    b->bytes = need ? need : 1;
+    *out = std::move(b);
     return GD_OK;
 }
 
-// Builds the canonical CIGARs of one contig's records (gd_normalize.hpp) and its position index on the compute
-// stream; long-read shaped contigs also get their checkpoints (build_ck).  Afterwards h.normed is set.
-int norm_contig(gd_ctx* c, ContigHost& h)
+int batch_host(gd_ctx* c, size_t words)
 {
-    drop_norm(h);
-    const uint32_t n_reads = (uint32_t)h.n_reads, n_units = (n_reads + 63u) / 64u;
+    if (words <= c->cap_h_batch && c->h_batch) return GD_OK;
+    if (c->h_batch) { (void)hipHostFree(c->h_batch); c->h_batch = nullptr; c->cap_h_batch = 0; }
+    const size_t cap = std::max<size_t>(words, 256);
+    HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_batch), cap * sizeof(uint32_t), hipHostMallocDefault));
+    c->cap_h_batch = cap;
+    return GD_OK;
+}
+
+// Long-read path: deletion lists, read records and tile indexes (gd_chunk.hpp) of a batch of contigs, from their
+// canonical CIGARs.  With `enqueue_only_before` (the caller is norm_batch, whose kernels are still in flight and whose
+// totals are not known yet) the lists are sized from the ORIGINAL op counts.  One host synchronisation for the sizes
+// of the tile indexes, one allocation for all of them.
+struct CkPending {
+    std::vector<ContigHost*> hs;
+    BlockRef blk;
+    size_t o_jobs = 0, o_tot = 0, o_span = 0;
+    std::vector<size_t> o_lrec, o_lfq, o_dl, o_unit;
+    uint32_t n_units = 0;
+    gd::DelBatch B{};
+};
+
+int ck_enqueue(gd_ctx* c, const std::vector<ContigHost*>& hs, bool ops_known, CkPending* P)
+{
+    P->hs = hs;
+    const size_t nj = hs.size();
+    if (nj == 0) return GD_OK;
+    BlockRef keep = hs[0]->ck_blk;
+    for (ContigHost* h : hs) drop_ck(*h);
+    Carve cv;
+    uint64_t units = 0;
+    P->o_lrec.resize(nj); P->o_lfq.resize(nj); P->o_dl.resize(nj); P->o_unit.resize(nj);
+    for (size_t k = 0; k < nj; ++k) {
+        const ContigHost& h = *hs[k];
+        const size_t n = h.n_reads;
+        const size_t n_dl = ((ops_known ? h.n_nops : h.n_ops) >> 1) + n + 1;
+        if (n_dl > 0xffffffffull) return fail(c, GD_E_RANGE, "too many deletions on one contig");
+        P->o_lrec[k] = cv.take((n + 2) * sizeof(uint4));
+        P->o_lfq[k] = cv.take((n + 1) * sizeof(uint32_t));
+        P->o_dl[k] = cv.take(n_dl * sizeof(uint2));
+        units += (n + 63) / 64;
+    }
+    if (units > 0xfffffff0ull) return fail(c, GD_E_RANGE, "too many records");
+    P->n_units = (uint32_t)units;
+    const size_t o_unit = cv.take((units + 2) * sizeof(uint32_t));
+    P->o_jobs = cv.take(nj * sizeof(gd::DelJob) + (nj + 1) * sizeof(uint32_t));   // the jobs, then ubeg
+    P->o_tot = cv.take(nj * sizeof(uint32_t));
+    if (int r = batch_block(c, std::move(keep), cv.at, &P->blk)) return r;
+    char* const base = static_cast<char*>(P->blk->p);
+    // job table (host copy kept in the context until the next batch)
+    c->batch_tab_ck.assign(nj * sizeof(gd::DelJob) + (nj + 1) * sizeof(uint32_t), 0);
+    gd::DelJob* jobs = reinterpret_cast<gd::DelJob*>(c->batch_tab_ck.data());
+    uint32_t* ubeg = reinterpret_cast<uint32_t*>(c->batch_tab_ck.data() + nj * sizeof(gd::DelJob));
+    uint32_t u = 0;
+    for (size_t k = 0; k < nj; ++k) {
+        ContigHost& h = *hs[k];
+        const uint32_t n = (uint32_t)h.n_reads, nu = (n + 63u) / 64u;
+        gd::DelJob& j = jobs[k];
+        j.pos = h.pos; j.off = h.noff; j.cigar = h.ncig; j.flag = h.flag; j.mapq = h.mapq;
+        j.n_reads = n; j.n_units = nu;
+        j.lrec = reinterpret_cast<uint4*>(base + P->o_lrec[k]);
+        j.lfq = reinterpret_cast<uint32_t*>(base + P->o_lfq[k]);
+        j.dl = reinterpret_cast<uint2*>(base + P->o_dl[k]);
+        j.max_span = reinterpret_cast<int32_t*>(j.lrec + n + 1);
+        j.unit = reinterpret_cast<uint32_t*>(base + o_unit) + u;
+        j.pck = nullptr;
+        j.total = reinterpret_cast<uint32_t*>(base + P->o_tot) + k;
+        ubeg[k] = u;
+        u += nu;
+    }
+    ubeg[nj] = u;
+    HIPCHK(c, hipMemcpyAsync(base + P->o_jobs, c->batch_tab_ck.data(), c->batch_tab_ck.size(), hipMemcpyHostToDevice, c->stream));
+    static_assert(sizeof(gd::DelJob) % 8 == 0, "the ubeg table follows the jobs");
+    gd::DelBatch& B = P->B;
+    B.jobs = reinterpret_cast<const gd::DelJob*>(base + P->o_jobs);
+    B.ubeg = reinterpret_cast<const uint32_t*>(base + P->o_jobs + nj * sizeof(gd::DelJob));
+    B.n_jobs = (uint32_t)nj; B.n_units = P->n_units;
+    for (size_t k = 0; k < nj; ++k)                          // lrec[n], lrec[n + 1] (the span accumulator)
+        HIPCHK(c, hipMemsetAsync(base + P->o_lrec[k] + hs[k]->n_reads * sizeof(uint4), 0, 2 * sizeof(uint4), c->stream));
+    if (P->n_units) {
+        const unsigned grid = (P->n_units + 3u) / 4u;
+        hipLaunchKernelGGL(gd::gd_dels_kernel, dim3(grid), dim3(256), 0, c->stream, B);
+        hipLaunchKernelGGL(gd::gd_ptile_count_kernel, dim3(grid), dim3(256), 0, c->stream, B);
+        if (int r = launch_scan(c, reinterpret_cast<uint32_t*>(base + o_unit), P->n_units)) return r;
+    } else {
+        HIPCHK(c, hipMemsetAsync(base + o_unit, 0, 2 * sizeof(uint32_t), c->stream));
+    }
+    hipLaunchKernelGGL(gd::gd_ptile_totals_kernel, dim3((unsigned)((nj + 255) / 256)), dim3(256), 0, c->stream, B);
+    HIPCHK(c, hipGetLastError());
+    return GD_OK;
+}
+
+// host words the totals of a ck batch take in gd_ctx::h_batch: [n_jobs totals][n_jobs spans]
+int ck_readback(gd_ctx* c, const CkPending& P, uint32_t* dst)
+{
+    const size_t nj = P.hs.size();
+    if (nj == 0) return GD_OK;
+    char* const base = static_cast<char*>(P.blk->p);
+    HIPCHK(c, hipMemcpyAsync(dst, base + P.o_tot, nj * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    for (size_t k = 0; k < nj; ++k)
+        HIPCHK(c, hipMemcpyAsync(dst + nj + k, base + P.o_lrec[k] + (P.hs[k]->n_reads + 1) * sizeof(uint4), sizeof(uint32_t),
+                                 hipMemcpyDeviceToHost, c->stream));
+    return GD_OK;
+}
+
+// after the synchronisation: allocate the tile indexes, fill them, publish
+int ck_finish(gd_ctx* c, CkPending& P, const uint32_t* tot)
+{
+    const size_t nj = P.hs.size();
+    if (nj == 0) return GD_OK;
+    char* const base = static_cast<char*>(P.blk->p);
+    Carve cv;
+    std::vector<size_t> o_pck(nj);
+    for (size_t k = 0; k < nj; ++k) {
+        const int32_t span = (int32_t)tot[nj + k];
+        // the index's 32-bit offsets cannot have wrapped if even this bound fits
+        if ((uint64_t)P.hs[k]->n_reads * (((uint64_t)(uint32_t)span >> gd::PT_SHIFT) + 2) > 0xffffffffull)
+            return fail(c, GD_E_RANGE, "long-read path: %zu reads spanning up to %d bases -- the tile index would not fit 2^32 entries",
+                        P.hs[k]->n_reads, span);
+        o_pck[k] = cv.take(((size_t)tot[k] + 1) * sizeof(uint32_t));
+    }
+    BlockRef pck;
+    if (int r = batch_block(c, BlockRef(), cv.at, &pck)) return r;
+    gd::DelJob* jobs = reinterpret_cast<gd::DelJob*>(c->batch_tab_ck.data());
+    for (size_t k = 0; k < nj; ++k) jobs[k].pck = reinterpret_cast<uint32_t*>(static_cast<char*>(pck->p) + o_pck[k]);
+    HIPCHK(c, hipMemcpyAsync(base + P.o_jobs, c->batch_tab_ck.data(), nj * sizeof(gd::DelJob), hipMemcpyHostToDevice, c->stream));
+    if (P.n_units)
+        hipLaunchKernelGGL(gd::gd_ptile_fill_kernel, dim3((P.n_units + 3u) / 4u), dim3(256), 0, c->stream, P.B);
+    HIPCHK(c, hipGetLastError());
+    for (size_t k = 0; k < nj; ++k) {
+        ContigHost& h = *P.hs[k];
+        h.ck_blk = P.blk; h.pck_blk = pck;
+        h.lrec = jobs[k].lrec; h.lfq = jobs[k].lfq; h.dl = jobs[k].dl; h.pck = jobs[k].pck;
+        h.max_span = (int32_t)tot[nj + k];
+        h.ck_ok = true;
+    }
+    return GD_OK;
+}
+
+// Builds the long-read structures of contigs whose canonical CIGARs exist already.
+int ck_batch(gd_ctx* c, const std::vector<ContigHost*>& hs)
+{
+    if (hs.empty()) return GD_OK;
+    for (const ContigHost* h : hs)
+        if (!h->normed) return fail(c, GD_E_STATE, "long-read path: a contig has no canonical CIGARs (internal error)");
+    HIPCHK(c, hipEventRecord(c->copy_done, c->copy_stream));
+    HIPCHK(c, hipStreamWaitEvent(c->stream, c->copy_done, 0));
+    if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[6], c->stream));
+    CkPending P;
+    if (int r = ck_enqueue(c, hs, true, &P)) return r;
+    if (int r = batch_host(c, 2 * hs.size())) return r;
+    if (int r = ck_readback(c, P, c->h_batch)) return r;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (int r = ck_finish(c, P, c->h_batch)) return r;
+    if (c->profiling) {
+        HIPCHK(c, hipEventRecord(c->ev[7], c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        float ms = 0;
+        HIPCHK(c, hipEventElapsedTime(&ms, c->ev[6], c->ev[7]));
+        c->kernel_ms[GD_K_CKPT] += ms;
+    }
+    return GD_OK;
+}
+
+// Builds the canonical CIGARs, record words and position indexes (gd_normalize.hpp) of a batch of contigs on the
+// compute stream: one allocation, one launch set, one host synchronisation.  Contigs listed in `with_ck` (a subset)
+// also get their long-read structures, enqueued behind the same kernels.  Afterwards h.normed is set.
+int norm_batch(gd_ctx* c, const std::vector<ContigHost*>& hs, const std::vector<ContigHost*>& with_ck)
+{
+    const size_t nj = hs.size();
+    if (nj == 0) return ck_batch(c, with_ck);
+    BlockRef keep = hs[0]->norm_blk;
+    for (ContigHost* h : hs) drop_norm(*h);
+    Carve cv;
+    std::vector<size_t> o_noff(nj), o_nrec(nj), o_ncig(nj), o_pidx(nj);
+    uint64_t units = 0, idxs = 0;
+    for (size_t k = 0; k < nj; ++k) {
+        const ContigHost& h = *hs[k];
+        const size_t n = h.n_reads;
+        o_noff[k] = cv.take((n + 1) * sizeof(uint32_t));
+        o_nrec[k] = cv.take((n + 4) * sizeof(uint32_t));
+        o_ncig[k] = cv.take(std::max<size_t>(h.n_ops, 1) * sizeof(uint32_t));
+        o_pidx[k] = cv.take(((size_t)(h.length >> 6) + 2) * sizeof(uint32_t));
+        units += (n + 63) / 64;
+        idxs += (uint64_t)(h.length >> 6) + 2;
+    }
+    if (units > 0xfffffff0ull) return fail(c, GD_E_RANGE, "too many records");
+    if (idxs > 0xfffffff0ull) return fail(c, GD_E_RANGE, "the contigs of one batch are too long for one position-index launch");
+    const size_t o_unit = cv.take((units + 2) * sizeof(uint32_t));
+    const size_t tab_bytes = nj * sizeof(gd::norm::NormJob) + 2 * (nj + 1) * sizeof(uint32_t);
+    const size_t o_tab = cv.take(tab_bytes);
+    const size_t o_out = cv.take(2 * nj * sizeof(uint32_t));             // [totals][status words]
+    BlockRef blk;
+    if (int r = batch_block(c, std::move(keep), cv.at, &blk)) return r;
+    char* const base = static_cast<char*>(blk->p);
+    static_assert(sizeof(gd::norm::NormJob) % 8 == 0, "the ubeg / ibeg tables follow the jobs");
+    c->batch_tab.assign(tab_bytes, 0);
+    gd::norm::NormJob* jobs = reinterpret_cast<gd::norm::NormJob*>(c->batch_tab.data());
+    uint32_t* ubeg = reinterpret_cast<uint32_t*>(c->batch_tab.data() + nj * sizeof(gd::norm::NormJob));
+    uint32_t* ibeg = ubeg + nj + 1;
+    uint32_t u = 0, ix = 0;
+    for (size_t k = 0; k < nj; ++k) {
+        const ContigHost& h = *hs[k];
+        const uint32_t n = (uint32_t)h.n_reads, nu = (n + 63u) / 64u;
+        gd::norm::NormJob& j = jobs[k];
+        j.pos = h.pos;
+        j.pidx = reinterpret_cast<uint32_t*>(base + o_pidx[k]);
+        j.n_idx = (uint32_t)(h.length >> 6) + 2u;
+        j.off = h.off; j.cigar = h.cigar; j.flag = h.flag; j.mapq = h.mapq;
+        j.rec = reinterpret_cast<uint32_t*>(base + o_nrec[k]);
+        j.status = reinterpret_cast<uint32_t*>(base + o_out) + nj + k;
+        j.n_reads = n; j.n_units = nu;
+        j.noff = reinterpret_cast<uint32_t*>(base + o_noff[k]);
+        j.unit = reinterpret_cast<uint32_t*>(base + o_unit) + u;
+        j.ncig = reinterpret_cast<uint32_t*>(base + o_ncig[k]);
+        j.total = reinterpret_cast<uint32_t*>(base + o_out) + k;
+        ubeg[k] = u; ibeg[k] = ix;
+        u += nu; ix += j.n_idx;
+    }
+    ubeg[nj] = u; ibeg[nj] = ix;
+    gd::norm::NormBatch B{};
+    B.jobs = reinterpret_cast<const gd::norm::NormJob*>(base + o_tab);
+    B.ubeg = reinterpret_cast<const uint32_t*>(base + o_tab + nj * sizeof(gd::norm::NormJob));
+    B.ibeg = B.ubeg + nj + 1;
+    B.n_jobs = (uint32_t)nj; B.n_units = u; B.n_idx = ix;
     // records staged on the copy stream must have landed
     HIPCHK(c, hipEventRecord(c->copy_done, c->copy_stream));
     HIPCHK(c, hipStreamWaitEvent(c->stream, c->copy_done, 0));
-    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&h.noff), ((size_t)n_reads + 1) * sizeof(uint32_t)));
-    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&h.nunit), ((size_t)n_units + 2) * sizeof(uint32_t)));
-    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&h.nrec), ((size_t)n_reads + 4) * sizeof(uint32_t)));
-    HIPCHK(c, hipMemsetAsync(h.noff + n_reads, 0, sizeof(uint32_t), c->stream));         // n_reads == 0: noff[0] = 0
-    HIPCHK(c, hipMemsetAsync(h.nunit + n_units, 0, 2 * sizeof(uint32_t), c->stream));
-    HIPCHK(c, hipMemsetAsync(h.nrec + n_reads, 0, 4 * sizeof(uint32_t), c->stream));
-    const uint32_t n_idx = (uint32_t)(h.length >> 6) + 2u;
-    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&h.pidx), (size_t)n_idx * sizeof(uint32_t)));
-    gd::norm::NormJob j{};
-    j.off = h.off; j.cigar = h.cigar; j.n_reads = n_reads; j.n_units = n_units;
-    j.noff = h.noff; j.unit = h.nunit; j.ncig = nullptr;
-    j.flag = h.flag; j.mapq = h.mapq; j.rec = h.nrec; j.status = h.nunit + n_units + 1;
-    uint32_t total[2] = {0, 0};                              // canonical ops, status bits
-    if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
-    if (n_units) {
-        hipLaunchKernelGGL(gd::norm::gd_norm_count_kernel, dim3((n_units + 3u) / 4u), dim3(256), 0, c->stream, j);
-        if (int r = launch_scan(c, h.nunit, n_units)) return r;
-        HIPCHK(c, hipMemcpyAsync(total, h.nunit + n_units, sizeof total, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(base + o_tab, c->batch_tab.data(), tab_bytes, hipMemcpyHostToDevice, c->stream));
+    if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[5], c->stream));
+    hipLaunchKernelGGL(gd::norm::gd_norm_init_kernel, dim3((unsigned)((nj + 255) / 256)), dim3(256), 0, c->stream, B);
+    if (u) {
+        hipLaunchKernelGGL(gd::norm::gd_norm_count_kernel, dim3((u + 3u) / 4u), dim3(256), 0, c->stream, B);
+        if (int r = launch_scan(c, reinterpret_cast<uint32_t*>(base + o_unit), u)) return r;
+        hipLaunchKernelGGL(gd::norm::gd_norm_write_kernel, dim3((u + 3u) / 4u), dim3(256), 0, c->stream, B);
     }
-    hipLaunchKernelGGL(gd::norm::gd_pidx_kernel, dim3((n_idx + 255u) / 256u), dim3(256), 0, c->stream,
-                       h.pos, n_reads, h.pidx, n_idx);                                // no reads: all zero
+    hipLaunchKernelGGL(gd::norm::gd_pidx_kernel, dim3((ix + 255u) / 256u), dim3(256), 0, c->stream, B);
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipStreamSynchronize(c->stream));              // the canonical array is allocated at its exact size
-    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&h.ncig), std::max<size_t>(total[0], 1) * sizeof(uint32_t)));
-    j.ncig = h.ncig;
-    if (n_units)
-        hipLaunchKernelGGL(gd::norm::gd_norm_write_kernel, dim3((n_units + 3u) / 4u), dim3(256), 0, c->stream, j);
-    HIPCHK(c, hipGetLastError());
-    if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[6], c->stream));
+    // publish the pointers now: the long-read structures are enqueued from them
+    for (size_t k = 0; k < nj; ++k) {
+        ContigHost& h = *hs[k];
+        h.norm_blk = blk;
+        h.noff = jobs[k].noff; h.ncig = jobs[k].ncig; h.nrec = jobs[k].rec; h.pidx = jobs[k].pidx;
+    }
+    CkPending P;
+    const size_t nck = with_ck.size();
+    if (int r = batch_host(c, 2 * nj + 2 * nck)) return r;
+    HIPCHK(c, hipMemcpyAsync(c->h_batch, base + o_out, 2 * nj * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    int rc = GD_OK;
+    if (nck) {
+        rc = ck_enqueue(c, with_ck, false, &P);
+        if (rc == GD_OK) rc = ck_readback(c, P, c->h_batch + 2 * nj);
+    }
+    hipError_t se = hipStreamSynchronize(c->stream);           // ONE wait: totals and status words (and the index sizes)
+    if (se != hipSuccess || rc != GD_OK) {
+        for (ContigHost* h : hs) drop_norm(*h);
+        if (rc != GD_OK) return rc;
+        return fail(c, GD_E_HIP, "normalisation failed: %s", hipGetErrorString(se));
+    }
+    for (size_t k = 0; k < nj; ++k) {
+        ContigHost& h = *hs[k];
+        h.n_nops = c->h_batch[k];
+        h.rec_ok = c->h_batch[nj + k] == 0;
+        h.normed = true;
+    }
+    if (nck)
+        if (int r = ck_finish(c, P, c->h_batch + 2 * nj)) return r;
     if (c->profiling) {
+        HIPCHK(c, hipEventRecord(c->ev[7], c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
         float ms = 0;
-        HIPCHK(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
+        HIPCHK(c, hipEventElapsedTime(&ms, c->ev[5], c->ev[6]));
         c->kernel_ms[GD_K_NORM] += ms;
+        if (nck) {
+            HIPCHK(c, hipEventElapsedTime(&ms, c->ev[6], c->ev[7]));
+            c->kernel_ms[GD_K_CKPT] += ms;
+        }
     }
-    h.n_nops = total[0];
-    h.rec_ok = total[1] == 0;
-    h.normed = true;
-    if (h.n_ops > 6 * h.n_reads)                             // what GD_PATH_AUTO sends to the long-read path
-        if (int r = build_ck(c, h)) return r;
     return GD_OK;
 }
 
@@ -503,7 +714,36 @@ int norm_contig(gd_ctx* c, ContigHost& h)
 // an independent cross-check of the normalisation).
 bool wants_norm(const gd_ctx* c, uint64_t, uint64_t)
 {
-    return c->normalize && c->path != GD_PATH_SCATTER;
+    return c->normalize == 1 && c->path != GD_PATH_SCATTER;     // (mode 2: gd_compute builds what its path needs)
+}
+
+// What GD_PATH_AUTO sends to the long-read path (contig-wise: its structures are built with the canonical records).
+bool long_shaped(const gd_ctx* c, const ContigHost& h)
+{
+    return c->path == GD_PATH_CHUNK || (c->path == GD_PATH_AUTO && (c->span_forces_long || h.n_ops > 6 * h.n_reads));
+}
+
+// Normalises the listed contigs that need it (all of them with `force`), long-read shaped ones with their
+// deletion lists and tile indexes.
+int norm_tids(gd_ctx* c, const std::vector<int32_t>& tids, bool force, bool ck_all)
+{
+    std::vector<ContigHost*> hs, ck;
+    for (int32_t tid : tids) {
+        ContigHost& h = c->contigs[tid];
+        if (h.length <= 0) continue;
+        const bool wants_ck = ck_all || long_shaped(c, h);
+        if (force || !h.normed) { hs.push_back(&h); if (wants_ck) ck.push_back(&h); }
+        else if (wants_ck && !h.ck_ok) ck.push_back(&h);
+    }
+    if (hs.empty() && ck.empty()) return GD_OK;
+    if (!hs.empty()) {
+        // contigs normalised earlier that only lack the long-read structures go in a batch of their own
+        std::vector<ContigHost*> ck_new, ck_old;
+        for (ContigHost* h : ck) (std::find(hs.begin(), hs.end(), h) != hs.end() ? ck_new : ck_old).push_back(h);
+        if (int r = norm_batch(c, hs, ck_new)) return r;
+        return ck_batch(c, ck_old);
+    }
+    return ck_batch(c, ck);
 }
 
 // RAII for the scratch device buffers of gd_ingest_bgzf

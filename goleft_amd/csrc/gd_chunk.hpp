@@ -74,14 +74,30 @@ struct DelJob {
     uint32_t* lfq;            // n_reads: flag << 8 | MAPQ (the filter is applied per tile)
     uint2*    dl;             // deletion lists {start, length}: (n_ops >> 1) + n_reads + 1 entries
     int32_t*  max_span;       // atomicMax of end - pos
+    // the tile index (PT kernels below)
+    uint32_t* unit;           // this contig's slice of the batch's unit array: n_units + 1 entries per 64-read unit, then
+                              // (after the scan) exclusive offsets over the batch: unit[k] - unit[0] is the contig's own
+    uint32_t* pck;            // the index
+    uint32_t* total;          // out: its entries
 };
 constexpr uint32_t PT_NONE = 0xffffffffu;
 
-__global__ __launch_bounds__(256) void gd_dels_kernel(DelJob job)
+// The long-read contigs of one batch: job j owns the 64-read units [ubeg[j], ubeg[j + 1]) of the batch.
+struct DelBatch {
+    const DelJob*   jobs;
+    const uint32_t* ubeg;     // n_jobs + 1
+    uint32_t n_jobs;
+    uint32_t n_units;
+};
+
+__global__ __launch_bounds__(256) void gd_dels_kernel(DelBatch B)
 {
     const int lane = threadIdx.x & 63;
-    const uint32_t unit = blockIdx.x * 4u + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    if (unit >= job.n_units) return;
+    const uint32_t gunit = blockIdx.x * 4u + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (gunit >= B.n_units) return;
+    const uint32_t ji = (uint32_t)__builtin_amdgcn_readfirstlane((int)norm::batch_find(B.ubeg, B.n_jobs, gunit));
+    const DelJob job = B.jobs[ji];
+    const uint32_t unit = gunit - B.ubeg[ji];
     const uint32_t n_reads = job.n_reads;
     const uint32_t* const cigar = job.cigar;
 
@@ -172,48 +188,55 @@ __global__ __launch_bounds__(256) void gd_dels_kernel(DelJob job)
 // K = (end >> 12) - (pos >> 12) + 2 (reads without deletions have none); entry k = number of the read's
 // deletions that start before b_k.  (M and N alternate and the last op is an M: a read of n canonical ops has
 // n >> 1 deletions.)
-struct PtJob {
-    const uint32_t* noff;     // canonical CSR offsets
-    uint4*    lrec;
-    const uint2* dl;
-    uint32_t  n_reads;
-    uint32_t  n_units;
-    uint32_t* unit;           // n_units + 1: entries per 64-read unit, then (gd_unit_scan_kernel) offsets; [n_units] = total
-    uint32_t* pck;            // the index
-};
-
 __device__ __forceinline__ uint32_t pt_entries(uint32_t p, uint32_t e, uint32_t n_del)
 {
     return (n_del != 0u && e >= p) ? (e >> PT_SHIFT) - (p >> PT_SHIFT) + 2u : 0u;   // (e < p: a negative POS)
 }
 
 // PT1: entries per read -> offsets inside the unit (parked in lrec.w) and unit totals.
-__global__ __launch_bounds__(256) void gd_ptile_count_kernel(PtJob job)
+__global__ __launch_bounds__(256) void gd_ptile_count_kernel(DelBatch B)
 {
     const int lane = threadIdx.x & 63;
-    const uint32_t unit = blockIdx.x * 4u + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    if (unit >= job.n_units) return;
+    const uint32_t gunit = blockIdx.x * 4u + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (gunit >= B.n_units) return;
+    const uint32_t ji = (uint32_t)__builtin_amdgcn_readfirstlane((int)norm::batch_find(B.ubeg, B.n_jobs, gunit));
+    const DelJob job = B.jobs[ji];
+    const uint32_t unit = gunit - B.ubeg[ji];
     const uint32_t r = unit * 64u + (uint32_t)lane;
     uint32_t K = 0;
     if (r < job.n_reads) {
         const uint4 rc = job.lrec[r];
-        K = pt_entries(rc.x, rc.y, (job.noff[r + 1] - job.noff[r]) >> 1);
+        K = pt_entries(rc.x, rc.y, (job.off[r + 1] - job.off[r]) >> 1);
     }
     const uint32_t incl = (uint32_t)wave_inclusive_scan((int)K);
     if (r < job.n_reads) job.lrec[r].w = K != 0u ? incl - K : PT_NONE;
     if (lane == 63) job.unit[unit] = incl;
 }
 
-// PT2: one lane per read fills its entries (a binary search of its own, sorted, deletion list per boundary).
-__global__ __launch_bounds__(256) void gd_ptile_fill_kernel(PtJob job)
+// Between the scan of the unit totals and PT2: every contig's number of index entries, for the host to allocate.
+__global__ __launch_bounds__(256) void gd_ptile_totals_kernel(DelBatch B)
 {
-    const uint32_t r = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t ji = blockIdx.x * 256u + threadIdx.x;
+    if (ji >= B.n_jobs) return;
+    const DelJob job = B.jobs[ji];
+    *job.total = job.unit[job.n_units] - job.unit[0];
+}
+
+// PT2: one lane per read fills its entries (a binary search of its own, sorted, deletion list per boundary).
+__global__ __launch_bounds__(256) void gd_ptile_fill_kernel(DelBatch B)
+{
+    const int lane = threadIdx.x & 63;
+    const uint32_t gunit = blockIdx.x * 4u + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (gunit >= B.n_units) return;
+    const uint32_t ji = (uint32_t)__builtin_amdgcn_readfirstlane((int)norm::batch_find(B.ubeg, B.n_jobs, gunit));
+    const DelJob job = B.jobs[ji];
+    const uint32_t r = (gunit - B.ubeg[ji]) * 64u + (uint32_t)lane;
     if (r >= job.n_reads) return;
     const uint4 rc = job.lrec[r];
     if (rc.w == PT_NONE) return;
-    const uint32_t n_del = (job.noff[r + 1] - job.noff[r]) >> 1;
+    const uint32_t n_del = (job.off[r + 1] - job.off[r]) >> 1;
     const uint32_t K = pt_entries(rc.x, rc.y, n_del);
-    const uint32_t pb = job.unit[r >> 6] + rc.w;
+    const uint32_t pb = job.unit[r >> 6] - job.unit[0] + rc.w;
     job.lrec[r].w = pb;
     const uint2* const d = job.dl + rc.z;
     uint32_t lo = 0;                                       // boundaries grow: the previous answer is a lower bound

@@ -95,9 +95,10 @@ struct __attribute__((aligned(16))) TileInfo {
 // nrd == 0xffffffff: the tile is on the slow list (job.tiles[0 .. n_slow)) instead.
 struct __attribute__((aligned(16))) TileFast {
     const int32_t*  pos;      // at read lo
-    const uint32_t* rec;      // record words (flag | MAPQ | op count), at read lo
-    const uint32_t* cig;      // canonical ops, at op clo
-    const void*     pad0_[2];
+    const uint32_t* rec;      // record words (flag | MAPQ | op count), at read lo; fast == 2: the CSR offsets, at read lo
+    const uint32_t* cig;      // canonical ops (fast == 2: the ops as they arrived), at op clo
+    const uint16_t* flag;     // fast == 2: at read lo
+    const uint8_t*  mapq;     // fast == 2: at read lo
     int32_t*  out;            // per-base output at t0 (null: windows-only)
     int64_t*  wsum;           // the contig's window sums
     int32_t*  wmin;
@@ -154,7 +155,8 @@ struct Job {
     unsigned long long* tile_status;   // scatter path: look-back status word per tile
     uint32_t  w_magic, w_shift;   // floor(x / W)    = (x * w_magic) >> w_shift for x < 2^31
     uint32_t  s_magic, s_shift;   // floor(x / step) likewise (step clamped to 2^31-1)
-    uint32_t  fast;               // 1: ordinary tiles get a TileFast record, the rest go to the slow list
+    uint32_t  fast;               // 1: ordinary tiles get a TileFast record, the rest go to the slow list;
+                                  // 2: the same over the records as they arrived (gd_tile_fast_kernel<ST, true>)
     uint32_t  parity;             // which Counters::n_slow this compute uses
     TileFast* ftiles;             // n_tiles records (fast run)
 };
@@ -264,17 +266,19 @@ __global__ void gd_prep_kernel(Job job)
     } else {
         lower_bound_pair(c.pos, c.n_reads, from, tend, ti.lo, ti.hi);
     }
+    if (job.fast == 2u) ti.lo &= ~3u;   // the raw straight-line kernel loads four reads per lane with aligned vector loads
     ti.clo = c.n_reads ? c.off[ti.lo] : 0u;
     ti.chi = c.n_reads ? c.off[ti.hi] : 0u;
     if (!job.fast) { job.tiles[t] = ti; return; }
     // fast run: an ordinary tile gets its resolved record; anything else joins the slow list
     TileFast tf;
     const uint32_t nrd = ti.hi - ti.lo, nst = ti.chi - ti.clo;
-    const bool ordinary = tend - ti.t0 == T && nrd <= 1024u && nst <= 1024u;
+    const bool ordinary = tend - ti.t0 == T && nrd <= 1024u && nst <= (job.fast == 2u ? 1280u : 1024u);
     tf.nrd = 0xffffffffu;
     if (ordinary) {
-        tf.pos = c.pos + ti.lo; tf.rec = c.rec + ti.lo; tf.cig = c.cigar + ti.clo;
-        tf.pad0_[0] = tf.pad0_[1] = nullptr;
+        tf.pos = c.pos + ti.lo; tf.cig = c.cigar + ti.clo;
+        if (job.fast == 2u) { tf.rec = c.off + ti.lo; tf.flag = c.flag + ti.lo; tf.mapq = c.mapq + ti.lo; }
+        else { tf.rec = c.rec + ti.lo; tf.flag = nullptr; tf.mapq = nullptr; }
         tf.out = job.perbase ? job.perbase + c.base_off + ti.t0 : nullptr;
         tf.wsum = job.win_sum + c.win_off;
         tf.wmin = job.win_min + c.win_off;
@@ -505,7 +509,7 @@ __global__ __launch_bounds__(SUPER) void gd_runs_order_kernel(const int2* __rest
 __global__ __launch_bounds__(256) void gd_export_kernel(const int64_t* __restrict__ wsum, const int32_t* __restrict__ wmin,
                                                         int64_t n_win, const int2* __restrict__ ordered,
                                                         const Counters* __restrict__ counters, int64_t* __restrict__ dst,
-                                                        int64_t max_w, int64_t cap_b)
+                                                        int64_t max_w, int64_t cap_b, uint32_t run_cap)
 {
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
@@ -515,7 +519,10 @@ __global__ __launch_bounds__(256) void gd_export_kernel(const int64_t* __restric
     int32_t* const d_min = reinterpret_cast<int32_t*>(dst + 1 + max_w);
     int2* const d_bnd = reinterpret_cast<int2*>(dst + 1 + max_w + (max_w + 1) / 2);
     for (int64_t w = gid; w < n_win; w += gsz) { d_sum[w] = wsum[w]; d_min[w] = wmin[w]; }
-    const int64_t m = (int64_t)nb < cap_b ? (int64_t)nb : cap_b;
+    // `ordered` holds run_cap entries: an attempt that found more (dst[0] says so; gd_compute grows the arrays
+    // and runs again, rewriting this block) must not be read past its end
+    int64_t m = (int64_t)nb < cap_b ? (int64_t)nb : cap_b;
+    m = m < (int64_t)run_cap ? m : (int64_t)run_cap;
     for (int64_t k = gid; k < m; k += gsz) d_bnd[k] = ordered[k];
 }
 

@@ -16,10 +16,13 @@
 // insertion is now the single op `kM` (98 % of short reads instead of 92 %), which is what the tile
 // kernel's straight-line path handles, and a long read carries about half as many ops.
 //
-// Three launches per contig, no host round trip: (N1) one lane per read counts its canonical ops, a wave
-// scan gives the offsets inside each 64-read unit and the unit totals; (N2) one workgroup scans the
-// unit totals; (N3) one lane per read walks its ops again and writes them at unit offset + local offset.
-// The canonical array is allocated at the size of the original (it can only shrink).
+// One launch set for ALL contigs of a batch (the 64-read units of the batch's contigs are numbered through; a
+// wave finds its contig in a small table), no host round trip in between: (N1) one lane per read counts its
+// canonical ops, a wave scan gives the offsets inside each 64-read unit and the unit totals; (N2) the unit
+// totals of the whole batch are scanned (a contig's offsets are differences against its first unit's);
+// (N3) one lane per read walks its ops again and writes them at unit offset + local offset.  Every array comes
+// out of one allocation sized up front -- the canonical array at the size of the original (it can only
+// shrink) -- so the host waits once, for the per-contig totals.
 #pragma once
 
 namespace gd {
@@ -32,7 +35,22 @@ namespace norm {
 // above 0xfff or a read of 4095 or more canonical ops is marked (status bit) and runs the generic kernel.
 constexpr uint32_t REC_NMAX = 0xfffu;
 
+// last j with beg[j] <= x (beg[0] = 0, n >= 1, entries ascending)
+__device__ __forceinline__ uint32_t batch_find(const uint32_t* __restrict__ beg, uint32_t n, uint32_t x)
+{
+    uint32_t lo = 0, hi = n;
+    while (hi - lo > 1u) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (beg[mid] <= x) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
 struct NormJob {
+    const int32_t*  pos;      // positions (the index kernel)
+    uint32_t* pidx;           // position index, n_idx entries
+    uint32_t  n_idx;
+    uint32_t  pad_;
     const uint32_t* off;      // original CSR offsets (n_reads + 1)
     const uint32_t* cigar;    // original ops
     const uint16_t* flag;
@@ -42,8 +60,21 @@ struct NormJob {
     uint32_t  n_reads;
     uint32_t  n_units;        // ceil(n_reads / 64)
     uint32_t* noff;           // canonical CSR offsets (n_reads + 1)
-    uint32_t* unit;           // n_units + 1: unit totals, then (after N2) exclusive offsets; [n_units] = grand total
+    uint32_t* unit;           // this contig's slice of the batch's unit array: n_units + 1 unit totals, then (after
+                              // N2) exclusive offsets over the BATCH -- unit[k] - unit[0] is the contig's own offset,
+                              // unit[n_units] - unit[0] its total (all modulo 2^32: a contig holds < 2^32 ops)
     uint32_t* ncig;           // canonical ops
+    uint32_t* total;          // out: canonical ops of the contig
+};
+
+// The contigs of one batch: job j owns units [ubeg[j], ubeg[j + 1]) and index entries [ibeg[j], ibeg[j + 1]).
+struct NormBatch {
+    const NormJob*  jobs;
+    const uint32_t* ubeg;     // n_jobs + 1
+    const uint32_t* ibeg;     // n_jobs + 1
+    uint32_t n_jobs;
+    uint32_t n_units;         // ubeg[n_jobs]
+    uint32_t n_idx;           // ibeg[n_jobs]
 };
 
 constexpr uint32_t LEN_MAX = 0x0fffffffu;
@@ -156,12 +187,27 @@ __device__ __forceinline__ uint32_t wave_canonical(const uint32_t* __restrict__ 
 
 constexpr uint32_t WAVE_WALK_MIN = 24;     // reads with more ops than this are walked by the whole wave
 
+// N0: what no other kernel of the batch writes: the four record words past a contig's last read (the tile kernel
+// loads 16 bytes per lane), the status word, the offset of a contig without reads.  One thread per contig.
+__global__ __launch_bounds__(256) void gd_norm_init_kernel(NormBatch B)
+{
+    const uint32_t ji = blockIdx.x * 256u + threadIdx.x;
+    if (ji >= B.n_jobs) return;
+    const NormJob j = B.jobs[ji];
+    for (uint32_t k = 0; k < 4u; ++k) j.rec[j.n_reads + k] = 0u;
+    *j.status = 0u;
+    if (j.n_reads == 0u) { j.noff[0] = 0u; *j.total = 0u; }
+}
+
 // N1: count.  One wave per unit of 64 consecutive reads.
-__global__ __launch_bounds__(256) void gd_norm_count_kernel(NormJob j)
+__global__ __launch_bounds__(256) void gd_norm_count_kernel(NormBatch B)
 {
     const int lane = threadIdx.x & 63;
-    const uint32_t unit = blockIdx.x * 4u + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    if (unit >= j.n_units) return;
+    const uint32_t gunit = blockIdx.x * 4u + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (gunit >= B.n_units) return;
+    const uint32_t ji = (uint32_t)__builtin_amdgcn_readfirstlane((int)batch_find(B.ubeg, B.n_jobs, gunit));
+    const NormJob j = B.jobs[ji];
+    const uint32_t unit = gunit - B.ubeg[ji];
     const uint32_t r = unit * 64u + (uint32_t)lane;
     uint32_t cnt = 0, o0 = 0, n = 0;
     if (r < j.n_reads) { o0 = j.off[r]; n = j.off[r + 1] - o0; }
@@ -252,18 +298,26 @@ __global__ __launch_bounds__(256) void gd_scan_apply_kernel(uint32_t* __restrict
 }
 
 // N3: write.  Same shape as N1.
-__global__ __launch_bounds__(256) void gd_norm_write_kernel(NormJob j)
+__global__ __launch_bounds__(256) void gd_norm_write_kernel(NormBatch B)
 {
     const int lane = threadIdx.x & 63;
-    const uint32_t unit = blockIdx.x * 4u + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    if (unit >= j.n_units) return;
+    const uint32_t gunit = blockIdx.x * 4u + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (gunit >= B.n_units) return;
+    const uint32_t ji = (uint32_t)__builtin_amdgcn_readfirstlane((int)batch_find(B.ubeg, B.n_jobs, gunit));
+    const NormJob j = B.jobs[ji];
+    const uint32_t unit = gunit - B.ubeg[ji];
     const uint32_t r = unit * 64u + (uint32_t)lane;
     const bool valid = r < j.n_reads;
     uint32_t dst0 = 0, o0 = 0, n = 0;
     if (valid) {
-        dst0 = j.unit[unit] + j.noff[r];
+        const uint32_t ubase = j.unit[0];
+        dst0 = j.unit[unit] - ubase + j.noff[r];
         j.noff[r] = dst0;
-        if (r + 1u == j.n_reads) j.noff[j.n_reads] = j.unit[j.n_units];
+        if (r + 1u == j.n_reads) {
+            const uint32_t tot = j.unit[j.n_units] - ubase;
+            j.noff[j.n_reads] = tot;
+            *j.total = tot;
+        }
         o0 = j.off[r]; n = j.off[r + 1] - o0;
     }
     bool serial = n <= WAVE_WALK_MIN;
@@ -290,11 +344,21 @@ __global__ __launch_bounds__(256) void gd_norm_write_kernel(NormJob j)
 // looks a tile's read range up in it instead of searching `pos` (two dependent chains of ~15 loads per tile,
 // 0.29 ms per genome: 7 % of a step).  4 bytes per 64 reference positions (194 MB for hg19).  One thread per
 // entry, a plain binary search each: latency bound, but wide, and paid once per ingest.
-__global__ __launch_bounds__(256) void gd_pidx_kernel(const int32_t* __restrict__ pos, uint32_t n_reads,
-                                                      uint32_t* __restrict__ pidx, uint32_t n_idx)
+__global__ __launch_bounds__(256) void gd_pidx_kernel(NormBatch B)
 {
-    const uint32_t k = blockIdx.x * 256u + threadIdx.x;
-    if (k >= n_idx) return;
+    const uint32_t g = blockIdx.x * 256u + threadIdx.x;
+    // the contig of this entry: one scalar search per wave when the whole wave lies inside one contig
+    const uint32_t g0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(g & ~63u));
+    if (g0 >= B.n_idx) return;
+    uint32_t ji = (uint32_t)__builtin_amdgcn_readfirstlane((int)batch_find(B.ibeg, B.n_jobs, g0));
+    if (g0 + 63u >= B.ibeg[ji + 1]) {
+        if (g >= B.n_idx) return;
+        ji = batch_find(B.ibeg, B.n_jobs, g);
+    }
+    const int32_t* __restrict__ const pos = B.jobs[ji].pos;
+    uint32_t* __restrict__ const pidx = B.jobs[ji].pidx;
+    const uint32_t n_reads = B.jobs[ji].n_reads;
+    const uint32_t k = g - B.ibeg[ji];
     const uint64_t key = (uint64_t)k << 6;
     uint32_t lo = 0, hi = n_reads;
     if (key > 0x7fffffffull) lo = n_reads;              // every position is below it

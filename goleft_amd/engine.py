@@ -18,6 +18,10 @@ K_PREP, K_TILE, K_RUNS, K_EXPAND, K_SCAN, K_CKPT, K_SEQSTATS, K_MDFLAGS, K_INFLA
 # gd_set_option keys (include/goleft_depth.h)
 OPT_NT_STORES, OPT_NORMALIZE, OPT_FAST_KERNEL, OPT_COPY_THREADS = 3, 4, 5, 6
 PATH_AUTO, PATH_TILE, PATH_SCATTER, PATH_CHUNK = 0, 1, 2, 3
+# gd_stats.tile_kernel (include/goleft_depth.h GD_TK_*)
+TK_NONE, TK_GENERIC, TK_FAST, TK_FAST_RAW, TK_LONG, TK_SCATTER, TK_SUMS_STREAM, TK_TILE_SUMS = range(8)
+TK_NAMES = ("none", "gd_tile_kernel", "gd_tile_fast_kernel", "gd_tile_fast_kernel<raw>", "gd_ltile2_kernel",
+            "gd_expand_scatter_kernel+gd_scan_kernel", "gd_sums_stream_kernel", "gd_tile_sums_kernel")
 
 
 class GdError(RuntimeError):
@@ -131,6 +135,14 @@ class DepthEngine:
     # -- compute ----------------------------------------------------------
     def compute(self):
         self._chk(self._lib.gd_compute(self._ctx))
+
+    def normalize(self, force: bool = False):
+        """gd_normalize: canonical records (+ long-read structures) of the selected contigs, one batch."""
+        self._chk(self._lib.gd_normalize(self._ctx, 1 if force else 0))
+
+    def drop_derived(self):
+        """gd_drop_derived: back to the state right after the records arrived."""
+        self._chk(self._lib.gd_drop_derived(self._ctx))
 
     def compute_launch(self):
         """gd_compute_launch: enqueue a compute, do not wait (compute_finish does)."""

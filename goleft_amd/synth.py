@@ -168,10 +168,19 @@ def _assemble(xp, pos, kind_r, u3, u4, f5, u6):
     return (pos, flag.astype(np.uint16), mapq.astype(np.uint8), cigar_off, cigar)
 
 
-def algorithmic_bytes(n_reads: int, n_ops: int, n_bases: int, n_windows: int) -> int:
+def algorithmic_bytes(n_reads: int, n_ops: int, n_bases: int, n_windows: int, raw: bool = False) -> int:
     """4*reads(pos) + 4*reads(CSR offsets, read on device)
-    + 4*ops + 4*bases (int32 per-base write) + 8*windows (int64 sums)."""
-    return 4 * n_reads + 4 * n_reads + 4 * n_ops + 4 * n_bases + 8 * n_windows
+    + 4*ops + 4*bases (int32 per-base write) + 8*windows (int64 sums).  raw: the kernel reads the
+    records as they arrived -- flag (2) and MAPQ (1) per read too, which the canonical record word
+    folds into the 4 bytes of the CSR offset."""
+    return (11 if raw else 8) * n_reads + 4 * n_ops + 4 * n_bases + 8 * n_windows
+
+
+def normalise_bytes(n_reads: int, n_ops: int, n_canonical_ops: int, n_bases: int) -> int:
+    """What one pass that builds the canonical records has to move at least: in pos 4 + CSR offset 4 +
+    flag 2 + MAPQ 1 per read and 4 per original op; out record word 4 + canonical offset 4 per read,
+    4 per canonical op, 4 per 64 reference positions (position index)."""
+    return 11 * n_reads + 4 * n_ops + 8 * n_reads + 4 * n_canonical_ops + n_bases // 16
 
 
 # ---------------------------------------------------------------------------

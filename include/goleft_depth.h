@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define GD_ABI_VERSION 9
+#define GD_ABI_VERSION 10
 
 typedef enum {
     GD_OK = 0,
@@ -109,7 +109,19 @@ typedef struct {
     int32_t  path;           /* GD_PATH_TILE / _SCATTER / _CHUNK: what the last gd_compute ran */
     int32_t  n_slow_tiles;   /* tile path with GD_OPT_FAST_KERNEL: tiles that took the generic kernel instead */
     uint64_t n_canonical_ops; /* ops of the canonical CIGARs the tile / long-read path read (0: it read the original ones) */
+    int32_t  tile_kernel;    /* GD_TK_*: the kernel that did the per-base arithmetic of the last gd_compute */
+    int32_t  reserved_;
 } gd_stats;
+
+/* gd_stats.tile_kernel */
+enum { GD_TK_NONE = 0,
+       GD_TK_GENERIC = 1,      /* gd_tile_kernel: any tile shape, CIGARs in any form */
+       GD_TK_FAST = 2,         /* gd_tile_fast_kernel on canonical records (+ the generic kernel for the slow list) */
+       GD_TK_FAST_RAW = 3,     /* gd_tile_fast_kernel on the records as they arrived (+ the slow list) */
+       GD_TK_LONG = 4,         /* gd_ltile2_kernel (long-read path) */
+       GD_TK_SCATTER = 5,      /* gd_expand_scatter_kernel + gd_scan_kernel */
+       GD_TK_SUMS_STREAM = 6,  /* gd_sums_stream_kernel (GD_OUT_SUMS_ONLY over canonical records) */
+       GD_TK_TILE_SUMS = 7 };  /* gd_tile_sums_kernel (GD_OUT_SUMS_ONLY otherwise) */
 
 /* Kernel ids for gd_kernel_ms.  Tile path: PREP, TILE, RUNS.  Long-read path: PREP, TILE (the long-read tile
  * kernel), RUNS; CKPT = its deletion lists + tile indexes, built when the records arrive (like NORM: summed over
@@ -164,14 +176,31 @@ int gd_set_path(gd_ctx* ctx, int path);
  * environment: these are calls. */
 enum { /* (1, 2: tile shapes other than 4096 positions x 256 threads -- measured slower everywhere, retired) */
        GD_OPT_NT_STORES = 3,        /* 1 (default): non-temporal per-base stores; 0: plain */
-       GD_OPT_NORMALIZE = 4,        /* 1 (default): canonical CIGARs are built when records arrive (I/S/H/P and
-                                       zero-length ops dropped, neighbouring M/=/X merged, neighbouring D/N
-                                       merged -- exactly what `samtools depth` without -J distinguishes); 0: the
-                                       kernels walk the CIGARs as given (generic tile kernel) */
+       GD_OPT_NORMALIZE = 4,        /* canonical records (I/S/H/P and zero-length ops dropped, neighbouring M/=/X
+                                       merged, neighbouring D/N merged -- exactly what `samtools depth` without -J
+                                       distinguishes -- plus record words and a position index; gd_normalize.hpp):
+                                       2 (default): built by the first gd_compute whose kernel reads them -- the
+                                       long-read path and the streaming sums of GD_OUT_SUMS_ONLY; the short-read tile
+                                       path reads the records AS THEY ARRIVED (a `goleft depth` run computes each
+                                       input once: a pass that rewrites ~28 bytes per read to save 3 bytes per read
+                                       in the tile kernel does not pay); 1: built when records arrive (gd_adopt_device,
+                                       gd_ingest_finish, the first gd_compute after gd_commit) -- for a host that
+                                       computes the same records many times; 0: never for the tile path.
+                                       gd_normalize builds them on request under every setting. */
        GD_OPT_FAST_KERNEL = 5,      /* 1 (default): ordinary tiles run the straight-line tile kernel, the rest the
                                        generic one; 0: the generic kernel for every tile */
        GD_OPT_COPY_THREADS = 6 };   /* host threads filling the staging buffer of gd_ingest_feed: 1 (default) .. 16 */
 int gd_set_option(gd_ctx* ctx, int option, int64_t value);
+
+/* Builds the canonical records of every selected contig that lacks them (force != 0: of every selected contig,
+ * again) in ONE batch -- one device allocation, one launch set over all contigs, one host synchronisation -- and,
+ * for contigs the long-read path will take (GD_PATH_CHUNK, or GD_PATH_AUTO and more than 6 CIGAR ops per record),
+ * their deletion lists and tile indexes.  gd_compute does this by itself when its kernel needs them; a host that
+ * will compute the same records repeatedly calls it once (then the tile path reads 8 + 4.2 instead of 11 + 4.4
+ * bytes per read).  gd_drop_derived forgets everything built from the records: the state right after they
+ * arrived (measurement: one gd_compute from there is what one `goleft depth` run pays). */
+int gd_normalize(gd_ctx* ctx, int force);
+int gd_drop_derived(gd_ctx* ctx);
 
 /* Diagnostic: the canonical CIGARs of contig tid (GD_OPT_NORMALIZE) as CSR offsets (n_reads + 1) and ops
  * (BAM encoding, op 0 = M or 3 = N) into host memory.  *n_ops receives the op count; GD_E_CAPACITY if cap_ops
@@ -226,10 +255,11 @@ int gd_push(gd_ctx* ctx, int32_t tid, const int32_t* pos, const uint16_t* flag,
 
 /* Use records already resident in HBM (zero copy).  Replaces any records of
  * that contig.  The call waits for the device (whatever stream produced the
- * arrays), checks them the way gd_commit checks a host block -- positions in
+ * arrays) and checks them the way gd_commit checks a host block -- positions in
  * coordinate order (GD_E_UNSORTED) and not negative (GD_E_RANGE), CSR offsets non-decreasing from 0 and ending
- * inside the op array (GD_E_INVALID); one pass over pos / cigar_off -- and builds
- * the contig's canonical CIGARs from them right away. */
+ * inside the op array (GD_E_INVALID); one pass over pos / cigar_off.  Arrays aligned to 16 (pos, cigar_off),
+ * 8 (flag) and 4 (mapq) bytes -- anything hipMalloc or a tensor allocator returns -- get the straight-line
+ * tile kernel; others the generic one. */
 int gd_adopt_device(gd_ctx* ctx, int32_t tid, const gd_batch* dev, size_t n_reads, size_t n_ops);
 
 /* Drop records and results, keep contigs/params/allocations. */
@@ -246,8 +276,10 @@ int gd_compute(gd_ctx* ctx);
  * stream and returns without waiting; gd_compute_finish waits, verifies (re-running synchronously when the
  * look-back / capacity checks ask for it) and publishes the results.  Between the two the host is free -- e.g.
  * to issue the collective of the PREVIOUS step while this one's kernels run (bench.py --gpus N).  Exactly one
- * compute may be in flight per context; result calls before gd_compute_finish see the previous compute, and calls
- * that change the job (records, contigs, parameters, path, outputs, options) are refused with GD_E_STATE. */
+ * compute may be in flight per context; until gd_compute_finish, result calls and calls that change the job
+ * (records, contigs, parameters, path, outputs, options, gd_ingest_*, gd_md_*) are refused with GD_E_STATE --
+ * gd_compute_launch starts overwriting the result arrays.  gd_set_export may be called in between (it takes
+ * effect with the next launch). */
 int gd_compute_launch(gd_ctx* ctx);
 int gd_compute_finish(gd_ctx* ctx);
 

@@ -59,6 +59,7 @@ def test_canonical_overflow_and_degenerate_reads():
         got = eng.canonical_cigars(0, n) if False else None
     from goleft_amd import engine as E
     with E.DepthEngine(0) as eng:
+        eng.set_option(E.OPT_NORMALIZE, 1)
         eng.set_params(window_size=100)
         eng.set_path(1)
         eng.set_contigs([1000])
@@ -86,10 +87,15 @@ def test_fast_kernel_equals_generic_and_oracle(W, mincov, maxmean, step):
              3: H.random_reads(rng, lengths[3], 8000, max_ops=9, max_len=60),     # many multi-op reads, many ops
              5: H.random_reads(rng, lengths[5], 3000, max_ops=1, max_len=300)}
     res = {}
-    for key, (fast, norm) in {"fast": (1, 1), "generic": (0, 1), "raw": (0, 0)}.items():
+    # straight-line kernel on canonical records / on the records as they arrived (default, and with normalisation
+    # switched off), generic kernel on canonical / original records
+    for key, (fast, norm) in {"fast": (1, 1), "fast-raw": (1, 2), "fast-raw0": (1, 0), "generic": (0, 1), "raw": (0, 0)}.items():
         with _engine(lengths, reads, fast=fast, norm=norm, window_size=W, min_mapq=1, min_cov=mincov,
                      max_mean_depth=maxmean, step=step) as eng:
             eng.compute()
+            from goleft_amd import engine as E
+            assert eng.stats().tile_kernel == {"fast": E.TK_FAST, "fast-raw": E.TK_FAST_RAW, "fast-raw0": E.TK_FAST_RAW,
+                                               "generic": E.TK_GENERIC, "raw": E.TK_GENERIC}[key]
             res[key] = [(eng.perbase(t), eng.windows(t), eng.callable_runs(t)) for t in range(len(lengths))]
     for t, L in enumerate(lengths):
         d = po.perbase_c(reads.get(t, H.empty_reads()), 1, 0, L)
@@ -106,6 +112,7 @@ def test_normalisation_is_ingest_time_not_compute_time():
     L = 3_000_000
     r = po.Reads(*synth.short_reads_numpy(L, synth.n_reads_for(L), 5))
     with E.DepthEngine(0) as eng:
+        eng.set_option(E.OPT_NORMALIZE, 1)
         eng.set_profiling(True)
         eng.set_params(window_size=1000)
         eng.set_contigs([L])
@@ -157,3 +164,73 @@ def test_wave_walked_canonical_cigars_equal_restatement(seed):
     assert np.array_equal(cig_got, wcig)
     assert st.path == 3 and st.n_canonical_ops == len(wcig)
     assert np.array_equal(got, po.perbase_c(r, 1, 0, L))
+
+
+def test_default_computes_from_the_records_as_they_arrived():
+    """GD_OPT_NORMALIZE = 2 (default): the short-read tile path builds nothing before its first compute (the raw
+    straight-line kernel); gd_normalize builds the canonical records on request, after which the canonical
+    kernel runs; gd_drop_derived goes back.  Same results every time."""
+    from goleft_amd import engine as E, synth
+    L = 2_000_000
+    r = po.Reads(*synth.short_reads_numpy(L, synth.n_reads_for(L), 11))
+    want = po.perbase_c(r, 1, 0, L)
+    with E.DepthEngine(0) as eng:
+        eng.set_profiling(True)
+        eng.set_params(window_size=1000)
+        eng.set_contigs([L])
+        eng.push(0, r.pos, r.flag, r.mapq, r.cigar_off, r.cigar)
+        eng.compute()
+        st = eng.stats()
+        assert eng.kernel_ms(E.K_NORM) == 0.0 and st.tile_kernel == E.TK_FAST_RAW and st.n_canonical_ops == 0
+        assert st.n_slow_tiles <= 2                      # the clipped last tile (+ at most a dense one)
+        assert np.array_equal(eng.perbase(0), want)
+        with pytest.raises(E.GdError):
+            eng.canonical_cigars(0, r.n)
+        eng.normalize()
+        assert eng.kernel_ms(E.K_NORM) > 0.0
+        eng.compute()
+        st = eng.stats()
+        assert st.tile_kernel == E.TK_FAST and st.n_canonical_ops > 0
+        assert np.array_equal(eng.perbase(0), want)
+        off, cig = eng.canonical_cigars(0, r.n)
+        woff, wcig = po.canonical_cigars(r)
+        assert np.array_equal(off, woff) and np.array_equal(cig, wcig)
+        eng.normalize(force=True)                        # again, into the same device block
+        eng.compute()
+        assert np.array_equal(eng.perbase(0), want)
+        eng.drop_derived()
+        eng.compute()
+        assert eng.stats().tile_kernel == E.TK_FAST_RAW
+        assert np.array_equal(eng.perbase(0), want)
+        s, m = eng.windows(0)
+        assert np.array_equal(s, want.reshape(-1, 1000).sum(1)) and np.array_equal(m, want.reshape(-1, 1000).min(1))
+
+
+def test_normalize_batches_many_contigs():
+    """One gd_normalize over contigs of every shape (empty, one read, short, long-read shaped, zero length): the
+    batch's kernels find each 64-read unit's contig in the table; canonical CIGARs equal the restatement."""
+    from goleft_amd import engine as E
+    rng = np.random.default_rng(3)
+    lengths = [70_000, 0, 5, 300_000, 64, 4096, 1_000_000, 129]
+    reads = {0: H.random_reads(rng, lengths[0], 5000, max_ops=7),
+             2: H.random_reads(rng, lengths[2], 1, max_ops=3),
+             3: H.long_cigar_reads(rng, lengths[3], [int(x) for x in rng.choice([3, 30, 200, 1500], size=300)], skip_every=5),
+             5: H.random_reads(rng, lengths[5], 64, max_ops=4),
+             6: H.long_cigar_reads(rng, lengths[6], [int(x) for x in rng.choice([50, 700, 5000], size=130)]),
+             7: H.random_reads(rng, lengths[7], 65, max_ops=2)}
+    with E.DepthEngine(0) as eng:
+        eng.set_params(window_size=100)
+        eng.set_contigs(lengths)
+        for t, r in reads.items():
+            eng.push(t, r.pos, r.flag, r.mapq, r.cigar_off, r.cigar)
+        eng.normalize()
+        for t, r in reads.items():
+            off, cig = eng.canonical_cigars(t, r.n)
+            woff, wcig = po.canonical_cigars(r)
+            assert np.array_equal(off, woff) and np.array_equal(cig, wcig), t
+        for path in (E.PATH_TILE, E.PATH_CHUNK, E.PATH_AUTO):
+            eng.set_path(path)
+            eng.compute()
+            for t, L in enumerate(lengths):
+                want = po.perbase_c(reads.get(t, H.empty_reads()), 1, 0, L) if L else np.zeros(0, np.int32)
+                assert np.array_equal(eng.perbase(t), want), (path, t)
