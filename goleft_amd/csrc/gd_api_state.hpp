@@ -470,7 +470,7 @@ int ck_enqueue(gd_ctx* c, const std::vector<ContigHost*>& hs, bool ops_known, Ck
         P->o_dl[k] = cv.take(n_dl * sizeof(uint2));
         units += (n + 63) / 64;
     }
-    if (units > 0xfffffff0ull) return fail(c, GD_E_RANGE, "too many records");
+    if (units > (1ull << 26) - 64) return fail(c, GD_E_RANGE, "too many records in one batch (internal error)");
     P->n_units = (uint32_t)units;
     const size_t o_unit = cv.take((units + 2) * sizeof(uint32_t));
     P->o_jobs = cv.take(nj * sizeof(gd::DelJob) + (nj + 1) * sizeof(uint32_t));   // the jobs, then ubeg
@@ -614,7 +614,7 @@ int norm_batch(gd_ctx* c, const std::vector<ContigHost*>& hs, const std::vector<
         units += (n + 63) / 64;
         idxs += (uint64_t)(h.length >> 6) + 2;
     }
-    if (units > 0xfffffff0ull) return fail(c, GD_E_RANGE, "too many records");
+    if (units > (1ull << 26) - 64) return fail(c, GD_E_RANGE, "too many records in one batch (internal error)");
     if (idxs > 0xfffffff0ull) return fail(c, GD_E_RANGE, "the contigs of one batch are too long for one position-index launch");
     const size_t o_unit = cv.take((units + 2) * sizeof(uint32_t));
     const size_t tab_bytes = nj * sizeof(gd::norm::NormJob) + 2 * (nj + 1) * sizeof(uint32_t);
@@ -736,14 +736,34 @@ int norm_tids(gd_ctx* c, const std::vector<int32_t>& tids, bool force, bool ck_a
         else if (wants_ck && !h.ck_ok) ck.push_back(&h);
     }
     if (hs.empty() && ck.empty()) return GD_OK;
-    if (!hs.empty()) {
-        // contigs normalised earlier that only lack the long-read structures go in a batch of their own
-        std::vector<ContigHost*> ck_new, ck_old;
-        for (ContigHost* h : ck) (std::find(hs.begin(), hs.end(), h) != hs.end() ? ck_new : ck_old).push_back(h);
-        if (int r = norm_batch(c, hs, ck_new)) return r;
-        return ck_batch(c, ck_old);
+    // A launch holds fewer than 2^32 work-items (the dispatch packet's grid size is 32 bits; a larger grid wraps
+    // silently): at one wave per 64-read unit that is 2^26 units, so a cohort of 10^10 reads is several batches.
+    constexpr uint64_t kMaxUnits = 48u << 20;
+    auto in = [](const std::vector<ContigHost*>& v, const ContigHost* h) { return std::find(v.begin(), v.end(), h) != v.end(); };
+    // contigs normalised earlier that only lack the long-read structures go in batches of their own
+    std::vector<ContigHost*> ck_old;
+    for (ContigHost* h : ck) if (!in(hs, h)) ck_old.push_back(h);
+    for (size_t i = 0; i < hs.size();) {
+        std::vector<ContigHost*> part, part_ck;
+        uint64_t units = 0;
+        while (i < hs.size() && (part.empty() || units + (hs[i]->n_reads + 63) / 64 <= kMaxUnits)) {
+            units += (hs[i]->n_reads + 63) / 64;
+            part.push_back(hs[i]);
+            if (in(ck, hs[i])) part_ck.push_back(hs[i]);
+            ++i;
+        }
+        if (int r = norm_batch(c, part, part_ck)) return r;
     }
-    return ck_batch(c, ck);
+    for (size_t i = 0; i < ck_old.size();) {
+        std::vector<ContigHost*> part;
+        uint64_t units = 0;
+        while (i < ck_old.size() && (part.empty() || units + (ck_old[i]->n_reads + 63) / 64 <= kMaxUnits)) {
+            units += (ck_old[i]->n_reads + 63) / 64;
+            part.push_back(ck_old[i++]);
+        }
+        if (int r = ck_batch(c, part)) return r;
+    }
+    return GD_OK;
 }
 
 // RAII for the scratch device buffers of gd_ingest_bgzf

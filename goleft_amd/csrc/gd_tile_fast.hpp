@@ -101,7 +101,7 @@ __global__ __launch_bounds__(NT) void gd_tile_fast_kernel(Job job)
     const uint32_t nrd = tf.nrd;
     const rsrc_t r_pos = make_rsrc(tf.pos, nrd * 4u);
     // RAW: tf.rec points at the CSR offsets of the tile's first read; entry nrd (the end of the last read) is read too
-    const rsrc_t r_rec = make_rsrc(tf.rec, (RAW ? nrd + 1u : nrd) * 4u);
+    const rsrc_t r_rec = make_rsrc(tf.rec, (RAW && nrd != 0u ? nrd + 1u : nrd) * 4u);   // (no reads: no array either)
     const rsrc_t r_cig = make_rsrc(tf.cig, tf.nst * 4u);
     const int tid4 = tid * 4;
     typedef unsigned int v4u __attribute__((ext_vector_type(4)));

@@ -20,7 +20,9 @@ for st in "$@"; do
   case "$st" in
     tests*)
       echo "== pytest -m gpu ${st#tests}" >> $LOG
-      timeout 1500 python -m pytest tests -m gpu -x -q ${st#tests} 2>&1 | tail -15 >> $LOG ;;
+      timeout 1500 python -X faulthandler -m pytest tests -m gpu -x -q ${st#tests} > gpurun_out/${T}_pytest.txt 2>&1
+      grep -n "Fatal\|fault\|tests/.*line\|passed\|failed\|Error" gpurun_out/${T}_pytest.txt | head -30 >> $LOG
+      tail -5 gpurun_out/${T}_pytest.txt >> $LOG ;;
     bench:*)
       w=${st#bench:}; extra=""; case "$w" in *:*) extra=${w#*:}; w=${w%%:*};; esac
       echo "== bench $w $extra" >> $LOG
