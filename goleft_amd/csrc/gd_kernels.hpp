@@ -216,6 +216,33 @@ __device__ __forceinline__ void lower_bound_pair(const int32_t* a, uint32_t n, i
     outB = lb;
 }
 
+// lower_bound(a[0..n), key) from a GUESS of where it lies: two probes 8192 elements either side of the guess
+// bracket it (a 30x genome's cumulative read count wanders a few thousand reads around the interpolated one), 14
+// bisection steps finish; a miss bisects the side the answer is on.  ONE such search per tile: for records without
+// a position index (gd_normalize.hpp builds one; a first compute has none) the pair of plain searches every tile
+// ran moved 3.8 GB of 64-byte sectors, most of them TLB misses -- 0.29 ms per genome.
+__device__ __forceinline__ uint32_t lower_bound_hint(const int32_t* a, uint32_t n, int32_t key, uint32_t guess)
+{
+    if (n == 0u) return 0u;
+    constexpr uint32_t R = 8192u;
+    const uint32_t g = guess < n ? guess : n - 1u;
+    const uint32_t pl = g > R ? g - R : 0u;
+    const uint32_t ph = n - 1u - g > R ? g + R : n - 1u;
+    const int32_t vl = a[pl], vh = a[ph];                  // two independent probes
+    uint32_t lo = 0, hi = n;
+    if (vl < key) {                                        // the answer is past pl ...
+        lo = pl + 1u;
+        if (vh >= key) hi = ph; else lo = ph + 1u;         // ... and at or before ph, or past it
+    } else {
+        hi = pl;
+    }
+    while (lo < hi) {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        if (a[mid] < key) lo = mid + 1u; else hi = mid;
+    }
+    return lo;
+}
+
 // ---------------------------------------------------------------------------
 // K0: tile table + accumulator init
 // ---------------------------------------------------------------------------
@@ -264,7 +291,34 @@ __global__ void gd_prep_kernel(Job job)
         const uint32_t a = c.pidx[k];
         ti.hi = (tend & 63) == 0 ? a : a + lower_bound_i32(c.pos + a, c.pidx[k + 1] - a, tend);
     } else {
-        lower_bound_pair(c.pos, c.n_reads, from, tend, ti.lo, ti.hi);
+        // no index.  ONE search per tile: s = first read at or past the tile's first position.  The tile's last
+        // read is the next tile's s (the neighbouring lane has it; the last lane of a wave and the last tile of a
+        // contig search for themselves), and the look-back start lies a few dozen reads before s: found by stepping
+        // back from it.
+        const uint32_t n = c.n_reads;
+        const uint32_t g0 = (uint32_t)(((uint64_t)(uint32_t)ti.t0 * n) / (uint32_t)c.length);
+        const uint32_t s0 = ti.t0 == 0 ? 0u : lower_bound_hint(c.pos, n, ti.t0, g0);
+        const uint32_t nxt = (uint32_t)__shfl_down((int)s0, 1, WAVE);
+        const int tnx = __shfl_down(t, 1, WAVE);                  // (lanes past the last tile returned above: not read)
+        const bool have = (threadIdx.x & 63u) != 63u && t + 1 < job.n_tiles && tnx == t + 1 &&
+                          t + 1 - c.tile_beg < c.n_tiles && ti.t0 + T == tend;
+        if (have) ti.hi = nxt;
+        else {
+            const uint32_t g1 = (uint32_t)(((uint64_t)(uint32_t)tend * n) / (uint32_t)c.length);
+            ti.hi = lower_bound_hint(c.pos + s0, n - s0, tend, g1 > s0 ? g1 - s0 : 0u) + s0;
+        }
+        // first read with pos >= from (from <= t0): step back from s0
+        uint32_t lo = 0, hi2 = s0;
+        if (from == 0) hi2 = 0u;
+        for (uint32_t step = 64u; hi2 > 0u; step <<= 2) {
+            const uint32_t p = hi2 > step ? hi2 - step : 0u;
+            if (c.pos[p] >= from) hi2 = p; else { lo = p + 1u; break; }
+        }
+        while (lo < hi2) {
+            const uint32_t mid = lo + ((hi2 - lo) >> 1);
+            if (c.pos[mid] < from) lo = mid + 1u; else hi2 = mid;
+        }
+        ti.lo = lo;
     }
     if (job.fast == 2u) ti.lo &= ~3u;   // the raw straight-line kernel loads four reads per lane with aligned vector loads
     ti.clo = c.n_reads ? c.off[ti.lo] : 0u;

@@ -48,6 +48,7 @@ constexpr int CQ = 1024;               // staged canonical ops
 constexpr int CQ_RAW = 1280;           // staged ops, records as they arrived (7 % more ops per read: 1024 would put 1-2 % of a 30x genome's tiles on the slow list)
 constexpr int U = 4;                   // reads per lane
 constexpr int QCAP = 128;              // queued multi-op reads per tile (more: walked in place)
+constexpr int QCAP_RAW = 120;          // ... raw variant: 23 004 bytes of LDS = seven workgroups per CU at any allocation granularity up to 512
 constexpr int NWORDS = T / 32;
 
 // ST: per-base stores 0 plain, 1 non-temporal, 2 none (windows-only output).
@@ -55,9 +56,10 @@ template <int ST, bool RAW = false>
 __global__ __launch_bounds__(NT) void gd_tile_fast_kernel(Job job)
 {
     constexpr int CQN = RAW ? CQ_RAW : CQ;
+    constexpr int QCAPN = RAW ? QCAP_RAW : QCAP;
     __shared__ __attribute__((aligned(16))) int32_t s_diffp[T + 4];   // [3] = index -1
     __shared__ __attribute__((aligned(16))) uint32_t s_cig[CQN];      // phase A: staged ops; B, C: boundary bitmaps
-    __shared__ uint32_t s_q[3 * QCAP];                                // ps4 | first op (staged index) | n ops
+    __shared__ uint32_t s_q[3 * QCAPN];                                // ps4 | first op (staged index) | n ops
     __shared__ int32_t  s_wtot[NW];
     __shared__ uint32_t s_wcnt[NW];
     __shared__ uint32_t s_qn;
@@ -247,8 +249,8 @@ __global__ __launch_bounds__(NT) void gd_tile_fast_kernel(Job job)
                 if (cx[u]) {
                     const uint32_t rk = b + __builtin_amdgcn_mbcnt_hi((uint32_t)(m[u] >> 32),
                                                 __builtin_amdgcn_mbcnt_lo((uint32_t)m[u], 0u));
-                    if (rk < (uint32_t)QCAP) {
-                        s_q[rk] = (uint32_t)ps4[u]; s_q[QCAP + rk] = idx[u]; s_q[2 * QCAP + rk] = n[u];
+                    if (rk < (uint32_t)QCAPN) {
+                        s_q[rk] = (uint32_t)ps4[u]; s_q[QCAPN + rk] = idx[u]; s_q[2 * QCAPN + rk] = n[u];
                     } else {
                         // did not fit the queue (not short-read shaped data): walked by its own lane
                         const uint32_t sp = walk_cigar4(s_cig + idx[u], n[u], ps4[u], T4, s_diff);
@@ -263,10 +265,10 @@ __global__ __launch_bounds__(NT) void gd_tile_fast_kernel(Job job)
 
     // ---- the queued multi-op reads: one lane each ------------------------------------------------
     {
-        const uint32_t nq = s_qn < (uint32_t)QCAP ? s_qn : (uint32_t)QCAP;
+        const uint32_t nq = s_qn < (uint32_t)QCAPN ? s_qn : (uint32_t)QCAPN;
         if ((uint32_t)(wv * WAVE) < nq) {                          // wave uniform: usually wave 0 only
             if ((uint32_t)tid < nq) {
-                const uint32_t sp = walk_cigar4(s_cig + s_q[QCAP + tid], s_q[2 * QCAP + tid], (int)s_q[tid], T4, s_diff);
+                const uint32_t sp = walk_cigar4(s_cig + s_q[QCAPN + tid], s_q[2 * QCAPN + tid], (int)s_q[tid], T4, s_diff);
                 smax = sp > smax ? sp : smax;
             }
         }
