@@ -576,14 +576,29 @@ def main():
         out["roofline"]["traffic_source"] = "%s: %s" % (tr.get("file"), tr.get("source"))
 
     if args.verify and rank == 0 and r["perbase"]:
+        # EVERY contig of this rank against the C oracle, bit for bit: per-base vector, window sums / minima and
+        # class runs (from the oracle's vector), 10 Mb tiles on all host cores
         from oracle import pyoracle as po
-        t = mine[-1]
-        rd = po.Reads(*[x.cpu().numpy() for x in streams[t]])
-        rd.flag = rd.flag.view(np.uint16)
-        want = po.perbase_c(rd, Q, 0, lengths[t], diff=True)
-        got = eng.perbase(t)
-        out["verified_contig"] = names[t]
-        out["verified_bit_exact"] = bool(np.array_equal(got, want))
+        cores = os.cpu_count() or 8
+        t1 = time.perf_counter()
+        ok, bad = True, []
+        for t in mine:
+            a = [x.cpu().numpy() for x in streams[t]]
+            rd = po.Reads(a[0], a[1].view(np.uint16), a[2], a[3].view(np.uint32), a[4].view(np.uint32))
+            res = po.tiled_contig_check(rd, Q, lengths[t], W, mincov, 0, po.step_for(W), cores, got=eng.perbase(t))
+            sums, mins = eng.windows(t)
+            runs = eng.callable_runs(t)
+            good = (res["equal"] and np.array_equal(sums, res["sums"]) and np.array_equal(mins, res["mins"]) and
+                    np.array_equal(runs[:, 0], res["run_starts"]) and np.array_equal(runs[:, 2], res["run_cls"]))
+            if not good:
+                ok = False
+                bad.append(names[t])
+            del a, rd, res
+        out["verified_contigs"] = len(mine)
+        out["verified_bit_exact"] = ok
+        out["verified_seconds"] = time.perf_counter() - t1
+        if bad:
+            out["verified_mismatch"] = bad
 
     if rank == 0 and world == 1 and not args.no_host_stream and args.workload in ("wgs", "chr20"):
         out["host_stream_scope"] = host_stream_scope(local_rank, W, Q, mincov)

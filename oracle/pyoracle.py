@@ -457,6 +457,66 @@ def perbase_c(r: Reads, q: int, start: int, end: int,
     return out
 
 
+def read_ends(r: Reads) -> np.ndarray:
+    """Reference position after the last reference-consuming op of every read (int64)."""
+    op = r.cigar & 0xF
+    cons = np.where((op == 0) | (op == 2) | (op == 3) | (op == 7) | (op == 8), (r.cigar >> 4).astype(np.int64), 0)
+    cs = np.zeros(cons.shape[0] + 1, np.int64)
+    np.cumsum(cons, out=cs[1:])
+    off = r.cigar_off.astype(np.int64)
+    return r.pos.astype(np.int64) + cs[off[1:]] - cs[off[:-1]]
+
+
+def tiled_contig_check(r: Reads, q: int, length: int, W: int, mincov: int, maxmean: int, step: int,
+                       workers: int, got: np.ndarray = None, tile: int = 10_000_000):
+    """One whole contig through the C oracle (gdo_perbase_diff) in W-aligned tiles of ~`tile` positions, `workers`
+    tiles at a time (ctypes and the numpy reductions release the GIL) -- what makes a 3.1 Gb genome affordable:
+    the per-base vector of a tile is compared with got[s:e] right away (never held for the whole contig), and the
+    tile's window sums / minima and class-run starts (depth/depth.go:293-323: a break where the class changes and at
+    multiples of `step`) are kept.  Reads that start before a tile but reach into it are found through the running
+    maximum of the read ends, so any read length is handled.
+    -> dict(equal, first_diff, sums int64[nw], mins int32[nw], run_starts int64[k], run_cls int8[k])"""
+    from concurrent.futures import ThreadPoolExecutor
+    lib()
+    tile = max(W, tile // W * W)
+    cmax = np.maximum.accumulate(read_ends(r)) if r.n else np.zeros(0, np.int64)
+    jobs = [(s, min(length, s + tile)) for s in range(0, length, tile)]
+
+    def one(j):
+        s, e = jobs[j]
+        lo = int(np.searchsorted(cmax, s, "right"))       # reads before it end at or before s
+        hi = int(np.searchsorted(r.pos, e, "left"))
+        s1 = s - 1 if s > 0 else 0                        # the class before the tile's first position
+        d1 = perbase_c(r.slice(min(lo, hi), hi), q, s1, e, diff=True)
+        d = d1[s - s1:]
+        eq, first = True, -1
+        if got is not None:
+            g = got[s:e]
+            if not np.array_equal(g, d):
+                eq, first = False, s + int(np.flatnonzero(g != d)[0])
+        edges = np.arange(0, e - s, W)
+        sums = np.add.reduceat(d.astype(np.int64), edges)
+        mins = np.minimum.reduceat(d, edges)
+        cls = np.where(d1 == 0, 0, np.where(d1 < mincov, 1, np.where((maxmean > 0) & (d1 >= maxmean), 3, 2))).astype(np.int8)
+        c = cls[s - s1:]
+        brk = np.empty(e - s, bool)
+        brk[0] = True if s == 0 else (c[0] != cls[0])
+        brk[1:] = c[1:] != c[:-1]
+        brk[(-s) % step::step] = True
+        st = np.flatnonzero(brk)
+        return eq, first, sums, mins, st + s, c[st]
+
+    with ThreadPoolExecutor(max_workers=max(1, workers)) as ex:
+        res = list(ex.map(one, range(len(jobs))))
+    bad = [x[1] for x in res if not x[0]]
+    z64, z32, z8 = np.zeros(0, np.int64), np.zeros(0, np.int32), np.zeros(0, np.int8)
+    return {"equal": not bad, "first_diff": min(bad) if bad else -1,
+            "sums": np.concatenate([x[2] for x in res]) if res else z64,
+            "mins": np.concatenate([x[3] for x in res]) if res else z32,
+            "run_starts": np.concatenate([x[4] for x in res]) if res else z64,
+            "run_cls": np.concatenate([x[5] for x in res]) if res else z8}
+
+
 def chrom_start_end_c(line: bytes):
     chrom = ctypes.create_string_buffer(1024)
     s, e = ctypes.c_long(), ctypes.c_long()

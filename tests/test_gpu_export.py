@@ -55,3 +55,37 @@ def test_export_block_equals_results():
                 eng.compute()
             eng.set_export(0, 0, 0)
             eng.compute()
+
+
+def test_export_attached_before_the_first_compute_with_more_runs_than_the_initial_capacity():
+    """gd_set_export before any compute, a job with more class boundaries than the boundary arrays hold at first
+    (65 536): the first attempt's export must not read past the ordered array (it is clamped to its capacity);
+    gd_compute grows the arrays, runs again, and the block is complete."""
+    import torch
+    from goleft_amd import shard
+    from goleft_amd.engine import DepthEngine
+    L = 400_000
+    pos = np.arange(0, 300_000, 4, dtype=np.int32)                 # 75 000 one-base reads: 150 000 class changes
+    n = len(pos)
+    r = po.Reads(pos, np.zeros(n, np.uint16), np.full(n, 60, np.uint8), np.arange(n + 1, dtype=np.uint32),
+                 np.full(n, (1 << 4) | 0, np.uint32))
+    W = 1000
+    nw = shard.n_windows(L, W)
+    cap_b = 1 << 18
+    words_m = (nw + 1) // 2
+    dev = torch.device("cuda", 0)
+    buf = torch.full((1 + nw + words_m + cap_b,), -1, dtype=torch.int64, device=dev)
+    with DepthEngine(0) as eng:
+        eng.set_params(window_size=W, min_mapq=1, min_cov=4)
+        eng.set_contigs([L])
+        eng.push(0, r.pos, r.flag, r.mapq, r.cigar_off, r.cigar)
+        eng.set_export(buf.data_ptr(), nw, cap_b)
+        eng.compute()
+        assert eng.stats().reruns >= 1
+        torch.cuda.synchronize()
+        h = buf.cpu().numpy()
+        d = po.perbase_c(r, 1, 0, L)
+        want = H.oracle_runs(d, 4, 0, po.step_for(W))
+        assert int(h[0]) == len(want) > 65536
+        got = h[1 + nw + words_m:1 + nw + words_m + len(want)].view(np.int32).reshape(-1, 2)
+        assert np.array_equal(got, np.stack([want[:, 0], want[:, 2]], 1))

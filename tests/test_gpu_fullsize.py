@@ -87,7 +87,7 @@ def test_ont_chr20_full_size_chunk_path():
 # ---------------------------------------------------------------------------------------------------------
 # BASELINE.json's FULL sizes (config 3: 30x WGS, 3.1 Gb; config 5: 20x ONT-like WGS), checked through
 # size-independent properties computed ON THE DEVICE with torch from the record streams and the engine's own
-# per-base vector -- no oracle can walk 3.1 Gb in seconds, these can:
+# per-base vector (the bit-for-bit comparison with the oracle, every contig, all host cores, follows below):
 #   * conservation: every contig's per-base vector adds up to the M/=/X bases of its kept reads that fall inside
 #     the contig (computed from the records alone, independent of any engine structure);
 #   * window sums / minima equal reductions of the per-base vector;
@@ -181,6 +181,95 @@ def test_config5_ont_wgs_full_size_properties():
         eng.compute()
         assert eng.stats().path == 3                                                 # GD_PATH_CHUNK chosen by AUTO
         _check_genome_properties(torch, eng, dev, lengths, streams, po.step_for(W))
+
+
+def _bit_compare_genome(eng, lengths, streams, Wd, q, mincov, maxmean=0):
+    """EVERY contig of a resident genome against the C oracle, bit for bit: the per-base vector (compared tile by
+    tile as the oracle produces it, oracle/pyoracle.py::tiled_contig_check, all host cores), and window sums /
+    minima / class runs derived from the ORACLE's vector -- nothing here reads the engine's own per-base output
+    to judge its other outputs."""
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    cores = os.cpu_count() or 8
+    outer = 4                                                  # contigs in flight (their host-side numpy passes overlap)
+    step = po.step_for(Wd)
+
+    def one(t):
+        a = [x.cpu().numpy() for x in streams[t]]
+        r = po.Reads(a[0], a[1].view(np.uint16), a[2], a[3].view(np.uint32), a[4].view(np.uint32))
+        got = eng.perbase(t)
+        res = po.tiled_contig_check(r, q, lengths[t], Wd, mincov, maxmean, step, max(2, cores // outer), got=got)
+        assert res["equal"], "contig %d: per-base depth differs from the oracle, first at %d" % (t, res["first_diff"])
+        sums, mins = eng.windows(t)
+        assert np.array_equal(sums, res["sums"]), "contig %d: window sums" % t
+        assert np.array_equal(mins, res["mins"]), "contig %d: window minima" % t
+        runs = eng.callable_runs(t)
+        assert np.array_equal(runs[:, 0], res["run_starts"]), "contig %d: run starts" % t
+        assert np.array_equal(runs[:, 2], res["run_cls"]), "contig %d: run classes" % t
+        assert runs[-1, 1] == lengths[t] and np.array_equal(runs[1:, 0], runs[:-1, 1])
+        return lengths[t]
+
+    with ThreadPoolExecutor(max_workers=outer) as ex:
+        assert sum(ex.map(one, range(len(lengths)))) == sum(lengths)
+
+
+def test_config3_wgs_full_size_bit_exact():
+    """BASELINE.json config 3 at its full size, every contig compared with the C oracle bit for bit (30x WGS, hg19
+    lengths, 619 M reads): what bench.py's headline is quoted on, through the kernel the default configuration
+    runs -- the straight-line tile kernel on the records as they arrived -- and, after gd_normalize, through the
+    canonical one."""
+    import torch
+    from goleft_amd import engine as E
+    dev = torch.device("cuda", 0)
+    lengths = list(synth.HG19_LENGTHS)
+    with E.DepthEngine(0) as eng:
+        eng.set_params(window_size=W, min_mapq=Q, min_cov=MINCOV)
+        eng.set_contigs(lengths)
+        streams = []
+        for t, Lt in enumerate(lengths):
+            s = synth.short_reads_torch(Lt, synth.n_reads_for(Lt), t + 1, dev)
+            streams.append(s)
+            eng.adopt_device(t, *s)
+        eng.compute()
+        st = eng.stats()
+        assert st.n_reads == 619_135_482 and st.tile_kernel == E.TK_FAST_RAW and st.n_slow_tiles < 100
+        _bit_compare_genome(eng, lengths, streams, W, Q, MINCOV)
+        eng.normalize()
+        eng.compute()
+        assert eng.stats().tile_kernel == E.TK_FAST
+        # the canonical kernel against the raw one's (verified) output: every contig's vector, on the device
+        from goleft_amd import shard
+        chk = []
+        for t in range(len(lengths)):
+            p, n = eng.device_perbase(t)
+            chk.append(int(shard.device_view(p, n, torch.int32, dev).sum(dtype=torch.int64).item()))
+        got_sums = np.concatenate([eng.windows(t)[0] for t in range(len(lengths))])
+        eng.drop_derived()
+        eng.compute()
+        assert np.array_equal(got_sums, np.concatenate([eng.windows(t)[0] for t in range(len(lengths))]))
+        for t in range(len(lengths)):
+            p, n = eng.device_perbase(t)
+            assert chk[t] == int(shard.device_view(p, n, torch.int32, dev).sum(dtype=torch.int64).item())
+
+
+def test_config5_ont_wgs_full_size_bit_exact():
+    """BASELINE.json config 5 at its full size (20x ONT-like WGS, 4.8e9 CIGAR ops), every contig compared with the
+    C oracle bit for bit."""
+    import torch
+    from goleft_amd.engine import DepthEngine
+    dev = torch.device("cuda", 0)
+    lengths = list(synth.HG19_LENGTHS)
+    with DepthEngine(0) as eng:
+        eng.set_params(window_size=W, min_mapq=Q, min_cov=MINCOV)
+        eng.set_contigs(lengths)
+        streams = []
+        for t, Lt in enumerate(lengths):
+            s = synth.ont_reads_torch(Lt, synth.n_ont_reads_for(Lt, 20.0), t + 1, dev)
+            streams.append(s)
+            eng.adopt_device(t, *s)
+        eng.compute()
+        assert eng.stats().path == 3
+        _bit_compare_genome(eng, lengths, streams, W, Q, MINCOV)
 
 
 def test_config4_cohort_full_size_properties():
