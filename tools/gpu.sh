@@ -19,8 +19,9 @@ print("  kernels_ms", d["kernels_ms"], "slow tiles", d["config"].get("tiles_on_t
 for st in "$@"; do
   case "$st" in
     tests*)
-      echo "== pytest -m gpu ${st#tests}" >> $LOG
-      timeout 1500 python -X faulthandler -m pytest tests -m gpu -x -q ${st#tests} > gpurun_out/${T}_pytest.txt 2>&1
+      what=${st#tests}; case "$what" in *tests/*) ;; *) what="tests $what";; esac      # "tests" = the whole directory; "tests tests/x.py -k y" = just that
+      echo "== pytest -m gpu $what" >> $LOG
+      timeout 1500 python -X faulthandler -m pytest -m gpu -x -q $what > gpurun_out/${T}_pytest.txt 2>&1
       grep -n "Fatal\|fault\|tests/.*line\|passed\|failed\|Error" gpurun_out/${T}_pytest.txt | head -30 >> $LOG
       tail -5 gpurun_out/${T}_pytest.txt >> $LOG ;;
     bench:*)
