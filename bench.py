@@ -72,6 +72,10 @@ def parse():
                     help="skip the PCIe-inclusive scope (host records -> pinned ring -> results on host)")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE",
                     help="experiments only: gd_set_option(KEY, VALUE) on the engine (include/goleft_depth.h GD_OPT_*)")
+    ap.add_argument("--emulate-shards", default="2,4,8", metavar="N[,N...]",
+                    help="N = 1 only: time every LPT shard of the N-GPU job on THIS device, one after the other "
+                         "(gd_select_contigs per shard, export block attached) -> per-shard ms and the projected "
+                         "speed-up step(1) / max shard; '' = off")
     ap.add_argument("--verify", action="store_true",
                     help="check one contig against the CPU oracle after timing")
     return ap.parse_args()
@@ -110,40 +114,97 @@ def cpu_baseline(sample, W, mincov, cores):
     return bases / dt, bases, dt
 
 
-def host_stream_scope(local_rank, W, Q, mincov, reps=3):
-    """SURVEY.md section 8d scope (ii), reported next to -- never as -- `value`: the chr20
-    stream of BASELINE.json config 2 starts in ordinary HOST memory, goes through the
-    library's pinned 3-slot ring (gd_push = memcpy into pinned blocks + asynchronous H2D
-    over PCIe), is computed, and the window sums / minima and class runs come back to the
-    host.  Everything a cgo caller would pay except the BAM decode itself."""
+def _batch_views(b, n, m):
+    """numpy views of a gd_acquire block (library-owned pinned memory)."""
+    import ctypes as C
+
+    def view(ptr, ct, k):
+        return np.ctypeslib.as_array((ct * max(1, k)).from_address(ptr))[:k]
+    return (view(b.pos, C.c_int32, n), view(b.flag, C.c_uint16, n), view(b.mapq, C.c_uint8, n),
+            view(b.cigar_off, C.c_uint32, n + 1), view(b.cigar, C.c_uint32, m))
+
+
+def host_stream_scope(local_rank, W, Q, mincov, genome=False, reps=3):
+    """SURVEY.md section 8d scope (ii), reported next to -- never as -- `value`: the records of
+    BASELINE.json config 2 (chr20; genome=True: config 3, the whole 30x genome) start in ordinary
+    HOST memory, go through the library's pinned ring and over PCIe, are computed, and the window
+    sums / minima and class runs come back to the host.  Everything a cgo caller would pay except
+    the BAM decode itself.  Two ways in:
+      push      gd_push from pageable arrays (the library's threads copy into the pinned blocks);
+      in_place  gd_acquire -> the caller's threads write the block in place -> gd_commit, what
+                INTEGRATION.md tells the Go host to do (its BAM decoder writes into the block; here
+                the "decoder" is a pool of threads copying from the same arrays)."""
+    from concurrent.futures import ThreadPoolExecutor
     from goleft_amd import synth
     from goleft_amd.engine import DepthEngine
-    L = synth.CHR20_LEN
-    n = synth.n_reads_for(L)
     import torch
     dev = torch.device("cuda", local_rank)
-    # generated on the device (the numpy twin is bit identical but slow), then moved to host memory
-    t = [x.cpu().numpy() for x in synth.short_reads_torch(L, n, 20, dev)]
-    rec = (t[0], t[1].view(np.uint16), t[2], t[3].view(np.uint32), t[4].view(np.uint32))
-    nbytes = sum(int(a.nbytes) for a in rec)
-    best = None
+    lengths = list(synth.HG19_LENGTHS) if genome else [synth.CHR20_LEN]
+    seeds = list(range(1, len(lengths) + 1)) if genome else [20]
+    recs = []
+    for L, sd in zip(lengths, seeds):
+        # generated on the device (the numpy twin is bit identical but slow), then moved to host memory
+        t = [x.cpu().numpy() for x in synth.short_reads_torch(L, synth.n_reads_for(L), sd, dev)]
+        recs.append((t[0], t[1].view(np.uint16), t[2], t[3].view(np.uint32), t[4].view(np.uint32)))
+    torch.cuda.empty_cache()
+    nbytes = sum(int(a.nbytes) for rec in recs for a in rec)
+    n_reads = sum(int(rec[0].shape[0]) for rec in recs)
+    fillers = min(16, max(2, (os.cpu_count() or 4) // 4))
+    pool = ThreadPoolExecutor(max_workers=fillers)
+    chunk = 1 << 21
+
+    def in_place(eng):
+        for tid, (pos, flag, mapq, off, cig) in enumerate(recs):
+            n_all = pos.shape[0]
+            for i in range(0, n_all, chunk):
+                n = min(chunk, n_all - i)
+                o0, o1 = int(off[i]), int(off[i + n])
+                b = eng.acquire(n, o1 - o0)
+                vp, vf, vq, vo, vc = _batch_views(b, n, o1 - o0)
+                jobs = []
+                for dst, src in ((vp, pos[i:i + n]), (vf, flag[i:i + n]), (vq, mapq[i:i + n]), (vc, cig[o0:o1])):
+                    k = dst.shape[0]
+                    step = max(1, -(-k // fillers))
+                    jobs += [(dst[j:j + step], src[j:j + step], 0) for j in range(0, k, step)]
+                step = max(1, -(-(n + 1) // fillers))
+                jobs += [(vo[j:j + step], off[i + j:i + j + step], o0) for j in range(0, n + 1, step)]
+                list(pool.map(lambda a: np.subtract(a[1], np.uint32(a[2]), out=a[0]) if a[2] else np.copyto(a[0], a[1]), jobs))
+                eng.commit(b, tid, n, o1 - o0)
+
+    def push(eng):
+        for tid, rec in enumerate(recs):
+            eng.push(tid, *rec)
+
+    out = {}
     with DepthEngine(local_rank) as eng:
         eng.set_params(window_size=W, min_mapq=Q, min_cov=mincov)
-        eng.set_contigs([L])
-        for _ in range(reps + 1):                    # first pass grows the device arrays (untimed)
-            eng.reset()
-            t0 = time.perf_counter()
-            eng.push(0, *rec)
-            eng.compute()
-            sums, mins = eng.windows(0)
-            runs = eng.callable_runs(0)
-            dt = time.perf_counter() - t0
-            if _ > 0 and (best is None or dt < best):
-                best = dt
-    return {"value": L / best, "unit": "ref-bases/s", "ms": best * 1e3,
-            "workload": "synthetic 30x chr20 (63 Mb), %d reads, %.0f MB of records from host memory" % (n, nbytes / 1e6),
-            "includes": "memcpy into the pinned ring + H2D + gd_compute + D2H of window sums/minima and class runs",
-            "host_to_device_GBps": nbytes / best / 1e9}
+        eng.set_contigs(lengths)
+        for name, feed in (("push", push), ("in_place", in_place)):
+            best = None
+            for rep in range(reps + 1):                  # the first pass grows the device arrays and the ring (untimed)
+                eng.reset()
+                t0 = time.perf_counter()
+                feed(eng)
+                t1 = time.perf_counter()
+                eng.compute()
+                for tid in range(len(lengths)):
+                    eng.windows(tid)
+                    eng.callable_runs(tid)
+                dt = time.perf_counter() - t0
+                if rep > 0 and (best is None or dt < best[0]):
+                    best = (dt, t1 - t0)
+            out[name] = {"value": sum(lengths) / best[0], "unit": "ref-bases/s", "ms": best[0] * 1e3,
+                         "feed_ms": best[1] * 1e3, "host_to_device_GBps": nbytes / best[0] / 1e9,
+                         "feed_GBps": nbytes / best[1] / 1e9}
+    pool.shutdown()
+    better = max(out, key=lambda k: out[k]["value"])
+    return {"value": out[better]["value"], "unit": "ref-bases/s", "ms": out[better]["ms"], "best": better,
+            "workload": "synthetic 30x %s, %d reads, %.0f MB of records from host memory"
+                        % ("WGS (3.1 Gb)" if genome else "chr20 (63 Mb)", n_reads, nbytes / 1e6),
+            "includes": "host arrays -> pinned ring -> H2D + gd_compute on the records as they arrived + D2H of window "
+                        "sums/minima and class runs; feed_ms: until the last block is committed (copies may still be in flight)",
+            "host_to_device_GBps": out[better]["host_to_device_GBps"], "variants": out,
+            "in_place_filler_threads": fillers}
 
 
 def load_traffic(tag, kernel):
@@ -402,6 +463,39 @@ def run_case(args, scaling, world, rank, dev, local_rank, want_streams=False):
                 tot += int(p[:gath.nwin[r_]].sum().item())
             split["gathered_sum_of_window_sums"] = tot
 
+    # ---- the N-GPU job's shards, one after the other on this device (a measured stand-in for the scaling curve) ----
+    emu = None
+    if world == 1 and args.emulate_shards and not cohort:
+        emu = {}
+        for N in [int(x) for x in args.emulate_shards.split(",") if x.strip()]:
+            if N < 2 or N > len(lengths):
+                continue
+            asg = shard.lpt_assign(lengths, N)
+            per, gbytes = [], []
+            for r_ in range(N):
+                eng.select_contigs(asg[r_])
+                nw_r = sum(shard.n_windows(lengths[t], W) for t in asg[r_])
+                cap_b = 1 << 16
+                buf = torch.zeros(1 + nw_r + (nw_r + 1) // 2 + cap_b, dtype=torch.int64, device=dev)
+                eng.set_export(buf.data_ptr(), nw_r, cap_b)
+                for _ in range(max(2, args.warmup)):
+                    step()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(args.steps):
+                    step()
+                torch.cuda.synchronize()
+                per.append((time.perf_counter() - t1) / args.steps * 1e3)
+                gbytes.append(int(buf.numel() * 8))
+                eng.set_export(0, 0, 0)
+                del buf
+            loads = [sum(lengths[t] for t in a) for a in asg]
+            emu[str(N)] = {"per_shard_ms": per, "max_shard_ms": max(per), "shard_ref_bases": loads,
+                           "projected_speedup": (dt / args.steps * 1e3) / max(per),
+                           "lpt_speedup_ceiling": sum(loads) / max(loads), "gather_bytes_per_rank": gbytes}
+        eng.select_contigs(mine)
+        eng.compute()
+
     st = eng.stats()
     my_bases = sum(lengths[t] for t in mine)
     my_windows = sum(shard.n_windows(lengths[t], W) for t in mine)
@@ -415,7 +509,7 @@ def run_case(args, scaling, world, rank, dev, local_rank, want_streams=False):
         "expand_ms": float(np.mean(expand_ms)), "scan_ms": float(np.mean(scan_ms)), "path": int(st.path),
         "ckpt_ms": float(np.mean(ckpt_ms)), "norm_ms": float(np.mean(norm_ms)), "only": only, "derive": derive,
         "n_canonical_ops": incl_canon, "n_slow_tiles": incl_slow, "kernel": TK_NAMES[incl_kernel],
-        "perbase": not cohort, "wed_shape": wed.get("shape"), "split": split,
+        "perbase": not cohort, "wed_shape": wed.get("shape"), "split": split, "emu": emu,
     }
     if not want_streams:
         streams.clear()
@@ -565,6 +659,14 @@ def main():
             "kernels_ms": o["normalise_kernels_ms"], "wall_ms": o["normalise_wall_ms"],
             "wall_ms_first_call_with_allocation": o["normalise_wall_first_ms"],
             "long_read_structures_kernels_ms": o["checkpoint_kernels_ms"], "algorithmic_bytes": nb}
+    if r.get("emu"):
+        out["emulated_sharding"] = {
+            "what": "every LPT shard of the N-GPU job (BASELINE.json config 3: one genome, contigs by LPT) computed on THIS "
+                    "one device, one shard after the other: the same step as the headline incl. the export block every rank "
+                    "hands to the gather; projected_speedup = step(N=1) / slowest shard.  The gather itself (one "
+                    "asynchronous collective of gather_bytes_per_rank per rank to rank 0, issued under the next step's "
+                    "kernels) is not in it: no second GPU here",
+            "by_n_gpus": r["emu"]}
     if world == 1 and args.workload != "cohort":
         from goleft_amd import shard as _sh
         # checksum of checksums: equals "split.gathered_sum_of_window_sums" of an N > 1 run of the same workload
@@ -602,6 +704,9 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_host_stream and args.workload in ("wgs", "chr20"):
         out["host_stream_scope"] = host_stream_scope(local_rank, W, Q, mincov)
+        if args.workload == "wgs":
+            # the genome-sized run needs the HBM the resident streams hold: measured after they are released (below)
+            out["host_stream_scope_wgs"] = "pending"
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:      # a reported baseline, N = 1 only
         from oracle import pyoracle as po
@@ -631,6 +736,12 @@ def main():
     eng.close()
     streams.clear()
     del r
+    if out.get("host_stream_scope_wgs") == "pending":
+        torch.cuda.empty_cache()
+        try:
+            out["host_stream_scope_wgs"] = host_stream_scope(local_rank, W, Q, mincov, genome=True, reps=1)
+        except Exception as e:                       # never lose the headline line to a side measurement
+            out["host_stream_scope_wgs"] = {"error": "%s: %s" % (type(e).__name__, e)}
 
     if r_split is not None:
         out["split"] = r_split

@@ -103,6 +103,7 @@ SYMBOLS = {
     "gd_drop_derived": (C.c_int, [_P]),
     "gd_canonical_cigars": (C.c_int, [_P, C.c_int32, _P, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
     "gd_set_export": (C.c_int, [_P, _P, C.c_int64, C.c_int64]),
+    "gd_wait_event": (C.c_int, [_P, _P]),
     "gd_get_stats": (C.c_int, [_P, C.POINTER(GdStats)]),
     "gd_set_profiling": (C.c_int, [_P, C.c_int]),
     "gd_kernel_ms": (C.c_int, [_P, C.c_int, C.POINTER(C.c_float)]),

@@ -8,7 +8,7 @@
 
 namespace {
 
-constexpr int kRingSlots = 3;
+constexpr int kRingSlots = 4;
 constexpr size_t kSpecBounds = 4096;     // boundaries copied to the host before their count is known (one synchronisation)
 constexpr int kDefaultLookback = 512;
 constexpr uint64_t kMaxReadsPerContig = 1ull << 30;
@@ -193,6 +193,7 @@ struct gd_ctx {
     hipStream_t ing_stream[8] = {};                     // inflate launches rotate over these (two pending ranges x 4)
     unsigned ing_launch_seq = 0;
     int ing_copy_threads = 1;                          // GD_OPT_COPY_THREADS: threads filling the staging buffer
+    int push_threads = 8;                              // GD_OPT_PUSH_THREADS: threads of gd_push filling a ring block
     uint32_t* d_scan_tmp = nullptr; size_t cap_scan_tmp = 0;   // launch_scan: block totals
     uint8_t* d_seq = nullptr;  size_t cap_seq = 0;     // gd_seq_load: one contig's bases, zero padded
     int64_t seq_len = -1;

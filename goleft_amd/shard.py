@@ -107,17 +107,27 @@ class RootGather:
             self._recvs = [torch.zeros(self.world, self.total, dtype=torch.int64, device=self.device) for _ in range(2)]
             self._partss = [list(r.unbind(0)) for r in self._recvs]   # views of the receive buffers
         self._works = [None, None]
+        self._events = [None, None]
         self._cur = 0                                           # the buffer pair the NEXT step uses
         self._last = 0                                          # the pair the last step used
         self.send, self.recv = self._sends[0], self._recvs[0]
 
-    def _wait(self, k: int):
-        """The collective that last used buffer pair k has finished (host side)."""
+    def _wait(self, k: int, host: bool = True):
+        """The collective that last used buffer pair k has finished: on the host (host=True), or only in stream
+        order -- the attached engine's stream then waits for it through an event and the host goes on (what flip()
+        needs: the next compute must not write into a buffer the collective of two steps ago may still read; with
+        a rank's step at ~0.5 ms a blocking wait here was the kind of fixed cost that decides 6x or 7x at N = 8)."""
         w = self._works[k] if getattr(self, "_works", None) else None
         if w is not None:
-            w.wait()
-            if self.device is not None and torch.device(self.device).type == "cuda":
-                torch.cuda.current_stream(self.device).synchronize()   # NCCL's wait() only orders the stream
+            w.wait()                                            # NCCL: the current torch stream waits; gloo: the host does
+            cuda = self.device is not None and torch.device(self.device).type == "cuda"
+            if cuda and not host and self._eng is not None and hasattr(self._eng, "wait_event"):
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(self.device))
+                self._eng.wait_event(ev.cuda_event)
+                self._events[k] = ev                            # (kept alive until the pair is waited for again)
+            elif cuda:
+                torch.cuda.current_stream(self.device).synchronize()
             self._works[k] = None
 
     def drain(self):
@@ -130,7 +140,7 @@ class RootGather:
         Its collective (two steps ago) must be over before anything writes into it again."""
         self._last = self._cur
         self._cur ^= 1
-        self._wait(self._cur)
+        self._wait(self._cur, host=False)
         self.send, self.recv = self._sends[self._cur], self._recvs[self._last]
         if self._eng is not None:
             self._eng.set_export(self.send.data_ptr(), self.max_w, self.cap_b)

@@ -189,7 +189,9 @@ enum { /* (1, 2: tile shapes other than 4096 positions x 256 threads -- measured
                                        gd_normalize builds them on request under every setting. */
        GD_OPT_FAST_KERNEL = 5,      /* 1 (default): ordinary tiles run the straight-line tile kernel, the rest the
                                        generic one; 0: the generic kernel for every tile */
-       GD_OPT_COPY_THREADS = 6 };   /* host threads filling the staging buffer of gd_ingest_feed: 1 (default) .. 16 */
+       GD_OPT_COPY_THREADS = 6,     /* host threads filling the staging buffer of gd_ingest_feed: 1 (default) .. 16 */
+       GD_OPT_PUSH_THREADS = 7 };   /* host threads of gd_push copying into a pinned ring block: 8 (default), 1 .. 64
+                                       (one core moves ~11 GB/s into pinned memory; the link takes five times that) */
 int gd_set_option(gd_ctx* ctx, int option, int64_t value);
 
 /* Builds the canonical records of every selected contig that lacks them (force != 0: of every selected contig,
@@ -478,6 +480,11 @@ int gd_device_runs(gd_ctx* ctx, const int32_t** d_bounds, size_t* n_bounds);
  * ascending tid order; a boundary is {int32 pos, int32 cls | index_among_computed_contigs << 2}.
  * GD_E_CAPACITY from gd_compute if the job has more windows than max_windows.  NULL switches it off. */
 int gd_set_export(gd_ctx* ctx, void* device_buf, int64_t max_windows, int64_t cap_bounds);
+/* Everything this context enqueues from now on waits for `hip_event` (a hipEvent_t the caller recorded on a
+ * stream of its own, passed as void*): how a caller that hands the export block to a collective tells the
+ * engine "the collective that was still reading this buffer is over" without blocking the host
+ * (hipStreamWaitEvent on the context's stream). */
+int gd_wait_event(gd_ctx* ctx, void* hip_event);
 
 /* ---- measurement ---------------------------------------------------------*/
 int gd_get_stats(gd_ctx* ctx, gd_stats* out);
