@@ -114,17 +114,7 @@ def cpu_baseline(sample, W, mincov, cores):
     return bases / dt, bases, dt
 
 
-def _batch_views(b, n, m):
-    """numpy views of a gd_acquire block (library-owned pinned memory)."""
-    import ctypes as C
-
-    def view(ptr, ct, k):
-        return np.ctypeslib.as_array((ct * max(1, k)).from_address(ptr))[:k]
-    return (view(b.pos, C.c_int32, n), view(b.flag, C.c_uint16, n), view(b.mapq, C.c_uint8, n),
-            view(b.cigar_off, C.c_uint32, n + 1), view(b.cigar, C.c_uint32, m))
-
-
-def host_stream_scope(local_rank, W, Q, mincov, genome=False, reps=3):
+def host_stream_scope(local_rank, W, Q, mincov, genome=False, reps=3, opts=()):
     """SURVEY.md section 8d scope (ii), reported next to -- never as -- `value`: the records of
     BASELINE.json config 2 (chr20; genome=True: config 3, the whole 30x genome) start in ordinary
     HOST memory, go through the library's pinned ring and over PCIe, are computed, and the window
@@ -134,7 +124,6 @@ def host_stream_scope(local_rank, W, Q, mincov, genome=False, reps=3):
       in_place  gd_acquire -> the caller's threads write the block in place -> gd_commit, what
                 INTEGRATION.md tells the Go host to do (its BAM decoder writes into the block; here
                 the "decoder" is a pool of threads copying from the same arrays)."""
-    from concurrent.futures import ThreadPoolExecutor
     from goleft_amd import synth
     from goleft_amd.engine import DepthEngine
     import torch
@@ -150,26 +139,16 @@ def host_stream_scope(local_rank, W, Q, mincov, genome=False, reps=3):
     nbytes = sum(int(a.nbytes) for rec in recs for a in rec)
     n_reads = sum(int(rec[0].shape[0]) for rec in recs)
     fillers = min(16, max(2, (os.cpu_count() or 4) // 4))
-    pool = ThreadPoolExecutor(max_workers=fillers)
-    chunk = 1 << 21
+    from goleft_amd import _hostlib
+    hostlib = _hostlib.load()
 
     def in_place(eng):
+        # the host library's producer: gd_acquire -> `fillers` threads write the block in place -> gd_commit
         for tid, (pos, flag, mapq, off, cig) in enumerate(recs):
-            n_all = pos.shape[0]
-            for i in range(0, n_all, chunk):
-                n = min(chunk, n_all - i)
-                o0, o1 = int(off[i]), int(off[i + n])
-                b = eng.acquire(n, o1 - o0)
-                vp, vf, vq, vo, vc = _batch_views(b, n, o1 - o0)
-                jobs = []
-                for dst, src in ((vp, pos[i:i + n]), (vf, flag[i:i + n]), (vq, mapq[i:i + n]), (vc, cig[o0:o1])):
-                    k = dst.shape[0]
-                    step = max(1, -(-k // fillers))
-                    jobs += [(dst[j:j + step], src[j:j + step], 0) for j in range(0, k, step)]
-                step = max(1, -(-(n + 1) // fillers))
-                jobs += [(vo[j:j + step], off[i + j:i + j + step], o0) for j in range(0, n + 1, step)]
-                list(pool.map(lambda a: np.subtract(a[1], np.uint32(a[2]), out=a[0]) if a[2] else np.copyto(a[0], a[1]), jobs))
-                eng.commit(b, tid, n, o1 - o0)
+            rc = hostlib.gdh_produce_in_place(eng._ctx, tid, pos.ctypes.data, flag.ctypes.data, mapq.ctypes.data,
+                                              off.ctypes.data, cig.ctypes.data, pos.shape[0], cig.shape[0], fillers, 1 << 20)
+            if rc != 0:
+                raise RuntimeError("gdh_produce_in_place: %d" % rc)
 
     def push(eng):
         for tid, rec in enumerate(recs):
@@ -178,6 +157,9 @@ def host_stream_scope(local_rank, W, Q, mincov, genome=False, reps=3):
     out = {}
     with DepthEngine(local_rank) as eng:
         eng.set_params(window_size=W, min_mapq=Q, min_cov=mincov)
+        for kv in opts:
+            k, v = kv.split("=")
+            eng.set_option(int(k), int(v))
         eng.set_contigs(lengths)
         for name, feed in (("push", push), ("in_place", in_place)):
             best = None
@@ -196,7 +178,6 @@ def host_stream_scope(local_rank, W, Q, mincov, genome=False, reps=3):
             out[name] = {"value": sum(lengths) / best[0], "unit": "ref-bases/s", "ms": best[0] * 1e3,
                          "feed_ms": best[1] * 1e3, "host_to_device_GBps": nbytes / best[0] / 1e9,
                          "feed_GBps": nbytes / best[1] / 1e9}
-    pool.shutdown()
     better = max(out, key=lambda k: out[k]["value"])
     return {"value": out[better]["value"], "unit": "ref-bases/s", "ms": out[better]["ms"], "best": better,
             "workload": "synthetic 30x %s, %d reads, %.0f MB of records from host memory"
@@ -703,7 +684,7 @@ def main():
             out["verified_mismatch"] = bad
 
     if rank == 0 and world == 1 and not args.no_host_stream and args.workload in ("wgs", "chr20"):
-        out["host_stream_scope"] = host_stream_scope(local_rank, W, Q, mincov)
+        out["host_stream_scope"] = host_stream_scope(local_rank, W, Q, mincov, opts=args.opt)
         if args.workload == "wgs":
             # the genome-sized run needs the HBM the resident streams hold: measured after they are released (below)
             out["host_stream_scope_wgs"] = "pending"
@@ -739,7 +720,7 @@ def main():
     if out.get("host_stream_scope_wgs") == "pending":
         torch.cuda.empty_cache()
         try:
-            out["host_stream_scope_wgs"] = host_stream_scope(local_rank, W, Q, mincov, genome=True, reps=1)
+            out["host_stream_scope_wgs"] = host_stream_scope(local_rank, W, Q, mincov, genome=True, reps=1, opts=args.opt)
         except Exception as e:                       # never lose the headline line to a side measurement
             out["host_stream_scope_wgs"] = {"error": "%s: %s" % (type(e).__name__, e)}
 

@@ -267,7 +267,35 @@ int gd_acquire(gd_ctx* c, size_t reads_cap, size_t ops_cap, gd_batch* out)
     return GD_OK;
 }
 
+static int commit_block(gd_ctx* c, const gd_batch* b, int32_t tid, size_t n_reads, size_t n_ops, bool validated);
+
 int gd_commit(gd_ctx* c, const gd_batch* b, int32_t tid, size_t n_reads, size_t n_ops)
+{
+    return commit_block(c, b, tid, n_reads, n_ops, false);
+}
+
+// Makes room for n_reads / n_ops more records of a contig in ONE step (a producer that knows its totals: gd_push;
+// growing geometrically block by block drains the copy pipeline at every step).
+static int reserve_records(gd_ctx* c, ContigHost& h, size_t n_reads, size_t n_ops)
+{
+    const size_t need_r = h.n_reads + n_reads, need_o = h.n_ops + n_ops;
+    if (need_r > h.cap_reads) {
+        size_t c1 = h.cap_reads, c2 = h.cap_reads, c3 = h.cap_reads, c4 = h.cap_reads ? h.cap_reads + 1 : 0;
+        if (int r = ensure_dev(c, &h.pos, &c1, need_r, true, h.n_reads)) return r;
+        if (int r = ensure_dev(c, &h.flag, &c2, need_r, true, h.n_reads)) return r;
+        if (int r = ensure_dev(c, &h.mapq, &c3, need_r, true, h.n_reads)) return r;
+        if (int r = ensure_dev(c, &h.off, &c4, need_r + 1, true, h.n_reads ? h.n_reads + 1 : 0)) return r;
+        h.cap_reads = need_r;
+    }
+    if (need_o > h.cap_ops) {
+        size_t co = h.cap_ops;
+        if (int r = ensure_dev(c, &h.cigar, &co, need_o, true, h.n_ops)) return r;
+        h.cap_ops = need_o;
+    }
+    return GD_OK;
+}
+
+static int commit_block(gd_ctx* c, const gd_batch* b, int32_t tid, size_t n_reads, size_t n_ops, bool validated)
 {
     if (c && c->cs.pending) return fail(c, GD_E_STATE, "a compute is in flight: gd_compute_finish first");
     if (!c || !b) return GD_E_INVALID;
@@ -292,7 +320,8 @@ int gd_commit(gd_ctx* c, const gd_batch* b, int32_t tid, size_t n_reads, size_t 
     // ~13 ms for the record-by-record loop, which was a quarter of the whole host-to-results path); only a block
     // that fails them is walked again to say where.
     int32_t last = h.last_pos;
-    {
+    if (validated) last = b->pos[n_reads - 1];           // (gd_push: its filler threads checked the block while copying)
+    else {
         const int32_t* __restrict__ const p = b->pos;
         const uint32_t* __restrict__ const o = b->cigar_off;
         uint32_t bad = (uint32_t)(p[0] < last) | (uint32_t)(p[0] < 0);
@@ -308,9 +337,10 @@ int gd_commit(gd_ctx* c, const gd_batch* b, int32_t tid, size_t n_reads, size_t 
         }
         last = p[n_reads - 1];
     }
-    // rebase CSR offsets to the contig stream
+    // the CSR offsets are rebased to the contig stream: on the way by the copy kernel, else here
     const uint32_t base = (uint32_t)h.n_ops;
-    if (base) {
+    const bool blit = c->h2d_kernel && n_reads >= 4096;
+    if (base && !blit) {
         uint32_t* __restrict__ const o = b->cigar_off;
         for (size_t i = 0; i <= n_reads; ++i) o[i] += base;
     }
@@ -331,12 +361,25 @@ int gd_commit(gd_ctx* c, const gd_batch* b, int32_t tid, size_t n_reads, size_t 
         h.cap_ops = ncap;
     }
     hipStream_t cs = c->copy_stream;
-    HIPCHK(c, hipMemcpyAsync(h.pos + h.n_reads, b->pos, n_reads * sizeof(int32_t), hipMemcpyHostToDevice, cs));
-    HIPCHK(c, hipMemcpyAsync(h.flag + h.n_reads, b->flag, n_reads * sizeof(uint16_t), hipMemcpyHostToDevice, cs));
-    HIPCHK(c, hipMemcpyAsync(h.mapq + h.n_reads, b->mapq, n_reads * sizeof(uint8_t), hipMemcpyHostToDevice, cs));
-    HIPCHK(c, hipMemcpyAsync(h.off + h.n_reads, b->cigar_off, (n_reads + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, cs));
-    if (n_ops)
-        HIPCHK(c, hipMemcpyAsync(h.cigar + h.n_ops, b->cigar, n_ops * sizeof(uint32_t), hipMemcpyHostToDevice, cs));
+    if (blit) {
+        // one launch: workgroups read the page-locked block over the link (gd_stage.hpp)
+        gd::H2DJob j{};
+        j.off_add = base;
+        j.seg[0] = {h.pos + h.n_reads, b->pos, n_reads * sizeof(int32_t)};
+        j.seg[1] = {h.off + h.n_reads, b->cigar_off, (n_reads + 1) * sizeof(uint32_t)};
+        j.seg[2] = {h.cigar + h.n_ops, b->cigar, n_ops * sizeof(uint32_t)};
+        j.seg[3] = {h.flag + h.n_reads, b->flag, n_reads * sizeof(uint16_t)};
+        j.seg[4] = {h.mapq + h.n_reads, b->mapq, n_reads * sizeof(uint8_t)};
+        hipLaunchKernelGGL(gd::gd_h2d_kernel, dim3(c->h2d_grid), dim3(256), 0, cs, j);
+        HIPCHK(c, hipGetLastError());
+    } else {
+        HIPCHK(c, hipMemcpyAsync(h.pos + h.n_reads, b->pos, n_reads * sizeof(int32_t), hipMemcpyHostToDevice, cs));
+        HIPCHK(c, hipMemcpyAsync(h.flag + h.n_reads, b->flag, n_reads * sizeof(uint16_t), hipMemcpyHostToDevice, cs));
+        HIPCHK(c, hipMemcpyAsync(h.mapq + h.n_reads, b->mapq, n_reads * sizeof(uint8_t), hipMemcpyHostToDevice, cs));
+        HIPCHK(c, hipMemcpyAsync(h.off + h.n_reads, b->cigar_off, (n_reads + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, cs));
+        if (n_ops)
+            HIPCHK(c, hipMemcpyAsync(h.cigar + h.n_ops, b->cigar, n_ops * sizeof(uint32_t), hipMemcpyHostToDevice, cs));
+    }
     HIPCHK(c, hipEventRecord(s.done, cs));
     s.busy = true;
     if (h.normed || h.ck_ok) {                          // the canonical CIGARs / checkpoints no longer cover the stream
@@ -354,7 +397,10 @@ int gd_commit(gd_ctx* c, const gd_batch* b, int32_t tid, size_t n_reads, size_t 
 // memory, a Gen5 x16 link takes five times that), block k + 1 while the copies of block k are on the link.
 namespace {
 struct FillPool {
-    struct Item { void* dst; const void* src; size_t bytes; uint32_t sub; };     // sub != 0: a CSR-offset piece, rebased by -sub
+    // kind 0: plain copy; 1: int32 positions, copied and checked (non-decreasing from `prev`, not negative);
+    // 2: 32-bit CSR offsets, rebased by -sub and checked (non-decreasing)
+    struct Item { void* dst; const void* src; size_t bytes; uint32_t sub; int kind; int32_t prev; };
+    std::atomic<uint32_t> bad{0};
     std::vector<std::thread> th;
     std::vector<Item> items;
     std::atomic<size_t> next{0}, done{0};
@@ -362,13 +408,23 @@ struct FillPool {
     std::atomic<bool> quit{false};
     std::mutex mu;
     std::condition_variable cv;
-    static void run_item(const Item& it)
+    void run_item(const Item& it)
     {
-        if (it.sub == 0) { memcpy(it.dst, it.src, it.bytes); return; }
-        uint32_t* __restrict__ d = static_cast<uint32_t*>(it.dst);
-        const uint32_t* __restrict__ s = static_cast<const uint32_t*>(it.src);
-        const size_t n = it.bytes / sizeof(uint32_t);
-        for (size_t k = 0; k < n; ++k) d[k] = s[k] - it.sub;
+        if (it.kind == 0) { memcpy(it.dst, it.src, it.bytes); return; }
+        const size_t n = it.bytes / 4;
+        uint32_t wrong = 0;
+        if (it.kind == 1) {
+            int32_t* __restrict__ d = static_cast<int32_t*>(it.dst);
+            const int32_t* __restrict__ s = static_cast<const int32_t*>(it.src);
+            if (n) { wrong = (uint32_t)(s[0] < it.prev) | (uint32_t)(s[0] < 0); d[0] = s[0]; }
+            for (size_t k = 1; k < n; ++k) { wrong |= (uint32_t)(s[k] < s[k - 1]); d[k] = s[k]; }
+        } else {
+            uint32_t* __restrict__ d = static_cast<uint32_t*>(it.dst);
+            const uint32_t* __restrict__ s = static_cast<const uint32_t*>(it.src);
+            if (n) d[0] = s[0] - it.sub;
+            for (size_t k = 1; k < n; ++k) { wrong |= (uint32_t)(s[k] < s[k - 1]); d[k] = s[k] - it.sub; }
+        }
+        if (wrong) bad.store(1);
     }
     void drain()
     {
@@ -428,11 +484,20 @@ int gd_push(gd_ctx* c, int32_t tid, const int32_t* pos, const uint16_t* flag, co
     if (!c) return GD_E_INVALID;
     if (n_reads == 0) return GD_OK;
     if (!pos || !flag || !mapq || !cigar_off || (n_ops && !cigar)) return GD_E_INVALID;
-    const size_t chunk = 1u << 20;   // records per staging block (kRingSlots blocks: one being filled, the others on the link)
+    if (tid < 0 || (size_t)tid >= c->contigs.size()) return fail(c, GD_E_RANGE, "tid %d out of range", tid);
+    if (c->cs.pending) return fail(c, GD_E_STATE, "a compute is in flight: gd_compute_finish first");
+    if (int r = set_device(c)) return r;
+    {
+        ContigHost& h = c->contigs[tid];
+        if (h.adopted) return fail(c, GD_E_STATE, "contig %d holds adopted device records", tid);
+        if (cigar_off[n_reads] > n_ops) return fail(c, GD_E_INVALID, "cigar_off out of range");
+        if (int r = reserve_records(c, h, n_reads, cigar_off[n_reads] - cigar_off[0])) return r;   // one allocation, not one per doubling
+    }
+    const size_t chunk = c->push_chunk;   // records per staging block (kRingSlots blocks: one being filled, the others on the link)
     const int workers = n_reads >= (1u << 18) ? c->push_threads - 1 : 0;
     FillPool pool;
     if (workers > 0) pool.start(workers);
-    const size_t piece = 2u << 20;   // bytes per work item
+    const size_t piece = 1u << 20;   // bytes per work item
     size_t i = 0;
     while (i < n_reads) {
         size_t n = std::min(chunk, n_reads - i);
@@ -441,18 +506,24 @@ int gd_push(gd_ctx* c, int32_t tid, const int32_t* pos, const uint16_t* flag, co
         gd_batch b;
         if (int r = gd_acquire(c, n, o1 - o0, &b)) return r;
         std::vector<FillPool::Item> work;
-        auto add = [&](void* dst, const void* src, size_t bytes, uint32_t sub) {
-            for (size_t at = 0; at < bytes; at += piece)
-                work.push_back({static_cast<char*>(dst) + at, static_cast<const char*>(src) + at, std::min(piece, bytes - at), sub});
+        pool.bad.store(0);
+        const int32_t before = i ? pos[i - 1] : c->contigs[tid].last_pos;
+        auto add = [&](void* dst, const void* src, size_t bytes, uint32_t sub, int kind) {
+            for (size_t at = 0; at < bytes; at += piece) {
+                FillPool::Item it{static_cast<char*>(dst) + at, static_cast<const char*>(src) + at, std::min(piece, bytes - at), sub, kind, 0};
+                if (kind == 1) it.prev = at ? reinterpret_cast<const int32_t*>(static_cast<const char*>(src) + at)[-1] : before;
+                work.push_back(it);
+            }
         };
-        add(b.pos, pos + i, n * sizeof(int32_t), 0);
-        add(b.flag, flag + i, n * sizeof(uint16_t), 0);
-        add(b.mapq, mapq + i, n * sizeof(uint8_t), 0);
-        add(b.cigar_off, cigar_off + i, (n + 1) * sizeof(uint32_t), (uint32_t)o0);   // block relative
-        if (o1 > o0) add(b.cigar, cigar + o0, (o1 - o0) * sizeof(uint32_t), 0);
+        add(b.pos, pos + i, n * sizeof(int32_t), 0, 1);                               // copied and checked: sorted, not negative
+        add(b.flag, flag + i, n * sizeof(uint16_t), 0, 0);
+        add(b.mapq, mapq + i, n * sizeof(uint8_t), 0, 0);
+        add(b.cigar_off, cigar_off + i, (n + 1) * sizeof(uint32_t), (uint32_t)o0, 2);   // block relative; checked: non-decreasing
+        if (o1 > o0) add(b.cigar, cigar + o0, (o1 - o0) * sizeof(uint32_t), 0, 0);
         if (workers > 0) pool.run(std::move(work));
-        else for (const auto& it : work) FillPool::run_item(it);
-        if (int r = gd_commit(c, &b, tid, n, o1 - o0)) return r;
+        else { for (const auto& it : work) pool.run_item(it); }
+        // a block that failed a check goes through gd_commit's own validation, which says where
+        if (int r = commit_block(c, &b, tid, n, o1 - o0, pool.bad.load() == 0)) return r;
         i += n;
     }
     return GD_OK;
@@ -594,6 +665,15 @@ int gd_set_option(gd_ctx* c, int option, int64_t value)
     case GD_OPT_COPY_THREADS:
         if (value < 1 || value > 16) return fail(c, GD_E_INVALID, "copy threads: 1..16");
         c->ing_copy_threads = (int)value;
+        break;
+    case GD_OPT_H2D_KERNEL:
+        if (value < 0 || value > 4096) return fail(c, GD_E_INVALID, "h2d kernel: 0 (hipMemcpyAsync) or its grid, 1..4096 workgroups");
+        c->h2d_kernel = value != 0;
+        if (value > 1) c->h2d_grid = (unsigned)value;
+        break;
+    case GD_OPT_PUSH_CHUNK:
+        if (value < 4096 || value > (1 << 24)) return fail(c, GD_E_INVALID, "push chunk: 4096 .. 2^24 records");
+        c->push_chunk = (size_t)value;
         break;
     case GD_OPT_PUSH_THREADS:
         if (value < 1 || value > 64) return fail(c, GD_E_INVALID, "push threads: 1..64");

@@ -193,7 +193,10 @@ struct gd_ctx {
     hipStream_t ing_stream[8] = {};                     // inflate launches rotate over these (two pending ranges x 4)
     unsigned ing_launch_seq = 0;
     int ing_copy_threads = 1;                          // GD_OPT_COPY_THREADS: threads filling the staging buffer
-    int push_threads = 8;                              // GD_OPT_PUSH_THREADS: threads of gd_push filling a ring block
+    bool h2d_kernel = true;                            // GD_OPT_H2D_KERNEL: staging blocks reach HBM through gd_h2d_kernel
+    unsigned h2d_grid = 512;                           // ... its workgroups
+    int push_threads = 16;
+    size_t push_chunk = 1u << 20;                      // GD_OPT_PUSH_CHUNK: records per staging block of gd_push                             // GD_OPT_PUSH_THREADS: threads of gd_push filling a ring block
     uint32_t* d_scan_tmp = nullptr; size_t cap_scan_tmp = 0;   // launch_scan: block totals
     uint8_t* d_seq = nullptr;  size_t cap_seq = 0;     // gd_seq_load: one contig's bases, zero padded
     int64_t seq_len = -1;

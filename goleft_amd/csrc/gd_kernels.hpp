@@ -505,6 +505,7 @@ __global__ __launch_bounds__(256) void gd_regions_bounds_kernel(const RegionTab*
 #include "gd_multidepth.hpp"
 #include "gd_inflate.hpp"
 #include "gd_bamdecode.hpp"
+#include "gd_stage.hpp"
 
 namespace gd {
 

@@ -8,6 +8,7 @@
 #include <map>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "bam_reader.hpp"
@@ -52,6 +53,45 @@ int stats_contract_from_env()
 }  // namespace
 
 extern "C" {
+
+int gdh_produce_in_place(void* vctx, int32_t tid, const int32_t* pos, const uint16_t* flag, const uint8_t* mapq,
+                         const uint32_t* cigar_off, const uint32_t* cigar, size_t n_reads, size_t n_ops,
+                         int threads, size_t chunk)
+{
+    gd_ctx* ctx = static_cast<gd_ctx*>(vctx);
+    if (!ctx || (n_reads && (!pos || !flag || !mapq || !cigar_off))) return GD_E_INVALID;
+    if (threads < 1) threads = 1;
+    if (chunk < 4096) chunk = 4096;
+    (void)n_ops;
+    for (size_t i = 0; i < n_reads; i += chunk) {
+        const size_t n = std::min(chunk, n_reads - i);
+        const size_t o0 = cigar_off[i], o1 = cigar_off[i + n];
+        gd_batch b;
+        if (int r = gd_acquire(ctx, n, o1 - o0, &b)) return r;
+        // every thread "decodes" a contiguous share of the block's records and their ops
+        auto part = [&](int k) {
+            const size_t a = n * (size_t)k / (size_t)threads, e = n * (size_t)(k + 1) / (size_t)threads;
+            if (e <= a) return;
+            memcpy(b.pos + a, pos + i + a, (e - a) * sizeof(int32_t));
+            memcpy(b.flag + a, flag + i + a, (e - a) * sizeof(uint16_t));
+            memcpy(b.mapq + a, mapq + i + a, (e - a) * sizeof(uint8_t));
+            const uint32_t* so = cigar_off + i;
+            for (size_t r = a; r < e; ++r) b.cigar_off[r] = so[r] - (uint32_t)o0;
+            if (e == n) b.cigar_off[n] = so[n] - (uint32_t)o0;
+            const size_t ca = so[a], ce = so[e];
+            if (ce > ca) memcpy(b.cigar + (ca - o0), cigar + ca, (ce - ca) * sizeof(uint32_t));
+        };
+        if (threads == 1 || n < (1u << 16)) { for (int k = 0; k < threads; ++k) part(k); }
+        else {
+            std::vector<std::thread> th;
+            for (int k = 1; k < threads; ++k) th.emplace_back(part, k);
+            part(0);
+            for (auto& t : th) t.join();
+        }
+        if (int r = gd_commit(ctx, &b, tid, n, o1 - o0)) return r;
+    }
+    return GD_OK;
+}
 
 static int g_fast_exit = 0;
 int gdh_set_fast_exit(int on) { g_fast_exit = on != 0; return 0; }

@@ -190,8 +190,12 @@ enum { /* (1, 2: tile shapes other than 4096 positions x 256 threads -- measured
        GD_OPT_FAST_KERNEL = 5,      /* 1 (default): ordinary tiles run the straight-line tile kernel, the rest the
                                        generic one; 0: the generic kernel for every tile */
        GD_OPT_COPY_THREADS = 6,     /* host threads filling the staging buffer of gd_ingest_feed: 1 (default) .. 16 */
-       GD_OPT_PUSH_THREADS = 7 };   /* host threads of gd_push copying into a pinned ring block: 8 (default), 1 .. 64
+       GD_OPT_PUSH_THREADS = 7,     /* host threads of gd_push copying into a pinned ring block: 16 (default), 1 .. 64
                                        (one core moves ~11 GB/s into pinned memory; the link takes five times that) */
+       GD_OPT_PUSH_CHUNK = 9,       /* records per staging block of gd_push: 2^20 (default), 4096 .. 2^24 */
+       GD_OPT_H2D_KERNEL = 8 };     /* how a committed staging block reaches HBM: 1 (default) one kernel whose workgroups
+                                       read the page-locked block over the link (all five arrays in one launch; n > 1:
+                                       with n workgroups), 0: five hipMemcpyAsync through a DMA engine */
 int gd_set_option(gd_ctx* ctx, int option, int64_t value);
 
 /* Builds the canonical records of every selected contig that lacks them (force != 0: of every selected contig,

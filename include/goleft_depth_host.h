@@ -133,6 +133,15 @@ size_t gdh_plan_ingest_passes(const uint64_t* start, const uint8_t* has, size_t 
                               size_t n_wanted, uint64_t file_size, uint64_t group_bytes, size_t cap,
                               uint64_t* first, uint64_t* last, uint64_t* beg, uint64_t* end);
 
+/* A producer writing records straight into the device library's pinned ring, through the PUBLIC device ABI only
+ * (gd_acquire -> `threads` threads fill the block in place -> gd_commit, blocks of `chunk` records): what the BAM
+ * decoder of a host does with its output, and what INTEGRATION.md tells the Go host to do.  The "decoder" here
+ * copies from the given arrays (bench.py measures the ring + link with it; nothing of the BAM format is involved).
+ * ctx is a gd_ctx*.  Returns the device library's status. */
+int gdh_produce_in_place(void* ctx, int32_t tid, const int32_t* pos, const uint16_t* flag, const uint8_t* mapq,
+                         const uint32_t* cigar_off, const uint32_t* cigar, size_t n_reads, size_t n_ops,
+                         int threads, size_t chunk);
+
 typedef struct gdh_bam gdh_bam;
 int  gdh_bam_open(const char* path, int threads, gdh_bam** out);
 void gdh_bam_close(gdh_bam* b);

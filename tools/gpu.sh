@@ -15,7 +15,13 @@ print("  step %.3f ms  value %.3e  kernel %s %.3f ms frac %.3f | compute_only %s
  d["ms_per_step"], d["value"], d["roofline"]["kernel"], d["roofline"]["avg_kernel_ms"], d["roofline"]["frac"],
  o.get("ms_per_step"), (o.get("roofline") or {}).get("frac"), (o.get("roofline") or {}).get("kernel"),
  i.get("kernels_ms"), i.get("wall_ms"), i.get("frac"), d.get("verified_bit_exact")))
-print("  kernels_ms", d["kernels_ms"], "slow tiles", d["config"].get("tiles_on_the_generic_kernel"), "host_stream", (d.get("host_stream_scope") or {}).get("value"))'
+print("  kernels_ms", d["kernels_ms"], "slow tiles", d["config"].get("tiles_on_the_generic_kernel"))
+for k in ("host_stream_scope", "host_stream_scope_wgs"):
+    h = d.get(k)
+    if isinstance(h, dict) and "variants" in h:
+        print("  %s: %s" % (k, {n: "%.3e ref-b/s %.1f ms (feed %.1f ms) %.1f GB/s" % (v["value"], v["ms"], v["feed_ms"], v["host_to_device_GBps"]) for n, v in h["variants"].items()}))
+e = (d.get("emulated_sharding") or {}).get("by_n_gpus") or {}
+if e: print("  emulated shards:", {n: "%.2fx (max %.3f ms)" % (v["projected_speedup"], v["max_shard_ms"]) for n, v in e.items()})'
 for st in "$@"; do
   case "$st" in
     tests*)
