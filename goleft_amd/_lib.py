@@ -54,6 +54,7 @@ SYMBOLS = {
     "gd_select_contigs": (C.c_int, [_P, C.c_int, _P]),
     "gd_acquire": (C.c_int, [_P, C.c_size_t, C.c_size_t, C.POINTER(GdBatch)]),
     "gd_commit": (C.c_int, [_P, C.POINTER(GdBatch), C.c_int32, C.c_size_t, C.c_size_t]),
+    "gd_reserve": (C.c_int, [_P, C.c_int32, C.c_size_t, C.c_size_t]),
     "gd_push": (C.c_int, [_P, C.c_int32, _P, _P, _P, _P, _P, C.c_size_t, C.c_size_t]),
     "gd_adopt_device": (C.c_int, [_P, C.c_int32, C.POINTER(GdBatch), C.c_size_t, C.c_size_t]),
     "gd_reset": (C.c_int, [_P]),

@@ -324,9 +324,29 @@ static int commit_block(gd_ctx* c, const gd_batch* b, int32_t tid, size_t n_read
     else {
         const int32_t* __restrict__ const p = b->pos;
         const uint32_t* __restrict__ const o = b->cigar_off;
-        uint32_t bad = (uint32_t)(p[0] < last) | (uint32_t)(p[0] < 0);
-        for (size_t i = 1; i < n_reads; ++i) bad |= (uint32_t)(p[i] < p[i - 1]);     // sorted: p[0] is the smallest
-        for (size_t i = 0; i < n_reads; ++i) bad |= (uint32_t)(o[i + 1] < o[i]);
+        // records [a, e): positions non-decreasing (from the record before), offsets non-decreasing
+        auto check = [p, o](size_t a, size_t e, int32_t before) -> uint32_t {
+            uint32_t bad = (uint32_t)(p[a] < before);
+            for (size_t i = a + 1; i < e; ++i) bad |= (uint32_t)(p[i] < p[i - 1]);
+            for (size_t i = a; i < e; ++i) bad |= (uint32_t)(o[i + 1] < o[i]);
+            return bad;
+        };
+        uint32_t bad = (uint32_t)(p[0] < 0);                 // sorted: p[0] is the smallest
+        constexpr int kCheckers = 4;
+        if (n_reads >= (1u << 18)) {                          // a large block: a few threads, a quarter each
+            uint32_t part[kCheckers] = {};
+            std::thread th[kCheckers - 1];
+            for (int k = 0; k < kCheckers; ++k) {
+                const size_t a = n_reads * (size_t)k / kCheckers, e = n_reads * (size_t)(k + 1) / kCheckers;
+                const int32_t before = k ? p[a - 1] : last;
+                if (k + 1 < kCheckers) th[k] = std::thread([&part, &check, a, e, before, k] { part[k] = check(a, e, before); });
+                else part[k] = check(a, e, before);
+            }
+            for (auto& t : th) t.join();
+            for (uint32_t x : part) bad |= x;
+        } else {
+            bad |= check(0, n_reads, last);
+        }
         if (bad) {
             for (size_t i = 0; i < n_reads; ++i) {
                 if (p[i] < 0) return fail(c, GD_E_RANGE, "contig %d record %zu: negative position %d (a placed BAM record has POS >= 0)", tid, h.n_reads + i, p[i]);
@@ -527,6 +547,19 @@ int gd_push(gd_ctx* c, int32_t tid, const int32_t* pos, const uint16_t* flag, co
         i += n;
     }
     return GD_OK;
+}
+
+int gd_reserve(gd_ctx* c, int32_t tid, size_t n_reads, size_t n_ops)
+{
+    if (!c) return GD_E_INVALID;
+    if (c->cs.pending) return fail(c, GD_E_STATE, "a compute is in flight: gd_compute_finish first");
+    if (int r = set_device(c)) return r;
+    if (tid < 0 || (size_t)tid >= c->contigs.size()) return fail(c, GD_E_RANGE, "tid %d out of range", tid);
+    ContigHost& h = c->contigs[tid];
+    if (h.adopted) return fail(c, GD_E_STATE, "contig %d holds adopted device records", tid);
+    if ((uint64_t)h.n_ops + n_ops > 0xffffffffull) return fail(c, GD_E_RANGE, "more than 2^32 CIGAR ops on contig %d", tid);
+    if ((uint64_t)h.n_reads + n_reads >= kMaxReadsPerContig) return fail(c, GD_E_RANGE, "more than 2^30 records on contig %d", tid);
+    return reserve_records(c, h, n_reads, n_ops);
 }
 
 int gd_adopt_device(gd_ctx* c, int32_t tid, const gd_batch* d, size_t n_reads, size_t n_ops)

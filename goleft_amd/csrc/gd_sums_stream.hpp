@@ -73,6 +73,7 @@ typedef const __attribute__((address_space(1))) uint32_t* gptr_u32;
 // The wave's queue of odd reads {POS, index of the first canonical op, op count}, 64 at a time: walk the canonical
 // ops, M (0) counted, N (3) skipped, every M interval on its own.  (Inlined, at its one call site and the final one: as a
 // function call it cost the kernel 25 vector registers, one resident wave per SIMD in six and a tenth of its speed.)
+template <bool RAW>
 __device__ __forceinline__ void drain_queue(const uint4* Q, uint32_t cnt, int lane, gptr_u32 cigar, uint32_t length,
                                          Acc acc, uint32_t W, uint32_t wm, uint32_t ws)
 {
@@ -87,15 +88,24 @@ __device__ __forceinline__ void drain_queue(const uint4* Q, uint32_t cnt, int la
             uint32_t x = (uint32_t)pu;
             for (uint32_t k = 0; k < nu && x < length; ++k) {
                 const uint32_t o = ops[k], ol = o >> 4;
-                const uint32_t xe = x + ol;
-                if ((o & 0xfu) == 0u) add_interval_direct(acc, W, wm, ws, x, xe < length ? xe : length);
-                x = xe;
+                if (RAW) {                                     // any BAM op: M = X counted, D N advance, I S H P nothing
+                    const uint32_t op = o & 0xfu;
+                    if (!((0x18du >> op) & 1u)) continue;
+                    const uint32_t xe = x + ol;
+                    if (((0x181u >> op) & 1u) && ol != 0u) add_interval_direct(acc, W, wm, ws, x, xe < length ? xe : length);
+                    x = xe;
+                } else {
+                    const uint32_t xe = x + ol;
+                    if ((o & 0xfu) == 0u) add_interval_direct(acc, W, wm, ws, x, xe < length ? xe : length);
+                    x = xe;
+                }
             }
         } else {
             long long x = pu;                                  // a negative POS (no aligner writes one): the long form
             for (uint32_t k = 0; k < nu; ++k) {
                 const uint32_t o = ops[k], ol = o >> 4;
-                if ((o & 0xfu) == 0u) {
+                if (RAW && !((0x18du >> (o & 0xfu)) & 1u)) continue;
+                if (RAW ? (bool)((0x181u >> (o & 0xfu)) & 1u) : (o & 0xfu) == 0u) {
                     const long long e64 = x + (long long)ol;
                     const uint32_t s = x > 0 ? (x < (long long)length ? (uint32_t)x : length) : 0u;
                     const uint32_t e = e64 < (long long)length ? (e64 > 0 ? (uint32_t)e64 : 0u) : length;
@@ -111,10 +121,12 @@ __device__ __forceinline__ void drain_queue(const uint4* Q, uint32_t cnt, int la
 // one group of 256 reads on its way through the wave's pipeline
 struct Stage {
     typedef unsigned int v4u __attribute__((ext_vector_type(4)));
-    v4u pv, rv;            // POS and record words of the lane's four reads
-    uint32_t ob;           // first canonical op of the group (wave uniform)
-    uint32_t obase;        // ops of the lanes before this one
-    uint32_t cg[U];        // first op of each read
+    v4u pv, rv;            // POS and record words of the lane's four reads (RAW: their CSR offsets)
+    uint32_t ob;           // first canonical op of the group (wave uniform); RAW: the CSR offset after the lane's last read
+    uint32_t obase;        // ops of the lanes before this one; RAW: bit u = read u is kept
+    uint32_t cg[U];        // first op of each read; RAW: the ONE counted op of a read that has just one (else 0xffffffff)
+    unsigned int fw0, fw1, mq;   // RAW: the four flags (two per word) and MAPQs as loaded
+    uint32_t g0;           // RAW: first read of the group (wave uniform)
 };
 
 // A wave that took one group per launch slot spent its life in dependent round trips (which contig? its
@@ -124,6 +136,13 @@ struct Stage {
 // worked on, the first ops of group g+1 (their addresses need that group's record words) and the records of
 // group g+2 are in flight.  The loop is unrolled three times so that a stage's registers are never copied while
 // their loads are outstanding (a copy is a wait).
+//
+// RAW: the same pass over the records AS THEY ARRIVED (pos / flag / MAPQ / CSR offsets / BAM ops): a cohort's
+// samples are computed once each, and building canonical records first moved 28 bytes per read to save 3 here
+// (181 ms for 200 x chr1 in front of a 25 ms kernel).  A read FITS the lane's three windows when it has ONE counted
+// op and nothing before it that consumes the reference: 150M, 20S130M, 100M50S, 5H145M, 70M3I, 150M2D (97 % of
+// short reads); everything else takes the queue and the general op walk.
+template <bool RAW>
 __global__ __launch_bounds__(256) void gd_sums_stream_kernel(Job job)
 {
     __shared__ uint4 s_q[4 * SQ_CAP];
@@ -157,7 +176,12 @@ __global__ __launch_bounds__(256) void gd_sums_stream_kernel(Job job)
     r_end = r_end < n_reads ? r_end : n_reads;
     // one descriptor pair for the wave's whole range: reads past it load 0 = no ops
     const rsrc_t r_pos = make_rsrc(c.pos + r_first, (r_end - r_first) * 4u);
-    const rsrc_t r_rec = make_rsrc(c.rec + r_first, (r_end - r_first) * 4u);
+    const rsrc_t r_rec = RAW ? make_rsrc(c.off + r_first, (r_end - r_first + 1u) * 4u)       // (+ the end of the last read)
+                             : make_rsrc(c.rec + r_first, (r_end - r_first) * 4u);
+    // RAW: flags (16 bits) and MAPQs (8 bits), four per lane in one load each; the ranges are rounded up to whole
+    // dwords (at most 2 / 3 bytes past the wave's last read, inside the same aligned word: gd_tile_fast.hpp)
+    const rsrc_t r_flag = make_rsrc(RAW ? (const void*)(c.flag + r_first) : nullptr, RAW ? ((r_end - r_first + 1u) & ~1u) * 2u : 0u);
+    const rsrc_t r_mapq = make_rsrc(RAW ? (const void*)(c.mapq + r_first) : nullptr, RAW ? ((r_end - r_first + 3u) & ~3u) : 0u);
 
     uint4* const Q = &s_q[(threadIdx.x >> 6) * SQ_CAP];
     uint32_t qn = 0;                                             // queued odd reads (wave uniform)
@@ -175,11 +199,65 @@ __global__ __launch_bounds__(256) void gd_sums_stream_kernel(Job job)
     auto load_records = [&](Stage& S, uint32_t g) {
         S.pv = __builtin_amdgcn_raw_buffer_load_b128(r_pos, (int)(g - r_first) * 4 + lane * 16, 0, 0);
         S.rv = __builtin_amdgcn_raw_buffer_load_b128(r_rec, (int)(g - r_first) * 4 + lane * 16, 0, 0);
-        S.ob = g < r_end ? off[g] : 0u;
+        if (RAW) {
+            typedef unsigned int v2u_t __attribute__((ext_vector_type(2)));
+            S.g0 = g;
+            S.ob = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r_rec, (int)(g - r_first) * 4 + lane * 16 + 16, 0, 0);
+            const v2u_t fv = __builtin_amdgcn_raw_buffer_load_b64(r_flag, (int)(g - r_first) * 2 + lane * 8, 0, 0);
+            S.fw0 = fv.x; S.fw1 = fv.y;
+            S.mq = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r_mapq, (int)(g - r_first) + lane * 4, 0, 0);
+        } else {
+            S.ob = g < r_end ? off[g] : 0u;
+        }
     };
     // stage 2: where the group's ops are -- a prefix sum of the op counts in the record words -- and the first op
     // of each read (the only one of 98 % of short reads)
     auto fetch_ops = [&](Stage& S) {
+        if (RAW) {
+            const uint32_t o[U + 1] = {S.rv.x, S.rv.y, S.rv.z, S.rv.w, S.ob};
+            uint32_t n[U];
+            bool keep[U];
+            const uint32_t fl[U] = {S.fw0 & 0xffffu, S.fw0 >> 16, S.fw1 & 0xffffu, S.fw1 >> 16};
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const bool valid = S.g0 + (uint32_t)lane * U + (uint32_t)u < r_end;
+                n[u] = valid ? o[u + 1] - o[u] : 0u;
+                keep[u] = ((fl[u] & job.flag_mask) == 0) & ((int)((S.mq >> (8 * u)) & 0xffu) >= Q_) & (n[u] != 0u);
+            }
+            typedef unsigned int v4u_t __attribute__((ext_vector_type(4)));
+            typedef const __attribute__((address_space(1))) v4u_t* gptr_v4;
+            // four reads of one op each: their ops lie side by side, ONE 16-byte load
+            const bool four = ((n[0] & n[1] & n[2] & n[3]) == 1u) & ((n[0] | n[1] | n[2] | n[3]) == 1u);
+            v4u_t o4 = {0u, 0u, 0u, 0u};
+            if (four) o4 = *(gptr_v4)(cigar + o[0]);
+            uint32_t c0[U] = {o4.x, o4.y, o4.z, o4.w}, c1[U] = {0u, 0u, 0u, 0u};
+            if (__builtin_amdgcn_ballot_w64(!four) != 0ull) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if (!four & keep[u]) c0[u] = cigar[o[u]];
+                    if (!four & keep[u] & (n[u] == 2u)) c1[u] = cigar[o[u] + 1u];
+                }
+            }
+            uint32_t kb = 0;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t oa = c0[u] & 0xfu, ob2 = c1[u] & 0xfu;
+                const bool ca = (0x181u >> oa) & 1u, ka = (0x18du >> oa) & 1u;       // counted (M = X), consumes (M D N = X)
+                const bool cb = (n[u] == 2u) & (bool)((0x181u >> ob2) & 1u);
+                // ONE counted op and nothing that consumes the reference before it: that op is the read
+                uint32_t eff = 0xffffffffu;                                          // everything else: the queue
+                if (n[u] <= 2u) {
+                    if (ca & !cb) eff = c0[u] >> 4;                                  // M | M S | M I | M D (a trailing D covers nothing counted)
+                    else if (!ka & cb) eff = c1[u] >> 4;                             // S M | H M | I M
+                    else if (!ca & !cb) eff = 0u;                                    // nothing counted at all
+                }
+                const bool k = keep[u] & (eff != 0u);
+                S.cg[u] = eff == 0xffffffffu ? eff : eff << 4;
+                kb |= k ? 1u << u : 0u;
+            }
+            S.obase = kb;
+            return;
+        }
         const uint32_t rec[U] = {S.rv.x, S.rv.y, S.rv.z, S.rv.w};
         uint32_t n[U], ex[U];
 #pragma unroll
@@ -214,12 +292,22 @@ __global__ __launch_bounds__(256) void gd_sums_stream_kernel(Job job)
         const uint32_t rec[U] = {S.rv.x, S.rv.y, S.rv.z, S.rv.w};
         uint32_t n[U], ex[U];
         bool keep[U];
+        if (RAW) {
+            const uint32_t oe[U] = {S.rv.y, S.rv.z, S.rv.w, S.ob};
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            n[u] = rec[u] & norm::REC_NMAX;
-            keep[u] = ((rec[u] & fmask) == 0) & ((int)((rec[u] >> 12) & 0xffu) >= Q_) & (n[u] != 0u);
+            for (int u = 0; u < U; ++u) {
+                keep[u] = (S.obase >> u) & 1u;
+                n[u] = keep[u] ? oe[u] - rec[u] : 0u;
+                ex[u] = rec[u];                                    // the read's first op, an index into the contig's ops
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                n[u] = rec[u] & norm::REC_NMAX;
+                keep[u] = ((rec[u] & fmask) == 0) & ((int)((rec[u] >> 12) & 0xffu) >= Q_) & (n[u] != 0u);
+            }
+            ex[0] = 0; ex[1] = n[0]; ex[2] = ex[1] + n[1]; ex[3] = ex[2] + n[2];
         }
-        ex[0] = 0; ex[1] = n[0]; ex[2] = ex[1] + n[1]; ex[3] = ex[2] + n[2];
 
         // this lane's window base: the start window of its first read (sorted records: non-decreasing over the
         // lanes; lanes past the contig's last read sort last and add nothing)
@@ -242,7 +330,7 @@ __global__ __launch_bounds__(256) void gd_sums_stream_kernel(Job job)
             const uint32_t s = p[u] > 0 ? (uint32_t)p[u] : 0u;
             const uint32_t eu = s + len;                           // < 2^31 + 2^28
             const uint32_t ec = eu < length ? eu : length;
-            const bool fits = keep[u] & (n[u] == 1u) & (len < (1u << 22)) & (p[u] >= 0) & (ec <= nb2);
+            const bool fits = keep[u] & (RAW ? S.cg[u] != 0xffffffffu : n[u] == 1u) & (len < (1u << 22)) & (p[u] >= 0) & (ec <= nb2);
             const uint32_t e = fits ? ec : s;
             const uint32_t l1 = s > nb0 ? s : nb0, l2 = s > nb1 ? s : nb1;
             const uint32_t h0 = e < nb0 ? e : nb0, h1 = e < nb1 ? e : nb1;
@@ -262,14 +350,14 @@ __global__ __launch_bounds__(256) void gd_sums_stream_kernel(Job job)
             odd &= odd - 1u;
             const unsigned long long m = __builtin_amdgcn_ballot_w64(mine);
             const uint32_t np = (uint32_t)__popcll(m);
-            if (qn + np > (uint32_t)SQ_CAP) { drain_queue(Q, qn, lane, cigar, length, acc, W, wm, ws); qn = 0; }
+            if (qn + np > (uint32_t)SQ_CAP) { drain_queue<RAW>(Q, qn, lane, cigar, length, acc, W, wm, ws); qn = 0; }
             if (mine) {
                 const uint32_t rk = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32),
                                              __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
                 const int32_t pu = u == 0 ? p[0] : u == 1 ? p[1] : u == 2 ? p[2] : p[3];
                 const uint32_t nu = u == 0 ? n[0] : u == 1 ? n[1] : u == 2 ? n[2] : n[3];
                 const uint32_t xu = u == 0 ? ex[0] : u == 1 ? ex[1] : u == 2 ? ex[2] : ex[3];
-                Q[rk] = make_uint4((uint32_t)pu, S.ob + S.obase + xu, nu, 0u);
+                Q[rk] = make_uint4((uint32_t)pu, RAW ? xu : S.ob + S.obase + xu, nu, 0u);
             }
             qn += np;
         }
@@ -310,7 +398,7 @@ __global__ __launch_bounds__(256) void gd_sums_stream_kernel(Job job)
         if (g + 2u * GROUP >= r_end) break;
         load_records(B, g + 4u * GROUP); fetch_ops(A); work(C, g + 2u * GROUP);
     }
-    if (qn != 0u) drain_queue(Q, qn, lane, cigar, length, acc, W, wm, ws);
+    if (qn != 0u) drain_queue<RAW>(Q, qn, lane, cigar, length, acc, W, wm, ws);
     // the wave's accumulators -> memory, once
     __builtin_amdgcn_wave_barrier();
 #pragma unroll

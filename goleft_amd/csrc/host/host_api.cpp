@@ -62,7 +62,7 @@ int gdh_produce_in_place(void* vctx, int32_t tid, const int32_t* pos, const uint
     if (!ctx || (n_reads && (!pos || !flag || !mapq || !cigar_off))) return GD_E_INVALID;
     if (threads < 1) threads = 1;
     if (chunk < 4096) chunk = 4096;
-    (void)n_ops;
+    if (int r = gd_reserve(ctx, tid, n_reads, n_ops)) return r;   // (a decoder has the count from the .bai metadata bin)
     for (size_t i = 0; i < n_reads; i += chunk) {
         const size_t n = std::min(chunk, n_reads - i);
         const size_t o0 = cigar_off[i], o1 = cigar_off[i + n];

@@ -19,9 +19,9 @@ K_PREP, K_TILE, K_RUNS, K_EXPAND, K_SCAN, K_CKPT, K_SEQSTATS, K_MDFLAGS, K_INFLA
 OPT_NT_STORES, OPT_NORMALIZE, OPT_FAST_KERNEL, OPT_COPY_THREADS, OPT_PUSH_THREADS, OPT_H2D_KERNEL = 3, 4, 5, 6, 7, 8
 PATH_AUTO, PATH_TILE, PATH_SCATTER, PATH_CHUNK = 0, 1, 2, 3
 # gd_stats.tile_kernel (include/goleft_depth.h GD_TK_*)
-TK_NONE, TK_GENERIC, TK_FAST, TK_FAST_RAW, TK_LONG, TK_SCATTER, TK_SUMS_STREAM, TK_TILE_SUMS = range(8)
+TK_NONE, TK_GENERIC, TK_FAST, TK_FAST_RAW, TK_LONG, TK_SCATTER, TK_SUMS_STREAM, TK_TILE_SUMS, TK_SUMS_STREAM_RAW = range(9)
 TK_NAMES = ("none", "gd_tile_kernel", "gd_tile_fast_kernel", "gd_tile_fast_kernel<raw>", "gd_ltile2_kernel",
-            "gd_expand_scatter_kernel+gd_scan_kernel", "gd_sums_stream_kernel", "gd_tile_sums_kernel")
+            "gd_expand_scatter_kernel+gd_scan_kernel", "gd_sums_stream_kernel", "gd_tile_sums_kernel", "gd_sums_stream_kernel<raw>")
 
 
 class GdError(RuntimeError):

@@ -121,7 +121,8 @@ enum { GD_TK_NONE = 0,
        GD_TK_LONG = 4,         /* gd_ltile2_kernel (long-read path) */
        GD_TK_SCATTER = 5,      /* gd_expand_scatter_kernel + gd_scan_kernel */
        GD_TK_SUMS_STREAM = 6,  /* gd_sums_stream_kernel (GD_OUT_SUMS_ONLY over canonical records) */
-       GD_TK_TILE_SUMS = 7 };  /* gd_tile_sums_kernel (GD_OUT_SUMS_ONLY otherwise) */
+       GD_TK_TILE_SUMS = 7,    /* gd_tile_sums_kernel (GD_OUT_SUMS_ONLY otherwise) */
+       GD_TK_SUMS_STREAM_RAW = 8 };  /* gd_sums_stream_kernel over the records as they arrived */
 
 /* Kernel ids for gd_kernel_ms.  Tile path: PREP, TILE, RUNS.  Long-read path: PREP, TILE (the long-read tile
  * kernel), RUNS; CKPT = its deletion lists + tile indexes, built when the records arrive (like NORM: summed over
@@ -252,6 +253,11 @@ int gd_acquire(gd_ctx* ctx, size_t reads_cap, size_t ops_cap, gd_batch* out);
  * committed in coordinate order (GD_E_UNSORTED); a negative position is
  * GD_E_RANGE (a placed BAM record has POS >= 0). */
 int gd_commit(gd_ctx* ctx, const gd_batch* b, int32_t tid, size_t n_reads, size_t n_ops);
+
+/* Optional: room for n_reads more records / n_ops more CIGAR ops of contig tid in one step.  A producer that knows
+ * its totals (the .bai metadata pseudo-bin holds a reference's mapped-record count) spares the device arrays their
+ * growth by doubling, each step of which waits for the copies in flight. */
+int gd_reserve(gd_ctx* ctx, int32_t tid, size_t n_reads, size_t n_ops);
 
 /* Convenience: copy records from ordinary host memory (copies before
  * returning; never keeps the pointers). */

@@ -364,7 +364,7 @@ def test_windows_only_output(auto_eng):
     assert np.array_equal(eng.perbase(0), want)
 
 
-@pytest.mark.parametrize("stream", [1, 0])
+@pytest.mark.parametrize("stream", [1, 2, 0])
 @pytest.mark.parametrize("W", [32, 100, 250, 1000, 4096, 5000, 1 << 20])
 def test_sums_only_output(W, stream):
     """gd_set_outputs(GD_OUT_SUMS_ONLY): window sums from read/window overlaps, no per-base scan -- the
@@ -372,6 +372,7 @@ def test_sums_only_output(W, stream):
     kernel it replaces (GD_OPT_FAST_KERNEL = 0); they equal the sums of the regular path; minima, class runs
     and the per-base vector report GD_E_STATE; the depthwed matrix is unchanged."""
     from goleft_amd import synth
+    from goleft_amd import engine as E
     from goleft_amd.engine import DepthEngine, GdError, PATH_TILE, OPT_FAST_KERNEL
     rng = np.random.default_rng(W)
     lengths = [300_001, 1, 4096, 70_000, 12_289]
@@ -380,7 +381,11 @@ def test_sums_only_output(W, stream):
              3: H.random_reads(rng, lengths[3], 6000, max_len=90, long_reads=True),
              4: H.random_reads(rng, lengths[4], 20000, max_len=60)}     # deep: several record batches per tile
     with DepthEngine(0) as eng:
-        eng.set_option(OPT_FAST_KERNEL, stream)
+        # stream 1: the streaming kernel over the records as they arrived (the default); 2: over canonical records
+        # built at arrival; 0: the tile kernel
+        eng.set_option(OPT_FAST_KERNEL, 1 if stream else 0)
+        if stream == 2:
+            eng.set_option(E.OPT_NORMALIZE, 1)
         eng.set_params(window_size=W, min_mapq=1, min_cov=4)
         eng.set_path(PATH_TILE)
         eng.set_outputs(sums_only=True)
@@ -388,6 +393,7 @@ def test_sums_only_output(W, stream):
         for t, r in reads.items():
             eng.push(t, r.pos, r.flag, r.mapq, r.cigar_off, r.cigar)
         eng.compute()
+        assert eng.stats().tile_kernel == {1: E.TK_SUMS_STREAM_RAW, 2: E.TK_SUMS_STREAM, 0: E.TK_TILE_SUMS}[stream]
         for t, L in enumerate(lengths):
             want = po.perbase_c(reads.get(t, H.empty_reads()), 1, 0, L)
             ws, _ = H.oracle_windows(want, W)
