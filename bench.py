@@ -288,7 +288,7 @@ def run_case(args, scaling, world, rank, dev, local_rank, want_streams=False):
     torch.cuda.synchronize()
     # derived structures (canonical records, deletion lists, tile indexes) are part of EVERY step where the path
     # needs them; the short-read tile path needs none
-    derive = ont or cohort
+    derive = ont                                    # (the cohort's streaming sums read the records as they arrived)
 
     wed = {}
     gath = None
@@ -296,8 +296,6 @@ def run_case(args, scaling, world, rank, dev, local_rank, want_streams=False):
         # set-up, outside the timed region: one compute to learn the boundary count, the ranks agree
         # on a fixed capacity, buffers are allocated once and the engine is told to fill the send
         # buffer itself (gd_set_export)
-        if derive:
-            eng.normalize(True)
         eng.compute()
         gath = shard.RootGather(assignment, lengths, W, rank, world, dev, bounds_cap=0)
         gath.reserve(eng.device_runs()[1])
@@ -305,7 +303,7 @@ def run_case(args, scaling, world, rank, dev, local_rank, want_streams=False):
 
     def step(inclusive=True):
         if derive and inclusive:
-            eng.normalize(True)                     # rebuilt from the records as they arrived, every step
+            eng.rebuild_derived()                   # deletion lists + tile indexes rebuilt from the records as they arrived, every step
         eng.compute()
         if cohort:
             # the sites x samples matrix of this rank's samples, left in HBM for its consumer
@@ -326,13 +324,13 @@ def run_case(args, scaling, world, rank, dev, local_rank, want_streams=False):
         # gather of step k - 1.  Every step is still a complete compute + gather; all of them have landed before
         # the clock stops (drain + synchronize below).
         if derive:
-            eng.normalize(True)
+            eng.rebuild_derived()
         eng.compute_launch()
         for _ in range(n - 1):
             eng.compute_finish()
             gath.flip()
             if derive:
-                eng.normalize(True)
+                eng.rebuild_derived()
             eng.compute_launch()
             gath.post()
         eng.compute_finish()
@@ -591,8 +589,8 @@ def main():
                    "min_mapq": Q, "min_cov": mincov, "total_ref_bases": r["total_bases"],
                    "reads_rank0": r["n_reads"], "cigar_ops_rank0": r["n_ops"],
                    "canonical_cigar_ops_rank0": r["n_canonical_ops"], "tiles_on_the_generic_kernel": r["n_slow_tiles"],
-                   "step": ("gd_normalize(force) [canonical records" + (", deletion lists, tile indexes" if chunk else "") +
-                            " rebuilt from the records as they arrived] + gd_compute" if r["derive"] else
+                   "step": ("gd_rebuild_derived [deletion lists, read records and tile indexes rebuilt straight from the "
+                            "records as they arrived] + gd_compute" if r["derive"] else
                             "gd_compute on the records as they arrived (nothing derived exists)" if raw_records else
                             "gd_compute") + (" + gd_depthwed_device" if args.workload == "cohort" else ""),
                    "in_step_normalise_kernels_ms_rank0": r["norm_ms"], "in_step_checkpoint_kernels_ms_rank0": r["ckpt_ms"],

@@ -33,7 +33,7 @@ class GdStats(C.Structure):
                 ("tile_positions", C.c_int32), ("lookback", C.c_int32),
                 ("max_span_seen", C.c_int32), ("reruns", C.c_int32),
                 ("path", C.c_int32), ("n_slow_tiles", C.c_int32), ("n_canonical_ops", C.c_uint64),
-                ("tile_kernel", C.c_int32), ("reserved_", C.c_int32)]
+                ("tile_kernel", C.c_int32), ("reserved_", C.c_int32), ("n_deletions", C.c_uint64)]
 
 
 # every symbol include/goleft_depth.h declares: (restype, argtypes)
@@ -102,6 +102,7 @@ SYMBOLS = {
     "gd_set_option": (C.c_int, [_P, C.c_int, C.c_int64]),
     "gd_normalize": (C.c_int, [_P, C.c_int]),
     "gd_drop_derived": (C.c_int, [_P]),
+    "gd_rebuild_derived": (C.c_int, [_P]),
     "gd_canonical_cigars": (C.c_int, [_P, C.c_int32, _P, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
     "gd_set_export": (C.c_int, [_P, _P, C.c_int64, C.c_int64]),
     "gd_wait_event": (C.c_int, [_P, _P]),

@@ -55,6 +55,7 @@ struct ContigHost {
     uint2*    dl = nullptr;            // (canonical ops >> 1) + n_reads + 1 deletions {start, length}
     uint32_t* pck = nullptr;           // tile indexes (gd_ptile_fill_kernel)
     int32_t   max_span = 0;
+    uint64_t  n_dels = 0;              // deletions in dl
     bool ck_ok = false;                // lrec / lfq / dl / pck describe the current records
     // layout in the result arrays of the last compute (-1 = not computed)
     int64_t base_off = -1;
@@ -267,6 +268,7 @@ void drop_ck(ContigHost& h)
     h.pck_blk.reset();
     h.lrec = nullptr; h.lfq = nullptr; h.dl = nullptr; h.pck = nullptr;
     h.max_span = 0;
+    h.n_dels = 0;
     h.ck_ok = false;
 }
 
@@ -447,30 +449,33 @@ int batch_host(gd_ctx* c, size_t words)
 // of the tile indexes, one allocation for all of them.
 struct CkPending {
     std::vector<ContigHost*> hs;
-    BlockRef blk;
+    BlockRef blk, keep_pck;
     size_t o_jobs = 0, o_tot = 0, o_span = 0;
-    std::vector<size_t> o_lrec, o_lfq, o_dl, o_unit;
+    std::vector<size_t> o_lrec, o_lfq, o_dl, o_unit, o_ndel;
     uint32_t n_units = 0;
     gd::DelBatch B{};
 };
 
-int ck_enqueue(gd_ctx* c, const std::vector<ContigHost*>& hs, bool ops_known, CkPending* P)
+// raw: straight from the records as they arrived (gd_dels_raw_kernel); else from the canonical CIGARs
+int ck_enqueue(gd_ctx* c, const std::vector<ContigHost*>& hs, bool ops_known, CkPending* P, bool raw = false)
 {
     P->hs = hs;
     const size_t nj = hs.size();
     if (nj == 0) return GD_OK;
     BlockRef keep = hs[0]->ck_blk;
+    P->keep_pck = hs[0]->pck_blk;
     for (ContigHost* h : hs) drop_ck(*h);
     Carve cv;
     uint64_t units = 0;
-    P->o_lrec.resize(nj); P->o_lfq.resize(nj); P->o_dl.resize(nj); P->o_unit.resize(nj);
+    P->o_lrec.resize(nj); P->o_lfq.resize(nj); P->o_dl.resize(nj); P->o_unit.resize(nj); P->o_ndel.resize(nj);
     for (size_t k = 0; k < nj; ++k) {
         const ContigHost& h = *hs[k];
         const size_t n = h.n_reads;
-        const size_t n_dl = ((ops_known ? h.n_nops : h.n_ops) >> 1) + n + 1;
+        const size_t n_dl = ((ops_known && !raw ? h.n_nops : h.n_ops) >> 1) + n + 1;
         if (n_dl > 0xffffffffull) return fail(c, GD_E_RANGE, "too many deletions on one contig");
         P->o_lrec[k] = cv.take((n + 2) * sizeof(uint4));
         P->o_lfq[k] = cv.take((n + 1) * sizeof(uint32_t));
+        P->o_ndel[k] = cv.take((n + 1) * sizeof(uint32_t));
         P->o_dl[k] = cv.take(n_dl * sizeof(uint2));
         units += (n + 63) / 64;
     }
@@ -478,7 +483,7 @@ int ck_enqueue(gd_ctx* c, const std::vector<ContigHost*>& hs, bool ops_known, Ck
     P->n_units = (uint32_t)units;
     const size_t o_unit = cv.take((units + 2) * sizeof(uint32_t));
     P->o_jobs = cv.take(nj * sizeof(gd::DelJob) + (nj + 1) * sizeof(uint32_t));   // the jobs, then ubeg
-    P->o_tot = cv.take(nj * sizeof(uint32_t));
+    P->o_tot = cv.take(2 * nj * sizeof(uint32_t));               // [index entries][deletions] per contig
     if (int r = batch_block(c, std::move(keep), cv.at, &P->blk)) return r;
     char* const base = static_cast<char*>(P->blk->p);
     // job table (host copy kept in the context until the next batch)
@@ -490,11 +495,15 @@ int ck_enqueue(gd_ctx* c, const std::vector<ContigHost*>& hs, bool ops_known, Ck
         ContigHost& h = *hs[k];
         const uint32_t n = (uint32_t)h.n_reads, nu = (n + 63u) / 64u;
         gd::DelJob& j = jobs[k];
-        j.pos = h.pos; j.off = h.noff; j.cigar = h.ncig; j.flag = h.flag; j.mapq = h.mapq;
+        j.pos = h.pos; j.flag = h.flag; j.mapq = h.mapq;
+        j.off = raw ? h.off : h.noff;
+        j.cigar = raw ? h.cigar : h.ncig;
         j.n_reads = n; j.n_units = nu;
         j.lrec = reinterpret_cast<uint4*>(base + P->o_lrec[k]);
         j.lfq = reinterpret_cast<uint32_t*>(base + P->o_lfq[k]);
         j.dl = reinterpret_cast<uint2*>(base + P->o_dl[k]);
+        j.ndel = reinterpret_cast<uint32_t*>(base + P->o_ndel[k]);
+        j.del_total = reinterpret_cast<uint32_t*>(base + P->o_tot) + nj + k;
         j.max_span = reinterpret_cast<int32_t*>(j.lrec + n + 1);
         j.unit = reinterpret_cast<uint32_t*>(base + o_unit) + u;
         j.pck = nullptr;
@@ -511,9 +520,11 @@ int ck_enqueue(gd_ctx* c, const std::vector<ContigHost*>& hs, bool ops_known, Ck
     B.n_jobs = (uint32_t)nj; B.n_units = P->n_units;
     for (size_t k = 0; k < nj; ++k)                          // lrec[n], lrec[n + 1] (the span accumulator)
         HIPCHK(c, hipMemsetAsync(base + P->o_lrec[k] + hs[k]->n_reads * sizeof(uint4), 0, 2 * sizeof(uint4), c->stream));
+    HIPCHK(c, hipMemsetAsync(base + P->o_tot, 0, 2 * nj * sizeof(uint32_t), c->stream));
     if (P->n_units) {
         const unsigned grid = (P->n_units + 3u) / 4u;
-        hipLaunchKernelGGL(gd::gd_dels_kernel, dim3(grid), dim3(256), 0, c->stream, B);
+        if (raw) hipLaunchKernelGGL(gd::gd_dels_raw_kernel, dim3(grid), dim3(256), 0, c->stream, B);
+        else hipLaunchKernelGGL(gd::gd_dels_kernel, dim3(grid), dim3(256), 0, c->stream, B);
         hipLaunchKernelGGL(gd::gd_ptile_count_kernel, dim3(grid), dim3(256), 0, c->stream, B);
         if (int r = launch_scan(c, reinterpret_cast<uint32_t*>(base + o_unit), P->n_units)) return r;
     } else {
@@ -524,15 +535,15 @@ int ck_enqueue(gd_ctx* c, const std::vector<ContigHost*>& hs, bool ops_known, Ck
     return GD_OK;
 }
 
-// host words the totals of a ck batch take in gd_ctx::h_batch: [n_jobs totals][n_jobs spans]
+// host words the totals of a ck batch take in gd_ctx::h_batch: [n_jobs index sizes][n_jobs deletion counts][n_jobs spans]
 int ck_readback(gd_ctx* c, const CkPending& P, uint32_t* dst)
 {
     const size_t nj = P.hs.size();
     if (nj == 0) return GD_OK;
     char* const base = static_cast<char*>(P.blk->p);
-    HIPCHK(c, hipMemcpyAsync(dst, base + P.o_tot, nj * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(dst, base + P.o_tot, 2 * nj * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     for (size_t k = 0; k < nj; ++k)
-        HIPCHK(c, hipMemcpyAsync(dst + nj + k, base + P.o_lrec[k] + (P.hs[k]->n_reads + 1) * sizeof(uint4), sizeof(uint32_t),
+        HIPCHK(c, hipMemcpyAsync(dst + 2 * nj + k, base + P.o_lrec[k] + (P.hs[k]->n_reads + 1) * sizeof(uint4), sizeof(uint32_t),
                                  hipMemcpyDeviceToHost, c->stream));
     return GD_OK;
 }
@@ -546,7 +557,7 @@ int ck_finish(gd_ctx* c, CkPending& P, const uint32_t* tot)
     Carve cv;
     std::vector<size_t> o_pck(nj);
     for (size_t k = 0; k < nj; ++k) {
-        const int32_t span = (int32_t)tot[nj + k];
+        const int32_t span = (int32_t)tot[2 * nj + k];
         // the index's 32-bit offsets cannot have wrapped if even this bound fits
         if ((uint64_t)P.hs[k]->n_reads * (((uint64_t)(uint32_t)span >> gd::PT_SHIFT) + 2) > 0xffffffffull)
             return fail(c, GD_E_RANGE, "long-read path: %zu reads spanning up to %d bases -- the tile index would not fit 2^32 entries",
@@ -554,7 +565,7 @@ int ck_finish(gd_ctx* c, CkPending& P, const uint32_t* tot)
         o_pck[k] = cv.take(((size_t)tot[k] + 1) * sizeof(uint32_t));
     }
     BlockRef pck;
-    if (int r = batch_block(c, BlockRef(), cv.at, &pck)) return r;
+    if (int r = batch_block(c, std::move(P.keep_pck), cv.at, &pck)) return r;
     gd::DelJob* jobs = reinterpret_cast<gd::DelJob*>(c->batch_tab_ck.data());
     for (size_t k = 0; k < nj; ++k) jobs[k].pck = reinterpret_cast<uint32_t*>(static_cast<char*>(pck->p) + o_pck[k]);
     HIPCHK(c, hipMemcpyAsync(base + P.o_jobs, c->batch_tab_ck.data(), nj * sizeof(gd::DelJob), hipMemcpyHostToDevice, c->stream));
@@ -565,24 +576,25 @@ int ck_finish(gd_ctx* c, CkPending& P, const uint32_t* tot)
         ContigHost& h = *P.hs[k];
         h.ck_blk = P.blk; h.pck_blk = pck;
         h.lrec = jobs[k].lrec; h.lfq = jobs[k].lfq; h.dl = jobs[k].dl; h.pck = jobs[k].pck;
-        h.max_span = (int32_t)tot[nj + k];
+        h.max_span = (int32_t)tot[2 * nj + k];
+        h.n_dels = tot[nj + k];
         h.ck_ok = true;
     }
     return GD_OK;
 }
 
 // Builds the long-read structures of contigs whose canonical CIGARs exist already.
-int ck_batch(gd_ctx* c, const std::vector<ContigHost*>& hs)
+int ck_batch(gd_ctx* c, const std::vector<ContigHost*>& hs, bool raw = false)
 {
     if (hs.empty()) return GD_OK;
     for (const ContigHost* h : hs)
-        if (!h->normed) return fail(c, GD_E_STATE, "long-read path: a contig has no canonical CIGARs (internal error)");
+        if (!raw && !h->normed) return fail(c, GD_E_STATE, "long-read path: a contig has no canonical CIGARs (internal error)");
     HIPCHK(c, hipEventRecord(c->copy_done, c->copy_stream));
     HIPCHK(c, hipStreamWaitEvent(c->stream, c->copy_done, 0));
     if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[6], c->stream));
     CkPending P;
-    if (int r = ck_enqueue(c, hs, true, &P)) return r;
-    if (int r = batch_host(c, 2 * hs.size())) return r;
+    if (int r = ck_enqueue(c, hs, true, &P, raw)) return r;
+    if (int r = batch_host(c, 3 * hs.size())) return r;
     if (int r = ck_readback(c, P, c->h_batch)) return r;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (int r = ck_finish(c, P, c->h_batch)) return r;
@@ -679,7 +691,7 @@ int norm_batch(gd_ctx* c, const std::vector<ContigHost*>& hs, const std::vector<
     }
     CkPending P;
     const size_t nck = with_ck.size();
-    if (int r = batch_host(c, 2 * nj + 2 * nck)) return r;
+    if (int r = batch_host(c, 2 * nj + 3 * nck)) return r;
     HIPCHK(c, hipMemcpyAsync(c->h_batch, base + o_out, 2 * nj * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     int rc = GD_OK;
     if (nck) {
@@ -766,6 +778,33 @@ int norm_tids(gd_ctx* c, const std::vector<int32_t>& tids, bool force, bool ck_a
             part.push_back(ck_old[i++]);
         }
         if (int r = ck_batch(c, part)) return r;
+    }
+    return GD_OK;
+}
+
+// The long-read structures of the listed contigs that lack them: from the canonical CIGARs where a contig has them,
+// else straight from the records as they arrived -- no canonical arrays are built for it (GD_OPT_NORMALIZE 0 / 2).
+int ck_tids(gd_ctx* c, const std::vector<int32_t>& tids)
+{
+    constexpr uint64_t kMaxUnits = 48u << 20;
+    for (int pass = 0; pass < 2; ++pass) {
+        std::vector<ContigHost*> part;
+        uint64_t units = 0;
+        auto flush = [&]() -> int {
+            if (part.empty()) return GD_OK;
+            const int r = ck_batch(c, part, pass == 1);
+            part.clear(); units = 0;
+            return r;
+        };
+        for (int32_t tid : tids) {
+            ContigHost& h = c->contigs[tid];
+            if (h.length <= 0 || h.ck_ok || (h.normed ? pass != 0 : pass != 1)) continue;
+            if (!part.empty() && units + (h.n_reads + 63) / 64 > kMaxUnits)
+                if (int r = flush()) return r;
+            units += (h.n_reads + 63) / 64;
+            part.push_back(&h);
+        }
+        if (int r = flush()) return r;
     }
     return GD_OK;
 }

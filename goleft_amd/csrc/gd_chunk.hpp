@@ -73,6 +73,8 @@ struct DelJob {
                               // is filled by gd_ptile_fill_kernel, PT_NONE: the read has no deletion)
     uint32_t* lfq;            // n_reads: flag << 8 | MAPQ (the filter is applied per tile)
     uint2*    dl;             // deletion lists {start, length}: (n_ops >> 1) + n_reads + 1 entries
+    uint32_t* ndel;           // n_reads: deletions of each read
+    uint32_t* del_total;      // out: deletions of the contig
     int32_t*  max_span;       // atomicMax of end - pos
     // the tile index (PT kernels below)
     uint32_t* unit;           // this contig's slice of the batch's unit array: n_units + 1 entries per 64-read unit, then
@@ -179,9 +181,147 @@ __global__ __launch_bounds__(256) void gd_dels_kernel(DelBatch B)
     if (valid) {
         job.lrec[r] = make_uint4(p, endp, doff, PT_NONE);
         job.lfq[r] = fq;
+        job.ndel[r] = n >> 1;                              // M and N alternate and the last op is an M
     }
     const uint32_t smax = wave_max_u32(n != 0u ? endp - p : 0u);
     if (lane == 0 && smax != 0u) atomicMax(job.max_span, (int32_t)smax);
+    const uint32_t dsum = (uint32_t)wave_total((int)(valid ? n >> 1 : 0u));
+    if (lane == 0 && dsum != 0u) atomicAdd(job.del_total, dsum);
+}
+
+// ---- the same structures straight from the records AS THEY ARRIVED ------------------------------------------------
+// One pass over the original CIGARs: what gd_normalize.hpp's count + write passes and gd_dels_kernel do in three
+// (a 20x ONT genome: 19 GB of ops read twice and 10 GB of canonical ops written and read again before the first
+// deletion list existed -- 24 + 3 ms in front of a 4.6 ms tile kernel; a run computes its input once).  The walk is
+// the canonical one without the output: I/S/H/P and zero-length ops vanish, neighbouring D/N ops merge into ONE
+// deletion, one that no M follows is dropped, and a read ends where its last M ends.
+
+// one lane, op by op (short CIGARs; ops longer than 2^22 bases or runs that overflow)
+__device__ __forceinline__ uint32_t serial_dels(const uint32_t* __restrict__ ops, uint32_t n, uint32_t pos,
+                                                uint2* __restrict__ out, uint32_t& endp)
+{
+    uint32_t x = pos, w = 0, last_end = pos;
+    uint32_t run_kind = 2u, run_start = pos, run_len = 0u;     // the open run: 0 counted (M = X), 1 skipped (D N), 2 none yet
+    for (uint32_t k = 0; k < n; ++k) {
+        const uint32_t cg = ops[k], op = cg & 0xfu, len = cg >> 4;
+        if (!((0x18du >> op) & 1u) || len == 0u) continue;
+        const uint32_t kind = ((0x181u >> op) & 1u) ? 0u : 1u;
+        if (kind == run_kind) run_len = sat_pos(run_len + len);
+        else {
+            if (run_kind == 1u) out[w++] = make_uint2(run_start, run_len);   // a deletion an M follows
+            if (run_kind == 0u) last_end = x;
+            run_kind = kind; run_start = x; run_len = len;
+        }
+        x = sat_pos(x + len);
+    }
+    if (run_kind == 0u) last_end = x;
+    endp = last_end;
+    return w;
+}
+
+// a whole wave, 64 ops at a time (wave_canonical's run logic: heads from ballots, run lengths as differences of one
+// wave prefix sum).  `overflow`: an op longer than 2^22 bases or a run past the 28-bit range -- the caller walks that
+// read with serial_dels (what it wrote before noticing is overwritten).
+__device__ __forceinline__ uint32_t wave_dels(const uint32_t* __restrict__ ops, uint32_t n, int lane, uint32_t pos,
+                                              uint2* __restrict__ out, uint32_t& endp, bool& overflow)
+{
+    uint32_t open_kind = 2u, open_len = 0u, open_start = pos, cur = pos, w = 0u;   // wave uniform
+    overflow = false;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    for (uint32_t b = 0; b < n; b += 64u) {
+        const uint32_t k = b + (uint32_t)lane;
+        const uint32_t cg = k < n ? ops[k] : 0u;
+        const uint32_t op = cg & 0xfu, len = cg >> 4;
+        const bool kept = ((0x18du >> op) & 1u) && len != 0u;
+        const uint32_t kind = ((0x181u >> op) & 1u) ? 0u : 1u;
+        const unsigned long long km = __builtin_amdgcn_ballot_w64(kept);
+        if (km == 0ull) continue;
+        if (__builtin_amdgcn_ballot_w64(kept && len > (1u << 22)) != 0ull || cur >= POS_CAP - (1u << 28)) { overflow = true; return 0u; }
+        const unsigned long long nm = __builtin_amdgcn_ballot_w64(kept && kind == 1u);
+        const unsigned long long pm = km & below;
+        uint32_t pk = open_kind;
+        if (pm != 0ull) pk = (uint32_t)((nm >> (63 - __clzll((long long)pm))) & 1ull);
+        const bool head = kept && kind != pk;
+        const unsigned long long hm = __builtin_amdgcn_ballot_w64(head);
+        const uint32_t kl = kept ? len : 0u;
+        const uint32_t S = (uint32_t)wave_inclusive_scan((int)kl);     // <= 64 * 2^22
+        const uint32_t E = S - kl;
+        const uint32_t gtot = (uint32_t)__builtin_amdgcn_readlane((int)S, 63);
+        if (hm == 0ull) {                                              // the open run goes on
+            open_len += gtot;
+            if (open_len > norm::LEN_MAX) { overflow = true; return 0u; }
+            cur += gtot;
+            continue;
+        }
+        const bool open_exists = open_kind != 2u;
+        const unsigned long long hb = hm & below;
+        const uint32_t q = (uint32_t)__popcll(hb);
+        const int ph = hb != 0ull ? 63 - __clzll((long long)hb) : 0;
+        const uint32_t Eph = (uint32_t)__shfl((int)E, ph, 64);         // where the run this head closes began
+        const uint32_t tot = q == 0u ? open_len + E : E - Eph;
+        const uint32_t start = q == 0u ? open_start : cur + Eph;
+        const bool closes = head && (q != 0u || open_exists);
+        if (__builtin_amdgcn_ballot_w64(closes && tot > norm::LEN_MAX) != 0ull) { overflow = true; return 0u; }
+        // an M head closes a D/N run: a deletion; its number = the deletions closed by the heads before this lane
+        const unsigned long long dm = __builtin_amdgcn_ballot_w64(closes && kind == 0u);
+        if (closes && kind == 0u) out[w + (uint32_t)__popcll(dm & below)] = make_uint2(start, tot);
+        w += (uint32_t)__popcll(dm);
+        const int lh = __builtin_amdgcn_readfirstlane(63 - __clzll((long long)hm));
+        const uint32_t Elh = (uint32_t)__builtin_amdgcn_readlane((int)E, lh);
+        open_kind = (uint32_t)__builtin_amdgcn_readlane((int)kind, lh);
+        open_len = gtot - Elh;
+        open_start = cur + Elh;
+        cur += gtot;
+    }
+    endp = open_kind == 0u ? cur : open_start;                         // (no run, or only a D/N run: open_start == pos)
+    return w;
+}
+
+constexpr uint32_t WAVE_DELS_MIN = 24;     // reads with more ops than this are walked by the whole wave
+
+__global__ __launch_bounds__(256) void gd_dels_raw_kernel(DelBatch B)
+{
+    const int lane = threadIdx.x & 63;
+    const uint32_t gunit = blockIdx.x * 4u + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (gunit >= B.n_units) return;
+    const uint32_t ji = (uint32_t)__builtin_amdgcn_readfirstlane((int)norm::batch_find(B.ubeg, B.n_jobs, gunit));
+    const DelJob job = B.jobs[ji];
+    const uint32_t unit = gunit - B.ubeg[ji];
+    const uint32_t r = unit * 64u + (uint32_t)lane;
+    const bool valid = r < job.n_reads;
+    uint32_t p = 0, o0 = 0, n = 0, fq = 0;
+    if (valid) {
+        p = (uint32_t)job.pos[r];
+        o0 = job.off[r];
+        n = job.off[r + 1] - o0;
+        fq = ((uint32_t)job.flag[r] << 8) | (uint32_t)job.mapq[r];
+    }
+    const uint32_t doff = (o0 >> 1) + r;                  // at most n / 2 deletions: an M follows each
+    uint32_t endp = p, nd = 0;
+    bool serial = n <= WAVE_DELS_MIN;
+    unsigned long long todo = __builtin_amdgcn_ballot_w64(!serial);
+    while (todo != 0ull) {                                // long reads: the wave walks one at a time
+        const int j = __ffsll((long long)todo) - 1;
+        todo &= todo - 1ull;
+        const uint32_t pj = (uint32_t)__builtin_amdgcn_readlane((int)p, j);
+        const uint32_t oj = (uint32_t)__builtin_amdgcn_readlane((int)o0, j);
+        const uint32_t nj = (uint32_t)__builtin_amdgcn_readlane((int)n, j);
+        const uint32_t dj = (uint32_t)__builtin_amdgcn_readlane((int)doff, j);
+        uint32_t ej = pj;
+        bool ovf;
+        const uint32_t wj = wave_dels(job.cigar + oj, nj, lane, pj, job.dl + dj, ej, ovf);
+        if (lane == j) { nd = wj; endp = ej; serial = ovf; }
+    }
+    if (serial && n != 0u) nd = serial_dels(job.cigar + o0, n, p, job.dl + doff, endp);
+    if (valid) {
+        job.lrec[r] = make_uint4(p, endp, doff, PT_NONE);
+        job.lfq[r] = fq;
+        job.ndel[r] = nd;
+    }
+    const uint32_t smax = wave_max_u32(endp - p);
+    if (lane == 0 && smax != 0u) atomicMax(job.max_span, (int32_t)smax);
+    const uint32_t dsum = (uint32_t)wave_total((int)nd);
+    if (lane == 0 && dsum != 0u) atomicAdd(job.del_total, dsum);
 }
 
 // PT: the tile index.  Entries of read r: boundaries b_k = ((pos >> 12) + k) << 12 for k = 0 .. K - 1 with
@@ -206,7 +346,7 @@ __global__ __launch_bounds__(256) void gd_ptile_count_kernel(DelBatch B)
     uint32_t K = 0;
     if (r < job.n_reads) {
         const uint4 rc = job.lrec[r];
-        K = pt_entries(rc.x, rc.y, (job.off[r + 1] - job.off[r]) >> 1);
+        K = pt_entries(rc.x, rc.y, job.ndel[r]);
     }
     const uint32_t incl = (uint32_t)wave_inclusive_scan((int)K);
     if (r < job.n_reads) job.lrec[r].w = K != 0u ? incl - K : PT_NONE;
@@ -234,7 +374,7 @@ __global__ __launch_bounds__(256) void gd_ptile_fill_kernel(DelBatch B)
     if (r >= job.n_reads) return;
     const uint4 rc = job.lrec[r];
     if (rc.w == PT_NONE) return;
-    const uint32_t n_del = (job.off[r + 1] - job.off[r]) >> 1;
+    const uint32_t n_del = job.ndel[r];
     const uint32_t K = pt_entries(rc.x, rc.y, n_del);
     const uint32_t pb = job.unit[r >> 6] - job.unit[0] + rc.w;
     job.lrec[r].w = pb;

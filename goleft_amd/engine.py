@@ -144,6 +144,10 @@ class DepthEngine:
         """gd_drop_derived: back to the state right after the records arrived."""
         self._chk(self._lib.gd_drop_derived(self._ctx))
 
+    def rebuild_derived(self):
+        """gd_rebuild_derived: every derived structure the contigs hold, again, from the records."""
+        self._chk(self._lib.gd_rebuild_derived(self._ctx))
+
     def compute_launch(self):
         """gd_compute_launch: enqueue a compute, do not wait (compute_finish does)."""
         self._chk(self._lib.gd_compute_launch(self._ctx))

@@ -111,6 +111,7 @@ typedef struct {
     uint64_t n_canonical_ops; /* ops of the canonical CIGARs the tile / long-read path read (0: it read the original ones) */
     int32_t  tile_kernel;    /* GD_TK_*: the kernel that did the per-base arithmetic of the last gd_compute */
     int32_t  reserved_;
+    uint64_t n_deletions;    /* long-read path: entries of the deletion lists the tile kernel read (8 bytes each) */
 } gd_stats;
 
 /* gd_stats.tile_kernel */
@@ -208,6 +209,11 @@ int gd_set_option(gd_ctx* ctx, int option, int64_t value);
  * arrived (measurement: one gd_compute from there is what one `goleft depth` run pays). */
 int gd_normalize(gd_ctx* ctx, int force);
 int gd_drop_derived(gd_ctx* ctx);
+/* Measurement: rebuilds every derived structure the selected contigs currently hold from their records, into the
+ * device blocks they already occupy (canonical records as gd_normalize(force); long-read structures that the
+ * long-read path built straight from the records, the same way again) -- the work a fresh input costs, without
+ * the allocator's. */
+int gd_rebuild_derived(gd_ctx* ctx);
 
 /* Diagnostic: the canonical CIGARs of contig tid (GD_OPT_NORMALIZE) as CSR offsets (n_reads + 1) and ops
  * (BAM encoding, op 0 = M or 3 = N) into host memory.  *n_ops receives the op count; GD_E_CAPACITY if cap_ops

@@ -155,10 +155,16 @@ def test_wave_walked_canonical_cigars_equal_restatement(seed):
         eng.set_path(3)                                      # GD_PATH_CHUNK
         eng.set_contigs([L])
         eng.push(0, r.pos, r.flag, r.mapq, r.cigar_off, r.cigar)
+        eng.compute()                                        # default: deletion lists straight from the records
+        st0 = eng.stats()
+        got0 = eng.perbase(0)
+        assert st0.path == 3 and st0.n_canonical_ops == 0
+        eng.normalize()                                      # ... and from the canonical CIGARs
         eng.compute()
         off, cig_got = eng.canonical_cigars(0, r.n)
         st = eng.stats()
         got = eng.perbase(0)
+        assert np.array_equal(got0, got) and st0.n_deletions == st.n_deletions == int((cig_got & 0xf == 3).sum())
     woff, wcig = po.canonical_cigars(r)
     assert np.array_equal(off, woff)
     assert np.array_equal(cig_got, wcig)

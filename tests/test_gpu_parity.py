@@ -8,20 +8,21 @@ from oracle import pyoracle as po
 pytestmark = pytest.mark.gpu
 
 
-PATH_IDS = {"tile": 1, "tile-canonical": 1, "scatter": 2, "chunk": 3}
+PATH_IDS = {"tile": 1, "tile-canonical": 1, "scatter": 2, "chunk": 3, "chunk-canonical": 3}
 
 
-@pytest.fixture(scope="module", params=["tile", "tile-canonical", "chunk", "scatter"])
+@pytest.fixture(scope="module", params=["tile", "tile-canonical", "chunk", "chunk-canonical", "scatter"])
 def eng(request):
     """Every parity test runs on all three device algorithms (GD_PATH_TILE: LDS tiles
     re-walking whole CIGARs, the short-read path -- once on the records as they arrived, the
     default (gd_tile_fast_kernel<raw>), once on canonical records built at arrival
     (GD_OPT_NORMALIZE = 1: gd_tile_fast_kernel); GD_PATH_CHUNK: LDS tiles over deletion lists,
-    the long-read path; GD_PATH_SCATTER: global scatter + in-place scan)."""
+    the long-read path -- lists built straight from the records (default) or from canonical CIGARs
+    (GD_OPT_NORMALIZE = 1); GD_PATH_SCATTER: global scatter + in-place scan)."""
     from goleft_amd.engine import DepthEngine, OPT_NORMALIZE
     e = DepthEngine(0)
     e.set_path(PATH_IDS[request.param])
-    if request.param == "tile-canonical":
+    if request.param.endswith("-canonical"):
         e.set_option(OPT_NORMALIZE, 1)
     e.path_name = request.param
     yield e
