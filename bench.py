@@ -367,6 +367,9 @@ def run_case(args, scaling, world, rank, dev, local_rank, want_streams=False):
     torch.cuda.synchronize()
     st_incl = eng.stats()
     incl_kernel, incl_canon, incl_slow = int(st_incl.tile_kernel), int(st_incl.n_canonical_ops), int(st_incl.n_slow_tiles)
+    if int(st_incl.n_deletions) and not incl_canon:
+        # deletion lists built straight from the records: a deletion is what an (M, N) pair of canonical ops was
+        incl_canon = 2 * int(st_incl.n_deletions) + n_reads
 
     # ---- the same step with the derived structures KEPT from step to step (round 2's `value`) --------------
     only = None
@@ -532,7 +535,7 @@ def main():
     # canonical ops on the tile and long-read paths) + 4 B/base + 8 B/window
     # (the raw straight-line kernel reads flag 2 + MAPQ 1 per read too and the ops as they arrived)
     ops_read = r["n_canonical_ops"] if r["n_canonical_ops"] else r["n_ops"]
-    raw_records = r["kernel"] == "gd_tile_fast_kernel<raw>"
+    raw_records = r["kernel"].endswith("<raw>")
     alg_bytes = synth.algorithmic_bytes(r["n_reads"], ops_read, r["my_bases"] if r["perbase"] else 0,
                                         r["my_windows"], raw=raw_records)   # windows-only: no 4 B/base write
     scatter = r["path"] == 2
@@ -621,7 +624,7 @@ def main():
         # the step with the derived structures kept (round 2's headline), and what building them costs
         ops_o = o["n_canonical_ops"] if o["n_canonical_ops"] else r["n_ops"]
         alg_o = synth.algorithmic_bytes(r["n_reads"], ops_o, r["my_bases"] if r["perbase"] else 0, r["my_windows"],
-                                        raw=o["kernel"] == "gd_tile_fast_kernel<raw>")
+                                        raw=o["kernel"].endswith("<raw>"))
         out["compute_only"] = {
             "value": r["total_bases"] * args.steps / o["dt"], "unit": "ref-bases/s", "ms_per_step": o["dt"] / args.steps * 1e3,
             "what": "the same step with canonical records / long-read structures kept from step to step",

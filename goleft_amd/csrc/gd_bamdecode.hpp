@@ -28,7 +28,8 @@ struct BamSegJob {
     uint64_t* n_ops;               // [n_seg]
     int32_t*  first_pos;           // [n_seg] (0x7fffffff when empty)
     int32_t*  last_pos;            // [n_seg]
-    uint32_t* flags;               // [n_seg] bit0 unsorted inside, bit1 corrupt record, bit2 walk overran seg_end
+    uint32_t* flags;               // [n_seg] bit0 unsorted inside, bit1 corrupt record, bit2 walk overran seg_end,
+                                   // bit3 a record of another reference ended the walk before seg_end
     // extract pass
     const uint64_t* rec_base;      // [n_seg] first record index of the segment
     const uint64_t* op_base;       // [n_seg] first op index
@@ -102,8 +103,11 @@ __global__ __launch_bounds__(64) void gd_bam_walk_kernel(BamSegJob j)
         const uint32_t block_size = ld32(j.data + off);
         if (block_size < 32 || off + 4 + block_size > j.n_bytes) { fl |= 2u; break; }
         const int32_t ref_id = (int32_t)ld32(r);
-        if (ref_id != j.tid) break;                          // the contig's records end here
+        if (ref_id != j.tid) { fl |= 8u; break; }            // the contig's records end here (the host checks that they do)
         const int32_t pos = (int32_t)ld32(r + 4);
+        // POS -1 is BAM's "no position": a record filed under the reference but not placed on it (what `samtools
+        // depth` drops through the 0x4 flag such a record carries) is not part of the contig's stream
+        if (pos < 0) { off += 4ull + block_size; continue; }
         const uint8_t* cg;
         uint32_t nc;
         if (!bam_record_cigar(r, block_size, &cg, &nc)) { fl |= 2u; break; }

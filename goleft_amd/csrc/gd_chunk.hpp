@@ -228,9 +228,17 @@ __device__ __forceinline__ uint32_t wave_dels(const uint32_t* __restrict__ ops, 
     uint32_t open_kind = 2u, open_len = 0u, open_start = pos, cur = pos, w = 0u;   // wave uniform
     overflow = false;
     const unsigned long long below = (1ull << lane) - 1ull;
-    for (uint32_t b = 0; b < n; b += 64u) {
-        const uint32_t k = b + (uint32_t)lane;
-        const uint32_t cg = k < n ? ops[k] : 0u;
+    // DL_UNROLL groups of 64 ops in flight: one group at a time left the wave waiting a memory round trip per 256 bytes
+    for (uint32_t b0 = 0; b0 < n; b0 += DL_UNROLL * 64u) {
+        uint32_t cgv[DL_UNROLL];
+#pragma unroll
+        for (int u = 0; u < DL_UNROLL; ++u) {
+            const uint32_t k = b0 + (uint32_t)u * 64u + (uint32_t)lane;
+            cgv[u] = k < n ? ops[k] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < DL_UNROLL; ++u) {
+        const uint32_t cg = cgv[u];
         const uint32_t op = cg & 0xfu, len = cg >> 4;
         const bool kept = ((0x18du >> op) & 1u) && len != 0u;
         const uint32_t kind = ((0x181u >> op) & 1u) ? 0u : 1u;
@@ -272,6 +280,7 @@ __device__ __forceinline__ uint32_t wave_dels(const uint32_t* __restrict__ ops, 
         open_len = gtot - Elh;
         open_start = cur + Elh;
         cur += gtot;
+        }
     }
     endp = open_kind == 0u ? cur : open_start;                         // (no run, or only a D/N run: open_start == pos)
     return w;

@@ -220,6 +220,8 @@ bool BamReader::open(const std::string& path, int threads, std::string* err)
         contigs_.push_back(c);
         cur_ += 8 + l_name;
     }
+    left_.assign(contigs_.size(), false);
+    last_ref_ = -2;
     return true;
 }
 
@@ -326,6 +328,8 @@ bool BamReader::seek_contig(int32_t tid, std::string* err)
     done_ = false;
     if (!need(uoff + 1, err)) return false;
     cur_ = uoff;
+    left_.assign(contigs_.size(), false);         // a deliberate jump: the run rule starts over
+    last_ref_ = -2;
     return true;
 }
 
@@ -409,8 +413,21 @@ int BamReader::next_block(RecordBlock& out, size_t max_reads, std::string* err)
         if (!need(p + 4 + (size_t)block_size, &e)) { if (err) *err = e.empty() ? "truncated BAM record" : e; return -1; }
         const int32_t ref_id = (int32_t)rd32(buf_.data() + cur_ + p + 4);
         if (!at.empty() && (ref_id != out.tid || at.size() >= max_reads)) break;   // leave it for the next call
+        // a coordinate-sorted BAM holds a reference's records in ONE run (`samtools depth -r` stops at the first
+        // record of another reference): records of a reference that was left already are refused, not appended
+        if (ref_id != last_ref_) {
+            if (last_ref_ >= 0 && (size_t)last_ref_ < left_.size()) left_[(size_t)last_ref_] = true;
+            last_ref_ = ref_id;
+            if (ref_id >= 0 && ((size_t)ref_id >= left_.size() || left_[(size_t)ref_id])) {
+                if (err) *err = (size_t)ref_id >= left_.size() ? "corrupt BAM record (reference id out of range)"
+                                                               : "BAM not sorted: records of a reference continue after another reference's";
+                return -1;
+            }
+        }
         ++n_records_;
-        if (ref_id < 0) { ++n_unplaced_; p += 4 + block_size; continue; }
+        // unplaced records: no reference, or filed under one with POS -1 ("no position", dropped by samtools depth
+        // through the 0x4 flag they carry)
+        if (ref_id < 0 || (int32_t)rd32(buf_.data() + cur_ + p + 8) < 0) { ++n_unplaced_; p += 4 + block_size; continue; }
         if (at.empty()) out.tid = ref_id;
         at.push_back(p + 4);
         p += 4 + block_size;

@@ -95,6 +95,8 @@ private:
     std::vector<BamContig> contigs_;
     std::string text_;
     uint64_t n_records_ = 0, n_unplaced_ = 0;
+    std::vector<bool> left_;          // references whose run of records has ended (a sorted BAM never returns to one)
+    int32_t last_ref_ = -2;           // reference of the last record seen (-2: none yet, or just after a seek)
 };
 
 }  // namespace gdh

@@ -301,3 +301,108 @@ def test_ingest_state_errors_and_pinned_alloc(tmp_path):
         assert lib.gd_host_alloc(eng._ctx, 1 << 20, C.byref(ptr)) == 0 and ptr.value
         C.memset(ptr, 7, 1 << 20)
         assert lib.gd_host_free(eng._ctx, ptr) == 0
+
+
+def _record_starts(inflated: bytes):
+    """Offsets of the records of a BAM's inflated stream (after the header and reference table)."""
+    l_text, = struct.unpack_from("<i", inflated, 4)
+    p = 8 + l_text
+    n_ref, = struct.unpack_from("<i", inflated, p)
+    p += 4
+    for _ in range(n_ref):
+        l_name, = struct.unpack_from("<i", inflated, p)
+        p += 8 + l_name
+    out = []
+    while p + 4 <= len(inflated):
+        bs, = struct.unpack_from("<i", inflated, p)
+        out.append(p)
+        p += 4 + bs
+    return out
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("GOLEFT_FUZZ_SEEDS", "40"))))
+def test_device_bam_walker_mutation_fuzz(tmp_path, seed):
+    """Random byte flips in the INFLATED record stream of a BAM (re-compressed, so every BGZF CRC holds and only the
+    record walker can notice), biased to the fields a walker trusts -- block_size, refID, pos, l_read_name,
+    n_cigar_op, l_seq, the CIGAR -- and flips in the compressed members: the device read must either refuse the file
+    (GD_E_INVALID / GD_E_UNSORTED) or deliver exactly what the host decoder delivers; the context stays usable and
+    the GPU never faults (a fault would end the test process).  The reference gets this from samtools
+    (depth/depth.go:395-399 just reports the child's exit code)."""
+    from goleft_amd import _hostlib
+    from goleft_amd.engine import DepthEngine, GdError
+    contigs, reads, _ = H.load_golden_bam("t")
+    p0 = str(tmp_path / "a.bam")
+    bamio.write_bam(p0, contigs, reads, unplaced=3, index=True)
+    data0 = open(p0, "rb").read()
+    infl = bytearray(bamio.bgzf_decompress(data0))
+    lin0 = bamio.read_bai_linear(p0 + ".bai")
+    # anchors as uncompressed offsets (every data member of bamio's files holds `block` bytes)
+    block = 0xff00
+    sizes0: list = []
+    bamio.bgzf_compress(bytes(infl), level=1, sizes=sizes0)
+    coff0 = np.concatenate([[0], np.cumsum(sizes0)]).astype(np.int64)
+    def to_uncompressed(v):
+        k = int(np.searchsorted(coff0, int(v) >> 16))
+        return k * block + (int(v) & 0xffff)
+    anchors_u = {t: [to_uncompressed(v) for v in lin0[t]] for t in lin0}
+    starts = _record_starts(bytes(infl))
+    rng = np.random.default_rng(1000 + seed)
+    mode = seed % 4
+    if mode < 3:
+        for _ in range(int(rng.integers(1, 6))):
+            s = starts[int(rng.integers(0, len(starts)))]
+            field = int(rng.integers(0, 9))
+            # block_size, refID, pos, l_read_name, n_cigar_op, l_seq, flag / mapq, first CIGAR bytes, anywhere in the record
+            at = s + [int(rng.integers(0, 4)), 4 + int(rng.integers(0, 4)), 8 + int(rng.integers(0, 4)), 12, 16 + int(rng.integers(0, 2)),
+                      20 + int(rng.integers(0, 4)), 13 + int(rng.integers(0, 6)), 36 + int(rng.integers(0, 24)),
+                      int(rng.integers(0, 200))][field]
+            if at < len(infl):
+                infl[at] = (infl[at] ^ (1 << int(rng.integers(0, 8)))) if rng.random() < 0.6 else int(rng.integers(0, 256))
+    sizes: list = []
+    data = bytearray(bamio.bgzf_compress(bytes(infl), level=1, sizes=sizes))
+    if mode == 3:                                            # the compressed bytes themselves
+        for _ in range(int(rng.integers(1, 4))):
+            data[int(rng.integers(0, len(data) - 28))] ^= 1 << int(rng.integers(0, 8))
+    data = bytes(data)
+    coff = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    p1 = str(tmp_path / "m.bam")
+    open(p1, "wb").write(data)
+    # what the host decoder makes of it
+    host = None
+    try:
+        _, host, _ = _hostlib.read_bam(p1, threads=2)
+        for t, (pos, flag, mapq, off, cig) in host.items():
+            if t >= len(contigs) or (len(pos) > 1 and (np.diff(pos) < 0).any()):
+                host = None                                  # a reference out of range / unsorted: gd_commit refuses it
+                break
+    except OSError:
+        host = None
+    with DepthEngine(0) as eng:
+        eng.set_params(window_size=100, min_mapq=1, min_cov=4)
+        eng.set_contigs([c[1] for c in contigs])
+        got = {}
+        try:
+            for t in sorted(anchors_u):
+                if len(anchors_u[t]) == 0:
+                    continue
+                anchors = np.array([(int(coff[o // block]) << 16) | (o % block) for o in anchors_u[t]], np.uint64)
+                got[t] = eng.ingest_bgzf(t, data, 0, anchors)
+            eng.compute()
+            dev = {t: eng.perbase(t) for t in got}
+        except GdError as e:
+            assert e.status in (-1, -7, -5), e               # GD_E_INVALID, GD_E_UNSORTED (GD_E_RANGE: a length past the limits)
+            dev = None
+        if dev is not None:
+            assert host is not None, "the device read accepted a file the host decoder refuses"
+            for t in got:
+                r = host.get(t)
+                want = po.perbase_c(po.Reads(*r), 1, 0, contigs[t][1]) if r is not None else np.zeros(contigs[t][1], np.int32)
+                assert got[t] == (len(r[0]) if r is not None else 0), (t, got[t])
+                assert np.array_equal(dev[t], want), t
+        # the context is still usable: the unmodified file goes through
+        for t in sorted(lin0):
+            if len(lin0[t]):
+                assert eng.ingest_bgzf(t, data0, 0, lin0[t]) == reads[t].n
+        eng.compute()
+        for t in reads:
+            assert np.array_equal(eng.perbase(t), po.perbase_c(reads[t], 1, 0, contigs[t][1]))
