@@ -704,6 +704,10 @@ int gd_set_option(gd_ctx* c, int option, int64_t value)
         c->h2d_kernel = value != 0;
         if (value > 1) c->h2d_grid = (unsigned)value;
         break;
+    case GD_OPT_BAM_REFS:
+        if (value < 0 || value > 0x7fffffff) return fail(c, GD_E_INVALID, "BAM references: 0 (unknown) .. 2^31 - 1");
+        c->bam_n_ref = (int32_t)value;
+        break;
     case GD_OPT_PUSH_CHUNK:
         if (value < 4096 || value > (1 << 24)) return fail(c, GD_E_INVALID, "push chunk: 4096 .. 2^24 records");
         c->push_chunk = (size_t)value;

@@ -196,6 +196,7 @@ struct gd_ctx {
     int ing_copy_threads = 1;                          // GD_OPT_COPY_THREADS: threads filling the staging buffer
     bool h2d_kernel = true;                            // GD_OPT_H2D_KERNEL: staging blocks reach HBM through gd_h2d_kernel
     unsigned h2d_grid = 512;                           // ... its workgroups
+    int32_t bam_n_ref = 0;                             // GD_OPT_BAM_REFS: references of the BAM being read (0: unknown)
     int push_threads = 16;
     size_t push_chunk = 1u << 20;                      // GD_OPT_PUSH_CHUNK: records per staging block of gd_push                             // GD_OPT_PUSH_THREADS: threads of gd_push filling a ring block
     uint32_t* d_scan_tmp = nullptr; size_t cap_scan_tmp = 0;   // launch_scan: block totals

@@ -22,6 +22,7 @@ struct BamSegJob {
     const uint64_t* seg_beg;       // [n_seg] byte offset of the first record of the segment
     const uint64_t* seg_end;       // [n_seg] where the walk stops (next anchor, or n_bytes)
     int32_t  tid;                  // records of another reference end the contig
+    int32_t  n_ref;                // references of the file: a sorted BAM goes on with tid < refID < n_ref, or -1
     uint32_t n_seg;
     // count pass
     uint32_t* n_rec;               // [n_seg]
@@ -29,7 +30,8 @@ struct BamSegJob {
     int32_t*  first_pos;           // [n_seg] (0x7fffffff when empty)
     int32_t*  last_pos;            // [n_seg]
     uint32_t* flags;               // [n_seg] bit0 unsorted inside, bit1 corrupt record, bit2 walk overran seg_end,
-                                   // bit3 a record of another reference ended the walk before seg_end
+                                   // bit3 a record of another reference ended the walk before seg_end, bit4 ... and
+                                   // the reference resumes within the next 64 records
     // extract pass
     const uint64_t* rec_base;      // [n_seg] first record index of the segment
     const uint64_t* op_base;       // [n_seg] first op index
@@ -103,7 +105,25 @@ __global__ __launch_bounds__(64) void gd_bam_walk_kernel(BamSegJob j)
         const uint32_t block_size = ld32(j.data + off);
         if (block_size < 32 || off + 4 + block_size > j.n_bytes) { fl |= 2u; break; }
         const int32_t ref_id = (int32_t)ld32(r);
-        if (ref_id != j.tid) { fl |= 8u; break; }            // the contig's records end here (the host checks that they do)
+        if (ref_id != j.tid) {
+            // the contig's records end here -- in a sorted BAM.  `samtools depth -r` stops at the first record of
+            // another reference and so does this walk; that the reference does not RESUME is checked over the next
+            // records up to the segment's end (at most 64: one damaged refID is caught, a contig's true end costs
+            // nothing), and by the host across segments (bit 3)
+            fl |= 8u;
+            if (!(ref_id == -1 || (ref_id > j.tid && ref_id < j.n_ref))) { fl |= 2u; break; }   // not a refID a sorted BAM holds here: a damaged record (or a walk out of step)
+            if (!EXTRACT) {
+                uint64_t o2 = off;
+                for (int k = 0; k < 64 && o2 < stop; ++k) {
+                    if (o2 + 36 > j.n_bytes) break;
+                    const uint32_t bs = ld32(j.data + o2);
+                    if (bs < 32 || o2 + 4 + bs > j.n_bytes) break;
+                    if ((int32_t)ld32(j.data + o2 + 4) == j.tid) { fl |= 16u; break; }
+                    o2 += 4ull + bs;
+                }
+            }
+            break;
+        }
         const int32_t pos = (int32_t)ld32(r + 4);
         // POS -1 is BAM's "no position": a record filed under the reference but not placed on it (what `samtools
         // depth` drops through the 0x4 flag such a record carries) is not part of the contig's stream

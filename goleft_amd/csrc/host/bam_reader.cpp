@@ -417,10 +417,15 @@ int BamReader::next_block(RecordBlock& out, size_t max_reads, std::string* err)
         // record of another reference): records of a reference that was left already are refused, not appended
         if (ref_id != last_ref_) {
             if (last_ref_ >= 0 && (size_t)last_ref_ < left_.size()) left_[(size_t)last_ref_] = true;
+            const int32_t before = last_ref_;
             last_ref_ = ref_id;
-            if (ref_id >= 0 && ((size_t)ref_id >= left_.size() || left_[(size_t)ref_id])) {
-                if (err) *err = (size_t)ref_id >= left_.size() ? "corrupt BAM record (reference id out of range)"
-                                                               : "BAM not sorted: records of a reference continue after another reference's";
+            if (ref_id < -1 || (ref_id >= 0 && (size_t)ref_id >= left_.size())) {
+                if (err) *err = "corrupt BAM record (reference id out of range)";
+                return -1;
+            }
+            // sorted by (reference, position): references ascend, the unplaced records (-1) come last
+            if (ref_id >= 0 && (left_[(size_t)ref_id] || before == -1 || (before >= 0 && ref_id < before))) {
+                if (err) *err = "BAM not sorted: records of a reference after a later reference's (or after the unplaced ones)";
                 return -1;
             }
         }

@@ -486,6 +486,7 @@ int run(const DArgs& args)
         GDCHK_ON(sh.ctx, gd_set_params(sh.ctx, &P));
         GDCHK_ON(sh.ctx, gd_set_option(sh.ctx, GD_OPT_COPY_THREADS, 4));   // staging copies of the device BAM read (8 % on a 3 GB file)
         GDCHK_ON(sh.ctx, gd_set_contigs(sh.ctx, (int)lens.size(), lens.data()));
+        GDCHK_ON(sh.ctx, gd_set_option(sh.ctx, GD_OPT_BAM_REFS, (int64_t)lens.size()));   // engine contigs = the BAM's references
         if (!need_perbase) GDCHK_ON(sh.ctx, gd_set_outputs(sh.ctx, 0));   // windows + class runs are all the rows need
         if (!contigs.empty() && !sh.wanted.empty())
             GDCHK_ON(sh.ctx, gd_select_contigs(sh.ctx, (int)sh.wanted.size(), sh.wanted.data()));

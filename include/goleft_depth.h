@@ -195,6 +195,10 @@ enum { /* (1, 2: tile shapes other than 4096 positions x 256 threads -- measured
        GD_OPT_PUSH_THREADS = 7,     /* host threads of gd_push copying into a pinned ring block: 16 (default), 1 .. 64
                                        (one core moves ~11 GB/s into pinned memory; the link takes five times that) */
        GD_OPT_PUSH_CHUNK = 9,       /* records per staging block of gd_push: 2^20 (default), 4096 .. 2^24 */
+       GD_OPT_BAM_REFS = 10,        /* gd_ingest_*: number of references in the BAM header (0, the default: unknown).  The
+                                       record walk takes the first record of ANOTHER reference as the end of a contig's
+                                       records only when its refID is one a sorted BAM can hold there (greater than the
+                                       contig's and below this number, or -1); anything else is a damaged record */
        GD_OPT_H2D_KERNEL = 8 };     /* how a committed staging block reaches HBM: 1 (default) one kernel whose workgroups
                                        read the page-locked block over the link (all five arrays in one launch; n > 1:
                                        with n workgroups), 0: five hipMemcpyAsync through a DMA engine */

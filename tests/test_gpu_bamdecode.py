@@ -160,8 +160,13 @@ def test_ingest_several_references_in_one_pass(tmp_path):
         with pytest.raises(GdError):
             eng.ingest_bgzf_refs(data, 0, [(0, 0, lin[0]), (2, 2, bogus)])
         assert eng.ingest_bgzf(0, data, 0, lin[0]) == reads[0].n
-        # anchors of one reference decoded as another: its walk ends at the first record (no records, no error)
-        assert eng.ingest_bgzf_refs(data, 0, [(1, 2, lin[1])]) == [0]
+        # anchors of a LATER reference decoded as an earlier one: its walk ends at the first record (no records, no
+        # error: a sorted BAM goes on with later references) ...
+        assert eng.ingest_bgzf_refs(data, 0, [(1, 1, lin[2])]) == [0]
+        # ... anchors of an EARLIER reference: records a sorted BAM cannot hold after this contig's -- refused
+        with pytest.raises(GdError):
+            eng.ingest_bgzf_refs(data, 0, [(1, 2, lin[1])])
+        assert eng.ingest_bgzf(0, data, 0, lin[0]) == reads[0].n
 
 
 def test_ingest_two_ranges_pending(tmp_path):
@@ -349,9 +354,11 @@ def test_device_bam_walker_mutation_fuzz(tmp_path, seed):
     rng = np.random.default_rng(1000 + seed)
     mode = seed % 4
     if mode < 3:
-        for _ in range(int(rng.integers(1, 6))):
+        # mode 0: one or two flips in fields whose every value is a legal record (pos, flag / mapq, CIGAR bytes): most
+        # of these files stay readable and are COMPARED; mode 1: one flip anywhere in the fixed fields; mode 2: up to five
+        for _ in range(int(rng.integers(1, 3 if mode < 2 else 6))):
             s = starts[int(rng.integers(0, len(starts)))]
-            field = int(rng.integers(0, 9))
+            field = int(rng.choice([2, 6, 7])) if mode == 0 else int(rng.integers(0, 9))
             # block_size, refID, pos, l_read_name, n_cigar_op, l_seq, flag / mapq, first CIGAR bytes, anywhere in the record
             at = s + [int(rng.integers(0, 4)), 4 + int(rng.integers(0, 4)), 8 + int(rng.integers(0, 4)), 12, 16 + int(rng.integers(0, 2)),
                       20 + int(rng.integers(0, 4)), 13 + int(rng.integers(0, 6)), 36 + int(rng.integers(0, 24)),
@@ -378,8 +385,10 @@ def test_device_bam_walker_mutation_fuzz(tmp_path, seed):
     except OSError:
         host = None
     with DepthEngine(0) as eng:
+        from goleft_amd.engine import OPT_BAM_REFS
         eng.set_params(window_size=100, min_mapq=1, min_cov=4)
         eng.set_contigs([c[1] for c in contigs])
+        eng.set_option(OPT_BAM_REFS, len(contigs))
         got = {}
         try:
             for t in sorted(anchors_u):
