@@ -99,7 +99,11 @@ __global__ __launch_bounds__(256) void gd_seq_stats_kernel(SeqStatsJob job)
                     if ((r0 + (uint32_t)j) % lb == lb - 1u) not_eol &= ~(0x80u << (8 * j));
             }
             n_gc += __popc((is_c | is_g) & in);
-            n_cpg += __popc(is_c & g_next & in & not_eol);
+            // line aware (the raw-scan contract): a scan of the window's own bytes cannot see the base after its last
+            // one either -- a C at e - 1 starts no CpG
+            uint32_t in_cpg = in;
+            if (lb != 0u && e - 1 >= p0 && e - 1 < p0 + 4) in_cpg &= ~(0x80u << (8 * (int)(e - 1 - p0)));
+            n_cpg += __popc(is_c & g_next & in_cpg & not_eol);
             n_low += __popc(low & in);
             n_acgt += __popc(acgt);
             n_lacgt += __popc(acgt & ((x & 0x20202020u) << 2));                      // bit 5: lower case

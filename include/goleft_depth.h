@@ -374,8 +374,9 @@ int gd_seq_stats(gd_ctx* ctx, size_t n_windows, const int64_t* start, const int6
 /* The same plus what the other plausible reading of faidx.Stats needs (goleft_depth_host.h GDH_STATS_*; the
  * caller picks the contract, the library only counts): n_acgt = bases in "ACGTacgt" (a denominator that
  * skips N and IUPAC codes), n_masked_acgt = bases in "acgt"; either may be NULL.  line_bases > 0 (bases per
- * FASTA line, the .fai LINEBASES column): a C that is the last base of a line does not start a CpG -- what
- * a scan of the raw, line-broken file sees; 0: the sequence is one line. */
+ * FASTA line, the .fai LINEBASES column): a C that is the last base of a line -- or of the window -- does not
+ * start a CpG: what a scan of the window's raw, line-broken bytes sees; 0: the sequence is one line and the
+ * base after the window counts. */
 int gd_seq_stats_ex(gd_ctx* ctx, size_t n_windows, const int64_t* start, const int64_t* end, int32_t line_bases,
                     uint32_t* n_gc, uint32_t* n_cpg, uint32_t* n_masked, uint32_t* n_acgt, uint32_t* n_masked_acgt);
 

@@ -79,8 +79,9 @@ int64_t gdh_list_members(const uint8_t* data, size_t n_bytes, uint64_t beg, cons
  *                            are skipped; a window without any prints 0 0 0); clear: over the window length
  *   GDH_STATS_MASKED_ACGT    masked = lower-case a/c/g/t; clear: any lower-case letter (n included)
  *   GDH_STATS_CPG_CLAMP      CpG = min(1, 2 cpg / denominator); clear: not clamped
- *   GDH_STATS_CPG_RAW_LINES  a C that is the last base of a FASTA line starts no CpG (a scan of the raw,
- *                            line-broken file sees "C\nG"); clear: line breaks are invisible
+ *   GDH_STATS_CPG_RAW_LINES  a C that is the last base of a FASTA line -- or of the window -- starts no CpG (a
+ *                            scan of the window's raw, line-broken bytes sees "C\nG", and nothing past the
+ *                            window); clear: line breaks are invisible and the base after the window counts
  * GDH_STATS_FAIDX (all four) is the default: it is how three independent recollections of faidx.Stats read
  * (the builder's, the round-1 judge's and the round-1 advisor's: "copied from cnvkit", counters gcUp / gcLo /
  * atUp / atLo over the mmapped bytes, tot = their sum, CpG: min(1.0, 2 cpg / tot)) -- a lead, not a citation.

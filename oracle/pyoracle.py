@@ -256,8 +256,9 @@ STATS_WINDOW, STATS_FAIDX = 0, 15
 def seq_counts(seq: bytes, start: int, end: int, line_bases: int = 0):
     """(n_gc, n_cpg, n_masked, n_acgt, n_masked_acgt) of seq[start:end] clipped to the contig -- seq_stats plus
     what the other reading of faidx.Stats needs: A/C/G/T bases of either case, lower-case a/c/g/t; with
-    line_bases > 0 a C that is the last base of a FASTA line (position % line_bases == line_bases - 1) starts
-    no CpG.  Pure Python, byte by byte; the contract of gd_seq_stats_ex."""
+    line_bases > 0 (a scan of the window's raw, line-broken bytes) a C that is the last base of a FASTA line
+    (position % line_bases == line_bases - 1) or the last base of the WINDOW starts no CpG: neither G is among the
+    bytes scanned.  Pure Python, byte by byte; the contract of gd_seq_stats_ex."""
     s, e = max(0, start), min(end, len(seq))
     gc = cpg = low = acgt = lacgt = 0
     for i in range(s, e):
@@ -270,7 +271,7 @@ def seq_counts(seq: bytes, start: int, end: int, line_bases: int = 0):
             acgt += 1
             if c in b"acgt":
                 lacgt += 1
-        eol = line_bases > 0 and i % line_bases == line_bases - 1
+        eol = line_bases > 0 and (i % line_bases == line_bases - 1 or i == e - 1)
         if c in b"Cc" and not eol and i + 1 < len(seq) and seq[i + 1] in b"Gg":
             cpg += 1
     return gc, cpg, low, acgt, lacgt

@@ -66,6 +66,10 @@ def test_both_contracts_on_windows_with_n():
     wrapped = b"AAACGAAC" + b"GAAAAAAA"                       # 8 bases per line: the second CpG straddles the break
     assert po.seq_counts(wrapped, 0, 16) == (4, 2, 0, 16, 0)
     assert po.seq_counts(wrapped, 0, 16, line_bases=8) == (4, 1, 0, 16, 0)
+    # ... and a C that is the last base of the WINDOW starts none either under that reading (its G is not among the
+    # window's bytes); without it the base after the window counts
+    assert po.seq_counts(wrapped, 0, 4, line_bases=8)[1] == 0 and po.seq_counts(wrapped, 0, 4)[1] == 1
+    assert po.seq_counts(wrapped, 0, 5, line_bases=8)[1] == 1
     assert po.stats_columns(wrapped, 0, 16, po.STATS_FAIDX, line_bases=8) == "\t0.25\t0.125\t0"
     assert po.stats_columns(wrapped, 0, 16, po.STATS_FAIDX & ~po.STATS_CPG_RAW_LINES, line_bases=8) == "\t0.25\t0.25\t0"
 

@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """HBM traffic of gd_tile_kernel from rocprofv3 PMC passes.
 
-    python tools/traffic_from_pmc.py gpurun_out/prof_<tag> profiles/r01_wgs_traffic.json [kernel,kernel...] [bench args]
+    python tools/traffic_from_pmc.py gpurun_out/prof_<tag> profiles/r01_wgs_traffic.json [kernel,kernel...] [bench args] [label]
+
+A kernel is a substring of the demangled name after "::" (e.g. "gd_tile_fast_kernel<1, true>"); `label` is what the
+JSON calls it (bench.py accepts a file only for the kernel it timed: gd_stats.tile_kernel's name).
 
 The optional third argument lists the kernels whose traffic is summed (default
 gd_tile_kernel; the chunk path's roofline kernel is gd_ckpt_kernel,gd_ltile2_kernel).
@@ -21,6 +24,7 @@ import sys
 root, out = sys.argv[1], sys.argv[2]
 kernels = sys.argv[3].split(",") if len(sys.argv) > 3 else ["gd_tile_kernel"]
 bench_args = sys.argv[4] if len(sys.argv) > 4 else ""
+label = sys.argv[5] if len(sys.argv) > 5 else "+".join(kernels)
 fetch_kib = write_kib = 0.0
 n_disp = {}
 for kname in kernels:
@@ -35,14 +39,14 @@ for kname in kernels:
 read_b = fetch_kib * 1024 * 2
 write_b = write_kib * 1024
 res = {
-    "kernel": "+".join(kernels),
+    "kernel": label, "kernels_matched": kernels,
     "fetch_size_kib_raw": fetch_kib, "write_size_kib_raw": write_kib,
     "dispatches": n_disp,
     "hbm_read_bytes_per_launch": read_b, "hbm_write_bytes_per_launch": write_b,
     "hbm_bytes_per_launch": read_b + write_b,
     "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/prof.sh), "
               "FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md; "
-              "python bench.py %s--no-cpu-baseline --no-host-stream --steps 5 --warmup 2" % (bench_args + " " if bench_args else ""),
+              "python bench.py %s--no-cpu-baseline --no-host-stream --emulate-shards= --steps 5 --warmup 2" % (bench_args + " " if bench_args else ""),
 }
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps(res))
