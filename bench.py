@@ -456,6 +456,8 @@ def run_case(args, scaling, world, rank, dev, local_rank, want_streams=False):
             per, gbytes = [], []
             for r_ in range(N):
                 eng.select_contigs(asg[r_])
+                if derive:
+                    eng.drop_derived()              # a rank only ever holds its own contigs' structures (and their device blocks)
                 nw_r = sum(shard.n_windows(lengths[t], W) for t in asg[r_])
                 cap_b = 1 << 16
                 buf = torch.zeros(1 + nw_r + (nw_r + 1) // 2 + cap_b, dtype=torch.int64, device=dev)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """HBM traffic of gd_tile_kernel from rocprofv3 PMC passes.
 
-    python tools/traffic_from_pmc.py gpurun_out/prof_<tag> profiles/r01_wgs_traffic.json [kernel,kernel...] [bench args] [label]
+    python tools/traffic_from_pmc.py gpurun_out/prof_<tag> profiles/r01_wgs_traffic.json [kernel+kernel...] [bench args] [label]
 
 A kernel is a substring of the demangled name after "::" (e.g. "gd_tile_fast_kernel<1, true>"); `label` is what the
 JSON calls it (bench.py accepts a file only for the kernel it timed: gd_stats.tile_kernel's name).
@@ -22,7 +22,7 @@ import os
 import sys
 
 root, out = sys.argv[1], sys.argv[2]
-kernels = sys.argv[3].split(",") if len(sys.argv) > 3 else ["gd_tile_kernel"]
+kernels = sys.argv[3].split("+") if len(sys.argv) > 3 else ["gd_tile_kernel"]
 bench_args = sys.argv[4] if len(sys.argv) > 4 else ""
 label = sys.argv[5] if len(sys.argv) > 5 else "+".join(kernels)
 fetch_kib = write_kib = 0.0
