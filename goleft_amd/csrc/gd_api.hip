@@ -704,6 +704,7 @@ int gd_set_option(gd_ctx* c, int option, int64_t value)
         c->h2d_kernel = value != 0;
         if (value > 1) c->h2d_grid = (unsigned)value;
         break;
+    case GD_OPT_FUSED_NORMALIZE: c->fused_norm = value != 0; break;
     case GD_OPT_BAM_REFS:
         if (value < 0 || value > 0x7fffffff) return fail(c, GD_E_INVALID, "BAM references: 0 (unknown) .. 2^31 - 1");
         c->bam_n_ref = (int32_t)value;

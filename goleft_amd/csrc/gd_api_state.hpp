@@ -196,6 +196,7 @@ struct gd_ctx {
     int ing_copy_threads = 1;                          // GD_OPT_COPY_THREADS: threads filling the staging buffer
     bool h2d_kernel = true;                            // GD_OPT_H2D_KERNEL: staging blocks reach HBM through gd_h2d_kernel
     unsigned h2d_grid = 512;                           // ... its workgroups
+    bool fused_norm = true;                            // GD_OPT_FUSED_NORMALIZE: gd_normalize as one pass (0: count / scan / write / index launches)
     int32_t bam_n_ref = 0;                             // GD_OPT_BAM_REFS: references of the BAM being read (0: unknown)
     int push_threads = 16;
     size_t push_chunk = 1u << 20;                      // GD_OPT_PUSH_CHUNK: records per staging block of gd_push                             // GD_OPT_PUSH_THREADS: threads of gd_push filling a ring block
@@ -634,9 +635,20 @@ int norm_batch(gd_ctx* c, const std::vector<ContigHost*>& hs, const std::vector<
     if (units > (1ull << 26) - 64) return fail(c, GD_E_RANGE, "too many records in one batch (internal error)");
     if (idxs > 0xfffffff0ull) return fail(c, GD_E_RANGE, "the contigs of one batch are too long for one position-index launch");
     const size_t o_unit = cv.take((units + 2) * sizeof(uint32_t));
-    const size_t tab_bytes = nj * sizeof(gd::norm::NormJob) + 2 * (nj + 1) * sizeof(uint32_t);
+    const size_t tab_bytes = nj * sizeof(gd::norm::NormJob) + 3 * (nj + 1) * sizeof(uint32_t);
     const size_t o_tab = cv.take(tab_bytes);
     const size_t o_out = cv.take(2 * nj * sizeof(uint32_t));             // [totals][status words]
+    // the fused pass: rows x 256 reads per workgroup (few ops per read -> many reads), a look-back word per workgroup
+    const bool fused = c->fused_norm;
+    std::vector<uint32_t> rows(nj, 4u);
+    uint64_t n_blocks = 0;
+    for (size_t k = 0; k < nj; ++k) {
+        const ContigHost& h = *hs[k];
+        const uint64_t avg = h.n_reads ? (h.n_ops + h.n_reads - 1) / h.n_reads : 0;
+        rows[k] = avg <= 3 ? 4u : avg <= 6 ? 2u : 1u;
+        n_blocks += (h.n_reads + rows[k] * 256u - 1) / (rows[k] * 256u);
+    }
+    const size_t o_bstat = cv.take((n_blocks + 1) * sizeof(unsigned long long) + 16);   // look-back words, then the ticket pair
     BlockRef blk;
     if (int r = batch_block(c, std::move(keep), cv.at, &blk)) return r;
     char* const base = static_cast<char*>(blk->p);
@@ -645,7 +657,8 @@ int norm_batch(gd_ctx* c, const std::vector<ContigHost*>& hs, const std::vector<
     gd::norm::NormJob* jobs = reinterpret_cast<gd::norm::NormJob*>(c->batch_tab.data());
     uint32_t* ubeg = reinterpret_cast<uint32_t*>(c->batch_tab.data() + nj * sizeof(gd::norm::NormJob));
     uint32_t* ibeg = ubeg + nj + 1;
-    uint32_t u = 0, ix = 0;
+    uint32_t* bbeg = ibeg + nj + 1;
+    uint32_t u = 0, ix = 0, bb = 0;
     for (size_t k = 0; k < nj; ++k) {
         const ContigHost& h = *hs[k];
         const uint32_t n = (uint32_t)h.n_reads, nu = (n + 63u) / 64u;
@@ -661,27 +674,42 @@ int norm_batch(gd_ctx* c, const std::vector<ContigHost*>& hs, const std::vector<
         j.unit = reinterpret_cast<uint32_t*>(base + o_unit) + u;
         j.ncig = reinterpret_cast<uint32_t*>(base + o_ncig[k]);
         j.total = reinterpret_cast<uint32_t*>(base + o_out) + k;
-        ubeg[k] = u; ibeg[k] = ix;
+        j.rows = rows[k]; j.blk_beg = bb;
+        ubeg[k] = u; ibeg[k] = ix; bbeg[k] = bb;
         u += nu; ix += j.n_idx;
+        bb += (uint32_t)(((uint64_t)n + rows[k] * 256u - 1) / (rows[k] * 256u));
     }
-    ubeg[nj] = u; ibeg[nj] = ix;
+    ubeg[nj] = u; ibeg[nj] = ix; bbeg[nj] = bb;
     gd::norm::NormBatch B{};
     B.jobs = reinterpret_cast<const gd::norm::NormJob*>(base + o_tab);
     B.ubeg = reinterpret_cast<const uint32_t*>(base + o_tab + nj * sizeof(gd::norm::NormJob));
     B.ibeg = B.ubeg + nj + 1;
+    B.bbeg = B.ibeg + nj + 1;
     B.n_jobs = (uint32_t)nj; B.n_units = u; B.n_idx = ix;
+    B.n_blocks = bb;
+    B.bstat = reinterpret_cast<unsigned long long*>(base + o_bstat);
+    B.ticket = reinterpret_cast<uint32_t*>(B.bstat + n_blocks + 1);
     // records staged on the copy stream must have landed
     HIPCHK(c, hipEventRecord(c->copy_done, c->copy_stream));
     HIPCHK(c, hipStreamWaitEvent(c->stream, c->copy_done, 0));
     HIPCHK(c, hipMemcpyAsync(base + o_tab, c->batch_tab.data(), tab_bytes, hipMemcpyHostToDevice, c->stream));
     if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[5], c->stream));
     hipLaunchKernelGGL(gd::norm::gd_norm_init_kernel, dim3((unsigned)((nj + 255) / 256)), dim3(256), 0, c->stream, B);
-    if (u) {
-        hipLaunchKernelGGL(gd::norm::gd_norm_count_kernel, dim3((u + 3u) / 4u), dim3(256), 0, c->stream, B);
-        if (int r = launch_scan(c, reinterpret_cast<uint32_t*>(base + o_unit), u)) return r;
-        hipLaunchKernelGGL(gd::norm::gd_norm_write_kernel, dim3((u + 3u) / 4u), dim3(256), 0, c->stream, B);
+    if (fused) {
+        // ONE pass: count, offsets (decoupled look-back), write and the position index (gd_norm_fused_kernel)
+        HIPCHK(c, hipMemsetAsync(base + o_bstat, 0, (n_blocks + 1) * sizeof(unsigned long long) + 16, c->stream));
+        for (size_t k = 0; k < nj; ++k)                       // a contig without records has no workgroup: its index is all zero
+            if (hs[k]->n_reads == 0)
+                HIPCHK(c, hipMemsetAsync(jobs[k].pidx, 0, (size_t)jobs[k].n_idx * sizeof(uint32_t), c->stream));
+        if (bb) hipLaunchKernelGGL(gd::norm::gd_norm_fused_kernel, dim3(bb), dim3(256), 0, c->stream, B);
+    } else {
+        if (u) {
+            hipLaunchKernelGGL(gd::norm::gd_norm_count_kernel, dim3((u + 3u) / 4u), dim3(256), 0, c->stream, B);
+            if (int r = launch_scan(c, reinterpret_cast<uint32_t*>(base + o_unit), u)) return r;
+            hipLaunchKernelGGL(gd::norm::gd_norm_write_kernel, dim3((u + 3u) / 4u), dim3(256), 0, c->stream, B);
+        }
+        hipLaunchKernelGGL(gd::norm::gd_pidx_kernel, dim3((ix + 255u) / 256u), dim3(256), 0, c->stream, B);
     }
-    hipLaunchKernelGGL(gd::norm::gd_pidx_kernel, dim3((ix + 255u) / 256u), dim3(256), 0, c->stream, B);
     HIPCHK(c, hipGetLastError());
     if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[6], c->stream));
     // publish the pointers now: the long-read structures are enqueued from them
@@ -692,8 +720,11 @@ int norm_batch(gd_ctx* c, const std::vector<ContigHost*>& hs, const std::vector<
     }
     CkPending P;
     const size_t nck = with_ck.size();
-    if (int r = batch_host(c, 2 * nj + 3 * nck)) return r;
+    if (int r = batch_host(c, 2 * nj + 3 * nck + 2)) return r;
     HIPCHK(c, hipMemcpyAsync(c->h_batch, base + o_out, 2 * nj * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    uint32_t* const h_tick = c->h_batch + 2 * nj + 3 * with_ck.size();
+    h_tick[0] = h_tick[1] = 0;
+    if (fused) HIPCHK(c, hipMemcpyAsync(h_tick, B.ticket, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     int rc = GD_OK;
     if (nck) {
         rc = ck_enqueue(c, with_ck, false, &P);
@@ -704,6 +735,10 @@ int norm_batch(gd_ctx* c, const std::vector<ContigHost*>& hs, const std::vector<
         for (ContigHost* h : hs) drop_norm(*h);
         if (rc != GD_OK) return rc;
         return fail(c, GD_E_HIP, "normalisation failed: %s", hipGetErrorString(se));
+    }
+    if (fused && h_tick[1] != 0) {
+        for (ContigHost* h : hs) drop_norm(*h);
+        return fail(c, GD_E_HIP, "normalisation: a look-back gave up (internal error)");
     }
     for (size_t k = 0; k < nj; ++k) {
         ContigHost& h = *hs[k];

@@ -228,13 +228,25 @@ __device__ __forceinline__ uint32_t wave_dels(const uint32_t* __restrict__ ops, 
     uint32_t open_kind = 2u, open_len = 0u, open_start = pos, cur = pos, w = 0u;   // wave uniform
     overflow = false;
     const unsigned long long below = (1ull << lane) - 1ull;
-    // DL_UNROLL groups of 64 ops in flight: one group at a time left the wave waiting a memory round trip per 256 bytes
+    // DL_UNROLL groups of 64 ops per batch, and the NEXT batch's loads are issued before this one is worked on: one
+    // group at a time left the wave waiting a memory round trip per 256 bytes, one batch at a time still one per KB
+    // (10.4 ms for a 20x genome's 19 GB of ops: latency, not bytes)
+    uint32_t nxt[DL_UNROLL];
+#pragma unroll
+    for (int u = 0; u < DL_UNROLL; ++u) {
+        const uint32_t k = (uint32_t)u * 64u + (uint32_t)lane;
+        nxt[u] = k < n ? ops[k] : 0u;
+    }
     for (uint32_t b0 = 0; b0 < n; b0 += DL_UNROLL * 64u) {
         uint32_t cgv[DL_UNROLL];
 #pragma unroll
-        for (int u = 0; u < DL_UNROLL; ++u) {
-            const uint32_t k = b0 + (uint32_t)u * 64u + (uint32_t)lane;
-            cgv[u] = k < n ? ops[k] : 0u;
+        for (int u = 0; u < DL_UNROLL; ++u) cgv[u] = nxt[u];
+        if (b0 + DL_UNROLL * 64u < n) {
+#pragma unroll
+            for (int u = 0; u < DL_UNROLL; ++u) {
+                const uint32_t k = b0 + (uint32_t)(DL_UNROLL + u) * 64u + (uint32_t)lane;
+                nxt[u] = k < n ? ops[k] : 0u;
+            }
         }
 #pragma unroll
         for (int u = 0; u < DL_UNROLL; ++u) {

@@ -65,6 +65,8 @@ struct NormJob {
                               // unit[n_units] - unit[0] its total (all modulo 2^32: a contig holds < 2^32 ops)
     uint32_t* ncig;           // canonical ops
     uint32_t* total;          // out: canonical ops of the contig
+    uint32_t  rows;           // fused pass: a workgroup takes rows x 256 consecutive reads (4, 2 or 1: few ops per read -> many reads)
+    uint32_t  blk_beg;        // fused pass: first workgroup of this contig
 };
 
 // The contigs of one batch: job j owns units [ubeg[j], ubeg[j + 1]) and index entries [ibeg[j], ibeg[j + 1]).
@@ -75,6 +77,11 @@ struct NormBatch {
     uint32_t n_jobs;
     uint32_t n_units;         // ubeg[n_jobs]
     uint32_t n_idx;           // ibeg[n_jobs]
+    // fused pass (gd_norm_fused_kernel)
+    const uint32_t* bbeg;     // n_jobs + 1: first workgroup of every job
+    uint32_t n_blocks;        // bbeg[n_jobs]
+    unsigned long long* bstat;   // n_blocks look-back words, zeroed before the launch
+    uint32_t* ticket;         // [0] workgroups handed out so far, [1] set when a look-back gave up (never expected)
 };
 
 constexpr uint32_t LEN_MAX = 0x0fffffffu;
@@ -367,6 +374,235 @@ __global__ __launch_bounds__(256) void gd_pidx_kernel(NormBatch B)
         if (pos[mid] < (int32_t)key) lo = mid + 1; else hi = mid;
     }
     pidx[k] = lo;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// The same three results -- canonical CIGARs, record words, position index -- in ONE pass (gd_normalize's kernel;
+// the count / scan / write / index launches above remain as GD_OPT_FUSED_NORMALIZE = 0 and as the cross-check).
+// A workgroup takes rows x 256 consecutive reads of one contig (rows = 4 for short reads: 1024 reads, ~4.5 KB of ops):
+//   * every array is read ONCE, coalesced: a read's two CSR offsets, flag, MAPQ, position and the position of the read
+//     before it; the workgroup's ops are staged in LDS (up to NF_CAP; a workgroup whose reads hold more -- long reads --
+//     walks them from memory, a wave per long read, as the two-pass kernels do);
+//   * a lane counts its reads' canonical ops from LDS, wave scans + 16 partial sums give the offsets inside the
+//     workgroup, and the workgroup's base comes from a DECOUPLED LOOK-BACK over the workgroups before it (status word =
+//     flag | total; workgroups are handed out by a ticket, so every predecessor is running or done; a contig's first
+//     workgroup starts its own chain) -- no count pass, no scan launch;
+//   * the ops are walked a second time FROM LDS and written, with the record words and offsets;
+//   * the position index falls out of the positions already loaded: read r is the first with pos >= 64 k for every k in
+//     (pos[r - 1] / 64, pos[r] / 64] -- usually none or one entry (12.8 reads per 64 positions at 30x); long gaps and
+//     the tail after the last read are filled by the whole wave.
+// Algorithmic bytes: 11 + 4 + 4 per read in (offsets twice from cache), 8 per read + 4 per canonical op out, 4 per 64
+// positions: what synth.normalise_bytes counts.
+constexpr uint32_t NF_CAP = 4096;          // staged ops per workgroup (16 KB)
+constexpr int NF_MAXROWS = 4;
+
+__global__ __launch_bounds__(256) void gd_norm_fused_kernel(NormBatch B)
+{
+    __shared__ uint32_t s_ops[NF_CAP];
+    __shared__ uint32_t s_part[NF_MAXROWS * 4 + 1];
+    __shared__ uint32_t s_blk;
+    __shared__ uint32_t s_base;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (tid == 0) s_blk = atomicAdd(&B.ticket[0], 1u);
+    __syncthreads();
+    const uint32_t blk = s_blk;
+    if (blk >= B.n_blocks) return;
+    const uint32_t ji = (uint32_t)__builtin_amdgcn_readfirstlane((int)batch_find(B.bbeg, B.n_jobs, blk));
+    const NormJob j = B.jobs[ji];
+    const uint32_t rows = j.rows;
+    const uint32_t lb = blk - B.bbeg[ji];                       // workgroup number inside the contig
+    const uint32_t r0 = lb * rows * 256u;
+    const uint32_t r_end = r0 + rows * 256u < j.n_reads ? r0 + rows * 256u : j.n_reads;
+    const uint32_t ob = j.off[r0], oe = j.off[r_end];
+    const bool staged = oe - ob <= NF_CAP;
+
+    // ---- loads: one round trip ----------------------------------------------------------------------
+    uint32_t o0[NF_MAXROWS], n[NF_MAXROWS], fl[NF_MAXROWS], mq[NF_MAXROWS];
+    int32_t p[NF_MAXROWS], q[NF_MAXROWS];
+#pragma unroll
+    for (int w = 0; w < NF_MAXROWS; ++w) {
+        const uint32_t r = r0 + (uint32_t)w * 256u + (uint32_t)tid;
+        o0[w] = 0; n[w] = 0; fl[w] = 0; mq[w] = 0; p[w] = 0; q[w] = -1;
+        if ((uint32_t)w < rows && r < r_end) {
+            o0[w] = j.off[r];
+            n[w] = j.off[r + 1] - o0[w];
+            fl[w] = j.flag[r];
+            mq[w] = j.mapq[r];
+            p[w] = j.pos[r];
+            if (r) q[w] = j.pos[r - 1];
+        }
+    }
+    if (staged)
+        for (uint32_t i = (uint32_t)tid; i < oe - ob; i += 256u) s_ops[i] = j.cigar[ob + i];
+
+    // ---- the position index, from the positions just loaded ------------------------------------------
+#pragma unroll
+    for (int w = 0; w < NF_MAXROWS; ++w) {
+        const uint32_t r = r0 + (uint32_t)w * 256u + (uint32_t)tid;
+        const bool valid = (uint32_t)w < rows && r < r_end;
+        // entries (q >> 6, p >> 6] get r; the contig's last read also fills the tail with n_reads
+        uint32_t k_lo = 0, k_hi = 0;                               // [k_lo, k_hi)
+        if (valid) {
+            const int32_t pp = p[w] > 0 ? p[w] : 0, qq = q[w];
+            k_lo = qq < 0 ? 0u : ((uint32_t)qq >> 6) + 1u;
+            k_hi = ((uint32_t)pp >> 6) + 1u;
+            k_hi = k_hi < j.n_idx ? k_hi : j.n_idx;
+            if (k_hi < k_lo) k_hi = k_lo;
+        }
+        const bool last = valid && r + 1u == j.n_reads;
+        uint32_t t_lo = 0, t_hi = 0;                               // the tail [t_lo, t_hi) := n_reads
+        if (last) { t_lo = k_hi > k_lo ? k_hi : k_lo; t_hi = j.n_idx; if (t_lo > t_hi) t_lo = t_hi; }
+        const uint32_t cnt = k_hi - k_lo;
+        for (uint32_t k = 0; k < cnt && k < 4u; ++k) j.pidx[k_lo + k] = r;       // the usual case: none or one
+        unsigned long long big = __builtin_amdgcn_ballot_w64(cnt > 4u || t_hi > t_lo);
+        while (big != 0ull) {                                      // a gap in the coverage, or the tail: the whole wave
+            const int l = __ffsll((long long)big) - 1;
+            big &= big - 1ull;
+            const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)k_lo, l) + 4u, e = (uint32_t)__builtin_amdgcn_readlane((int)k_hi, l);
+            const uint32_t rr = (uint32_t)__builtin_amdgcn_readlane((int)r, l);
+            for (uint32_t k = a + (uint32_t)lane; k < e; k += 64u) j.pidx[k] = rr;
+            const uint32_t ta = (uint32_t)__builtin_amdgcn_readlane((int)t_lo, l), te = (uint32_t)__builtin_amdgcn_readlane((int)t_hi, l);
+            for (uint32_t k = ta + (uint32_t)lane; k < te; k += 64u) j.pidx[k] = j.n_reads;
+        }
+    }
+    __syncthreads();                                               // the staged ops are in LDS
+
+    // ---- count --------------------------------------------------------------------------------------
+    uint32_t cnt[NF_MAXROWS];
+    bool serial[NF_MAXROWS];
+#pragma unroll
+    for (int w = 0; w < NF_MAXROWS; ++w) {
+        cnt[w] = 0;
+        serial[w] = true;
+        if ((uint32_t)w >= rows) continue;                         // (uniform)
+        if (staged) {
+            if (n[w] != 0u) cnt[w] = canonical_walk(s_ops + (o0[w] - ob), n[w], [](uint32_t, uint32_t) {});
+        } else {
+            serial[w] = n[w] <= WAVE_WALK_MIN;
+            unsigned long long todo = __builtin_amdgcn_ballot_w64(!serial[w]);
+            while (todo != 0ull) {                                 // long reads: the wave walks one at a time
+                const int jl = __ffsll((long long)todo) - 1;
+                todo &= todo - 1ull;
+                const uint32_t oj = (uint32_t)__builtin_amdgcn_readlane((int)o0[w], jl);
+                const uint32_t nj = (uint32_t)__builtin_amdgcn_readlane((int)n[w], jl);
+                bool ovf;
+                const uint32_t cw = wave_canonical<false>(j.cigar + oj, nj, lane, nullptr, ovf);
+                if (lane == jl) { cnt[w] = cw; serial[w] = ovf; }
+            }
+            if (serial[w] && n[w] != 0u) cnt[w] = canonical_walk(j.cigar + o0[w], n[w], [](uint32_t, uint32_t) {});
+        }
+    }
+    // ---- offsets inside the workgroup: reads are numbered row by row ---------------------------------
+    uint32_t incl[NF_MAXROWS];
+#pragma unroll
+    for (int w = 0; w < NF_MAXROWS; ++w) {
+        incl[w] = (uint32_t)wave_inclusive_scan((int)cnt[w]);
+        if (lane == 63) s_part[w * 4 + wv] = incl[w];
+    }
+    __syncthreads();
+    uint32_t before[NF_MAXROWS], total = 0;
+    {
+        uint32_t run = 0;
+#pragma unroll
+        for (int w = 0; w < NF_MAXROWS; ++w) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                if (v == wv) before[w] = run;
+                run += s_part[w * 4 + v];
+            }
+        }
+        total = run;
+    }
+    // ---- the workgroup's base: decoupled look-back (wave 0) -------------------------------------------
+    constexpr unsigned long long ST_AGG = 1ull << 32, ST_INC = 2ull << 32;
+    if (wv == 0) {
+        uint32_t prefix = 0;
+        if (lb == 0u) {
+            if (lane == 0) __hip_atomic_store(&B.bstat[blk], ST_INC | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            if (lane == 0) __hip_atomic_store(&B.bstat[blk], ST_AGG | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t first = B.bbeg[ji];
+            int64_t look = (int64_t)blk - 1;
+            uint32_t spins = 0;
+            for (;;) {
+                const int64_t idx = look - lane;
+                unsigned long long st = ST_INC;                    // before the contig's first workgroup: inclusive 0
+                if (idx >= (int64_t)first) st = __hip_atomic_load(&B.bstat[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t flag = (uint32_t)(st >> 32);
+                const uint32_t val = (uint32_t)st;
+                const unsigned long long ready = __builtin_amdgcn_ballot_w64(flag != 0u);
+                const unsigned long long incm = __builtin_amdgcn_ballot_w64(flag == 2u);
+                if (incm != 0ull) {
+                    const int fi = __ffsll((long long)incm) - 1;
+                    const unsigned long long need = fi == 63 ? ~0ull : ((1ull << (fi + 1)) - 1ull);
+                    if ((ready & need) == need) {
+                        prefix += (uint32_t)__builtin_amdgcn_readlane(wave_inclusive_scan((int)(lane <= fi ? val : 0u)), 63);
+                        break;
+                    }
+                } else if (ready == ~0ull) {
+                    prefix += (uint32_t)__builtin_amdgcn_readlane(wave_inclusive_scan((int)val), 63);
+                    look -= 64;
+                    continue;
+                }
+                if (++spins > (1u << 24)) {                        // never expected: report, do not hang
+                    if (lane == 0) atomicMax(&B.ticket[1], 1u);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            if (lane == 0) __hip_atomic_store(&B.bstat[blk], ST_INC | (prefix + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (lane == 0) s_base = prefix;
+    }
+    __syncthreads();
+    const uint32_t base = s_base;
+
+    // ---- write: offsets, record words, canonical ops ---------------------------------------------------
+    uint32_t bad = 0;
+#pragma unroll
+    for (int w = 0; w < NF_MAXROWS; ++w) {
+        if ((uint32_t)w >= rows) continue;
+        const uint32_t r = r0 + (uint32_t)w * 256u + (uint32_t)tid;
+        const bool valid = r < r_end;
+        const uint32_t dst0 = base + before[w] + incl[w] - cnt[w];
+        if (valid) {
+            j.noff[r] = dst0;
+            const bool fits = fl[w] <= 0xfffu && cnt[w] < REC_NMAX;
+            j.rec[r] = ((fl[w] & 0xfffu) << 20) | (mq[w] << 12) | (fits ? cnt[w] : REC_NMAX);
+            bad |= fits ? 0u : 1u;
+        }
+        if (staged) {
+            if (n[w] != 0u) {
+                uint32_t* out = j.ncig + dst0;
+                uint32_t k = 0;
+                canonical_walk(s_ops + (o0[w] - ob), n[w], [&](uint32_t op, uint32_t len) { out[k++] = (len << 4) | op; });
+            }
+        } else {
+            bool ser = n[w] <= WAVE_WALK_MIN;
+            unsigned long long todo = __builtin_amdgcn_ballot_w64(!ser);
+            while (todo != 0ull) {
+                const int jl = __ffsll((long long)todo) - 1;
+                todo &= todo - 1ull;
+                const uint32_t oj = (uint32_t)__builtin_amdgcn_readlane((int)o0[w], jl);
+                const uint32_t nj = (uint32_t)__builtin_amdgcn_readlane((int)n[w], jl);
+                const uint32_t dj = (uint32_t)__builtin_amdgcn_readlane((int)dst0, jl);
+                bool ovf;
+                (void)wave_canonical<true>(j.cigar + oj, nj, lane, j.ncig + dj, ovf);
+                if (lane == jl) ser = ovf;
+            }
+            if (ser && n[w] != 0u) {
+                uint32_t* out = j.ncig + dst0;
+                uint32_t k = 0;
+                canonical_walk(j.cigar + o0[w], n[w], [&](uint32_t op, uint32_t len) { out[k++] = (len << 4) | op; });
+            }
+        }
+    }
+    if (__builtin_amdgcn_ballot_w64(bad != 0u) != 0ull && lane == 0) atomicOr(j.status, 1u);
+    if (r_end == j.n_reads && tid == 0) {                          // the contig's last workgroup
+        j.noff[j.n_reads] = base + total;
+        *j.total = base + total;
+    }
 }
 
 // gd_adopt_device: the arrays come from the caller's own kernels -- the one check a host block gets in gd_commit.

@@ -16,7 +16,7 @@ from ._lib import GdBatch, GdParams, GdRun, GdStats
 CLASS_NAMES = ("NO_COVERAGE", "LOW_COVERAGE", "CALLABLE", "EXCESSIVE_COVERAGE")
 K_PREP, K_TILE, K_RUNS, K_EXPAND, K_SCAN, K_CKPT, K_SEQSTATS, K_MDFLAGS, K_INFLATE, K_NORM = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9
 # gd_set_option keys (include/goleft_depth.h)
-OPT_NT_STORES, OPT_NORMALIZE, OPT_FAST_KERNEL, OPT_COPY_THREADS, OPT_PUSH_THREADS, OPT_H2D_KERNEL, OPT_PUSH_CHUNK, OPT_BAM_REFS = 3, 4, 5, 6, 7, 8, 9, 10
+OPT_NT_STORES, OPT_NORMALIZE, OPT_FAST_KERNEL, OPT_COPY_THREADS, OPT_PUSH_THREADS, OPT_H2D_KERNEL, OPT_PUSH_CHUNK, OPT_BAM_REFS, OPT_FUSED_NORMALIZE = 3, 4, 5, 6, 7, 8, 9, 10, 11
 PATH_AUTO, PATH_TILE, PATH_SCATTER, PATH_CHUNK = 0, 1, 2, 3
 # gd_stats.tile_kernel (include/goleft_depth.h GD_TK_*)
 TK_NONE, TK_GENERIC, TK_FAST, TK_FAST_RAW, TK_LONG, TK_SCATTER, TK_SUMS_STREAM, TK_TILE_SUMS, TK_SUMS_STREAM_RAW = range(9)

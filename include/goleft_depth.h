@@ -199,6 +199,8 @@ enum { /* (1, 2: tile shapes other than 4096 positions x 256 threads -- measured
                                        record walk takes the first record of ANOTHER reference as the end of a contig's
                                        records only when its refID is one a sorted BAM can hold there (greater than the
                                        contig's and below this number, or -1); anything else is a damaged record */
+       GD_OPT_FUSED_NORMALIZE = 11, /* 1 (default): gd_normalize builds canonical CIGARs, record words and position index in ONE
+                                       pass (offsets by decoupled look-back); 0: count / scan / write / index launches */
        GD_OPT_H2D_KERNEL = 8 };     /* how a committed staging block reaches HBM: 1 (default) one kernel whose workgroups
                                        read the page-locked block over the link (all five arrays in one launch; n > 1:
                                        with n workgroups), 0: five hipMemcpyAsync through a DMA engine */

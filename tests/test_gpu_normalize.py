@@ -10,9 +10,10 @@ from tests import helpers as H
 pytestmark = pytest.mark.gpu
 
 
-def _engine(lengths, reads, fast=1, norm=1, **params):
+def _engine(lengths, reads, fast=1, norm=1, fused=1, **params):
     from goleft_amd import engine as E
     eng = E.DepthEngine(0)
+    eng.set_option(E.OPT_FUSED_NORMALIZE, fused)     # 1: the one-pass kernel (default); 0: count / scan / write / index launches
     eng.set_option(E.OPT_NORMALIZE, norm)
     eng.set_option(E.OPT_FAST_KERNEL, fast)
     eng.set_params(**params)
@@ -23,12 +24,13 @@ def _engine(lengths, reads, fast=1, norm=1, **params):
     return eng
 
 
+@pytest.mark.parametrize("fused", [1, 0])
 @pytest.mark.parametrize("seed", range(3))
-def test_canonical_cigars_equal_restatement(seed):
+def test_canonical_cigars_equal_restatement(seed, fused):
     rng = np.random.default_rng(seed)
     L = 200_000
     r = H.random_reads(rng, L, 30_000, max_ops=9, max_len=120)
-    with _engine([L], {0: r}, window_size=100) as eng:
+    with _engine([L], {0: r}, fused=fused, window_size=100) as eng:
         eng.compute()
         off, cig = eng.canonical_cigars(0, r.n)
     woff, wcig = po.canonical_cigars(r)
@@ -129,8 +131,9 @@ def test_normalisation_is_ingest_time_not_compute_time():
         assert np.array_equal(eng.perbase(0), po.perbase_c(r, 1, 0, L))
 
 
+@pytest.mark.parametrize("fused", [1, 0])
 @pytest.mark.parametrize("seed", range(3))
-def test_wave_walked_canonical_cigars_equal_restatement(seed):
+def test_wave_walked_canonical_cigars_equal_restatement(seed, fused):
     """Reads with more than 24 ops are normalised by a whole wave (runs spanning the 64-op groups, leading and
     trailing D/N runs, zero-length ops, a long N skip); shorter ones in the same 64-read unit by one lane."""
     rng = np.random.default_rng(100 + seed)
@@ -151,6 +154,7 @@ def test_wave_walked_canonical_cigars_equal_restatement(seed):
     r = po.Reads(r.pos, r.flag, r.mapq, r.cigar_off, cig)
     from goleft_amd import engine as E
     with E.DepthEngine(0) as eng:
+        eng.set_option(E.OPT_FUSED_NORMALIZE, fused)
         eng.set_params(window_size=1000)
         eng.set_path(3)                                      # GD_PATH_CHUNK
         eng.set_contigs([L])
@@ -212,7 +216,8 @@ def test_default_computes_from_the_records_as_they_arrived():
         assert np.array_equal(s, want.reshape(-1, 1000).sum(1)) and np.array_equal(m, want.reshape(-1, 1000).min(1))
 
 
-def test_normalize_batches_many_contigs():
+@pytest.mark.parametrize("fused", [1, 0])
+def test_normalize_batches_many_contigs(fused):
     """One gd_normalize over contigs of every shape (empty, one read, short, long-read shaped, zero length): the
     batch's kernels find each 64-read unit's contig in the table; canonical CIGARs equal the restatement."""
     from goleft_amd import engine as E
@@ -225,6 +230,7 @@ def test_normalize_batches_many_contigs():
              6: H.long_cigar_reads(rng, lengths[6], [int(x) for x in rng.choice([50, 700, 5000], size=130)]),
              7: H.random_reads(rng, lengths[7], 65, max_ops=2)}
     with E.DepthEngine(0) as eng:
+        eng.set_option(E.OPT_FUSED_NORMALIZE, fused)
         eng.set_params(window_size=100)
         eng.set_contigs(lengths)
         for t, r in reads.items():
@@ -240,3 +246,32 @@ def test_normalize_batches_many_contigs():
             for t, L in enumerate(lengths):
                 want = po.perbase_c(reads.get(t, H.empty_reads()), 1, 0, L) if L else np.zeros(0, np.int32)
                 assert np.array_equal(eng.perbase(t), want), (path, t)
+
+
+def test_position_index_of_the_fused_pass_serves_sparse_and_clustered_records():
+    """The one-pass normalisation derives the position index from the positions it loads anyway: reads in clusters
+    with megabase gaps between them, many reads at one position, a long empty tail, a contig without records -- the
+    tile kernel on canonical records (its tile table is looked up in that index) must still be bit exact."""
+    from goleft_amd import engine as E
+    rng = np.random.default_rng(12)
+    L = 9_000_000
+    pos = np.sort(np.concatenate([np.full(700, 5), rng.integers(0, 3000, 900), rng.integers(2_500_000, 2_500_400, 5000),
+                                  np.full(3, 4_194_304), rng.integers(6_000_000, 6_300_000, 2000)])).astype(np.int32)
+    n = len(pos)
+    r = po.Reads(pos, np.zeros(n, np.uint16), np.full(n, 60, np.uint8), np.arange(n + 1, dtype=np.uint32),
+                 np.full(n, (100 << 4) | 0, np.uint32))
+    lengths = [L, 70_000, L]
+    for fused in (1, 0):
+        with E.DepthEngine(0) as eng:
+            eng.set_option(E.OPT_FUSED_NORMALIZE, fused)
+            eng.set_params(window_size=1000)
+            eng.set_path(E.PATH_TILE)
+            eng.set_contigs(lengths)
+            eng.push(0, r.pos, r.flag, r.mapq, r.cigar_off, r.cigar)
+            eng.push(2, r.pos[:1], r.flag[:1], r.mapq[:1], r.cigar_off[:2], r.cigar[:1])
+            eng.normalize()
+            eng.compute()
+            assert eng.stats().tile_kernel == E.TK_FAST
+            assert np.array_equal(eng.perbase(0), po.perbase_c(r, 1, 0, L))
+            assert int(eng.perbase(1).sum()) == 0
+            assert int(eng.perbase(2).sum()) == 100
