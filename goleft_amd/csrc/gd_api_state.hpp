@@ -639,13 +639,16 @@ int norm_batch(gd_ctx* c, const std::vector<ContigHost*>& hs, const std::vector<
     const size_t o_tab = cv.take(tab_bytes);
     const size_t o_out = cv.take(2 * nj * sizeof(uint32_t));             // [totals][status words]
     // the fused pass: rows x 256 reads per workgroup (few ops per read -> many reads), a look-back word per workgroup
-    const bool fused = c->fused_norm;
+    bool fused = c->fused_norm;
     std::vector<uint32_t> rows(nj, 4u);
     uint64_t n_blocks = 0;
     for (size_t k = 0; k < nj; ++k) {
         const ContigHost& h = *hs[k];
         const uint64_t avg = h.n_reads ? (h.n_ops + h.n_reads - 1) / h.n_reads : 0;
         rows[k] = avg <= 3 ? 4u : avg <= 6 ? 2u : 1u;
+        // long reads never fit the LDS staging: four waves of a workgroup walking them from memory between barriers
+        // measured slower than the unit-per-wave kernels (35 vs 24 ms on the 20x ONT genome): those batches keep them
+        if (avg > 6) fused = false;
         n_blocks += (h.n_reads + rows[k] * 256u - 1) / (rows[k] * 256u);
     }
     const size_t o_bstat = cv.take((n_blocks + 1) * sizeof(unsigned long long) + 16);   // look-back words, then the ticket pair

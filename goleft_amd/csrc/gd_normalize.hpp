@@ -385,7 +385,7 @@ __global__ __launch_bounds__(256) void gd_pidx_kernel(NormBatch B)
 //     walks them from memory, a wave per long read, as the two-pass kernels do);
 //   * a lane counts its reads' canonical ops from LDS, wave scans + 16 partial sums give the offsets inside the
 //     workgroup, and the workgroup's base comes from a DECOUPLED LOOK-BACK over the workgroups before it (status word =
-//     flag | total; workgroups are handed out by a ticket, so every predecessor is running or done; a contig's first
+//     flag | total; a contig's first
 //     workgroup starts its own chain) -- no count pass, no scan launch;
 //   * the ops are walked a second time FROM LDS and written, with the record words and offsets;
 //   * the position index falls out of the positions already loaded: read r is the first with pos >= 64 k for every k in
@@ -396,7 +396,7 @@ __global__ __launch_bounds__(256) void gd_pidx_kernel(NormBatch B)
 constexpr uint32_t NF_CAP = 4096;          // staged ops per workgroup (16 KB)
 constexpr int NF_MAXROWS = 4;
 
-__global__ __launch_bounds__(256) void gd_norm_fused_kernel(NormBatch B)
+__global__ __launch_bounds__(256, 8) void gd_norm_fused_kernel(NormBatch B)
 {
     __shared__ uint32_t s_ops[NF_CAP];
     __shared__ uint32_t s_part[NF_MAXROWS * 4 + 1];
@@ -404,9 +404,11 @@ __global__ __launch_bounds__(256) void gd_norm_fused_kernel(NormBatch B)
     __shared__ uint32_t s_base;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    if (tid == 0) s_blk = atomicAdd(&B.ticket[0], 1u);
-    __syncthreads();
-    const uint32_t blk = s_blk;
+    // Workgroups look back at smaller ids only, and every XCD starts its share of the grid (ids k, k + 8, ...) in
+    // order: the smallest unfinished id is always resident, so the chain cannot stall.  (A ticket -- one atomic on
+    // one address per workgroup, 6*10^5 per genome -- was as slow as the two-pass kernels all by itself.)
+    const uint32_t blk = blockIdx.x;
+    (void)s_blk;
     if (blk >= B.n_blocks) return;
     const uint32_t ji = (uint32_t)__builtin_amdgcn_readfirstlane((int)batch_find(B.bbeg, B.n_jobs, blk));
     const NormJob j = B.jobs[ji];
