@@ -102,6 +102,8 @@ int gd_create(int device_id, gd_ctx** out)
     return GD_OK;
 }
 
+namespace { void drop_pool(gd_ctx* c); }
+
 void gd_destroy(gd_ctx* c)
 {
     if (!c) return;
@@ -133,6 +135,7 @@ void gd_destroy(gd_ctx* c)
     if (c->h_counters) (void)hipHostFree(c->h_counters);
     if (c->h_bounds) (void)hipHostFree(c->h_bounds);
     if (c->h_batch) (void)hipHostFree(c->h_batch);
+    drop_pool(c);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     delete c;
@@ -233,6 +236,114 @@ int gd_select_contigs(gd_ctx* c, int n, const int32_t* tids)
     return GD_OK;
 }
 
+// Worker threads of a context (created by the first large gd_push / gd_commit, kept until gd_destroy): the staging blocks are filled by several threads (one core moves ~11 GB/s into pinned
+// memory, a Gen5 x16 link takes five times that), block k + 1 while the copies of block k are on the link.
+namespace {
+struct FillPool {
+    // kind 0: plain copy; 1: int32 positions, copied and checked (non-decreasing from `prev`, not negative);
+    // 2: 32-bit CSR offsets, rebased by -sub and checked (non-decreasing); 3 / 4: the checks of 1 / 2 alone (gd_commit:
+    // the caller filled the block itself)
+    struct Item { void* dst; const void* src; size_t bytes; uint32_t sub; int kind; int32_t prev; };
+    std::atomic<uint32_t> bad{0};
+    std::vector<std::thread> th;
+    std::vector<Item> items;
+    std::atomic<size_t> next{0}, done{0};
+    std::atomic<uint64_t> gen{0};
+    std::atomic<bool> quit{false};
+    std::mutex mu;
+    std::condition_variable cv;
+    void run_item(const Item& it)
+    {
+        if (it.kind == 0) { memcpy(it.dst, it.src, it.bytes); return; }
+        const size_t n = it.bytes / 4;
+        uint32_t wrong = 0;
+        if (it.kind == 3) {
+            const int32_t* __restrict__ s = static_cast<const int32_t*>(it.src);
+            if (n) wrong = (uint32_t)(s[0] < it.prev) | (uint32_t)(s[0] < 0);
+            for (size_t k = 1; k < n; ++k) wrong |= (uint32_t)(s[k] < s[k - 1]);
+        } else if (it.kind == 4) {
+            const uint32_t* __restrict__ s = static_cast<const uint32_t*>(it.src);
+            for (size_t k = 1; k < n; ++k) wrong |= (uint32_t)(s[k] < s[k - 1]);
+        } else if (it.kind == 1) {
+            int32_t* __restrict__ d = static_cast<int32_t*>(it.dst);
+            const int32_t* __restrict__ s = static_cast<const int32_t*>(it.src);
+            if (n) { wrong = (uint32_t)(s[0] < it.prev) | (uint32_t)(s[0] < 0); d[0] = s[0]; }
+            for (size_t k = 1; k < n; ++k) { wrong |= (uint32_t)(s[k] < s[k - 1]); d[k] = s[k]; }
+        } else {
+            uint32_t* __restrict__ d = static_cast<uint32_t*>(it.dst);
+            const uint32_t* __restrict__ s = static_cast<const uint32_t*>(it.src);
+            if (n) d[0] = s[0] - it.sub;
+            for (size_t k = 1; k < n; ++k) { wrong |= (uint32_t)(s[k] < s[k - 1]); d[k] = s[k] - it.sub; }
+        }
+        if (wrong) bad.store(1);
+    }
+    void drain()
+    {
+        for (;;) {
+            const size_t i = next.fetch_add(1);
+            if (i >= items.size()) break;
+            run_item(items[i]);
+            done.fetch_add(1);
+        }
+    }
+    std::atomic<int> active{0};
+    void start(int n)
+    {
+        for (int k = 0; k < n; ++k)
+            th.emplace_back([this] {
+                uint64_t seen = 0;
+                for (;;) {
+                    {
+                        std::unique_lock<std::mutex> lk(mu);
+                        cv.wait(lk, [&] { return quit.load() || gen.load() != seen; });
+                        if (quit.load()) return;
+                        seen = gen.load();
+                        active.fetch_add(1);               // (under the lock: run() never swaps the items under a worker)
+                    }
+                    drain();
+                    active.fetch_sub(1);
+                }
+            });
+    }
+    // runs the items on the workers and the calling thread; returns when all are done
+    void run(std::vector<Item>&& work)
+    {
+        for (;;) {
+            std::unique_lock<std::mutex> lk(mu);
+            if (active.load() != 0) { lk.unlock(); std::this_thread::yield(); continue; }
+            items = std::move(work);
+            next.store(0); done.store(0);
+            gen.fetch_add(1);
+            break;
+        }
+        cv.notify_all();
+        drain();
+        while (done.load() < items.size()) std::this_thread::yield();
+    }
+    ~FillPool()
+    {
+        { std::lock_guard<std::mutex> lk(mu); quit.store(true); }
+        cv.notify_all();
+        for (auto& t : th) t.join();
+    }
+};
+
+void drop_pool(gd_ctx* c) { delete c->pool; c->pool = nullptr; c->pool_workers = 0; }
+
+// the context's pool, with push_threads - 1 workers (the calling thread works too)
+FillPool* ctx_pool(gd_ctx* c)
+{
+    const int want = c->push_threads - 1;
+    if (c->pool && c->pool_workers != want) { delete c->pool; c->pool = nullptr; }
+    if (!c->pool && want > 0) {
+        c->pool = new (std::nothrow) FillPool();
+        if (c->pool) { c->pool->start(want); c->pool_workers = want; }
+    }
+    return c->pool;
+}
+}  // namespace
+
+
 int gd_acquire(gd_ctx* c, size_t reads_cap, size_t ops_cap, gd_batch* out)
 {
     if (!c || !out) return GD_E_INVALID;
@@ -332,18 +443,18 @@ static int commit_block(gd_ctx* c, const gd_batch* b, int32_t tid, size_t n_read
             return bad;
         };
         uint32_t bad = (uint32_t)(p[0] < 0);                 // sorted: p[0] is the smallest
-        constexpr int kCheckers = 4;
-        if (n_reads >= (1u << 18)) {                          // a large block: a few threads, a quarter each
-            uint32_t part[kCheckers] = {};
-            std::thread th[kCheckers - 1];
-            for (int k = 0; k < kCheckers; ++k) {
-                const size_t a = n_reads * (size_t)k / kCheckers, e = n_reads * (size_t)(k + 1) / kCheckers;
-                const int32_t before = k ? p[a - 1] : last;
-                if (k + 1 < kCheckers) th[k] = std::thread([&part, &check, a, e, before, k] { part[k] = check(a, e, before); });
-                else part[k] = check(a, e, before);
+        FillPool* const pool = n_reads >= (1u << 18) ? ctx_pool(c) : nullptr;
+        if (pool) {                                          // a large block: the context's worker threads, 256 k records each
+            std::vector<FillPool::Item> work;
+            const size_t piece = 1u << 18;
+            for (size_t a = 0; a < n_reads; a += piece) {
+                const size_t e = std::min(n_reads, a + piece);
+                work.push_back({nullptr, p + a, (e - a) * 4, 0u, 3, a ? p[a - 1] : last});
+                work.push_back({nullptr, o + a, (e - a + 1) * 4, 0u, 4, 0});
             }
-            for (auto& t : th) t.join();
-            for (uint32_t x : part) bad |= x;
+            pool->bad.store(0);
+            pool->run(std::move(work));
+            bad |= pool->bad.load();
         } else {
             bad |= check(0, n_reads, last);
         }
@@ -413,91 +524,6 @@ static int commit_block(gd_ctx* c, const gd_batch* b, int32_t tid, size_t n_read
     return GD_OK;
 }
 
-// Workers of one gd_push: the staging blocks are filled by several threads (one core moves ~11 GB/s into pinned
-// memory, a Gen5 x16 link takes five times that), block k + 1 while the copies of block k are on the link.
-namespace {
-struct FillPool {
-    // kind 0: plain copy; 1: int32 positions, copied and checked (non-decreasing from `prev`, not negative);
-    // 2: 32-bit CSR offsets, rebased by -sub and checked (non-decreasing)
-    struct Item { void* dst; const void* src; size_t bytes; uint32_t sub; int kind; int32_t prev; };
-    std::atomic<uint32_t> bad{0};
-    std::vector<std::thread> th;
-    std::vector<Item> items;
-    std::atomic<size_t> next{0}, done{0};
-    std::atomic<uint64_t> gen{0};
-    std::atomic<bool> quit{false};
-    std::mutex mu;
-    std::condition_variable cv;
-    void run_item(const Item& it)
-    {
-        if (it.kind == 0) { memcpy(it.dst, it.src, it.bytes); return; }
-        const size_t n = it.bytes / 4;
-        uint32_t wrong = 0;
-        if (it.kind == 1) {
-            int32_t* __restrict__ d = static_cast<int32_t*>(it.dst);
-            const int32_t* __restrict__ s = static_cast<const int32_t*>(it.src);
-            if (n) { wrong = (uint32_t)(s[0] < it.prev) | (uint32_t)(s[0] < 0); d[0] = s[0]; }
-            for (size_t k = 1; k < n; ++k) { wrong |= (uint32_t)(s[k] < s[k - 1]); d[k] = s[k]; }
-        } else {
-            uint32_t* __restrict__ d = static_cast<uint32_t*>(it.dst);
-            const uint32_t* __restrict__ s = static_cast<const uint32_t*>(it.src);
-            if (n) d[0] = s[0] - it.sub;
-            for (size_t k = 1; k < n; ++k) { wrong |= (uint32_t)(s[k] < s[k - 1]); d[k] = s[k] - it.sub; }
-        }
-        if (wrong) bad.store(1);
-    }
-    void drain()
-    {
-        for (;;) {
-            const size_t i = next.fetch_add(1);
-            if (i >= items.size()) break;
-            run_item(items[i]);
-            done.fetch_add(1);
-        }
-    }
-    std::atomic<int> active{0};
-    void start(int n)
-    {
-        for (int k = 0; k < n; ++k)
-            th.emplace_back([this] {
-                uint64_t seen = 0;
-                for (;;) {
-                    {
-                        std::unique_lock<std::mutex> lk(mu);
-                        cv.wait(lk, [&] { return quit.load() || gen.load() != seen; });
-                        if (quit.load()) return;
-                        seen = gen.load();
-                        active.fetch_add(1);               // (under the lock: run() never swaps the items under a worker)
-                    }
-                    drain();
-                    active.fetch_sub(1);
-                }
-            });
-    }
-    // runs the items on the workers and the calling thread; returns when all are done
-    void run(std::vector<Item>&& work)
-    {
-        for (;;) {
-            std::unique_lock<std::mutex> lk(mu);
-            if (active.load() != 0) { lk.unlock(); std::this_thread::yield(); continue; }
-            items = std::move(work);
-            next.store(0); done.store(0);
-            gen.fetch_add(1);
-            break;
-        }
-        cv.notify_all();
-        drain();
-        while (done.load() < items.size()) std::this_thread::yield();
-    }
-    ~FillPool()
-    {
-        { std::lock_guard<std::mutex> lk(mu); quit.store(true); }
-        cv.notify_all();
-        for (auto& t : th) t.join();
-    }
-};
-}  // namespace
-
 int gd_push(gd_ctx* c, int32_t tid, const int32_t* pos, const uint16_t* flag, const uint8_t* mapq,
             const uint32_t* cigar_off, const uint32_t* cigar, size_t n_reads, size_t n_ops)
 {
@@ -514,9 +540,10 @@ int gd_push(gd_ctx* c, int32_t tid, const int32_t* pos, const uint16_t* flag, co
         if (int r = reserve_records(c, h, n_reads, cigar_off[n_reads] - cigar_off[0])) return r;   // one allocation, not one per doubling
     }
     const size_t chunk = c->push_chunk;   // records per staging block (kRingSlots blocks: one being filled, the others on the link)
-    const int workers = n_reads >= (1u << 18) ? c->push_threads - 1 : 0;
-    FillPool pool;
-    if (workers > 0) pool.start(workers);
+    FillPool local;                                     // (no workers: small pushes run on the calling thread)
+    FillPool* const shared = n_reads >= (1u << 18) ? ctx_pool(c) : nullptr;
+    FillPool& pool = shared ? *shared : local;
+    const int workers = shared ? 1 : 0;
     const size_t piece = 1u << 20;   // bytes per work item
     size_t i = 0;
     while (i < n_reads) {

@@ -74,6 +74,7 @@ struct RingSlot {
 
 // State of a device BAM read between gd_ingest_begin and gd_ingest_finish.
 struct IngestState;
+namespace { struct FillPool; }
 
 // Device buffers of one pending range (compressed bytes, inflated bytes, member tables): grow-only and
 // kept by the context between ranges -- allocating and freeing gigabytes per range cost 0.1-0.2 s.
@@ -199,6 +200,7 @@ struct gd_ctx {
     bool fused_norm = true;                            // GD_OPT_FUSED_NORMALIZE: gd_normalize as one pass (0: count / scan / write / index launches)
     int32_t bam_n_ref = 0;                             // GD_OPT_BAM_REFS: references of the BAM being read (0: unknown)
     int push_threads = 16;
+    FillPool* pool = nullptr; int pool_workers = 0;    // host worker threads (gd_push fills, gd_commit validates), created on first use
     size_t push_chunk = 1u << 20;                      // GD_OPT_PUSH_CHUNK: records per staging block of gd_push                             // GD_OPT_PUSH_THREADS: threads of gd_push filling a ring block
     uint32_t* d_scan_tmp = nullptr; size_t cap_scan_tmp = 0;   // launch_scan: block totals
     uint8_t* d_seq = nullptr;  size_t cap_seq = 0;     // gd_seq_load: one contig's bases, zero padded

@@ -2,6 +2,7 @@
 #include "../../../include/goleft_depth_host.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -63,34 +64,54 @@ int gdh_produce_in_place(void* vctx, int32_t tid, const int32_t* pos, const uint
     if (threads < 1) threads = 1;
     if (chunk < 4096) chunk = 4096;
     if (int r = gd_reserve(ctx, tid, n_reads, n_ops)) return r;   // (a decoder has the count from the .bai metadata bin)
-    for (size_t i = 0; i < n_reads; i += chunk) {
-        const size_t n = std::min(chunk, n_reads - i);
-        const size_t o0 = cigar_off[i], o1 = cigar_off[i + n];
-        gd_batch b;
-        if (int r = gd_acquire(ctx, n, o1 - o0, &b)) return r;
-        // every thread "decodes" a contiguous share of the block's records and their ops
-        auto part = [&](int k) {
-            const size_t a = n * (size_t)k / (size_t)threads, e = n * (size_t)(k + 1) / (size_t)threads;
-            if (e <= a) return;
-            memcpy(b.pos + a, pos + i + a, (e - a) * sizeof(int32_t));
-            memcpy(b.flag + a, flag + i + a, (e - a) * sizeof(uint16_t));
-            memcpy(b.mapq + a, mapq + i + a, (e - a) * sizeof(uint8_t));
-            const uint32_t* so = cigar_off + i;
-            for (size_t r = a; r < e; ++r) b.cigar_off[r] = so[r] - (uint32_t)o0;
-            if (e == n) b.cigar_off[n] = so[n] - (uint32_t)o0;
-            const size_t ca = so[a], ce = so[e];
-            if (ce > ca) memcpy(b.cigar + (ca - o0), cigar + ca, (ce - ca) * sizeof(uint32_t));
-        };
-        if (threads == 1 || n < (1u << 16)) { for (int k = 0; k < threads; ++k) part(k); }
-        else {
-            std::vector<std::thread> th;
-            for (int k = 1; k < threads; ++k) th.emplace_back(part, k);
-            part(0);
-            for (auto& t : th) t.join();
+    // `threads` producers for the whole call (like decoder goroutines): each writes its share of every block, a
+    // spin barrier separates "block filled" from "block committed, next one acquired"
+    std::atomic<int> arrived{0}, phase{0}, status{GD_OK};
+    gd_batch b{};
+    size_t i = 0, n = 0, o0 = 0, o1 = 0;
+    bool done = n_reads == 0;
+    auto next_block = [&]() -> int {                      // (one thread)
+        if (i >= n_reads) { done = true; return GD_OK; }
+        n = std::min(chunk, n_reads - i);
+        o0 = cigar_off[i]; o1 = cigar_off[i + n];
+        return gd_acquire(ctx, n, o1 - o0, &b);
+    };
+    if (int r = next_block()) return r;
+    auto part = [&](int k) {
+        const size_t a = n * (size_t)k / (size_t)threads, e = n * (size_t)(k + 1) / (size_t)threads;
+        if (e <= a) return;
+        memcpy(b.pos + a, pos + i + a, (e - a) * sizeof(int32_t));
+        memcpy(b.flag + a, flag + i + a, (e - a) * sizeof(uint16_t));
+        memcpy(b.mapq + a, mapq + i + a, (e - a) * sizeof(uint8_t));
+        const uint32_t* so = cigar_off + i;
+        for (size_t r = a; r < e; ++r) b.cigar_off[r] = so[r] - (uint32_t)o0;
+        if (e == n) b.cigar_off[n] = so[n] - (uint32_t)o0;
+        const size_t ca = so[a], ce = so[e];
+        if (ce > ca) memcpy(b.cigar + (ca - o0), cigar + ca, (ce - ca) * sizeof(uint32_t));
+    };
+    auto worker = [&](int k) {
+        int my = 0;
+        while (!done) {
+            part(k);
+            // barrier: the last producer to arrive commits the block and acquires the next
+            if (arrived.fetch_add(1) + 1 == threads) {
+                int rc = gd_commit(ctx, &b, tid, n, o1 - o0);
+                i += n;
+                if (rc == GD_OK) rc = next_block(); else done = true;
+                if (rc != GD_OK) { status.store(rc); done = true; }
+                arrived.store(0);
+                phase.fetch_add(1);
+            } else {
+                while (phase.load() == my) std::this_thread::yield();
+            }
+            ++my;
         }
-        if (int r = gd_commit(ctx, &b, tid, n, o1 - o0)) return r;
-    }
-    return GD_OK;
+    };
+    std::vector<std::thread> th;
+    for (int k = 1; k < threads; ++k) th.emplace_back(worker, k);
+    worker(0);
+    for (auto& t : th) t.join();
+    return status.load();
 }
 
 static int g_fast_exit = 0;

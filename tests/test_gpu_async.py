@@ -78,3 +78,43 @@ def test_finish_repeats_a_failed_attempt_and_the_order_is_enforced():
         assert np.array_equal(eng.perbase(0), po.perbase_c(r, 1, 0, L))
         eng.compute()                                          # and the synchronous form still works afterwards
         assert eng.stats().reruns == 0
+
+
+def test_producers_fill_the_ring_in_place_and_push_agree():
+    """Two ways from host memory into HBM -- gd_push (library threads copy and validate) and the public-ABI producer of
+    the host library (gd_reserve, gd_acquire, N threads write the block in place, gd_commit validates) -- with blocks
+    small enough that both ring and worker pool turn over many times: same records, same depth; an unsorted block is
+    refused by either with GD_E_UNSORTED and the context goes on."""
+    import numpy as np
+    from goleft_amd import _hostlib, synth
+    from goleft_amd.engine import DepthEngine, GdError, OPT_PUSH_CHUNK, OPT_PUSH_THREADS
+    from oracle import pyoracle as po
+    L = 4_000_000
+    r = po.Reads(*synth.short_reads_numpy(L, synth.n_reads_for(L), 9))
+    want = po.perbase_c(r, 1, 0, L)
+    host = _hostlib.load()
+    with DepthEngine(0) as eng:
+        eng.set_params(window_size=1000)
+        eng.set_contigs([L, L])
+        eng.set_option(OPT_PUSH_CHUNK, 1 << 18)
+        eng.set_option(OPT_PUSH_THREADS, 5)
+        eng.push(0, r.pos, r.flag, r.mapq, r.cigar_off, r.cigar)
+        rc = host.gdh_produce_in_place(eng._ctx, 1, r.pos.ctypes.data, r.flag.ctypes.data, r.mapq.ctypes.data,
+                                       r.cigar_off.ctypes.data, r.cigar.ctypes.data, r.n, r.n_ops, 7, 1 << 18)
+        assert rc == 0
+        eng.compute()
+        assert np.array_equal(eng.perbase(0), want) and np.array_equal(eng.perbase(1), want)
+        bad = r.pos.copy()
+        bad[600_000], bad[600_001] = bad[600_001] + 5, bad[600_000]          # out of order inside a later block
+        eng.reset()
+        with pytest.raises(GdError) as ei:
+            eng.push(0, bad, r.flag, r.mapq, r.cigar_off, r.cigar)
+        assert ei.value.status == -7
+        eng.reset()
+        rc = host.gdh_produce_in_place(eng._ctx, 1, bad.ctypes.data, r.flag.ctypes.data, r.mapq.ctypes.data,
+                                       r.cigar_off.ctypes.data, r.cigar.ctypes.data, r.n, r.n_ops, 7, 1 << 18)
+        assert rc == -7
+        eng.reset()
+        eng.push(0, r.pos, r.flag, r.mapq, r.cigar_off, r.cigar)
+        eng.compute()
+        assert np.array_equal(eng.perbase(0), want)
