@@ -293,6 +293,10 @@ struct FillPool {
             th.emplace_back([this] {
                 uint64_t seen = 0;
                 for (;;) {
+                    // the next block of a push follows within a fraction of a millisecond: spin that long before sleeping
+                    // (a condition-variable wake-up costs tens of microseconds per worker and block)
+                    for (int spin = 0; spin < 20000 && gen.load(std::memory_order_relaxed) == seen && !quit.load(std::memory_order_relaxed); ++spin)
+                        __builtin_ia32_pause();
                     {
                         std::unique_lock<std::mutex> lk(mu);
                         cv.wait(lk, [&] { return quit.load() || gen.load() != seen; });
