@@ -46,6 +46,7 @@ SYMBOLS = {
     "gdh_intervals_count": (C.c_size_t, [_P, C.c_char_p]),
     "gdh_list_members": (C.c_int64, [_P, C.c_size_t, C.c_uint64, _P, C.c_size_t, C.c_uint, C.c_size_t, C.c_size_t,
                                      _P, _P, _P, _P, _P]),
+    "gdh_samtools_main": (C.c_int, [C.c_int, C.POINTER(C.c_char_p)]),
     "gdh_produce_in_place": (C.c_int, [_P, C.c_int32, _P, _P, _P, _P, _P, C.c_size_t, C.c_size_t, C.c_int, C.c_size_t]),
     "gdh_set_fast_exit": (C.c_int, [C.c_int]),
     "gdh_get_fast_exit": (C.c_int, []),

@@ -3,6 +3,8 @@
 //   goleft-depth [flags] BAM          or          goleft-depth depth [flags] BAM
 //   goleft-depth depthwed -s SIZE a.depth.bed b.depth.bed ...   (the consumer of depth.bed files)
 //   goleft-depth multidepth -c CHROM a.bam b.bam ...            (/root/reference/multidepth, its own binary there)
+//   samtools depth -Q q -d D -r REGION in.bam                   (the same program installed under the NAME samtools,
+//                                                                goleft_amd/shim/samtools: an unmodified goleft finds it on PATH)
 #include <unistd.h>
 
 #include <cstdio>
@@ -25,6 +27,14 @@ int main(int argc, char** argv)
 {
     gdh_set_fast_exit(1);
     std::vector<const char*> av;
+    {
+        const char* base = strrchr(argv[0], '/');
+        base = base ? base + 1 : argv[0];
+        if (strcmp(base, "samtools") == 0) {
+            for (int i = 0; i < argc; ++i) av.push_back(argv[i]);
+            return leave(gdh_samtools_main((int)av.size(), av.data()));
+        }
+    }
     if (argc > 1 && strcmp(argv[1], "depthwed") == 0) {
         av.push_back("goleft depthwed");
         for (int i = 2; i < argc; ++i) av.push_back(argv[i]);

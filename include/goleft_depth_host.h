@@ -134,6 +134,12 @@ size_t gdh_plan_ingest_passes(const uint64_t* start, const uint8_t* has, size_t 
                               size_t n_wanted, uint64_t file_size, uint64_t group_bytes, size_t cap,
                               uint64_t* first, uint64_t* last, uint64_t* beg, uint64_t* end);
 
+/* `samtools depth [-a] -Q q -d D -r chr:s-e in.bam` served by the engine: what the reference shells out to per tile
+ * (depth/depth.go:45).  argv[0] is the program name, argv[1] must be "depth".  Lines `chrom \t pos (1-based) \t depth`
+ * on stdout, positions of depth 0 omitted unless -a; 0, or 1 with a message on stderr.  goleft_amd/shim/samtools is
+ * this function under the name an unmodified goleft looks for on PATH (SURVEY.md 8b option A). */
+int gdh_samtools_main(int argc, const char* const* argv);
+
 /* A producer writing records straight into the device library's pinned ring, through the PUBLIC device ABI only
  * (gd_acquire -> `threads` threads fill the block in place -> gd_commit, blocks of `chunk` records): what the BAM
  * decoder of a host does with its output, and what INTEGRATION.md tells the Go host to do.  The "decoder" here

@@ -420,3 +420,15 @@ def test_member_listing_on_damaged_ranges_agrees_with_the_serial_walk(tmp_path):
         if want is not None:
             for a, b in zip(got, want):
                 assert np.array_equal(a, b), case
+
+
+def test_samtools_shim_refuses_what_it_does_not_serve():
+    """goleft_amd/shim/samtools answers `samtools depth` only (no GPU is touched before the arguments are accepted)."""
+    import subprocess
+    shim = os.path.join(ROOT, "goleft_amd", "shim", "samtools")
+    assert os.path.exists(shim), "run __graft_entry__.build()"
+    for argv in (["view", "x.bam"], ["depth"], ["depth", "-q", "13", "x.bam"], ["depth", "--bogus", "x.bam"], ["depth", "a.bam", "b.bam"]):
+        p = subprocess.run([shim] + argv, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert p.returncode == 1 and b"goleft_amd shim" in p.stderr and p.stdout == b"", argv
+    p = subprocess.run([shim, "depth", "-Q", "1", "-r", "chr1:1-10", "/nonexistent.bam"], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert p.returncode == 1
