@@ -554,7 +554,7 @@ def main():
         tr = load_traffic("wgs", kname)
     elif world == 1 and args.workload == "ont" and args.coverage == 20.0 and chunk:
         tr = load_traffic("ont", kname)
-    elif world == 1 and args.workload == "cohort" and args.samples == 200 and kname == "gd_sums_stream_kernel":
+    elif world == 1 and args.workload == "cohort" and args.samples == 200 and kname.startswith("gd_sums_stream_kernel"):
         tr = load_traffic("cohort", kname)
     if tr:
         traffic = tr.get("hbm_bytes_per_launch")   # measured on this exact launch shape
