@@ -221,7 +221,8 @@ __device__ __forceinline__ uint32_t serial_dels(const uint32_t* __restrict__ ops
 
 // a whole wave, 64 ops at a time (wave_canonical's run logic: heads from ballots, run lengths as differences of one
 // wave prefix sum).  `overflow`: an op longer than 2^22 bases or a run past the 28-bit range -- the caller walks that
-// read with serial_dels (what it wrote before noticing is overwritten).
+// read with serial_dels (what it wrote before noticing is overwritten).  A run's length is a plain 32-bit sum: it cannot
+// pass the position cap the walk checks (a deletion is {start, length} in 32 bits each; no 28-bit op field to fit).
 __device__ __forceinline__ uint32_t wave_dels(const uint32_t* __restrict__ ops, uint32_t n, int lane, uint32_t pos,
                                               uint2* __restrict__ out, uint32_t& endp, bool& overflow)
 {
@@ -248,28 +249,46 @@ __device__ __forceinline__ uint32_t wave_dels(const uint32_t* __restrict__ ops, 
                 nxt[u] = k < n ? ops[k] : 0u;
             }
         }
+        // what does not depend on the run carried from group to group, for all four groups at once: kept / kind masks,
+        // one overflow test, and the four prefix sums INTERLEAVED (scan4: no DPP hazard stalls between the steps)
+        uint32_t lenv[DL_UNROLL], klv[DL_UNROLL], kindv[DL_UNROLL];
+        bool keptv[DL_UNROLL];
+        unsigned long long kmv[DL_UNROLL], nmv[DL_UNROLL];
+        bool big = false;
+        int sc[DL_UNROLL];
 #pragma unroll
         for (int u = 0; u < DL_UNROLL; ++u) {
-        const uint32_t cg = cgv[u];
-        const uint32_t op = cg & 0xfu, len = cg >> 4;
-        const bool kept = ((0x18du >> op) & 1u) && len != 0u;
-        const uint32_t kind = ((0x181u >> op) & 1u) ? 0u : 1u;
-        const unsigned long long km = __builtin_amdgcn_ballot_w64(kept);
+            const uint32_t op = cgv[u] & 0xfu;
+            lenv[u] = cgv[u] >> 4;
+            keptv[u] = ((0x18du >> op) & 1u) && lenv[u] != 0u;
+            kindv[u] = ((0x181u >> op) & 1u) ? 0u : 1u;
+            kmv[u] = __builtin_amdgcn_ballot_w64(keptv[u]);
+            nmv[u] = __builtin_amdgcn_ballot_w64(keptv[u] && kindv[u] == 1u);
+            big = big || (keptv[u] && lenv[u] > (1u << 22));
+            klv[u] = keptv[u] ? lenv[u] : 0u;
+            sc[u] = (int)klv[u];
+        }
+        if (__builtin_amdgcn_ballot_w64(big) != 0ull) { overflow = true; return 0u; }
+        static_assert(DL_UNROLL == 4, "one scan4 group");
+        scan4(sc[0], sc[1], sc[2], sc[3]);                             // each <= 64 * 2^22
+#pragma unroll
+        for (int u = 0; u < DL_UNROLL; ++u) {
+        const unsigned long long km = kmv[u];
         if (km == 0ull) continue;
-        if (__builtin_amdgcn_ballot_w64(kept && len > (1u << 22)) != 0ull || cur >= POS_CAP - (1u << 28)) { overflow = true; return 0u; }
-        const unsigned long long nm = __builtin_amdgcn_ballot_w64(kept && kind == 1u);
+        if (cur >= POS_CAP - (1u << 28)) { overflow = true; return 0u; }
+        const bool kept = keptv[u];
+        const uint32_t kind = kindv[u], kl = klv[u];
+        const unsigned long long nm = nmv[u];
         const unsigned long long pm = km & below;
         uint32_t pk = open_kind;
         if (pm != 0ull) pk = (uint32_t)((nm >> (63 - __clzll((long long)pm))) & 1ull);
         const bool head = kept && kind != pk;
         const unsigned long long hm = __builtin_amdgcn_ballot_w64(head);
-        const uint32_t kl = kept ? len : 0u;
-        const uint32_t S = (uint32_t)wave_inclusive_scan((int)kl);     // <= 64 * 2^22
+        const uint32_t S = (uint32_t)sc[u];
         const uint32_t E = S - kl;
         const uint32_t gtot = (uint32_t)__builtin_amdgcn_readlane((int)S, 63);
         if (hm == 0ull) {                                              // the open run goes on
             open_len += gtot;
-            if (open_len > norm::LEN_MAX) { overflow = true; return 0u; }
             cur += gtot;
             continue;
         }
@@ -278,10 +297,9 @@ __device__ __forceinline__ uint32_t wave_dels(const uint32_t* __restrict__ ops, 
         const uint32_t q = (uint32_t)__popcll(hb);
         const int ph = hb != 0ull ? 63 - __clzll((long long)hb) : 0;
         const uint32_t Eph = (uint32_t)__shfl((int)E, ph, 64);         // where the run this head closes began
-        const uint32_t tot = q == 0u ? open_len + E : E - Eph;
+        const uint32_t tot = q == 0u ? open_len + E : E - Eph;        // (32 bits: a run stays below the position cap checked above)
         const uint32_t start = q == 0u ? open_start : cur + Eph;
         const bool closes = head && (q != 0u || open_exists);
-        if (__builtin_amdgcn_ballot_w64(closes && tot > norm::LEN_MAX) != 0ull) { overflow = true; return 0u; }
         // an M head closes a D/N run: a deletion; its number = the deletions closed by the heads before this lane
         const unsigned long long dm = __builtin_amdgcn_ballot_w64(closes && kind == 0u);
         if (closes && kind == 0u) out[w + (uint32_t)__popcll(dm & below)] = make_uint2(start, tot);
@@ -300,6 +318,87 @@ __device__ __forceinline__ uint32_t wave_dels(const uint32_t* __restrict__ ops, 
 
 constexpr uint32_t WAVE_DELS_MIN = 24;     // reads with more ops than this are walked by the whole wave
 
+// ---- the walk without any run logic ---------------------------------------------------------------------------------
+//     depth(read, x) = [pos <= x < end] - [x inside one of the read's D/N ops]
+// holds for ANY way of cutting the D/N bases into pieces, and for end = the position after the LAST reference-consuming
+// op whatever its kind: a trailing deletion lies inside [pos, end) and cancels itself, neighbouring D/N ops are two
+// pieces that share an edge.  So every D/N op of length >= 1 is its own list entry at its reference position -- one
+// prefix sum of the consumed lengths per 64 ops and one ballot, nothing carried from group to group but the position and
+// the count.  (The run-merging walk above spends ~1 us per 64 ops on heads, closing runs and their bookkeeping, most
+// of it on the scalar unit the four SIMDs of a CU share: 10.4 ms for a 20x genome.)  What merging bought is the bound
+// "at most half the ops are deletions" behind the dense list offset (op offset >> 1) + r; a read with more D/N ops
+// than its slots hold (cap) -- D D D ..., no aligner's output -- is walked again by the merging walk, which fits.
+__device__ __forceinline__ uint32_t serial_dels_plain(const uint32_t* __restrict__ ops, uint32_t n, uint32_t pos,
+                                                      uint2* __restrict__ out, uint32_t cap, uint32_t& endp)
+{
+    uint32_t x = pos, w = 0;
+    for (uint32_t k = 0; k < n; ++k) {
+        const uint32_t cg = ops[k], op = cg & 0xfu, len = cg >> 4;
+        if (!((0x18du >> op) & 1u) || len == 0u) continue;
+        if (!((0x181u >> op) & 1u)) {                                  // D / N
+            if (w < cap) out[w] = make_uint2(x, len);
+            ++w;
+        }
+        x = sat_pos(x + len);
+    }
+    endp = x;
+    return w;                                                          // > cap: the caller walks the read again
+}
+
+__device__ __forceinline__ uint32_t wave_dels_plain(const uint32_t* __restrict__ ops, uint32_t n, int lane, uint32_t pos,
+                                                    uint2* __restrict__ out, uint32_t cap, uint32_t& endp, bool& again)
+{
+    uint32_t cur = pos, w = 0u;                                         // wave uniform
+    again = false;
+    uint32_t nxt[DL_UNROLL];
+#pragma unroll
+    for (int u = 0; u < DL_UNROLL; ++u) {
+        const uint32_t k = (uint32_t)u * 64u + (uint32_t)lane;
+        nxt[u] = k < n ? ops[k] : 0u;
+    }
+    for (uint32_t b0 = 0; b0 < n; b0 += DL_UNROLL * 64u) {
+        uint32_t cgv[DL_UNROLL];
+#pragma unroll
+        for (int u = 0; u < DL_UNROLL; ++u) cgv[u] = nxt[u];
+        if (b0 + DL_UNROLL * 64u < n) {
+#pragma unroll
+            for (int u = 0; u < DL_UNROLL; ++u) {
+                const uint32_t k = b0 + (uint32_t)(DL_UNROLL + u) * 64u + (uint32_t)lane;
+                nxt[u] = k < n ? ops[k] : 0u;
+            }
+        }
+        uint32_t lenv[DL_UNROLL];
+        bool dnv[DL_UNROLL], big = false;
+        int sc[DL_UNROLL];
+#pragma unroll
+        for (int u = 0; u < DL_UNROLL; ++u) {
+            const uint32_t op = cgv[u] & 0xfu;
+            lenv[u] = cgv[u] >> 4;
+            const bool cons = ((0x18du >> op) & 1u) && lenv[u] != 0u;
+            dnv[u] = cons && !((0x181u >> op) & 1u);
+            big = big || (cons && lenv[u] > (1u << 22));
+            sc[u] = cons ? (int)lenv[u] : 0;
+        }
+        if (__builtin_amdgcn_ballot_w64(big) != 0ull || cur >= POS_CAP - (1u << 30)) { again = true; return 0u; }
+        static_assert(DL_UNROLL == 4, "one scan4 group");
+        scan4(sc[0], sc[1], sc[2], sc[3]);                             // each <= 64 * 2^22: the batch advances by < 2^30
+#pragma unroll
+        for (int u = 0; u < DL_UNROLL; ++u) {
+            const unsigned long long dm = __builtin_amdgcn_ballot_w64(dnv[u]);
+            const uint32_t cnt = (uint32_t)__popcll(dm);
+            if (w + cnt > cap) { again = true; return 0u; }
+            if (dnv[u]) {
+                const uint32_t rk = __builtin_amdgcn_mbcnt_hi((uint32_t)(dm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)dm, 0u));
+                out[w + rk] = make_uint2(cur + (uint32_t)sc[u] - lenv[u], lenv[u]);
+            }
+            w += cnt;
+            cur += (uint32_t)__builtin_amdgcn_readlane(sc[u], 63);
+        }
+    }
+    endp = cur;
+    return w;
+}
+
 __global__ __launch_bounds__(256) void gd_dels_raw_kernel(DelBatch B)
 {
     const int lane = threadIdx.x & 63;
@@ -317,7 +416,8 @@ __global__ __launch_bounds__(256) void gd_dels_raw_kernel(DelBatch B)
         n = job.off[r + 1] - o0;
         fq = ((uint32_t)job.flag[r] << 8) | (uint32_t)job.mapq[r];
     }
-    const uint32_t doff = (o0 >> 1) + r;                  // at most n / 2 deletions: an M follows each
+    const uint32_t doff = (o0 >> 1) + r;                  // the read's slots: up to the next read's (o1 >> 1) + r + 1
+    const uint32_t cap = ((o0 + n) >> 1) - (o0 >> 1) + 1u;
     uint32_t endp = p, nd = 0;
     bool serial = n <= WAVE_DELS_MIN;
     unsigned long long todo = __builtin_amdgcn_ballot_w64(!serial);
@@ -328,12 +428,18 @@ __global__ __launch_bounds__(256) void gd_dels_raw_kernel(DelBatch B)
         const uint32_t oj = (uint32_t)__builtin_amdgcn_readlane((int)o0, j);
         const uint32_t nj = (uint32_t)__builtin_amdgcn_readlane((int)n, j);
         const uint32_t dj = (uint32_t)__builtin_amdgcn_readlane((int)doff, j);
+        const uint32_t cj = (uint32_t)__builtin_amdgcn_readlane((int)cap, j);
         uint32_t ej = pj;
-        bool ovf;
-        const uint32_t wj = wave_dels(job.cigar + oj, nj, lane, pj, job.dl + dj, ej, ovf);
+        bool ovf, again;
+        uint32_t wj = wave_dels_plain(job.cigar + oj, nj, lane, pj, job.dl + dj, cj, ej, again);
+        ovf = false;
+        if (again) wj = wave_dels(job.cigar + oj, nj, lane, pj, job.dl + dj, ej, ovf);   // merged runs always fit
         if (lane == j) { nd = wj; endp = ej; serial = ovf; }
     }
-    if (serial && n != 0u) nd = serial_dels(job.cigar + o0, n, p, job.dl + doff, endp);
+    if (serial && n != 0u) {
+        nd = serial_dels_plain(job.cigar + o0, n, p, job.dl + doff, cap, endp);
+        if (nd > cap) nd = serial_dels(job.cigar + o0, n, p, job.dl + doff, endp);
+    }
     if (valid) {
         job.lrec[r] = make_uint4(p, endp, doff, PT_NONE);
         job.lfq[r] = fq;
