@@ -507,9 +507,22 @@ __global__ __launch_bounds__(256) void gd_ptile_fill_kernel(DelBatch B)
     job.lrec[r].w = pb;
     const uint2* const d = job.dl + rc.z;
     uint32_t lo = 0;                                       // boundaries grow: the previous answer is a lower bound
+    // a read's deletions are spread over its span: where the one before boundary b lies is GUESSED from that (two probes
+    // 8 entries either side of the guess bracket it, three bisection steps finish; a miss bisects the side it is on) --
+    // a plain bisection per boundary was ~70 dependent loads per read, 2.3 ms for a 20x genome's 6 M reads
+    const uint32_t span = rc.y > rc.x ? rc.y - rc.x : 1u;
     for (uint32_t k = 0; k < K; ++k) {
         const uint64_t b = (uint64_t)((rc.x >> PT_SHIFT) + k) << PT_SHIFT;
         uint32_t hi = n_del;
+        if (lo < hi) {
+            const uint64_t rel = b > rc.x ? b - rc.x : 0u;
+            uint32_t g = (uint32_t)((rel * n_del) / span);
+            g = g < lo ? lo : (g >= n_del ? n_del - 1u : g);
+            const uint32_t pl = g > lo + 8u ? g - 8u : lo, ph = n_del - 1u - g > 8u ? g + 8u : n_del - 1u;
+            const uint32_t vl = d[pl].x, vh = d[ph].x;
+            if ((uint64_t)vl < b) { lo = pl + 1u; if ((uint64_t)vh >= b) hi = ph; else lo = ph + 1u; }
+            else hi = pl;
+        }
         while (lo < hi) {
             const uint32_t mid = lo + ((hi - lo) >> 1);
             if ((uint64_t)d[mid].x < b) lo = mid + 1; else hi = mid;
