@@ -35,6 +35,17 @@ def test_wgs_bench_line_has_the_contract_fields():
     # whole-job throughput: the units of one step over its duration
     assert abs(d["value"] - d["config"]["total_ref_bases"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
     assert d["value"] >= 1e9                                            # BASELINE.json's target at one GPU
+    # round 3: the step starts from the records as they crossed the ABI; what round 2 called `value` is a side field
+    assert "as they arrived" in d["config"]["step"] and d["roofline"]["kernel"].endswith("<raw>")
+    o = d["compute_only"]
+    assert o["value"] > d["value"] * 0.9 and o["roofline"]["kernel"] == "gd_tile_fast_kernel"
+    g = d["roofline_ingest"]
+    assert g["bound"] == "hbm" and g["kernels_ms"] > 0 and g["wall_ms"] < g["kernels_ms"] * 1.5   # one batch: no host overhead
+    e = d["emulated_sharding"]["by_n_gpus"]
+    assert set(e) == {"2", "4", "8"} and all(len(e[n]["per_shard_ms"]) == int(n) for n in e)
+    assert e["8"]["projected_speedup"] >= 6.0                           # north_star: >= 6x aggregate at 8 GPUs
+    for k in ("host_stream_scope", "host_stream_scope_wgs"):
+        assert set(d[k]["variants"]) == {"push", "in_place"} and d[k]["value"] > 3e9
 
 
 def test_product_never_uses_the_oracle():
