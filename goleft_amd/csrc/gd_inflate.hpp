@@ -4,376 +4,487 @@
 // (/root/reference/depth/depth.go:45) starts with inflating BGZF members; on the host that
 // is the end-to-end limiter (scope iii).  A BGZF file is a sequence of
 // independent <= 64 KiB deflate streams, so the file offers tens of thousands to millions
-// of independent decode jobs: here ONE LANE inflates ONE member, start to end, with the
-// classic canonical-Huffman bit-serial decoder (count[] / symbol[] per code length, as in
-// zlib's contrib/puff) -- no shared state between lanes, no host involvement beyond
-// listing the members.  The Huffman tables of a lane live in LDS ([entry][lane] layout: the
-// 64 lanes of a wave read/write the same entry of 64 different tables without bank
-// conflicts when they are in step), the code lengths of a dynamic block in the lane's
-// private memory, input is fetched 4 bytes at a time, output goes to the member's own
-// region of the inflated buffer (back-references read that same region); the member's CRC32
-// is verified at the end (table in LDS).
+// of independent decode jobs: ONE LANE inflates ONE member, start to end.
+//
+// Round 3 rewrote the symbol loop as a per-lane STATE MACHINE with a fixed memory schedule.  The first
+// kernel (one `if` per symbol kind, loads and stores inside the branches) left the compiler no way to
+// count what is in flight, so every use of a loaded value became `s_waitcnt vmcnt(0)` -- the wave then
+// paid a full store round trip per symbol (7 000 cycles per step measured, 72 % of wave cycles waiting).
+// Here every iteration of every lane issues exactly three vector-memory operations, unconditionally and
+// in the same order -- (1) the next 8 input bytes, (2) one 16-byte store, (3) one 16-byte load -- and
+// consumes what the PREVIOUS iteration loaded, so the waits are counted (`vmcnt(2)`, `vmcnt(1)`) and a
+// whole iteration of Huffman decoding hides each round trip:
+//   * input: the branch-free 64-bit bit buffer (`buf |= next << cnt; p += (63 - cnt) >> 3; cnt |= 56`);
+//     the word for the next refill is loaded right after this one, its address does not depend on what
+//     the decode consumes;
+//   * output: the last 16 bytes of the member live in registers (T).  Literals shift into T and are
+//     stored 16 at a time (or when a match starts); a match is copied in 16-byte chunks, one per
+//     iteration: the chunk's source is loaded in iteration i and stored in iteration i + 1, AFTER that
+//     iteration has decoded its own symbol.  The store slot comes before the load slot, so a chunk may
+//     read what the previous chunk wrote (any distance >= 16); distances below 16 take their first chunk
+//     from T with two byte permutes (selectors from a table shared by the workgroup) and continue at
+//     the next multiple of the distance that is >= 16;
+//   * lanes with nothing to store write T over the 16 bytes it mirrors (or to a dump line while the
+//     member is shorter than that), lanes with nothing to load read their member's first bytes.
+// Huffman decoding is canonical and branch free: the 15-bit peek is compared with the left-aligned end
+// of every code length (15 compares against packed registers) and the symbol index is one add and two
+// LDS reads ([entry][lane] tables: 408 bytes per lane, six workgroups per CU).  Block headers (dynamic
+// tables: ~300 serial code lengths per lane) are a divergent side path; lanes that reach one wait a
+// few iterations so that the wave builds its tables together.  CRC32 is a second, converged kernel.
 #pragma once
 
 namespace gd {
 
 struct InflateJob {
-    const uint8_t* comp;           // the compressed bytes
+    const uint8_t* comp;           // the compressed bytes (readable up to 64 bytes past the last member)
     const uint64_t* in_off;        // [n] offset of each member's deflate payload in comp
     const uint32_t* in_len;        // [n] payload bytes
     const uint64_t* out_off;       // [n] offset of the member's data in out
     const uint32_t* out_len;       // [n] ISIZE
     const uint32_t* crc;           // [n] CRC32 of the member's data (gzip trailer), or nullptr: not checked
-    uint8_t* out;
+    uint8_t* out;                  // (readable up to 64 bytes past the last member)
     uint32_t* status;              // [n] 0 ok, else an error code (18: CRC32 mismatch)
+    uint8_t* dump;                 // 1 KiB nobody reads: where idle lanes put their store
     uint32_t n;
 };
 
+constexpr size_t INF_SLACK = 256;  // bytes the inflate buffers are allocated beyond their contents
+constexpr size_t INF_DUMP = 1024;
+
 constexpr int INF_LANES = 64;      // lanes (= members in flight) per workgroup
 constexpr int INF_MAXL = 288, INF_MAXD = 30;
-// Per-lane LDS tables, 384 bytes: cnt[16] (uint16, shared by the two builds: the counts live in
-// registers while a block is decoded), nlit[16] (uint16), litlen symbols [288] and distance symbols
-// [32] as BYTES.  A lit/len symbol needs 9 bits; the ninth is not stored: within one code length the
-// canonical order is ascending symbol value, so the first nlit[len] entries are literals (< 256) and
-// the rest are 256 + the stored byte.  (uint16 symbols were 700 bytes per lane = 3 workgroups per CU;
-// one lane inflates one member and is latency bound, so members in flight are the throughput.)
-constexpr int INF_TBL_BYTES = 32 + 32 + INF_MAXL + 32;
+// LDS of a workgroup: per-lane tables in an [entry][lane] layout (the 64 lanes of the wave read the same
+// entry of 64 tables without bank conflicts when they are in step)
+constexpr int INF_LDN = 0;                               // u32 [15][64]: lit/len, per code length: index delta | (first length symbol index << 16)
+constexpr int INF_DDN = INF_LDN + 15 * 64 * 4;           // u16 [15][64]: distance, per code length: index delta
+constexpr int INF_LSYM = INF_DDN + 15 * 64 * 2;          // u8 [288][64]: low 8 bits of the lit/len symbols in code order
+constexpr int INF_DSYM = INF_LSYM + INF_MAXL * 64;       // u8 [30][64]
+constexpr int INF_PERM = INF_DSYM + INF_MAXD * 64;       // u32 [16][8]: byte-permute selectors of a period-d chunk (shared)
+constexpr int INF_LDS_BYTES = INF_PERM + 16 * 32;        // 26 624: six workgroups per CU
 
-struct BitReader {
-    const uint8_t* p;              // next byte not yet fetched into `ahead`
-    const uint8_t* end;
-    uint64_t buf;                  // bits not yet consumed, LSB first
-    uint64_t ahead;                // the next 8 input bytes, fetched one refill early (hides the load latency)
-    int cnt, acnt;                 // valid bits in buf / valid BYTES in ahead
-    bool bad;
-    __device__ __forceinline__ void fetch()
-    {
-        ahead = 0;
-        acnt = 0;
-        if (p + 8 <= end) { __builtin_memcpy(&ahead, p, 8); acnt = 8; p += 8; }   // unaligned 64-bit global load
-        else while (p < end) { ahead |= (uint64_t)(*p++) << (8 * acnt); ++acnt; }
-    }
-    __device__ __forceinline__ void init(const uint8_t* b, const uint8_t* e)
-    {
-        p = b; end = e; buf = 0; cnt = 0; bad = false;
-        fetch();
-    }
-    __device__ __forceinline__ void refill()              // afterwards cnt >= 32 unless the input is exhausted
-    {
-        if (cnt <= 32 && acnt > 0) {
-            const int take = acnt < 4 ? acnt : 4;         // whole bytes that fit: 32 + 32 <= 64
-            buf |= (ahead & (take == 4 ? 0xffffffffull : ((1ull << (8 * take)) - 1))) << cnt;
-            cnt += 8 * take;
-            ahead >>= 8 * take;
-            acnt -= take;
-            if (acnt == 0) fetch();
-        }
-    }
-    __device__ __forceinline__ uint32_t bits(int n)       // n <= 16
-    {
-        if (cnt < n) { refill(); if (cnt < n) { bad = true; return 0; } }
-        const uint32_t v = (uint32_t)(buf & ((1ull << n) - 1));
-        buf >>= n;
-        cnt -= n;
-        return v;
-    }
-};
+typedef uint32_t inf_v4 __attribute__((ext_vector_type(4)));
 
-// Canonical Huffman tables of one lane in LDS: t[entry * INF_LANES + lane]
-struct HuffLds {
-    uint16_t* cnt;                 // [16] codes of each length
-    uint16_t* nlit;                // [16] of those, symbols below 256 (lit/len table only)
-    uint8_t* sym;                  // low 8 bits of the symbols, ordered by code
-    __device__ __forceinline__ uint16_t& c(int i) const { return cnt[i * INF_LANES]; }
-    __device__ __forceinline__ uint16_t& nl(int i) const { return nlit[i * INF_LANES]; }
-    __device__ __forceinline__ uint8_t& s(int i) const { return sym[i * INF_LANES]; }
-};
-
-// Builds the tables from code lengths (puff.c construct()); returns false for an over-subscribed set.
-// LIT: also count the symbols below 256 per length (what restores the ninth symbol bit).
+// Canonical Huffman tables from code lengths.  A code of length l and value v (MSB first) is decoded from the
+// 15-bit peek x (first stream bit = MSB) as: l = 1 + #{k : x >= E_k}, E_k = (first_k + count_k) << (15 - k)
+// (non-decreasing); index in code order = (x >> (15 - l)) + (offset_l - first_l).  The ends go to E (two per
+// register), the deltas to LDS.  LIT: a lit/len symbol needs nine bits and a byte is stored -- within one length
+// the canonical order is ascending, so indexes from `offset_l + #literals of length l` on are 256 + the byte.
+// false: over-subscribed lengths.
 template <bool LIT>
-__device__ __forceinline__ bool huff_build(const HuffLds& h, const uint8_t* lengths, int n)
+__device__ __forceinline__ bool inf_build(const uint8_t* lens, int n, uint8_t* s_tbl, int lane, uint32_t (&E)[8])
 {
-    for (int l = 0; l <= 15; ++l) { h.c(l) = 0; if (LIT) h.nl(l) = 0; }
-    for (int i = 0; i < n; ++i) {
-        h.c(lengths[i]) = (uint16_t)(h.c(lengths[i]) + 1);
-        if (LIT && i < 256) h.nl(lengths[i]) = (uint16_t)(h.nl(lengths[i]) + 1);
+    uint32_t* const t32 = reinterpret_cast<uint32_t*>(s_tbl + INF_LDN) + lane;
+    uint16_t* const t16 = reinterpret_cast<uint16_t*>(s_tbl + INF_DDN) + lane;
+    uint8_t* const sym = s_tbl + (LIT ? INF_LSYM : INF_DSYM) + lane;
+    auto rd = [&](int l) -> uint32_t { return LIT ? t32[(l - 1) * 64] : (uint32_t)t16[(l - 1) * 64]; };
+    auto wr = [&](int l, uint32_t v) { if (LIT) t32[(l - 1) * 64] = v; else t16[(l - 1) * 64] = (uint16_t)v; };
+    for (int l = 1; l <= 15; ++l) wr(l, 0);
+    for (int i = 0; i < n; ++i) {                        // codes per length (bits 0-8), of those literals (bits 9-17)
+        const int l = lens[i];
+        if (l) wr(l, rd(l) + 1u + ((LIT && i < 256) ? 512u : 0u));
     }
     int left = 1;
+    uint32_t first = 0, offs = 0;
+    bool ok = true;
+    uint32_t fin[15];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) E[k] = 0;
+#pragma unroll
     for (int l = 1; l <= 15; ++l) {
-        left <<= 1;
-        left -= h.c(l);
-        if (left < 0) return false;
+        const uint32_t v = rd(l), c = v & 511u, nl = (v >> 9) & 511u;
+        left = (left << 1) - (int)c;
+        ok = ok && left >= 0;
+        const uint32_t e = ((first + c) << (15 - l)) & 0xffffu;          // <= 32768 while ok
+        E[(l - 1) >> 1] |= e << (((l - 1) & 1) * 16);
+        const uint32_t delta = (offs - first) & 0xffffu;
+        fin[l - 1] = LIT ? delta | ((offs + nl) << 16) : delta;
+        wr(l, offs);
+        offs += c;
+        first = (first + c) << 1;
     }
-    uint16_t offs[16];
-    offs[1] = 0;
-    for (int l = 1; l < 15; ++l) offs[l + 1] = (uint16_t)(offs[l] + h.c(l));
-    for (int i = 0; i < n; ++i)
-        if (lengths[i] != 0) h.s(offs[lengths[i]]++) = (uint8_t)i;
+    if (!ok) return false;
+    for (int i = 0; i < n; ++i) {
+        const int l = lens[i];
+        if (l) {
+            const uint32_t pos = rd(l);
+            wr(l, pos + 1u);
+            sym[pos * 64] = (uint8_t)i;
+        }
+    }
+#pragma unroll
+    for (int l = 1; l <= 15; ++l) wr(l, fin[l - 1]);
     return true;
 }
 
-// The 15 per-length code counts of a table, held in registers while a block is decoded (the
-// bit-serial walk below then touches LDS once per symbol instead of once per code bit).
-struct HuffCnt {
-    uint32_t w[8];                 // counts of lengths 2k, 2k+1 in the halves of w[k]
-    __device__ __forceinline__ void load(const HuffLds& h)
-    {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) w[k] = (uint32_t)h.c(2 * k) | ((uint32_t)h.c(2 * k + 1) << 16);
-    }
-    __device__ __forceinline__ void load_nlit(const HuffLds& h)
-    {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) w[k] = (uint32_t)h.nl(2 * k) | ((uint32_t)h.nl(2 * k + 1) << 16);
-    }
-    __device__ __forceinline__ int at(int len) const { return (int)((w[len >> 1] >> ((len & 1) * 16)) & 0xffffu); }
-};
-
-// One symbol (puff.c decode(), bit serial over the code lengths).  LIT: a lit/len table, nl holds its
-// per-length literal counts.
+// One symbol from the 15-bit peek x.  len: its code length (1..15); bad: x is no code of this table.
 template <bool LIT>
-__device__ __forceinline__ int huff_decode(BitReader& br, const HuffLds& h, const HuffCnt& hc, const HuffCnt& nl)
+__device__ __forceinline__ uint32_t inf_decode(uint32_t x, const uint32_t (&E)[8], const uint8_t* s_tbl, int lane, uint32_t& len,
+                                               bool& bad)
 {
-    if (br.cnt < 15) br.refill();
-    int code = 0, first = 0, index = 0;
-    uint64_t b = br.buf;
+    uint32_t n = 1;
 #pragma unroll
-    for (int len = 1; len <= 15; ++len) {
-        code |= (int)(b & 1);
-        b >>= 1;
-        const int count = hc.at(len);
-        if (code - count < first) {
-            if (br.cnt < len) { br.bad = true; return -1; }
-            br.buf >>= len;
-            br.cnt -= len;
-            const int k = code - first;
-            const int v = h.s(index + k);
-            return LIT ? v | ((int)(k >= nl.at(len)) << 8) : v;
-        }
-        index += count;
-        first += count;
-        first <<= 1;
-        code <<= 1;
+    for (int l = 1; l <= 15; ++l) {
+        const uint32_t e = (l - 1) & 1 ? E[(l - 1) >> 1] >> 16 : E[(l - 1) >> 1] & 0xffffu;
+        n += x >= e ? 1u : 0u;
     }
-    br.bad = true;
-    return -1;
+    bad = n > 15u;
+    n = n > 15u ? 15u : n;
+    len = n;
+    int delta;
+    uint32_t thr = 0;
+    if (LIT) {
+        const uint32_t w = reinterpret_cast<const uint32_t*>(s_tbl + INF_LDN)[(n - 1) * 64 + lane];
+        delta = (int)(int16_t)(w & 0xffffu);
+        thr = w >> 16;
+    } else {
+        delta = (int)(int16_t)reinterpret_cast<const uint16_t*>(s_tbl + INF_DDN)[(n - 1) * 64 + lane];
+    }
+    int idx = (int)(x >> (15u - n)) + delta;
+    idx = idx < 0 ? 0 : idx;
+    idx = idx > (LIT ? INF_MAXL : INF_MAXD) - 1 ? (LIT ? INF_MAXL : INF_MAXD) - 1 : idx;
+    uint32_t v = s_tbl[(LIT ? INF_LSYM : INF_DSYM) + idx * 64 + lane];
+    if (LIT) v |= (uint32_t)idx >= thr ? 256u : 0u;
+    return v;
+}
+
+__device__ __forceinline__ inf_v4 inf_load16(const uint8_t* p)
+{
+    inf_v4 v;
+    __builtin_memcpy(&v, p, 16);
+    return v;
+}
+__device__ __forceinline__ void inf_store16(uint8_t* p, inf_v4 v) { __builtin_memcpy(p, &v, 16); }
+__device__ __forceinline__ uint64_t inf_load8(const uint8_t* p)
+{
+    uint64_t v;
+    __builtin_memcpy(&v, p, 8);
+    return v;
+}
+
+// The last 16 bytes of (t followed by the first n bytes of c), 0 <= n <= 16.
+__device__ __forceinline__ inf_v4 inf_append(inf_v4 t, inf_v4 c, uint32_t n)
+{
+    uint32_t a0 = t.x, a1 = t.y, a2 = t.z, a3 = t.w, a4 = c.x, a5 = c.y, a6 = c.z, a7 = c.w;
+    if (n & 16u) { a0 = a4; a1 = a5; a2 = a6; a3 = a7; }
+    if (n & 8u) { a0 = a2; a1 = a3; a2 = a4; a3 = a5; a4 = a6; a5 = a7; }
+    if (n & 4u) { a0 = a1; a1 = a2; a2 = a3; a3 = a4; a4 = a5; }
+    const uint32_t r = n & 3u;
+    inf_v4 o;
+    o.x = __builtin_amdgcn_alignbyte(a1, a0, r);
+    o.y = __builtin_amdgcn_alignbyte(a2, a1, r);
+    o.z = __builtin_amdgcn_alignbyte(a3, a2, r);
+    o.w = __builtin_amdgcn_alignbyte(a4, a3, r);
+    return o;
 }
 
 __global__ __launch_bounds__(INF_LANES) void gd_inflate_kernel(InflateJob job)
 {
-    __shared__ __attribute__((aligned(4))) uint8_t s_tbl[INF_TBL_BYTES * INF_LANES];
-    __shared__ uint32_t s_crc[256];                        // CRC-32 (IEEE 802.3, reflected) byte table
-    for (int i = threadIdx.x; i < 256; i += INF_LANES) {
-        uint32_t c = (uint32_t)i;
-        for (int k = 0; k < 8; ++k) c = (c >> 1) ^ (0xedb88320u & (0u - (c & 1u)));
-        s_crc[i] = c;
+    __shared__ __attribute__((aligned(16))) uint8_t s_tbl[INF_LDS_BYTES];
+    const int lane = threadIdx.x;
+    // selectors of a chunk with period d, taken from the last d of 16 bytes: byte b of the chunk is byte
+    // 16 - d + b % d; one permute reads bytes 0-7 (selector 0x0c: zero), a second one bytes 8-15
+    for (int i = lane; i < 16 * 8; i += INF_LANES) {
+        const int d = i >> 3, half = (i >> 2) & 1, j = i & 3;
+        uint32_t w = 0;
+        for (int t = 0; t < 4; ++t) {
+            const int b = 4 * j + t, s = d ? 16 - d + b % d : 0;
+            const uint32_t sel = half == 0 ? (s < 8 ? (uint32_t)s : 0x0cu) : (s >= 8 ? (uint32_t)(s - 8) : 0x0cu);
+            w |= sel << (8 * t);
+        }
+        reinterpret_cast<uint32_t*>(s_tbl + INF_PERM)[i] = w;
     }
     __syncthreads();
     const uint32_t m = blockIdx.x * INF_LANES + threadIdx.x;
-    if (m >= job.n) return;
-    const int lane = threadIdx.x;
-    HuffLds hl, hd;
-    hl.cnt = reinterpret_cast<uint16_t*>(s_tbl) + lane;
-    hl.nlit = reinterpret_cast<uint16_t*>(s_tbl + 32 * INF_LANES) + lane;
-    hl.sym = s_tbl + 64 * INF_LANES + lane;
-    hd.cnt = hl.cnt;                                       // built after the lit/len counts are in registers
-    hd.nlit = nullptr;
-    hd.sym = s_tbl + (64 + INF_MAXL) * INF_LANES + lane;
+    const bool mine = m < job.n;
+    const uint32_t mm = mine ? m : 0u;
+    const uint8_t* const in_beg = job.comp + job.in_off[mm];
+    const uint8_t* const in_end = in_beg + job.in_len[mm];
+    uint8_t* const out = job.out + job.out_off[mm];
+    const uint32_t olen = job.out_len[mm];
+    uint8_t* const dump = job.dump + lane * 16;
 
-    BitReader br;
-    br.init(job.comp + job.in_off[m], job.comp + job.in_off[m] + job.in_len[m]);
-    uint8_t* const out = job.out + job.out_off[m];
-    const uint32_t olen = job.out_len[m];
-    uint32_t o = 0;
+    enum : uint32_t { DECODE = 0, COPY = 1, HDR = 2, DONE = 3 };
+    uint32_t mode = mine ? HDR : DONE;
     uint32_t err = 0;
+    uint32_t o = 0;                                        // bytes of the member produced (some still in T / C)
+    uint32_t rem = 0, deff = 16;                           // a match in progress: bytes left, source distance (>= 16)
+    uint32_t pend = 0;                                     // trailing bytes of T not stored yet (literals)
+    bool cpend = false, csmall = false;                    // a chunk waits for its store: [co, co + cn), from cl (loaded) or cs (built from T)
+    uint32_t co = 0, cn = 0;
+    bool lastblk = false;
+    inf_v4 T = {0, 0, 0, 0}, cs = {0, 0, 0, 0};
+    uint32_t LE[8], DE[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) LE[k] = DE[k] = 0;
+    const uint8_t* p = in_beg;
+    uint64_t buf = 0;
+    uint32_t cnt = 0;
+    const uint8_t* ld_addr = out;                          // the chunk source the next iteration loads (or any readable address)
 
-    static const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
-
-    bool last = false;
-    while (!last && err == 0) {
-        last = br.bits(1) != 0;
-        const uint32_t type = br.bits(2);
-        if (br.bad) { err = 1; break; }
-        if (type == 0) {                                   // stored
-            br.buf >>= (br.cnt & 7);                       // to the byte boundary
-            br.cnt &= ~7;
-            const uint32_t len = br.bits(16), nlen = br.bits(16);
-            if (br.bad || (len ^ 0xffffu) != nlen) { err = 2; break; }
-            if (o + len > olen) { err = 3; break; }
-            for (uint32_t k = 0; k < len; ++k) {
-                const uint32_t v = br.bits(8);
-                out[o++] = (uint8_t)v;
-            }
-            if (br.bad) { err = 1; break; }
-            continue;
+    for (uint32_t it = 0;; ++it) {
+        const uint64_t live = __ballot(mode != DONE);
+        if (live == 0) break;
+        if (it >= (1u << 20)) {                            // (a member is at most 65 536 symbols: never reached)
+            if (mode != DONE) err = 19;
+            break;
         }
-        if (type == 3) { err = 4; break; }
-        uint8_t lengths[INF_MAXL + INF_MAXD + 2];
-        HuffCnt cl, cd, nl;
-        if (type == 1) {                                   // fixed codes
-            int s = 0;
-            for (; s < 144; ++s) lengths[s] = 8;
-            for (; s < 256; ++s) lengths[s] = 9;
-            for (; s < 280; ++s) lengths[s] = 7;
-            for (; s < 288; ++s) lengths[s] = 8;
-            huff_build<true>(hl, lengths, 288);
-            cl.load(hl);
-            nl.load_nlit(hl);
-            for (s = 0; s < 30; ++s) lengths[s] = 5;
-            huff_build<false>(hd, lengths, 30);
-            cd.load(hd);
-        } else {                                           // dynamic codes
-            const int nlen = (int)br.bits(5) + 257, ndist = (int)br.bits(5) + 1, ncode = (int)br.bits(4) + 4;
-            if (br.bad || nlen > INF_MAXL || ndist > INF_MAXD) { err = 5; break; }
-            int idx = 0;
-            for (; idx < ncode; ++idx) lengths[order[idx]] = (uint8_t)br.bits(3);
-            for (; idx < 19; ++idx) lengths[order[idx]] = 0;
-            if (!huff_build<false>(hl, lengths, 19)) { err = 6; break; }   // the code-length code borrows the lit/len table
-            HuffCnt cc;
-            cc.load(hl);
-            idx = 0;
-            while (idx < nlen + ndist) {
-                int sym = huff_decode<false>(br, hl, cc, cc);
-                if (sym < 0) { err = 7; break; }
-                if (sym < 16) { lengths[idx++] = (uint8_t)sym; continue; }
-                int prev = 0, rep;
-                if (sym == 16) {
-                    if (idx == 0) { err = 8; break; }
-                    prev = lengths[idx - 1];
-                    rep = 3 + (int)br.bits(2);
-                } else if (sym == 17) rep = 3 + (int)br.bits(3);
-                else rep = 11 + (int)br.bits(7);
-                if (idx + rep > nlen + ndist) { err = 9; break; }
-                while (rep--) lengths[idx++] = (uint8_t)prev;
-            }
-            if (err) break;
-            if (lengths[256] == 0) { err = 10; break; }
-            uint8_t dl[INF_MAXD];
-            for (int k = 0; k < ndist; ++k) dl[k] = lengths[nlen + k];
-            if (!huff_build<true>(hl, lengths, nlen)) { err = 11; break; }
-            cl.load(hl);
-            nl.load_nlit(hl);
-            if (!huff_build<false>(hd, dl, ndist)) { err = 12; break; }
-            cd.load(hd);
-        }
-        // ---- the block's symbols ---------------------------------------------
-        // Short matches far enough back (the common case) are DEFERRED: their 16 source bytes are
-        // loaded now and stored only after the next symbol has been decoded, so the global load
-        // latency overlaps that decode instead of stalling the wave (with 64 lanes in 64 different
-        // places, nearly every step has some lane copying).  Bytes past the match length that the
-        // 16-byte store also writes are overwritten by the output that follows.
-        uint32_t pw0 = 0, pw1 = 0, pw2 = 0, pw3 = 0, pend_o = 0;
-        int pend_n = 0;
-        auto flush = [&]() {
-            if (pend_n == 0) return;
-            if (pend_o + 16u <= olen) {
-                __builtin_memcpy(out + pend_o, &pw0, 4); __builtin_memcpy(out + pend_o + 4, &pw1, 4);
-                __builtin_memcpy(out + pend_o + 8, &pw2, 4); __builtin_memcpy(out + pend_o + 12, &pw3, 4);
-            } else {                                       // next to the member's end: exactly the match
-                const uint32_t w[4] = {pw0, pw1, pw2, pw3};
-                for (int k = 0; k < pend_n; ++k) out[pend_o + k] = (uint8_t)(w[k >> 2] >> (8 * (k & 3)));
-            }
-            pend_n = 0;
-        };
-        for (;;) {
-            const int sym = huff_decode<true>(br, hl, cl, nl);
-            flush();
-            if (sym < 0) { err = 13; break; }
-            if (sym < 256) {
-                if (o >= olen) { err = 3; break; }
-                out[o++] = (uint8_t)sym;
-            } else if (sym == 256) {
-                break;
-            } else {
-                // base value and extra-bit count of length / distance symbols in closed form
-                // (RFC 1951 3.2.5) -- table lookups would be dependent global loads on the
-                // critical path of every match
-                const int ls = sym - 257;
-                if (ls >= 29) { err = 14; break; }
-                uint32_t len;
-                if (ls < 8) len = 3u + (uint32_t)ls;
-                else if (ls == 28) len = 258u;
-                else { const int e = (ls >> 2) - 1; len = 3u + ((4u + (uint32_t)(ls & 3)) << e) + br.bits(e); }
-                const int ds = huff_decode<false>(br, hd, cd, cd);
-                if (ds < 0 || ds >= 30) { err = 15; break; }
-                uint32_t dist;
-                if (ds < 4) dist = 1u + (uint32_t)ds;
-                else { const int e = (ds >> 1) - 1; dist = 1u + ((2u + (uint32_t)(ds & 1)) << e) + br.bits(e); }
-                if (br.bad) { err = 1; break; }
-                if (dist > o || o + len > olen) { err = 16; break; }
-                if (dist >= 16 && len <= 16) {
-                    const uint8_t* src = out + o - dist;    // src + 16 <= out + o: only finished bytes are read
-                    __builtin_memcpy(&pw0, src, 4); __builtin_memcpy(&pw1, src + 4, 4);
-                    __builtin_memcpy(&pw2, src + 8, 4); __builtin_memcpy(&pw3, src + 12, 4);
-                    pend_o = o;
-                    pend_n = (int)len;
-                    o += len;
-                    continue;
-                }
-                uint32_t k = 0;
-                if (dist < 4) {
-                    // run-length style matches (distance 1..3, up to 258 bytes): the pattern is read
-                    // once and replayed from registers -- a byte loop here would chain a
-                    // store -> load round trip through memory per output byte
-                    const uint32_t b0 = out[o - dist];
-                    const uint32_t b1 = dist > 1 ? out[o - dist + 1] : b0;
-                    const uint32_t b2 = dist > 2 ? out[o - dist + 2] : (dist == 2 ? b0 : b0);
-                    uint32_t w[3];
-                    if (dist == 1) { w[0] = w[1] = w[2] = b0 * 0x01010101u; }
-                    else if (dist == 2) { w[0] = w[1] = w[2] = b0 | (b1 << 8) | (b0 << 16) | (b1 << 24); }
+        // ---- block header (a divergent side path; lanes wait for each other to build together) ----
+        const uint64_t hm = __ballot(mode == HDR);
+        if (hm != 0 && (hm == live || __popcll(hm) >= 32 || (it & 31u) == 31u)) {
+            if (mode == HDR) {
+                auto need = [&](uint32_t nb) {             // nb <= 32
+                    if (cnt < nb) {
+                        buf |= inf_load8(p) << cnt;
+                        p += (63u - cnt) >> 3;
+                        cnt |= 56u;
+                    }
+                };
+                auto bits = [&](uint32_t nb) -> uint32_t { // nb <= 16
+                    need(nb);
+                    const uint32_t v = (uint32_t)buf & ((1u << nb) - 1u);
+                    buf >>= nb;
+                    cnt -= nb;
+                    return v;
+                };
+                auto past_end = [&]() { return (int64_t)(p - in_beg) * 8 - (int64_t)cnt > (int64_t)(in_end - in_beg) * 8; };
+                lastblk = bits(1) != 0;
+                const uint32_t type = bits(2);
+                uint8_t lens[INF_MAXL + INF_MAXD + 4];
+                if (type == 0) {                           // stored: byte loop, then T is read back
+                    const uint32_t drop = cnt & 7u;
+                    buf >>= drop;
+                    cnt -= drop;
+                    const uint32_t len = bits(16), nlen = bits(16);
+                    if ((len ^ 0xffffu) != nlen) err = 2;
+                    else if (o + len > olen || past_end()) err = 3;
                     else {
-                        w[0] = b0 | (b1 << 8) | (b2 << 16) | (b0 << 24);
-                        w[1] = b1 | (b2 << 8) | (b0 << 16) | (b1 << 24);
-                        w[2] = b2 | (b0 << 8) | (b1 << 16) | (b2 << 24);
+                        for (uint32_t k = 0; k < len && err == 0; ++k) {
+                            out[o++] = (uint8_t)bits(8);
+                            if (p > in_end + 16) err = 1;
+                        }
+                        uint32_t w[4] = {0, 0, 0, 0};
+                        for (uint32_t k = 0; k < 16 && k < o; ++k)
+                            w[3 - (k >> 2)] |= (uint32_t)out[o - 1 - k] << (8 * (3 - (k & 3)));
+                        T = inf_v4{w[0], w[1], w[2], w[3]};
+                        if (err == 0 && past_end()) err = 1;
                     }
-                    uint32_t ph = 0;
-                    for (; k + 4 <= len; k += 4, o += 4) {
-                        const uint32_t v = ph == 0 ? w[0] : ph == 1 ? w[1] : w[2];
-                        __builtin_memcpy(out + o, &v, 4);
-                        ph = ph == 2 ? 0 : ph + 1;
+                    // the next header follows (or the member ends)
+                    if (err == 0 && lastblk) mode = DONE;
+                } else if (type == 3) {
+                    err = 4;
+                } else {
+                    int nlen = 288, ndist = 30;
+                    if (type == 1) {                       // fixed codes
+                        int s = 0;
+                        for (; s < 144; ++s) lens[s] = 8;
+                        for (; s < 256; ++s) lens[s] = 9;
+                        for (; s < 280; ++s) lens[s] = 7;
+                        for (; s < 288; ++s) lens[s] = 8;  // (286 and 287 complete the code; a stream must not use them)
+                        for (s = 0; s < 30; ++s) lens[nlen + s] = 5;
+                    } else {                               // dynamic codes
+                        nlen = (int)bits(5) + 257;
+                        ndist = (int)bits(5) + 1;
+                        const int ncode = (int)bits(4) + 4;
+                        if (nlen > 286 || ndist > INF_MAXD) err = 5;
+                        static const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+                        uint8_t cl_len[19];
+                        for (int k = 0; k < 19; ++k) cl_len[order[k]] = k < ncode ? (uint8_t)bits(3) : (uint8_t)0;
+                        // the code-length code borrows the distance tables
+                        if (err == 0 && !inf_build<false>(cl_len, 19, s_tbl, lane, DE)) err = 6;
+                        int idx = 0;
+                        while (err == 0 && idx < nlen + ndist) {
+                            need(32);
+                            uint32_t l = 0;
+                            bool bad = false;
+                            const uint32_t sym = inf_decode<false>(__brev((uint32_t)buf) >> 17, DE, s_tbl, lane, l, bad);
+                            if (bad || sym > 18u) { err = 7; break; }
+                            buf >>= l;
+                            cnt -= l;
+                            if (sym < 16u) { lens[idx++] = (uint8_t)sym; continue; }
+                            uint32_t prev = 0, rep;
+                            if (sym == 16u) {
+                                if (idx == 0) { err = 8; break; }
+                                prev = lens[idx - 1];
+                                rep = 3u + bits(2);
+                            } else if (sym == 17u) rep = 3u + bits(3);
+                            else rep = 11u + bits(7);
+                            if (idx + (int)rep > nlen + ndist) { err = 9; break; }
+                            while (rep--) lens[idx++] = (uint8_t)prev;
+                            if (p > in_end + 16) err = 1;
+                        }
+                        if (err == 0 && lens[256] == 0) err = 10;
                     }
-                    uint32_t v = ph == 0 ? w[0] : ph == 1 ? w[1] : w[2];
-                    for (; k < len; ++k, ++o, v >>= 8) out[o] = (uint8_t)v;
+                    if (err == 0 && past_end()) err = 1;
+                    if (err == 0 && !inf_build<true>(lens, nlen, s_tbl, lane, LE)) err = 11;
+                    if (err == 0 && !inf_build<false>(lens + nlen, ndist, s_tbl, lane, DE)) err = 12;
+                    if (err == 0) mode = DECODE;
                 }
-                if (dist >= 16)                            // 16-byte groups: four loads in flight, then four stores
-                    for (; k + 16 <= len; k += 16, o += 16) {
-                        uint32_t w0, w1, w2, w3;
-                        const uint8_t* src = out + o - dist;
-                        __builtin_memcpy(&w0, src, 4); __builtin_memcpy(&w1, src + 4, 4);
-                        __builtin_memcpy(&w2, src + 8, 4); __builtin_memcpy(&w3, src + 12, 4);
-                        __builtin_memcpy(out + o, &w0, 4); __builtin_memcpy(out + o + 4, &w1, 4);
-                        __builtin_memcpy(out + o + 8, &w2, 4); __builtin_memcpy(out + o + 12, &w3, 4);
-                    }
-                if (dist >= 4)                             // source and destination words do not overlap
-                    for (; k + 4 <= len; k += 4, o += 4) {
-                        uint32_t w;
-                        __builtin_memcpy(&w, out + o - dist, 4);
-                        __builtin_memcpy(out + o, &w, 4);
-                    }
-                for (; k < len; ++k, ++o) out[o] = out[o - dist];
+                if (err != 0) { mode = DONE; p = in_beg; }
+                if (mode == DONE && err == 0 && o != olen) err = 17;
+                need(56);                                  // what the decode below may consume
             }
         }
-        flush();                                           // a match deferred by the block's last step
-    }
-    if (err == 0 && (o != olen || br.bad)) err = 17;
-    if (err == 0 && job.crc) {
-        // the gzip trailer's CRC32 over what was just written (all lanes are here together again:
-        // a converged byte loop, ~2 % of the decode time)
-        uint32_t c = 0xffffffffu;
-        uint32_t k = 0;
-        for (; k + 4 <= olen; k += 4) {
-            uint32_t w;
-            __builtin_memcpy(&w, out + k, 4);
-            c = s_crc[(c ^ w) & 0xffu] ^ (c >> 8);
-            c = s_crc[(c ^ (w >> 8)) & 0xffu] ^ (c >> 8);
-            c = s_crc[(c ^ (w >> 16)) & 0xffu] ^ (c >> 8);
-            c = s_crc[(c ^ (w >> 24)) & 0xffu] ^ (c >> 8);
+
+        // ---- (1) the iteration's two loads: the chunk of a match in progress, the input word of the refill at the
+        //      end of the iteration (its address does not depend on what the decode consumes) ----
+        const inf_v4 cl = inf_load16(ld_addr);
+        const uint64_t nw = inf_load8(p);
+
+        // ---- (2) decode one symbol: everything a match needs, for every lane (no branches) ----
+        const uint32_t lo = (uint32_t)buf;
+        uint32_t l1 = 0, l2 = 0;
+        bool bad1 = false, bad2 = false;
+        const uint32_t sym = inf_decode<true>(__brev(lo) >> 17, LE, s_tbl, lane, l1, bad1);
+        const uint32_t ls = sym - 257u;                    // length symbols 257..285
+        uint32_t e1 = ls < 8u || ls >= 28u ? 0u : (ls >> 2) - 1u;
+        uint32_t mlen = ls < 8u ? 3u + ls : ls == 28u ? 258u : 3u + ((4u + (ls & 3u)) << e1) + ((lo >> l1) & ((1u << e1) - 1u));
+        const uint32_t used1 = l1 + e1;                    // <= 20
+        const uint32_t lo2 = (uint32_t)(buf >> used1);
+        const uint32_t ds = inf_decode<false>(__brev(lo2) >> 17, DE, s_tbl, lane, l2, bad2);
+        const uint32_t e2 = ds < 4u ? 0u : (ds >> 1) - 1u;
+        const uint32_t mdist = ds < 4u ? 1u + ds : 1u + ((2u + (ds & 1u)) << e2) + ((lo2 >> l2) & ((1u << e2) - 1u));
+        const uint32_t used2 = used1 + l2 + e2;            // <= 48
+
+        // ---- (3) the chunk loaded (or built) in the previous iteration goes into T ----
+        const bool cp = cpend;
+        const inf_v4 c = csmall ? cs : cl;
+        if (cp) T = inf_append(T, c, cn);
+        cpend = false;
+
+        // ---- (4) this iteration's symbol ----
+        bool flush = false;
+        bool start = false;
+        if (mode == DECODE) {
+            if (bad1) { err = 13; mode = DONE; }
+            else if (sym < 256u) {
+                if (o >= olen) { err = 3; mode = DONE; }
+                else {
+                    T.x = __builtin_amdgcn_alignbyte(T.y, T.x, 1);
+                    T.y = __builtin_amdgcn_alignbyte(T.z, T.y, 1);
+                    T.z = __builtin_amdgcn_alignbyte(T.w, T.z, 1);
+                    T.w = (T.w >> 8) | (sym << 24);
+                    ++o;
+                    ++pend;
+                    flush = pend == 16u;
+                    buf >>= l1;
+                    cnt -= l1;
+                }
+            } else if (sym == 256u) {
+                buf >>= l1;
+                cnt -= l1;
+                flush = pend != 0u;
+                mode = lastblk ? DONE : HDR;
+                if (lastblk) {
+                    if (o != olen) err = 17;
+                    else if ((int64_t)(p - in_beg) * 8 - (int64_t)cnt > (int64_t)(in_end - in_beg) * 8) err = 1;
+                }
+            } else {
+                if (ls >= 29u) { err = 14; mode = DONE; }
+                else if (bad2 || ds >= 30u) { err = 15; mode = DONE; }
+                else if (mdist > o || o + mlen > olen) { err = 16; mode = DONE; }
+                else {
+                    buf >>= used2;
+                    cnt -= used2;
+                    flush = pend != 0u;
+                    start = true;
+                    mode = COPY;
+                    rem = mlen;
+                }
+            }
+            if (mode == DONE) p = in_beg;
         }
-        for (; k < olen; ++k) c = s_crc[(c ^ out[k]) & 0xffu] ^ (c >> 8);
-        if ((c ^ 0xffffffffu) != job.crc[m]) err = 18;
+        // the iteration's one store: the chunk; or T over the 16 bytes it mirrors -- that writes the literals
+        // gathered in T when they are due (`flush`), a chunk that may not run past the member's end, and is a
+        // harmless rewrite otherwise
+        uint8_t* st_addr = dump;
+        inf_v4 st_data = T;
+        if (cp && co + 16u <= olen) {
+            st_addr = out + co;
+            st_data = c;
+        } else if (o >= 16u) {
+            st_addr = out + (o - 16u);
+        } else if (flush || cp) {                          // the member's first bytes: T holds them right-aligned
+            const uint32_t w[4] = {T.x, T.y, T.z, T.w};
+            for (uint32_t k = 0; k < o; ++k) {
+                const uint32_t b = 16u - o + k;
+                out[k] = (uint8_t)(w[b >> 2] >> (8 * (b & 3)));
+            }
+        }
+        if (flush) pend = 0;
+        inf_store16(st_addr, st_data);
+
+        // ---- (5) a match in progress: its next chunk, loaded (next iteration) after the store above ----
+        ld_addr = out;
+        csmall = false;
+        if (mode == COPY) {
+            const uint32_t n = rem < 16u ? rem : 16u;
+            if (start && mdist < 16u) {
+                // period mdist, from the last mdist bytes of T
+                const inf_v4 s0 = *reinterpret_cast<const inf_v4*>(s_tbl + INF_PERM + mdist * 32);
+                const inf_v4 s1 = *reinterpret_cast<const inf_v4*>(s_tbl + INF_PERM + mdist * 32 + 16);
+                cs.x = __builtin_amdgcn_perm(T.y, T.x, s0.x) | __builtin_amdgcn_perm(T.w, T.z, s1.x);
+                cs.y = __builtin_amdgcn_perm(T.y, T.x, s0.y) | __builtin_amdgcn_perm(T.w, T.z, s1.y);
+                cs.z = __builtin_amdgcn_perm(T.y, T.x, s0.z) | __builtin_amdgcn_perm(T.w, T.z, s1.z);
+                cs.w = __builtin_amdgcn_perm(T.y, T.x, s0.w) | __builtin_amdgcn_perm(T.w, T.z, s1.w);
+                csmall = true;
+                // the following chunks repeat with the next multiple of the period that is >= 16
+                deff = 16u + (uint32_t)((0xECA8642052402000ull >> (4u * mdist)) & 15u);
+            } else {
+                if (start) deff = mdist;
+                ld_addr = out + (o - deff);
+            }
+            co = o;
+            cn = n;
+            o += n;
+            rem -= n;
+            cpend = true;
+            if (rem == 0u) mode = DECODE;
+        }
+
+        // ---- (6) refill from the word loaded at the top ----
+        if (mode != DONE) {
+            buf |= nw << cnt;
+            p += (63u - cnt) >> 3;
+            cnt |= 56u;
+            if (p > in_end + 16) { err = 1; mode = DONE; p = in_beg; }   // ran off the member's input
+        }
     }
-    job.status[m] = err;
+    if (mine) job.status[m] = err;
+}
+
+// CRC32 of every member that inflated cleanly against its gzip trailer: one lane per member, all lanes of a wave
+// in step (four table look-ups per loaded word).
+__global__ __launch_bounds__(256) void gd_inflate_crc_kernel(InflateJob job)
+{
+    __shared__ uint32_t s_crc[256];                        // CRC-32 (IEEE 802.3, reflected) byte table
+    {
+        uint32_t c = threadIdx.x;
+        for (int k = 0; k < 8; ++k) c = (c >> 1) ^ (0xedb88320u & (0u - (c & 1u)));
+        s_crc[threadIdx.x] = c;
+    }
+    __syncthreads();
+    const uint32_t m = blockIdx.x * 256u + threadIdx.x;
+    if (m >= job.n || job.status[m] != 0) return;
+    const uint8_t* const out = job.out + job.out_off[m];
+    const uint32_t olen = job.out_len[m];
+    uint32_t c = 0xffffffffu, k = 0;
+    for (; k + 4 <= olen; k += 4) {
+        uint32_t w;
+        __builtin_memcpy(&w, out + k, 4);
+        c = s_crc[(c ^ w) & 0xffu] ^ (c >> 8);
+        c = s_crc[(c ^ (w >> 8)) & 0xffu] ^ (c >> 8);
+        c = s_crc[(c ^ (w >> 16)) & 0xffu] ^ (c >> 8);
+        c = s_crc[(c ^ (w >> 24)) & 0xffu] ^ (c >> 8);
+    }
+    for (; k < olen; ++k) c = s_crc[(c ^ out[k]) & 0xffu] ^ (c >> 8);
+    if ((c ^ 0xffffffffu) != job.crc[m]) job.status[m] = 18;
+}
+
+// Both kernels on one stream.
+inline void inflate_launch(const InflateJob& job, hipStream_t stream)
+{
+    hipLaunchKernelGGL(gd_inflate_kernel, dim3((job.n + INF_LANES - 1) / INF_LANES), dim3(INF_LANES), 0, stream, job);
+    if (job.crc) hipLaunchKernelGGL(gd_inflate_crc_kernel, dim3((job.n + 255u) / 256u), dim3(256), 0, stream, job);
 }
 
 }  // namespace gd

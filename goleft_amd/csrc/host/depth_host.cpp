@@ -363,8 +363,16 @@ bool parse_devices(std::vector<int>* out, std::string* err)
         }                                                                              \
     } while (0)
 
+// measurement switches of the CLI (README): an integer from the environment, or the default
+int env_int(const char* name, int dflt)
+{
+    const char* e = getenv(name);
+    return e && *e ? atoi(e) : dflt;
+}
+
 int run(const DArgs& args)
 {
+    const auto t_run = std::chrono::steady_clock::now();
     int exit_code = 0;
     std::string err;
     gdh::BamReader bam;
@@ -484,7 +492,7 @@ int run(const DArgs& args)
             return 1;
         }
         GDCHK_ON(sh.ctx, gd_set_params(sh.ctx, &P));
-        GDCHK_ON(sh.ctx, gd_set_option(sh.ctx, GD_OPT_COPY_THREADS, 4));   // staging copies of the device BAM read (8 % on a 3 GB file)
+        GDCHK_ON(sh.ctx, gd_set_option(sh.ctx, GD_OPT_COPY_THREADS, env_int("GOLEFT_COPY_THREADS", 4)));   // staging copies of the device BAM read
         GDCHK_ON(sh.ctx, gd_set_contigs(sh.ctx, (int)lens.size(), lens.data()));
         GDCHK_ON(sh.ctx, gd_set_option(sh.ctx, GD_OPT_BAM_REFS, (int64_t)lens.size()));   // engine contigs = the BAM's references
         if (!need_perbase) GDCHK_ON(sh.ctx, gd_set_outputs(sh.ctx, 0));   // windows + class runs are all the rows need
@@ -539,7 +547,7 @@ int run(const DArgs& args)
             if (gpu_decode) {
                 if (!on_every_shard("the device BAM read", [&](Shard& sh) {
                         return gdh::ingest_references_on_device(sh.ctx, fm, lin, sh.wanted, sh.wanted, &sh.n_gpu_records, &sh.io_ok,
-                                                                512ull << 20, &chunk_end);
+                                                                (uint64_t)env_int("GOLEFT_INGEST_GROUP_MB", 512) << 20, &chunk_end);
                     }))
                     return 1;
                 for (Shard& sh : S.v) {
@@ -720,8 +728,8 @@ int run(const DArgs& args)
     if (fclose(fhd) != 0) io_ok = false;
     if (!io_ok) { fprintf(stderr, "goleft depth: write error\n"); return 1; }
     if (timing)
-        fprintf(stderr, "{\"decode_and_ingest_s\": %.4f, \"compute_s\": %.4f, \"rows_s\": %.4f, \"records\": %llu, \"decoder\": \"%s\"}\n",
-                secs(t_begin, t_ingested), secs(t_ingested, t_computed), secs(t_computed, now()),
+        fprintf(stderr, "{\"setup_s\": %.4f, \"decode_and_ingest_s\": %.4f, \"compute_s\": %.4f, \"rows_s\": %.4f, \"records\": %llu, \"decoder\": \"%s\"}\n",
+                secs(t_run, t_begin), secs(t_begin, t_ingested), secs(t_ingested, t_computed), secs(t_computed, now()),
                 (unsigned long long)(n_gpu_records ? n_gpu_records : bam.n_records()), n_gpu_records ? "device" : "host");
     return exit_code;
 }

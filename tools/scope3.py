@@ -26,6 +26,10 @@ def main():
     ap.add_argument("--paper", action="store_true",
                     help="the one invocation the reference itself times (indexcov/paper/cmp.sh:6): "
                          "`goleft depth --chrom <name> -p 20 -o -w 16384`")
+    ap.add_argument("--variants", default="", help="extra device-decoder runs, each a comma list of ENV=VALUE, separated by ';' "
+                                                   "(e.g. 'GOLEFT_INGEST_GROUP_MB=4096;GOLEFT_COPY_THREADS=16')")
+    ap.add_argument("--no-host", action="store_true", help="skip the host-decoder run")
+    ap.add_argument("--rocprof", default="", help="directory: one more device-decoder run under rocprofv3 --kernel-trace --stats")
     args = ap.parse_args()
     d = tempfile.mkdtemp(prefix="gd_scope3_", dir="/tmp")
     bam = os.path.join(d, "synth.bam")
@@ -43,9 +47,10 @@ def main():
            "bam_MB": info["bam_bytes"] / 1e6, "host_cores": os.cpu_count(), "bam_write_s": t_write}
     beds = {}
     variants = [("device", {}), ("host", {"GOLEFT_GPU_DECODE": "0"})]
-    if os.environ.get("SCOPE3_COPY_SWEEP"):
-        variants = [("device", {}), ("device", {"GOLEFT_GD_COPY_THREADS": "4"}), ("device", {"GOLEFT_GD_COPY_THREADS": "8"}),
-                    ("device", {})]
+    if args.no_host:
+        variants = variants[:1]
+    for v in filter(None, args.variants.split(";")):
+        variants.insert(1, ("device", dict(kv.split("=", 1) for kv in v.split(","))))
     for vi, (decoder, env) in enumerate(variants):
         best = None
         for rep in range(3):                               # the file is in the page cache after the write
@@ -53,22 +58,29 @@ def main():
             p = subprocess.run([os.path.join(ROOT, "goleft_amd", "goleft-depth"), "depth", "-w", str(args.window),
                                 "-p", str(args.threads)] + extra + ["-r", os.path.join(d, "synth.fa"), "--prefix",
                                 os.path.join(d, "out_" + decoder), bam],
-                               env=dict(os.environ, GOLEFT_DEPTH_TIMING="1", **env), stderr=subprocess.PIPE)
+                               env=dict(os.environ, GOLEFT_DEPTH_TIMING="1", GOLEFT_INGEST_TIMING="1", **env), stderr=subprocess.PIPE)
             dt = time.perf_counter() - t0
             assert p.returncode == 0, p.stderr.decode()
-            phases = json.loads(p.stderr.decode().strip().splitlines()[-1])
+            lines = p.stderr.decode().strip().splitlines()
+            phases = json.loads(lines[-1])
             assert phases["decoder"] == decoder, phases
-            if rep == 2 and os.environ.get("GOLEFT_INGEST_TIMING"):
-                sys.stderr.write(p.stderr.decode())
+            for ln in lines[:-1]:                          # GOLEFT_INGEST_TIMING: the device read's own phases
+                if ln.startswith("{"):
+                    phases.update(json.loads(ln))
             if best is None or dt < best[0]:
                 best = (dt, phases)
         dt, phases = best
         stem = os.path.join(d, "out_" + decoder) + ((".%s" % args.name) if args.paper else "")   # depth/depth.go:382-388
         beds[decoder] = open(stem + ".depth.bed").read() + open(stem + ".callable.bed").read()
-        out[decoder + "_decoder" + (("_%d" % vi) if len(variants) > 2 else "")] = {"env": env, "wall_s": dt, "ref_bases_per_s": args.length / dt,
+        out[decoder + "_decoder" + (("_%d" % vi) if vi and decoder == "device" else "")] = {"env": env, "wall_s": dt, "ref_bases_per_s": args.length / dt,
                                      "bam_MB_per_s": info["bam_bytes"] / 1e6 / dt, "phases": phases}
     out["outputs_identical"] = beds["device"] == beds["host"] if "host" in beds else None
     out["depth_rows"] = beds["device"].count("\n")
+    if args.rocprof:
+        subprocess.run(["rocprofv3", "--kernel-trace", "--stats", "-d", args.rocprof, "-o", "scope3", "--output-format", "csv", "--",
+                        os.path.join(ROOT, "goleft_amd", "goleft-depth"), "depth", "-w", str(args.window), "-p", str(args.threads)] + extra +
+                       ["-r", os.path.join(d, "synth.fa"), "--prefix", os.path.join(d, "out_prof"), bam],
+                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, env=dict(os.environ, TMPDIR="/tmp", GOLEFT_SLOW_EXIT="1"))
     print(json.dumps(out))
     for f in os.listdir(d):
         os.unlink(os.path.join(d, f))
