@@ -22,6 +22,8 @@
 #include <thread>
 #include <vector>
 
+#include <unistd.h>
+
 #include "gd_api_state.hpp"
 
 extern "C" {
@@ -242,7 +244,7 @@ namespace {
 struct FillPool {
     // kind 0: plain copy; 1: int32 positions, copied and checked (non-decreasing from `prev`, not negative);
     // 2: 32-bit CSR offsets, rebased by -sub and checked (non-decreasing); 3 / 4: the checks of 1 / 2 alone (gd_commit:
-    // the caller filled the block itself)
+    // the caller filled the block itself); 5: `bytes` from offset `src` of the file descriptor `sub` (gd_ingest_feed_fd)
     struct Item { void* dst; const void* src; size_t bytes; uint32_t sub; int kind; int32_t prev; };
     std::atomic<uint32_t> bad{0};
     std::vector<std::thread> th;
@@ -255,6 +257,16 @@ struct FillPool {
     void run_item(const Item& it)
     {
         if (it.kind == 0) { memcpy(it.dst, it.src, it.bytes); return; }
+        if (it.kind == 5) {
+            size_t got = 0;
+            while (got < it.bytes) {
+                const ssize_t r = pread((int)it.sub, static_cast<char*>(it.dst) + got, it.bytes - got,
+                                        (off_t)(reinterpret_cast<uintptr_t>(it.src) + got));
+                if (r <= 0) { bad.store(1); return; }
+                got += (size_t)r;
+            }
+            return;
+        }
         const size_t n = it.bytes / 4;
         uint32_t wrong = 0;
         if (it.kind == 3) {

@@ -873,7 +873,7 @@ struct IngestState {
     // One lane inflates one member start to end (~0.1 s whatever the member count), so the members are
     // handed to the kernel in at most kBatches launches, each on its own stream: they overlap each other
     // and the upload of the bytes still to come.
-    static constexpr int kBatches = 4;
+    static constexpr int kBatches = 8;
     int n_launch = 0;
     std::vector<hipEvent_t> inf_done;                   // one per inflate launch of THIS range
     bool inflated = false;                              // every member inflated and its status checked

@@ -24,8 +24,8 @@
 //     read what the previous chunk wrote (any distance >= 16); distances below 16 take their first chunk
 //     from T with two byte permutes (selectors from a table shared by the workgroup) and continue at
 //     the next multiple of the distance that is >= 16;
-//   * lanes with nothing to store write T over the 16 bytes it mirrors (or to a dump line while the
-//     member is shorter than that), lanes with nothing to load read their member's first bytes.
+//   * lanes with nothing to store write to a dump slot of their workgroup, lanes with nothing to load read
+//     their member's first bytes.
 // Huffman decoding is canonical and branch free: the 15-bit peek is compared with the left-aligned end
 // of every code length (15 compares against packed registers) and the symbol index is one add and two
 // LDS reads ([entry][lane] tables: 408 bytes per lane, six workgroups per CU).  Block headers (dynamic
@@ -44,12 +44,12 @@ struct InflateJob {
     const uint32_t* crc;           // [n] CRC32 of the member's data (gzip trailer), or nullptr: not checked
     uint8_t* out;                  // (readable up to 64 bytes past the last member)
     uint32_t* status;              // [n] 0 ok, else an error code (18: CRC32 mismatch)
-    uint8_t* dump;                 // 1 KiB nobody reads: where idle lanes put their store
+    uint8_t* dump;                 // INF_DUMP bytes nobody reads: where idle lanes put their store
     uint32_t n;
 };
 
 constexpr size_t INF_SLACK = 256;  // bytes the inflate buffers are allocated beyond their contents
-constexpr size_t INF_DUMP = 1024;
+constexpr size_t INF_DUMP = 1024 * 1024;   // 1024 workgroup slots of 64 lanes x 16 bytes
 
 constexpr int INF_LANES = 64;      // lanes (= members in flight) per workgroup
 constexpr int INF_MAXL = 288, INF_MAXD = 30;
@@ -153,6 +153,14 @@ __device__ __forceinline__ inf_v4 inf_load16(const uint8_t* p)
     __builtin_memcpy(&v, p, 16);
     return v;
 }
+// a match source is read once: it should not push the output lines that are still being filled out of L2
+__device__ __forceinline__ inf_v4 inf_load16_stream(const uint8_t* p)
+{
+    uint32_t w[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) w[k] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(p + 4 * k));
+    return inf_v4{w[0], w[1], w[2], w[3]};
+}
 __device__ __forceinline__ void inf_store16(uint8_t* p, inf_v4 v) { __builtin_memcpy(p, &v, 16); }
 __device__ __forceinline__ uint64_t inf_load8(const uint8_t* p)
 {
@@ -201,7 +209,6 @@ __global__ __launch_bounds__(INF_LANES) void gd_inflate_kernel(InflateJob job)
     const uint8_t* const in_end = in_beg + job.in_len[mm];
     uint8_t* const out = job.out + job.out_off[mm];
     const uint32_t olen = job.out_len[mm];
-    uint8_t* const dump = job.dump + lane * 16;
 
     enum : uint32_t { DECODE = 0, COPY = 1, HDR = 2, DONE = 3 };
     uint32_t mode = mine ? HDR : DONE;
@@ -327,7 +334,8 @@ __global__ __launch_bounds__(INF_LANES) void gd_inflate_kernel(InflateJob job)
 
         // ---- (1) the iteration's two loads: the chunk of a match in progress, the input word of the refill at the
         //      end of the iteration (its address does not depend on what the decode consumes) ----
-        const inf_v4 cl = inf_load16(ld_addr);
+        inf_v4 cl = {0, 0, 0, 0};
+        if (cpend && !csmall) cl = inf_load16_stream(ld_addr);
         const uint64_t nw = inf_load8(p);
 
         // ---- (2) decode one symbol: everything a match needs, for every lane (no branches) ----
@@ -393,28 +401,32 @@ __global__ __launch_bounds__(INF_LANES) void gd_inflate_kernel(InflateJob job)
             }
             if (mode == DONE) p = in_beg;
         }
-        // the iteration's one store: the chunk; or T over the 16 bytes it mirrors -- that writes the literals
-        // gathered in T when they are due (`flush`), a chunk that may not run past the member's end, and is a
-        // harmless rewrite otherwise
-        uint8_t* st_addr = dump;
-        inf_v4 st_data = T;
+        // ---- (6) refill from the word loaded at the top (before the store: nothing else is in flight then) ----
+        if (mode != DONE) {
+            buf |= nw << cnt;
+            p += (63u - cnt) >> 3;
+            cnt |= 56u;
+            if (p > in_end + 16) { err = 1; mode = DONE; p = in_beg; }   // ran off the member's input
+        }
+
+        // the iteration's one store: the chunk; or T over the 16 bytes it mirrors when the literals gathered in it are
+        // due (`flush`) or the chunk may not run past the member's end
         if (cp && co + 16u <= olen) {
-            st_addr = out + co;
-            st_data = c;
-        } else if (o >= 16u) {
-            st_addr = out + (o - 16u);
-        } else if (flush || cp) {                          // the member's first bytes: T holds them right-aligned
-            const uint32_t w[4] = {T.x, T.y, T.z, T.w};
-            for (uint32_t k = 0; k < o; ++k) {
-                const uint32_t b = 16u - o + k;
-                out[k] = (uint8_t)(w[b >> 2] >> (8 * (b & 3)));
+            inf_store16(out + co, c);
+        } else if (flush || cp) {
+            if (o >= 16u) {
+                inf_store16(out + (o - 16u), T);
+            } else {                                       // the member's first bytes: T holds them right-aligned
+                const uint32_t w[4] = {T.x, T.y, T.z, T.w};
+                for (uint32_t k = 0; k < o; ++k) {
+                    const uint32_t b = 16u - o + k;
+                    out[k] = (uint8_t)(w[b >> 2] >> (8 * (b & 3)));
+                }
             }
         }
         if (flush) pend = 0;
-        inf_store16(st_addr, st_data);
 
         // ---- (5) a match in progress: its next chunk, loaded (next iteration) after the store above ----
-        ld_addr = out;
         csmall = false;
         if (mode == COPY) {
             const uint32_t n = rem < 16u ? rem : 16u;
@@ -441,13 +453,6 @@ __global__ __launch_bounds__(INF_LANES) void gd_inflate_kernel(InflateJob job)
             if (rem == 0u) mode = DECODE;
         }
 
-        // ---- (6) refill from the word loaded at the top ----
-        if (mode != DONE) {
-            buf |= nw << cnt;
-            p += (63u - cnt) >> 3;
-            cnt |= 56u;
-            if (p > in_end + 16) { err = 1; mode = DONE; p = in_beg; }   // ran off the member's input
-        }
     }
     if (mine) job.status[m] = err;
 }

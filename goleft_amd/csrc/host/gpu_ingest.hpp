@@ -15,6 +15,8 @@
 #include <cstdlib>
 #include <algorithm>
 #include <string>
+#include <condition_variable>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -26,19 +28,23 @@ namespace gdh {
 struct FileMap {
     const uint8_t* p = nullptr;
     size_t size = 0;
+    int fd = -1;                                           // stays open: the bulk of the bytes is read with pread (gd_ingest_feed_fd)
     FileMap() = default;
     FileMap(const FileMap&) = delete;
     FileMap& operator=(const FileMap&) = delete;
-    ~FileMap() { if (p) munmap(const_cast<uint8_t*>(p), size); }
+    ~FileMap()
+    {
+        if (p) munmap(const_cast<uint8_t*>(p), size);
+        if (fd >= 0) ::close(fd);
+    }
     bool open(const std::string& path)
     {
-        const int fd = ::open(path.c_str(), O_RDONLY);
+        fd = ::open(path.c_str(), O_RDONLY);
         if (fd < 0) return false;
         struct stat st;
-        if (fstat(fd, &st) != 0 || st.st_size <= 0) { ::close(fd); return false; }
+        if (fstat(fd, &st) != 0 || st.st_size <= 0) { ::close(fd); fd = -1; return false; }
         void* m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
-        ::close(fd);
-        if (m == MAP_FAILED) return false;
+        if (m == MAP_FAILED) { ::close(fd); fd = -1; return false; }
         (void)madvise(m, (size_t)st.st_size, MADV_SEQUENTIAL);
         p = static_cast<const uint8_t*>(m);
         size = (size_t)st.st_size;
@@ -107,6 +113,7 @@ struct MemberTable {
     std::vector<uint32_t> size, isize, crc;
     std::vector<uint16_t> hdr;
     size_t n = 0;
+    void swap_into(MemberTable* o) { off.swap(o->off); size.swap(o->size); isize.swap(o->isize); crc.swap(o->crc); hdr.swap(o->hdr); std::swap(n, o->n); }
 };
 
 inline bool list_members_serial(const uint8_t* base, size_t nb, MemberTable* t, size_t guess)
@@ -216,23 +223,59 @@ inline int ingest_references_on_device(gd_ctx* ctx, const FileMap& fm, const std
     };
     // GOLEFT_INGEST_TIMING=1: where a pass spends its wall clock (stderr; measurement only)
     const bool timing = getenv("GOLEFT_INGEST_TIMING") != nullptr;
+    const bool from_mapping = getenv("GOLEFT_INGEST_MMAP") != nullptr;   // (measurement: the bytes through the mapping instead of pread)
     auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double t_list = 0, t_begin = 0, t_feed = 0, t_decode = 0;
+    // The member tables are listed one pass ahead on a thread of their own (headers and trailers only, read from the
+    // mapping): pass k + 1 is listed while pass k is fed.
+    struct Listed { MemberTable mt; bool ok = false; double secs = 0; };
+    std::vector<Listed> listed(passes.size());
+    std::mutex mu;
+    std::condition_variable cv;
+    size_t n_listed = 0, n_taken = 0;                      // the lister stays at most two passes ahead
+    bool stop = false;
+    std::thread lister([&]() {
+        for (size_t k = 0; k < passes.size(); ++k) {
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return stop || k < n_taken + 2; });
+                if (stop) return;
+            }
+            const IngestPass& ps = passes[k];
+            const double t0 = now();
+            if (ps.beg < ps.end) {
+                std::vector<uint64_t> member_starts;       // what the .bai knows about where members begin
+                for (size_t r = ps.first; r <= ps.last; ++r)
+                    for (uint64_t v : lin[(size_t)refs[r]]) member_starts.push_back(v >> 16);
+                listed[k].ok = list_members(fm.p + ps.beg, (size_t)(ps.end - ps.beg), ps.beg, member_starts, &listed[k].mt) &&
+                               listed[k].mt.n != 0;
+            }
+            listed[k].secs = now() - t0;
+            { std::lock_guard<std::mutex> lk(mu); n_listed = k + 1; }
+            cv.notify_all();
+        }
+    });
+    struct Joiner {
+        std::thread& t; std::mutex& mu; std::condition_variable& cv; bool& stop;
+        ~Joiner() { { std::lock_guard<std::mutex> lk(mu); stop = true; } cv.notify_all(); if (t.joinable()) t.join(); }
+    } joiner{lister, mu, cv, stop};
     bool pending = false;                                  // a fed pass waits for its decode
     size_t pa = 0, pb = 0;
-    for (const IngestPass& ps : passes) {
+    for (size_t pk = 0; pk < passes.size(); ++pk) {
+        const IngestPass& ps = passes[pk];
         const size_t i = ps.first, j = ps.last;
         const uint64_t beg = ps.beg, end = ps.end;
         auto bad_file = [&]() { (void)gd_ingest_abort(ctx); *io_ok = false; *n_records = 0; return GD_OK; };
         if (beg >= end) return bad_file();
-        const uint8_t* base = fm.p + beg;
-        const size_t nb = (size_t)(end - beg);
         const double t0 = now();
-        std::vector<uint64_t> member_starts;                   // what the .bai knows about where members begin
-        for (size_t k = i; k <= j; ++k)
-            for (uint64_t v : lin[(size_t)refs[k]]) member_starts.push_back(v >> 16);
-        MemberTable mt;
-        if (!list_members(base, nb, beg, member_starts, &mt) || mt.n == 0) return bad_file();
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return n_listed > pk; });
+            n_taken = pk + 1;
+        }
+        cv.notify_all();
+        if (!listed[pk].ok) return bad_file();
+        MemberTable& mt = listed[pk].mt;
         const size_t nm = mt.n;
         std::vector<uint64_t>& moff = mt.off;
         std::vector<uint32_t>&msize = mt.size, &misize = mt.isize, &mcrc = mt.crc;
@@ -243,11 +286,15 @@ inline int ingest_references_on_device(gd_ctx* ctx, const FileMap& fm, const std
         rc = gd_ingest_begin(ctx, used, beg, nm, moff.data(), msize.data(), mhdr.data(), misize.data(), mcrc.data());
         if (rc != GD_OK) { (void)gd_ingest_abort(ctx); return rc; }
         const double t2 = now();
-        const size_t piece = 32u << 20;
-        for (size_t off = 0; off < used; off += piece) {
-            rc = gd_ingest_feed(ctx, base + off, used - off < piece ? used - off : piece);
-            if (rc != GD_OK) { (void)gd_ingest_abort(ctx); return rc; }
+        if (!from_mapping) {
+            rc = gd_ingest_feed_fd(ctx, fm.fd, beg, used); // pread on the context's workers, straight into the staging buffers
+        } else {
+            const size_t piece = 32u << 20;
+            for (size_t off = 0; off < used && rc == GD_OK; off += piece)
+                rc = gd_ingest_feed(ctx, fm.p + beg + off, used - off < piece ? used - off : piece);
         }
+        if (rc != GD_OK) { (void)gd_ingest_abort(ctx); return rc; }
+        MemberTable().swap_into(&mt);                      // (the table is on the device now)
         const double t3 = now();
         // this pass is on its way (upload + inflate are asynchronous): now decode the one before it
         if (pending) {
@@ -259,6 +306,11 @@ inline int ingest_references_on_device(gd_ctx* ctx, const FileMap& fm, const std
     }
     int rc_last = GD_OK;
     if (pending) { const double t = now(); rc_last = decode_pass(pa, pb); t_decode += now() - t; }
+    if (timing) {
+        double t_listing = 0;
+        for (const Listed& l : listed) t_listing += l.secs;
+        fprintf(stderr, "{\"listing_thread_s\": %.4f}\n", t_listing);
+    }
     if (timing)
         fprintf(stderr, "{\"ingest_list_members_s\": %.4f, \"begin_s\": %.4f, \"feed_s\": %.4f, \"decode_s\": %.4f}\n",
                 t_list, t_begin, t_feed, t_decode);

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define GD_ABI_VERSION 10
+#define GD_ABI_VERSION 11
 
 typedef enum {
     GD_OK = 0,
@@ -471,6 +471,10 @@ int gd_ingest_begin(gd_ctx* ctx, uint64_t n_bytes, uint64_t base_coffset, size_t
                     const uint64_t* member_off, const uint32_t* member_size, const uint16_t* header_size,
                     const uint32_t* isize, const uint32_t* crc);
 int gd_ingest_feed(gd_ctx* ctx, const uint8_t* bytes, size_t n);
+/* gd_ingest_feed with the bytes taken from an open file: n bytes from `offset` of `fd` are read (pread on the
+ * context's worker threads, GD_OPT_PUSH_THREADS of them) straight into the page-locked staging buffers -- none
+ * of the page faults of a mapping, no second copy.  GD_E_INVALID: the file ended early or could not be read. */
+int gd_ingest_feed_fd(gd_ctx* ctx, int fd, uint64_t offset, size_t n);
 int gd_ingest_finish(gd_ctx* ctx, int32_t tid, int32_t ref_id, const uint64_t* anchors, size_t n_anchors,
                      uint64_t* n_records);
 int gd_ingest_decode(gd_ctx* ctx, int32_t tid, int32_t ref_id, const uint64_t* anchors, size_t n_anchors,

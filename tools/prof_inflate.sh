@@ -5,9 +5,10 @@ out=$R/gpurun_out/prof_inflate
 mkdir -p $out
 i=1
 for pmc in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS" \
-           "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE"; do
+           "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE" \
+           "FETCH_SIZE" "WRITE_SIZE"; do
   rocprofv3 --kernel-trace --pmc $pmc --output-format csv -d $out/pmc$i -- python $R/tools/inflate_bench.py 63025520 > $out/pmc$i.log 2>&1
   i=$((i+1))
 done
-python $R/tools/pmc_summary.py $out 2>&1 | grep -A 18 "gd_inflate"
+python $R/tools/pmc_summary.py $out 2>&1 | grep -A 20 "gd_inflate_kernel"
 rm -rf $out
