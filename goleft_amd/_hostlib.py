@@ -46,6 +46,8 @@ SYMBOLS = {
     "gdh_intervals_count": (C.c_size_t, [_P, C.c_char_p]),
     "gdh_list_members": (C.c_int64, [_P, C.c_size_t, C.c_uint64, _P, C.c_size_t, C.c_uint, C.c_size_t, C.c_size_t,
                                      _P, _P, _P, _P, _P]),
+    "gdh_list_members_fd": (C.c_int64, [C.c_int, C.c_uint64, C.c_size_t, _P, C.c_size_t, C.c_uint, C.c_size_t, C.c_size_t,
+                                        _P, _P, _P, _P, _P]),
     "gdh_samtools_main": (C.c_int, [C.c_int, C.POINTER(C.c_char_p)]),
     "gdh_produce_in_place": (C.c_int, [_P, C.c_int32, _P, _P, _P, _P, _P, C.c_size_t, C.c_size_t, C.c_int, C.c_size_t]),
     "gdh_set_fast_exit": (C.c_int, [C.c_int]),
@@ -236,6 +238,25 @@ def list_members(data: bytes, beg: int, member_starts, threads: int = 16, min_by
     isize = np.zeros(n, np.uint32); crc = np.zeros(n, np.uint32)
     load().gdh_list_members(*args, n, off.ctypes.data, size.ctypes.data, hdr.ctypes.data, isize.ctypes.data, crc.ctypes.data)
     return off, size, hdr, isize, crc
+
+
+def list_members_fd(path: str, beg: int, n_bytes: int, member_starts, threads: int = 16, min_bytes: int = 64 << 20):
+    """gdh_list_members_fd: the same table, the n_bytes from offset `beg` of the file read with pread."""
+    import os
+    import numpy as np
+    st = np.ascontiguousarray(member_starts, np.uint64)
+    fd = os.open(path, os.O_RDONLY)
+    try:
+        args = (fd, int(beg), int(n_bytes), st.ctypes.data if st.size else None, st.size, int(threads), int(min_bytes))
+        n = load().gdh_list_members_fd(*args, 0, None, None, None, None, None)
+        if n < 0:
+            raise ValueError("not a BGZF range")
+        off = np.zeros(n, np.uint64); size = np.zeros(n, np.uint32); hdr = np.zeros(n, np.uint16)
+        isize = np.zeros(n, np.uint32); crc = np.zeros(n, np.uint32)
+        load().gdh_list_members_fd(*args, n, off.ctypes.data, size.ctypes.data, hdr.ctypes.data, isize.ctypes.data, crc.ctypes.data)
+        return off, size, hdr, isize, crc
+    finally:
+        os.close(fd)
 
 
 def plan_ingest_passes(start, has, wanted, file_size, group_bytes):

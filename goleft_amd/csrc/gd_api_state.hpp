@@ -5,6 +5,7 @@
 #pragma once
 
 #include <memory>
+#include <thread>
 
 namespace {
 
@@ -185,6 +186,8 @@ struct gd_ctx {
     // one range overlaps the upload of the next.
     IngestState* ing_q[2] = {nullptr, nullptr};
     int ing_n = 0;
+    std::thread ing_feeder;                             // gd_ingest_feed_fd: the read of the newest range in progress
+    int ing_feeder_rc = 0;
     bool ing_stage_used[2] = {false, false};
     int ing_cur = 0;
     IngestBufs ing_bufs[2];

@@ -526,7 +526,7 @@ int run(const DArgs& args)
     };
     const auto t_begin = now();
     uint64_t n_gpu_records = 0;
-    auto t_ingested = t_begin, t_computed = t_begin, t_indexed = t_begin;
+    auto t_ingested = t_begin, t_computed = t_begin, t_indexed = t_begin, t_mapped = t_begin, t_read = t_begin;
     // ---- records into HBM (replaces the samtools children) ---------------------------
     // With a .bai next to the BAM (goleft depth needs one anyway: `samtools depth -r`), the whole
     // read happens on the device: the contig's byte range goes to gd_ingest_bgzf, which inflates
@@ -547,6 +547,8 @@ int run(const DArgs& args)
         if (gpu_decode) {
             gdh::FileMap fm;
             if (!fm.open(args.bam)) gpu_decode = false;
+            fm.keep = gdh_get_fast_exit() != 0;
+            t_mapped = now();
             if (gpu_decode) {
                 if (!on_every_shard("the device BAM read", [&](Shard& sh) {
                         return gdh::ingest_references_on_device(sh.ctx, fm, lin, sh.wanted, sh.wanted, &sh.n_gpu_records, &sh.io_ok,
@@ -558,6 +560,7 @@ int run(const DArgs& args)
                     n_gpu_records += sh.n_gpu_records;
                 }
                 if (!gpu_decode) n_gpu_records = 0;
+                t_read = now();
             }
             if (!gpu_decode)
                 for (Shard& sh : S.v) GDCHK_ON(sh.ctx, gd_reset(sh.ctx));   // fall back to the host decoder below
@@ -791,8 +794,8 @@ int run(const DArgs& args)
     if (fclose(fhd) != 0) io_ok = false;
     if (!io_ok) { fprintf(stderr, "goleft depth: write error\n"); return 1; }
     if (timing)
-        fprintf(stderr, "{\"setup_s\": %.4f, \"index_s\": %.4f, \"decode_and_ingest_s\": %.4f, \"compute_s\": %.4f, \"rows_s\": %.4f, \"records\": %llu, \"decoder\": \"%s\"}\n",
-                secs(t_run, t_begin), secs(t_begin, t_indexed), secs(t_begin, t_ingested), secs(t_ingested, t_computed), secs(t_computed, now()),
+        fprintf(stderr, "{\"setup_s\": %.4f, \"index_s\": %.4f, \"map_s\": %.4f, \"read_s\": %.4f, \"decode_and_ingest_s\": %.4f, \"compute_s\": %.4f, \"rows_s\": %.4f, \"records\": %llu, \"decoder\": \"%s\"}\n",
+                secs(t_run, t_begin), secs(t_begin, t_indexed), secs(t_indexed, t_mapped), secs(t_mapped, t_read), secs(t_begin, t_ingested), secs(t_ingested, t_computed), secs(t_computed, now()),
                 (unsigned long long)(n_gpu_records ? n_gpu_records : bam.n_records()), n_gpu_records ? "device" : "host");
     return exit_code;
 }

@@ -13,6 +13,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <algorithm>
 #include <string>
 #include <condition_variable>
@@ -32,8 +33,10 @@ struct FileMap {
     FileMap() = default;
     FileMap(const FileMap&) = delete;
     FileMap& operator=(const FileMap&) = delete;
+    bool keep = false;                                     // a process about to exit leaves the unmapping (0.15 s for a touched 7 GB mapping) to the kernel
     ~FileMap()
     {
+        if (keep) return;
         if (p) munmap(const_cast<uint8_t*>(p), size);
         if (fd >= 0) ::close(fd);
     }
@@ -134,9 +137,71 @@ inline bool list_members_serial(const uint8_t* base, size_t nb, MemberTable* t, 
     return false;
 }
 
-inline bool list_members(const uint8_t* base, size_t nb, uint64_t beg, const std::vector<uint64_t>& member_starts,
-                         MemberTable* out, unsigned max_threads = 16, size_t kMin = 64u << 20)
+// The same walk with pread: one read per member -- its trailer and the header that follows -- instead of one
+// mapped page per member (a 7 GB file: 460 k pages faulted in, and 0.15 s to unmap them again at exit).
+inline bool list_members_serial_fd(int fd, uint64_t file_beg, size_t nb, MemberTable* t)
 {
+    auto rd = [&](uint64_t off, uint8_t* dst, size_t n) {
+        size_t got = 0;
+        while (got < n) {
+            const ssize_t r = pread(fd, dst + got, n - got, (off_t)(off + got));
+            if (r <= 0) return false;
+            got += (size_t)r;
+        }
+        return true;
+    };
+    const size_t guess = nb / 12000 + 64;
+    t->off.clear(); t->size.clear(); t->isize.clear(); t->crc.clear(); t->hdr.clear();
+    t->off.reserve(guess); t->size.reserve(guess); t->isize.reserve(guess); t->crc.reserve(guess); t->hdr.reserve(guess);
+    constexpr size_t kHead = 96;
+    uint8_t hdr[kHead], tl[8 + kHead];
+    std::vector<uint8_t> big;
+    size_t p = 0, have = 0;
+    while (p + 18 <= nb) {
+        if (have < 18) {
+            have = std::min(kHead, nb - p);
+            if (!rd(file_beg + p, hdr, have)) return false;
+        }
+        const uint8_t* h = hdr;
+        if (h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4)) return false;
+        const size_t xlen = (size_t)h[10] | ((size_t)h[11] << 8);
+        if (p + 12 + xlen > nb) break;
+        if (12 + xlen > have) {                             // an unusually long extra field
+            big.resize(12 + xlen);
+            if (!rd(file_beg + p, big.data(), big.size())) return false;
+            h = big.data();
+        }
+        size_t q = 12, bsize = 0;
+        while (q + 4 <= 12 + xlen) {
+            const size_t slen = (size_t)h[q + 2] | ((size_t)h[q + 3] << 8);
+            if (h[q] == 66 && h[q + 1] == 67 && slen == 2 && q + 6 <= 12 + xlen)
+                bsize = ((size_t)h[q + 4] | ((size_t)h[q + 5] << 8)) + 1;
+            q += 4 + slen;
+        }
+        if (bsize < 12 + xlen + 8) return false;
+        if (p + bsize > nb) break;                          // a trailing partial member is ignored
+        const size_t next = std::min(kHead, nb - (p + bsize));
+        if (!rd(file_beg + p + bsize - 8, tl, 8 + next)) return false;
+        t->off.push_back(p);
+        t->size.push_back((uint32_t)bsize);
+        t->hdr.push_back((uint16_t)(12 + xlen));
+        t->crc.push_back((uint32_t)tl[0] | ((uint32_t)tl[1] << 8) | ((uint32_t)tl[2] << 16) | ((uint32_t)tl[3] << 24));
+        t->isize.push_back((uint32_t)tl[4] | ((uint32_t)tl[5] << 8) | ((uint32_t)tl[6] << 16) | ((uint32_t)tl[7] << 24));
+        p += bsize;
+        have = next;
+        memcpy(hdr, tl + 8, next);
+    }
+    t->n = t->off.size();
+    return true;
+}
+
+inline bool list_members(const uint8_t* base, size_t nb, uint64_t beg, const std::vector<uint64_t>& member_starts,
+                         MemberTable* out, unsigned max_threads = 16, size_t kMin = 64u << 20, int fd = -1)
+{
+    // fd >= 0: `base` is not dereferenced, the bytes come from offset beg of the file
+    auto serial = [&](uint64_t b, size_t n, MemberTable* t) {
+        return fd >= 0 ? list_members_serial_fd(fd, beg + b, n, t) : list_members_serial(base + b, n, t, n / 12000 + 64);
+    };
     // (ranges under kMin bytes: not worth the threads)
     std::vector<uint64_t> cuts;                              // range-relative member starts, strictly inside the range
     if (nb >= kMin && max_threads > 1) {
@@ -153,7 +218,7 @@ inline bool list_members(const uint8_t* base, size_t nb, uint64_t beg, const std
             if (cuts.empty() || *it > cuts.back()) cuts.push_back(*it);
         }
     }
-    if (cuts.empty()) return list_members_serial(base, nb, out, nb / 12000 + 64);
+    if (cuts.empty()) return serial(0, nb, out);
     std::vector<uint64_t> seg_beg{0};
     seg_beg.insert(seg_beg.end(), cuts.begin(), cuts.end());
     const size_t ns = seg_beg.size();
@@ -163,7 +228,7 @@ inline bool list_members(const uint8_t* base, size_t nb, uint64_t beg, const std
     for (size_t k = 0; k < ns; ++k)
         th.emplace_back([&, k]() {
             const uint64_t b = seg_beg[k], e = k + 1 < ns ? seg_beg[k + 1] : (uint64_t)nb;
-            ok[k] = list_members_serial(base + b, (size_t)(e - b), &part[k], (size_t)((e - b) / 12000 + 64));
+            ok[k] = serial(b, (size_t)(e - b), &part[k]);
             if (ok[k] && k + 1 < ns) {                         // an inner piece must be tiled exactly by its members
                 const MemberTable& p = part[k];
                 ok[k] = p.n != 0 && p.off[p.n - 1] + p.size[p.n - 1] == e - b;
@@ -171,7 +236,7 @@ inline bool list_members(const uint8_t* base, size_t nb, uint64_t beg, const std
         });
     for (auto& t : th) t.join();
     for (size_t k = 0; k < ns; ++k)
-        if (!ok[k]) return list_members_serial(base, nb, out, nb / 12000 + 64);   // the index lied: walk the chain
+        if (!ok[k]) return serial(0, nb, out);              // the index lied: walk the chain
     size_t total = 0;
     for (const MemberTable& p : part) total += p.n;
     out->off.resize(total); out->size.resize(total); out->isize.resize(total); out->crc.resize(total); out->hdr.resize(total);
@@ -204,6 +269,7 @@ inline int ingest_references_on_device(gd_ctx* ctx, const FileMap& fm, const std
 {
     *io_ok = true;
     *n_records = 0;
+    const double t_enter = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
     std::vector<uint64_t> start(lin.size(), 0);
     std::vector<char> has(lin.size(), 0);
     for (size_t r = 0; r < lin.size(); ++r)
@@ -247,7 +313,8 @@ inline int ingest_references_on_device(gd_ctx* ctx, const FileMap& fm, const std
                 std::vector<uint64_t> member_starts;       // what the .bai knows about where members begin
                 for (size_t r = ps.first; r <= ps.last; ++r)
                     for (uint64_t v : lin[(size_t)refs[r]]) member_starts.push_back(v >> 16);
-                listed[k].ok = list_members(fm.p + ps.beg, (size_t)(ps.end - ps.beg), ps.beg, member_starts, &listed[k].mt) &&
+                listed[k].ok = list_members(fm.p + ps.beg, (size_t)(ps.end - ps.beg), ps.beg, member_starts, &listed[k].mt, 16,
+                                            64u << 20, from_mapping ? -1 : fm.fd) &&
                                listed[k].mt.n != 0;
             }
             listed[k].secs = now() - t0;
@@ -309,7 +376,7 @@ inline int ingest_references_on_device(gd_ctx* ctx, const FileMap& fm, const std
     if (timing) {
         double t_listing = 0;
         for (const Listed& l : listed) t_listing += l.secs;
-        fprintf(stderr, "{\"listing_thread_s\": %.4f}\n", t_listing);
+        fprintf(stderr, "{\"listing_thread_s\": %.4f, \"ingest_call_s\": %.4f}\n", t_listing, now() - t_enter);
     }
     if (timing)
         fprintf(stderr, "{\"ingest_list_members_s\": %.4f, \"begin_s\": %.4f, \"feed_s\": %.4f, \"decode_s\": %.4f}\n",

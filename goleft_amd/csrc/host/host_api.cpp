@@ -164,6 +164,24 @@ int64_t gdh_list_members(const uint8_t* data, size_t n_bytes, uint64_t beg, cons
     return (int64_t)t.n;
 }
 
+int64_t gdh_list_members_fd(int fd, uint64_t beg, size_t n_bytes, const uint64_t* member_starts, size_t n_starts,
+                            unsigned threads, size_t min_bytes, size_t cap, uint64_t* off, uint32_t* size, uint16_t* hdr,
+                            uint32_t* isize, uint32_t* crc)
+{
+    if (fd < 0 || (n_starts && !member_starts)) return -1;
+    gdh::MemberTable t;
+    const std::vector<uint64_t> st(member_starts, member_starts + n_starts);
+    if (!gdh::list_members(nullptr, n_bytes, beg, st, &t, threads, min_bytes, fd)) return -1;
+    for (size_t k = 0; k < t.n && k < cap; ++k) {
+        if (off) off[k] = t.off[k];
+        if (size) size[k] = t.size[k];
+        if (hdr) hdr[k] = t.hdr[k];
+        if (isize) isize[k] = t.isize[k];
+        if (crc) crc[k] = t.crc[k];
+    }
+    return (int64_t)t.n;
+}
+
 size_t gdh_plan_ingest_passes(const uint64_t* start, const uint8_t* has, size_t n_refs, const int32_t* wanted,
                               size_t n_wanted, uint64_t file_size, uint64_t group_bytes, size_t cap,
                               uint64_t* first, uint64_t* last, uint64_t* beg, uint64_t* end)

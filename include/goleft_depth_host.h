@@ -68,6 +68,12 @@ int gdh_format_region(const char* chrom, int64_t region_start, int64_t region_en
 int64_t gdh_list_members(const uint8_t* data, size_t n_bytes, uint64_t beg, const uint64_t* member_starts, size_t n_starts,
                          unsigned threads, size_t min_bytes, size_t cap, uint64_t* off, uint32_t* size, uint16_t* hdr,
                          uint32_t* isize, uint32_t* crc);
+/* The same table read from an open file with pread (one read per member: its trailer and the header that follows)
+ * instead of from memory: the n_bytes from offset `beg` of fd.  This is what goleft-depth uses -- a mapped file costs
+ * a page fault per member and as much again to unmap. */
+int64_t gdh_list_members_fd(int fd, uint64_t beg, size_t n_bytes, const uint64_t* member_starts, size_t n_starts,
+                            unsigned threads, size_t min_bytes, size_t cap, uint64_t* off, uint32_t* size, uint16_t* hdr,
+                            uint32_t* isize, uint32_t* crc);
 
 /* ---- the contract of the `--stats` columns ------------------------------------------------------------
  * depth/depth.go:191-200 prints "%.3g" of faidx.Stats(chrom, start, end).GC / .CpG / .Masked.  faidx is an

@@ -377,6 +377,13 @@ def test_parallel_member_listing_equals_the_serial_walk(tmp_path):
         got = hl.list_members(data, 1000, list(starts) + extra, threads=th, min_bytes=1)
         for a, b in zip(got, ser):
             assert np.array_equal(a, b), (th, extra)
+    # the same table read with pread (what goleft-depth does): a range inside a larger file
+    padded = str(tmp_path / "padded.bin")
+    open(padded, "wb").write(b"\0" * 1000 + data + b"tail")
+    for th in (1, 16):
+        got = hl.list_members_fd(padded, 1000, len(data), list(starts), threads=th, min_bytes=1)
+        for a, b in zip(got, ser):
+            assert np.array_equal(a, b), th
     # a range that stops in the middle of a member: the partial one is not listed
     cut = int(ser[0][n // 2]) + 7
     got = hl.list_members(data[:cut], 0, list(ser[0][2::3]), threads=8, min_bytes=1)
@@ -404,6 +411,15 @@ def test_member_listing_on_damaged_ranges_agrees_with_the_serial_walk(tmp_path):
         except ValueError:
             return None
 
+    scratch = str(tmp_path / "damaged.bin")
+
+    def listing_fd(data, starts, threads):
+        open(scratch, "wb").write(data + b"\x1f\x8b\x08\x04 bytes past the range that must not be read as part of it")
+        try:
+            return hl.list_members_fd(scratch, 0, len(data), starts, threads=threads, min_bytes=1)
+        except ValueError:
+            return None
+
     for case in range(150):
         data = bytearray(good)
         for _ in range(int(rng.integers(0, 6))):
@@ -417,9 +433,11 @@ def test_member_listing_on_damaged_ranges_agrees_with_the_serial_walk(tmp_path):
         want = listing(data, [], 1)
         got = listing(data, sorted(true_starts + bogus), int(rng.integers(2, 17)))
         assert (want is None) == (got is None), case
+        got_fd = listing_fd(data, sorted(true_starts + bogus), int(rng.integers(1, 17)))
+        assert (want is None) == (got_fd is None), case
         if want is not None:
-            for a, b in zip(got, want):
-                assert np.array_equal(a, b), case
+            for a, b, f in zip(got, want, got_fd):
+                assert np.array_equal(a, b) and np.array_equal(f, b), case
 
 
 def test_samtools_shim_refuses_what_it_does_not_serve():

@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--variants", default="", help="extra device-decoder runs, each a comma list of ENV=VALUE, separated by ';' "
                                                    "(e.g. 'GOLEFT_INGEST_GROUP_MB=4096;GOLEFT_COPY_THREADS=16')")
     ap.add_argument("--no-host", action="store_true", help="skip the host-decoder run")
+    ap.add_argument("--host-reps", type=int, default=3, help="repetitions of the host-decoder run (device runs: 3)")
     ap.add_argument("--rocprof", default="", help="directory: one more device-decoder run under rocprofv3 --kernel-trace --stats")
     args = ap.parse_args()
     d = tempfile.mkdtemp(prefix="gd_scope3_", dir="/tmp")
@@ -53,7 +54,7 @@ def main():
         variants.insert(1, ("device", dict(kv.split("=", 1) for kv in v.split(","))))
     for vi, (decoder, env) in enumerate(variants):
         best = None
-        for rep in range(3):                               # the file is in the page cache after the write
+        for rep in range(args.host_reps if decoder == "host" else 3):   # the file is in the page cache after the write
             t0 = time.perf_counter()
             p = subprocess.run([os.path.join(ROOT, "goleft_amd", "goleft-depth"), "depth", "-w", str(args.window),
                                 "-p", str(args.threads)] + extra + ["-r", os.path.join(d, "synth.fa"), "--prefix",
