@@ -90,6 +90,7 @@ SYMBOLS = {
     "gd_ingest_begin": (C.c_int, [_P, C.c_uint64, C.c_uint64, C.c_size_t, _P, _P, _P, _P, _P]),
     "gd_ingest_feed": (C.c_int, [_P, _P, C.c_size_t]),
     "gd_ingest_feed_fd": (C.c_int, [_P, C.c_int, C.c_uint64, C.c_size_t]),
+    "gd_ingest_timing": (C.c_int, [_P, _P, C.c_size_t]),
     "gd_ingest_finish": (C.c_int, [_P, C.c_int32, C.c_int32, _P, C.c_size_t, C.POINTER(C.c_uint64)]),
     "gd_ingest_decode": (C.c_int, [_P, C.c_int32, C.c_int32, _P, C.c_size_t, C.POINTER(C.c_uint64)]),
     "gd_ingest_release": (C.c_int, [_P]),

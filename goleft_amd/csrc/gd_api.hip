@@ -118,6 +118,8 @@ void gd_destroy(gd_ctx* c)
         if (c->ing_staged[k]) (void)hipEventDestroy(c->ing_staged[k]);
     }
     for (hipStream_t st : c->ing_stream) if (st) (void)hipStreamDestroy(st);
+    for (hipStream_t st : c->ing_dma) if (st) (void)hipStreamDestroy(st);
+    for (auto& evs : c->ing_dma_ev) for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
     for (auto& b : c->ing_bufs) b.drop();
     for (auto& h : c->contigs) free_contig(h);
     for (auto& s : c->ring) {
@@ -748,6 +750,11 @@ int gd_set_option(gd_ctx* c, int option, int64_t value)
         if (value > 1) c->h2d_grid = (unsigned)value;
         break;
     case GD_OPT_FUSED_NORMALIZE: c->fused_norm = value != 0; break;
+    case GD_OPT_INGEST_CRC: c->ingest_crc = value != 0; break;
+    case GD_OPT_INGEST_DMA:
+        if (value < 1 || value > 4) return fail(c, GD_E_INVALID, "ingest DMA streams: 1 .. 4");
+        c->ing_dma_n = (int)value;
+        break;
     case GD_OPT_BAM_REFS:
         if (value < 0 || value > 0x7fffffff) return fail(c, GD_E_INVALID, "BAM references: 0 (unknown) .. 2^31 - 1");
         c->bam_n_ref = (int32_t)value;

@@ -186,6 +186,7 @@ struct gd_ctx {
     // one range overlaps the upload of the next.
     IngestState* ing_q[2] = {nullptr, nullptr};
     int ing_n = 0;
+    double ing_secs[7] = {0, 0, 0, 0, 0, 0, 0};         // gd_ingest_timing
     std::thread ing_feeder;                             // gd_ingest_feed_fd: the read of the newest range in progress
     int ing_feeder_rc = 0;
     bool ing_stage_used[2] = {false, false};
@@ -195,11 +196,15 @@ struct gd_ctx {
     // (page-locking 128 MB per contig would cost more than many contigs' whole decode)
     uint8_t* ing_stage[2] = {nullptr, nullptr};
     hipEvent_t ing_staged[2] = {nullptr, nullptr};
+    hipStream_t ing_dma[3] = {nullptr, nullptr, nullptr};   // GD_OPT_INGEST_DMA > 1: a staged piece leaves in slices on several streams (DMA engines)
+    hipEvent_t ing_dma_ev[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
+    int ing_dma_n = 1;
     hipStream_t ing_stream[8] = {};                     // inflate launches rotate over these (two pending ranges x 4)
     unsigned ing_launch_seq = 0;
     int ing_copy_threads = 1;                          // GD_OPT_COPY_THREADS: threads filling the staging buffer
     bool h2d_kernel = true;                            // GD_OPT_H2D_KERNEL: staging blocks reach HBM through gd_h2d_kernel
     unsigned h2d_grid = 512;                           // ... its workgroups
+    bool ingest_crc = true;                            // GD_OPT_INGEST_CRC
     bool fused_norm = true;                            // GD_OPT_FUSED_NORMALIZE: gd_normalize as one pass (0: count / scan / write / index launches)
     int32_t bam_n_ref = 0;                             // GD_OPT_BAM_REFS: references of the BAM being read (0: unknown)
     int push_threads = 16;

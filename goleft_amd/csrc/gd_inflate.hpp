@@ -458,14 +458,23 @@ __global__ __launch_bounds__(INF_LANES) void gd_inflate_kernel(InflateJob job)
 }
 
 // CRC32 of every member that inflated cleanly against its gzip trailer: one lane per member, all lanes of a wave
-// in step (four table look-ups per loaded word).
+// in step.  Slicing-by-8: eight bytes per step through eight tables -- eight INDEPENDENT look-ups instead of a chain
+// of dependent ones (a lane's CRC is a latency chain: the byte-at-a-time form took a quarter of the inflate's time).
 __global__ __launch_bounds__(256) void gd_inflate_crc_kernel(InflateJob job)
 {
-    __shared__ uint32_t s_crc[256];                        // CRC-32 (IEEE 802.3, reflected) byte table
+    __shared__ uint32_t s_crc[8][256];                     // CRC-32 (IEEE 802.3, reflected): s_crc[k][b] = b followed by k zero bytes
     {
         uint32_t c = threadIdx.x;
         for (int k = 0; k < 8; ++k) c = (c >> 1) ^ (0xedb88320u & (0u - (c & 1u)));
-        s_crc[threadIdx.x] = c;
+        s_crc[0][threadIdx.x] = c;
+    }
+    __syncthreads();
+    {
+        uint32_t c = s_crc[0][threadIdx.x];
+        for (int k = 1; k < 8; ++k) {
+            c = (c >> 8) ^ s_crc[0][c & 0xffu];
+            s_crc[k][threadIdx.x] = c;
+        }
     }
     __syncthreads();
     const uint32_t m = blockIdx.x * 256u + threadIdx.x;
@@ -473,15 +482,15 @@ __global__ __launch_bounds__(256) void gd_inflate_crc_kernel(InflateJob job)
     const uint8_t* const out = job.out + job.out_off[m];
     const uint32_t olen = job.out_len[m];
     uint32_t c = 0xffffffffu, k = 0;
-    for (; k + 4 <= olen; k += 4) {
-        uint32_t w;
-        __builtin_memcpy(&w, out + k, 4);
-        c = s_crc[(c ^ w) & 0xffu] ^ (c >> 8);
-        c = s_crc[(c ^ (w >> 8)) & 0xffu] ^ (c >> 8);
-        c = s_crc[(c ^ (w >> 16)) & 0xffu] ^ (c >> 8);
-        c = s_crc[(c ^ (w >> 24)) & 0xffu] ^ (c >> 8);
+    for (; k + 8 <= olen; k += 8) {
+        uint32_t w0, w1;
+        __builtin_memcpy(&w0, out + k, 4);
+        __builtin_memcpy(&w1, out + k + 4, 4);
+        w0 ^= c;
+        c = s_crc[7][w0 & 0xffu] ^ s_crc[6][(w0 >> 8) & 0xffu] ^ s_crc[5][(w0 >> 16) & 0xffu] ^ s_crc[4][w0 >> 24] ^
+            s_crc[3][w1 & 0xffu] ^ s_crc[2][(w1 >> 8) & 0xffu] ^ s_crc[1][(w1 >> 16) & 0xffu] ^ s_crc[0][w1 >> 24];
     }
-    for (; k < olen; ++k) c = s_crc[(c ^ out[k]) & 0xffu] ^ (c >> 8);
+    for (; k < olen; ++k) c = s_crc[0][(c ^ out[k]) & 0xffu] ^ (c >> 8);
     if ((c ^ 0xffffffffu) != job.crc[m]) job.status[m] = 18;
 }
 

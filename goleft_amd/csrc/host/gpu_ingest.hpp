@@ -377,6 +377,11 @@ inline int ingest_references_on_device(gd_ctx* ctx, const FileMap& fm, const std
         double t_listing = 0;
         for (const Listed& l : listed) t_listing += l.secs;
         fprintf(stderr, "{\"listing_thread_s\": %.4f, \"ingest_call_s\": %.4f}\n", t_listing, now() - t_enter);
+        double lib[7] = {0, 0, 0, 0, 0, 0, 0};
+        if (gd_ingest_timing(ctx, lib, 7) == GD_OK)
+            fprintf(stderr, "{\"lib_read_s\": %.4f, \"lib_wait_link_s\": %.4f, \"lib_begin_s\": %.4f, \"lib_wait_inflate_s\": %.4f, "
+                            "\"lib_count_walk_s\": %.4f, \"lib_alloc_s\": %.4f, \"lib_alloc_and_extract_walk_s\": %.4f}\n",
+                    lib[0], lib[1], lib[2], lib[3], lib[4], lib[5], lib[6]);
     }
     if (timing)
         fprintf(stderr, "{\"ingest_list_members_s\": %.4f, \"begin_s\": %.4f, \"feed_s\": %.4f, \"decode_s\": %.4f}\n",

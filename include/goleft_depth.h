@@ -201,6 +201,10 @@ enum { /* (1, 2: tile shapes other than 4096 positions x 256 threads -- measured
                                        contig's and below this number, or -1); anything else is a damaged record */
        GD_OPT_FUSED_NORMALIZE = 11, /* 1 (default): gd_normalize builds canonical CIGARs, record words and position index in ONE
                                        pass (offsets by decoupled look-back); 0: count / scan / write / index launches */
+       GD_OPT_INGEST_CRC = 12,      /* 1 (default): gd_ingest_* checks the CRC32 of every BGZF member after inflating it, as htslib
+                                       does; 0: the file is trusted (a second pass over the inflated bytes is saved) */
+       GD_OPT_INGEST_DMA = 13,      /* gd_ingest_feed*: streams a staged piece is split over: 1 (default) .. 4.  Measured on MI355X next to the
+                                       inflate kernels: one stream 24-27 GB/s, two to four streams slower */
        GD_OPT_H2D_KERNEL = 8 };     /* how a committed staging block reaches HBM: 1 (default) one kernel whose workgroups
                                        read the page-locked block over the link (all five arrays in one launch; n > 1:
                                        with n workgroups), 0: five hipMemcpyAsync through a DMA engine */
@@ -473,13 +477,21 @@ int gd_ingest_begin(gd_ctx* ctx, uint64_t n_bytes, uint64_t base_coffset, size_t
 int gd_ingest_feed(gd_ctx* ctx, const uint8_t* bytes, size_t n);
 /* gd_ingest_feed with the bytes taken from an open file: n bytes from `offset` of `fd` are read (pread on the
  * context's worker threads, GD_OPT_PUSH_THREADS of them) straight into the page-locked staging buffers -- none
- * of the page faults of a mapping, no second copy.  GD_E_INVALID: the file ended early or could not be read. */
+ * of the page faults of a mapping, no second copy.  The read runs on a thread of the context and the call returns
+ * at once (fd must stay open): gd_ingest_decode / _release of the OLDER of two pending ranges and gd_ingest_begin of
+ * the next one proceed meanwhile; every other gd_ingest_* call waits for the read first and reports its error
+ * (GD_E_INVALID: the file ended early or could not be read). */
 int gd_ingest_feed_fd(gd_ctx* ctx, int fd, uint64_t offset, size_t n);
 int gd_ingest_finish(gd_ctx* ctx, int32_t tid, int32_t ref_id, const uint64_t* anchors, size_t n_anchors,
                      uint64_t* n_records);
 int gd_ingest_decode(gd_ctx* ctx, int32_t tid, int32_t ref_id, const uint64_t* anchors, size_t n_anchors,
                      uint64_t* n_records);
 int gd_ingest_release(gd_ctx* ctx);
+/* Where the device BAM read of this context has spent its wall clock so far, in seconds (measurement only):
+ * out[0] reading into the staging buffers, [1] waiting for a staging buffer to leave for the device, [2] gd_ingest_begin
+ * (allocations, member table), [3] decode: waiting for the inflate launches, [4] decode: the counting walk, [5] decode:
+ * allocating the contig's arrays, [6] decode: the extracting walk.  Fills min(n, 7) values. */
+int gd_ingest_timing(gd_ctx* ctx, double* out, size_t n);
 int gd_ingest_abort(gd_ctx* ctx);
 /* Page-locked host memory for the byte range handed to gd_ingest_bgzf (read the file
  * straight into it: the H2D copy then runs at PCIe speed instead of through a bounce

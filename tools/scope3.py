@@ -39,6 +39,7 @@ def main():
         args.window, args.threads = 16384, 20
     info = json.loads(subprocess.check_output([os.path.join(ROOT, "goleft_amd", "synth-bam"), bam, args.name,
                                                args.length, str(args.coverage), "20"]).decode())
+    subprocess.run(["sync"])                                # the file at rest: no write-back under the timed runs
     args.length = sum(int(x) for x in args.length.split(","))
     t_write = time.perf_counter() - t0
     extra = ["--chrom", args.name, "-o"] if args.paper else []
