@@ -119,6 +119,7 @@ void gd_destroy(gd_ctx* c)
     }
     for (hipStream_t st : c->ing_stream) if (st) (void)hipStreamDestroy(st);
     for (hipStream_t st : c->ing_dma) if (st) (void)hipStreamDestroy(st);
+    if (c->ing_hp) (void)hipStreamDestroy(c->ing_hp);
     for (auto& evs : c->ing_dma_ev) for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
     for (auto& b : c->ing_bufs) b.drop();
     for (auto& h : c->contigs) free_contig(h);
@@ -752,7 +753,7 @@ int gd_set_option(gd_ctx* c, int option, int64_t value)
     case GD_OPT_FUSED_NORMALIZE: c->fused_norm = value != 0; break;
     case GD_OPT_INGEST_CRC: c->ingest_crc = value != 0; break;
     case GD_OPT_INGEST_DMA:
-        if (value < 1 || value > 4) return fail(c, GD_E_INVALID, "ingest DMA streams: 1 .. 4");
+        if (value < 0 || value > 4) return fail(c, GD_E_INVALID, "ingest DMA streams: 1 .. 4 (0: a copy kernel on a high-priority stream)");
         c->ing_dma_n = (int)value;
         break;
     case GD_OPT_BAM_REFS:

@@ -199,6 +199,7 @@ struct gd_ctx {
     hipStream_t ing_dma[3] = {nullptr, nullptr, nullptr};   // GD_OPT_INGEST_DMA > 1: a staged piece leaves in slices on several streams (DMA engines)
     hipEvent_t ing_dma_ev[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
     int ing_dma_n = 1;
+    hipStream_t ing_hp = nullptr;                       // GD_OPT_INGEST_DMA 0: the piece leaves with a copy kernel on a high-priority stream
     hipStream_t ing_stream[8] = {};                     // inflate launches rotate over these (two pending ranges x 4)
     unsigned ing_launch_seq = 0;
     int ing_copy_threads = 1;                          // GD_OPT_COPY_THREADS: threads filling the staging buffer

@@ -203,7 +203,8 @@ enum { /* (1, 2: tile shapes other than 4096 positions x 256 threads -- measured
                                        pass (offsets by decoupled look-back); 0: count / scan / write / index launches */
        GD_OPT_INGEST_CRC = 12,      /* 1 (default): gd_ingest_* checks the CRC32 of every BGZF member after inflating it, as htslib
                                        does; 0: the file is trusted (a second pass over the inflated bytes is saved) */
-       GD_OPT_INGEST_DMA = 13,      /* gd_ingest_feed*: streams a staged piece is split over: 1 (default) .. 4.  Measured on MI355X next to the
+       GD_OPT_INGEST_DMA = 13,      /* gd_ingest_feed*: streams a staged piece is split over: 1 (default) .. 4; 0: a copy kernel on a
+                                       high-priority stream instead.  Measured on MI355X next to the
                                        inflate kernels: one stream 24-27 GB/s, two to four streams slower */
        GD_OPT_H2D_KERNEL = 8 };     /* how a committed staging block reaches HBM: 1 (default) one kernel whose workgroups
                                        read the page-locked block over the link (all five arrays in one launch; n > 1:
