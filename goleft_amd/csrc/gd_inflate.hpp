@@ -10,22 +10,24 @@
 // kernel (one `if` per symbol kind, loads and stores inside the branches) left the compiler no way to
 // count what is in flight, so every use of a loaded value became `s_waitcnt vmcnt(0)` -- the wave then
 // paid a full store round trip per symbol (7 000 cycles per step measured, 72 % of wave cycles waiting).
-// Here every iteration of every lane issues exactly three vector-memory operations, unconditionally and
-// in the same order -- (1) the next 8 input bytes, (2) one 16-byte store, (3) one 16-byte load -- and
-// consumes what the PREVIOUS iteration loaded, so the waits are counted (`vmcnt(2)`, `vmcnt(1)`) and a
-// whole iteration of Huffman decoding hides each round trip:
+// Here every iteration of every lane does the same things in the same order -- issue its two loads (the
+// 16-byte chunk of a match in progress, the next 8 input bytes), decode one symbol while they are in
+// flight, retire them, issue one 16-byte store -- so no load crosses the loop's back edge, the waits are
+// counted (`vmcnt(1)`, then `vmcnt(0)` with nothing else outstanding) and a whole iteration of Huffman
+// decoding hides each round trip:
 //   * input: the branch-free 64-bit bit buffer (`buf |= next << cnt; p += (63 - cnt) >> 3; cnt |= 56`);
 //     the word for the next refill is loaded right after this one, its address does not depend on what
 //     the decode consumes;
 //   * output: the last 16 bytes of the member live in registers (T).  Literals shift into T and are
 //     stored 16 at a time (or when a match starts); a match is copied in 16-byte chunks, one per
-//     iteration: the chunk's source is loaded in iteration i and stored in iteration i + 1, AFTER that
-//     iteration has decoded its own symbol.  The store slot comes before the load slot, so a chunk may
-//     read what the previous chunk wrote (any distance >= 16); distances below 16 take their first chunk
+//     iteration: a chunk is planned at the end of one iteration, its source loaded at the top of the next
+//     and stored at that one's end, AFTER it has decoded its own symbol.  An iteration's store precedes the
+//     next iteration's load, so a chunk may read what the previous chunk wrote (any distance >= 16);
+//     distances below 16 take their first chunk
 //     from T with two byte permutes (selectors from a table shared by the workgroup) and continue at
 //     the next multiple of the distance that is >= 16;
-//   * lanes with nothing to store write to a dump slot of their workgroup, lanes with nothing to load read
-//     their member's first bytes.
+//   * lanes with nothing to load or store issue nothing (the loads are waited for inside the iteration that
+//     issued them, so the counts hold either way).
 // Huffman decoding is canonical and branch free: the 15-bit peek is compared with the left-aligned end
 // of every code length (15 compares against packed registers) and the symbol index is one add and two
 // LDS reads ([entry][lane] tables: 408 bytes per lane, six workgroups per CU).  Block headers (dynamic
@@ -44,12 +46,10 @@ struct InflateJob {
     const uint32_t* crc;           // [n] CRC32 of the member's data (gzip trailer), or nullptr: not checked
     uint8_t* out;                  // (readable up to 64 bytes past the last member)
     uint32_t* status;              // [n] 0 ok, else an error code (18: CRC32 mismatch)
-    uint8_t* dump;                 // INF_DUMP bytes nobody reads: where idle lanes put their store
     uint32_t n;
 };
 
 constexpr size_t INF_SLACK = 256;  // bytes the inflate buffers are allocated beyond their contents
-constexpr size_t INF_DUMP = 1024 * 1024;   // 1024 workgroup slots of 64 lanes x 16 bytes
 
 constexpr int INF_LANES = 64;      // lanes (= members in flight) per workgroup
 constexpr int INF_MAXL = 288, INF_MAXD = 30;
