@@ -1,0 +1,169 @@
+"""CPU: the device inflate kernels (goleft_amd/csrc/gd_inflate.hpp) compiled for the HOST and run lane by lane as
+fibers (tests/emul/inflate_emul.cpp) against zlib -- the state machine, the table builder and the CRC kernel as the
+product compiles them, on streams chosen for the rare paths: stored and fixed blocks, members shorter than the
+16-byte register window, matches of every distance below 16, chunks that end at the member's end, several blocks per
+member, damaged payloads.  The GPU tests compare the kernel on an MI355X with zlib (tests/test_gpu_bamdecode.py);
+this is the same check where no GPU is needed, and tens of times as many streams."""
+import ctypes as C
+import os
+import shutil
+import subprocess
+import sys
+import zlib
+
+import numpy as np
+import pytest
+
+from tests import helpers as H
+
+EMUL_DIR = os.path.join(H.ROOT, "tests", "emul")
+CLANG = next((p for p in ("/opt/rocm/lib/llvm/bin/clang++", shutil.which("clang++") or "") if p and os.path.exists(p)), None)
+
+pytestmark = pytest.mark.skipif(CLANG is None, reason="the kernel source needs clang (ext_vector_type) to compile for the host")
+
+
+def _lib():
+    src = os.path.join(EMUL_DIR, "inflate_emul.cpp")
+    so = os.path.join(EMUL_DIR, "inflate_emul.so")
+    hdr = os.path.join(H.ROOT, "goleft_amd", "csrc", "gd_inflate.hpp")
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        subprocess.check_call([CLANG, "-O2", "-std=c++17", "-shared", "-fPIC", "-o", so, src])
+    lib = C.CDLL(so)
+    lib.emul_inflate.argtypes = [C.c_void_p] * 8 + [C.c_uint32]
+    lib.emul_inflate.restype = C.c_int
+    return lib
+
+
+def deflate(x: bytes, level=6, strategy=zlib.Z_DEFAULT_STRATEGY) -> bytes:
+    co = zlib.compressobj(level, zlib.DEFLATED, -15, 8, strategy)
+    return co.compress(x) + co.flush()
+
+
+def emul_inflate(payloads, sizes, crcs=None):
+    """payloads: raw deflate streams; sizes: what each is said to inflate to.  Laid out like BGZF members: eight bytes
+    of trailer after every payload, the outputs back to back.  -> (bytes of every member, status[])"""
+    lib = _lib()
+    n = len(payloads)
+    in_off = np.zeros(n, np.uint64); in_len = np.zeros(n, np.uint32)
+    out_off = np.zeros(n, np.uint64); out_len = np.asarray(sizes, np.uint32)
+    p = q = 0
+    for i, c in enumerate(payloads):
+        in_off[i] = p; in_len[i] = len(c); out_off[i] = q
+        p += len(c) + 8
+        q += int(out_len[i])
+    comp = np.full(p + 256, 0xa5, np.uint8)                 # (the slack the device buffers have: gd::INF_SLACK)
+    for i, c in enumerate(payloads):
+        comp[int(in_off[i]):int(in_off[i]) + len(c)] = np.frombuffer(c, np.uint8)
+    out = np.full(q + 256, 0xee, np.uint8)
+    status = np.full(n, 99, np.uint32)
+    crc = None if crcs is None else np.asarray(crcs, np.uint32)
+    lib.emul_inflate(comp.ctypes.data, in_off.ctypes.data, in_len.ctypes.data, out_off.ctypes.data, out_len.ctypes.data,
+                     None if crc is None else crc.ctypes.data, out.ctypes.data, status.ctypes.data, n)
+    assert (out[q:] == 0xee).all(), "the kernel wrote past the last member"
+    return [out[int(out_off[i]):int(out_off[i]) + int(out_len[i])].tobytes() for i in range(n)], status
+
+
+def check(parts, how):
+    payloads = [deflate(x, lv, st) for x, (lv, st) in zip(parts, how)]
+    got, status = emul_inflate(payloads, [len(x) for x in parts], [zlib.crc32(x) & 0xffffffff for x in parts])
+    for i, x in enumerate(parts):
+        assert status[i] == 0 and got[i] == x, (i, int(status[i]), len(x), how[i],
+                                                 next((k for k in range(len(x)) if got[i][k] != x[k]), None))
+
+
+STRATEGIES = [zlib.Z_DEFAULT_STRATEGY, zlib.Z_FILTERED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE, zlib.Z_FIXED]
+
+
+def random_part(rng, n):
+    kind = int(rng.integers(0, 7))
+    if kind == 0:
+        x = rng.integers(0, 256, n, dtype=np.uint8)
+    elif kind == 1:
+        x = rng.integers(0, 4, n, dtype=np.uint8) + 65
+    elif kind == 2:
+        x = np.repeat(rng.integers(0, 256, n // 50 + 1, dtype=np.uint8), 50)[:n]
+    elif kind == 3:                                          # a period below 16: the chunks built from the register window
+        d = int(rng.integers(1, 16))
+        x = np.tile(rng.integers(0, 256, d, dtype=np.uint8), n // d + 1)[:n]
+    elif kind == 4:                                          # a period of 16..40: chunks that read what the previous chunk wrote
+        d = int(rng.integers(16, 41))
+        x = np.tile(rng.integers(0, 256, d, dtype=np.uint8), n // d + 1)[:n]
+    elif kind == 5:                                          # BAM-like: short random runs, quality-like plateaus
+        x = np.concatenate([np.concatenate([rng.integers(0, 16, 30, dtype=np.uint8) * 17,
+                                            np.full(int(rng.integers(1, 80)), int(rng.integers(30, 42)), np.uint8)])
+                            for _ in range(n // 60 + 1)])[:n]
+    else:
+        x = np.zeros(n, np.uint8)
+    return x.tobytes()
+
+
+def test_short_members_and_every_small_distance():
+    """Members shorter than the 16-byte window, a member of every length 0..48, every period 1..40 at lengths that
+    end a chunk exactly at, one before and one past the member's end."""
+    rng = np.random.default_rng(1)
+    parts, how = [], []
+    for n in range(0, 49):
+        parts.append(rng.integers(0, 256, n, dtype=np.uint8).tobytes()); how.append((6, zlib.Z_DEFAULT_STRATEGY))
+    for d in range(1, 41):
+        base = rng.integers(0, 256, d, dtype=np.uint8)
+        for n in (d + 3, 16 + d, 31, 32, 33, 47, 48, 49, 258 + d, 300):
+            parts.append(np.tile(base, n // d + 1)[:n].tobytes()); how.append((int(rng.integers(1, 10)), zlib.Z_DEFAULT_STRATEGY))
+    check(parts, how)
+
+
+def test_stored_fixed_and_empty_blocks():
+    rng = np.random.default_rng(2)
+    parts, how = [], []
+    for n in (0, 1, 15, 16, 17, 1000, 40000):
+        x = rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+        parts += [x, x, x]
+        how += [(0, zlib.Z_DEFAULT_STRATEGY), (6, zlib.Z_FIXED), (1, zlib.Z_HUFFMAN_ONLY)]
+    check(parts, how)
+    # stored, dynamic and fixed blocks in ONE member (Z_FULL_FLUSH leaves an empty stored block between them)
+    a, b, c = (rng.integers(0, 8, 3000, dtype=np.uint8).tobytes() for _ in range(3))
+    co = zlib.compressobj(6, zlib.DEFLATED, -15)
+    payload = co.compress(a) + co.flush(zlib.Z_FULL_FLUSH) + co.compress(b) + co.flush(zlib.Z_SYNC_FLUSH) + co.compress(c) + co.flush()
+    got, status = emul_inflate([payload], [9000], [zlib.crc32(a + b + c) & 0xffffffff])
+    assert status[0] == 0 and got[0] == a + b + c
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_random_members_of_every_kind(seed):
+    """Two workgroups of small members (every payload kind x level x strategy) and a few of BGZF's full size (four or
+    five blocks each: the lanes of a wave meet their headers at different iterations)."""
+    rng = np.random.default_rng(100 + seed)
+    parts = [random_part(rng, int(rng.integers(0, 5000))) for _ in range(120)]
+    parts += [random_part(rng, int(rng.integers(30000, 65281))) for _ in range(8)]
+    how = [(int(rng.integers(0, 10)), STRATEGIES[int(rng.integers(0, 5))]) for _ in parts]
+    check(parts, how)
+
+
+def test_damaged_payloads_are_refused_or_inflate_to_what_zlib_makes_of_them():
+    """Bit flips in the payload: the kernel reports an error (a decoder code, or 18 from the CRC kernel), or -- when the
+    damaged stream is still a valid one -- delivers exactly zlib's bytes; it never writes outside the member (the guard
+    bytes behind the output are checked by emul_inflate) and never runs away (the process would not return)."""
+    rng = np.random.default_rng(7)
+    good = [random_part(rng, int(rng.integers(200, 4000))) for _ in range(40)]
+    payloads, sizes, crcs, want = [], [], [], []
+    for x in good:
+        c = bytearray(deflate(x, int(rng.integers(1, 10)), STRATEGIES[int(rng.integers(0, 5))]))
+        for _ in range(int(rng.integers(1, 4))):
+            c[int(rng.integers(0, len(c)))] ^= 1 << int(rng.integers(0, 8))
+        try:
+            d = zlib.decompressobj(-15)
+            y = d.decompress(bytes(c)) + d.flush()
+            ok = d.eof and len(y) == len(x)
+        except zlib.error:
+            y, ok = b"", False
+        payloads.append(bytes(c)); sizes.append(len(x)); crcs.append(zlib.crc32(x) & 0xffffffff)
+        want.append(y if ok else None)
+    got, status = emul_inflate(payloads, sizes, crcs)
+    n_refused = 0
+    for i, x in enumerate(good):
+        if status[i] == 0:
+            assert got[i] == x                              # the CRC of the intact payload held: these are its bytes
+        else:
+            n_refused += 1
+            if status[i] == 18:                             # inflated cleanly to other bytes: zlib agrees on which
+                assert want[i] is not None and got[i] == want[i]
+    assert n_refused >= 20
