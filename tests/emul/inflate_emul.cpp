@@ -129,6 +129,41 @@ static const gd::InflateJob* g_job = nullptr;
 static void body_inflate() { gd::gd_inflate_kernel(*g_job); }
 static void body_crc() { gd::gd_inflate_crc_kernel(*g_job); }
 
+// The same with every buffer ending exactly INF_SLACK bytes (what the device buffers are allocated beyond their contents)
+// before an inaccessible page: a read or write past what the kernel may touch ends the process.
+#include <sys/mman.h>
+namespace {
+struct Guarded {
+    uint8_t* map = nullptr; size_t len = 0; uint8_t* p = nullptr;
+    Guarded(size_t n)
+    {
+        const size_t page = 4096, body = (n + page - 1) / page * page;
+        len = body + page;
+        map = static_cast<uint8_t*>(mmap(nullptr, len, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0));
+        mprotect(map + body, page, PROT_NONE);
+        p = map + (body - n);
+    }
+    ~Guarded() { if (map) munmap(map, len); }
+};
+}
+extern "C" int emul_inflate(const uint8_t* comp, const uint64_t* in_off, const uint32_t* in_len, const uint64_t* out_off,
+                            const uint32_t* out_len, const uint32_t* crc, uint8_t* out, uint32_t* status, uint32_t n);
+
+extern "C" int emul_inflate_guarded(const uint8_t* comp, uint64_t comp_bytes, const uint64_t* in_off, const uint32_t* in_len,
+                                    const uint64_t* out_off, const uint32_t* out_len, const uint32_t* crc, uint8_t* out,
+                                    uint64_t out_bytes, uint32_t* status, uint32_t n)
+{
+    Guarded c(comp_bytes + gd::INF_SLACK), o(out_bytes + gd::INF_SLACK);
+    memcpy(c.p, comp, comp_bytes);
+    memset(c.p + comp_bytes, 0x5a, gd::INF_SLACK);
+    memset(o.p, 0xee, out_bytes + gd::INF_SLACK);
+    const int rc = emul_inflate(c.p, in_off, in_len, out_off, out_len, crc, o.p, status, n);
+    for (size_t k = 0; k < gd::INF_SLACK; ++k)
+        if (o.p[out_bytes + k] != 0xee) return -2;         // wrote past the last member
+    memcpy(out, o.p, out_bytes);
+    return rc;
+}
+
 extern "C" int emul_inflate(const uint8_t* comp, const uint64_t* in_off, const uint32_t* in_len, const uint64_t* out_off,
                             const uint32_t* out_len, const uint32_t* crc, uint8_t* out, uint32_t* status, uint32_t n)
 {

@@ -31,6 +31,8 @@ def _lib():
     lib = C.CDLL(so)
     lib.emul_inflate.argtypes = [C.c_void_p] * 8 + [C.c_uint32]
     lib.emul_inflate.restype = C.c_int
+    lib.emul_inflate_guarded.argtypes = [C.c_void_p, C.c_uint64] + [C.c_void_p] * 6 + [C.c_uint64, C.c_void_p, C.c_uint32]
+    lib.emul_inflate_guarded.restype = C.c_int
     return lib
 
 
@@ -39,9 +41,10 @@ def deflate(x: bytes, level=6, strategy=zlib.Z_DEFAULT_STRATEGY) -> bytes:
     return co.compress(x) + co.flush()
 
 
-def emul_inflate(payloads, sizes, crcs=None):
+def emul_inflate(payloads, sizes, crcs=None, guarded=False):
     """payloads: raw deflate streams; sizes: what each is said to inflate to.  Laid out like BGZF members: eight bytes
-    of trailer after every payload, the outputs back to back.  -> (bytes of every member, status[])"""
+    of trailer after every payload, the outputs back to back.  -> (bytes of every member, status[]).  guarded: both
+    buffers end gd::INF_SLACK bytes before an inaccessible page (a stray access ends the process)."""
     lib = _lib()
     n = len(payloads)
     in_off = np.zeros(n, np.uint64); in_len = np.zeros(n, np.uint32)
@@ -57,8 +60,14 @@ def emul_inflate(payloads, sizes, crcs=None):
     out = np.full(q + 256, 0xee, np.uint8)
     status = np.full(n, 99, np.uint32)
     crc = None if crcs is None else np.asarray(crcs, np.uint32)
-    lib.emul_inflate(comp.ctypes.data, in_off.ctypes.data, in_len.ctypes.data, out_off.ctypes.data, out_len.ctypes.data,
-                     None if crc is None else crc.ctypes.data, out.ctypes.data, status.ctypes.data, n)
+    if guarded:
+        rc = lib.emul_inflate_guarded(comp.ctypes.data, p, in_off.ctypes.data, in_len.ctypes.data, out_off.ctypes.data,
+                                      out_len.ctypes.data, None if crc is None else crc.ctypes.data, out.ctypes.data, q,
+                                      status.ctypes.data, n)
+        assert rc == 0, "the kernel wrote past the last member"
+    else:
+        lib.emul_inflate(comp.ctypes.data, in_off.ctypes.data, in_len.ctypes.data, out_off.ctypes.data, out_len.ctypes.data,
+                         None if crc is None else crc.ctypes.data, out.ctypes.data, status.ctypes.data, n)
     assert (out[q:] == 0xee).all(), "the kernel wrote past the last member"
     return [out[int(out_off[i]):int(out_off[i]) + int(out_len[i])].tobytes() for i in range(n)], status
 
@@ -167,3 +176,40 @@ def test_damaged_payloads_are_refused_or_inflate_to_what_zlib_makes_of_them():
             if status[i] == 18:                             # inflated cleanly to other bytes: zlib agrees on which
                 assert want[i] is not None and got[i] == want[i]
     assert n_refused >= 20
+
+
+GUARDED_FUZZ = r"""
+import sys, zlib
+import numpy as np
+sys.path.insert(0, %r)
+from tests import test_inflate_emul as T
+rng = np.random.default_rng(int(sys.argv[1]))
+payloads, sizes = [], []
+for k in range(192):
+    x = T.random_part(rng, int(rng.integers(1, 3000)))
+    c = bytearray(T.deflate(x, int(rng.integers(0, 10)), T.STRATEGIES[int(rng.integers(0, 5))]))
+    mode = k %% 4
+    if mode == 0:                                            # bit flips
+        for _ in range(int(rng.integers(1, 6))):
+            c[int(rng.integers(0, len(c)))] ^= 1 << int(rng.integers(0, 8))
+    elif mode == 1:                                          # truncated: the stream runs into the trailer and beyond
+        c = c[:int(rng.integers(1, len(c) + 1))]
+    elif mode == 2:                                          # random bytes
+        c = bytearray(rng.integers(0, 256, int(rng.integers(1, 400)), dtype=np.uint8).tobytes())
+    else:                                                    # a valid stream with the wrong size announced
+        pass
+    payloads.append(bytes(c))
+    sizes.append(len(x) if mode != 3 else max(0, len(x) + int(rng.integers(-40, 41))))
+got, status = T.emul_inflate(payloads, sizes, None, guarded=True)
+print("ran", len(payloads), "refused", int((status != 0).sum()))
+"""
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_damaged_streams_stay_inside_their_buffers(seed):
+    """Flipped, truncated, random and mis-sized streams with the compressed and the inflated buffer ending exactly
+    gd::INF_SLACK bytes before an inaccessible page: the kernel must neither read nor write there (in a child process:
+    a stray access is a segmentation fault), must terminate, and must not write behind the last member."""
+    r = subprocess.run([sys.executable, "-c", GUARDED_FUZZ % H.ROOT, str(seed)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.returncode, r.stdout[-500:], r.stderr[-2000:])
+    assert "ran 192" in r.stdout and int(r.stdout.split("refused")[1]) > 100
