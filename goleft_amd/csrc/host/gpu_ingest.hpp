@@ -1,6 +1,6 @@
 // gpu_ingest.hpp -- host side of the device BAM read: which bytes of the file hold one
 // reference's records (from the .bai linear index), and streaming them to the device decoder
-// (gd_ingest_begin / _feed / _finish, include/goleft_depth.h: inflate + record decode on the GPU).
+// (gd_ingest_begin / _feed_fd / _decode, include/goleft_depth.h: inflate + record decode on the GPU).
 // Shared by `goleft depth` and `multidepth`.
 #pragma once
 
@@ -255,13 +255,14 @@ inline bool list_members(const uint8_t* base, size_t nb, uint64_t beg, const std
 // Records of the BAM references refs[0..n) (ascending reference ids that have records) -> engine
 // contigs tids[0..n), decoded on the device.  lin = BamReader::linear_index() of the file.
 // References that follow each other in the file share one pass while the pass stays under
-// `group_bytes` of BGZF: an inflate pass costs ~0.1 s however small it is, and an assembly with
-// thousands of small contigs would otherwise pay it per contig; and a pass is decoded only after the
-// NEXT one has been fed, so that its last inflate launches overlap that upload.  A pass streams its byte range:
-// the members are listed from the mapping (headers and trailers only), then the bytes are fed in
-// 32 MB pieces -- page-cache reads of the next piece overlap the upload and inflate of the
-// previous ones.  Returns GD_OK (with *io_ok = false when the file does not look as the index
-// says: the caller falls back to the host decoder) or a gd_* error.
+// `group_bytes` of BGZF: an inflate pass costs ~0.05 s however small it is, and an assembly with
+// thousands of small contigs would otherwise pay it per contig.  The passes form a pipeline that keeps
+// the link busy: a lister thread walks the BGZF members of the next pass (pread: headers and trailers
+// only); gd_ingest_begin uploads the table -- while the pass before is still being read;
+// gd_ingest_feed_fd hands the byte range to a thread of the context (pread straight into page-locked
+// buffers, upload, inflate launches) and returns at once; the pass before that is decoded meanwhile.
+// Returns GD_OK (with *io_ok = false when the file does not look as the index says: the caller
+// falls back to the host decoder) or a gd_* error.
 inline int ingest_references_on_device(gd_ctx* ctx, const FileMap& fm, const std::vector<std::vector<uint64_t>>& lin,
                                        const std::vector<int32_t>& refs, const std::vector<int32_t>& tids,
                                        uint64_t* n_records, bool* io_ok, uint64_t group_bytes = 512ull << 20,
@@ -292,8 +293,7 @@ inline int ingest_references_on_device(gd_ctx* ctx, const FileMap& fm, const std
     const bool from_mapping = getenv("GOLEFT_INGEST_MMAP") != nullptr;   // (measurement: the bytes through the mapping instead of pread)
     auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double t_list = 0, t_begin = 0, t_feed = 0, t_decode = 0;
-    // The member tables are listed one pass ahead on a thread of their own (headers and trailers only, read from the
-    // mapping): pass k + 1 is listed while pass k is fed.
+    // The member tables are listed up to two passes ahead on a thread of their own.
     struct Listed { MemberTable mt; bool ok = false; double secs = 0; };
     std::vector<Listed> listed(passes.size());
     std::mutex mu;
