@@ -1,0 +1,58 @@
+"""CPU: the shape of the inflate kernel's machine code.  The kernel is fast because its memory waits are COUNTED
+(goleft_amd/csrc/gd_inflate.hpp): the chunk load and the input word are issued at the top of an iteration, one symbol
+is decoded while they are in flight, and the first wait for vector memory after them is `s_waitcnt vmcnt(1)`.  That
+property is the compiler's to give and to take: a harmless-looking edit (moving the block-header code into a function
+was tried) changed the register allocation and put an `s_waitcnt vmcnt(0)` into the path that builds a chunk from the
+register window -- a full store round trip in every iteration that starts a short-distance match -- without failing any
+functional test.  This test compiles the kernel for gfx950 and checks the schedule, so such a change is seen on the
+CPU box."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+from tests import helpers as H
+
+HIPCC = next((p for p in ("/opt/rocm/bin/hipcc", shutil.which("hipcc") or "") if p and os.path.exists(p)), None)
+
+pytestmark = pytest.mark.skipif(HIPCC is None, reason="needs hipcc")
+
+
+def test_waits_of_the_symbol_loop_are_counted(tmp_path):
+    src = tmp_path / "k.hip"
+    src.write_text('#include <hip/hip_runtime.h>\n#include <cstdint>\n#include "%s"\n' %
+                   os.path.join(H.ROOT, "goleft_amd", "csrc", "gd_inflate.hpp"))
+    asm = tmp_path / "k.s"
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-o", str(asm), str(src)],
+                          stderr=subprocess.DEVNULL)
+    text = asm.read_text()
+    body = text[text.index("gd_inflate_kernel"):text.index("s_endpgm")].splitlines()
+    # the chunk load (the kernel's only 16-byte load with the streaming hint) and the input word right after it
+    loads = [i for i, l in enumerate(body) if "global_load_dwordx4" in l and " nt" in l]
+    assert len(loads) == 1, loads
+    at = loads[0]
+    assert any("global_load_dwordx2" in l for l in body[at + 1:at + 8]), "the input word is not issued with the chunk load"
+    stores = [i for i, l in enumerate(body) if "global_store_dwordx4" in l and i > at]
+    assert stores, "no 16-byte store after the loads"
+    between = body[at:stores[0]]
+    waits = [l.strip() for l in between if "s_waitcnt" in l and "vmcnt" in l]
+    # first the chunk (the input word may stay in flight), later the input word; never more than these
+    assert waits and waits[0] == "s_waitcnt vmcnt(1)", waits
+    assert len(waits) <= 3, waits
+    # the decode between the loads and that first wait is long: a whole symbol (both Huffman look-ups)
+    first_wait = next(i for i, l in enumerate(between) if "vmcnt" in l)
+    assert first_wait > 120, first_wait
+    assert sum("ds_read" in l for l in between[:first_wait]) >= 4
+    # the chunk built from the register window (two 16-byte selector reads, byte permutes) waits for LDS only
+    perm = [i for i, l in enumerate(body) if "ds_read_b128" in l]
+    assert len(perm) == 2 and perm[1] == perm[0] + 1
+    window = body[perm[0]:perm[0] + 30]
+    assert sum("v_perm_b32" in l for l in window) == 8
+    assert not any("vmcnt" in l for l in window), [l.strip() for l in window if "vmcnt" in l]
+    # occupancy is set by LDS (six workgroups per CU); the registers must allow at least two waves per SIMD
+    vgprs = int(re.search(r"\.vgpr_count:\s+(\d+)", text[text.index("gd_inflate_kernel"):]).group(1))
+    assert vgprs <= 256, vgprs
+    lds = int(re.search(r"\.group_segment_fixed_size:\s+(\d+)", text).group(1))
+    assert lds * 6 <= 160 * 1024, lds
