@@ -86,13 +86,19 @@ BamReader::~BamReader()
 // Producer side: reads the next kChunk compressed bytes, inflates every complete BGZF member
 // in it (in parallel) and returns the decoded bytes.  Runs on a background thread one chunk
 // ahead of the record decoder (prefetch_), so file I/O + inflate overlap the decode.
+// Every batch of inflated bytes starts kHead bytes into its buffer: the consumer copies the record that straddles two
+// batches (hundreds of bytes; megabytes for an ultra-long read) in FRONT of the new batch and goes on in that buffer,
+// instead of appending the new batch (a quarter of a gigabyte) to the old one.
+static size_t kHead = 8u << 20;                        // (GOLEFT_BAM_HEAD_KB, read when a file is opened: tests shrink it)
+static size_t kChunkBytes = 64u << 20;                 // compressed bytes per batch (GOLEFT_BAM_CHUNK_KB)
+
 BamReader::Chunk BamReader::produce(std::vector<uint8_t> spare)
 {
     Chunk c;
     c.data = std::move(spare);                           // recycled pages: no fresh page faults per batch
     c.data.clear();
     if (eof_ && raw_.empty()) { c.end = true; return c; }
-    const size_t kChunk = 64u << 20;
+    const size_t kChunk = kChunkBytes;
     for (;;) {
         double t0 = Tm::now();
         if (!eof_) {
@@ -124,7 +130,7 @@ BamReader::Chunk BamReader::produce(std::vector<uint8_t> spare)
             }
             continue;                                    // a member larger than what is buffered: read on
         }
-        c.data.resize(out);
+        c.data.resize(kHead + out);
         std::atomic<size_t> next{0};
         std::atomic<bool> bad{false};
         auto work = [&]() {
@@ -133,7 +139,7 @@ BamReader::Chunk BamReader::produce(std::vector<uint8_t> spare)
                 if (i >= ms.size() || bad.load()) return;
                 for (size_t k = i; k < std::min(i + 8, ms.size()); ++k) {
                     if (ms[k].isize == 0) continue;
-                    if (!inflate_member(raw_.data(), ms[k], c.data.data())) bad.store(true);
+                    if (!inflate_member(raw_.data(), ms[k], c.data.data() + kHead)) bad.store(true);
                 }
             }
         };
@@ -159,11 +165,6 @@ void BamReader::drop_prefetch()
 
 bool BamReader::fill(std::string* err)
 {
-    // drop consumed bytes
-    if (cur_ > 0) {
-        buf_.erase(buf_.begin(), buf_.begin() + (ptrdiff_t)cur_);
-        cur_ = 0;
-    }
     if (done_) return false;
     double t0 = Tm::now();
     Chunk c = prefetch_.valid() ? prefetch_.get() : produce(std::vector<uint8_t>());
@@ -171,12 +172,26 @@ bool BamReader::fill(std::string* err)
     t0 = Tm::now();
     if (!c.err.empty()) { if (err) *err = c.err; done_ = true; return false; }
     if (c.end) { done_ = true; return false; }
-    if (buf_.capacity() < buf_.size() + c.data.size()) buf_.reserve(3 * c.data.size() + buf_.size());
-    buf_.insert(buf_.end(), c.data.begin(), c.data.end());
+    const size_t rest = buf_.size() - cur_;              // decoded bytes not consumed yet: normally one partial record
+    std::vector<uint8_t> spare;
+    if (rest <= kHead) {
+        if (rest) memcpy(c.data.data() + kHead - rest, buf_.data() + cur_, rest);
+        spare = std::move(buf_);
+        buf_ = std::move(c.data);
+        cur_ = kHead - rest;
+    } else {                                             // (a record larger than the headroom, or a caller that holds on to a block's bytes)
+        if (cur_ > 0) {
+            buf_.erase(buf_.begin(), buf_.begin() + (ptrdiff_t)cur_);
+            cur_ = 0;
+        }
+        if (buf_.capacity() < buf_.size() + c.data.size()) buf_.reserve(3 * c.data.size() + buf_.size());
+        buf_.insert(buf_.end(), c.data.begin() + (ptrdiff_t)kHead, c.data.end());
+        spare = std::move(c.data);
+    }
     g_tm.append += Tm::now() - t0;
     // one batch ahead, into the buffer just emptied
     prefetch_ = std::async(std::launch::async,
-                           [this](std::vector<uint8_t> sp) { return produce(std::move(sp)); }, std::move(c.data));
+                           [this](std::vector<uint8_t> sp) { return produce(std::move(sp)); }, std::move(spare));
     return true;
 }
 
@@ -198,6 +213,8 @@ bool BamReader::open(const std::string& path, int threads, std::string* err)
 {
     path_ = path;
     threads_ = threads > 0 ? threads : (int)std::max(1u, std::thread::hardware_concurrency());
+    if (const char* e = getenv("GOLEFT_BAM_CHUNK_KB")) kChunkBytes = (size_t)std::max(64, atoi(e)) << 10;
+    if (const char* e = getenv("GOLEFT_BAM_HEAD_KB")) kHead = (size_t)std::max(0, atoi(e)) << 10;
     fp_ = fopen(path.c_str(), "rb");
     if (!fp_) { if (err) *err = "cannot open " + path; return false; }
     if (!need(12, err) || memcmp(buf_.data() + cur_, "BAM\1", 4) != 0) {
@@ -327,7 +344,7 @@ bool BamReader::seek_contig(int32_t tid, std::string* err)
     eof_ = false;
     done_ = false;
     if (!need(uoff + 1, err)) return false;
-    cur_ = uoff;
+    cur_ += uoff;
     left_.assign(contigs_.size(), false);         // a deliberate jump: the run rule starts over
     last_ref_ = -2;
     return true;
@@ -402,6 +419,10 @@ int BamReader::next_block(RecordBlock& out, size_t max_reads, std::string* err)
     std::vector<size_t> at;                               // offset of every record's body, relative to cur_
     size_t p = 0;                                         // bytes hopped over, relative to cur_
     for (;;) {
+        const size_t have = buf_.size() - cur_;
+        if (at.empty() && p) { cur_ += p; p = 0; continue; }           // records skipped so far are consumed
+        // a block ends where the decoded bytes end: the record that straddles two batches opens the next block
+        if (!at.empty() && (have < p + 4 || have < p + 4 + (size_t)rd32(buf_.data() + cur_ + p))) break;
         std::string e;
         if (!need(p + 4, &e)) {
             if (!e.empty()) { if (err) *err = e; return -1; }

@@ -163,6 +163,46 @@ def test_bam_reader_roundtrip(hostlib, name, threads, tmp_path):
     _same_streams(got, reads)
 
 
+BATCHED_READ = r"""
+import sys
+import numpy as np
+sys.path.insert(0, %r)
+from goleft_amd import _hostlib as hl
+from oracle import bamio
+path = sys.argv[1]
+_, want, total = bamio.read_bam(path)[1:]
+_, got, n = hl.read_bam(path, threads=int(sys.argv[2]), max_reads=int(sys.argv[3]))
+assert n == total, (n, total)
+assert sorted(got) == sorted(want)
+for t in want:
+    for a, b in zip(got[t], (want[t].pos, want[t].flag, want[t].mapq, want[t].cigar_off, want[t].cigar)):
+        assert np.array_equal(a, b), t
+print("same", n)
+"""
+
+
+@pytest.mark.parametrize("head_kb", ["8192", "1", "0"])
+@pytest.mark.parametrize("max_reads", [700, 1 << 20])
+def test_bam_reader_across_many_batches(tmp_path, head_kb, max_reads):
+    """The reader decodes batch by batch (64 MB of BGZF each) and goes on IN the new batch's buffer: the record that
+    straddles two batches is copied in front of it.  With 64 KB batches a 3 MB file has dozens of them; records
+    larger than a batch (a 70 000-op CIGAR behind the CG tag), thousands of unplaced records at the end and a headroom
+    too small for the straddling record (the appending fallback) all have to give the stream the pure-Python reader
+    gives.  (A child process: batch and headroom sizes are read from the environment when a file is opened.)"""
+    import subprocess
+    import sys
+    rng = np.random.default_rng(11)
+    contigs = [("a", 2_000_000), ("b", 500_000), ("c", 50_000)]
+    reads = {0: H.random_reads(rng, 2_000_000, 30_000, max_len=120), 1: H.long_cigar_reads(rng, 500_000, [70_000, 5, 66_000], max_step=3),
+             2: H.random_reads(rng, 50_000, 4_000, max_len=90)}
+    path = str(tmp_path / "many.bam")
+    bamio.write_bam(path, contigs, reads, unplaced=3000, level=0 if max_reads == 700 else 1)   # stored members: dozens of batches; deflated: a few
+    assert os.path.getsize(path) > (12 if max_reads == 700 else 3) * 65536, os.path.getsize(path)
+    env = dict(os.environ, GOLEFT_BAM_CHUNK_KB="64", GOLEFT_BAM_HEAD_KB=head_kb)
+    r = subprocess.run([sys.executable, "-c", BATCHED_READ % ROOT, path, "3", str(max_reads)], capture_output=True, text=True, env=env)
+    assert r.returncode == 0 and "same" in r.stdout, (r.stdout[-300:], r.stderr[-1500:])
+
+
 def test_bam_reader_long_cigar_cg_tag(hostlib, tmp_path):
     rng = np.random.default_rng(5)
     n_ops = 70000                       # > 65535: stored through the CG:B,I convention
