@@ -879,7 +879,7 @@ struct IngestState {
     uint8_t *d_in = nullptr, *d_out = nullptr;
     uint64_t *t_in_off = nullptr, *t_out_off = nullptr;
     uint32_t *t_in_len = nullptr, *t_out_len = nullptr, *t_status = nullptr, *t_crc = nullptr;
-    // One lane inflates one member start to end (~0.1 s whatever the member count), so the members are
+    // One lane inflates one member start to end (~0.04 s whatever the member count), so the members are
     // handed to the kernel in at most kBatches launches, each on its own stream: they overlap each other
     // and the upload of the bytes still to come.
     static constexpr int kBatches = 8;

@@ -460,7 +460,7 @@ int gd_ingest_bgzf(gd_ctx* ctx, int32_t tid, int32_t ref_id, const uint8_t* data
  * behind the copy while the caller reads the next piece -- and finish with the anchors.
  * gd_ingest_bgzf is begin + one feed + finish.  gd_ingest_abort drops an unfinished read.
  * A fed range may hold several references (a BAM with thousands of small contigs: one inflate
- * pass has a latency floor of ~0.1 s whatever its size): gd_ingest_decode is gd_ingest_finish
+ * pass has a latency floor of ~0.04 s whatever its size): gd_ingest_decode is gd_ingest_finish
  * without the release, so call it once per reference of the range (each with that reference's
  * anchors and its own contig), then gd_ingest_release -- or gd_ingest_finish for the last one.
  * Two ranges may be pending at a time: once a range is completely fed, gd_ingest_begin / _feed of
