@@ -5,11 +5,77 @@
 
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
 #include <cstring>
+#include <functional>
+#include <mutex>
 #include <thread>
 
 #include <chrono>
 namespace gdh {
+
+// Worker threads that live as long as the reader: a batch used to start (and join) one thread per core for the
+// inflate and two more sets for the record passes -- on a 256-core host more time than the work itself.
+struct Workers {
+    std::vector<std::thread> th;
+    std::mutex mu;
+    std::condition_variable cv, idle_cv;
+    std::function<void(size_t)> fn;
+    size_t n_tasks = 0;
+    std::atomic<size_t> next{0};
+    uint64_t gen = 0;
+    int active = 0;
+    bool quit = false;
+    explicit Workers(int n)
+    {
+        for (int k = 0; k < n; ++k)
+            th.emplace_back([this] {
+                uint64_t seen = 0;
+                std::unique_lock<std::mutex> lk(mu);
+                for (;;) {
+                    cv.wait(lk, [&] { return quit || gen != seen; });
+                    if (quit) return;
+                    seen = gen;
+                    ++active;
+                    lk.unlock();
+                    drain();
+                    lk.lock();
+                    if (--active == 0) idle_cv.notify_all();
+                }
+            });
+    }
+    ~Workers()
+    {
+        { std::lock_guard<std::mutex> lk(mu); quit = true; }
+        cv.notify_all();
+        for (auto& t : th) t.join();
+    }
+    void drain()
+    {
+        for (;;) {
+            const size_t i = next.fetch_add(1);
+            if (i >= n_tasks) return;
+            fn(i);
+        }
+    }
+    // f(0) .. f(n - 1) on the workers and the calling thread; returns when all have returned
+    void run(size_t n, std::function<void(size_t)> f)
+    {
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            idle_cv.wait(lk, [&] { return active == 0; });     // (a worker that woke late for the previous call is through)
+            fn = std::move(f);
+            n_tasks = n;
+            next.store(0);
+            ++gen;
+        }
+        cv.notify_all();
+        drain();
+        std::unique_lock<std::mutex> lk(mu);
+        idle_cv.wait(lk, [&] { return active == 0; });
+        n_tasks = 0;                                         // a worker that wakes from now on finds nothing to do
+    }
+};
 
 namespace {
 struct Tm {                                   // GOLEFT_BAM_TIMING=1: phase wall times on stderr at close
@@ -73,6 +139,8 @@ bool inflate_member(const uint8_t* raw, const Member& m, uint8_t* out)
 }
 
 }  // namespace
+
+BamReader::BamReader() = default;
 
 BamReader::~BamReader()
 {
@@ -144,13 +212,8 @@ BamReader::Chunk BamReader::produce(std::vector<uint8_t> spare)
             }
         };
         const int nt = (int)std::min<size_t>((size_t)threads_, (ms.size() + 15) / 16);
-        if (nt <= 1) {
-            work();
-        } else {
-            std::vector<std::thread> th;
-            for (int t = 0; t < nt; ++t) th.emplace_back(work);
-            for (auto& t : th) t.join();
-        }
+        if (nt <= 1 || !inflate_workers_) work();
+        else inflate_workers_->run((size_t)nt, [&](size_t) { work(); });
         if (bad.load()) { c.err = "BGZF inflate/CRC failure in " + path_; c.data.clear(); c.end = true; return c; }
         raw_.erase(raw_.begin(), raw_.begin() + (ptrdiff_t)off);
         g_tm.inflate += Tm::now() - t0;
@@ -213,6 +276,10 @@ bool BamReader::open(const std::string& path, int threads, std::string* err)
 {
     path_ = path;
     threads_ = threads > 0 ? threads : (int)std::max(1u, std::thread::hardware_concurrency());
+    if (threads_ > 1) {
+        inflate_workers_.reset(new Workers(threads_ - 1));
+        parse_workers_.reset(new Workers(threads_ - 1));
+    }
     if (const char* e = getenv("GOLEFT_BAM_CHUNK_KB")) kChunkBytes = (size_t)std::max(64, atoi(e)) << 10;
     if (const char* e = getenv("GOLEFT_BAM_HEAD_KB")) kHead = (size_t)std::max(0, atoi(e)) << 10;
     fp_ = fopen(path.c_str(), "rb");
@@ -395,15 +462,12 @@ bool record_cigar(const uint8_t* r, uint32_t block_size, const uint8_t** cg_out,
 }
 
 template <typename F>
-void parallel_for(size_t n, int threads, F f)            // f(begin, end) over [0, n)
+void parallel_for(size_t n, int threads, Workers* pool, F f)   // f(begin, end) over [0, n)
 {
     const size_t grain = 1u << 15;
-    const int nt = (int)std::min<size_t>((size_t)std::max(1, threads), (n + grain - 1) / grain);
-    if (nt <= 1) { f((size_t)0, n); return; }
-    std::vector<std::thread> th;
-    for (int t = 0; t < nt; ++t)
-        th.emplace_back([&, t]() { f(n * (size_t)t / (size_t)nt, n * (size_t)(t + 1) / (size_t)nt); });
-    for (auto& t : th) t.join();
+    const size_t nt = std::min<size_t>((size_t)std::max(1, threads), (n + grain - 1) / grain);
+    if (nt <= 1 || !pool) { f((size_t)0, n); return; }
+    pool->run(nt, [&](size_t t) { f(n * t / nt, n * (t + 1) / nt); });
 }
 
 }  // namespace
@@ -466,7 +530,7 @@ int BamReader::next_block(RecordBlock& out, size_t max_reads, std::string* err)
         out.pos.resize(n); out.flag.resize(n); out.mapq.resize(n);
         out.cigar_off.assign(n + 1, 0);
         std::atomic<bool> bad{false};
-        parallel_for(n, threads_, [&](size_t b, size_t e) {
+        parallel_for(n, threads_, parse_workers_.get(), [&](size_t b, size_t e) {
             for (size_t i = b; i < e; ++i) {
                 const uint8_t* r = base + at[i];
                 const uint8_t* cg;
@@ -485,7 +549,7 @@ int BamReader::next_block(RecordBlock& out, size_t max_reads, std::string* err)
         for (size_t i = 0; i < n; ++i) { tot += out.cigar_off[i + 1]; out.cigar_off[i + 1] = (uint32_t)tot; }
         if (tot > 0xffffffffull) { if (err) *err = "more than 2^32 CIGAR ops in one block"; return -1; }
         out.cigar.resize((size_t)tot);
-        parallel_for(n, threads_, [&](size_t b, size_t e) {
+        parallel_for(n, threads_, parse_workers_.get(), [&](size_t b, size_t e) {
             for (size_t i = b; i < e; ++i) {
                 const uint8_t* r = base + at[i];
                 const uint8_t* cg;

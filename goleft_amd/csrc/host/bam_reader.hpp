@@ -10,10 +10,13 @@
 #include <cstdint>
 #include <cstdio>
 #include <future>
+#include <memory>
 #include <string>
 #include <vector>
 
 namespace gdh {
+
+struct Workers;                                 // persistent worker threads (bam_reader.cpp)
 
 struct BamContig {
     std::string name;
@@ -39,7 +42,7 @@ struct RecordBlock {
 
 class BamReader {
 public:
-    BamReader() = default;
+    BamReader();
     ~BamReader();
     BamReader(const BamReader&) = delete;
     BamReader& operator=(const BamReader&) = delete;
@@ -86,6 +89,8 @@ private:
     FILE* fp_ = nullptr;
     std::string path_;
     int threads_ = 1;
+    // two sets: the producer inflates the next batch (on the prefetch thread) while the consumer extracts the records of this one
+    std::unique_ptr<Workers> inflate_workers_, parse_workers_;
     bool eof_ = false;                        // producer: the file is exhausted
     bool done_ = false;                       // consumer: the last batch has been appended
     std::future<Chunk> prefetch_;
