@@ -166,7 +166,9 @@ BamReader::Chunk BamReader::produce(std::vector<uint8_t> spare)
     c.data = std::move(spare);                           // recycled pages: no fresh page faults per batch
     c.data.clear();
     if (eof_ && raw_.empty()) { c.end = true; return c; }
-    const size_t kChunk = kChunkBytes;
+    // the first batch after open / seek is small: whoever only wants the header (goleft-depth with the device decoder)
+    // does not pay for 64 MB of BGZF, and the first records arrive sooner
+    const size_t kChunk = n_batches_++ == 0 ? std::min<size_t>(kChunkBytes, 1u << 20) : kChunkBytes;
     for (;;) {
         double t0 = Tm::now();
         if (!eof_) {
@@ -212,8 +214,12 @@ BamReader::Chunk BamReader::produce(std::vector<uint8_t> spare)
             }
         };
         const int nt = (int)std::min<size_t>((size_t)threads_, (ms.size() + 15) / 16);
-        if (nt <= 1 || !inflate_workers_) work();
-        else inflate_workers_->run((size_t)nt, [&](size_t) { work(); });
+        if (nt <= 1) {
+            work();
+        } else {
+            if (!inflate_workers_) inflate_workers_.reset(new Workers(threads_ - 1));
+            inflate_workers_->run((size_t)nt, [&](size_t) { work(); });
+        }
         if (bad.load()) { c.err = "BGZF inflate/CRC failure in " + path_; c.data.clear(); c.end = true; return c; }
         raw_.erase(raw_.begin(), raw_.begin() + (ptrdiff_t)off);
         g_tm.inflate += Tm::now() - t0;
@@ -230,7 +236,7 @@ bool BamReader::fill(std::string* err)
 {
     if (done_) return false;
     double t0 = Tm::now();
-    Chunk c = prefetch_.valid() ? prefetch_.get() : produce(std::vector<uint8_t>());
+    Chunk c = prefetch_.valid() ? prefetch_.get() : produce(std::move(spare_));
     g_tm.wait += Tm::now() - t0;
     t0 = Tm::now();
     if (!c.err.empty()) { if (err) *err = c.err; done_ = true; return false; }
@@ -252,7 +258,9 @@ bool BamReader::fill(std::string* err)
         spare = std::move(c.data);
     }
     g_tm.append += Tm::now() - t0;
-    // one batch ahead, into the buffer just emptied
+    // one batch ahead, into the buffer just emptied -- from the second batch on: nothing is read ahead of the first
+    // (small) one, so that opening a file for its header leaves the cores alone
+    if (n_fills_++ == 0) { spare_ = std::move(spare); return true; }
     prefetch_ = std::async(std::launch::async,
                            [this](std::vector<uint8_t> sp) { return produce(std::move(sp)); }, std::move(spare));
     return true;
@@ -276,10 +284,8 @@ bool BamReader::open(const std::string& path, int threads, std::string* err)
 {
     path_ = path;
     threads_ = threads > 0 ? threads : (int)std::max(1u, std::thread::hardware_concurrency());
-    if (threads_ > 1) {
-        inflate_workers_.reset(new Workers(threads_ - 1));
-        parse_workers_.reset(new Workers(threads_ - 1));
-    }
+    inflate_workers_.reset();                            // (started by the first batch that has work for them)
+    parse_workers_.reset();
     if (const char* e = getenv("GOLEFT_BAM_CHUNK_KB")) kChunkBytes = (size_t)std::max(64, atoi(e)) << 10;
     if (const char* e = getenv("GOLEFT_BAM_HEAD_KB")) kHead = (size_t)std::max(0, atoi(e)) << 10;
     fp_ = fopen(path.c_str(), "rb");
@@ -410,6 +416,8 @@ bool BamReader::seek_contig(int32_t tid, std::string* err)
     cur_ = 0;
     eof_ = false;
     done_ = false;
+    n_batches_ = 0;
+    n_fills_ = 0;
     if (!need(uoff + 1, err)) return false;
     cur_ += uoff;
     left_.assign(contigs_.size(), false);         // a deliberate jump: the run rule starts over
@@ -530,6 +538,7 @@ int BamReader::next_block(RecordBlock& out, size_t max_reads, std::string* err)
         out.pos.resize(n); out.flag.resize(n); out.mapq.resize(n);
         out.cigar_off.assign(n + 1, 0);
         std::atomic<bool> bad{false};
+        if (!parse_workers_ && threads_ > 1 && n > (1u << 15)) parse_workers_.reset(new Workers(threads_ - 1));
         parallel_for(n, threads_, parse_workers_.get(), [&](size_t b, size_t e) {
             for (size_t i = b; i < e; ++i) {
                 const uint8_t* r = base + at[i];

@@ -93,6 +93,9 @@ private:
     std::unique_ptr<Workers> inflate_workers_, parse_workers_;
     bool eof_ = false;                        // producer: the file is exhausted
     bool done_ = false;                       // consumer: the last batch has been appended
+    size_t n_fills_ = 0;                      // batches taken over by the consumer since open / seek
+    size_t n_batches_ = 0;                    // batches produced since open / seek: the first one is small and nothing is read ahead of it
+    std::vector<uint8_t> spare_;              // the buffer the next batch will be inflated into
     std::future<Chunk> prefetch_;
     std::vector<uint8_t> raw_;                // compressed batch
     std::vector<uint8_t> buf_;                // decoded bytes not yet consumed
