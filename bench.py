@@ -500,26 +500,141 @@ def run_case(args, scaling, world, rank, dev, local_rank, want_streams=False):
     return res
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment: THIS process is the launcher.
+    It starts N copies of itself, one rank per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 /
+    MASTER_PORT set, everything else inherited -- the environment `torch.distributed.run` would give them), waits
+    for all of them and exits with the first non-zero status.  It refuses to start when the node has fewer than N
+    devices: N ranks on fewer GPUs is not an N-GPU measurement (the reference's counterpart is the `-p` worker
+    pool, depth/depth.go:392-394).  GOLEFT_BENCH_SINGLE_DEVICE=1 (dry run, every rank on device 0) and
+    GOLEFT_BENCH_STUB=1 (CPU test of this launcher) lift that check and say so in the line."""
+    import socket
+    import subprocess
+    n = args.gpus
+    stub = os.environ.get("GOLEFT_BENCH_STUB") == "1"
+    if not stub:
+        import torch
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if os.environ.get("GOLEFT_BENCH_SINGLE_DEVICE") == "1":
+            if have < 1:
+                raise SystemExit("bench.py --gpus %d (single-device dry run): no GPU visible" % n)
+        elif have < n:
+            raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible on this node -- refusing to run %d ranks on "
+                             "fewer devices (that would not be an %d-GPU measurement)" % (n, have, n, n))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), GOLEFT_BENCH_LAUNCHER="self")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    alive = set(range(n))
+    while alive:
+        for r in sorted(alive):
+            c = procs[r].poll()
+            if c is None:
+                continue
+            alive.discard(r)
+            if c != 0 and rc == 0:
+                rc = c if c > 0 else 1
+                sys.stderr.write("bench.py: rank %d exited with status %d; stopping the other ranks\n" % (r, c))
+                for q in alive:
+                    procs[q].terminate()                # exactly the processes started above
+        if alive:
+            time.sleep(0.05)
+    raise SystemExit(rc)
+
+
+def stub_rank(args, world, rank):
+    """GOLEFT_BENCH_STUB=1: the launcher and the rendezvous without an engine (tests/test_bench_launcher.py).
+    Every rank joins a gloo group, runs `steps` trivial steps between the same barriers as the real loop and
+    rank 0 prints a line that cannot be mistaken for a measurement (value null, data "stub")."""
+    import torch
+    import torch.distributed as dist
+    if os.environ.get("GOLEFT_BENCH_STUB_FAIL_RANK") == str(rank):
+        raise SystemExit(7)                             # (the test of the launcher's failure handling)
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    seen = who_took_part(world, rank, "cpu:%d" % os.getpid())
+    acc = np.zeros(16, np.int64)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        acc += k
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(dict({"metric": "stub (launcher test, nothing measured)", "value": None, "unit": "ref-bases/s",
+                               "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                               "ms_per_step": dt / max(1, args.steps) * 1e3, "data": "stub"}, **seen)))
+
+
+def who_took_part(world, rank, my_device):
+    """The ranks and devices that really joined the process group, collected through it: `n_gpus` in the line is
+    only believable when `ranks_seen` == --gpus and `devices_seen` names that many DIFFERENT devices."""
+    if world == 1:
+        return {"ranks_seen": 1, "devices_seen": [my_device], "distinct_devices": 1,
+                "launcher": os.environ.get("GOLEFT_BENCH_LAUNCHER", "none")}
+    import torch.distributed as dist
+    got = [None] * world
+    dist.all_gather_object(got, (rank, my_device))
+    assert dist.get_world_size() == world
+    ranks = sorted(g[0] for g in got)
+    devs = [g[1] for g in sorted(got)]
+    return {"ranks_seen": len(set(ranks)), "devices_seen": devs, "distinct_devices": len(set(devs)),
+            "launcher": os.environ.get("GOLEFT_BENCH_LAUNCHER", "torch.distributed.run or another external launcher")}
+
+
+def device_identity(torch, index):
+    p = torch.cuda.get_device_properties(index)
+    u = getattr(p, "uuid", None)
+    bus = "%04x:%02x:%02x" % (getattr(p, "pci_domain_id", 0), getattr(p, "pci_bus_id", 0), getattr(p, "pci_device_id", 0))
+    return "%s@%s#%d" % (u if u is not None else p.name, bus, index)
+
+
 def main():
     args = parse()
     if args.coverage is None:
         args.coverage = 20.0 if args.workload.startswith("ont") else 30.0
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        launch_ranks(args)                              # never returns
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        # an external launcher started a different number of ranks than --gpus asks for: the line's n_gpus would
+        # contradict the command line either way
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if os.environ.get("GOLEFT_BENCH_STUB") == "1":
+        return stub_rank(args, world, rank)
     import torch
     import torch.distributed as dist
     from goleft_amd import synth
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # dry-run hooks for the 1-GPU dev box (the multi-process control flow with every rank on
     # device 0 over gloo); the driver's real runs use one GPU per rank over RCCL
     backend = os.environ.get("GOLEFT_BENCH_BACKEND", "nccl")
-    if os.environ.get("GOLEFT_BENCH_SINGLE_DEVICE") == "1":
+    single = os.environ.get("GOLEFT_BENCH_SINGLE_DEVICE") == "1"
+    if single:
         local_rank = 0
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the engine has no CPU fallback)")
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit("bench.py: rank %d wants device %d but only %d GPU(s) are visible"
+                         % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -527,6 +642,12 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+    took_part = who_took_part(world, rank, device_identity(torch, local_rank))
+    if single and world > 1:
+        took_part["launcher"] += " (GOLEFT_BENCH_SINGLE_DEVICE=1: every rank on device 0 -- a dry run of the control flow, not a measurement)"
+    if world > 1 and not single and took_part["distinct_devices"] != world:
+        raise SystemExit("bench.py --gpus %d: the %d ranks sit on %d distinct device(s) %s -- not an %d-GPU run"
+                         % (args.gpus, world, took_part["distinct_devices"], took_part["devices_seen"], world))
 
     r = run_case(args, args.scaling, world, rank, dev, local_rank, want_streams=True)
     eng, streams, names, lengths, mine = r["eng"], r["streams"], r["names"], r["lengths"], r["mine"]
@@ -578,6 +699,10 @@ def main():
         "value": value,
         "unit": "ref-bases/s",
         "n_gpus": world,
+        "ranks_seen": took_part["ranks_seen"],
+        "devices_seen": took_part["devices_seen"],
+        "distinct_devices": took_part["distinct_devices"],
+        "launcher": took_part["launcher"],
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3,

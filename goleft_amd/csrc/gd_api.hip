@@ -246,7 +246,7 @@ int gd_select_contigs(gd_ctx* c, int n, const int32_t* tids)
 namespace {
 struct FillPool {
     // kind 0: plain copy; 1: int32 positions, copied and checked (non-decreasing from `prev`, not negative);
-    // 2: 32-bit CSR offsets, rebased by -sub and checked (non-decreasing); 3 / 4: the checks of 1 / 2 alone (gd_commit:
+    // 2: 32-bit CSR offsets, rebased by -sub and checked (non-decreasing from `prev`); 3 / 4: the checks of 1 / 2 alone (gd_commit:
     // the caller filled the block itself); 5: `bytes` from offset `src` of the file descriptor `sub` (gd_ingest_feed_fd)
     struct Item { void* dst; const void* src; size_t bytes; uint32_t sub; int kind; int32_t prev; };
     std::atomic<uint32_t> bad{0};
@@ -287,7 +287,9 @@ struct FillPool {
         } else {
             uint32_t* __restrict__ d = static_cast<uint32_t*>(it.dst);
             const uint32_t* __restrict__ s = static_cast<const uint32_t*>(it.src);
-            if (n) d[0] = s[0] - it.sub;
+            // (`prev` = the offset in front of this item, as bits: items are cut every 1 MB without overlap, and a dip exactly
+            // at a cut -- possibly below `sub`, so that the rebased offset wraps -- must not pass)
+            if (n) { wrong = (uint32_t)(s[0] < (uint32_t)it.prev); d[0] = s[0] - it.sub; }
             for (size_t k = 1; k < n; ++k) { wrong |= (uint32_t)(s[k] < s[k - 1]); d[k] = s[k] - it.sub; }
         }
         if (wrong) bad.store(1);
@@ -578,6 +580,7 @@ int gd_push(gd_ctx* c, int32_t tid, const int32_t* pos, const uint16_t* flag, co
             for (size_t at = 0; at < bytes; at += piece) {
                 FillPool::Item it{static_cast<char*>(dst) + at, static_cast<const char*>(src) + at, std::min(piece, bytes - at), sub, kind, 0};
                 if (kind == 1) it.prev = at ? reinterpret_cast<const int32_t*>(static_cast<const char*>(src) + at)[-1] : before;
+                if (kind == 2) it.prev = at ? reinterpret_cast<const int32_t*>(static_cast<const char*>(src) + at)[-1] : (int32_t)sub;
                 work.push_back(it);
             }
         };

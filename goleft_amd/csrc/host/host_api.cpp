@@ -74,6 +74,7 @@ int gdh_produce_in_place(void* vctx, int32_t tid, const int32_t* pos, const uint
         if (i >= n_reads) { done = true; return GD_OK; }
         n = std::min(chunk, n_reads - i);
         o0 = cigar_off[i]; o1 = cigar_off[i + n];
+        if (o1 < o0 || o1 > n_ops) return GD_E_INVALID;   // (before anything is sized or copied by these offsets)
         return gd_acquire(ctx, n, o1 - o0, &b);
     };
     if (int r = next_block()) return r;
@@ -87,6 +88,9 @@ int gdh_produce_in_place(void* vctx, int32_t tid, const int32_t* pos, const uint
         for (size_t r = a; r < e; ++r) b.cigar_off[r] = so[r] - (uint32_t)o0;
         if (e == n) b.cigar_off[n] = so[n] - (uint32_t)o0;
         const size_t ca = so[a], ce = so[e];
+        // a share's ops must lie inside the block's [o0, o1): offsets that leave it would write outside the pinned block
+        // before gd_commit's validation ever sees them
+        if (ca < o0 || ce > o1 || ce < ca) { status.store(GD_E_INVALID); return; }
         if (ce > ca) memcpy(b.cigar + (ca - o0), cigar + ca, (ce - ca) * sizeof(uint32_t));
     };
     auto worker = [&](int k) {
@@ -95,7 +99,8 @@ int gdh_produce_in_place(void* vctx, int32_t tid, const int32_t* pos, const uint
             part(k);
             // barrier: the last producer to arrive commits the block and acquires the next
             if (arrived.fetch_add(1) + 1 == threads) {
-                int rc = gd_commit(ctx, &b, tid, n, o1 - o0);
+                int rc = status.load();
+                if (rc == GD_OK) rc = gd_commit(ctx, &b, tid, n, o1 - o0);
                 i += n;
                 if (rc == GD_OK) rc = next_block(); else done = true;
                 if (rc != GD_OK) { status.store(rc); done = true; }

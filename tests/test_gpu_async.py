@@ -118,3 +118,38 @@ def test_producers_fill_the_ring_in_place_and_push_agree():
         eng.push(0, r.pos, r.flag, r.mapq, r.cigar_off, r.cigar)
         eng.compute()
         assert np.array_equal(eng.perbase(0), want)
+
+
+def test_csr_offsets_that_dip_exactly_at_a_work_item_cut_are_refused():
+    """gd_push's filler threads cut the CSR offsets into 1 MB work items (262 144 offsets) without
+    overlap; a decrease exactly at a cut -- even below the block's first offset, so that the rebased value wraps --
+    must be refused like any other (GD_E_INVALID), by gd_push and by the in-place producer, and nothing may be
+    written outside the pinned block on the way."""
+    import numpy as np
+    from goleft_amd import _hostlib, synth
+    from goleft_amd.engine import DepthEngine, GdError
+    from oracle import pyoracle as po
+    L = 2_500_000
+    r = po.Reads(*synth.short_reads_numpy(L, synth.n_reads_for(L), 11))
+    assert r.n > 2 * 262144 + 10
+    host = _hostlib.load()
+    with DepthEngine(0) as eng:
+        eng.set_params(window_size=1000)
+        eng.set_contigs([L, L])
+        pos, flag, mapq = (np.ascontiguousarray(a[5:]) for a in (r.pos, r.flag, r.mapq))   # (block offsets start above 0)
+        assert r.cigar_off[5] >= 5
+        for cut, low in ((262144, 3), (2 * 262144, 0), (262144, None)):
+            bad = r.cigar_off[5:].copy()
+            bad[cut] = bad[cut - 1] - 1 if low is None else low     # below its predecessor; `low` is below the block's start too
+            eng.reset()
+            with pytest.raises(GdError) as ei:
+                eng.push(0, pos, flag, mapq, bad, r.cigar)
+            assert ei.value.status == -1, ei.value.status
+            eng.reset()
+            rc = host.gdh_produce_in_place(eng._ctx, 1, pos.ctypes.data, flag.ctypes.data, mapq.ctypes.data,
+                                           bad.ctypes.data, r.cigar.ctypes.data, len(pos), r.n_ops, 7, 1 << 20)
+            assert rc == -1, rc
+        eng.reset()
+        eng.push(0, r.pos, r.flag, r.mapq, r.cigar_off, r.cigar)
+        eng.compute()
+        assert np.array_equal(eng.perbase(0), po.perbase_c(r, 1, 0, L))
