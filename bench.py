@@ -290,6 +290,28 @@ def run_case(args, scaling, world, rank, dev, local_rank, want_streams=False):
     # needs them; the short-read tile path needs none
     derive = ont                                    # (the cohort's streaming sums read the records as they arrived)
 
+    # ---- the COLD step: what ONE `goleft depth` run pays -- this context has never computed anything ----------
+    # fresh context -> gd_adopt_device (above) -> ONE gd_compute with the default max_span_hint.  Device allocations
+    # of the result arrays (gd_compute_timing's prepare share) are reported separately: `ms` is the rest.
+    first = None
+    if world == 1:
+        eng.set_profiling(True)
+        t1 = time.perf_counter()
+        eng.compute()
+        wall = time.perf_counter() - t1
+        tm = eng.compute_timing()
+        st1 = eng.stats()
+        first = {"what": "fresh context, records adopted, ONE gd_compute (default max_span_hint): wall clock minus the "
+                         "device allocations of the result arrays (prepare_alloc_ms), which only a context's first "
+                         "compute of a job size pays",
+                 "ms": (wall - tm["prepare_s"]) * 1e3, "wall_ms": wall * 1e3, "prepare_alloc_ms": tm["prepare_s"] * 1e3,
+                 "enqueue_ms": tm["enqueue_s"] * 1e3, "wait_ms": tm["wait_s"] * 1e3,
+                 "kernels_ms": {"prep": eng.kernel_ms(K_PREP), "tile": eng.kernel_ms(K_TILE), "runs": eng.kernel_ms(K_RUNS),
+                                "long_read_structures": eng.kernel_ms(K_CKPT)},
+                 "slow_tiles": int(st1.n_slow_tiles), "lookback": int(st1.lookback), "reruns": int(st1.reruns),
+                 "max_span_seen": int(st1.max_span_seen), "kernel": TK_NAMES[int(st1.tile_kernel)]}
+        eng.set_profiling(False)
+
     wed = {}
     gath = None
     if exchange:
@@ -493,7 +515,7 @@ def run_case(args, scaling, world, rank, dev, local_rank, want_streams=False):
         "expand_ms": float(np.mean(expand_ms)), "scan_ms": float(np.mean(scan_ms)), "path": int(st.path),
         "ckpt_ms": float(np.mean(ckpt_ms)), "norm_ms": float(np.mean(norm_ms)), "only": only, "derive": derive,
         "n_canonical_ops": incl_canon, "n_slow_tiles": incl_slow, "kernel": TK_NAMES[incl_kernel],
-        "perbase": not cohort, "wed_shape": wed.get("shape"), "split": split, "emu": emu,
+        "perbase": not cohort, "wed_shape": wed.get("shape"), "split": split, "emu": emu, "first": first,
     }
     if not want_streams:
         streams.clear()
@@ -659,8 +681,13 @@ def main():
     # (the raw straight-line kernel reads flag 2 + MAPQ 1 per read too and the ops as they arrived)
     ops_read = r["n_canonical_ops"] if r["n_canonical_ops"] else r["n_ops"]
     raw_records = r["kernel"].endswith("<raw>")
+    # `achieved` / `frac` are on SURVEY.md 8(d)'s formula, CSR term included (the offsets are read on device):
+    # 4 reads + 4 reads + 4 ops + 4 bases + 8 windows.  The raw kernel really reads 3 B per read more (flag 2 + MAPQ 1);
+    # counting those too gives `frac_bytes_really_read`.
     alg_bytes = synth.algorithmic_bytes(r["n_reads"], ops_read, r["my_bases"] if r["perbase"] else 0,
-                                        r["my_windows"], raw=raw_records)   # windows-only: no 4 B/base write
+                                        r["my_windows"], raw=False)         # windows-only: no 4 B/base write
+    alg_bytes_read = synth.algorithmic_bytes(r["n_reads"], ops_read, r["my_bases"] if r["perbase"] else 0,
+                                             r["my_windows"], raw=raw_records)
     scatter = r["path"] == 2
     chunk = r["path"] == 3
     # tile path: gd_tile_kernel does all the arithmetic; chunk path: the long-read tile kernel (the CIGAR
@@ -735,6 +762,10 @@ def main():
                    "device_path": "scatter" if scatter else "chunk" if chunk else "tile"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                     "formula": "SURVEY.md 8(d): 4 B/read pos + 4 B/read CSR offset + 4 B/op + 4 B/ref-base + 8 B/window",
+                     "frac_survey_8d": achieved / HBM_PEAK_GBPS,
+                     "frac_bytes_really_read": alg_bytes_read / avg_tile_s / 1e9 / HBM_PEAK_GBPS,
+                     "bytes_really_read_per_launch": alg_bytes_read,
                      "kernel": kname,
                      "avg_kernel_ms": avg_tile_s * 1e3,
                      "algorithmic_bytes_per_launch": alg_bytes,
@@ -746,12 +777,14 @@ def main():
                        if chunk else {"prep": r["prep_ms"], "tile": r["tile_ms"], "runs": r["runs_ms"]}),
         "with_d2h_windows_ref_bases_per_s": r["my_bases"] / (dt / args.steps + d2h) if world == 1 else None,
     }
+    if r.get("first"):
+        out["first_compute"] = dict(r["first"], warm_ms_per_step=dt / args.steps * 1e3,
+                                    ratio_to_warm=r["first"]["ms"] / (dt / args.steps * 1e3))
     o = r["only"]
     if o is not None:
         # the step with the derived structures kept (round 2's headline), and what building them costs
         ops_o = o["n_canonical_ops"] if o["n_canonical_ops"] else r["n_ops"]
-        alg_o = synth.algorithmic_bytes(r["n_reads"], ops_o, r["my_bases"] if r["perbase"] else 0, r["my_windows"],
-                                        raw=o["kernel"].endswith("<raw>"))
+        alg_o = synth.algorithmic_bytes(r["n_reads"], ops_o, r["my_bases"] if r["perbase"] else 0, r["my_windows"], raw=False)
         out["compute_only"] = {
             "value": r["total_bases"] * args.steps / o["dt"], "unit": "ref-bases/s", "ms_per_step": o["dt"] / args.steps * 1e3,
             "what": "the same step with canonical records / long-read structures kept from step to step",

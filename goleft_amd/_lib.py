@@ -111,6 +111,7 @@ SYMBOLS = {
     "gd_get_stats": (C.c_int, [_P, C.POINTER(GdStats)]),
     "gd_set_profiling": (C.c_int, [_P, C.c_int]),
     "gd_kernel_ms": (C.c_int, [_P, C.c_int, C.POINTER(C.c_float)]),
+    "gd_compute_timing": (C.c_int, [_P, C.POINTER(C.c_double), C.c_int]),
 }
 
 _LIB = None

@@ -100,6 +100,8 @@ int gd_create(int device_id, gd_ctx** out)
     if ((e = hipHostMalloc(reinterpret_cast<void**>(&c->h_counters), sizeof(gd::Counters), hipHostMallocDefault)) != hipSuccess) return bail(e);
     if ((e = hipHostMalloc(reinterpret_cast<void**>(&c->h_bounds), kSpecBounds * sizeof(int2), hipHostMallocDefault)) != hipSuccess) return bail(e);
     if ((e = hipMemset(c->d_counters, 0, sizeof(gd::Counters))) != hipSuccess) return bail(e);
+    if ((e = hipMalloc(reinterpret_cast<void**>(&c->d_ingest), 4 * sizeof(uint32_t))) != hipSuccess) return bail(e);
+    if ((e = hipMemset(c->d_ingest, 0, 4 * sizeof(uint32_t))) != hipSuccess) return bail(e);
     *out = c;
     return GD_OK;
 }
@@ -135,7 +137,7 @@ void gd_destroy(gd_ctx* c)
     if (c->copy_done) (void)hipEventDestroy(c->copy_done);
     void* frees[] = {c->d_ctgs, c->d_tiles, c->d_ftiles, c->d_perbase, c->d_wsum, c->d_wmin, c->d_chunks,
                      c->d_ordered, c->d_tile_cnt, c->d_tile_off, c->d_super_cnt, c->d_counters,
-                     c->d_region_cursor, c->d_status, c->d_seq, c->d_md_bits, c->d_md_cnt, c->d_wed, c->d_scan_tmp};
+                     c->d_region_cursor, c->d_status, c->d_seq, c->d_md_bits, c->d_md_cnt, c->d_wed, c->d_scan_tmp, c->d_ingest};
     for (void* p : frees) if (p) (void)hipFree(p);
     if (c->h_counters) (void)hipHostFree(c->h_counters);
     if (c->h_bounds) (void)hipHostFree(c->h_bounds);
@@ -224,6 +226,9 @@ int gd_set_contigs(gd_ctx* c, int n, const int64_t* lengths)
     // a new data set: forget the look-back learnt from the previous one
     c->lookback = c->params.max_span_hint > 0 ? c->params.max_span_hint : kDefaultLookback;
     c->span_forces_long = false;
+    HIPCHK(c, hipMemsetAsync(c->d_ingest, 0, 4 * sizeof(uint32_t), c->stream));   // spans of records that are gone
+    c->ingest_span = 0;
+    c->ingest_span_dirty = false;
     return GD_OK;
 }
 
@@ -364,6 +369,43 @@ FillPool* ctx_pool(gd_ctx* c)
 }
 }  // namespace
 
+
+// gd_index_records_kernel over the reads [r0, r1) of a contig that are resident (or will be, in stream order) on `st`:
+// position index (allocated on first use), spans, and -- check != 0 -- the record checks.
+static int index_records(gd_ctx* c, ContigHost& h, size_t r0, size_t r1, int32_t prev_pos, bool check, hipStream_t st)
+{
+    if (r1 <= r0) return GD_OK;
+    const size_t n_idx = (size_t)(h.length >> 6) + 2;
+    const bool idx = c->ingest_index && h.ridx_reads == r0;      // (an index with a hole is no index)
+    if (idx && !h.ridx) HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&h.ridx), n_idx * sizeof(uint32_t)));
+    if (!idx && !check) return GD_OK;
+    gd::norm::IndexJob j{};
+    j.pos = h.pos; j.off = h.off; j.cigar = h.cigar;
+    j.ridx = idx ? h.ridx : nullptr;
+    j.n_idx = (uint32_t)n_idx;
+    j.out = c->d_ingest;
+    j.r0 = (uint32_t)r0; j.r1 = (uint32_t)r1;
+    j.n_reads_total = (uint32_t)r1;
+    j.n_ops_total = (uint32_t)std::min<size_t>(h.n_ops, 0xffffffffu);
+    j.prev_pos = r0 ? prev_pos : -1;
+    j.check = check ? 1u : 0u;
+    // spans are measured for short-read shaped data only (a lane walks its read's ops one by one)
+    j.walk_ops = (c->ingest_index && h.n_ops <= 6 * h.n_reads) ? 1u : 0u;
+    hipLaunchKernelGGL(gd::norm::gd_index_records_kernel, dim3((unsigned)((r1 - r0 + 255) / 256)), dim3(256), 0, st, j);
+    HIPCHK(c, hipGetLastError());
+    if (idx) h.ridx_reads = r1;
+    if (j.walk_ops) c->ingest_span_dirty = true;
+    return GD_OK;
+}
+
+// The spans the index kernel has measured so far become the look-back of the next gd_compute (verified there as ever).
+static void take_ingest_span(gd_ctx* c, int32_t span)
+{
+    c->ingest_span_dirty = false;
+    if (span <= 0 || span == c->ingest_span) return;
+    c->ingest_span = span;
+    if (!c->lookback_pinned && span <= kAutoLongSpan) c->lookback = std::max(64, (span + 63) & ~63);
+}
 
 int gd_acquire(gd_ctx* c, size_t reads_cap, size_t ops_cap, gd_batch* out)
 {
@@ -532,6 +574,15 @@ static int commit_block(gd_ctx* c, const gd_batch* b, int32_t tid, size_t n_read
         if (n_ops)
             HIPCHK(c, hipMemcpyAsync(h.cigar + h.n_ops, b->cigar, n_ops * sizeof(uint32_t), hipMemcpyHostToDevice, cs));
     }
+    {
+        // the block is part of the contig's stream now (in copy-stream order): index it, measure its spans
+        const size_t r0 = h.n_reads;
+        const int32_t before = h.last_pos;
+        h.n_ops += n_ops;                                  // (index_records reads the contig's totals)
+        const int ri = index_records(c, h, r0, r0 + n_reads, before, false, cs);
+        h.n_ops -= n_ops;
+        if (ri) return ri;
+    }
     HIPCHK(c, hipEventRecord(s.done, cs));
     s.busy = true;
     if (h.normed || h.ck_ok) {                          // the canonical CIGARs / checkpoints no longer cover the stream
@@ -625,26 +676,36 @@ int gd_adopt_device(gd_ctx* c, int32_t tid, const gd_batch* d, size_t n_reads, s
     // stream of the caller produced them must have finished.  A device-wide wait makes that true for
     // any producer (a few microseconds per contig, at ingest time).
     HIPCHK(c, hipDeviceSynchronize());
-    if (n_reads) {
-        // what gd_commit checks on a host block, here in one pass over pos / cigar_off on the device
-        if (int r = ensure_dev(c, &c->d_scan_tmp, &c->cap_scan_tmp, 1)) return r;
-        uint32_t bad = 0;
-        HIPCHK(c, hipMemsetAsync(c->d_scan_tmp, 0, sizeof(uint32_t), c->stream));
-        hipLaunchKernelGGL(gd::norm::gd_check_records_kernel, dim3((unsigned)((n_reads + 255) / 256)), dim3(256), 0, c->stream,
-                           d->pos, d->cigar_off, (uint32_t)n_reads, (uint32_t)n_ops, c->d_scan_tmp);
-        HIPCHK(c, hipMemcpyAsync(&bad, c->d_scan_tmp, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        if (bad & 4u) return fail(c, GD_E_RANGE, "contig %d: a device record has a negative position (a placed BAM record has POS >= 0)", tid);
-        if (bad & 1u) return fail(c, GD_E_UNSORTED, "contig %d: device records not coordinate sorted", tid);
-        if (bad & 2u) return fail(c, GD_E_INVALID, "contig %d: CSR offsets of the device records are not a non-decreasing sequence from 0 to at most %zu", tid, n_ops);
-    }
     ContigHost& h = c->contigs[tid];
-    int64_t len = h.length;
+    ContigHost t;                                          // the new stream, checked before the old one is let go
+    t.length = h.length;
+    t.pos = d->pos; t.flag = d->flag; t.mapq = d->mapq; t.off = d->cigar_off; t.cigar = d->cigar;
+    t.n_reads = n_reads; t.n_ops = n_ops;
+    t.adopted = true;
+    if (n_reads) {
+        // what gd_commit checks on a host block, here in one pass over pos / cigar_off on the device -- the same pass
+        // leaves the position index and the largest span (gd_index_records_kernel)
+        uint32_t w[3] = {0, 0, 0};
+        int r = GD_OK;
+        if (hipMemsetAsync(c->d_ingest, 0, sizeof(uint32_t), c->stream) != hipSuccess) r = fail(c, GD_E_HIP, "hipMemsetAsync failed");
+        if (r == GD_OK) r = index_records(c, t, 0, n_reads, -1, true, c->stream);
+        if (r == GD_OK) {
+            hipError_t e = hipMemcpyAsync(w, c->d_ingest, sizeof w, hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+            if (e != hipSuccess) r = fail(c, GD_E_HIP, "reading the record check back failed: %s", hipGetErrorString(e));
+        }
+        if (r == GD_OK) {
+            const uint32_t bad = w[0];
+            if (bad & 4u) r = fail(c, GD_E_RANGE, "contig %d: a device record has a negative position (a placed BAM record has POS >= 0)", tid);
+            else if (bad & 1u) r = fail(c, GD_E_UNSORTED, "contig %d: device records not coordinate sorted", tid);
+            else if (bad & 2u) r = fail(c, GD_E_INVALID, "contig %d: CSR offsets of the device records are not a non-decreasing sequence from 0 to at most %zu", tid, n_ops);
+        }
+        if (r != GD_OK) { free_contig(t); return r; }      // (the contig keeps what it held)
+        t.last_pos = (int32_t)w[2];
+        take_ingest_span(c, (int32_t)w[1]);
+    }
     free_contig(h);
-    h.length = len;
-    h.pos = d->pos; h.flag = d->flag; h.mapq = d->mapq; h.off = d->cigar_off; h.cigar = d->cigar;
-    h.n_reads = n_reads; h.n_ops = n_ops;
-    h.adopted = true;
+    h = t;
     c->computed = false;
     // GD_OPT_NORMALIZE = 1: canonical records are built as part of taking the records in
     if (n_reads && wants_norm(c, n_reads, n_ops))
@@ -668,6 +729,9 @@ int gd_reset(gd_ctx* c)
     c->computed = false;
     c->lookback = c->params.max_span_hint > 0 ? c->params.max_span_hint : kDefaultLookback;
     c->span_forces_long = false;
+    HIPCHK(c, hipMemsetAsync(c->d_ingest, 0, 4 * sizeof(uint32_t), c->stream));   // spans of records that are gone
+    c->ingest_span = 0;
+    c->ingest_span_dirty = false;
     return GD_OK;
 }
 
@@ -771,6 +835,7 @@ int gd_set_option(gd_ctx* c, int option, int64_t value)
         if (value < 1 || value > 64) return fail(c, GD_E_INVALID, "push threads: 1..64");
         c->push_threads = (int)value;
         break;
+    case GD_OPT_INGEST_INDEX: c->ingest_index = value != 0; break;
     default: return fail(c, GD_E_INVALID, "unknown option %d", option);
     }
     c->computed = false;
@@ -796,6 +861,13 @@ int gd_get_stats(gd_ctx* c, gd_stats* out)
 {
     if (!c || !out) return GD_E_INVALID;
     *out = c->stats;
+    return GD_OK;
+}
+
+int gd_compute_timing(gd_ctx* c, double* seconds, int n)
+{
+    if (!c || !seconds || n < 0) return GD_E_INVALID;
+    for (int i = 0; i < n; ++i) seconds[i] = i < 4 ? c->timing[i] : 0.0;
     return GD_OK;
 }
 

@@ -58,6 +58,9 @@ struct ContigHost {
     int32_t   max_span = 0;
     uint64_t  n_dels = 0;              // deletions in dl
     bool ck_ok = false;                // lrec / lfq / dl / pck describe the current records
+    // built as the records arrive (gd_index_records_kernel): the same position index without canonical records
+    uint32_t* ridx = nullptr;          // (length >> 6) + 2 entries; valid up to entry pos[ridx_reads - 1] >> 6
+    size_t ridx_reads = 0;             // records it covers (== n_reads: gd_prep_kernel uses it)
     // layout in the result arrays of the last compute (-1 = not computed)
     int64_t base_off = -1;
     int64_t win_off = -1;
@@ -149,6 +152,13 @@ struct gd_ctx {
     bool span_forces_long = false;      // AUTO: the tile path met a read too long for it
     unsigned long long* d_status = nullptr;  size_t cap_status = 0;   // scatter path look-back words
     int lookback = kDefaultLookback;
+    // gd_index_records_kernel's words: [0] check flags, [1] the largest reference span of any record that has arrived
+    // since gd_reset / gd_set_contigs (INT_MAX: a record it did not walk), [2] the last position of the last launch
+    uint32_t* d_ingest = nullptr;
+    bool ingest_span_dirty = false;     // [1] may have grown since the host last read it
+    int32_t ingest_span = 0;            // the host's copy (0: nothing measured)
+    bool ingest_index = true;           // GD_OPT_INGEST_INDEX
+    double timing[4] = {0, 0, 0, 0};    // gd_compute_timing: allocations + contig table, enqueue, wait, total of the last gd_compute
 
     // device job state
     gd::ContigDev* d_ctgs = nullptr;  size_t cap_ctgs = 0;
@@ -306,6 +316,8 @@ void free_contig(ContigHost& h)
         if (h.cigar) (void)hipFree(h.cigar);
     }
     drop_ck(h);
+    if (h.ridx) (void)hipFree(h.ridx);
+    h.ridx = nullptr; h.ridx_reads = 0;
     h.pos = nullptr; h.flag = nullptr; h.mapq = nullptr; h.off = nullptr; h.cigar = nullptr;
     h.n_reads = h.n_ops = h.cap_reads = h.cap_ops = 0;
     h.adopted = false;

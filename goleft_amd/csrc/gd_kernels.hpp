@@ -61,7 +61,10 @@ struct ContigDev {
     const uint2*    dl;       // deletion lists {start, length}
     const uint32_t* pck;      // tile indexes: deletions starting before every 4096-base boundary a read spans
     const uint32_t* rec;      // record words (gd_normalize.hpp) of the canonical records, null otherwise
-    const uint32_t* pidx;     // position index (gd_pidx_kernel): first read with pos >= 64 k; null: search `pos`
+    const uint32_t* pidx;     // position index: first read with pos >= 64 k (gd_pidx_kernel, or gd_index_records_kernel as the
+                              // records arrived); null: search `pos`
+    uint32_t pidx_last;       // entries above this one read as n_reads (an index built block by block has no tail)
+    uint32_t pad_;
 };
 
 // Everything a workgroup needs for its tile in ONE record (one scalar load
@@ -286,10 +289,10 @@ __global__ void gd_prep_kernel(Job job)
         // the index answers both searches: the look-back start rounded DOWN to a multiple of 64 (a few more
         // reads examined, never fewer), the tile end exactly (T is a multiple of 64; the clipped last tile of a
         // contig searches the one 64-position bucket its end lies in)
-        ti.lo = c.pidx[from >> 6];
-        const uint32_t k = (uint32_t)tend >> 6;
-        const uint32_t a = c.pidx[k];
-        ti.hi = (tend & 63) == 0 ? a : a + lower_bound_i32(c.pos + a, c.pidx[k + 1] - a, tend);
+        const uint32_t kl = (uint32_t)from >> 6, k = (uint32_t)tend >> 6;
+        ti.lo = kl > c.pidx_last ? c.n_reads : c.pidx[kl];
+        const uint32_t a = k > c.pidx_last ? c.n_reads : c.pidx[k];
+        ti.hi = (tend & 63) == 0 ? a : a + lower_bound_i32(c.pos + a, (k + 1u > c.pidx_last ? c.n_reads : c.pidx[k + 1]) - a, tend);
     } else {
         // no index.  ONE search per tile: s = first read at or past the tile's first position.  The tile's last
         // read is the next tile's s (the neighbouring lane has it; the last lane of a wave and the last tile of a

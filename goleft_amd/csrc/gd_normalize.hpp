@@ -607,24 +607,90 @@ __global__ __launch_bounds__(256, 8) void gd_norm_fused_kernel(NormBatch B)
     }
 }
 
-// gd_adopt_device: the arrays come from the caller's own kernels -- the one check a host block gets in gd_commit.
-// flags: bit 0 positions out of order, bit 1 CSR offsets decreasing / not starting at 0 / ending past the ops,
-// bit 2 a negative position.
-__global__ __launch_bounds__(256) void gd_check_records_kernel(const int32_t* __restrict__ pos, const uint32_t* __restrict__ off,
-                                                               uint32_t n_reads, uint32_t n_ops, uint32_t* __restrict__ flags)
+// What every way into the engine runs over records once they are resident (gd_adopt_device: the caller's own arrays;
+// gd_commit: a staged block that has landed; the device BAM read: a contig the record walk has written) -- ONE pass over
+// pos / CSR offsets / ops of the reads [r0, r1) of a contig:
+//   * the checks a host block gets in gd_commit (check != 0).  out[0] bits: 0 positions out of order, 1 CSR offsets
+//     decreasing / not starting at 0 / ending past the ops, 2 a negative position;
+//   * the position index the prep kernel would otherwise search for: ridx[k] = first read with pos >= 64 k, written
+//     for every k in (pos[r - 1] >> 6, pos[r] >> 6] by read r (k <= pos[r1 - 1] >> 6 is all that exists afterwards:
+//     gd_prep_kernel reads anything above ContigDev::pidx_last as n_reads, so blocks append without a tail to redo);
+//   * the largest reference span of ANY record (out[1], atomicMax; unfiltered, so never below what the tile kernel
+//     will measure on the kept ones): the first gd_compute starts with the right look-back instead of learning it.
+//     Reads of more than 64 ops are not walked here (out[1] = INT_MAX: unknown -- the default look-back and its
+//     verification take over; long-read data takes the long-read path, which measures spans itself);
+//   * out[2] = pos[r1 - 1].
+struct IndexJob {
+    const int32_t*  pos;
+    const uint32_t* off;
+    const uint32_t* cigar;
+    uint32_t* ridx;           // null: no index wanted
+    uint32_t n_idx;           // its entries ((length >> 6) + 2); records placed past the contig's end write none
+    uint32_t* out;            // [3]
+    uint32_t r0, r1;
+    uint32_t n_reads_total;   // records of the contig once this block is in (offset checks at its last record)
+    uint32_t n_ops_total;
+    int32_t  prev_pos;        // pos[r0 - 1]; r0 == 0: -1
+    uint32_t check;
+    uint32_t walk_ops;        // 0: spans not measured (out[1] untouched)
+};
+
+__global__ __launch_bounds__(256) void gd_index_records_kernel(IndexJob j)
 {
-    const uint32_t r = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t r = j.r0 + blockIdx.x * 256u + threadIdx.x;
+    const bool in = r < j.r1;
     uint32_t bad = 0;
-    if (r < n_reads) {
-        if (r + 1u < n_reads && pos[r] > pos[r + 1u]) bad |= 1u;
-        if (r == 0u && pos[0] < 0) bad |= 4u;                  // (sorted: the first position is the smallest)
-        const uint32_t a = off[r], b = off[r + 1u];
-        if (a > b || (r == 0u && a != 0u) || (r + 1u == n_reads && b > n_ops)) bad |= 2u;
+    int32_t ka = 0, kb = -1;
+    int32_t span = 0;
+    if (in) {
+        const int32_t p = j.pos[r];
+        const int32_t q = r > j.r0 ? j.pos[r - 1u] : j.prev_pos;
+        if (q > p) bad |= 1u;
+        if (p < 0) bad |= 4u;
+        const uint32_t a = j.off[r], b = j.off[r + 1u];
+        if (a > b || (r == 0u && a != 0u) || (r + 1u == j.n_reads_total && b > j.n_ops_total)) bad |= 2u;
+        if (bad == 0u) { ka = (q >> 6) + 1; kb = p >> 6; kb = kb < (int32_t)j.n_idx ? kb : (int32_t)j.n_idx - 1; }        // (q = -1 in front of the first record: from entry 0)
+        if (j.walk_ops && bad == 0u && b <= j.n_ops_total) {
+            if (b - a > 64u) span = 0x7fffffff;
+            else {
+                uint32_t sp = 0;
+                for (uint32_t o = a; o < b; ++o) {
+                    const uint32_t op = j.cigar[o];
+                    sp += ((0x18du >> (op & 15u)) & 1u) ? (op >> 4) : 0u;     // M D N = X consume the reference
+                    sp = sp > 0x7fffffffu ? 0x7fffffffu : sp;
+                }
+                span = (int32_t)sp;
+            }
+        }
+        if (r + 1u == j.r1) j.out[2] = (uint32_t)p;
     }
-    const uint32_t any = (__builtin_amdgcn_ballot_w64((bad & 1u) != 0u) != 0ull ? 1u : 0u) |
-                         (__builtin_amdgcn_ballot_w64((bad & 2u) != 0u) != 0ull ? 2u : 0u) |
-                         (__builtin_amdgcn_ballot_w64((bad & 4u) != 0u) != 0ull ? 4u : 0u);
-    if (any != 0u && (threadIdx.x & 63u) == 0u) atomicOr(flags, any);
+    if (j.ridx) {
+        // nearly every read owns zero or one entry; a read behind a gap (a centromere: 10^5 entries) hands it to its wave
+        int32_t k = ka;
+        for (int n = 0; n < 2 && k <= kb; ++n, ++k) j.ridx[k] = r;
+        unsigned long long m = __builtin_amdgcn_ballot_w64(k <= kb);
+        const int lane = (int)(threadIdx.x & 63u);
+        while (m) {
+            const int l = __builtin_ctzll(m);
+            m &= m - 1ull;
+            const int32_t k0 = __shfl(k, l, 64), k1 = __shfl(kb, l, 64);
+            const uint32_t rr = (uint32_t)__shfl((int)r, l, 64);
+            for (int32_t x = k0 + lane; x <= k1; x += 64) j.ridx[x] = rr;
+        }
+    }
+    if (j.check) {
+        const uint32_t any = (__builtin_amdgcn_ballot_w64((bad & 1u) != 0u) != 0ull ? 1u : 0u) |
+                             (__builtin_amdgcn_ballot_w64((bad & 2u) != 0u) != 0ull ? 2u : 0u) |
+                             (__builtin_amdgcn_ballot_w64((bad & 4u) != 0u) != 0ull ? 4u : 0u);
+        if (any != 0u && (threadIdx.x & 63u) == 0u) atomicOr(j.out, any);
+    }
+    if (j.walk_ops) {
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) { const int32_t o = __shfl_xor(span, m, 64); span = o > span ? o : span; }
+        // one address for the whole launch: ask first, most waves have nothing new to say
+        if ((threadIdx.x & 63u) == 0u && span > 0 && span > (int32_t)__atomic_load_n(j.out + 1, __ATOMIC_RELAXED))
+            atomicMax(reinterpret_cast<int32_t*>(j.out + 1), span);
+    }
 }
 
 }  // namespace norm

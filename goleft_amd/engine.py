@@ -17,6 +17,7 @@ CLASS_NAMES = ("NO_COVERAGE", "LOW_COVERAGE", "CALLABLE", "EXCESSIVE_COVERAGE")
 K_PREP, K_TILE, K_RUNS, K_EXPAND, K_SCAN, K_CKPT, K_SEQSTATS, K_MDFLAGS, K_INFLATE, K_NORM = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9
 # gd_set_option keys (include/goleft_depth.h)
 OPT_NT_STORES, OPT_NORMALIZE, OPT_FAST_KERNEL, OPT_COPY_THREADS, OPT_PUSH_THREADS, OPT_H2D_KERNEL, OPT_PUSH_CHUNK, OPT_BAM_REFS, OPT_FUSED_NORMALIZE = 3, 4, 5, 6, 7, 8, 9, 10, 11
+OPT_INGEST_INDEX = 14
 PATH_AUTO, PATH_TILE, PATH_SCATTER, PATH_CHUNK = 0, 1, 2, 3
 # gd_stats.tile_kernel (include/goleft_depth.h GD_TK_*)
 TK_NONE, TK_GENERIC, TK_FAST, TK_FAST_RAW, TK_LONG, TK_SCATTER, TK_SUMS_STREAM, TK_TILE_SUMS, TK_SUMS_STREAM_RAW = range(9)
@@ -162,6 +163,12 @@ class DepthEngine:
         ms = C.c_float()
         self._chk(self._lib.gd_kernel_ms(self._ctx, kernel_id, C.byref(ms)))
         return float(ms.value)
+
+    def compute_timing(self):
+        """Host wall clock of the last compute: dict(prepare_s, enqueue_s, wait_s, total_s) (gd_compute_timing)."""
+        t = (C.c_double * 4)()
+        self._chk(self._lib.gd_compute_timing(self._ctx, t, 4))
+        return {"prepare_s": t[0], "enqueue_s": t[1], "wait_s": t[2], "total_s": t[3]}
 
     def stats(self) -> GdStats:
         s = GdStats()

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define GD_ABI_VERSION 11
+#define GD_ABI_VERSION 12
 
 typedef enum {
     GD_OK = 0,
@@ -206,6 +206,12 @@ enum { /* (1, 2: tile shapes other than 4096 positions x 256 threads -- measured
        GD_OPT_INGEST_DMA = 13,      /* gd_ingest_feed*: streams a staged piece is split over: 1 (default) .. 4; 0: a copy kernel on a
                                        high-priority stream instead.  Measured on MI355X next to the
                                        inflate kernels: one stream 24-27 GB/s, two to four streams slower */
+       GD_OPT_INGEST_INDEX = 14,    /* 1 (default): records are indexed as they arrive -- gd_adopt_device's check pass, a pass over
+                                       every committed block once it has landed, the device BAM read's write pass: a position
+                                       index (first read at or past every 64th position: the prep kernel looks its tiles' read
+                                       ranges up instead of searching) and the largest reference span of any record (the first
+                                       gd_compute starts with the right look-back instead of learning it; still verified).
+                                       0: neither (the prep kernel searches, the look-back starts at max_span_hint or 512) */
        GD_OPT_H2D_KERNEL = 8 };     /* how a committed staging block reaches HBM: 1 (default) one kernel whose workgroups
                                        read the page-locked block over the link (all five arrays in one launch; n > 1:
                                        with n workgroups), 0: five hipMemcpyAsync through a DMA engine */
@@ -532,6 +538,11 @@ int gd_get_stats(gd_ctx* ctx, gd_stats* out);
  * stream the kernels ran on.  Enable before gd_compute. */
 int gd_set_profiling(gd_ctx* ctx, int on);
 int gd_kernel_ms(gd_ctx* ctx, int kernel_id, float* ms);
+/* Host wall clock of the last gd_compute (or launch + finish pair), seconds[0 .. n): [0] contig table + device
+ * allocations (what only a context's FIRST compute of a job size pays), [1] enqueueing the launches, [2] the wait
+ * for the device incl. verification, re-runs and publishing, [3] their total.  What the reference's counterpart
+ * spends per tile on fork/exec and pipes (depth/depth.go:392-394) is here one number per genome. */
+int gd_compute_timing(gd_ctx* ctx, double* seconds, int n);
 
 #ifdef __cplusplus
 }

@@ -97,3 +97,12 @@ def oracle_runs(depth, mincov, maxmean, step, start=0):
     s = p[brk]
     e = np.append(s[1:], start + n)
     return np.stack([s, e, cls[brk]], 1).astype(np.int32)
+
+
+def ref_span(r):
+    """Reference bases each record's CIGAR consumes (M, D, N, =, X), per read."""
+    consumes = np.array([1, 0, 1, 1, 0, 0, 0, 1, 1, 0, 0, 0, 0, 0, 0, 0], np.int64)
+    c = r.cigar.astype(np.int64)
+    cs = np.concatenate([[0], np.cumsum(consumes[c & 15] * (c >> 4))])
+    off = r.cigar_off.astype(np.int64)
+    return cs[off[1:]] - cs[off[:-1]]
