@@ -27,6 +27,7 @@ SYMBOLS = {
     "gdh_multidepth_run": (C.c_int, [C.c_int, C.POINTER(C.c_char_p), C.c_char_p]),
     "gdh_plan_ingest_passes": (C.c_size_t, [_P, _P, C.c_size_t, _P, C.c_size_t, C.c_uint64, C.c_uint64, C.c_size_t,
                                             _P, _P, _P, _P]),
+    "gdh_plan_ingest_parts": (C.c_size_t, [_P, C.c_size_t, C.c_uint64, C.c_uint64, C.c_size_t, _P, _P, _P, _P, _P]),
     "gdh_multidepth_blocks": (C.c_int64, [_P, _P, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
                                           _P, _P, C.c_int64]),
     "gdh_bam_open": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(_P)]),
@@ -270,3 +271,15 @@ def plan_ingest_passes(start, has, wanted, file_size, group_bytes):
     n = load().gdh_plan_ingest_passes(st.ctypes.data, hs.ctypes.data, len(st), w.ctypes.data, len(w), file_size,
                                       group_bytes, cap, f.ctypes.data, l.ctypes.data, b.ctypes.data, e.ctypes.data)
     return [(int(f[k]), int(l[k]), int(b[k]), int(e[k])) for k in range(n)]
+
+
+def plan_ingest_parts(anchors, end, part_bytes):
+    """[(a_lo, a_hi, beg, end, scale)] -- how one reference is read in parts cut at .bai anchors (gdh_plan_ingest_parts)."""
+    import numpy as np
+    an = np.ascontiguousarray(anchors, np.uint64)
+    cap = len(an) + 1
+    lo, hi, b, e = (np.zeros(cap, np.uint64) for _ in range(4))
+    sc = np.zeros(cap, np.float64)
+    n = load().gdh_plan_ingest_parts(an.ctypes.data, len(an), end, part_bytes, cap, lo.ctypes.data, hi.ctypes.data,
+                                     b.ctypes.data, e.ctypes.data, sc.ctypes.data)
+    return [(int(lo[k]), int(hi[k]), int(b[k]), int(e[k]), float(sc[k])) for k in range(n)]

@@ -93,6 +93,8 @@ SYMBOLS = {
     "gd_ingest_timing": (C.c_int, [_P, _P, C.c_size_t]),
     "gd_ingest_finish": (C.c_int, [_P, C.c_int32, C.c_int32, _P, C.c_size_t, C.POINTER(C.c_uint64)]),
     "gd_ingest_decode": (C.c_int, [_P, C.c_int32, C.c_int32, _P, C.c_size_t, C.POINTER(C.c_uint64)]),
+    "gd_ingest_decode_part": (C.c_int, [_P, C.c_int32, C.c_int32, _P, C.c_size_t, C.c_uint64, C.c_uint, C.c_double,
+                              C.POINTER(C.c_uint64)]),
     "gd_ingest_release": (C.c_int, [_P]),
     "gd_ingest_abort": (C.c_int, [_P]),
     "gd_host_alloc": (C.c_int, [_P, C.c_size_t, C.POINTER(_P)]),

@@ -390,7 +390,7 @@ static int index_records(gd_ctx* c, ContigHost& h, size_t r0, size_t r1, int32_t
     j.prev_pos = r0 ? prev_pos : -1;
     j.check = check ? 1u : 0u;
     // spans are measured for short-read shaped data only (a lane walks its read's ops one by one)
-    j.walk_ops = (c->ingest_index && h.n_ops <= 6 * h.n_reads) ? 1u : 0u;
+    j.walk_ops = (c->ingest_index && h.n_ops <= 6 * r1) ? 1u : 0u;          // (r1 = the contig's records once this block is in)
     hipLaunchKernelGGL(gd::norm::gd_index_records_kernel, dim3((unsigned)((r1 - r0 + 255) / 256)), dim3(256), 0, st, j);
     HIPCHK(c, hipGetLastError());
     if (idx) h.ridx_reads = r1;

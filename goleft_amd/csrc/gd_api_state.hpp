@@ -61,6 +61,7 @@ struct ContigHost {
     // built as the records arrive (gd_index_records_kernel): the same position index without canonical records
     uint32_t* ridx = nullptr;          // (length >> 6) + 2 entries; valid up to entry pos[ridx_reads - 1] >> 6
     size_t ridx_reads = 0;             // records it covers (== n_reads: gd_prep_kernel uses it)
+    bool ing_left = false;             // device BAM read in parts: a record of another reference has ended this one's records
     // layout in the result arrays of the last compute (-1 = not computed)
     int64_t base_off = -1;
     int64_t win_off = -1;
@@ -318,6 +319,7 @@ void free_contig(ContigHost& h)
     drop_ck(h);
     if (h.ridx) (void)hipFree(h.ridx);
     h.ridx = nullptr; h.ridx_reads = 0;
+    h.ing_left = false;
     h.pos = nullptr; h.flag = nullptr; h.mapq = nullptr; h.off = nullptr; h.cigar = nullptr;
     h.n_reads = h.n_ops = h.cap_reads = h.cap_ops = 0;
     h.adopted = false;

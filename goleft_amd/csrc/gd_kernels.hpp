@@ -359,6 +359,17 @@ __global__ void gd_prep_kernel(Job job)
     job.ftiles[t] = tf;
 }
 
+// What the host reads after a compute: the counter block and the boundaries that exist (at most `spec`), stored
+// straight into page-locked host memory.
+__global__ __launch_bounds__(256) void gd_readback_kernel(const Counters* __restrict__ k, const int2* __restrict__ ordered, uint32_t spec,
+                                                          Counters* __restrict__ h_counters, int2* __restrict__ h_bounds)
+{
+    const uint32_t n = k->run_cursor < spec ? k->run_cursor : spec;
+    for (uint32_t i = threadIdx.x; i < n; i += 256u) h_bounds[i] = ordered[i];
+    if (threadIdx.x < sizeof(Counters) / 4u)
+        reinterpret_cast<uint32_t*>(h_counters)[threadIdx.x] = reinterpret_cast<const uint32_t*>(k)[threadIdx.x];
+}
+
 // ---------------------------------------------------------------------------
 // wavefront primitives (wave64, DPP)
 // ---------------------------------------------------------------------------

@@ -554,7 +554,11 @@ int run(const DArgs& args)
             if (gpu_decode) {
                 if (!on_every_shard("the device BAM read", [&](Shard& sh) {
                         return gdh::ingest_references_on_device(sh.ctx, fm, lin, sh.wanted, sh.wanted, &sh.n_gpu_records, &sh.io_ok,
-                                                                (uint64_t)env_int("GOLEFT_INGEST_GROUP_MB", 512) << 20, &chunk_end);
+                                                                (uint64_t)env_int("GOLEFT_INGEST_GROUP_MB", 512) << 20, &chunk_end,
+                                                                // a reference larger than this is read in parts cut at .bai anchors
+                                                                // (0: never; _KB: tests cut small files)
+                                                                getenv("GOLEFT_INGEST_PART_KB") ? (uint64_t)env_int("GOLEFT_INGEST_PART_KB", 0) << 10
+                                                                                                : (uint64_t)env_int("GOLEFT_INGEST_PART_MB", 1024) << 20);
                     }))
                     return 1;
                 for (Shard& sh : S.v) {

@@ -60,6 +60,11 @@ struct FileMap {
 struct IngestPass {
     size_t first, last;
     uint64_t beg, end;
+    // a reference whose byte range exceeds the pass size is read in PARTS cut at anchors of its linear index:
+    // first == last, the part holds its anchors [a_lo, a_hi) and ends at anchor a_hi (a_hi == n_anchors: the last part)
+    bool part = false;
+    size_t a_lo = 0, a_hi = 0;
+    double scale = 0;                  // the reference's byte range over this part's (first part: sizes the contig's arrays)
 };
 
 // Plans the passes for the wanted references refs (ascending reference ids).  start[r] is the file offset
@@ -70,9 +75,14 @@ struct IngestPass {
 // ref_end (optional): the largest chunk end of every reference's .bai bins (virtual offsets).  The last
 // reference with records then ends one member past it instead of at the end of the file -- the unmapped
 // tail of a WGS BAM (often gigabytes) is neither uploaded nor inflated.
+// lin + part_bytes (optional): a pass that would hold ONE reference and more than 1.5 x part_bytes of the file is cut
+// into parts of about part_bytes at anchors of that reference's linear index (lin[r]: strictly ascending virtual
+// offsets of record starts); part k ends with the member that holds the first anchor of part k + 1 (that member is read
+// and inflated by both parts: the records before the anchor belong to part k, the rest to part k + 1).
 inline std::vector<IngestPass> plan_ingest_passes(const std::vector<uint64_t>& start, const std::vector<char>& has,
                                                   const std::vector<int32_t>& refs, uint64_t file_size,
-                                                  uint64_t group_bytes, const std::vector<uint64_t>* ref_end = nullptr)
+                                                  uint64_t group_bytes, const std::vector<uint64_t>* ref_end = nullptr,
+                                                  const std::vector<std::vector<uint64_t>>* lin = nullptr, uint64_t part_bytes = 0)
 {
     std::vector<IngestPass> out;
     auto next_with_records = [&](size_t r) {
@@ -99,6 +109,33 @@ inline std::vector<IngestPass> plan_ingest_passes(const std::vector<uint64_t>& s
         else if (ref_end && (size_t)refs[j] < ref_end->size() && (*ref_end)[(size_t)refs[j]] != 0)
             end = ((*ref_end)[(size_t)refs[j]] >> 16) + 2 * (65536 + 26);   // the member holding the last record's end, whole
         if (end > file_size) end = file_size;
+        if (i == j && lin && part_bytes > 0 && end > beg && end - beg > part_bytes + part_bytes / 2 && (*lin)[(size_t)refs[i]].size() > 1) {
+            const std::vector<uint64_t>& an = (*lin)[(size_t)refs[i]];
+            const uint64_t total = end - beg;
+            const size_t want = (size_t)((total + part_bytes - 1) / part_bytes);
+            std::vector<size_t> cut{0};                    // anchor indices where parts begin
+            for (size_t k = 1; k < want; ++k) {
+                const uint64_t target = beg + (uint64_t)((unsigned __int128)total * k / want);
+                // the first anchor whose member starts at or after the target
+                size_t lo = cut.back() + 1, hi = an.size();
+                while (lo < hi) { const size_t mid = (lo + hi) / 2; if ((an[mid] >> 16) < target) lo = mid + 1; else hi = mid; }
+                if (lo >= an.size()) break;
+                if ((an[lo] >> 16) > (an[cut.back()] >> 16)) cut.push_back(lo);   // (a part must start in a later member than the one before)
+            }
+            cut.push_back(an.size());
+            for (size_t k = 0; k + 1 < cut.size(); ++k) {
+                IngestPass ps{i, i, an[cut[k]] >> 16, end};
+                if (k == 0) ps.beg = beg;
+                if (k + 2 < cut.size()) ps.end = std::min<uint64_t>((an[cut[k + 1]] >> 16) + 65536 + 26, end);
+                ps.part = true;
+                ps.a_lo = cut[k]; ps.a_hi = cut[k + 1];
+                ps.scale = ps.end > ps.beg ? (double)total / (double)(ps.end - ps.beg) : 0.0;
+                out.push_back(ps);
+            }
+            if (cut.size() == 2) out.back().part = false;  // one part after all: the ordinary whole-reference pass
+            i = j + 1;
+            continue;
+        }
         out.push_back(IngestPass{i, j, beg, end});
         i = j + 1;
     }
@@ -266,7 +303,7 @@ inline bool list_members(const uint8_t* base, size_t nb, uint64_t beg, const std
 inline int ingest_references_on_device(gd_ctx* ctx, const FileMap& fm, const std::vector<std::vector<uint64_t>>& lin,
                                        const std::vector<int32_t>& refs, const std::vector<int32_t>& tids,
                                        uint64_t* n_records, bool* io_ok, uint64_t group_bytes = 512ull << 20,
-                                       const std::vector<uint64_t>* ref_end = nullptr)
+                                       const std::vector<uint64_t>* ref_end = nullptr, uint64_t part_bytes = 1ull << 30)
 {
     *io_ok = true;
     *n_records = 0;
@@ -275,9 +312,20 @@ inline int ingest_references_on_device(gd_ctx* ctx, const FileMap& fm, const std
     std::vector<char> has(lin.size(), 0);
     for (size_t r = 0; r < lin.size(); ++r)
         if (!lin[r].empty()) { has[r] = 1; start[r] = lin[r].front() >> 16; }
-    const std::vector<IngestPass> passes = plan_ingest_passes(start, has, refs, fm.size, group_bytes, ref_end);
-    // decode + release of the oldest pending pass: references refs[a..b]
-    auto decode_pass = [&](size_t a, size_t b) -> int {
+    const std::vector<IngestPass> passes = plan_ingest_passes(start, has, refs, fm.size, group_bytes, ref_end, &lin, part_bytes);
+    // decode + release of the oldest pending pass: references refs[a..b], or one part of one reference
+    auto decode_pass = [&](const IngestPass& ps) -> int {
+        const size_t a = ps.first, b = ps.last;
+        if (ps.part) {
+            const std::vector<uint64_t>& an = lin[(size_t)refs[a]];
+            uint64_t n = 0;
+            const int rc = gd_ingest_decode_part(ctx, tids[a], refs[a], an.data() + ps.a_lo, ps.a_hi - ps.a_lo,
+                                                 ps.a_hi < an.size() ? an[ps.a_hi] : 0, (ps.a_lo ? (unsigned)GD_PART_APPEND : 0u) | (unsigned)GD_PART_RELEASE,
+                                                 ps.a_lo ? 0.0 : ps.scale, &n);
+            if (rc != GD_OK) return rc;
+            *n_records += n;
+            return GD_OK;
+        }
         for (size_t k = a; k <= b; ++k) {
             const std::vector<uint64_t>& an = lin[(size_t)refs[k]];
             if (an.empty()) continue;
@@ -312,7 +360,8 @@ inline int ingest_references_on_device(gd_ctx* ctx, const FileMap& fm, const std
             if (ps.beg < ps.end) {
                 std::vector<uint64_t> member_starts;       // what the .bai knows about where members begin
                 for (size_t r = ps.first; r <= ps.last; ++r)
-                    for (uint64_t v : lin[(size_t)refs[r]]) member_starts.push_back(v >> 16);
+                    for (uint64_t v : lin[(size_t)refs[r]])
+                        if ((v >> 16) >= ps.beg && (v >> 16) < ps.end) member_starts.push_back(v >> 16);
                 listed[k].ok = list_members(fm.p + ps.beg, (size_t)(ps.end - ps.beg), ps.beg, member_starts, &listed[k].mt, 16,
                                             64u << 20, from_mapping ? -1 : fm.fd) &&
                                listed[k].mt.n != 0;
@@ -327,10 +376,9 @@ inline int ingest_references_on_device(gd_ctx* ctx, const FileMap& fm, const std
         ~Joiner() { { std::lock_guard<std::mutex> lk(mu); stop = true; } cv.notify_all(); if (t.joinable()) t.join(); }
     } joiner{lister, mu, cv, stop};
     bool pending = false;                                  // a fed pass waits for its decode
-    size_t pa = 0, pb = 0;
+    size_t pprev = 0;
     for (size_t pk = 0; pk < passes.size(); ++pk) {
         const IngestPass& ps = passes[pk];
-        const size_t i = ps.first, j = ps.last;
         const uint64_t beg = ps.beg, end = ps.end;
         auto bad_file = [&]() { (void)gd_ingest_abort(ctx); *io_ok = false; *n_records = 0; return GD_OK; };
         if (beg >= end) return bad_file();
@@ -365,14 +413,14 @@ inline int ingest_references_on_device(gd_ctx* ctx, const FileMap& fm, const std
         const double t3 = now();
         // this pass is on its way (upload + inflate are asynchronous): now decode the one before it
         if (pending) {
-            rc = decode_pass(pa, pb);
+            rc = decode_pass(passes[pprev]);
             if (rc != GD_OK) return rc;
         }
         t_list += t1 - t0; t_begin += t2 - t1; t_feed += t3 - t2; t_decode += now() - t3;
-        pending = true; pa = i; pb = j;
+        pending = true; pprev = pk;
     }
     int rc_last = GD_OK;
-    if (pending) { const double t = now(); rc_last = decode_pass(pa, pb); t_decode += now() - t; }
+    if (pending) { const double t = now(); rc_last = decode_pass(passes[pprev]); t_decode += now() - t; }
     if (timing) {
         double t_listing = 0;
         for (const Listed& l : listed) t_listing += l.secs;

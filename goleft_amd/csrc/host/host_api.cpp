@@ -207,6 +207,27 @@ size_t gdh_plan_ingest_passes(const uint64_t* start, const uint8_t* has, size_t 
     return ps.size();
 }
 
+// Test hook: how ONE reference with the linear-index anchors `anchors` (virtual offsets of record starts, strictly
+// ascending), whose records end by file offset `end`, is cut into parts of about part_bytes (gdh::plan_ingest_passes).
+size_t gdh_plan_ingest_parts(const uint64_t* anchors, size_t n_anchors, uint64_t end, uint64_t part_bytes, size_t cap,
+                             uint64_t* a_lo, uint64_t* a_hi, uint64_t* beg, uint64_t* pend, double* scale)
+{
+    if (!anchors || n_anchors == 0) return 0;
+    std::vector<std::vector<uint64_t>> lin(1, std::vector<uint64_t>(anchors, anchors + n_anchors));
+    const std::vector<uint64_t> st{anchors[0] >> 16};
+    const std::vector<char> hs{1};
+    const std::vector<int32_t> w{0};
+    const std::vector<gdh::IngestPass> ps = gdh::plan_ingest_passes(st, hs, w, end, ~0ull, nullptr, &lin, part_bytes);
+    for (size_t k = 0; k < ps.size() && k < cap; ++k) {
+        if (a_lo) a_lo[k] = ps[k].part ? ps[k].a_lo : 0;
+        if (a_hi) a_hi[k] = ps[k].part ? ps[k].a_hi : n_anchors;
+        if (beg) beg[k] = ps[k].beg;
+        if (pend) pend[k] = ps[k].end;
+        if (scale) scale[k] = ps[k].scale;
+    }
+    return ps.size();
+}
+
 int gdh_bam_open(const char* path, int threads, gdh_bam** out)
 {
     if (!path || !out) return -1;

@@ -493,6 +493,16 @@ class DepthEngine:
         self._chk(self._lib.gd_ingest_decode(self._ctx, tid, ref_id, a.ctypes.data, a.size, C.byref(cnt)))
         return int(cnt.value)
 
+    def ingest_decode_part(self, tid: int, ref_id: int, anchors, end_anchor: int = 0, append: bool = False,
+                           release: bool = False, expect_scale: float = 0.0) -> int:
+        """One PART of a reference from the oldest pending range (gd_ingest_decode_part): its anchors up to
+        end_anchor (0: the range's end), appended to / replacing the contig's records."""
+        a = np.ascontiguousarray(anchors, np.uint64)
+        cnt = C.c_uint64()
+        self._chk(self._lib.gd_ingest_decode_part(self._ctx, tid, ref_id, a.ctypes.data, a.size, int(end_anchor),
+                                                  (1 if append else 0) | (2 if release else 0), float(expect_scale), C.byref(cnt)))
+        return int(cnt.value)
+
     def ingest_release(self) -> None:
         self._chk(self._lib.gd_ingest_release(self._ctx))
 

@@ -494,6 +494,19 @@ int gd_ingest_finish(gd_ctx* ctx, int32_t tid, int32_t ref_id, const uint64_t* a
 int gd_ingest_decode(gd_ctx* ctx, int32_t tid, int32_t ref_id, const uint64_t* anchors, size_t n_anchors,
                      uint64_t* n_records);
 int gd_ingest_release(gd_ctx* ctx);
+/* A reference read in SEVERAL ranges (passes cut inside a chromosome at .bai anchors: buffers of one pass instead of
+ * one chromosome, and only the last pass's inflate and record walks left without an upload to hide behind): the
+ * oldest pending range holds the reference's records from anchors[0] up to `end_anchor` -- the virtual offset of the
+ * first record that belongs to the NEXT part (a record start the index knows, inside a member of this range; 0: the
+ * part runs to the range's end, as gd_ingest_decode).  flags: GD_PART_APPEND -- the records are appended to what the
+ * contig holds (parts must arrive in file order; coordinate order is checked across parts, and a reference that ended
+ * in an earlier part must not resume), else they replace it; GD_PART_RELEASE -- the range is released afterwards.
+ * expect_scale (>= 1; 0: unknown): how many times this part's share the whole reference is expected to be (its byte
+ * range over this part's), so that the FIRST part allocates the contig's arrays once for all parts (they grow
+ * geometrically when the estimate was short). */
+enum { GD_PART_APPEND = 1, GD_PART_RELEASE = 2 };
+int gd_ingest_decode_part(gd_ctx* ctx, int32_t tid, int32_t ref_id, const uint64_t* anchors, size_t n_anchors,
+                          uint64_t end_anchor, unsigned flags, double expect_scale, uint64_t* n_records);
 /* Where the device BAM read of this context has spent its wall clock so far, in seconds (measurement only):
  * out[0] reading into the staging buffers, [1] waiting for a staging buffer to leave for the device, [2] gd_ingest_begin
  * (allocations, member table), [3] decode: waiting for the inflate launches, [4] decode: the counting walk, [5] decode:

@@ -139,6 +139,10 @@ int64_t gdh_multidepth_blocks(const uint32_t* any_bits, const uint32_t* suf_bits
 size_t gdh_plan_ingest_passes(const uint64_t* start, const uint8_t* has, size_t n_refs, const int32_t* wanted,
                               size_t n_wanted, uint64_t file_size, uint64_t group_bytes, size_t cap,
                               uint64_t* first, uint64_t* last, uint64_t* beg, uint64_t* end);
+/* Test hook: how one reference whose records start at the .bai anchors `anchors` and end by file offset `end` is read
+ * in parts of about part_bytes, cut at anchors (host/gpu_ingest.hpp: passes inside a chromosome). */
+size_t gdh_plan_ingest_parts(const uint64_t* anchors, size_t n_anchors, uint64_t end, uint64_t part_bytes, size_t cap,
+                             uint64_t* a_lo, uint64_t* a_hi, uint64_t* beg, uint64_t* part_end, double* scale);
 
 /* `samtools depth [-a] -Q q -d D -r chr:s-e in.bam` served by the engine: what the reference shells out to per tile
  * (depth/depth.go:45).  argv[0] is the program name, argv[1] must be "depth".  Lines `chrom \t pos (1-based) \t depth`

@@ -129,9 +129,9 @@ def test_csr_offsets_that_dip_exactly_at_a_work_item_cut_are_refused():
     from goleft_amd import _hostlib, synth
     from goleft_amd.engine import DepthEngine, GdError
     from oracle import pyoracle as po
-    L = 2_500_000
+    L = 3_000_000
     r = po.Reads(*synth.short_reads_numpy(L, synth.n_reads_for(L), 11))
-    assert r.n > 2 * 262144 + 10
+    assert r.n > 2 * 262144 + 10, r.n
     host = _hostlib.load()
     with DepthEngine(0) as eng:
         eng.set_params(window_size=1000)

@@ -415,3 +415,73 @@ def test_device_bam_walker_mutation_fuzz(tmp_path, seed):
         eng.compute()
         for t in reads:
             assert np.array_equal(eng.perbase(t), po.perbase_c(reads[t], 1, 0, contigs[t][1]))
+
+
+def test_ingest_a_reference_in_parts(tmp_path):
+    """gd_ingest_decode_part: a reference read as several byte ranges cut at its .bai anchors -- part k holds the bytes
+    from the member of its first anchor through the member of part k + 1's first anchor, its records are appended to
+    the contig's arrays, coordinate order is checked ACROSS parts, and what each call refuses."""
+    from goleft_amd.engine import DepthEngine, GdError
+    rng = np.random.default_rng(71)
+    lens = [900_000, 50_000]
+    contigs = [("p%d" % i, l) for i, l in enumerate(lens)]
+    reads = {0: H.random_reads(rng, lens[0], 40_000, max_ops=4, max_len=90), 1: H.random_reads(rng, lens[1], 3_000, max_len=90)}
+    p = str(tmp_path / "p.bam")
+    bamio.write_bam(p, contigs, reads, unplaced=2, index=True)
+    data = open(p, "rb").read()
+    lin = bamio.read_bai_linear(p + ".bai")
+    an = np.asarray(lin[0], np.uint64)
+    assert len(an) > 12
+    want = po.perbase_c(reads[0], 1, 0, lens[0])
+    end_of_0 = (int(lin[1][0]) >> 16) + 65536 + 26                  # reference 0's records end in reference 1's first member
+    with DepthEngine(0) as eng:
+        eng.set_params(window_size=100, min_mapq=1, min_cov=4)
+        eng.set_contigs(lens)
+        for cuts in ([0, 5, len(an)], [0, 1, 2, 7, len(an) - 1, len(an)], list(range(len(an) + 1))):
+            # (cuts only where the next part starts in a LATER member, as the CLI's planner does)
+            keep = [0]
+            for c in cuts[1:]:
+                if c == len(an) or (int(an[c]) >> 16) > (int(an[keep[-1]]) >> 16):
+                    keep.append(c)
+            cuts = keep if keep[-1] == len(an) else keep + [len(an)]
+            total = 0
+            for k in range(len(cuts) - 1):
+                lo, hi = cuts[k], cuts[k + 1]
+                beg = int(an[lo]) >> 16
+                end = min(len(data), (int(an[hi]) >> 16) + 65536 + 26) if hi < len(an) else min(len(data), end_of_0)
+                eng.ingest_feed_range(data[beg:end], beg, piece=70_001)
+                total += eng.ingest_decode_part(0, 0, an[lo:hi], int(an[hi]) if hi < len(an) else 0, append=k > 0, release=True,
+                                                expect_scale=0.0 if k else 3.0)
+            assert total == reads[0].n, cuts
+            eng.compute()
+            assert np.array_equal(eng.perbase(0), want), cuts
+            assert eng.stats().reruns == 0
+        # the second part fed again: records that go back in coordinates -> refused (the arrays keep what they held)
+        lo, hi = 5, len(an)
+        beg = int(an[lo]) >> 16
+        eng.ingest_feed_range(data[beg:end_of_0], beg)
+        with pytest.raises(GdError) as ei:
+            eng.ingest_decode_part(0, 0, an[lo:hi], 0, append=True, release=True)
+        assert ei.value.status == -7
+        # an end anchor outside the fed range / not behind the last anchor
+        beg = int(an[0]) >> 16
+        eng.ingest_feed_range(data[beg:(int(an[5]) >> 16) + 65536 + 26], beg)
+        with pytest.raises(GdError) as ei:
+            eng.ingest_decode_part(0, 0, an[0:5], int(an[-1]), release=True)
+        assert ei.value.status == -1
+        eng.ingest_feed_range(data[beg:(int(an[5]) >> 16) + 65536 + 26], beg)
+        with pytest.raises(GdError) as ei:
+            eng.ingest_decode_part(0, 0, an[0:5], int(an[2]), release=True)
+        assert ei.value.status == -1
+        # a reference that ENDED in an earlier part must not resume: part 1 = reference 0's tail (a record of reference 1
+        # ends the walk), then reference 0's first part again as an appended part
+        eng.ingest_feed_range(data[int(an[5]) >> 16:end_of_0], int(an[5]) >> 16)
+        eng.ingest_decode_part(0, 0, an[5:], 0, release=True)
+        eng.ingest_feed_range(data[beg:(int(an[5]) >> 16) + 65536 + 26], beg)
+        with pytest.raises(GdError) as ei:
+            eng.ingest_decode_part(0, 0, an[0:5], int(an[5]), append=True, release=True)
+        assert ei.value.status == -7
+        # and the context reads the whole file as before
+        assert eng.ingest_bgzf(0, data, 0, lin[0]) == reads[0].n
+        eng.compute()
+        assert np.array_equal(eng.perbase(0), want)

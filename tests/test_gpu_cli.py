@@ -206,3 +206,32 @@ def test_host_decoder_still_selectable(workdir, indexed, capfd):
         del os.environ["GOLEFT_DEPTH_TIMING"], os.environ["GOLEFT_GPU_DECODE"]
     assert '"decoder": "host"' in capfd.readouterr().err
     assert read(prefix, "depth") == beds["depth"]
+
+
+def test_device_decoder_reads_a_reference_in_parts(workdir, capfd):
+    """Passes cut INSIDE a chromosome at .bai anchors (GOLEFT_INGEST_PART_MB, default 1 GB; _KB here so that a small
+    file is cut dozens of times): every part's records are appended to the contig's arrays (gd_ingest_decode_part),
+    the member that holds a cut is inflated by both neighbours -- and the BED files are those of the uncut read and
+    of the oracle's restatement of depth/depth.go:238-364."""
+    from goleft_amd import synth
+    La, Lb = 6_000_000, 2_500_000
+    ra = po.Reads(*synth.short_reads_numpy(La, synth.n_reads_for(La, 9.0), 5))
+    rb = po.Reads(*synth.short_reads_numpy(Lb, synth.n_reads_for(Lb, 5.0), 6))
+    contigs = [("chrA", La), ("chrEmpty", 5000), ("chrB", Lb)]
+    bam = workdir / "parts.bam"
+    bamio.write_bam(str(bam), contigs, {0: ra, 2: rb}, index=True, unplaced=3)
+    (workdir / "parts.fa.fai").write_text("".join("%s\t%d\t6\t60\t61\n" % c for c in contigs))
+    hd, ca = po.depth_run_oracle(contigs, {0: ra, 2: rb}, W=250, Q=1, mincov=4)
+    size = os.path.getsize(bam)
+    outs = {}
+    for kb in (0, 64, 300, max(64, size // 3000)):
+        prefix = workdir / ("parts%d" % kb)
+        os.environ["GOLEFT_INGEST_PART_KB"] = str(kb)
+        os.environ["GOLEFT_DEPTH_TIMING"] = "1"
+        try:
+            assert run_depth(["-w", 250, "-r", workdir / "parts.fa", "--prefix", prefix, bam]) == 0
+        finally:
+            del os.environ["GOLEFT_INGEST_PART_KB"], os.environ["GOLEFT_DEPTH_TIMING"]
+        assert '"decoder": "device"' in capfd.readouterr().err
+        outs[kb] = (read(prefix, "depth"), read(prefix, "callable"))
+        assert outs[kb][0] == hd and outs[kb][1] == ca, kb

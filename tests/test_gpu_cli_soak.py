@@ -73,7 +73,13 @@ def test_cli_soak(case, tmp_path):
     decode = str(rng.choice(["1", "1", "0"]))
     prefix = tmp_path / "out"
     tag = (case, mode, W, Q, mincov, maxmean, lens, index, devices, decode)
-    assert run_depth(args + ["--prefix", prefix, bam], devices=devices, decode=decode) == 0, tag
+    part_kb = str(rng.choice(["", "", "64", "128"]))          # references read in parts cut at .bai anchors
+    if part_kb:
+        os.environ["GOLEFT_INGEST_PART_KB"] = part_kb
+    try:
+        assert run_depth(args + ["--prefix", prefix, bam], devices=devices, decode=decode) == 0, tag
+    finally:
+        os.environ.pop("GOLEFT_INGEST_PART_KB", None)
     if mode == "chrom":
         t = names.index(chrom)
         hd, ca = po.depth_run_oracle(contigs, reads, W=W, Q=Q, mincov=mincov, maxmean=maxmean)

