@@ -76,6 +76,9 @@ def parse():
                     help="N = 1 only: time every LPT shard of the N-GPU job on THIS device, one after the other "
                          "(gd_select_contigs per shard, export block attached) -> per-shard ms and the projected "
                          "speed-up step(1) / max shard; '' = off")
+    ap.add_argument("--bam-scope", default="auto", choices=["auto", "genome", "chr1-2", "chr20-21", "off"],
+                    help="N = 1, wgs workload: BAM file -> BED through the CLI (SURVEY 8d scope iii) on a synthetic BAM of this "
+                         "size; auto = genome on a host with >= 64 cores and the room for a 46 GB file, else chr20-21")
     ap.add_argument("--verify", action="store_true",
                     help="check one contig against the CPU oracle after timing")
     return ap.parse_args()
@@ -186,6 +189,84 @@ def host_stream_scope(local_rank, W, Q, mincov, genome=False, reps=3, opts=()):
                         "sums/minima and class runs; feed_ms: until the last block is committed (copies may still be in flight)",
             "host_to_device_GBps": out[better]["host_to_device_GBps"], "variants": out,
             "in_place_filler_threads": fillers}
+
+
+def bam_file_scope(which, W, device_reps=3, host_decoder=True):
+    """SURVEY.md section 8d scope (iii), the only scope the reference itself runs and times (`time goleft depth ...`,
+    indexcov/paper/cmp.sh:6): a BAM FILE -> depth.bed + callable.bed through the CLI twin, process start to exit.
+    A synthetic but realistic coordinate-sorted BAM (tools/synth_bam.cpp: 150 bp records WITH SEQ and QUAL, BGZF, .bai)
+    of `which` -- "genome": all 24 hg19 contigs, 30x, ~46 GB; "chr1-2": two chromosomes, ~7 GB; "chr20-21": ~1.4 GB --
+    is written to $TMPDIR, read by `goleft-depth depth -w W` with the device decoder (best of device_reps runs;
+    the file is in the page cache, as after any write) and once with the host decoder; the BED files must be byte
+    identical.  Reported next to -- never as -- `value`."""
+    import shutil
+    import subprocess
+    from goleft_amd import synth
+    exe = os.path.join(ROOT, "goleft_amd", "goleft-depth")
+    gen = os.path.join(ROOT, "goleft_amd", "synth-bam")
+    names = list(synth.HG19_NAMES)
+    lengths = {"genome": list(synth.HG19_LENGTHS), "chr1-2": list(synth.HG19_LENGTHS[:2]),
+               "chr20-21": [synth.HG19_LENGTHS[names.index("chr20")], synth.HG19_LENGTHS[names.index("chr21")]]}[which]
+    tmp = os.environ.get("TMPDIR") or "/tmp"
+    need = int(sum(lengths) * 16)                      # ~15 B of BGZF per reference base at 30x, and the BED files
+    free = shutil.disk_usage(tmp).free
+    if free < need * 1.2:
+        return {"error": "%s needs %.0f GB in %s, %.0f GB free" % (which, need / 1e9, tmp, free / 1e9)}
+    d = tempfile.mkdtemp(prefix="gd_bamscope_", dir=tmp)
+    try:
+        bam = os.path.join(d, "synth.bam")
+        t0 = time.perf_counter()
+        info = json.loads(subprocess.check_output([gen, bam, "chrS", ",".join(str(x) for x in lengths), "30", "20"],
+                                                  timeout=900).decode())
+        t_write = time.perf_counter() - t0
+        ref_bases = int(sum(lengths))
+        out = {"what": "BAM file -> depth.bed + callable.bed, `goleft-depth depth -w %d -p 0 -r synth.fa --prefix OUT synth.bam`, "
+                       "process start to exit (the scope the reference times: indexcov/paper/cmp.sh:6); file in the page cache" % W,
+               "file": which, "contigs": len(lengths), "ref_bases": ref_bases, "reads": info["reads"],
+               "bam_bytes": info["bam_bytes"], "synth_bam_s": t_write, "host_cores": os.cpu_count(), "unit": "ref-bases/s"}
+        beds = {}
+        runs = [("device", {}, device_reps)] + ([("host", {"GOLEFT_GPU_DECODE": "0"}, 1)] if host_decoder else [])
+        for decoder, env, reps in runs:
+            walls, best = [], None
+            for _ in range(reps):
+                t0 = time.perf_counter()
+                p = subprocess.run([exe, "depth", "-w", str(W), "-p", "0", "-r", os.path.join(d, "synth.fa"), "--prefix",
+                                    os.path.join(d, "out_" + decoder), bam],
+                                   env=dict(os.environ, GOLEFT_DEPTH_TIMING="1", GOLEFT_INGEST_TIMING="1", **env),
+                                   stderr=subprocess.PIPE, stdout=subprocess.DEVNULL, timeout=900)
+                dt = time.perf_counter() - t0
+                if p.returncode != 0:
+                    return dict(out, error="goleft-depth (%s decoder) exited with %d: %s" % (decoder, p.returncode, p.stderr.decode()[-400:]))
+                phases = {}
+                for ln in p.stderr.decode().strip().splitlines():
+                    if ln.startswith("{"):
+                        phases.update(json.loads(ln))
+                if phases.get("decoder") != decoder:
+                    return dict(out, error="asked for the %s decoder, %r ran" % (decoder, phases.get("decoder")))
+                walls.append(dt)
+                if best is None or dt < best[0]:
+                    best = (dt, phases)
+            stem = os.path.join(d, "out_" + decoder)
+            h = []
+            for kind in ("depth", "callable"):
+                import hashlib
+                m = hashlib.sha256()
+                with open("%s.%s.bed" % (stem, kind), "rb") as fh:
+                    for blk in iter(lambda: fh.read(1 << 24), b""):
+                        m.update(blk)
+                h.append(m.hexdigest())
+            beds[decoder] = h
+            out[decoder + "_decoder"] = {"wall_s": best[0], "all_wall_s": walls, "ref_bases_per_s": ref_bases / best[0],
+                                         "bgzf_GBps": info["bam_bytes"] / best[0] / 1e9,
+                                         "phases": {k: v for k, v in best[1].items() if isinstance(v, (int, float))}}
+        out["value"] = out["device_decoder"]["ref_bases_per_s"]
+        out["wall_s"] = out["device_decoder"]["wall_s"]
+        out["bgzf_GBps"] = out["device_decoder"]["bgzf_GBps"]
+        out["outputs_identical"] = (beds["device"] == beds["host"]) if "host" in beds else None
+        out["bed_sha256"] = beds["device"]
+        return out
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
 
 
 def load_traffic(tag, kernel):
@@ -884,6 +965,19 @@ def main():
             out["host_stream_scope_wgs"] = host_stream_scope(local_rank, W, Q, mincov, genome=True, reps=1, opts=args.opt)
         except Exception as e:                       # never lose the headline line to a side measurement
             out["host_stream_scope_wgs"] = {"error": "%s: %s" % (type(e).__name__, e)}
+
+    if rank == 0 and world == 1 and args.workload == "wgs" and args.bam_scope != "off":
+        which = args.bam_scope
+        if which == "auto":
+            which = "genome" if (os.cpu_count() or 1) >= 64 else "chr20-21"
+        torch.cuda.empty_cache()
+        try:
+            res = bam_file_scope(which, W)
+            if "error" in res and which == "genome" and args.bam_scope == "auto":
+                res = dict(bam_file_scope("chr1-2", W), fell_back_from=res["error"])
+            out["bam_file_scope"] = res
+        except Exception as e:                       # never lose the headline line to a side measurement
+            out["bam_file_scope"] = {"error": "%s: %s" % (type(e).__name__, e)}
 
     if r_split is not None:
         out["split"] = r_split

@@ -295,6 +295,32 @@ struct Shard {
     std::string what;                   // the failing call
 };
 
+// The HIP runtime and an engine context take 0.2 - 0.3 s to come up: they are created on threads of their own the
+// moment the device list is known, while the main thread reads the BAM header, the .fai and the .bai.
+struct EarlyContexts {
+    std::vector<int> devices;
+    std::vector<gd_ctx*> ctx;
+    std::vector<int> rc;
+    std::vector<std::thread> th;
+    void start(const std::vector<int>& devs)
+    {
+        devices = devs;
+        ctx.assign(devs.size(), nullptr);
+        rc.assign(devs.size(), GD_OK);
+        for (size_t k = 0; k < devs.size(); ++k)
+            th.emplace_back([this, k]() { rc[k] = gd_create(devices[k], &ctx[k]); });
+    }
+    void join() { for (auto& t : th) if (t.joinable()) t.join(); }
+    // the context of devices[k]: the caller owns it from now on
+    int take(size_t k, gd_ctx** out) { join(); *out = ctx[k]; ctx[k] = nullptr; return rc[k]; }
+    ~EarlyContexts()
+    {
+        join();
+        if (gdh_get_fast_exit()) return;
+        for (gd_ctx* c : ctx) if (c) gd_destroy(c);
+    }
+};
+
 struct Shards {
     std::vector<Shard> v;
     ~Shards()
@@ -376,6 +402,10 @@ int run(const DArgs& args)
     const auto t_run = std::chrono::steady_clock::now();
     int exit_code = 0;
     std::string err;
+    EarlyContexts early;                                     // (declared first: joined and emptied last)
+    std::vector<int> devices;
+    if (!parse_devices(&devices, &err)) { fprintf(stderr, "goleft depth: %s\n", err.c_str()); return 1; }
+    early.start(devices);
     gdh::BamReader bam;
     if (!bam.open(args.bam, args.processes, &err)) {
         fprintf(stderr, "goleft depth: %s\n", err.c_str());
@@ -456,8 +486,6 @@ int run(const DArgs& args)
 
     // ---- device engines: one context per device, contigs assigned by LPT -------------------
     Shards S;                                                // destroys every context on any return
-    std::vector<int> devices;
-    if (!parse_devices(&devices, &err)) { fprintf(stderr, "goleft depth: %s\n", err.c_str()); return 1; }
     std::vector<int64_t> lens(contigs.size());
     for (size_t i = 0; i < contigs.size(); ++i) lens[i] = contigs[i].length;
     const size_t n_shards = std::max<size_t>(1, std::min(devices.size(), std::max<size_t>(wanted.size(), 1)));
@@ -487,7 +515,7 @@ int run(const DArgs& args)
         sh.device = devices[k];
         sh.wanted = assignment[k];
         for (int32_t t : sh.wanted) shard_of[(size_t)t] = (int)k;
-        const int rc = gd_create(sh.device, &sh.ctx);
+        const int rc = early.take(k, &sh.ctx);               // (created since the start of run(), on its own thread)
         if (rc != GD_OK) {
             fprintf(stderr, "goleft depth: no usable MI355X device %d (%s); this build has no CPU path\n", sh.device, gd_strerror(rc));
             return 1;

@@ -61,7 +61,8 @@ def test_finish_repeats_a_failed_attempt_and_the_order_is_enforced():
     with DepthEngine(0) as eng:
         eng.set_params(window_size=250, min_mapq=1, min_cov=1)
         eng.set_path(1)
-        eng.set_contigs([L])
+        eng.set_option(14, 0)                                  # GD_OPT_INGEST_INDEX off: spans are not measured at arrival, the
+        eng.set_contigs([L])                                   # look-back starts at the default and has to be learnt
         eng.push(0, r.pos, r.flag, r.mapq, r.cigar_off, r.cigar)
         with pytest.raises(GdError):
             eng.compute_finish()                               # nothing launched

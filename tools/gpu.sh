@@ -27,7 +27,7 @@ for st in "$@"; do
     tests*)
       what=${st#tests}; case "$what" in *tests/*) ;; *) what="tests $what";; esac      # "tests" = the whole directory; "tests tests/x.py -k y" = just that
       echo "== pytest -m gpu $what" >> $LOG
-      timeout 1500 python -X faulthandler -m pytest -m gpu -x -q $what > gpurun_out/${T}_pytest.txt 2>&1
+      timeout 1500 python -X faulthandler -m pytest -m gpu --maxfail=8 -q $what > gpurun_out/${T}_pytest.txt 2>&1
       grep -n "Fatal\|fault\|tests/.*line\|passed\|failed\|Error" gpurun_out/${T}_pytest.txt | head -30 >> $LOG
       tail -5 gpurun_out/${T}_pytest.txt >> $LOG ;;
     bench:*)
