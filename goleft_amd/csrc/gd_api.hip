@@ -102,6 +102,7 @@ int gd_create(int device_id, gd_ctx** out)
     if ((e = hipMemset(c->d_counters, 0, sizeof(gd::Counters))) != hipSuccess) return bail(e);
     if ((e = hipMalloc(reinterpret_cast<void**>(&c->d_ingest), 4 * sizeof(uint32_t))) != hipSuccess) return bail(e);
     if ((e = hipMemset(c->d_ingest, 0, 4 * sizeof(uint32_t))) != hipSuccess) return bail(e);
+    if ((e = hipHostMalloc(reinterpret_cast<void**>(&c->h_ingest), 4 * sizeof(uint32_t), hipHostMallocDefault)) != hipSuccess) return bail(e);
     *out = c;
     return GD_OK;
 }
@@ -115,7 +116,7 @@ void gd_destroy(gd_ctx* c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
     (void)gd_ingest_abort(c);
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < 8; ++k) {
         if (c->ing_stage[k]) (void)hipHostFree(c->ing_stage[k]);
         if (c->ing_staged[k]) (void)hipEventDestroy(c->ing_staged[k]);
     }
@@ -123,7 +124,9 @@ void gd_destroy(gd_ctx* c)
     for (hipStream_t st : c->ing_dma) if (st) (void)hipStreamDestroy(st);
     if (c->ing_hp) (void)hipStreamDestroy(c->ing_hp);
     for (auto& evs : c->ing_dma_ev) for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
-    for (auto& b : c->ing_bufs) b.drop();
+    for (auto& b : c->ing_bufs) b.drop_all();
+    if (c->h_walk) (void)hipHostFree(c->h_walk);
+    if (c->h_ingest) (void)hipHostFree(c->h_ingest);
     for (auto& h : c->contigs) free_contig(h);
     for (auto& s : c->ring) {
         if (s.b.pos) (void)hipHostFree(s.b.pos);
@@ -395,6 +398,17 @@ static int index_records(gd_ctx* c, ContigHost& h, size_t r0, size_t r1, int32_t
     HIPCHK(c, hipGetLastError());
     if (idx) h.ridx_reads = r1;
     if (j.walk_ops) c->ingest_span_dirty = true;
+    return GD_OK;
+}
+
+// d_ingest's words on the host: a one-wave kernel stores them into page-locked memory and the stream is waited for -- no
+// copy command (a device-to-host copy queues on the copy engine behind whatever a read in progress has put there).
+static int read_ingest_words(gd_ctx* c, hipStream_t st, uint32_t (&w)[3])
+{
+    hipLaunchKernelGGL(gd::gd_copy_words_kernel, dim3(1), dim3(64), 0, st, c->d_ingest, c->h_ingest, 3u);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(st));
+    w[0] = c->h_ingest[0]; w[1] = c->h_ingest[1]; w[2] = c->h_ingest[2];
     return GD_OK;
 }
 
@@ -689,11 +703,7 @@ int gd_adopt_device(gd_ctx* c, int32_t tid, const gd_batch* d, size_t n_reads, s
         int r = GD_OK;
         if (hipMemsetAsync(c->d_ingest, 0, sizeof(uint32_t), c->stream) != hipSuccess) r = fail(c, GD_E_HIP, "hipMemsetAsync failed");
         if (r == GD_OK) r = index_records(c, t, 0, n_reads, -1, true, c->stream);
-        if (r == GD_OK) {
-            hipError_t e = hipMemcpyAsync(w, c->d_ingest, sizeof w, hipMemcpyDeviceToHost, c->stream);
-            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-            if (e != hipSuccess) r = fail(c, GD_E_HIP, "reading the record check back failed: %s", hipGetErrorString(e));
-        }
+        if (r == GD_OK) r = read_ingest_words(c, c->stream, w);
         if (r == GD_OK) {
             const uint32_t bad = w[0];
             if (bad & 4u) r = fail(c, GD_E_RANGE, "contig %d: a device record has a negative position (a placed BAM record has POS >= 0)", tid);
@@ -836,6 +846,11 @@ int gd_set_option(gd_ctx* c, int option, int64_t value)
         c->push_threads = (int)value;
         break;
     case GD_OPT_INGEST_INDEX: c->ingest_index = value != 0; break;
+    case GD_OPT_INGEST_PIECE_STREAMS:
+        if (value < 1 || value > 4) return fail(c, GD_E_INVALID, "ingest piece streams: 1 .. 4");
+        if (c->ing_n) return fail(c, GD_E_STATE, "a device BAM read is pending");
+        c->ing_piece_streams = (int)value;
+        break;
     default: return fail(c, GD_E_INVALID, "unknown option %d", option);
     }
     c->computed = false;

@@ -95,13 +95,31 @@ struct IngestBufs {
         *cap = need ? need : 1;
         return true;
     }
+    // The member tables live in PAGE-LOCKED HOST memory that the kernels read (and write: the status words) over the
+    // link: a few bytes per member, once.  As device arrays they were five blocking uploads per range -- each of which
+    // queued on the copy engine behind the 64 MB pieces of the read in progress (20 ms per gd_ingest_begin measured).
+    static bool fit_host(void** p, size_t* cap, size_t need)
+    {
+        if (need <= *cap && *p) return true;
+        if (*p) { (void)hipHostFree(*p); *p = nullptr; *cap = 0; }
+        const size_t want = need + need / 2 + 4096;
+        if (hipHostMalloc(p, want, hipHostMallocDefault) != hipSuccess) { *p = nullptr; return false; }
+        *cap = want;
+        return true;
+    }
     void drop()
     {
         if (in) (void)hipFree(in);
         if (out) (void)hipFree(out);
-        if (tab) (void)hipFree(tab);
-        in = out = tab = nullptr;
-        cap_in = cap_out = cap_tab = 0;
+        in = out = nullptr;
+        cap_in = cap_out = 0;
+    }
+    void drop_all()
+    {
+        drop();
+        if (tab) (void)hipHostFree(tab);
+        tab = nullptr;
+        cap_tab = 0;
     }
 };
 
@@ -200,15 +218,17 @@ struct gd_ctx {
     double ing_secs[7] = {0, 0, 0, 0, 0, 0, 0};         // gd_ingest_timing
     std::thread ing_feeder;                             // gd_ingest_feed_fd: the read of the newest range in progress
     int ing_feeder_rc = 0;
-    bool ing_stage_used[2] = {false, false};
+    bool ing_stage_used[8] = {false, false, false, false, false, false, false, false};
     int ing_cur = 0;
     IngestBufs ing_bufs[2];
     // staging of the device BAM read, created by the first gd_ingest_begin and kept until gd_destroy
     // (page-locking 128 MB per contig would cost more than many contigs' whole decode)
-    uint8_t* ing_stage[2] = {nullptr, nullptr};
-    hipEvent_t ing_staged[2] = {nullptr, nullptr};
+    uint8_t* ing_stage[8] = {};                        // page-locked staging buffers: two per upload stream
+    hipEvent_t ing_staged[8] = {};
+    int ing_piece_streams = 1;                         // GD_OPT_INGEST_PIECE_STREAMS: whole pieces alternate over this many streams (copy engines)
+    uint64_t ing_piece_seq = 0;
     hipStream_t ing_dma[3] = {nullptr, nullptr, nullptr};   // GD_OPT_INGEST_DMA > 1: a staged piece leaves in slices on several streams (DMA engines)
-    hipEvent_t ing_dma_ev[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
+    hipEvent_t ing_dma_ev[8][3] = {};
     int ing_dma_n = 1;
     hipStream_t ing_hp = nullptr;                       // GD_OPT_INGEST_DMA 0: the piece leaves with a copy kernel on a high-priority stream
     hipStream_t ing_stream[8] = {};                     // inflate launches rotate over these (two pending ranges x 4)
@@ -223,6 +243,9 @@ struct gd_ctx {
     FillPool* pool = nullptr; int pool_workers = 0;    // host worker threads (gd_push fills, gd_commit validates), created on first use
     size_t push_chunk = 1u << 20;                      // GD_OPT_PUSH_CHUNK: records per staging block of gd_push                             // GD_OPT_PUSH_THREADS: threads of gd_push filling a ring block
     uint32_t* d_scan_tmp = nullptr; size_t cap_scan_tmp = 0;   // launch_scan: block totals
+    uint8_t* h_walk = nullptr; size_t cap_walk = 0;            // gd_ingest_decode: per-segment tables of the record walk (page-locked host memory
+                                                               // the walk kernels read and write over the link: no copy command)
+    uint32_t* h_ingest = nullptr;                              // page-locked: d_ingest's words as the host reads them (gd_copy_words_kernel)
     uint8_t* d_seq = nullptr;  size_t cap_seq = 0;     // gd_seq_load: one contig's bases, zero padded
     int64_t seq_len = -1;
     uint32_t seq_padded = 0;

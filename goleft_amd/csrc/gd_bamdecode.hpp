@@ -88,67 +88,137 @@ __device__ __forceinline__ bool bam_record_cigar(const uint8_t* r, uint32_t bloc
     return true;
 }
 
+// ONE WAVE PER SEGMENT.  Records are self-delimiting only forwards, so finding where they start is a chain of
+// dependent reads -- as loads from HBM, one lane per segment, that chain cost ~2 us per record and a pass over a
+// chromosome's 3 300 records per segment took 20 - 30 ms however few segments there were (a reference read in 1 GB
+// parts paid that per part: 4 s per genome, more than the link).  Here the wave stages 3 KB of the stream in LDS with
+// coalesced 16-byte loads, lane 0 follows the block_size chain THERE (an LDS round trip per record) and notes up to 32
+// record starts, and then every lane takes one record -- CIGAR resolved (CG:B,I), fields extracted -- with 64 records'
+// memory latencies in flight at once.  Output positions inside a round come from the op counts the lanes leave in LDS.
+// LDS: 3 KB of stream + 0.5 KB of tables.  Not more: the walks run BESIDE the inflate kernel of the next range, whose six
+// workgroups per CU leave 4 KB of LDS -- with a 16 KB window a walk workgroup waited for an inflate workgroup to retire.
+constexpr int BW_WIN = 3072;           // bytes of the stream staged per round
+constexpr int BW_REC = 32;             // records per round at most (one lane each)
+
 template <bool EXTRACT>
 __global__ __launch_bounds__(64) void gd_bam_walk_kernel(BamSegJob j)
 {
-    const uint32_t s = blockIdx.x * 64 + threadIdx.x;
+    __shared__ __attribute__((aligned(16))) uint8_t s_win[BW_WIN];
+    __shared__ uint64_t s_off[BW_REC];     // stream offsets of the round's records
+    __shared__ uint32_t s_nc[BW_REC];      // their op counts
+    __shared__ uint32_t s_bad[BW_REC];
+    __shared__ uint64_t s_wbase;           // where the next window begins (16-byte aligned)
+    __shared__ uint32_t s_n, s_done;       // records of this round; the segment is finished
+    const uint32_t s = blockIdx.x;
     if (s >= j.n_seg) return;
-    uint64_t off = j.seg_beg[s];
+    const uint32_t lane = threadIdx.x;
     const uint64_t stop = j.seg_end[s];
+    // lane 0's walk state
+    uint64_t off = j.seg_beg[s];
     uint32_t nrec = 0, fl = 0;
     uint64_t nops = 0;
     int32_t first = 0x7fffffff, last = -0x7fffffff;
+    // every lane's copy of where the round's output begins
     uint64_t ri = EXTRACT ? j.rec_base[s] : 0, oi = EXTRACT ? j.op_base[s] : 0;
-    while (off < stop) {
-        if (off + 36 > j.n_bytes) { fl |= 2u; break; }
-        const uint8_t* r = j.data + off + 4;
-        const uint32_t block_size = ld32(j.data + off);
-        if (block_size < 32 || off + 4 + block_size > j.n_bytes) { fl |= 2u; break; }
-        const int32_t ref_id = (int32_t)ld32(r);
-        if (ref_id != j.tid) {
-            // the contig's records end here -- in a sorted BAM.  `samtools depth -r` stops at the first record of
-            // another reference and so does this walk; that the reference does not RESUME is checked over the next
-            // records up to the segment's end (at most 64: one damaged refID is caught, a contig's true end costs
-            // nothing), and by the host across segments (bit 3)
-            fl |= 8u;
-            if (!(ref_id == -1 || (ref_id > j.tid && ref_id < j.n_ref))) { fl |= 2u; break; }   // not a refID a sorted BAM holds here: a damaged record (or a walk out of step)
-            if (!EXTRACT) {
-                uint64_t o2 = off;
-                for (int k = 0; k < 64 && o2 < stop; ++k) {
-                    if (o2 + 36 > j.n_bytes) break;
-                    const uint32_t bs = ld32(j.data + o2);
-                    if (bs < 32 || o2 + 4 + bs > j.n_bytes) break;
-                    if ((int32_t)ld32(j.data + o2 + 4) == j.tid) { fl |= 16u; break; }
-                    o2 += 4ull + bs;
+    if (lane == 0) { s_wbase = off & ~15ull; s_done = off < stop ? 0u : 1u; s_n = 0; }
+    __syncthreads();
+    while (s_done == 0u) {
+        // ---- (1) the window: [wbase, wbase + BW_WIN), bytes past the stream read as zero ----
+        const uint64_t wbase = s_wbase;
+        for (uint32_t i = lane; i < BW_WIN / 16; i += 64) {
+            const uint64_t a = wbase + 16ull * i;
+            uint32_t w[4] = {0, 0, 0, 0};
+            if (a + 16 <= j.n_bytes) __builtin_memcpy(w, j.data + a, 16);
+            else if (a < j.n_bytes) __builtin_memcpy(w, j.data + a, (size_t)(j.n_bytes - a));
+            __builtin_memcpy(s_win + 16u * i, w, 16);
+        }
+        __syncthreads();
+        // ---- (2) lane 0: the block_size chain, in LDS ----
+        if (lane == 0) {
+            uint32_t k = 0, done = 0;
+            while (k < (uint32_t)BW_REC) {
+                if (off >= stop) { done = 1; break; }
+                const uint64_t rel = off - wbase;
+                if (rel + 16 > (uint64_t)BW_WIN) break;                     // block_size, refID and POS of the record lie in the next window
+                if (off + 36 > j.n_bytes) { fl |= 2u; done = 1; break; }
+                const uint32_t block_size = ld32(s_win + rel);
+                if (block_size < 32 || off + 4 + block_size > j.n_bytes) { fl |= 2u; done = 1; break; }
+                const int32_t ref_id = (int32_t)ld32(s_win + rel + 4);
+                if (ref_id != j.tid) {
+                    // the contig's records end here -- in a sorted BAM.  `samtools depth -r` stops at the first record of
+                    // another reference and so does this walk; that the reference does not RESUME is checked over the next
+                    // records up to the segment's end (at most 64: one damaged refID is caught, a contig's true end costs
+                    // nothing), and by the host across segments (bit 3)
+                    fl |= 8u;
+                    done = 1;
+                    if (!(ref_id == -1 || (ref_id > j.tid && ref_id < j.n_ref))) { fl |= 2u; break; }   // not a refID a sorted BAM holds here: a damaged record (or a walk out of step)
+                    if (!EXTRACT) {
+                        uint64_t o2 = off;
+                        for (int q = 0; q < 64 && o2 < stop; ++q) {
+                            if (o2 + 36 > j.n_bytes) break;
+                            const uint32_t bs = ld32(j.data + o2);
+                            if (bs < 32 || o2 + 4 + bs > j.n_bytes) break;
+                            if ((int32_t)ld32(j.data + o2 + 4) == j.tid) { fl |= 16u; break; }
+                            o2 += 4ull + bs;
+                        }
+                    }
+                    break;
                 }
+                const int32_t pos = (int32_t)ld32(s_win + rel + 8);
+                // POS -1 is BAM's "no position": a record filed under the reference but not placed on it (what `samtools
+                // depth` drops through the 0x4 flag such a record carries) is not part of the contig's stream
+                if (pos >= 0) {
+                    if (nrec && pos < last) fl |= 1u;
+                    if (nrec == 0) first = pos;
+                    last = pos;
+                    ++nrec;
+                    s_off[k++] = off;
+                }
+                off += 4ull + block_size;
             }
-            break;
+            if (!done && off >= stop) done = 1;
+            s_n = k;
+            s_done = done;
+            s_wbase = off & ~15ull;
         }
-        const int32_t pos = (int32_t)ld32(r + 4);
-        // POS -1 is BAM's "no position": a record filed under the reference but not placed on it (what `samtools
-        // depth` drops through the 0x4 flag such a record carries) is not part of the contig's stream
-        if (pos < 0) { off += 4ull + block_size; continue; }
-        const uint8_t* cg;
-        uint32_t nc;
-        if (!bam_record_cigar(r, block_size, &cg, &nc)) { fl |= 2u; break; }
-        if (nrec && pos < last) fl |= 1u;
-        if (nrec == 0) first = pos;
-        last = pos;
-        if (EXTRACT) {
-            j.pos[ri] = pos;
-            j.mapq[ri] = r[9];
-            j.flag[ri] = (uint16_t)((uint32_t)r[14] | ((uint32_t)r[15] << 8));
-            j.cigar_off[ri] = (uint32_t)oi;
-            for (uint32_t k = 0; k < nc; ++k) j.cigar[oi + k] = ld32(cg + 4 * (uint64_t)k);
-            ++ri;
-            oi += nc;
+        __syncthreads();
+        // ---- (3) one record per lane: its CIGAR (the stored one or the CG tag's) ----
+        const uint32_t n = s_n;
+        const uint8_t* r = nullptr;
+        const uint8_t* cg = nullptr;
+        uint32_t nc = 0;
+        if (lane < n) {
+            const uint64_t o = s_off[lane];
+            r = j.data + o + 4;
+            const bool ok = bam_record_cigar(r, ld32(j.data + o), &cg, &nc);
+            s_bad[lane] = ok ? 0u : 1u;
+            s_nc[lane] = ok ? nc : 0u;
         }
-        ++nrec;
-        nops += nc;
-        off += 4ull + block_size;
+        __syncthreads();
+        uint32_t bad = 0;
+        uint64_t before = 0, total = 0;                                     // ops of the round's records in front of this lane's; of all
+        for (uint32_t q = 0; q < n; ++q) {
+            bad |= s_bad[q];
+            if (q < lane) before += s_nc[q];
+            total += s_nc[q];
+        }
+        if (bad) {                                                          // a corrupt record: the host refuses the file
+            if (lane == 0) { fl |= 2u; s_done = 1; }
+        } else if (EXTRACT && lane < n) {
+            const uint64_t rr = ri + lane, oo = oi + before;
+            j.pos[rr] = (int32_t)ld32(r + 4);
+            j.mapq[rr] = r[9];
+            j.flag[rr] = (uint16_t)((uint32_t)r[14] | ((uint32_t)r[15] << 8));
+            j.cigar_off[rr] = (uint32_t)oo;
+            for (uint32_t q = 0; q < nc; ++q) j.cigar[oo + q] = ld32(cg + 4 * (uint64_t)q);
+        }
+        ri += n;
+        oi += total;
+        if (lane == 0) nops += total;
+        __syncthreads();                                                    // (s_done above; and nobody still reads what the next round overwrites)
     }
-    if (off > stop) fl |= 4u;                                // an anchor that is not a record start
-    if (!EXTRACT) {
+    if (lane == 0 && !EXTRACT) {
+        if (off > stop) fl |= 4u;                                // an anchor that is not a record start
         j.n_rec[s] = nrec;
         j.n_ops[s] = nops;
         j.first_pos[s] = first;

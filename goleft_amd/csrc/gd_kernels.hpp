@@ -359,6 +359,11 @@ __global__ void gd_prep_kernel(Job job)
     job.ftiles[t] = tf;
 }
 
+__global__ __launch_bounds__(64) void gd_copy_words_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, uint32_t n)
+{
+    for (uint32_t i = threadIdx.x; i < n; i += 64u) dst[i] = src[i];
+}
+
 // What the host reads after a compute: the counter block and the boundaries that exist (at most `spec`), stored
 // straight into page-locked host memory.
 __global__ __launch_bounds__(256) void gd_readback_kernel(const Counters* __restrict__ k, const int2* __restrict__ ordered, uint32_t spec,

@@ -212,6 +212,10 @@ enum { /* (1, 2: tile shapes other than 4096 positions x 256 threads -- measured
                                        ranges up instead of searching) and the largest reference span of any record (the first
                                        gd_compute starts with the right look-back instead of learning it; still verified).
                                        0: neither (the prep kernel searches, the look-back starts at max_span_hint or 512) */
+       GD_OPT_INGEST_PIECE_STREAMS = 15, /* gd_ingest_feed*: WHOLE staged pieces (64 MB) alternate over this many streams, two staging
+                                       buffers each: 1 (default) .. 4.  One copy engine moves 20 - 25 GB/s next to the inflate
+                                       kernels; this asks for several at once (GD_OPT_INGEST_DMA > 1 cuts ONE piece into slices
+                                       instead, which was measured slower) */
        GD_OPT_H2D_KERNEL = 8 };     /* how a committed staging block reaches HBM: 1 (default) one kernel whose workgroups
                                        read the page-locked block over the link (all five arrays in one launch; n > 1:
                                        with n workgroups), 0: five hipMemcpyAsync through a DMA engine */

@@ -24,7 +24,7 @@ extern "C" int emul_bam_walk(const uint8_t* data, uint64_t n_bytes, const uint64
     j.data = d.p; j.n_bytes = n_bytes; j.seg_beg = seg_beg; j.seg_end = seg_end; j.tid = tid; j.n_ref = n_ref; j.n_seg = n_seg;
     j.n_rec = n_rec; j.n_ops = n_ops; j.first_pos = first; j.last_pos = last; j.flags = flags;
     g_job = &j;
-    for (unsigned b = 0; b < (n_seg + 63u) / 64u; ++b) emul::run(body_count, 64, b);
+    for (unsigned b = 0; b < n_seg; ++b) emul::run(body_count, 64, b);          // one wave per segment
     std::vector<uint64_t> rbase(n_seg), obase(n_seg);
     uint64_t N = 0, M = 0;
     bool clean = true;
@@ -40,7 +40,7 @@ extern "C" int emul_bam_walk(const uint8_t* data, uint64_t n_bytes, const uint64
     j.rec_base = rbase.data(); j.op_base = obase.data();
     j.pos = reinterpret_cast<int32_t*>(g_pos.p + 4); j.flag = reinterpret_cast<uint16_t*>(g_flag.p + 2); j.mapq = g_mapq.p + 1;
     j.cigar_off = reinterpret_cast<uint32_t*>(g_off.p + 4); j.cigar = reinterpret_cast<uint32_t*>(g_cig.p + 4);
-    for (unsigned b = 0; b < (n_seg + 63u) / 64u; ++b) emul::run(body_extract, 64, b);
+    for (unsigned b = 0; b < n_seg; ++b) emul::run(body_extract, 64, b);
     memcpy(pos, j.pos, N * 4); memcpy(flag, j.flag, N * 2); memcpy(mapq, j.mapq, N);
     memcpy(cigar_off, j.cigar_off, N * 4); memcpy(cigar, j.cigar, M * 4);
     return 0;

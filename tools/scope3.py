@@ -29,10 +29,15 @@ def main():
     ap.add_argument("--variants", default="", help="extra device-decoder runs, each a comma list of ENV=VALUE, separated by ';' "
                                                    "(e.g. 'GOLEFT_INGEST_GROUP_MB=4096;GOLEFT_COPY_THREADS=16')")
     ap.add_argument("--no-host", action="store_true", help="skip the host-decoder run")
+    ap.add_argument("--dir", default="", help="where the BAM is written (default: /dev/shm when it has the room, else /tmp)")
     ap.add_argument("--host-reps", type=int, default=3, help="repetitions of the host-decoder run (device runs: 3)")
     ap.add_argument("--rocprof", default="", help="directory: one more device-decoder run under rocprofv3 --kernel-trace --stats")
     args = ap.parse_args()
-    d = tempfile.mkdtemp(prefix="gd_scope3_", dir="/tmp")
+    import shutil
+    need = sum(int(x) for x in args.length.split(",")) * 17
+    # a RAM-backed directory when it has the room (the GPU boxes' /tmp is an overlay that writes at 0.3 GB/s)
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and shutil.disk_usage("/dev/shm").free > need * 1.3 else "/tmp"
+    d = tempfile.mkdtemp(prefix="gd_scope3_", dir=args.dir or base)
     bam = os.path.join(d, "synth.bam")
     t0 = time.perf_counter()
     if args.paper:
@@ -46,7 +51,7 @@ def main():
     out = {"scope": "BAM file -> depth.bed + callable.bed (goleft-depth CLI, process start to exit)",
            "invocation": "goleft-depth depth -w %d -p %d %s--prefix OUT synth.bam" % (args.window, args.threads, " ".join(extra) + (" " if extra else "")),
            "ref_bases": args.length, "coverage": args.coverage, "reads": info["reads"],
-           "bam_MB": info["bam_bytes"] / 1e6, "host_cores": os.cpu_count(), "bam_write_s": t_write}
+           "bam_MB": info["bam_bytes"] / 1e6, "host_cores": os.cpu_count(), "bam_write_s": t_write, "dir": d}
     beds = {}
     variants = [("device", {}), ("host", {"GOLEFT_GPU_DECODE": "0"})]
     if args.no_host:

@@ -50,7 +50,8 @@ static int reg2bin(int64_t beg, int64_t end)
 static void bgzf_member(const uint8_t* data, size_t n, std::vector<uint8_t>* out)
 {
     out->clear();
-    std::vector<uint8_t> c(n + n / 8 + 128);
+    static thread_local std::vector<uint8_t> c;          // (scratch kept per thread: 3 million members otherwise allocate and zero 74 KB each)
+    if (c.size() < n + n / 8 + 128) c.resize(n + n / 8 + 128);
     z_stream zs;
     memset(&zs, 0, sizeof zs);
     deflateInit2(&zs, 1, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY);
@@ -85,21 +86,43 @@ int main(int argc, char** argv)
     const int fd = open(path.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
     if (fd < 0) { perror("open"); return 1; }
 
-    std::vector<uint8_t> raw;                 // uncompressed BAM bytes of the current batch
-    raw.reserve(300u << 20);
+    // uncompressed BAM bytes not yet written: a plain buffer (a std::vector zero-fills what resize() adds -- 4 GB per
+    // batch on one thread, a third of the tool's run time on a 256-core host)
+    struct Raw {
+        uint8_t* p = nullptr; size_t n = 0, cap = 0;
+        size_t size() const { return n; }
+        uint8_t* data() { return p; }
+        void grow_to(size_t m)
+        {
+            if (m > cap) {
+                size_t nc = std::max(m, cap + cap / 2);
+                uint8_t* q = static_cast<uint8_t*>(malloc(nc));
+                if (!q) { perror("malloc"); exit(1); }
+                if (n) memcpy(q, p, n);
+                free(p);
+                p = q; cap = nc;
+            }
+            n = m;
+        }
+        void drop_front(size_t k) { if (k < n) memmove(p, p + k, n - k); n -= k; }
+    } raw;
+    std::vector<uint8_t> hdr;
     std::string text = "@HD\tVN:1.6\tSO:coordinate\n";
     for (size_t k = 0; k < lens.size(); ++k) text += "@SQ\tSN:" + names[k] + "\tLN:" + std::to_string(lens[k]) + "\n";
     text += "@RG\tID:rg1\tSM:synth\n";
-    raw.insert(raw.end(), {'B', 'A', 'M', 1});
-    put32(raw, (uint32_t)text.size());
-    raw.insert(raw.end(), text.begin(), text.end());
-    put32(raw, (uint32_t)lens.size());
+    hdr.insert(hdr.end(), {'B', 'A', 'M', 1});
+    put32(hdr, (uint32_t)text.size());
+    hdr.insert(hdr.end(), text.begin(), text.end());
+    put32(hdr, (uint32_t)lens.size());
     for (size_t k = 0; k < lens.size(); ++k) {
-        put32(raw, (uint32_t)names[k].size() + 1);
-        raw.insert(raw.end(), names[k].begin(), names[k].end());
-        raw.push_back(0);
-        put32(raw, (uint32_t)lens[k]);
+        put32(hdr, (uint32_t)names[k].size() + 1);
+        hdr.insert(hdr.end(), names[k].begin(), names[k].end());
+        hdr.push_back(0);
+        put32(hdr, (uint32_t)lens[k]);
     }
+
+    raw.grow_to(hdr.size());
+    memcpy(raw.data(), hdr.data(), hdr.size());
 
     const size_t BLK = 0xff00;
     uint64_t out_bytes = 0;
@@ -114,8 +137,11 @@ int main(int argc, char** argv)
         // the sizes before it give (one thread's fwrite of 46 GB was a third of the tool's run time)
         const size_t nblk = raw.size() / BLK + ((final && raw.size() % BLK) ? 1 : 0);
         const size_t nt = (size_t)threads;
-        std::vector<std::vector<uint8_t>> comp(nt);
-        std::vector<std::vector<uint32_t>> sizes(nt);
+        // kept from flush to flush: fresh gigabytes per batch mean page faults of 256 threads on one address space
+        static std::vector<std::vector<uint8_t>> comp;
+        static std::vector<std::vector<uint32_t>> sizes;
+        comp.resize(nt); sizes.resize(nt);
+        for (size_t t = 0; t < nt; ++t) { comp[t].clear(); sizes[t].clear(); }
         std::vector<std::thread> pool;
         for (size_t t = 0; t < nt; ++t)
             pool.emplace_back([&, t]() {
@@ -146,7 +172,7 @@ int main(int argc, char** argv)
         out_bytes = at[nt];
         for (size_t t = 0; t < nt; ++t) csize.insert(csize.end(), sizes[t].begin(), sizes[t].end());
         const size_t used = std::min(raw.size(), nblk * BLK);
-        raw.erase(raw.begin(), raw.begin() + (long)used);
+        raw.drop_front(used);
         stream_off += used;
     };
 
@@ -236,7 +262,7 @@ int main(int argc, char** argv)
             pool.clear();
             std::vector<size_t> at((size_t)nch + 1, raw.size());
             for (int t = 0; t < nch; ++t) at[(size_t)t + 1] = at[(size_t)t] + chunks[(size_t)t].bytes.size();
-            raw.resize(at[(size_t)nch]);
+            raw.grow_to(at[(size_t)nch]);
             for (int t = 0; t < nch; ++t)
                 pool.emplace_back([&, t]() { memcpy(raw.data() + at[(size_t)t], chunks[(size_t)t].bytes.data(), chunks[(size_t)t].bytes.size()); });
             for (auto& th : pool) th.join();
