@@ -977,9 +977,19 @@ def main():
             which = "genome" if (os.cpu_count() or 1) >= 64 else "chr20-21"
         torch.cuda.empty_cache()
         try:
-            res = bam_file_scope(which, W)
+            # the genome-sized file with the device decoder (the number); the host decoder -- 39 s per genome on this
+            # class of box, profiles/r04f_bench_wgs_n1.json -- runs on a small file of the same make, where the two
+            # decoders' BED files are compared byte for byte
+            res = bam_file_scope(which, W, device_reps=2, host_decoder=which != "genome")
             if "error" in res and which == "genome" and args.bam_scope == "auto":
                 res = dict(bam_file_scope("chr1-2", W), fell_back_from=res["error"])
+            if which == "genome" and "error" not in res:
+                chk = bam_file_scope("chr20-21", W, device_reps=1, host_decoder=True)
+                res["decoders_identical_on"] = {k: chk.get(k) for k in ("file", "ref_bases", "bam_bytes", "outputs_identical", "error")
+                                                if k in chk}
+                res["decoders_identical_on"]["device_wall_s"] = (chk.get("device_decoder") or {}).get("wall_s")
+                res["decoders_identical_on"]["host_wall_s"] = (chk.get("host_decoder") or {}).get("wall_s")
+                res["outputs_identical"] = chk.get("outputs_identical")
             out["bam_file_scope"] = res
         except Exception as e:                       # never lose the headline line to a side measurement
             out["bam_file_scope"] = {"error": "%s: %s" % (type(e).__name__, e)}

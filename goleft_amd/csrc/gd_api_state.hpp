@@ -90,9 +90,13 @@ struct IngestBufs {
     static bool fit(void** p, size_t* cap, size_t need)
     {
         if (need <= *cap && *p) return true;
+        // (a quarter more than asked for when it has to GROW: ranges of about one size -- a reference read in parts --
+        // would otherwise free and allocate again for every range a little larger than the last, and a hipFree waits for
+        // the whole device, the other range's inflate kernels included)
+        const size_t want = *p ? need + need / 4 : (need ? need : 1);
         if (*p) { (void)hipFree(*p); *p = nullptr; *cap = 0; }
-        if (hipMalloc(p, need ? need : 1) != hipSuccess) { *p = nullptr; return false; }
-        *cap = need ? need : 1;
+        if (hipMalloc(p, want) != hipSuccess) { *p = nullptr; return false; }
+        *cap = want;
         return true;
     }
     // The member tables live in PAGE-LOCKED HOST memory that the kernels read (and write: the status words) over the

@@ -587,7 +587,7 @@ int run(const DArgs& args)
                                                                 // a reference larger than this is read in parts cut at .bai anchors
                                                                 // (0: never; _KB: tests cut small files)
                                                                 getenv("GOLEFT_INGEST_PART_KB") ? (uint64_t)env_int("GOLEFT_INGEST_PART_KB", 0) << 10
-                                                                                                : (uint64_t)env_int("GOLEFT_INGEST_PART_MB", 1024) << 20);
+                                                                                                : (uint64_t)env_int("GOLEFT_INGEST_PART_MB", 2048) << 20);
                     }))
                     return 1;
                 for (Shard& sh : S.v) {

@@ -303,7 +303,7 @@ inline bool list_members(const uint8_t* base, size_t nb, uint64_t beg, const std
 inline int ingest_references_on_device(gd_ctx* ctx, const FileMap& fm, const std::vector<std::vector<uint64_t>>& lin,
                                        const std::vector<int32_t>& refs, const std::vector<int32_t>& tids,
                                        uint64_t* n_records, bool* io_ok, uint64_t group_bytes = 512ull << 20,
-                                       const std::vector<uint64_t>* ref_end = nullptr, uint64_t part_bytes = 1ull << 30)
+                                       const std::vector<uint64_t>* ref_end = nullptr, uint64_t part_bytes = 2ull << 30)
 {
     *io_ok = true;
     *n_records = 0;
