@@ -405,7 +405,15 @@ def run_case(args, scaling, world, rank, dev, local_rank, want_streams=False):
         # on a fixed capacity, buffers are allocated once and the engine is told to fill the send
         # buffer itself (gd_set_export)
         eng.compute()
-        gath = shard.RootGather(assignment, lengths, W, rank, world, dev, bounds_cap=0)
+        native = os.environ.get("GOLEFT_BENCH_NATIVE_GATHER") == "1"
+        if native:
+            # the library's own collective (gd_comm_init / gd_gather_export: RCCL opened by the C ABI, what a cgo host
+            # calls); the 128-byte id travels through the process group that exists anyway
+            from goleft_amd.engine import comm_unique_id
+            box = [comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            eng.comm_init(rank, world, box[0])
+        gath = shard.RootGather(assignment, lengths, W, rank, world, dev, bounds_cap=0, native=native)
         gath.reserve(eng.device_runs()[1])
         gath.attach(eng)
 
@@ -540,6 +548,7 @@ def run_case(args, scaling, world, rank, dev, local_rank, want_streams=False):
                  "shard_ref_bases": loads, "lpt_imbalance": max(loads) / (sum(loads) / world),
                  "lpt_speedup_ceiling": sum(loads) / max(loads),
                  "gather_bytes_per_rank": int(gath.total * 8), "bounds_capacity": int(gath.cap_b),
+                 "collective": "gd_gather_export (RCCL from the C ABI)" if gath.native else "torch.distributed gather",
                  "pipelined": "in the timed loop a step is finish(k-1); flip(); launch(k); post(): the asynchronous, "
                               "double-buffered gather of step k-1 and its host-side cost run under the kernels of step k; "
                               "compute_ms / gather_ms here are measured one after the other"}

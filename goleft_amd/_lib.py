@@ -113,6 +113,11 @@ SYMBOLS = {
     "gd_get_stats": (C.c_int, [_P, C.POINTER(GdStats)]),
     "gd_set_profiling": (C.c_int, [_P, C.c_int]),
     "gd_kernel_ms": (C.c_int, [_P, C.c_int, C.POINTER(C.c_float)]),
+    "gd_comm_unique_id": (C.c_int, [_P, C.c_size_t]),
+    "gd_comm_init": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_size_t]),
+    "gd_comm_destroy": (C.c_int, [_P]),
+    "gd_gather_export": (C.c_int, [_P, _P, _P, C.c_size_t, C.c_int]),
+    "gd_gather_wait": (C.c_int, [_P]),
     "gd_compute_timing": (C.c_int, [_P, C.POINTER(C.c_double), C.c_int]),
 }
 

@@ -116,6 +116,8 @@ void gd_destroy(gd_ctx* c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
     (void)gd_ingest_abort(c);
+    (void)gd_comm_destroy(c);
+    for (hipEvent_t e : c->comm_ev) if (e) (void)hipEventDestroy(e);
     for (int k = 0; k < 8; ++k) {
         if (c->ing_stage[k]) (void)hipHostFree(c->ing_stage[k]);
         if (c->ing_staged[k]) (void)hipEventDestroy(c->ing_staged[k]);
@@ -749,6 +751,7 @@ int gd_reset(gd_ctx* c)
 #include "gd_api_results.inc"
 #include "gd_api_aux.inc"
 #include "gd_api_ingest.inc"
+#include "gd_api_comm.inc"
 
 int gd_device_perbase(gd_ctx* c, int32_t tid, const int32_t** dptr, int64_t* len)
 {

@@ -145,6 +145,8 @@ struct ComputeState {
     bool nothing = false;               // ... a job without tiles
 };
 
+struct GdUniqueId { char internal[128]; };   // ncclUniqueId's layout (rccl.h: NCCL_UNIQUE_ID_BYTES = 128)
+
 struct gd_ctx {
     int device = 0;
     hipStream_t stream = nullptr;       // compute stream
@@ -256,6 +258,12 @@ struct gd_ctx {
 
     int64_t* export_buf = nullptr;     // gd_set_export: caller-owned device buffer, written by every gd_compute
     int64_t export_max_w = 0, export_cap_b = 0;
+
+    // gd_comm_init: one RCCL communicator per context (gd_api_comm.inc)
+    void* comm = nullptr;
+    int comm_rank = 0, comm_world = 0;
+    hipEvent_t comm_ev[3] = {nullptr, nullptr, nullptr};   // [0], [1]: the last two gathers; [2]: "computed so far"
+    unsigned comm_seq = 0;
 
     ComputeState cs;
     bool computed = false;

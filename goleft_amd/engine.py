@@ -552,6 +552,23 @@ class DepthEngine:
         self._chk(self._lib.gd_set_export(self._ctx, C.c_void_p(device_ptr) if device_ptr else None,
                                           int(max_windows), int(cap_bounds)))
 
+    def comm_init(self, rank: int, world: int, unique_id: bytes):
+        """gd_comm_init: this context becomes rank `rank` of `world` (collective; RCCL opened on first use)."""
+        assert len(unique_id) >= 128
+        buf = (C.c_char * 128).from_buffer_copy(unique_id[:128])
+        self._chk(self._lib.gd_comm_init(self._ctx, int(rank), int(world), buf, 128))
+
+    def comm_destroy(self):
+        self._chk(self._lib.gd_comm_destroy(self._ctx))
+
+    def gather_export(self, recv_ptr: int = 0, words: int = 0, root: int = 0, send_ptr: int = 0):
+        """gd_gather_export: the export block (or send_ptr) to `root`, asynchronous on the context's copy stream."""
+        self._chk(self._lib.gd_gather_export(self._ctx, C.c_void_p(send_ptr) if send_ptr else None,
+                                             C.c_void_p(recv_ptr) if recv_ptr else None, int(words), int(root)))
+
+    def gather_wait(self):
+        self._chk(self._lib.gd_gather_wait(self._ctx))
+
     def wait_event(self, hip_event: int):
         """gd_wait_event: the engine's stream waits for a hipEvent_t (e.g. torch.cuda.Event().cuda_event)."""
         self._chk(self._lib.gd_wait_event(self._ctx, C.c_void_p(int(hip_event))))
@@ -566,3 +583,12 @@ def device_count() -> int:
     n = C.c_int()
     _lib.load().gd_device_count(C.byref(n))
     return n.value
+
+
+def comm_unique_id() -> bytes:
+    """gd_comm_unique_id: 128 bytes that every rank of a communicator must be given (RCCL's ncclUniqueId)."""
+    buf = (C.c_char * 128)()
+    rc = _lib.load().gd_comm_unique_id(buf, 128)
+    if rc != 0:
+        raise GdError(rc, "gd_comm_unique_id failed (RCCL not available?)")
+    return bytes(buf.raw)

@@ -86,9 +86,13 @@ class RootGather:
     cost falls under the kernels of step k too; step_exported() is flip() + post() for a synchronous compute."""
 
     def __init__(self, assignment: List[List[int]], lengths: Sequence[int], W: int, rank: int,
-                 world: int, device, bounds_cap: int = 1 << 16, group=None):
+                 world: int, device, bounds_cap: int = 1 << 16, group=None, native: bool = False):
+        """native: the collective is the library's own (gd_gather_export: grouped ncclSend / ncclRecv on the attached
+        engine's copy stream, RCCL opened by gd_comm_init) instead of torch.distributed's -- what a cgo host would
+        call.  The engine must have been given a communicator (DepthEngine.comm_init) and be attach()ed."""
         self.assignment, self.lengths, self.W = assignment, list(lengths), int(W)
         self.rank, self.world, self.device, self.group = rank, world, device, group
+        self.native = bool(native)
         self.nwin = [sum(n_windows(lengths[t], W) for t in assignment[r]) for r in range(world)]
         self.max_w = max(self.nwin) if self.nwin else 0
         self.words_m = (self.max_w + 1) // 2
@@ -118,6 +122,13 @@ class RootGather:
         needs: the next compute must not write into a buffer the collective of two steps ago may still read; with
         a rank's step at ~0.5 ms a blocking wait here was the kind of fixed cost that decides 6x or 7x at N = 8)."""
         w = self._works[k] if getattr(self, "_works", None) else None
+        if w == "native":
+            # the library keeps its own order: the compute stream waits for the gather before the last one
+            # (gd_gather_export); only a host-side wait has anything to do
+            if host:
+                self._eng.gather_wait()
+            self._works[k] = None
+            return
         if w is not None:
             w.wait()                                            # NCCL: the current torch stream waits; gloo: the host does
             cuda = self.device is not None and torch.device(self.device).type == "cuda"
@@ -149,7 +160,11 @@ class RootGather:
         """ONE collective on the buffer pair flip() retired, asynchronous."""
         k = self._last
         buf = self._sends[k]
-        if self.world == 1:
+        if self.native:
+            self._eng.gather_export(recv_ptr=self._recvs[k].data_ptr() if self.rank == 0 else 0, words=self.total, root=0,
+                                    send_ptr=buf.data_ptr())
+            self._works[k] = "native"
+        elif self.world == 1:
             self._recvs[k][0].copy_(buf)
         elif self.rank == 0:
             self._works[k] = dist.gather(buf, self._partss[k], dst=0, group=self.group, async_op=True)

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define GD_ABI_VERSION 12
+#define GD_ABI_VERSION 13
 
 typedef enum {
     GD_OK = 0,
@@ -548,6 +548,29 @@ int gd_set_export(gd_ctx* ctx, void* device_buf, int64_t max_windows, int64_t ca
  * engine "the collective that was still reading this buffer is over" without blocking the host
  * (hipStreamWaitEvent on the context's stream). */
 int gd_wait_event(gd_ctx* ctx, void* hip_event);
+
+/* ---- the exchange step: export blocks to one root over RCCL (xGMI between the GPUs of a node) ----------------
+ * One context per GPU, one rank per context -- in one process (a worker thread per device, the counterpart of the
+ * reference's `-p` pool, depth/depth.go:392-394) or one process per GPU.  The root owns the BED files like the
+ * reference's merge loop (depth/depth.go:394-421) and receives every rank's export block (gd_set_export: window sums,
+ * minima, ordered class-run boundaries; the boundary count travels in word 0) with ONE grouped send / receive.
+ *   gd_comm_unique_id   on one rank; the 128 bytes reach the others by whatever means the host has (a Go channel,
+ *                       a file, MPI, torch.distributed)
+ *   gd_comm_init        collective over the `world` contexts; librccl is opened here, on first use (dlopen): a
+ *                       single-GPU run never loads it.  GD_E_NODEVICE: no RCCL on this machine
+ *   gd_gather_export    after a gd_compute: `words` int64 words -- send == NULL: the export block (words == 0: all
+ *                       of it) -- to `root`, which receives rank r's at recv + r * words (every rank passes the same
+ *                       `words`).  Asynchronous: issued on the context's copy stream behind the compute that filled
+ *                       the block, so it runs under the kernels of the next gd_compute; with two export buffers
+ *                       alternating (gd_set_export before each compute) nothing is written into a buffer a gather
+ *                       may still read -- the compute stream waits for the gather before the last one
+ *   gd_gather_wait      the host waits until every gather issued so far has landed */
+#define GD_COMM_ID_BYTES 128
+int gd_comm_unique_id(void* id, size_t bytes);
+int gd_comm_init(gd_ctx* ctx, int rank, int world, const void* id, size_t bytes);
+int gd_comm_destroy(gd_ctx* ctx);
+int gd_gather_export(gd_ctx* ctx, const int64_t* send, int64_t* recv, size_t words, int root);
+int gd_gather_wait(gd_ctx* ctx);
 
 /* ---- measurement ---------------------------------------------------------*/
 int gd_get_stats(gd_ctx* ctx, gd_stats* out);

@@ -600,6 +600,37 @@ def depthwed_cell(mean_text: str) -> int:
     return int(0.5 + float(mean_text))
 
 
+def depthwed_cells_contig(sums, length: int, W: int, size: int):
+    """One sample's column of the depthwed matrix for ONE contig, from its W-window sums -- the chain the reference
+    runs through text, restated on arrays so that a whole chromosome (a million windows) takes seconds:
+    goleft depth prints "%.4g" of float64(sum) / float64(window length) per W-window (depth/depth.go:181-189, :301;
+    the last window of a contig is shorter); depthwed parses it back and adds int(0.5 + x) (depthwed/depthwed.go:96,
+    :103) over the rows of a group, a group running from the current row until its span reaches `size`
+    or the contig's rows run out (depthwed/depthwed.go:126: the loop also ends when the next row of the first file is on
+    another chromosome -- or absent -- so the last, shorter group of a contig IS written; `eof` only ends a group that
+    has read nothing).  -> (cells int64[rows], starts int64[rows], ends int64[rows]);
+    tests/test_depthwed.py holds it against depthwed_py, the line-by-line restatement."""
+    sums = np.asarray(sums, np.int64)
+    nw = (length + W - 1) // W
+    assert sums.shape[0] == nw
+    ends = np.minimum((np.arange(nw, dtype=np.int64) + 1) * W, length)
+    starts = np.arange(nw, dtype=np.int64) * W
+    lens = ends - starts
+    cell = np.fromiter((depthwed_cell("%.4g" % (0.0 if s == 0 else float(s) / float(l)))
+                        for s, l in zip(sums.tolist(), lens.tolist())), np.int64, nw)
+    out_c, out_s, out_e = [], [], []
+    k = 0
+    while k < nw:
+        j = k
+        while j + 1 < nw and ends[j] - starts[k] < size:
+            j += 1                                   # rows k..j: the span reaches `size` with row j, or the rows run out
+        out_c.append(int(cell[k:j + 1].sum()))
+        out_s.append(int(starts[k]))
+        out_e.append(int(ends[j]))
+        k = j + 1
+    return np.asarray(out_c, np.int64), np.asarray(out_s, np.int64), np.asarray(out_e, np.int64)
+
+
 def depthwed_py(beds, names, size: int) -> str:
     """Line-by-line restatement of depthwed/depthwed.go:48-157 (`run` + `next`).
 

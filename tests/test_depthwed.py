@@ -161,3 +161,29 @@ def test_host_cli_survives_malformed_rows(seed):
         rc = _hostlib.load().gdh_depthwed_run(int(rng.choice([1, 250, 1000, 10 ** 9])), arr, len(paths),
                                               os.path.join(td, "o.txt").encode())
         assert isinstance(rc, int)
+
+
+@pytest.mark.parametrize("L,W,size", [(100001, 250, 1000), (35250, 250, 600), (999, 100, 100), (64000, 1000, 16000),
+                                      (4001, 250, 1000), (1000, 250, 1000), (1, 250, 1000)])
+def test_array_restatement_equals_the_line_by_line_one(L, W, size):
+    """pyoracle.depthwed_cells_contig (what the full-size GPU test of BASELINE config 4 compares with) against
+    depthwed_py on the BED text of the same window sums."""
+    rng = np.random.default_rng(L + W)
+    nw = (L + W - 1) // W
+    cols = [rng.integers(0, 90 * W, size=nw), rng.integers(0, 3, size=nw) * rng.integers(0, 5 * W, size=nw),
+            np.full(nw, 30 * W + 125)]
+    beds = []
+    for sums in cols:
+        rows = []
+        for k in range(nw):
+            s, e = k * W, min(L, (k + 1) * W)
+            mean = 0.0 if sums[k] == 0 else float(sums[k]) / float(e - s)
+            rows.append("chrQ\t%d\t%d\t%s" % (s, e, "%.4g" % mean))
+        beds.append("\n".join(rows) + "\n")
+    want = po.depthwed_py(beds, ["a", "b", "c"], size).strip().split("\n")[1:]
+    got = [po.depthwed_cells_contig(sums, L, W, size) for sums in cols]
+    assert all(len(g[0]) == len(want) for g in got)
+    for k, line in enumerate(want):
+        t = line.split("\t")
+        assert int(t[1]) == got[0][1][k] and int(t[2]) == got[0][2][k]
+        assert [int(x) for x in t[3:]] == [int(g[0][k]) for g in got], (k, line)

@@ -89,3 +89,62 @@ def test_export_attached_before_the_first_compute_with_more_runs_than_the_initia
         assert int(h[0]) == len(want) > 65536
         got = h[1 + nw + words_m:1 + nw + words_m + len(want)].view(np.int32).reshape(-1, 2)
         assert np.array_equal(got, np.stack([want[:, 0], want[:, 2]], 1))
+
+
+def test_native_gather_of_the_export_block_world_of_one():
+    """gd_comm_init / gd_gather_export: the exchange step inside the C ABI -- RCCL opened by
+    the library, a grouped send / receive of the export block on the context's copy stream.  One GPU here: a world of
+    one rank (the root sends to itself), which exercises the loading of RCCL, the communicator, the stream order
+    between compute, gather and the next compute, two alternating buffers, and the state machine's refusals."""
+    import torch
+    from goleft_amd import shard, synth
+    from goleft_amd.engine import DepthEngine, GdError, comm_unique_id
+    L = 3_000_000
+    r = po.Reads(*synth.short_reads_numpy(L, synth.n_reads_for(L, 12.0), 4))
+    W = 1000
+    dev = torch.device("cuda", 0)
+    with DepthEngine(0) as eng:
+        eng.set_params(window_size=W, min_mapq=1, min_cov=4)
+        eng.set_contigs([L])
+        eng.push(0, r.pos, r.flag, r.mapq, r.cigar_off, r.cigar)
+        with pytest.raises(GdError) as ei:
+            eng.gather_export(words=8)                         # no communicator yet
+        assert ei.value.status == -4
+        uid = comm_unique_id()
+        assert len(uid) == 128
+        eng.comm_init(0, 1, uid)
+        with pytest.raises(GdError):
+            eng.comm_init(0, 1, uid)                           # one communicator per context
+        eng.compute()
+        g = shard.RootGather([[0]], [L], W, 0, 1, dev, bounds_cap=0, native=True)
+        g.reserve(eng.device_runs()[1])
+        g.attach(eng)
+        d = po.perbase_c(r, 1, 0, L)
+        sums, mins = H.oracle_windows(d, W)
+        for step in range(5):                                  # the buffers alternate; every step is a full compute + gather
+            eng.compute()
+            g.step_exported()
+            res = g.result()
+            assert not res["overflow"]
+            parts = shard.unpack_gathered(res)
+            assert np.array_equal(parts[0]["sums"].cpu().numpy(), sums), step
+            assert np.array_equal(parts[0]["mins"].cpu().numpy(), mins), step
+            runs = eng.callable_runs(0)
+            assert np.array_equal(parts[0]["bounds"][:, 0].cpu().numpy(), runs[:, 0]), step
+        # pipelined as bench.py does: finish(k - 1); flip(); launch(k); post()
+        eng.compute_launch()
+        for step in range(4):
+            eng.compute_finish()
+            g.flip()
+            eng.compute_launch()
+            g.post()
+        eng.compute_finish()
+        g.flip()
+        g.post()
+        g.drain()
+        parts = shard.unpack_gathered(g.result())
+        assert np.array_equal(parts[0]["sums"].cpu().numpy(), sums)
+        with pytest.raises(GdError):
+            eng.gather_export(words=10 ** 12)                  # more than the export block holds
+        eng.comm_destroy()
+        eng.comm_destroy()                                     # idempotent

@@ -5,6 +5,8 @@ finishes a chromosome in about a second), and through size-independent propertie
 no oracle at all -- conservation of counted bases, window sums / minima recomputed from the
 per-base vector, class runs tiling the contig with breaks exactly at class changes and at
 multiples of the step."""
+import os
+
 import numpy as np
 import pytest
 
@@ -273,14 +275,20 @@ def test_config5_ont_wgs_full_size_bit_exact():
         _bit_compare_genome(eng, lengths, streams, W, Q, MINCOV)
 
 
-def test_config4_cohort_full_size_properties():
+def test_config4_cohort_full_size_against_the_oracle():
     """200 samples x chr1 (BASELINE.json config 4), window sums only (what the depthwed matrix is made of), through
-    the streaming sums kernel: every sample's window sums add up to the M/=/X bases of its kept reads inside the
-    contig (from the records alone), and a sample drawn at random equals the sums of the per-base path."""
+    the streaming sums kernel.  Every sample's window sums add up to the M/=/X bases of its kept reads inside the contig
+    (from the records alone); and for FIVE samples drawn at random the window sums are compared, bit for bit, with the
+    C oracle's per-base depth of the same records (oracle/depth_oracle.c in 10 Mb tiles, reduced per window), and their
+    columns of the sites x samples matrix (gd_depthwed_device at -s 1000) with the restatement of the reference's text
+    chain -- "%.4g" of sum / length per row (depth/depth.go:301), int(0.5 + parse) summed over a group
+    (depthwed/depthwed.go:93-157) -- computed FROM THE ORACLE'S sums: nothing of the engine judges the engine."""
     import torch
     from goleft_amd.engine import DepthEngine
     dev = torch.device("cuda", 0)
-    L1, S, Wc = synth.HG19_LENGTHS[0], 200, 250
+    L1, S, Wc, size = synth.HG19_LENGTHS[0], 200, 250, 1000
+    rng = np.random.default_rng(404)
+    picked = sorted(int(x) for x in rng.choice(S, size=5, replace=False))
     with DepthEngine(0) as eng:
         eng.set_params(window_size=Wc, min_mapq=Q, min_cov=MINCOV)
         eng.set_outputs(sums_only=True)
@@ -293,19 +301,27 @@ def test_config4_cohort_full_size_properties():
             want.append(_counted_bases_torch(torch, *st, Q, L1))
             keep[s] = st                                       # adopted, not copied: the engine reads these tensors
         eng.compute()
+        assert eng.stats().tile_kernel == 8                    # GD_TK_SUMS_STREAM_RAW: the streaming kernel on the records as they arrived
         from goleft_amd import shard
         ps, _, nwt = eng.device_windows()
         sums_all = shard.device_view(ps, nwt, torch.int64, dev)
         nw = (L1 + Wc - 1) // Wc
         got = sums_all.view(S, nw).sum(1).tolist()
         assert got == want
-        one = sums_all.view(S, nw)[137].clone()
-    with DepthEngine(0) as eng:                                # the same sample through the per-base path
-        eng.set_params(window_size=Wc, min_mapq=Q, min_cov=MINCOV)
-        eng.set_contigs([L1])
-        eng.adopt_device(0, *keep[137])
-        eng.compute()
-        assert np.array_equal(eng.windows(0)[0], one.cpu().numpy())
+        mine = {s: sums_all.view(S, nw)[s].cpu().numpy() for s in picked}
+        tids = np.asarray(picked, np.int32).reshape(-1, 1)
+        ptr, rows = eng.depthwed_device(tids, size)
+        matrix = shard.device_view(ptr, rows * len(picked), torch.int64, dev).view(rows, len(picked)).cpu().numpy()
+        cores = os.cpu_count() or 8
+        for j, s in enumerate(picked):
+            a = [x.cpu().numpy() for x in keep[s]]
+            rd = po.Reads(a[0], a[1].view(np.uint16), a[2], a[3].view(np.uint32), a[4].view(np.uint32))
+            res = po.tiled_contig_check(rd, Q, L1, Wc, MINCOV, 0, po.step_for(Wc), cores)     # the oracle's vector, tile by tile
+            assert np.array_equal(mine[s], res["sums"]), "sample %d: window sums differ from the oracle" % s
+            cells, st_, en_ = po.depthwed_cells_contig(res["sums"], L1, Wc, size)
+            assert len(cells) == rows and st_[0] == 0 and en_[-1] == L1
+            assert np.array_equal(matrix[:, j], cells), "sample %d: matrix column differs" % s
+            del a, rd, res
 
 
 @pytest.mark.parametrize("path,mode", [(1, "full"), (1, "windows"), (1, "sums"), (3, "full"), (3, "windows"),
