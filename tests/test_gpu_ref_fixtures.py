@@ -162,9 +162,17 @@ def test_ingest_reference_bam(name, key):
     with DepthEngine(0) as eng:
         eng.set_params(window_size=100, min_mapq=1, min_cov=4)
         eng.set_contigs([c[1] for c in contigs])
+        # what htslib wrote into the index about each reference (pseudo-bin 37450, SAMv1 5.2): n_mapped + n_unmapped
+        # records -- a reference-held count the device walk must deliver (tests/test_bai_pins.py: the whole index)
+        from tests.test_bai_pins import parse_bai
+        idx, _ = parse_bai(path + ".bai")
         for tid in range(len(contigs)):
             if len(lin[tid]):
-                assert eng.ingest_bgzf(tid, data, 0, lin[tid]) == reads[tid].n
+                n = eng.ingest_bgzf(tid, data, 0, lin[tid])
+                assert n == reads[tid].n
+                assert idx[tid]["meta"] is not None and n == idx[tid]["meta"][2] + idx[tid]["meta"][3]
+            else:
+                assert idx[tid]["meta"] is None or idx[tid]["meta"][2] + idx[tid]["meta"][3] == 0
         eng.compute()
         for tid, (_, L) in enumerate(contigs):
             r = reads.get(tid, H.empty_reads())
