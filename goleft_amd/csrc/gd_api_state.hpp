@@ -233,6 +233,7 @@ struct gd_ctx {
     hipEvent_t ing_staged[8] = {};
     int ing_piece_streams = 1;                         // GD_OPT_INGEST_PIECE_STREAMS: whole pieces alternate over this many streams (copy engines)
     uint64_t ing_piece_seq = 0;
+    bool ing_hybrid = false;                           // GD_OPT_INGEST_HYBRID: with two piece streams, the second one's pieces leave through a copy kernel
     hipStream_t ing_dma[3] = {nullptr, nullptr, nullptr};   // GD_OPT_INGEST_DMA > 1: a staged piece leaves in slices on several streams (DMA engines)
     hipEvent_t ing_dma_ev[8][3] = {};
     int ing_dma_n = 1;
@@ -243,6 +244,7 @@ struct gd_ctx {
     bool h2d_kernel = true;                            // GD_OPT_H2D_KERNEL: staging blocks reach HBM through gd_h2d_kernel
     unsigned h2d_grid = 512;                           // ... its workgroups
     bool ingest_crc = true;                            // GD_OPT_INGEST_CRC
+    unsigned inflate_pad = 0;                          // GD_OPT_INFLATE_LDS_PAD: extra LDS per inflate workgroup (occupancy limiter)
     bool fused_norm = true;                            // GD_OPT_FUSED_NORMALIZE: gd_normalize as one pass (0: count / scan / write / index launches)
     int32_t bam_n_ref = 0;                             // GD_OPT_BAM_REFS: references of the BAM being read (0: unknown)
     int push_threads = 16;

@@ -495,9 +495,11 @@ __global__ __launch_bounds__(256) void gd_inflate_crc_kernel(InflateJob job)
 }
 
 // Both kernels on one stream.
-inline void inflate_launch(const InflateJob& job, hipStream_t stream)
+// lds_pad: bytes of LDS a workgroup claims on top of its tables -- an occupancy limiter (26 KB of tables: six workgroups
+// per CU; + 6 KB: five; + 14 KB: four; + 27 KB: three), GD_OPT_INFLATE_LDS_PAD.
+inline void inflate_launch(const InflateJob& job, hipStream_t stream, unsigned lds_pad = 0)
 {
-    hipLaunchKernelGGL(gd_inflate_kernel, dim3((job.n + INF_LANES - 1) / INF_LANES), dim3(INF_LANES), 0, stream, job);
+    hipLaunchKernelGGL(gd_inflate_kernel, dim3((job.n + INF_LANES - 1) / INF_LANES), dim3(INF_LANES), lds_pad, stream, job);
     if (job.crc) hipLaunchKernelGGL(gd_inflate_crc_kernel, dim3((job.n + 255u) / 256u), dim3(256), 0, stream, job);
 }
 

@@ -524,6 +524,8 @@ int run(const DArgs& args)
         GDCHK_ON(sh.ctx, gd_set_option(sh.ctx, GD_OPT_COPY_THREADS, env_int("GOLEFT_COPY_THREADS", 4)));   // staging copies of the device BAM read
         if (getenv("GOLEFT_INGEST_DMA")) GDCHK_ON(sh.ctx, gd_set_option(sh.ctx, GD_OPT_INGEST_DMA, env_int("GOLEFT_INGEST_DMA", 2)));
         if (getenv("GOLEFT_INGEST_PIECE_STREAMS")) GDCHK_ON(sh.ctx, gd_set_option(sh.ctx, GD_OPT_INGEST_PIECE_STREAMS, env_int("GOLEFT_INGEST_PIECE_STREAMS", 1)));
+        if (getenv("GOLEFT_INGEST_HYBRID")) GDCHK_ON(sh.ctx, gd_set_option(sh.ctx, GD_OPT_INGEST_HYBRID, env_int("GOLEFT_INGEST_HYBRID", 0)));
+        if (getenv("GOLEFT_INFLATE_LDS_PAD")) GDCHK_ON(sh.ctx, gd_set_option(sh.ctx, GD_OPT_INFLATE_LDS_PAD, env_int("GOLEFT_INFLATE_LDS_PAD", 0)));
         if (env_int("GOLEFT_TRUST_BGZF", 0)) GDCHK_ON(sh.ctx, gd_set_option(sh.ctx, GD_OPT_INGEST_CRC, 0));
         if (const int pt = env_int("GOLEFT_PUSH_THREADS", 0)) GDCHK_ON(sh.ctx, gd_set_option(sh.ctx, GD_OPT_PUSH_THREADS, pt));
         GDCHK_ON(sh.ctx, gd_set_contigs(sh.ctx, (int)lens.size(), lens.data()));
