@@ -730,6 +730,7 @@ int gd_reset(gd_ctx* c)
     if (c && c->cs.pending) return fail(c, GD_E_STATE, "a compute is in flight: gd_compute_finish first");
     if (!c) return GD_E_INVALID;
     if (int r = set_device(c)) return r;
+    (void)gd_ingest_abort(c);                              // a device BAM read in progress (its reader thread) ends here
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipStreamSynchronize(c->copy_stream));
     for (auto& h : c->contigs) {

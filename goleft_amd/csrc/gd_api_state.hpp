@@ -224,6 +224,8 @@ struct gd_ctx {
     double ing_secs[7] = {0, 0, 0, 0, 0, 0, 0};         // gd_ingest_timing
     std::thread ing_feeder;                             // gd_ingest_feed_fd: the read of the newest range in progress
     int ing_feeder_rc = 0;
+    std::string ing_feeder_err;                         // what the feeder thread's failure said (published by ingest_join)
+    double ing_feeder_secs[2] = {0, 0};                 // its share of gd_ingest_timing [0], [1] (merged by ingest_join)
     bool ing_stage_used[8] = {false, false, false, false, false, false, false, false};
     int ing_cur = 0;
     IngestBufs ing_bufs[2];
@@ -280,6 +282,8 @@ struct gd_ctx {
 
 namespace {
 
+thread_local bool tl_ingest_feeder = false;              // this thread is a context's reader thread (gd_ingest_feed_fd)
+
 int fail(gd_ctx* c, int code, const char* fmt, ...)
 {
     if (c) {
@@ -288,7 +292,10 @@ int fail(gd_ctx* c, int code, const char* fmt, ...)
         va_start(ap, fmt);
         vsnprintf(buf, sizeof buf, fmt, ap);
         va_end(ap);
-        c->err = buf;
+        // the read of a pending range runs on a thread of the context (gd_ingest_feed_fd) beside the caller's own
+        // calls: its failures are kept apart and published when the read is joined (ingest_join)
+        if (tl_ingest_feeder) c->ing_feeder_err = buf;
+        else c->err = buf;
     }
     return code;
 }

@@ -231,7 +231,11 @@ __global__ __launch_bounds__(INF_LANES) void gd_inflate_kernel(InflateJob job)
     for (uint32_t it = 0;; ++it) {
         const uint64_t live = __ballot(mode != DONE);
         if (live == 0) break;
-        if (it >= (1u << 20)) {                            // (a member is at most 65 536 symbols: never reached)
+        // A backstop, not a budget: a member is at most 65 536 output bytes (one iteration each at least, 16 per chunk of a
+        // match) plus its block headers -- a 64 KB payload of nothing but empty stored / fixed blocks is ~50 000 of them,
+        // each of which may wait up to 32 iterations for the other lanes: 2^22 iterations cover that; a lane that runs off
+        // its input ends long before (err 1).
+        if (it >= (1u << 22)) {
             if (mode != DONE) err = 19;
             break;
         }

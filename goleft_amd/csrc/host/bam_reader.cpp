@@ -380,37 +380,43 @@ bool BamReader::linear_index(const std::string& bam_path, std::vector<std::vecto
     return true;
 }
 
-bool BamReader::seek_contig(int32_t tid, std::string* err)
+bool BamReader::seek_contig(int32_t tid, std::string* err) { return seek_contig_ex(tid, err) == 1; }
+
+// 1: positioned at the reference's first record; 0: the index says the reference holds no records (nothing was touched);
+// -1: no usable index (nothing was touched: the caller may scan from where it is); -2: the index pointed somewhere the
+// file could not be read -- the reader's position is gone, the caller must give up.
+int BamReader::seek_contig_ex(int32_t tid, std::string* err)
 {
     std::vector<uint8_t> d;
-    if (!load_bai(path_, &d)) return false;
+    if (!load_bai(path_, &d)) return -1;
     const int32_t n_ref = (int32_t)rd32(d.data() + 4);
+    if (tid < 0 || tid >= n_ref) return -1;
     size_t p = 8;
     uint64_t best = ~0ull;
     for (int32_t r = 0; r < n_ref; ++r) {
-        if (p + 4 > d.size()) return false;
+        if (p + 4 > d.size()) return -1;
         const int32_t n_bin = (int32_t)rd32(d.data() + p);
         p += 4;
         for (int32_t b = 0; b < n_bin; ++b) {
-            if (p + 8 > d.size()) return false;
+            if (p + 8 > d.size()) return -1;
             const uint32_t bin = rd32(d.data() + p);
             const int32_t n_chunk = (int32_t)rd32(d.data() + p + 4);
             p += 8;
-            if (n_chunk < 0 || (d.size() - p) / 16 < (size_t)n_chunk) return false;
+            if (n_chunk < 0 || (d.size() - p) / 16 < (size_t)n_chunk) return -1;
             if (r == tid && bin != 37450)
                 for (int32_t k = 0; k < n_chunk; ++k) best = std::min(best, rd64(d.data() + p + 16 * (size_t)k));
             p += 16 * (size_t)n_chunk;
         }
-        if (p + 4 > d.size()) return false;
+        if (p + 4 > d.size()) return -1;
         const int32_t n_intv = (int32_t)rd32(d.data() + p);
-        if (n_intv < 0 || (d.size() - p - 4) / 8 < (size_t)n_intv) return false;
+        if (n_intv < 0 || (d.size() - p - 4) / 8 < (size_t)n_intv) return -1;
         p += 4 + 8 * (size_t)n_intv;
         if (r == tid) break;
     }
-    if (best == ~0ull) return false;
+    if (best == ~0ull) return 0;                    // a well-formed index without a chunk for this reference: no records
     const uint64_t coff = best >> 16, uoff = best & 0xffff;
     drop_prefetch();                              // the producer owns fp_/raw_ while a chunk is in flight
-    if (fseeko(fp_, (off_t)coff, SEEK_SET) != 0) { if (err) *err = "seek failed"; return false; }
+    if (fseeko(fp_, (off_t)coff, SEEK_SET) != 0) { if (err) *err = "seek failed"; return -2; }
     raw_.clear();
     buf_.clear();
     cur_ = 0;
@@ -418,11 +424,11 @@ bool BamReader::seek_contig(int32_t tid, std::string* err)
     done_ = false;
     n_batches_ = 0;
     n_fills_ = 0;
-    if (!need(uoff + 1, err)) return false;
+    if (!need(uoff + 1, err)) { if (err && err->empty()) *err = "the index points past the end of the file"; return -2; }
     cur_ += uoff;
     left_.assign(contigs_.size(), false);         // a deliberate jump: the run rule starts over
     last_ref_ = -2;
-    return true;
+    return 1;
 }
 
 namespace {

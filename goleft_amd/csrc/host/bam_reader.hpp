@@ -56,6 +56,7 @@ public:
     // (path + ".bai"); returns false (stream untouched) when there is no usable
     // index or the contig has no records.
     bool seek_contig(int32_t tid, std::string* err);
+    int seek_contig_ex(int32_t tid, std::string* err);   // 1 positioned, 0 no records (index), -1 no usable index, -2 I/O error
 
     // The .bai linear index (SAMv1 5.2): for every reference the sorted, distinct, non-zero
     // virtual offsets of record starts (one per 16 kb window that holds reads).  false when

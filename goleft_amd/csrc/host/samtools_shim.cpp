@@ -82,9 +82,17 @@ extern "C" int gdh_samtools_main(int argc, const char* const* argv)
     if (gd_set_contigs(ctx, (int)lens.size(), lens.data()) != GD_OK) return fail("gd_set_contigs");
     if (gd_select_contigs(ctx, (int)tids.size(), tids.data()) != GD_OK) return fail("gd_select_contigs");
     // records: the reference's run of the file up to the region's end (reads that start before the region may reach in)
-    if (!region.empty()) rd.seek_contig(tids[0], &err);
+    // ... found through the .bai: a reference the index knows to be empty (decoy and alt contigs: most of an assembly's
+    // names) is answered at once instead of by inflating the whole file; only WITHOUT a usable index is the file scanned;
+    // an index that points where the file cannot be read is an error, not zero coverage
+    bool scan = true;
+    if (!region.empty()) {
+        const int sk = rd.seek_contig_ex(tids[0], &err);
+        if (sk == -2) { fprintf(stderr, "samtools (goleft_amd shim): %s\n", err.c_str()); gd_destroy(ctx); return 1; }
+        if (sk == 0) scan = false;
+    }
     gdh::RecordBlock blk;
-    for (;;) {
+    while (scan) {
         const int rc = rd.next_block(blk, 1u << 20, &err);
         if (rc < 0) { fprintf(stderr, "samtools (goleft_amd shim): %s\n", err.c_str()); gd_destroy(ctx); return 1; }
         if (rc == 0) break;

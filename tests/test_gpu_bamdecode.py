@@ -485,3 +485,32 @@ def test_ingest_a_reference_in_parts(tmp_path):
         assert eng.ingest_bgzf(0, data, 0, lin[0]) == reads[0].n
         eng.compute()
         assert np.array_equal(eng.perbase(0), want)
+
+
+def test_inflate_a_member_of_fifty_thousand_empty_blocks():
+    """a VALID member may consist of tens of thousands of empty blocks (10 bits each with the fixed
+    code), each of which waits up to 32 iterations of the symbol loop for the other lanes' headers -- more iterations
+    than the loop's former backstop of 2^20 allowed, which refused the member (err 19) although zlib inflates it."""
+    import struct
+    from goleft_amd.engine import DepthEngine
+    n_empty = 50_000
+    payload = b"the bytes behind fifty thousand empty blocks"
+    bits = []
+    for _ in range(n_empty):
+        bits += [0, 1, 0] + [0] * 7                          # BFINAL 0, BTYPE 01 (fixed), end-of-block (0000000)
+    bits += [1, 0, 0]                                        # the last block: stored
+    while len(bits) % 8:
+        bits.append(0)
+    raw = bytearray()
+    for i in range(0, len(bits), 8):
+        raw.append(sum(b << k for k, b in enumerate(bits[i:i + 8])))
+    raw += struct.pack("<HH", len(payload), len(payload) ^ 0xffff) + payload
+    assert zlib.decompress(bytes(raw), -15) == payload       # the yardstick accepts it
+    assert len(raw) + 26 < 65536
+    member = (b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", len(raw) + 25) + bytes(raw) +
+              struct.pack("<II", zlib.crc32(payload) & 0xffffffff, len(payload)))
+    data = member + bamio.bgzf_compress(b"ACGT" * 1000)      # (another member in the same wave, and the EOF marker)
+    with DepthEngine(0) as eng:
+        got, status = eng.inflate_bgzf(data)
+    assert (status == 0).all(), status
+    assert got == payload + b"ACGT" * 1000
