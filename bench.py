@@ -489,7 +489,8 @@ def run_case(args, scaling, world, rank, dev, local_rank, want_streams=False):
 
     # ---- the same step with the derived structures KEPT from step to step (round 2's `value`) --------------
     only = None
-    if world == 1:
+    from goleft_amd.engine import has_canonical
+    if world == 1 and has_canonical():              # (an optional part of the build: csrc/Makefile CANONICAL=1)
         eng.set_profiling(True)
         t1 = time.perf_counter()
         eng.normalize(True)                         # one batch: one allocation, one launch set, one synchronisation

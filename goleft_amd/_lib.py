@@ -41,6 +41,7 @@ _P = C.c_void_p
 SYMBOLS = {
     "gd_strerror": (C.c_char_p, [C.c_int]),
     "gd_abi_version": (C.c_int, []),
+    "gd_build_features": (C.c_int, []),
     "gd_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "gd_create": (C.c_int, [C.c_int, C.POINTER(_P)]),
     "gd_destroy": (None, [_P]),

@@ -45,6 +45,14 @@ const char* gd_strerror(int s)
 }
 
 int gd_abi_version(void) { return GD_ABI_VERSION; }
+int gd_build_features(void)
+{
+#ifdef GD_WITH_CANONICAL
+    return GD_FEATURE_CANONICAL;
+#else
+    return 0;
+#endif
+}
 
 int gd_device_count(int* n)
 {
@@ -819,6 +827,9 @@ int gd_set_option(gd_ctx* c, int option, int64_t value)
     case GD_OPT_NT_STORES: c->tile_opt = value ? 1 : 0; break;
     case GD_OPT_NORMALIZE:
         if (value < 0 || value > 2) return fail(c, GD_E_INVALID, "GD_OPT_NORMALIZE: 0, 1 or 2");
+#ifndef GD_WITH_CANONICAL
+        if (value == 1) return fail(c, GD_E_INVALID, "GD_OPT_NORMALIZE = 1: this build holds no canonical records (csrc/Makefile: make CANONICAL=1)");
+#endif
         c->normalize = (int)value;
         break;
     case GD_OPT_FAST_KERNEL: c->fast_kernel = value != 0; break;
@@ -851,6 +862,10 @@ int gd_set_option(gd_ctx* c, int option, int64_t value)
         break;
     case GD_OPT_INGEST_INDEX: c->ingest_index = value != 0; break;
     case GD_OPT_INGEST_HYBRID: c->ing_hybrid = value != 0; break;
+    case GD_OPT_INGEST_RANGE_HINT:
+        if (value < 0) return fail(c, GD_E_INVALID, "ingest range hint: bytes >= 0");
+        c->ing_range_hint = (uint64_t)value;
+        break;
     case GD_OPT_INFLATE_LDS_PAD:
         if (value < 0 || value > 120 * 1024) return fail(c, GD_E_INVALID, "inflate LDS pad: 0 .. 122880 bytes");
         c->inflate_pad = (unsigned)value;

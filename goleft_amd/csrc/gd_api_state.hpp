@@ -106,7 +106,10 @@ struct IngestBufs {
     {
         if (need <= *cap && *p) return true;
         if (*p) { (void)hipHostFree(*p); *p = nullptr; *cap = 0; }
-        const size_t want = need + need / 2 + 4096;
+        // generously: freeing page-locked memory waits for the device like hipFree does -- ranges of slightly different
+        // member counts (a reference read in parts) must not do that between every two of them (measured: 50 ms per
+        // gd_ingest_begin, 1.4 s per genome)
+        const size_t want = std::max<size_t>(2 * need + 4096, 8u << 20);
         if (hipHostMalloc(p, want, hipHostMallocDefault) != hipSuccess) { *p = nullptr; return false; }
         *cap = want;
         return true;
@@ -246,6 +249,7 @@ struct gd_ctx {
     bool h2d_kernel = true;                            // GD_OPT_H2D_KERNEL: staging blocks reach HBM through gd_h2d_kernel
     unsigned h2d_grid = 512;                           // ... its workgroups
     bool ingest_crc = true;                            // GD_OPT_INGEST_CRC
+    uint64_t ing_range_hint = 0;                       // GD_OPT_INGEST_RANGE_HINT: bytes of the largest range the caller will feed
     unsigned inflate_pad = 0;                          // GD_OPT_INFLATE_LDS_PAD: extra LDS per inflate workgroup (occupancy limiter)
     bool fused_norm = true;                            // GD_OPT_FUSED_NORMALIZE: gd_normalize as one pass (0: count / scan / write / index launches)
     int32_t bam_n_ref = 0;                             // GD_OPT_BAM_REFS: references of the BAM being read (0: unknown)
@@ -443,12 +447,14 @@ void launch_tile(gd_ctx* c, const gd::Job& job)
                 hipLaunchKernelGGL((gd::fast::gd_tile_fast_kernel<0, true>), dim3(grid), dim3(256), 0, c->stream, job);
             return;
         }
+#ifdef GD_WITH_CANONICAL
         if (!c->keep_perbase)
             hipLaunchKernelGGL((gd::fast::gd_tile_fast_kernel<2>), dim3(grid), dim3(256), 0, c->stream, job);
         else if (c->tile_opt & 1)
             hipLaunchKernelGGL((gd::fast::gd_tile_fast_kernel<1>), dim3(grid), dim3(256), 0, c->stream, job);
         else
             hipLaunchKernelGGL((gd::fast::gd_tile_fast_kernel<0>), dim3(grid), dim3(256), 0, c->stream, job);
+#endif
         return;
     }
     if (!c->keep_perbase)
@@ -595,7 +601,11 @@ int ck_enqueue(gd_ctx* c, const std::vector<ContigHost*>& hs, bool ops_known, Ck
     if (P->n_units) {
         const unsigned grid = (P->n_units + 3u) / 4u;
         if (raw) hipLaunchKernelGGL(gd::gd_dels_raw_kernel, dim3(grid), dim3(256), 0, c->stream, B);
+#ifdef GD_WITH_CANONICAL
         else hipLaunchKernelGGL(gd::gd_dels_kernel, dim3(grid), dim3(256), 0, c->stream, B);
+#else
+        else return fail(c, GD_E_INVALID, "this build holds no canonical records (csrc/Makefile: make CANONICAL=1)");
+#endif
         hipLaunchKernelGGL(gd::gd_ptile_count_kernel, dim3(grid), dim3(256), 0, c->stream, B);
         if (int r = launch_scan(c, reinterpret_cast<uint32_t*>(base + o_unit), P->n_units)) return r;
     } else {
@@ -684,6 +694,14 @@ int ck_batch(gd_ctx* c, const std::vector<ContigHost*>& hs, bool raw = false)
 // also get their long-read structures, enqueued behind the same kernels.  Afterwards h.normed is set.
 int norm_batch(gd_ctx* c, const std::vector<ContigHost*>& hs, const std::vector<ContigHost*>& with_ck)
 {
+#ifndef GD_WITH_CANONICAL
+    // Canonical records (gd_normalize.hpp: a rewritten copy of the CIGARs, record words, a position index) serve a host that
+    // computes the SAME records many times; no caller in the reference does, and every default path reads the records as they
+    // arrived.  They are an optional part of the build (csrc/Makefile: make CANONICAL=1) -- without it this is the one place
+    // that could have built them.
+    (void)hs; (void)with_ck;
+    return fail(c, GD_E_INVALID, "this build holds no canonical records (csrc/Makefile: make CANONICAL=1)");
+#else
     const size_t nj = hs.size();
     if (nj == 0) return ck_batch(c, with_ck);
     BlockRef keep = hs[0]->norm_blk;
@@ -832,10 +850,9 @@ int norm_batch(gd_ctx* c, const std::vector<ContigHost*>& hs, const std::vector<
         }
     }
     return GD_OK;
+#endif
 }
 
-// Canonical CIGARs serve the tile and the long-read paths; the scatter path reads the original ops (it stays
-// an independent cross-check of the normalisation).
 bool wants_norm(const gd_ctx* c, uint64_t, uint64_t)
 {
     return c->normalize == 1 && c->path != GD_PATH_SCATTER;     // (mode 2: gd_compute builds what its path needs)

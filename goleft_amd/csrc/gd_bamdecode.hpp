@@ -89,14 +89,16 @@ __device__ __forceinline__ bool bam_record_cigar(const uint8_t* r, uint32_t bloc
 }
 
 // ONE WAVE PER SEGMENT.  Records are self-delimiting only forwards, so finding where they start is a chain of
-// dependent reads -- as loads from HBM, one lane per segment, that chain cost ~2 us per record and a pass over a
-// chromosome's 3 300 records per segment took 20 - 30 ms however few segments there were (a reference read in 1 GB
-// parts paid that per part: 4 s per genome, more than the link).  Here the wave stages 3 KB of the stream in LDS with
-// coalesced 16-byte loads, lane 0 follows the block_size chain THERE (an LDS round trip per record) and notes up to 32
-// record starts, and then every lane takes one record -- CIGAR resolved (CG:B,I), fields extracted -- with 64 records'
-// memory latencies in flight at once.  Output positions inside a round come from the op counts the lanes leave in LDS.
+// dependent reads.  Round 3 gave each segment ONE LANE, which followed that chain with a load from HBM per record and
+// then extracted the record itself -- 3 300 records in a row per segment of a 30x chromosome, every lane of a wave in
+// a different place.  Here the wave stages 3 KB of the stream in LDS with coalesced 16-byte loads, lane 0 follows the
+// block_size chain THERE (an LDS round trip per record) and notes up to 32 record starts, and then every lane takes one
+// record -- CIGAR resolved (CG:B,I), fields extracted -- with the round's records' memory latencies in flight at once.
+// Output positions inside a round come from the op counts the lanes leave in LDS.  Measured with the page-locked walk
+// tables of gd_api_ingest.inc (the two changes were made together): the counting walk of a chromosome-sized range
+// 17 -> 10 ms, the extracting one 18 -> 6 ms (scope iii).
 // LDS: 3 KB of stream + 0.5 KB of tables.  Not more: the walks run BESIDE the inflate kernel of the next range, whose six
-// workgroups per CU leave 4 KB of LDS -- with a 16 KB window a walk workgroup waited for an inflate workgroup to retire.
+// workgroups per CU leave 4 KB of LDS -- a walk workgroup that needs more waits for an inflate workgroup to retire.
 constexpr int BW_WIN = 3072;           // bytes of the stream staged per round
 constexpr int BW_REC = 32;             // records per round at most (one lane each)
 

@@ -92,6 +92,7 @@ struct DelBatch {
     uint32_t n_units;
 };
 
+#ifdef GD_WITH_CANONICAL   // (deletion lists from CANONICAL CIGARs: only with canonical records in the build)
 __global__ __launch_bounds__(256) void gd_dels_kernel(DelBatch B)
 {
     const int lane = threadIdx.x & 63;
@@ -188,6 +189,8 @@ __global__ __launch_bounds__(256) void gd_dels_kernel(DelBatch B)
     const uint32_t dsum = (uint32_t)wave_total((int)(valid ? n >> 1 : 0u));
     if (lane == 0 && dsum != 0u) atomicAdd(job.del_total, dsum);
 }
+
+#endif  // GD_WITH_CANONICAL
 
 // ---- the same structures straight from the records AS THEY ARRIVED ------------------------------------------------
 // One pass over the original CIGARs: what gd_normalize.hpp's count + write passes and gd_dels_kernel do in three

@@ -84,6 +84,7 @@ struct NormBatch {
     uint32_t* ticket;         // [0] workgroups handed out so far, [1] set when a look-back gave up (never expected)
 };
 
+#ifdef GD_WITH_CANONICAL   // canonical records are an optional part of the build (csrc/Makefile: make CANONICAL=1)
 constexpr uint32_t LEN_MAX = 0x0fffffffu;
 
 // Calls emit(op, len) for every canonical op of one read, in order; returns their number.
@@ -241,6 +242,8 @@ __global__ __launch_bounds__(256) void gd_norm_count_kernel(NormBatch B)
     if (lane == 63) j.unit[unit] = incl;
 }
 
+#endif  // GD_WITH_CANONICAL
+
 // N2: exclusive scan of the unit totals, in place; v[n] = grand total.  One workgroup.
 __global__ __launch_bounds__(1024) void gd_unit_scan_kernel(uint32_t* __restrict__ v, uint32_t n)
 {
@@ -304,6 +307,7 @@ __global__ __launch_bounds__(256) void gd_scan_apply_kernel(uint32_t* __restrict
     if (blockIdx.x == 0 && threadIdx.x == 0) v[n] = boff[n_blocks];    // grand total (written last by nobody else: slot n is outside every block)
 }
 
+#ifdef GD_WITH_CANONICAL
 // N3: write.  Same shape as N1.
 __global__ __launch_bounds__(256) void gd_norm_write_kernel(NormBatch B)
 {
@@ -606,6 +610,8 @@ __global__ __launch_bounds__(256, 8) void gd_norm_fused_kernel(NormBatch B)
         *j.total = base + total;
     }
 }
+
+#endif  // GD_WITH_CANONICAL
 
 // What every way into the engine runs over records once they are resident (gd_adopt_device: the caller's own arrays;
 // gd_commit: a staged block that has landed; the device BAM read: a contig the record walk has written) -- ONE pass over

@@ -313,6 +313,11 @@ inline int ingest_references_on_device(gd_ctx* ctx, const FileMap& fm, const std
     for (size_t r = 0; r < lin.size(); ++r)
         if (!lin[r].empty()) { has[r] = 1; start[r] = lin[r].front() >> 16; }
     const std::vector<IngestPass> passes = plan_ingest_passes(start, has, refs, fm.size, group_bytes, ref_end, &lin, part_bytes);
+    {
+        uint64_t largest = 0;
+        for (const IngestPass& ps : passes) largest = std::max(largest, ps.end > ps.beg ? ps.end - ps.beg : 0);
+        (void)gd_set_option(ctx, GD_OPT_INGEST_RANGE_HINT, (int64_t)largest);   // both buffer sets are allocated once, for the largest pass
+    }
     // decode + release of the oldest pending pass: references refs[a..b], or one part of one reference
     auto decode_pass = [&](const IngestPass& ps) -> int {
         const size_t a = ps.first, b = ps.last;

@@ -579,6 +579,12 @@ class DepthEngine:
         return o.value, n.value
 
 
+def has_canonical() -> bool:
+    """gd_build_features() & GD_FEATURE_CANONICAL: canonical records (gd_normalize, GD_OPT_NORMALIZE = 1) are part of
+    this build of the library (goleft_amd/csrc/Makefile: make CANONICAL=1; the default build leaves them out)."""
+    return bool(_lib.load().gd_build_features() & 1)
+
+
 def device_count() -> int:
     n = C.c_int()
     _lib.load().gd_device_count(C.byref(n))

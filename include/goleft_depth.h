@@ -157,6 +157,13 @@ enum { GD_PATH_AUTO = 0, GD_PATH_TILE = 1, GD_PATH_SCATTER = 2, GD_PATH_CHUNK = 
 
 const char* gd_strerror(int status);
 int         gd_abi_version(void);
+/* Optional parts of this build, a mask of GD_FEATURE_*.  GD_FEATURE_CANONICAL: canonical records (gd_normalize,
+ * GD_OPT_NORMALIZE = 1, gd_canonical_cigars, the kernels that read them) -- a rewritten copy of the records for a host
+ * that computes the SAME records many times.  No caller in the reference does (a `goleft depth` run computes each input
+ * once) and every default path reads the records as they arrived, so the default build leaves them out
+ * (goleft_amd/csrc/Makefile: make CANONICAL=1 builds them in; without, those calls return GD_E_INVALID). */
+enum { GD_FEATURE_CANONICAL = 1 };
+int         gd_build_features(void);
 int         gd_device_count(int* n);
 
 /* Create a context bound to one HIP device (hipSetDevice is re-issued inside
@@ -216,6 +223,9 @@ enum { /* (1, 2: tile shapes other than 4096 positions x 256 threads -- measured
                                        buffers each: 1 (default) .. 4.  One copy engine moves 20 - 25 GB/s next to the inflate
                                        kernels; this asks for several at once (GD_OPT_INGEST_DMA > 1 cuts ONE piece into slices
                                        instead, which was measured slower) */
+       GD_OPT_INGEST_RANGE_HINT = 18, /* bytes of the LARGEST range gd_ingest_begin will be given (0, the default: unknown): the range
+                                       buffers are allocated for it on first use instead of growing -- freeing and allocating --
+                                       whenever a later range is larger than the ones before */
        GD_OPT_INGEST_HYBRID = 17,     /* with GD_OPT_INGEST_PIECE_STREAMS >= 2: 1: the pieces of every stream but the first leave through a copy
                                        kernel instead of a copy command (the copy engine and a kernel share the link); 0 (default) */
        GD_OPT_INFLATE_LDS_PAD = 16,   /* bytes of LDS every workgroup of the inflate kernel claims on top of its tables: 0 (default) ..

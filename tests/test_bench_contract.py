@@ -37,10 +37,22 @@ def test_wgs_bench_line_has_the_contract_fields():
     assert d["value"] >= 1e9                                            # BASELINE.json's target at one GPU
     # round 3: the step starts from the records as they crossed the ABI; what round 2 called `value` is a side field
     assert "as they arrived" in d["config"]["step"] and d["roofline"]["kernel"].endswith("<raw>")
-    o = d["compute_only"]
-    assert o["value"] > d["value"] * 0.9 and o["roofline"]["kernel"] == "gd_tile_fast_kernel"
-    g = d["roofline_ingest"]
-    assert g["bound"] == "hbm" and g["kernels_ms"] > 0 and g["wall_ms"] < g["kernels_ms"] * 1.5   # one batch: no host overhead
+    if "compute_only" in d:                                             # (a build with canonical records: csrc/Makefile CANONICAL=1)
+        o = d["compute_only"]
+        assert o["value"] > d["value"] * 0.9 and o["roofline"]["kernel"] == "gd_tile_fast_kernel"
+        g = d["roofline_ingest"]
+        assert g["bound"] == "hbm" and g["kernels_ms"] > 0 and g["wall_ms"] < g["kernels_ms"] * 1.5   # one batch: no host overhead
+    # round 4: the roofline is on SURVEY.md 8(d)'s byte count; the cold step and the BAM-file scope are in the line
+    assert abs(d["roofline"]["frac_survey_8d"] - d["roofline"]["frac"]) < 1e-12
+    assert d["roofline"]["frac_bytes_really_read"] > d["roofline"]["frac"]
+    f = d["first_compute"]
+    assert f["reruns"] == 0 and f["ratio_to_warm"] <= 1.10 and f["lookback"] == 192
+    assert d["ranks_seen"] == 1 and d["distinct_devices"] == 1
+    b = d["bam_file_scope"]
+    # (BAM file -> BED at genome size: 1.02 - 1.06e9 ref-bases/s on three boxes of the round, 6.8e8 on one whose page-cache
+    # reads and device allocations ran at half speed -- profiles/README.md; the line must carry the measurement, the claim
+    # is DESIGN.md's)
+    assert b["file"] == "genome" and b["value"] >= 5e8 and b["outputs_identical"] is True
     e = d["emulated_sharding"]["by_n_gpus"]
     assert set(e) == {"2", "4", "8"} and all(len(e[n]["per_shard_ms"]) == int(n) for n in e)
     assert e["8"]["projected_speedup"] >= 6.0                           # north_star: >= 6x aggregate at 8 GPUs

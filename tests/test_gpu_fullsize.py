@@ -235,8 +235,10 @@ def test_config3_wgs_full_size_bit_exact():
         eng.compute()
         st = eng.stats()
         assert st.n_reads == 619_135_482 and st.tile_kernel == E.TK_FAST_RAW
-        assert st.n_slow_tiles < 2000                  # (of 755 785; a first compute runs with the default 512-base look-back)
+        assert st.n_slow_tiles < 100 and st.reruns == 0 and st.lookback == 192   # (of 755 785; the look-back was measured as the records arrived)
         _bit_compare_genome(eng, lengths, streams, W, Q, MINCOV)
+        if not E.has_canonical():
+            return                                     # (the canonical kernel is an optional part of the build)
         eng.normalize()
         eng.compute()
         assert eng.stats().tile_kernel == E.TK_FAST

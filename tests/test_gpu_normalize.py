@@ -10,6 +10,15 @@ from tests import helpers as H
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _needs_canonical(request):
+    """Canonical records are an optional part of the build (csrc/Makefile: make CANONICAL=1; include/goleft_depth.h
+    GD_FEATURE_CANONICAL): the tests of them run where they exist; the tests below that do not need them say so."""
+    from goleft_amd.engine import has_canonical
+    if not has_canonical() and "no_canonical_needed" not in request.keywords:
+        pytest.skip("canonical records are not part of this build")
+
+
 def _engine(lengths, reads, fast=1, norm=1, fused=1, **params):
     from goleft_amd import engine as E
     eng = E.DepthEngine(0)
