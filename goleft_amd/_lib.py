@@ -119,6 +119,9 @@ SYMBOLS = {
     "gd_comm_destroy": (C.c_int, [_P]),
     "gd_gather_export": (C.c_int, [_P, _P, _P, C.c_size_t, C.c_int]),
     "gd_gather_wait": (C.c_int, [_P]),
+    "gd_device_alloc": (C.c_int, [_P, C.c_size_t, C.POINTER(_P)]),
+    "gd_device_free": (C.c_int, [_P, _P]),
+    "gd_device_read": (C.c_int, [_P, _P, _P, C.c_size_t]),
     "gd_compute_timing": (C.c_int, [_P, C.POINTER(C.c_double), C.c_int]),
 }
 

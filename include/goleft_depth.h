@@ -586,6 +586,11 @@ int gd_comm_init(gd_ctx* ctx, int rank, int world, const void* id, size_t bytes)
 int gd_comm_destroy(gd_ctx* ctx);
 int gd_gather_export(gd_ctx* ctx, const int64_t* send, int64_t* recv, size_t words, int root);
 int gd_gather_wait(gd_ctx* ctx);
+/* Device memory for a host that has no HIP binding of its own (cgo): the send / receive buffers of gd_gather_export, and
+ * a synchronous read of them (waits for the context's streams first). */
+int gd_device_alloc(gd_ctx* ctx, size_t bytes, void** out);
+int gd_device_free(gd_ctx* ctx, void* p);
+int gd_device_read(gd_ctx* ctx, void* dst_host, const void* src_device, size_t bytes);
 
 /* ---- measurement ---------------------------------------------------------*/
 int gd_get_stats(gd_ctx* ctx, gd_stats* out);

@@ -144,6 +144,20 @@ def test_native_gather_of_the_export_block_world_of_one():
         g.drain()
         parts = shard.unpack_gathered(g.result())
         assert np.array_equal(parts[0]["sums"].cpu().numpy(), sums)
+        # the same exchange with buffers from the ABI itself (what a cgo host has: no HIP binding of its own)
+        import ctypes as C
+        lib = eng._lib
+        words = g.total
+        ps, pr = C.c_void_p(), C.c_void_p()
+        assert lib.gd_device_alloc(eng._ctx, 8 * words, C.byref(ps)) == 0 and lib.gd_device_alloc(eng._ctx, 8 * words, C.byref(pr)) == 0
+        eng.set_export(ps.value, g.max_w, g.cap_b)
+        eng.compute()
+        eng.gather_export(recv_ptr=pr.value, words=words, root=0)
+        got = np.empty(words, np.int64)
+        assert lib.gd_device_read(eng._ctx, got.ctypes.data, pr, 8 * words) == 0
+        assert got[0] == len(eng.callable_runs(0)) and np.array_equal(got[1:1 + len(sums)], sums)
+        eng.set_export(0, 0, 0)
+        assert lib.gd_device_free(eng._ctx, ps) == 0 and lib.gd_device_free(eng._ctx, pr) == 0
         with pytest.raises(GdError):
             eng.gather_export(words=10 ** 12)                  # more than the export block holds
         eng.comm_destroy()
