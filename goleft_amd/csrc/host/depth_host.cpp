@@ -397,28 +397,12 @@ int env_int(const char* name, int dflt)
     return e && *e ? atoi(e) : dflt;
 }
 
-int run(const DArgs& args)
+// The regions of a run, in output order: the rows of --bed (depth/depth.go:103-120; quirk Q6: an unterminated last line
+// is dropped as ReadBytes + io.EOF drop it) or the W-aligned 10 Mb tiles of every .fai contig (:122-159; --chrom keeps
+// one).  tid = the BAM reference of the name, -1 when the BAM has none.  0, or the process's exit code.
+static int collect_regions(const DArgs& args, const std::map<std::string, int>& tid_of, int64_t step, std::vector<Region>* out)
 {
-    const auto t_run = std::chrono::steady_clock::now();
-    int exit_code = 0;
-    std::string err;
-    EarlyContexts early;                                     // (declared first: joined and emptied last)
-    std::vector<int> devices;
-    if (!parse_devices(&devices, &err)) { fprintf(stderr, "goleft depth: %s\n", err.c_str()); return 1; }
-    early.start(devices);
-    gdh::BamReader bam;
-    if (!bam.open(args.bam, args.processes, &err)) {
-        fprintf(stderr, "goleft depth: %s\n", err.c_str());
-        return 1;
-    }
-    const auto& contigs = bam.contigs();
-    std::map<std::string, int> tid_of;
-    for (size_t i = 0; i < contigs.size(); ++i) tid_of.emplace(contigs[i].name, (int)i);
-
-    // ---- regions: --bed rows (:103-120) or .fai tiles (:122-159) ------------
-    const int W = args.window_size;
-    const int64_t step = step_for(W);
-    std::vector<Region> regions;
+    std::vector<Region>& regions = *out;
     if (!args.bed.empty()) {
         FILE* f = fopen(args.bed.c_str(), "r");
         if (!f) { fprintf(stderr, "goleft depth: open %s: %s\n", args.bed.c_str(), strerror(errno)); return 1; }
@@ -455,6 +439,136 @@ int run(const DArgs& args)
                 regions.push_back(Region{e.name, i, std::min(i + step, e.length), tid});
         }
     }
+    return 0;
+}
+
+// fn on every shard that has contigs, each on its own OS thread (every gd_* entry point re-issues hipSetDevice); false
+// (after a message) when one failed.
+static bool run_on_every_shard(Shards& S, const char* what, const std::function<int(Shard&)>& fn)
+{
+    std::vector<std::thread> th;
+    for (size_t k = 1; k < S.v.size(); ++k)
+        th.emplace_back([&, k]() { S.v[k].rc = S.v[k].wanted.empty() ? GD_OK : fn(S.v[k]); });
+    S.v[0].rc = S.v[0].wanted.empty() ? GD_OK : fn(S.v[0]);
+    for (auto& t : th) t.join();
+    for (Shard& sh : S.v)
+        if (sh.rc != GD_OK) {
+            fprintf(stderr, "goleft depth: %s failed on device %d: %s (%s)\n", what, sh.device, gd_strerror(sh.rc),
+                    gd_last_error(sh.ctx));
+            return false;
+        }
+    return true;
+}
+
+struct ReadTimes { std::chrono::steady_clock::time_point indexed, mapped, read; };
+
+// ---- records into HBM (replaces the samtools children) ---------------------------
+// With a .bai next to the BAM (goleft depth needs one anyway: `samtools depth -r`), the whole
+// read happens on the device: the contig's byte range goes to gd_ingest_bgzf, which inflates
+// the BGZF members and decodes the records there (GOLEFT_GPU_DECODE=0 keeps the host decoder).
+// Every shard reads its own contigs' byte ranges from the shared mapping.
+// -> 0, or the process's exit code; *n_gpu_records: what the device decoder delivered (0: the host decoder ran).
+static int read_records(const DArgs& args, gdh::BamReader& bam, const std::vector<int32_t>& wanted, Shards& S,
+                        const std::vector<int>& shard_of, uint64_t* n_gpu_records_out, ReadTimes* T)
+{
+    const auto& contigs = bam.contigs();
+    std::string err;
+    uint64_t n_gpu_records = 0;
+    auto now = []() { return std::chrono::steady_clock::now(); };
+    auto ctx_of = [&](int tid) -> gd_ctx* { return S.v[(size_t)shard_of[(size_t)tid]].ctx; };
+    auto on_every_shard = [&](const char* what, const std::function<int(Shard&)>& fn) { return run_on_every_shard(S, what, fn); };
+    auto& t_indexed = T->indexed; auto& t_mapped = T->mapped; auto& t_read = T->read;
+    {
+        std::vector<std::vector<uint64_t>> lin;
+        std::vector<char> has_chunks;
+        std::vector<uint64_t> chunk_end;
+        const char* gd_env = getenv("GOLEFT_GPU_DECODE");
+        bool gpu_decode = !(gd_env && gd_env[0] == '0') && gdh::BamReader::linear_index(args.bam, &lin, &err, &has_chunks, &chunk_end) &&
+                          lin.size() == contigs.size();
+        // a reference whose bins hold chunks but whose linear index is empty (a non-htslib indexer):
+        // the anchors cannot be trusted to mean "no records" -> host decoder
+        for (size_t r = 0; gpu_decode && r < lin.size(); ++r)
+            if (lin[r].empty() && r < has_chunks.size() && has_chunks[r]) gpu_decode = false;
+        t_indexed = now();
+        if (gpu_decode) {
+            gdh::FileMap fm;
+            if (!fm.open(args.bam)) gpu_decode = false;
+            fm.keep = gdh_get_fast_exit() != 0;
+            t_mapped = now();
+            if (gpu_decode) {
+                if (!on_every_shard("the device BAM read", [&](Shard& sh) {
+                        return gdh::ingest_references_on_device(sh.ctx, fm, lin, sh.wanted, sh.wanted, &sh.n_gpu_records, &sh.io_ok,
+                                                                (uint64_t)env_int("GOLEFT_INGEST_GROUP_MB", 512) << 20, &chunk_end,
+                                                                // a reference larger than this is read in parts cut at .bai anchors
+                                                                // (0: never; _KB: tests cut small files)
+                                                                getenv("GOLEFT_INGEST_PART_KB") ? (uint64_t)env_int("GOLEFT_INGEST_PART_KB", 0) << 10
+                                                                                                : (uint64_t)env_int("GOLEFT_INGEST_PART_MB", 2048) << 20);
+                    }))
+                    return 1;
+                for (Shard& sh : S.v) {
+                    if (!sh.io_ok) gpu_decode = false;
+                    n_gpu_records += sh.n_gpu_records;
+                }
+                if (!gpu_decode) n_gpu_records = 0;
+                t_read = now();
+            }
+            if (!gpu_decode)
+                for (Shard& sh : S.v) GDCHK_ON(sh.ctx, gd_reset(sh.ctx));   // fall back to the host decoder below
+        }
+        if (!gpu_decode) {
+        if (wanted.size() == 1) bam.seek_contig(wanted[0], &err);   // .bai shortcut for --chrom
+        std::vector<char> want(contigs.size(), 0);
+        for (int32_t t : wanted) want[(size_t)t] = 1;
+        const int32_t last_wanted = wanted.back();
+        gdh::RecordBlock blk;
+        for (;;) {
+            const int rc = bam.next_block(blk, 1u << 21, &err);
+            if (rc < 0) {
+                fprintf(stderr, "goleft depth: %s\n", err.c_str());
+                return 1;
+            }
+            if (rc == 0) break;
+            if (blk.tid > last_wanted) break;                       // coordinate sorted: done
+            if (blk.tid >= (int32_t)contigs.size() || !want[(size_t)blk.tid]) continue;
+            gd_ctx* const ctx = ctx_of(blk.tid);
+            gd_batch b;
+            GDCHK_ON(ctx, gd_acquire(ctx, blk.size(), blk.cigar.size(), &b));
+            memcpy(b.pos, blk.pos.data(), blk.size() * sizeof(int32_t));
+            memcpy(b.flag, blk.flag.data(), blk.size() * sizeof(uint16_t));
+            memcpy(b.mapq, blk.mapq.data(), blk.size() * sizeof(uint8_t));
+            memcpy(b.cigar_off, blk.cigar_off.data(), (blk.size() + 1) * sizeof(uint32_t));
+            if (!blk.cigar.empty()) memcpy(b.cigar, blk.cigar.data(), blk.cigar.size() * sizeof(uint32_t));
+            GDCHK_ON(ctx, gd_commit(ctx, &b, blk.tid, blk.size(), blk.cigar.size()));
+        }
+        }
+    }
+    *n_gpu_records_out = n_gpu_records;
+    return 0;
+}
+
+int run(const DArgs& args)
+{
+    const auto t_run = std::chrono::steady_clock::now();
+    int exit_code = 0;
+    std::string err;
+    EarlyContexts early;                                     // (declared first: joined and emptied last)
+    std::vector<int> devices;
+    if (!parse_devices(&devices, &err)) { fprintf(stderr, "goleft depth: %s\n", err.c_str()); return 1; }
+    early.start(devices);
+    gdh::BamReader bam;
+    if (!bam.open(args.bam, args.processes, &err)) {
+        fprintf(stderr, "goleft depth: %s\n", err.c_str());
+        return 1;
+    }
+    const auto& contigs = bam.contigs();
+    std::map<std::string, int> tid_of;
+    for (size_t i = 0; i < contigs.size(); ++i) tid_of.emplace(contigs[i].name, (int)i);
+
+    // ---- regions: --bed rows (:103-120) or .fai tiles (:122-159) ------------
+    const int W = args.window_size;
+    const int64_t step = step_for(W);
+    std::vector<Region> regions;
+    if (int rc = collect_regions(args, tid_of, step, &regions)) return rc;
     std::vector<int32_t> wanted;
     for (const Region& r : regions)
         if (r.tid >= 0) wanted.push_back(r.tid);
@@ -535,21 +649,7 @@ int run(const DArgs& args)
             GDCHK_ON(sh.ctx, gd_select_contigs(sh.ctx, (int)sh.wanted.size(), sh.wanted.data()));
     }
     auto ctx_of = [&](int tid) -> gd_ctx* { return S.v[(size_t)shard_of[(size_t)tid]].ctx; };
-    // each worker runs on its own OS thread (every gd_* entry point re-issues hipSetDevice)
-    auto on_every_shard = [&](const char* what, const std::function<int(Shard&)>& fn) -> bool {
-        std::vector<std::thread> th;
-        for (size_t k = 1; k < S.v.size(); ++k)
-            th.emplace_back([&, k]() { S.v[k].rc = S.v[k].wanted.empty() ? GD_OK : fn(S.v[k]); });
-        S.v[0].rc = S.v[0].wanted.empty() ? GD_OK : fn(S.v[0]);
-        for (auto& t : th) t.join();
-        for (Shard& sh : S.v)
-            if (sh.rc != GD_OK) {
-                fprintf(stderr, "goleft depth: %s failed on device %d: %s (%s)\n", what, sh.device, gd_strerror(sh.rc),
-                        gd_last_error(sh.ctx));
-                return false;
-            }
-        return true;
-    };
+    auto on_every_shard = [&](const char* what, const std::function<int(Shard&)>& fn) { return run_on_every_shard(S, what, fn); };
 
     // GOLEFT_DEPTH_TIMING=1: wall-clock phases on stderr (measurement only, SURVEY.md 8d scope iii)
     const bool timing = getenv("GOLEFT_DEPTH_TIMING") != nullptr;
@@ -560,74 +660,11 @@ int run(const DArgs& args)
     const auto t_begin = now();
     uint64_t n_gpu_records = 0;
     auto t_ingested = t_begin, t_computed = t_begin, t_indexed = t_begin, t_mapped = t_begin, t_read = t_begin;
-    // ---- records into HBM (replaces the samtools children) ---------------------------
-    // With a .bai next to the BAM (goleft depth needs one anyway: `samtools depth -r`), the whole
-    // read happens on the device: the contig's byte range goes to gd_ingest_bgzf, which inflates
-    // the BGZF members and decodes the records there (GOLEFT_GPU_DECODE=0 keeps the host decoder).
-    // Every shard reads its own contigs' byte ranges from the shared mapping.
+    // ---- records into HBM: the device decoder when a .bai exists, else the host decoder through the pinned ring ----
     if (!wanted.empty()) {
-        std::vector<std::vector<uint64_t>> lin;
-        std::vector<char> has_chunks;
-        std::vector<uint64_t> chunk_end;
-        const char* gd_env = getenv("GOLEFT_GPU_DECODE");
-        bool gpu_decode = !(gd_env && gd_env[0] == '0') && gdh::BamReader::linear_index(args.bam, &lin, &err, &has_chunks, &chunk_end) &&
-                          lin.size() == contigs.size();
-        // a reference whose bins hold chunks but whose linear index is empty (a non-htslib indexer):
-        // the anchors cannot be trusted to mean "no records" -> host decoder
-        for (size_t r = 0; gpu_decode && r < lin.size(); ++r)
-            if (lin[r].empty() && r < has_chunks.size() && has_chunks[r]) gpu_decode = false;
-        t_indexed = now();
-        if (gpu_decode) {
-            gdh::FileMap fm;
-            if (!fm.open(args.bam)) gpu_decode = false;
-            fm.keep = gdh_get_fast_exit() != 0;
-            t_mapped = now();
-            if (gpu_decode) {
-                if (!on_every_shard("the device BAM read", [&](Shard& sh) {
-                        return gdh::ingest_references_on_device(sh.ctx, fm, lin, sh.wanted, sh.wanted, &sh.n_gpu_records, &sh.io_ok,
-                                                                (uint64_t)env_int("GOLEFT_INGEST_GROUP_MB", 512) << 20, &chunk_end,
-                                                                // a reference larger than this is read in parts cut at .bai anchors
-                                                                // (0: never; _KB: tests cut small files)
-                                                                getenv("GOLEFT_INGEST_PART_KB") ? (uint64_t)env_int("GOLEFT_INGEST_PART_KB", 0) << 10
-                                                                                                : (uint64_t)env_int("GOLEFT_INGEST_PART_MB", 2048) << 20);
-                    }))
-                    return 1;
-                for (Shard& sh : S.v) {
-                    if (!sh.io_ok) gpu_decode = false;
-                    n_gpu_records += sh.n_gpu_records;
-                }
-                if (!gpu_decode) n_gpu_records = 0;
-                t_read = now();
-            }
-            if (!gpu_decode)
-                for (Shard& sh : S.v) GDCHK_ON(sh.ctx, gd_reset(sh.ctx));   // fall back to the host decoder below
-        }
-        if (!gpu_decode) {
-        if (wanted.size() == 1) bam.seek_contig(wanted[0], &err);   // .bai shortcut for --chrom
-        std::vector<char> want(contigs.size(), 0);
-        for (int32_t t : wanted) want[(size_t)t] = 1;
-        const int32_t last_wanted = wanted.back();
-        gdh::RecordBlock blk;
-        for (;;) {
-            const int rc = bam.next_block(blk, 1u << 21, &err);
-            if (rc < 0) {
-                fprintf(stderr, "goleft depth: %s\n", err.c_str());
-                return 1;
-            }
-            if (rc == 0) break;
-            if (blk.tid > last_wanted) break;                       // coordinate sorted: done
-            if (blk.tid >= (int32_t)contigs.size() || !want[(size_t)blk.tid]) continue;
-            gd_ctx* const ctx = ctx_of(blk.tid);
-            gd_batch b;
-            GDCHK_ON(ctx, gd_acquire(ctx, blk.size(), blk.cigar.size(), &b));
-            memcpy(b.pos, blk.pos.data(), blk.size() * sizeof(int32_t));
-            memcpy(b.flag, blk.flag.data(), blk.size() * sizeof(uint16_t));
-            memcpy(b.mapq, blk.mapq.data(), blk.size() * sizeof(uint8_t));
-            memcpy(b.cigar_off, blk.cigar_off.data(), (blk.size() + 1) * sizeof(uint32_t));
-            if (!blk.cigar.empty()) memcpy(b.cigar, blk.cigar.data(), blk.cigar.size() * sizeof(uint32_t));
-            GDCHK_ON(ctx, gd_commit(ctx, &b, blk.tid, blk.size(), blk.cigar.size()));
-        }
-        }
+        ReadTimes T{t_begin, t_begin, t_begin};
+        if (int rc = read_records(args, bam, wanted, S, shard_of, &n_gpu_records, &T)) return rc;
+        t_indexed = T.indexed; t_mapped = T.mapped; t_read = T.read;
         t_ingested = now();
         if (!on_every_shard("gd_compute", [&](Shard& sh) { return gd_compute(sh.ctx); })) return 1;
         t_computed = now();
