@@ -30,7 +30,7 @@
 //     issued them, so the counts hold either way).
 // Huffman decoding is canonical and branch free: the 15-bit peek is compared with the left-aligned end
 // of every code length (15 compares against packed registers) and the symbol index is one add and two
-// LDS reads ([entry][lane] tables: 408 bytes per lane, six workgroups per CU).  Block headers (dynamic
+// LDS reads ([entry][lane] tables: 408 bytes per lane + a 64-byte input window, five workgroups per CU).  Block headers (dynamic
 // tables: ~300 serial code lengths per lane) are a divergent side path; lanes that reach one wait a
 // few iterations so that the wave builds its tables together.  CRC32 is a second, converged kernel.
 #pragma once
@@ -60,7 +60,8 @@ constexpr int INF_DDN = INF_LDN + 15 * 64 * 4;           // u16 [15][64]: distan
 constexpr int INF_LSYM = INF_DDN + 15 * 64 * 2;          // u8 [288][64]: low 8 bits of the lit/len symbols in code order
 constexpr int INF_DSYM = INF_LSYM + INF_MAXL * 64;       // u8 [30][64]
 constexpr int INF_PERM = INF_DSYM + INF_MAXD * 64;       // u32 [16][8]: byte-permute selectors of a period-d chunk (shared)
-constexpr int INF_LDS_BYTES = INF_PERM + 16 * 32;        // 26 624: six workgroups per CU
+constexpr int INF_INWIN = INF_PERM + 16 * 32;            // u32 [16][64]: every lane's 64-byte window of its member's input
+constexpr int INF_LDS_BYTES = INF_INWIN + 16 * 64 * 4;   // 30 720: five workgroups per CU
 
 typedef uint32_t inf_v4 __attribute__((ext_vector_type(4)));
 
@@ -227,6 +228,26 @@ __global__ __launch_bounds__(INF_LANES) void gd_inflate_kernel(InflateJob job)
     uint64_t buf = 0;
     uint32_t cnt = 0;
     const uint8_t* ld_addr = out;                          // the chunk source the next iteration loads (or any readable address)
+    // The member's INPUT goes through a 64-byte window in LDS ([dword][lane]: four 16-byte slots, a ring).  The refill of
+    // the bit buffer used to load its 8 bytes from memory in every iteration -- from a line that advances by a byte or two
+    // per iteration and, with ~100 000 members in flight (each with an input line, an output line and match sources:
+    // more than L2 holds), was evicted in between: FETCH_SIZE 126 GB per 1.9 GB of input + 7 GB of output.  Now a
+    // 16-byte slot is loaded ONCE, when everything in it has been consumed (about every tenth iteration), and the
+    // refill reads three dwords of LDS.  win_hi: payload offset (a multiple of 16) where the window's newest slot ends;
+    // it always reaches at least 32 bytes past the byte the bit buffer is at.
+    uint32_t* const s_win = reinterpret_cast<uint32_t*>(s_tbl + INF_INWIN) + lane;
+    uint32_t win_hi = 0;
+    auto win_put = [&](uint32_t at, inf_v4 v) {            // payload bytes [at, at + 16), at % 16 == 0
+        const uint32_t j = (at >> 2) & 12u;
+        s_win[(j + 0u) * 64u] = v.x; s_win[(j + 1u) * 64u] = v.y; s_win[(j + 2u) * 64u] = v.z; s_win[(j + 3u) * 64u] = v.w;
+    };
+    auto win_restart = [&](uint32_t poff) {                // (start of the member; behind a block header) four slots from poff's on
+        const uint32_t b = poff & ~15u;
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k) win_put(b + 16u * k, inf_load16(in_beg + b + 16u * k));
+        win_hi = b + 64u;
+    };
+    win_restart(0);
 
     for (uint32_t it = 0;; ++it) {
         const uint64_t live = __ballot(mode != DONE);
@@ -333,6 +354,7 @@ __global__ __launch_bounds__(INF_LANES) void gd_inflate_kernel(InflateJob job)
                 if (err != 0) { mode = DONE; p = in_beg; }
                 if (mode == DONE && err == 0 && o != olen) err = 17;
                 need(56);                                  // what the decode below may consume
+                win_restart((uint32_t)(p - in_beg));       // the header was read past the window
             }
         }
 
@@ -340,7 +362,12 @@ __global__ __launch_bounds__(INF_LANES) void gd_inflate_kernel(InflateJob job)
         //      end of the iteration (its address does not depend on what the decode consumes) ----
         inf_v4 cl = {0, 0, 0, 0};
         if (cpend && !csmall) cl = inf_load16_stream(ld_addr);
-        const uint64_t nw = inf_load8(p);
+        const uint32_t poff = (uint32_t)(p - in_beg);
+        const bool want_in = mode != DONE && poff + 48u >= win_hi;   // the slot 64 bytes behind win_hi has been consumed
+        inf_v4 in16 = {0, 0, 0, 0};
+        if (want_in) in16 = inf_load16(in_beg + win_hi);
+        const uint32_t wj = poff >> 2;
+        const uint32_t wd0 = s_win[((wj + 0u) & 15u) * 64u], wd1 = s_win[((wj + 1u) & 15u) * 64u], wd2 = s_win[((wj + 2u) & 15u) * 64u];
 
         // ---- (2) decode one symbol: everything a match needs, for every lane (no branches) ----
         const uint32_t lo = (uint32_t)buf;
@@ -406,7 +433,10 @@ __global__ __launch_bounds__(INF_LANES) void gd_inflate_kernel(InflateJob job)
             if (mode == DONE) p = in_beg;
         }
         // ---- (6) refill from the word loaded at the top (before the store: nothing else is in flight then) ----
+        if (want_in) { win_put(win_hi, in16); win_hi += 16u; }   // (the slot's first byte is >= 32 bytes ahead: nobody reads it yet)
         if (mode != DONE) {
+            const uint32_t sh = poff & 3u;
+            const uint64_t nw = (uint64_t)__builtin_amdgcn_alignbyte(wd1, wd0, sh) | ((uint64_t)__builtin_amdgcn_alignbyte(wd2, wd1, sh) << 32);
             buf |= nw << cnt;
             p += (63u - cnt) >> 3;
             cnt |= 56u;

@@ -33,14 +33,17 @@ def test_waits_of_the_symbol_loop_are_counted(tmp_path):
     loads = [i for i, l in enumerate(body) if "global_load_dwordx4" in l and " nt" in l]
     assert len(loads) == 1, loads
     at = loads[0]
-    assert any("global_load_dwordx2" in l for l in body[at + 1:at + 8]), "the input word is not issued with the chunk load"
+    # round 4: the input comes through a 64-byte window in LDS; its refill -- one 16-byte load, by the lanes whose oldest
+    # slot is consumed -- is issued right behind the chunk load, and the bit buffer's refill reads LDS
+    assert any("global_load_dwordx4" in l and " nt" not in l for l in body[at + 1:at + 24]), "the window's refill is not issued with the chunk load"
+    assert not any("global_load_dwordx2" in l for l in body[at:at + 600]), "an 8-byte input load is back in the symbol loop"
     stores = [i for i, l in enumerate(body) if "global_store_dwordx4" in l and i > at]
     assert stores, "no 16-byte store after the loads"
     between = body[at:stores[0]]
     waits = [l.strip() for l in between if "s_waitcnt" in l and "vmcnt" in l]
-    # first the chunk (the input word may stay in flight), later the input word; never more than these
-    assert waits and waits[0] == "s_waitcnt vmcnt(1)", waits
-    assert len(waits) <= 3, waits
+    # both loads are conditional (few lanes refill in an iteration), so the one wait for them is vmcnt(0) -- once, after
+    # a whole symbol has been decoded; never a second wait for vector memory before the store
+    assert waits == ["s_waitcnt vmcnt(0)"], waits
     # the decode between the loads and that first wait is long: a whole symbol (both Huffman look-ups)
     first_wait = next(i for i, l in enumerate(between) if "vmcnt" in l)
     assert first_wait > 120, first_wait
@@ -55,4 +58,4 @@ def test_waits_of_the_symbol_loop_are_counted(tmp_path):
     vgprs = int(re.search(r"\.vgpr_count:\s+(\d+)", text[text.index("gd_inflate_kernel"):]).group(1))
     assert vgprs <= 256, vgprs
     lds = int(re.search(r"\.group_segment_fixed_size:\s+(\d+)", text).group(1))
-    assert lds * 6 <= 160 * 1024, lds
+    assert lds * 4 <= 160 * 1024, lds

@@ -61,7 +61,9 @@ def test_streaming_and_ingest_kernels(kernels):
         assert r["scratch"] == 0, (name, r)
 
 
-def test_inflate_kernel_keeps_six_workgroups_per_cu(kernels):
+def test_inflate_kernel_keeps_four_workgroups_per_cu(kernels):
+    # round 4: the lanes' input windows (and output rings) live in LDS next to the tables -- four to five workgroups per
+    # CU, measured faster than the six the tables alone allowed (profiles/r10k_inflate_occupancy.txt, r10v_…)
     (name, r), = pick(kernels, "gd_inflate_kernel").items()
-    assert r["lds"] * 6 <= LDS_PER_CU and r["vgpr"] <= 256, (name, r)      # LDS decides: six waves per CU, two per SIMD at most
+    assert r["lds"] * 4 <= LDS_PER_CU and r["vgpr"] <= 256, (name, r)      # LDS decides; two waves per SIMD at most
     assert r["scratch"] <= 512, (name, r)                    # the code lengths of a dynamic block (a lane's private array)
