@@ -30,9 +30,24 @@
 //     issued them, so the counts hold either way).
 // Huffman decoding is canonical and branch free: the 15-bit peek is compared with the left-aligned end
 // of every code length (15 compares against packed registers) and the symbol index is one add and two
-// LDS reads ([entry][lane] tables: 408 bytes per lane + a 64-byte input window, five workgroups per CU).  Block headers (dynamic
+// LDS reads ([entry][lane] tables: 408 bytes per lane).  Block headers (dynamic
 // tables: ~300 serial code lengths per lane) are a divergent side path; lanes that reach one wait a
 // few iterations so that the wave builds its tables together.  CRC32 is a second, converged kernel.
+//
+// Round 4: a lane's INPUT and OUTPUT go through LDS (608 bytes per lane in all: four workgroups per CU, measured faster
+// than the six the tables alone allowed).  With ~100 000 members in flight every lane kept an input line, an output line
+// and match sources alive in an L2 that holds a third of that: the 8 bytes the refill loaded per iteration came from a
+// line evicted since the last iteration, and each 16-byte store was a partial write of a line that left L2 before its
+// neighbours arrived -- FETCH_SIZE 126 GB and WRITE_SIZE 66 GB for 1.9 GB of input and 7.0 GB of output (108 k members).
+//   * input: a 64-byte window per lane; a 16-byte slot is loaded once, when everything in it has been consumed, and the
+//     refill reads three dwords of LDS;
+//   * output: a 128-byte ring per lane, addressed like memory (offset + the member's address mod 64); what an iteration
+//     produces is written there (five aligned dwords around the 16-byte register window), and the 64-byte block the
+//     output has just passed leaves for memory as four 16-byte stores to one aligned block, back to back; the source of
+//     a match is loaded from memory when it lies completely below what has been stored, else it lies completely inside
+//     the ring's last 96 bytes and is read from there.
+// 82.8 -> 54.3 ms for those 108 k members, WRITE_SIZE 66 -> 8.1 GB (1.15 x the output), FETCH_SIZE 126 -> 92 GB
+// (profiles/r10u_…, r10v_…, r10w_inflate_output_ring.txt).
 #pragma once
 
 namespace gd {
@@ -61,7 +76,8 @@ constexpr int INF_LSYM = INF_DDN + 15 * 64 * 2;          // u8 [288][64]: low 8 
 constexpr int INF_DSYM = INF_LSYM + INF_MAXL * 64;       // u8 [30][64]
 constexpr int INF_PERM = INF_DSYM + INF_MAXD * 64;       // u32 [16][8]: byte-permute selectors of a period-d chunk (shared)
 constexpr int INF_INWIN = INF_PERM + 16 * 32;            // u32 [16][64]: every lane's 64-byte window of its member's input
-constexpr int INF_LDS_BYTES = INF_INWIN + 16 * 64 * 4;   // 30 720: five workgroups per CU
+constexpr int INF_RING = INF_INWIN + 16 * 64 * 4;        // u32 [32][64]: every lane's last 128 bytes of output
+constexpr int INF_LDS_BYTES = INF_RING + 32 * 64 * 4;    // 38 912: four workgroups per CU
 
 typedef uint32_t inf_v4 __attribute__((ext_vector_type(4)));
 
@@ -186,6 +202,21 @@ __device__ __forceinline__ inf_v4 inf_append(inf_v4 t, inf_v4 c, uint32_t n)
     return o;
 }
 
+// The last 20 bytes of (e t followed by the first n bytes of c), 0 <= n <= 16: e' (the oldest four) and t'.
+__device__ __forceinline__ void inf_append5(uint32_t& e, inf_v4& t, inf_v4 c, uint32_t n)
+{
+    uint32_t a0 = e, a1 = t.x, a2 = t.y, a3 = t.z, a4 = t.w, a5 = c.x, a6 = c.y, a7 = c.z, a8 = c.w;
+    if (n & 16u) { a0 = a4; a1 = a5; a2 = a6; a3 = a7; a4 = a8; }
+    if (n & 8u) { a0 = a2; a1 = a3; a2 = a4; a3 = a5; a4 = a6; a5 = a7; a6 = a8; }
+    if (n & 4u) { a0 = a1; a1 = a2; a2 = a3; a3 = a4; a4 = a5; a5 = a6; }
+    const uint32_t r = n & 3u;
+    e = __builtin_amdgcn_alignbyte(a1, a0, r);
+    t.x = __builtin_amdgcn_alignbyte(a2, a1, r);
+    t.y = __builtin_amdgcn_alignbyte(a3, a2, r);
+    t.z = __builtin_amdgcn_alignbyte(a4, a3, r);
+    t.w = __builtin_amdgcn_alignbyte(a5, a4, r);
+}
+
 __global__ __launch_bounds__(INF_LANES) void gd_inflate_kernel(InflateJob job)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_tbl[INF_LDS_BYTES];
@@ -248,6 +279,22 @@ __global__ __launch_bounds__(INF_LANES) void gd_inflate_kernel(InflateJob job)
         win_hi = b + 64u;
     };
     win_restart(0);
+    // The member's OUTPUT goes through a 128-byte ring in LDS and leaves for memory in whole 64-byte blocks, aligned in
+    // MEMORY (ring and blocks are addressed by ao = the output offset + the low six bits of the member's address): a
+    // lane's 16-byte pieces at scattered addresses -- the chunk of a match, the window of the last 16 literals -- were
+    // each a partial write of a line that ~100 000 members in flight kept evicting from L2 before its neighbours
+    // arrived (WRITE_SIZE 9.4 x the output at six workgroups per CU, 1.7 x at two).  fl: everything below it has been
+    // stored; a block is stored as soon as the output has passed its end, so at most 79 bytes are ever only in the ring --
+    // and the source of a match that is not completely below fl lies completely inside the ring's last 96 bytes.
+    uint32_t* const s_ring = reinterpret_cast<uint32_t*>(s_tbl + INF_RING) + lane;
+    const uint32_t obase = (uint32_t)(reinterpret_cast<uintptr_t>(out) & 63u);
+    uint8_t* const out_al = out - obase;                   // 64-byte aligned: block [fl, fl + 64) lives at out_al + fl
+    uint32_t fl = 0;
+    uint32_t E0 = 0;                                       // the four bytes before T: bytes [o - 20, o - 16)
+    auto ring_byte = [&](uint32_t a) -> uint32_t { return (s_ring[((a >> 2) & 31u) * 64u] >> (8u * (a & 3u))) & 0xffu; };
+    // the bytes [lo, hi) of the ring to memory, one by one (a member's first block when the member starts inside it, its
+    // last bytes, what is pending when a stored block starts)
+    auto ring_bytes_out = [&](uint32_t lo, uint32_t hi) { for (uint32_t a = lo; a < hi; ++a) out_al[a] = (uint8_t)ring_byte(a); };
 
     for (uint32_t it = 0;; ++it) {
         const uint64_t live = __ballot(mode != DONE);
@@ -290,14 +337,23 @@ __global__ __launch_bounds__(INF_LANES) void gd_inflate_kernel(InflateJob job)
                     if ((len ^ 0xffffu) != nlen) err = 2;
                     else if (o + len > olen || past_end()) err = 3;
                     else {
+                        // (a stored block's bytes go straight to memory: what is still only in the ring goes first, and the
+                        // ring restarts behind the block -- with the bytes of the block's last, incomplete 64-byte block)
+                        ring_bytes_out(fl > obase ? fl : obase, obase + o);
                         for (uint32_t k = 0; k < len && err == 0; ++k) {
                             out[o++] = (uint8_t)bits(8);
                             if (p > in_end + 16) err = 1;
                         }
-                        uint32_t w[4] = {0, 0, 0, 0};
-                        for (uint32_t k = 0; k < 16 && k < o; ++k)
-                            w[3 - (k >> 2)] |= (uint32_t)out[o - 1 - k] << (8 * (3 - (k & 3)));
-                        T = inf_v4{w[0], w[1], w[2], w[3]};
+                        uint32_t w[5] = {0, 0, 0, 0, 0};
+                        for (uint32_t k = 0; k < 20 && k < o; ++k)
+                            w[4 - (k >> 2)] |= (uint32_t)out[o - 1 - k] << (8 * (3 - (k & 3)));
+                        E0 = w[0];
+                        T = inf_v4{w[1], w[2], w[3], w[4]};
+                        fl = (obase + o) & ~63u;
+                        for (uint32_t a = fl > obase ? fl : obase; a < obase + o; ++a) {
+                            uint32_t& d = s_ring[((a >> 2) & 31u) * 64u];
+                            d = (d & ~(0xffu << (8u * (a & 3u)))) | ((uint32_t)out_al[a] << (8u * (a & 3u)));
+                        }
                         if (err == 0 && past_end()) err = 1;
                     }
                     // the next header follows (or the member ends)
@@ -361,7 +417,20 @@ __global__ __launch_bounds__(INF_LANES) void gd_inflate_kernel(InflateJob job)
         // ---- (1) the iteration's two loads: the chunk of a match in progress, the input word of the refill at the
         //      end of the iteration (its address does not depend on what the decode consumes) ----
         inf_v4 cl = {0, 0, 0, 0};
-        if (cpend && !csmall) cl = inf_load16_stream(ld_addr);
+        const bool cload = cpend && !csmall;
+        const uint32_t sa = obase + co - deff;             // where the chunk's source begins (ao); it ends at or before co
+        const bool from_mem = cload && sa + 16u <= fl;     // completely stored -- else completely inside the ring
+        if (from_mem) cl = inf_load16_stream(ld_addr);
+        inf_v4 cr = {0, 0, 0, 0};
+        if (cload && !from_mem) {
+            const uint32_t rj = sa >> 2, rs = sa & 3u;
+            const uint32_t r0 = s_ring[((rj + 0u) & 31u) * 64u], r1 = s_ring[((rj + 1u) & 31u) * 64u], r2 = s_ring[((rj + 2u) & 31u) * 64u],
+                           r3 = s_ring[((rj + 3u) & 31u) * 64u], r4 = s_ring[((rj + 4u) & 31u) * 64u];
+            cr.x = __builtin_amdgcn_alignbyte(r1, r0, rs);
+            cr.y = __builtin_amdgcn_alignbyte(r2, r1, rs);
+            cr.z = __builtin_amdgcn_alignbyte(r3, r2, rs);
+            cr.w = __builtin_amdgcn_alignbyte(r4, r3, rs);
+        }
         const uint32_t poff = (uint32_t)(p - in_beg);
         const bool want_in = mode != DONE && poff + 48u >= win_hi;   // the slot 64 bytes behind win_hi has been consumed
         inf_v4 in16 = {0, 0, 0, 0};
@@ -386,8 +455,8 @@ __global__ __launch_bounds__(INF_LANES) void gd_inflate_kernel(InflateJob job)
 
         // ---- (3) the chunk loaded (or built) in the previous iteration goes into T ----
         const bool cp = cpend;
-        const inf_v4 c = csmall ? cs : cl;
-        if (cp) T = inf_append(T, c, cn);
+        const inf_v4 c = csmall ? cs : (from_mem ? cl : cr);
+        if (cp) inf_append5(E0, T, c, cn);
         cpend = false;
 
         // ---- (4) this iteration's symbol ----
@@ -398,6 +467,7 @@ __global__ __launch_bounds__(INF_LANES) void gd_inflate_kernel(InflateJob job)
             else if (sym < 256u) {
                 if (o >= olen) { err = 3; mode = DONE; }
                 else {
+                    E0 = __builtin_amdgcn_alignbyte(T.x, E0, 1);
                     T.x = __builtin_amdgcn_alignbyte(T.y, T.x, 1);
                     T.y = __builtin_amdgcn_alignbyte(T.z, T.y, 1);
                     T.z = __builtin_amdgcn_alignbyte(T.w, T.z, 1);
@@ -443,19 +513,34 @@ __global__ __launch_bounds__(INF_LANES) void gd_inflate_kernel(InflateJob job)
             if (p > in_end + 16) { err = 1; mode = DONE; p = in_beg; }   // ran off the member's input
         }
 
-        // the iteration's one store: the chunk; or T over the 16 bytes it mirrors when the literals gathered in it are
-        // due (`flush`) or the chunk may not run past the member's end
-        if (cp && co + 16u <= olen) {
-            inf_store16(out + co, c);
-        } else if (flush || cp) {
-            if (o >= 16u) {
-                inf_store16(out + (o - 16u), T);
-            } else {                                       // the member's first bytes: T holds them right-aligned
-                const uint32_t w[4] = {T.x, T.y, T.z, T.w};
-                for (uint32_t k = 0; k < o; ++k) {
-                    const uint32_t b = 16u - o + k;
-                    out[k] = (uint8_t)(w[b >> 2] >> (8 * (b & 3)));
+        // what this iteration produced goes into the ring: the 20 bytes [o - 20, o) (E0, T) as five aligned dwords from the
+        // dword that holds byte o - 20 on -- up to three bytes more than T needs on either side: in front bytes that are
+        // there already, behind bytes that the next write replaces before anything reads them
+        if (flush || cp) {
+            const uint32_t ao = obase + o;
+            const uint32_t sh = (4u - (ao & 3u)) & 3u;
+            const uint32_t jw = (ao - 20u + sh) >> 2;
+            s_ring[((jw + 0u) & 31u) * 64u] = __builtin_amdgcn_alignbyte(T.x, E0, sh);
+            s_ring[((jw + 1u) & 31u) * 64u] = __builtin_amdgcn_alignbyte(T.y, T.x, sh);
+            s_ring[((jw + 2u) & 31u) * 64u] = __builtin_amdgcn_alignbyte(T.z, T.y, sh);
+            s_ring[((jw + 3u) & 31u) * 64u] = __builtin_amdgcn_alignbyte(T.w, T.z, sh);
+            s_ring[((jw + 4u) & 31u) * 64u] = __builtin_amdgcn_alignbyte(0u, T.w, sh);
+            // ... and the 64-byte block the output has just passed the end of leaves for memory: four 16-byte stores to ONE
+            // aligned 64-byte block, back to back (at most one block per iteration: the output grows by 16 bytes at most)
+            if (ao >= fl + 64u) {
+                const uint32_t j0 = (fl >> 2) & 31u;       // 0 or 16
+                if (fl >= obase) {
+#pragma unroll
+                    for (uint32_t q = 0; q < 4u; ++q) {
+                        inf_v4 v;
+                        v.x = s_ring[(j0 + 4u * q + 0u) * 64u]; v.y = s_ring[(j0 + 4u * q + 1u) * 64u];
+                        v.z = s_ring[(j0 + 4u * q + 2u) * 64u]; v.w = s_ring[(j0 + 4u * q + 3u) * 64u];
+                        inf_store16(out_al + fl + 16u * q, v);
+                    }
+                } else {
+                    ring_bytes_out(obase, fl + 64u);       // the member starts inside this block: the bytes in front of it are another member's
                 }
+                fl += 64u;
             }
         }
         if (flush) pend = 0;
@@ -488,6 +573,8 @@ __global__ __launch_bounds__(INF_LANES) void gd_inflate_kernel(InflateJob job)
         }
 
     }
+    // the member's last bytes: what never completed a 64-byte block
+    if (mine && err == 0u) ring_bytes_out(fl > obase ? fl : obase, obase + olen);
     if (mine) job.status[m] = err;
 }
 
@@ -529,8 +616,8 @@ __global__ __launch_bounds__(256) void gd_inflate_crc_kernel(InflateJob job)
 }
 
 // Both kernels on one stream.
-// lds_pad: bytes of LDS a workgroup claims on top of its tables -- an occupancy limiter (26 KB of tables: six workgroups
-// per CU; + 6 KB: five; + 14 KB: four; + 27 KB: three), GD_OPT_INFLATE_LDS_PAD.
+// lds_pad: bytes of LDS a workgroup claims on top of its own 38 KB -- an occupancy limiter for measurements (four
+// workgroups per CU as built; + 16 KB: three; + 42 KB: two), GD_OPT_INFLATE_LDS_PAD.
 inline void inflate_launch(const InflateJob& job, hipStream_t stream, unsigned lds_pad = 0)
 {
     hipLaunchKernelGGL(gd_inflate_kernel, dim3((job.n + INF_LANES - 1) / INF_LANES), dim3(INF_LANES), lds_pad, stream, job);

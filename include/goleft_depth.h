@@ -229,8 +229,7 @@ enum { /* (1, 2: tile shapes other than 4096 positions x 256 threads -- measured
        GD_OPT_INGEST_HYBRID = 17,     /* with GD_OPT_INGEST_PIECE_STREAMS >= 2: 1: the pieces of every stream but the first leave through a copy
                                        kernel instead of a copy command (the copy engine and a kernel share the link); 0 (default) */
        GD_OPT_INFLATE_LDS_PAD = 16,   /* bytes of LDS every workgroup of the inflate kernel claims on top of its tables: 0 (default) ..
-                                       122880.  An occupancy limiter for measurements: fewer members in flight per CU are fewer
-                                       partly written output lines competing for L2 */
+                                       122880.  An occupancy limiter for measurements (fewer members in flight per CU) */
        GD_OPT_H2D_KERNEL = 8 };     /* how a committed staging block reaches HBM: 1 (default) one kernel whose workgroups
                                        read the page-locked block over the link (all five arrays in one launch; n > 1:
                                        with n workgroups), 0: five hipMemcpyAsync through a DMA engine */

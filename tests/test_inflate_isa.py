@@ -34,16 +34,21 @@ def test_waits_of_the_symbol_loop_are_counted(tmp_path):
     assert len(loads) == 1, loads
     at = loads[0]
     # round 4: the input comes through a 64-byte window in LDS; its refill -- one 16-byte load, by the lanes whose oldest
-    # slot is consumed -- is issued right behind the chunk load, and the bit buffer's refill reads LDS
-    assert any("global_load_dwordx4" in l and " nt" not in l for l in body[at + 1:at + 24]), "the window's refill is not issued with the chunk load"
+    # slot is consumed -- is issued behind the chunk load (and the ring reads of the lanes whose match source has not been
+    # stored yet), and the bit buffer's refill reads LDS
+    assert any("global_load_dwordx4" in l and " nt" not in l for l in body[at + 1:at + 120]), "the window's refill is not issued with the chunk load"
     assert not any("global_load_dwordx2" in l for l in body[at:at + 600]), "an 8-byte input load is back in the symbol loop"
     stores = [i for i, l in enumerate(body) if "global_store_dwordx4" in l and i > at]
     assert stores, "no 16-byte store after the loads"
+    # the output leaves in whole 64-byte blocks: four 16-byte stores to one block, back to back
+    assert len(stores) >= 4 and stores[3] - stores[0] <= 8, stores[:6]
+    offs = [re.search(r"offset:(\d+)", body[i]) for i in stores[:4]]
+    assert [int(m.group(1)) if m else 0 for m in offs] == [0, 16, 32, 48], [body[i].strip() for i in stores[:4]]
     between = body[at:stores[0]]
     waits = [l.strip() for l in between if "s_waitcnt" in l and "vmcnt" in l]
-    # both loads are conditional (few lanes refill in an iteration), so the one wait for them is vmcnt(0) -- once, after
-    # a whole symbol has been decoded; never a second wait for vector memory before the store
-    assert waits == ["s_waitcnt vmcnt(0)"], waits
+    # both loads are conditional (few lanes refill in an iteration; a source may come from the ring), so the waits for them
+    # are vmcnt(0) -- the first after a whole symbol has been decoded, at most one more (the window slot's write)
+    assert waits and set(waits) == {"s_waitcnt vmcnt(0)"} and len(waits) <= 2, waits
     # the decode between the loads and that first wait is long: a whole symbol (both Huffman look-ups)
     first_wait = next(i for i, l in enumerate(between) if "vmcnt" in l)
     assert first_wait > 120, first_wait
