@@ -560,7 +560,7 @@ int ck_enqueue(gd_ctx* c, const std::vector<ContigHost*>& hs, bool ops_known, Ck
     P->n_units = (uint32_t)units;
     const size_t o_unit = cv.take((units + 2) * sizeof(uint32_t));
     P->o_jobs = cv.take(nj * sizeof(gd::DelJob) + (nj + 1) * sizeof(uint32_t));   // the jobs, then ubeg
-    P->o_tot = cv.take(2 * nj * sizeof(uint32_t));               // [index entries][deletions] per contig
+    P->o_tot = cv.take(3 * nj * sizeof(uint32_t));               // [index entries][deletions][largest span] per contig
     if (int r = batch_block(c, std::move(keep), cv.at, &P->blk)) return r;
     char* const base = static_cast<char*>(P->blk->p);
     // job table (host copy kept in the context until the next batch)
@@ -622,10 +622,10 @@ int ck_readback(gd_ctx* c, const CkPending& P, uint32_t* dst)
     const size_t nj = P.hs.size();
     if (nj == 0) return GD_OK;
     char* const base = static_cast<char*>(P.blk->p);
-    HIPCHK(c, hipMemcpyAsync(dst, base + P.o_tot, 2 * nj * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-    for (size_t k = 0; k < nj; ++k)
-        HIPCHK(c, hipMemcpyAsync(dst + 2 * nj + k, base + P.o_lrec[k] + (P.hs[k]->n_reads + 1) * sizeof(uint4), sizeof(uint32_t),
-                                 hipMemcpyDeviceToHost, c->stream));
+    // (dst is page-locked: a one-wave kernel stores the 3 n words there -- no copy commands; there used to be 1 + n of them)
+    hipLaunchKernelGGL(gd::gd_copy_words_kernel, dim3(1), dim3(64), 0, c->stream, reinterpret_cast<const uint32_t*>(base + P.o_tot), dst,
+                       (uint32_t)(3 * nj));
+    HIPCHK(c, hipGetLastError());
     return GD_OK;
 }
 

@@ -490,6 +490,9 @@ __global__ __launch_bounds__(256) void gd_ptile_totals_kernel(DelBatch B)
     if (ji >= B.n_jobs) return;
     const DelJob job = B.jobs[ji];
     *job.total = job.unit[job.n_units] - job.unit[0];
+    // the contig's largest span next to its totals ([entries x n][deletions x n][spans x n]): ONE read-back for the batch
+    // instead of one 4-byte copy per contig
+    job.total[2u * B.n_jobs] = (uint32_t)*job.max_span;
 }
 
 // PT2: one lane per read fills its entries (a binary search of its own, sorted, deletion list per boundary).
