@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Where a context's FIRST gd_compute spends its time: fresh context, the 30x genome adopted,
-one compute; then a second one.  GOLEFT_TRACE_ENQUEUE=1 prints the host's time per call inside the enqueue."""
+one compute; then a second and a third, and the same in a second context of the process (gd_compute_timing: prepare =
+allocations + contig table, enqueue, wait).  It was this script, with per-call timers inside the enqueue, that found the
+first device-to-host copy command of a process blocking the enqueue behind the running kernels."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
