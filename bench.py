@@ -990,7 +990,7 @@ def main():
             # the genome-sized file with the device decoder (the number); the host decoder -- 39 s per genome on this
             # class of box, profiles/r04f_bench_wgs_n1.json -- runs on a small file of the same make, where the two
             # decoders' BED files are compared byte for byte
-            res = bam_file_scope(which, W, device_reps=2, host_decoder=which != "genome")
+            res = bam_file_scope(which, W, device_reps=3, host_decoder=which != "genome")
             if "error" in res and which == "genome" and args.bam_scope == "auto":
                 res = dict(bam_file_scope("chr1-2", W), fell_back_from=res["error"])
             if which == "genome" and "error" not in res:

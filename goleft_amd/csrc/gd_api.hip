@@ -862,6 +862,11 @@ int gd_set_option(gd_ctx* c, int option, int64_t value)
         break;
     case GD_OPT_INGEST_INDEX: c->ingest_index = value != 0; break;
     case GD_OPT_INGEST_HYBRID: c->ing_hybrid = value != 0; break;
+    case GD_OPT_INGEST_CU_SPLIT:
+        if (value < 0 || value > 64 || value == 1) return fail(c, GD_E_INVALID, "ingest CU split: 0 (off) or 2 .. 64");
+        if (c->ing_stream[0] || c->ing_hp) return fail(c, GD_E_STATE, "the ingest streams exist already: set GD_OPT_INGEST_CU_SPLIT before the first gd_ingest_begin");
+        c->ing_cu_split = (int)value;
+        break;
     case GD_OPT_INGEST_RANGE_HINT:
         if (value < 0) return fail(c, GD_E_INVALID, "ingest range hint: bytes >= 0");
         c->ing_range_hint = (uint64_t)value;

@@ -222,7 +222,8 @@ struct gd_ctx {
     // gd_ingest_begin .. gd_ingest_finish.  Two ranges may be pending: ing_q[0] is the oldest (the one
     // gd_ingest_decode / _finish / _release act on), the last one is being fed -- so the inflate tail of
     // one range overlaps the upload of the next.
-    IngestState* ing_q[2] = {nullptr, nullptr};
+    static constexpr int kIngestDepth = 3;              // ranges that may be pending: one being decoded, one inflating, one being fed
+    IngestState* ing_q[kIngestDepth] = {nullptr, nullptr, nullptr};
     int ing_n = 0;
     double ing_secs[7] = {0, 0, 0, 0, 0, 0, 0};         // gd_ingest_timing
     std::thread ing_feeder;                             // gd_ingest_feed_fd: the read of the newest range in progress
@@ -231,13 +232,14 @@ struct gd_ctx {
     double ing_feeder_secs[2] = {0, 0};                 // its share of gd_ingest_timing [0], [1] (merged by ingest_join)
     bool ing_stage_used[8] = {false, false, false, false, false, false, false, false};
     int ing_cur = 0;
-    IngestBufs ing_bufs[2];
+    IngestBufs ing_bufs[kIngestDepth];
     // staging of the device BAM read, created by the first gd_ingest_begin and kept until gd_destroy
     // (page-locking 128 MB per contig would cost more than many contigs' whole decode)
     uint8_t* ing_stage[8] = {};                        // page-locked staging buffers: two per upload stream
     hipEvent_t ing_staged[8] = {};
     int ing_piece_streams = 1;                         // GD_OPT_INGEST_PIECE_STREAMS: whole pieces alternate over this many streams (copy engines)
     uint64_t ing_piece_seq = 0;
+    int ing_cu_split = 0;                              // GD_OPT_INGEST_CU_SPLIT: every n-th CU for the copy kernel, the rest for the inflate launches
     bool ing_hybrid = false;                           // GD_OPT_INGEST_HYBRID: with two piece streams, the second one's pieces leave through a copy kernel
     hipStream_t ing_dma[3] = {nullptr, nullptr, nullptr};   // GD_OPT_INGEST_DMA > 1: a staged piece leaves in slices on several streams (DMA engines)
     hipEvent_t ing_dma_ev[8][3] = {};

@@ -636,8 +636,16 @@ int run(const DArgs& args)
         }
         GDCHK_ON(sh.ctx, gd_set_params(sh.ctx, &P));
         GDCHK_ON(sh.ctx, gd_set_option(sh.ctx, GD_OPT_COPY_THREADS, env_int("GOLEFT_COPY_THREADS", 4)));   // staging copies of the device BAM read
-        if (getenv("GOLEFT_INGEST_DMA")) GDCHK_ON(sh.ctx, gd_set_option(sh.ctx, GD_OPT_INGEST_DMA, env_int("GOLEFT_INGEST_DMA", 2)));
+        // How the BAM's bytes reach the device: a copy KERNEL on CUs of its own (every 8th), the inflate launches on the
+        // others (CU-masked streams).  One copy engine moves 21-22 GB/s next to the inflate kernels (and its reads of host
+        // memory slow the pread into the staging buffers down: 0.8-2.1 s per genome by box against 0.65 s); the kernel on 32
+        // dedicated CUs moves 35 GB/s.  GOLEFT_INGEST_DMA=1 brings the copy engine back, GOLEFT_INGEST_CU_SPLIT=0 the
+        // unmasked streams (profiles/r11d_, r11e_scope3_genome.json).
+        GDCHK_ON(sh.ctx, gd_set_option(sh.ctx, GD_OPT_INGEST_DMA, env_int("GOLEFT_INGEST_DMA", 0)));
+        if (!getenv("GOLEFT_INGEST_CU_SPLIT") && env_int("GOLEFT_INGEST_DMA", 0) == 0)
+            GDCHK_ON(sh.ctx, gd_set_option(sh.ctx, GD_OPT_INGEST_CU_SPLIT, 8));
         if (getenv("GOLEFT_INGEST_PIECE_STREAMS")) GDCHK_ON(sh.ctx, gd_set_option(sh.ctx, GD_OPT_INGEST_PIECE_STREAMS, env_int("GOLEFT_INGEST_PIECE_STREAMS", 1)));
+        if (getenv("GOLEFT_INGEST_CU_SPLIT")) GDCHK_ON(sh.ctx, gd_set_option(sh.ctx, GD_OPT_INGEST_CU_SPLIT, env_int("GOLEFT_INGEST_CU_SPLIT", 0)));
         if (getenv("GOLEFT_INGEST_HYBRID")) GDCHK_ON(sh.ctx, gd_set_option(sh.ctx, GD_OPT_INGEST_HYBRID, env_int("GOLEFT_INGEST_HYBRID", 0)));
         if (getenv("GOLEFT_INFLATE_LDS_PAD")) GDCHK_ON(sh.ctx, gd_set_option(sh.ctx, GD_OPT_INFLATE_LDS_PAD, env_int("GOLEFT_INFLATE_LDS_PAD", 0)));
         if (env_int("GOLEFT_TRUST_BGZF", 0)) GDCHK_ON(sh.ctx, gd_set_option(sh.ctx, GD_OPT_INGEST_CRC, 0));

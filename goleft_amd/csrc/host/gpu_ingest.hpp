@@ -380,8 +380,11 @@ inline int ingest_references_on_device(gd_ctx* ctx, const FileMap& fm, const std
         std::thread& t; std::mutex& mu; std::condition_variable& cv; bool& stop;
         ~Joiner() { { std::lock_guard<std::mutex> lk(mu); stop = true; } cv.notify_all(); if (t.joinable()) t.join(); }
     } joiner{lister, mu, cv, stop};
-    bool pending = false;                                  // a fed pass waits for its decode
-    size_t pprev = 0;
+    // Three passes are in flight: the one being fed (its bytes on the link, its first members inflating), the one before it
+    // (its last members inflating) and the one before that, which the caller decodes meanwhile -- with only two, the decode
+    // had to wait for the inflate tail of the pass that had JUST been fed before the next pass could be announced, and the
+    // link stood still for that long (it matters once the link is fast: GD_OPT_INGEST_CU_SPLIT).
+    std::vector<size_t> fed;                               // passes fed and not yet decoded, oldest first
     for (size_t pk = 0; pk < passes.size(); ++pk) {
         const IngestPass& ps = passes[pk];
         const uint64_t beg = ps.beg, end = ps.end;
@@ -414,18 +417,25 @@ inline int ingest_references_on_device(gd_ctx* ctx, const FileMap& fm, const std
                 rc = gd_ingest_feed(ctx, fm.p + beg + off, used - off < piece ? used - off : piece);
         }
         if (rc != GD_OK) { (void)gd_ingest_abort(ctx); return rc; }
-        MemberTable().swap_into(&mt);                      // (the table is on the device now)
+        MemberTable().swap_into(&mt);                      // (the table is page-locked memory of the context now)
         const double t3 = now();
-        // this pass is on its way (upload + inflate are asynchronous): now decode the one before it
-        if (pending) {
-            rc = decode_pass(passes[pprev]);
+        fed.push_back(pk);
+        // this pass is on its way (upload + inflate are asynchronous): now decode the oldest one, once two are behind it
+        if (fed.size() > 2) {
+            rc = decode_pass(passes[fed.front()]);
             if (rc != GD_OK) return rc;
+            fed.erase(fed.begin());
         }
         t_list += t1 - t0; t_begin += t2 - t1; t_feed += t3 - t2; t_decode += now() - t3;
-        pending = true; pprev = pk;
     }
     int rc_last = GD_OK;
-    if (pending) { const double t = now(); rc_last = decode_pass(passes[pprev]); t_decode += now() - t; }
+    while (!fed.empty() && rc_last == GD_OK) {
+        const double t = now();
+        rc_last = decode_pass(passes[fed.front()]);
+        fed.erase(fed.begin());
+        t_decode += now() - t;
+    }
+    if (rc_last != GD_OK) return rc_last;
     if (timing) {
         double t_listing = 0;
         for (const Listed& l : listed) t_listing += l.secs;

@@ -226,6 +226,9 @@ enum { /* (1, 2: tile shapes other than 4096 positions x 256 threads -- measured
        GD_OPT_INGEST_RANGE_HINT = 18, /* bytes of the LARGEST range gd_ingest_begin will be given (0, the default: unknown): the range
                                        buffers are allocated for it on first use instead of growing -- freeing and allocating --
                                        whenever a later range is larger than the ones before */
+       GD_OPT_INGEST_CU_SPLIT = 19,   /* with GD_OPT_INGEST_DMA = 0: every n-th CU (2 .. 64; 0, the default: off) runs only the copy kernel that
+                                       pulls staged pieces over the link, the other CUs only the inflate launches (CU-masked
+                                       streams); set before the first gd_ingest_begin */
        GD_OPT_INGEST_HYBRID = 17,     /* with GD_OPT_INGEST_PIECE_STREAMS >= 2: 1: the pieces of every stream but the first leave through a copy
                                        kernel instead of a copy command (the copy engine and a kernel share the link); 0 (default) */
        GD_OPT_INFLATE_LDS_PAD = 16,   /* bytes of LDS every workgroup of the inflate kernel claims on top of its tables: 0 (default) ..
@@ -487,10 +490,11 @@ int gd_ingest_bgzf(gd_ctx* ctx, int32_t tid, int32_t ref_id, const uint8_t* data
  * pass has a latency floor of ~0.04 s whatever its size): gd_ingest_decode is gd_ingest_finish
  * without the release, so call it once per reference of the range (each with that reference's
  * anchors and its own contig), then gd_ingest_release -- or gd_ingest_finish for the last one.
- * Two ranges may be pending at a time: once a range is completely fed, gd_ingest_begin / _feed of
+ * Three ranges may be pending at a time: once a range is completely fed, gd_ingest_begin / _feed of
  * the NEXT range may run before the first is decoded, so that the last inflate launches of one
- * range (latency bound) overlap the upload of the next; gd_ingest_decode, _finish and _release
- * always act on the oldest pending range, gd_ingest_feed on the newest.  A third gd_ingest_begin is
+ * range (latency bound) overlap the upload of the next -- and with a third, the decode of the oldest
+ * never holds the upload up; gd_ingest_decode, _finish and _release
+ * always act on the oldest pending range, gd_ingest_feed on the newest.  A fourth gd_ingest_begin is
  * refused (GD_E_STATE, nothing changes); gd_ingest_begin while the newest range is only partly fed
  * abandons what is pending, like gd_ingest_abort (which drops everything).  An error while feeding or
  * decoding drops everything pending. */

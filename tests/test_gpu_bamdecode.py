@@ -170,9 +170,9 @@ def test_ingest_several_references_in_one_pass(tmp_path):
 
 
 def test_ingest_two_ranges_pending(tmp_path):
-    """The next range is fed before the previous one is decoded (what the CLI does so that the inflate
-    tail of one pass overlaps the next upload): decode / release act on the oldest, a third begin is
-    refused."""
+    """The next ranges are fed before the previous one is decoded (what the CLI does so that the inflate
+    tail of one pass overlaps the next upload; three may be pending since round 4): decode / release act on
+    the oldest, a fourth begin is refused."""
     from goleft_amd.engine import DepthEngine, GdError
     rng = np.random.default_rng(44)
     lens = [90_000, 30_000, 150_000, 700]
@@ -187,13 +187,15 @@ def test_ingest_two_ranges_pending(tmp_path):
         eng.set_params(window_size=100, min_mapq=1, min_cov=4)
         eng.set_contigs(lens)
         eng.ingest_feed_range(data[:start[2] + 65536 + 26], 0, piece=40_000)       # references 0 and 1
-        eng.ingest_feed_range(data[start[2]:], start[2], piece=1 << 20)            # references 2 and 3
+        eng.ingest_feed_range(data[start[2]:start[3] + 65536 + 26], start[2], piece=1 << 20)   # reference 2
+        eng.ingest_feed_range(data[start[3]:], start[3], piece=1 << 20)            # reference 3
         with pytest.raises(GdError):
-            eng.ingest_feed_range(data, 0)                                         # a third pending range: refused,
+            eng.ingest_feed_range(data, 0)                                         # a fourth pending range: refused,
         assert eng.ingest_decode(0, 0, lin[0]) == reads[0].n                       # nothing changed
         assert eng.ingest_decode(1, 1, lin[1]) == reads[1].n
         eng.ingest_release()
         assert eng.ingest_decode(2, 2, lin[2]) == reads[2].n
+        eng.ingest_release()
         assert eng.ingest_decode(3, 3, lin[3]) == reads[3].n
         eng.ingest_release()
         with pytest.raises(GdError):
