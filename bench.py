@@ -191,14 +191,46 @@ def host_stream_scope(local_rank, W, Q, mincov, genome=False, reps=3, opts=()):
             "in_place_filler_threads": fillers}
 
 
-def bam_file_scope(which, W, device_reps=3, host_decoder=True):
+def read_once(path, threads=16, block=8 << 20):
+    """One pass over a file that was just written, before anything is timed on it: the first read after the write is when
+    the kernel moves the file's pages to the active list of the page cache, under one lock taken by every reading thread
+    -- measured on the GPU boxes as twice the system time and 3x the wall time of every later read of the same file
+    (profiles/r11g_read_variance.jsonl: `pread` phase 0.54 s for 13 GB in the first run, 0.16-0.22 s in the next 25).
+    Seconds it took."""
+    from concurrent.futures import ThreadPoolExecutor
+    t0 = time.perf_counter()
+    size = os.path.getsize(path)
+    fd = os.open(path, os.O_RDONLY)
+    try:
+        per = (size // threads + block) // block * block
+
+        def part(i):
+            buf = bytearray(block)
+            off, end = i * per, min(size, (i + 1) * per)
+            while off < end:
+                n = os.preadv(fd, [buf], off)
+                if n <= 0:
+                    break
+                off += n
+        with ThreadPoolExecutor(threads) as ex:
+            list(ex.map(part, range(threads)))
+    finally:
+        os.close(fd)
+    return time.perf_counter() - t0
+
+
+def bam_file_scope(which, W, device_reps=3, host_decoder=True, pause_s=0.0):
     """SURVEY.md section 8d scope (iii), the only scope the reference itself runs and times (`time goleft depth ...`,
     indexcov/paper/cmp.sh:6): a BAM FILE -> depth.bed + callable.bed through the CLI twin, process start to exit.
     A synthetic but realistic coordinate-sorted BAM (tools/synth_bam.cpp: 150 bp records WITH SEQ and QUAL, BGZF, .bai)
     of `which` -- "genome": all 24 hg19 contigs, 30x, ~46 GB; "chr1-2": two chromosomes, ~7 GB; "chr20-21": ~1.4 GB --
-    is written to $TMPDIR, read by `goleft-depth depth -w W` with the device decoder (best of device_reps runs;
-    the file is in the page cache, as after any write) and once with the host decoder; the BED files must be byte
-    identical.  Reported next to -- never as -- `value`."""
+    is written to $TMPDIR, read once untimed (read_once above), then read by `goleft-depth depth -w W` with the device
+    decoder (best of device_reps runs; the file is in the page cache, as after any write) and once with the host decoder;
+    the BED files must be byte identical.  `pause_s`: seconds to wait before each run -- a process that starts while the
+    driver is still clearing the device memory the previous one released waits for it in its first large hipMalloc
+    (profiles/r11i_pause_test.jsonl, a 13 GB file: `gd_ingest_begin` 1.7-2.6 s and 2.5-3.4 s per run in 12 runs started
+    back to back, 0.23-0.36 s and 1.06-1.26 s per run in 12 runs started 1, 2 or 4 s after the previous one's exit); one
+    run of a real job has no such predecessor.  Reported next to -- never as -- `value`."""
     import shutil
     import subprocess
     from goleft_amd import synth
@@ -223,17 +255,21 @@ def bam_file_scope(which, W, device_reps=3, host_decoder=True):
         info = json.loads(subprocess.check_output([gen, bam, "chrS", ",".join(str(x) for x in lengths), "30", "20"],
                                                   timeout=900).decode())
         t_write = time.perf_counter() - t0
+        t_settle = read_once(bam)
         ref_bases = int(sum(lengths))
         out = {"what": "BAM file -> depth.bed + callable.bed, `goleft-depth depth -w %d -p 0 -r synth.fa --prefix OUT synth.bam`, "
-                       "process start to exit (the scope the reference times: indexcov/paper/cmp.sh:6); file in the page cache" % W,
+                       "process start to exit (the scope the reference times: indexcov/paper/cmp.sh:6); file in the page cache "
+                       "and read once before; %.1f s between runs" % (W, pause_s),
                "file": which, "contigs": len(lengths), "ref_bases": ref_bases, "reads": info["reads"],
-               "bam_bytes": info["bam_bytes"], "synth_bam_s": t_write, "written_to": tmp, "host_cores": os.cpu_count(),
-               "unit": "ref-bases/s"}
+               "bam_bytes": info["bam_bytes"], "synth_bam_s": t_write, "read_once_s": t_settle, "pause_before_each_run_s": pause_s,
+               "written_to": tmp, "host_cores": os.cpu_count(), "unit": "ref-bases/s"}
         beds = {}
         runs = [("device", {}, device_reps)] + ([("host", {"GOLEFT_GPU_DECODE": "0"}, 1)] if host_decoder else [])
         for decoder, env, reps in runs:
-            walls, best = [], None
+            walls, best, seen = [], None, []
             for _ in range(reps):
+                if pause_s:
+                    time.sleep(pause_s)
                 t0 = time.perf_counter()
                 p = subprocess.run([exe, "depth", "-w", str(W), "-p", "0", "-r", os.path.join(d, "synth.fa"), "--prefix",
                                     os.path.join(d, "out_" + decoder), bam],
@@ -249,6 +285,7 @@ def bam_file_scope(which, W, device_reps=3, host_decoder=True):
                 if phases.get("decoder") != decoder:
                     return dict(out, error="asked for the %s decoder, %r ran" % (decoder, phases.get("decoder")))
                 walls.append(dt)
+                seen.append({k: phases.get(k) for k in ("lib_begin_s", "lib_read_s", "lib_wait_link_s", "setup_s")})
                 if best is None or dt < best[0]:
                     best = (dt, phases)
             stem = os.path.join(d, "out_" + decoder)
@@ -261,7 +298,7 @@ def bam_file_scope(which, W, device_reps=3, host_decoder=True):
                         m.update(blk)
                 h.append(m.hexdigest())
             beds[decoder] = h
-            out[decoder + "_decoder"] = {"wall_s": best[0], "all_wall_s": walls, "ref_bases_per_s": ref_bases / best[0],
+            out[decoder + "_decoder"] = {"wall_s": best[0], "all_wall_s": walls, "all_runs": seen, "ref_bases_per_s": ref_bases / best[0],
                                          "bgzf_GBps": info["bam_bytes"] / best[0] / 1e9,
                                          "phases": {k: v for k, v in best[1].items() if isinstance(v, (int, float))}}
         out["value"] = out["device_decoder"]["ref_bases_per_s"]
@@ -990,7 +1027,10 @@ def main():
             # the genome-sized file with the device decoder (the number); the host decoder -- 39 s per genome on this
             # class of box, profiles/r04f_bench_wgs_n1.json -- runs on a small file of the same make, where the two
             # decoders' BED files are compared byte for byte
-            res = bam_file_scope(which, W, device_reps=3, host_decoder=which != "genome")
+            # (the pause: 1 s is enough after a run over a 13 GB file, profiles/r11i_pause_test.jsonl; the genome's run
+            # releases four times the device memory)
+            res = bam_file_scope(which, W, device_reps=4 if which == "genome" else 3, host_decoder=which != "genome",
+                                 pause_s=5.0 if which == "genome" else 2.0)
             if "error" in res and which == "genome" and args.bam_scope == "auto":
                 res = dict(bam_file_scope("chr1-2", W), fell_back_from=res["error"])
             if which == "genome" and "error" not in res:

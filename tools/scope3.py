@@ -31,6 +31,10 @@ def main():
     ap.add_argument("--no-host", action="store_true", help="skip the host-decoder run")
     ap.add_argument("--dir", default="", help="where the BAM is written (default: /dev/shm when it has the room, else /tmp)")
     ap.add_argument("--host-reps", type=int, default=3, help="repetitions of the host-decoder run (device runs: 3)")
+    ap.add_argument("--pause", type=float, default=2.0,
+                    help="seconds between the previous run's exit and the next start: a process that starts while the driver still "
+                         "clears the device memory its predecessor released waits for it in its first large hipMalloc "
+                         "(profiles/r11i_pause_test.jsonl: 2.5-3.4 s per run back to back, 1.06-1.26 s with >= 1 s between)")
     ap.add_argument("--rocprof", default="", help="directory: one more device-decoder run under rocprofv3 --kernel-trace --stats")
     args = ap.parse_args()
     import shutil
@@ -45,6 +49,12 @@ def main():
     info = json.loads(subprocess.check_output([os.path.join(ROOT, "goleft_amd", "synth-bam"), bam, args.name,
                                                args.length, str(args.coverage), "20"]).decode())
     subprocess.run(["sync"])                                # the file at rest: no write-back under the timed runs
+    # one untimed pass over the file: the first read after a write moves the file's pages to the page cache's active list
+    # under one lock (3x the wall time of every later read, profiles/r11g_read_variance.jsonl)
+    with open(bam, "rb", buffering=0) as fh:
+        buf = bytearray(64 << 20)
+        while fh.readinto(buf):
+            pass
     args.length = sum(int(x) for x in args.length.split(","))
     t_write = time.perf_counter() - t0
     extra = ["--chrom", args.name, "-o"] if args.paper else []
@@ -61,6 +71,7 @@ def main():
     for vi, (decoder, env) in enumerate(variants):
         best = None
         for rep in range(args.host_reps if decoder == "host" else 3):   # the file is in the page cache after the write
+            time.sleep(args.pause)
             t0 = time.perf_counter()
             p = subprocess.run([os.path.join(ROOT, "goleft_amd", "goleft-depth"), "depth", "-w", str(args.window),
                                 "-p", str(args.threads)] + extra + ["-r", os.path.join(d, "synth.fa"), "--prefix",
