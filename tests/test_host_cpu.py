@@ -203,6 +203,35 @@ def test_bam_reader_across_many_batches(tmp_path, head_kb, max_reads):
     assert r.returncode == 0 and "same" in r.stdout, (r.stdout[-300:], r.stderr[-1500:])
 
 
+@pytest.mark.parametrize("zlib_only", ["", "1"])
+def test_bam_reader_inflate_back_ends(tmp_path, zlib_only):
+    """The host reader inflates with libdeflate when the system has libdeflate.so.0 and with zlib otherwise (or when
+    GOLEFT_HOST_ZLIB is set): the same stream from both -- deflated members of three levels, stored members, a member whose
+    payload was damaged (CRC fails) reported as an error by both.  (A child process: the choice is made once per process.)"""
+    import subprocess
+    import sys
+    rng = np.random.default_rng(5)
+    contigs = [("a", 300_000), ("b", 40_000)]
+    reads = {0: H.random_reads(rng, 300_000, 20_000, max_len=120), 1: H.long_cigar_reads(rng, 40_000, [66_000, 4], max_step=2)}
+    env = dict(os.environ, GOLEFT_BAM_CHUNK_KB="256")
+    env.pop("GOLEFT_HOST_ZLIB", None)
+    if zlib_only:
+        env["GOLEFT_HOST_ZLIB"] = "1"
+    for level in (0, 1, 6, 9):
+        path = str(tmp_path / ("l%d.bam" % level))
+        bamio.write_bam(path, contigs, reads, unplaced=11, level=level)
+        r = subprocess.run([sys.executable, "-c", BATCHED_READ % ROOT, path, "3", "5000"], capture_output=True, text=True, env=env)
+        assert r.returncode == 0 and "same" in r.stdout, (level, r.stdout[-300:], r.stderr[-1500:])
+    raw = bytearray(open(path, "rb").read())
+    bsize = int.from_bytes(raw[16:18], "little") + 1                 # the header's member, then the first records' member
+    raw[bsize + 18 + 40] ^= 0x10
+    bad = str(tmp_path / "bad.bam")
+    open(bad, "wb").write(bytes(raw))
+    only_host = "import sys; sys.path.insert(0, %r); from goleft_amd import _hostlib as hl; hl.read_bam(sys.argv[1], threads=3)" % ROOT
+    r = subprocess.run([sys.executable, "-c", only_host, bad], capture_output=True, text=True, env=env)
+    assert r.returncode != 0 and "BGZF inflate/CRC failure" in r.stderr, (r.stdout[-300:], r.stderr[-600:])
+
+
 def test_bam_reader_long_cigar_cg_tag(hostlib, tmp_path):
     rng = np.random.default_rng(5)
     n_ops = 70000                       # > 65535: stored through the CG:B,I convention

@@ -213,3 +213,77 @@ def test_damaged_streams_stay_inside_their_buffers(seed):
     r = subprocess.run([sys.executable, "-c", GUARDED_FUZZ % H.ROOT, str(seed)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, (r.returncode, r.stdout[-500:], r.stderr[-2000:])
     assert "ran 192" in r.stdout and int(r.stdout.split("refused")[1]) > 100
+
+
+def _libdeflate():
+    try:
+        ld = C.CDLL("libdeflate.so.0")
+    except OSError:
+        return None
+    ld.libdeflate_alloc_compressor.restype = C.c_void_p
+    ld.libdeflate_alloc_compressor.argtypes = [C.c_int]
+    ld.libdeflate_deflate_compress.restype = C.c_size_t
+    ld.libdeflate_deflate_compress.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]
+    ld.libdeflate_free_compressor.argtypes = [C.c_void_p]
+    return ld
+
+
+@pytest.mark.skipif(_libdeflate() is None, reason="no libdeflate.so.0 on this system")
+def test_streams_libdeflate_writes():
+    """tools/synth_bam.cpp deflates with libdeflate when the system has it (as htslib does when built against it), and
+    real BAM files mostly come from it: its block splitting, its choice between stored / fixed / dynamic blocks and its
+    match statistics are not zlib's.  Streams of every level 1..12 over BAM-like records, text, runs and noise."""
+    ld = _libdeflate()
+    rng = np.random.default_rng(7)
+    rec = bytearray()
+    for i in range(260):                                       # records shaped like the synthetic BAM's
+        rec += (295).to_bytes(4, "little") + bytes(8) + bytes([13, 60]) + rng.integers(0, 255, 6, dtype=np.uint8).tobytes()
+        rec += (150).to_bytes(4, "little") + b"\xff" * 8 + bytes(4) + b"synth.%07d\0" % i + (150 << 4).to_bytes(4, "little")
+        rec += rng.choice(np.frombuffer(bytes([0x11, 0x21, 0x41, 0x81, 0x12, 0x22, 0x42, 0x82]), np.uint8), 75).tobytes()
+        rec += bytes(np.repeat(np.where(rng.integers(0, 8, 19) == 0, rng.integers(2, 37, 19), 37).astype(np.uint8), 8)[:150])
+    rec = bytes(rec)
+    parts, payloads = [], []
+    texts = [rec[:0xff00], rec[:1000], b"", b"A", bytes(5000), rng.integers(0, 256, 3000, dtype=np.uint8).tobytes(),
+             (b"the quick brown fox " * 400)[:7001], rng.integers(0, 4, 20000, dtype=np.uint8).tobytes()]
+    for level in range(1, 13):
+        co = ld.libdeflate_alloc_compressor(level)
+        assert co
+        for x in texts:
+            buf = C.create_string_buffer(len(x) + len(x) // 8 + 256)
+            n = ld.libdeflate_deflate_compress(co, x, len(x), buf, len(buf))
+            assert n > 0
+            c = buf.raw[:n]
+            assert zlib.decompress(c, -15) == x
+            parts.append(x); payloads.append(c)
+        ld.libdeflate_free_compressor(co)
+    got, status = emul_inflate(payloads, [len(x) for x in parts], [zlib.crc32(x) & 0xffffffff for x in parts], guarded=True)
+    for i, x in enumerate(parts):
+        assert status[i] == 0 and got[i] == x, (i, int(status[i]), len(x))
+
+
+def test_members_of_the_synthetic_bam(tmp_path):
+    """The file bench.py's `bam_file_scope` reads (tools/synth_bam.cpp -> goleft_amd/synth-bam), member by member: what the
+    emulated kernel makes of each payload is what zlib makes of it, and the CRC the kernel checks is the trailer's."""
+    import json
+    import struct
+    exe = os.path.join(H.ROOT, "goleft_amd", "synth-bam")
+    if not os.path.exists(exe):
+        pytest.skip("goleft_amd/synth-bam is not built")
+    bam = str(tmp_path / "s.bam")
+    info = json.loads(subprocess.check_output([exe, bam, "chrS", "150000,90000", "30", "20", "3"]).decode())
+    raw = open(bam, "rb").read()
+    assert info["bam_bytes"] == len(raw)
+    parts, payloads, crcs, off = [], [], [], 0
+    while off < len(raw):
+        assert raw[off:off + 4] == b"\x1f\x8b\x08\x04" and raw[off + 12:off + 16] == b"BC\x02\x00"
+        bsize, = struct.unpack_from("<H", raw, off + 16)
+        c = raw[off + 18:off + bsize + 1 - 8]
+        crc, isize = struct.unpack_from("<II", raw, off + bsize + 1 - 8)
+        x = zlib.decompress(c, -15)
+        assert len(x) == isize and zlib.crc32(x) & 0xffffffff == crc
+        parts.append(x); payloads.append(c); crcs.append(crc)
+        off += bsize + 1
+    assert len(parts) > 150 and parts[-1] == b""                # the EOF member too
+    got, status = emul_inflate(payloads, [len(x) for x in parts], crcs, guarded=True)
+    for i, x in enumerate(parts):
+        assert status[i] == 0 and got[i] == x, (i, int(status[i]), len(x), info.get("deflate"))

@@ -8,9 +8,10 @@
 // 1 % one insertion; 5 % DUP, 0.3 % other filtered flags, 1 % MAPQ 0), coordinate sorted, WITH
 // SEQ and QUAL (random bases, run-structured qualities) so that the file has the size and the
 // inflate cost of a real one (~250 B per record before BGZF).  BGZF members are deflated in
-// parallel (zlib level 1).  Also writes a "<contig>\t<length>\t..." line to OUT.fa.fai and
+// parallel (level 1; libdeflate when the system has it, else zlib; SYNTH_BAM_LEVEL changes the level).  Also writes a "<contig>\t<length>\t..." line to OUT.fa.fai and
 // OUT.bam.bai (exact 16 kb linear index; the binning index is collapsed into bin 0, enough
 // for this repository's readers, not for region queries by other tools).
+#include <dlfcn.h>
 #include <fcntl.h>
 #include <unistd.h>
 #include <zlib.h>
@@ -47,26 +48,64 @@ static int reg2bin(int64_t beg, int64_t end)
     return 0;
 }
 
-static void bgzf_member(const uint8_t* data, size_t n, std::vector<uint8_t>* out)
+// libdeflate, when the system has its shared library (what htslib itself compresses BAM files with when built against it,
+// and three times as fast as zlib here: the genome's 170 GB are deflated on the 16 CPUs' worth of time a GPU box gives a
+// container, two thirds of bench.py's run time with zlib); zlib otherwise.  SYNTH_BAM_ZLIB=1 forces zlib.
+struct LibDeflate {
+    void* (*alloc)(int) = nullptr;
+    size_t (*compress)(void*, const void*, size_t, void*, size_t) = nullptr;
+    uint32_t (*crc)(uint32_t, const void*, size_t) = nullptr;
+    LibDeflate()
+    {
+        if (getenv("SYNTH_BAM_ZLIB")) return;
+        void* h = dlopen("libdeflate.so.0", RTLD_NOW);
+        if (!h) return;
+        alloc = reinterpret_cast<void* (*)(int)>(dlsym(h, "libdeflate_alloc_compressor"));
+        compress = reinterpret_cast<size_t (*)(void*, const void*, size_t, void*, size_t)>(dlsym(h, "libdeflate_deflate_compress"));
+        crc = reinterpret_cast<uint32_t (*)(uint32_t, const void*, size_t)>(dlsym(h, "libdeflate_crc32"));
+        if (!alloc || !compress || !crc) alloc = nullptr;
+    }
+    bool ok() const { return alloc != nullptr; }
+};
+static const LibDeflate g_ld;
+static int g_level = 1;
+
+// what one worker keeps from flush to flush (the threads themselves are started per flush): its compressor and its scratch
+struct Worker {
+    void* comp = nullptr;
+    std::vector<uint8_t> c, one;
+};
+
+static void bgzf_member(const uint8_t* data, size_t n, std::vector<uint8_t>* out, Worker* wk)
 {
     out->clear();
-    static thread_local std::vector<uint8_t> c;          // (scratch kept per thread: 3 million members otherwise allocate and zero 74 KB each)
+    std::vector<uint8_t>& c = wk->c;                     // (3 million members otherwise allocate and zero 74 KB each)
     if (c.size() < n + n / 8 + 128) c.resize(n + n / 8 + 128);
-    z_stream zs;
-    memset(&zs, 0, sizeof zs);
-    deflateInit2(&zs, 1, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY);
-    zs.next_in = const_cast<uint8_t*>(data);
-    zs.avail_in = (uInt)n;
-    zs.next_out = c.data();
-    zs.avail_out = (uInt)c.size();
-    deflate(&zs, Z_FINISH);
-    const size_t clen = c.size() - zs.avail_out;
-    deflateEnd(&zs);
+    size_t clen = 0;
+    uint32_t crc = 0;
+    if (g_ld.ok()) {
+        if (!wk->comp) wk->comp = g_ld.alloc(g_level);
+        clen = wk->comp ? g_ld.compress(wk->comp, data, n, c.data(), c.size()) : 0;
+        crc = g_ld.crc(0, data, n);
+    }
+    if (clen == 0) {
+        z_stream zs;
+        memset(&zs, 0, sizeof zs);
+        deflateInit2(&zs, g_level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY);
+        zs.next_in = const_cast<uint8_t*>(data);
+        zs.avail_in = (uInt)n;
+        zs.next_out = c.data();
+        zs.avail_out = (uInt)c.size();
+        deflate(&zs, Z_FINISH);
+        clen = c.size() - zs.avail_out;
+        deflateEnd(&zs);
+        crc = (uint32_t)crc32(crc32(0L, nullptr, 0), data, (uInt)n);
+    }
     static const uint8_t hdr[16] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0};
     out->insert(out->end(), hdr, hdr + 16);
     put16(*out, (uint16_t)(clen + 25));
     out->insert(out->end(), c.begin(), c.begin() + (long)clen);
-    put32(*out, (uint32_t)crc32(crc32(0L, nullptr, 0), data, (uInt)n));
+    put32(*out, crc);
     put32(*out, (uint32_t)n);
 }
 
@@ -82,6 +121,7 @@ int main(int argc, char** argv)
     const uint64_t seed = argc > 5 ? strtoull(argv[5], nullptr, 10) : 1;
     int threads = argc > 6 ? atoi(argv[6]) : (int)std::thread::hardware_concurrency();
     if (threads < 1) threads = 1;
+    if (const char* lv = getenv("SYNTH_BAM_LEVEL")) g_level = std::max(1, std::min(9, atoi(lv)));
     const int RL = 150;
     const int fd = open(path.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
     if (fd < 0) { perror("open"); return 1; }
@@ -140,15 +180,16 @@ int main(int argc, char** argv)
         // kept from flush to flush: fresh gigabytes per batch mean page faults of 256 threads on one address space
         static std::vector<std::vector<uint8_t>> comp;
         static std::vector<std::vector<uint32_t>> sizes;
-        comp.resize(nt); sizes.resize(nt);
+        static std::vector<Worker> workers;
+        comp.resize(nt); sizes.resize(nt); workers.resize(nt);
         for (size_t t = 0; t < nt; ++t) { comp[t].clear(); sizes[t].clear(); }
         std::vector<std::thread> pool;
         for (size_t t = 0; t < nt; ++t)
             pool.emplace_back([&, t]() {
-                std::vector<uint8_t> one;
+                std::vector<uint8_t>& one = workers[t].one;
                 for (size_t b = nblk * t / nt; b < nblk * (t + 1) / nt; ++b) {
                     const size_t off = b * BLK, len = std::min(BLK, raw.size() - off);
-                    bgzf_member(raw.data() + off, len, &one);
+                    bgzf_member(raw.data() + off, len, &one, &workers[t]);
                     comp[t].insert(comp[t].end(), one.begin(), one.end());
                     sizes[t].push_back((uint32_t)one.size());
                 }
@@ -186,64 +227,86 @@ int main(int argc, char** argv)
     };
     const int64_t CH = 1 << 16;                              // reads per chunk (~17 MB)
     auto gen_chunk = [&](size_t ctg, int64_t i0, int64_t i1, int64_t n, int64_t span, Chunk* c) {
-        std::vector<uint8_t>& raw = c->bytes;
-        raw.clear();
-        raw.reserve((size_t)(i1 - i0) * 280);
+        // (written through a pointer into a buffer of the largest possible size: a push_back per byte was most of the tool's
+        // CPU time once the deflate was libdeflate's)
+        std::vector<uint8_t>& buf = c->bytes;
+        const size_t worst = (size_t)(i1 - i0) * 320;
+        if (buf.capacity() < worst) { buf.clear(); buf.reserve(worst); }
+        buf.resize(worst);                                   // (no-op after the first chunk of this size)
+        uint8_t* const w0 = buf.data();
+        uint8_t* w = w0;
+        auto p32 = [&](uint32_t x) { memcpy(w, &x, 4); w += 4; };
+        auto p16 = [&](uint16_t x) { memcpy(w, &x, 2); w += 2; };
         c->lin.clear();
         uint32_t last_w = 0xffffffffu;
-    for (int64_t i = i0; i < i1; ++i) {
-        const uint64_t h = mix((seed + ctg * 7919) * 0x100000001b3ull + (uint64_t)i);
         const int64_t stride = span / n > 0 ? span / n : 1;
-        int64_t pos = (int64_t)(((__int128)i * span) / n) + (int64_t)(h % (uint64_t)stride);
-        if (pos > span) pos = span;
-        const uint32_t kind = (uint32_t)((h >> 20) % 10000);
-        uint32_t cig[3];
-        int nc = 1, ref = RL;
-        if (kind < 9200) { cig[0] = (uint32_t)RL << 4; }
-        else if (kind < 9700) { const uint32_t k = 1 + (uint32_t)((h >> 40) % 30); cig[0] = k << 4 | 4; cig[1] = (RL - k) << 4; nc = 2; ref = RL - (int)k; }
-        else if (kind < 9900) { const uint32_t a = 20 + (uint32_t)((h >> 40) % 100), d = 1 + (uint32_t)((h >> 50) % 10);
-                                cig[0] = a << 4; cig[1] = d << 4 | 2; cig[2] = (RL - a) << 4; nc = 3; ref = RL + (int)d; }
-        else { const uint32_t a = 20 + (uint32_t)((h >> 40) % 100), ins = 1 + (uint32_t)((h >> 50) % 10);
-               cig[0] = a << 4; cig[1] = ins << 4 | 1; cig[2] = (RL - a - ins) << 4; nc = 3; ref = RL - (int)ins; }
-        const uint32_t fr = (uint32_t)((h >> 8) % 1000);
-        uint16_t flag = (h & 1) ? 99 : 147;
-        if (fr < 50) flag |= 0x400; else if (fr < 51) flag |= 0x100; else if (fr < 52) flag |= 0x200; else if (fr < 57) flag |= 0x800;
-        const uint8_t mapq = ((h >> 12) % 100) == 0 ? 0 : 60;
-        char name[32];
-        const int ln = snprintf(name, sizeof name, "synth.%llu", (unsigned long long)i) + 1;
-        const uint32_t block = 32 + (uint32_t)ln + 4u * (uint32_t)nc + (RL + 1) / 2 + RL;
-        {
-            const uint64_t off = raw.size();                 // chunk local
-            c->after_last = off + 4 + block;
-            // windows are met in ascending order (positions ascend): only a window beyond the last one noted is new
-            for (int64_t w = pos >> 14; w <= (pos + ref - 1) >> 14; ++w)
-                if (last_w == 0xffffffffu || (uint32_t)w > last_w) { c->lin.emplace_back((uint32_t)w, off); last_w = (uint32_t)w; }
+        for (int64_t i = i0; i < i1; ++i) {
+            const uint64_t h = mix((seed + ctg * 7919) * 0x100000001b3ull + (uint64_t)i);
+            int64_t pos = (int64_t)(((__int128)i * span) / n) + (int64_t)(h % (uint64_t)stride);
+            if (pos > span) pos = span;
+            const uint32_t kind = (uint32_t)((h >> 20) % 10000);
+            uint32_t cig[3];
+            int nc = 1, ref = RL;
+            if (kind < 9200) { cig[0] = (uint32_t)RL << 4; }
+            else if (kind < 9700) { const uint32_t k = 1 + (uint32_t)((h >> 40) % 30); cig[0] = k << 4 | 4; cig[1] = (RL - k) << 4; nc = 2; ref = RL - (int)k; }
+            else if (kind < 9900) { const uint32_t a = 20 + (uint32_t)((h >> 40) % 100), d = 1 + (uint32_t)((h >> 50) % 10);
+                                    cig[0] = a << 4; cig[1] = d << 4 | 2; cig[2] = (RL - a) << 4; nc = 3; ref = RL + (int)d; }
+            else { const uint32_t a = 20 + (uint32_t)((h >> 40) % 100), ins = 1 + (uint32_t)((h >> 50) % 10);
+                   cig[0] = a << 4; cig[1] = ins << 4 | 1; cig[2] = (RL - a - ins) << 4; nc = 3; ref = RL - (int)ins; }
+            const uint32_t fr = (uint32_t)((h >> 8) % 1000);
+            uint16_t flag = (h & 1) ? 99 : 147;
+            if (fr < 50) flag |= 0x400; else if (fr < 51) flag |= 0x100; else if (fr < 52) flag |= 0x200; else if (fr < 57) flag |= 0x800;
+            const uint8_t mapq = ((h >> 12) % 100) == 0 ? 0 : 60;
+            char name[32] = "synth.";
+            int ln = 6;
+            {
+                char dig[24];
+                int nd = 0;
+                uint64_t v = (uint64_t)i;
+                do { dig[nd++] = (char)('0' + v % 10); v /= 10; } while (v);
+                while (nd) name[ln++] = dig[--nd];
+                name[ln++] = 0;
+            }
+            const uint32_t block = 32 + (uint32_t)ln + 4u * (uint32_t)nc + (RL + 1) / 2 + RL;
+            {
+                const uint64_t off = (uint64_t)(w - w0);         // chunk local
+                c->after_last = off + 4 + block;
+                // windows are met in ascending order (positions ascend): only a window beyond the last one noted is new
+                for (int64_t win = pos >> 14; win <= (pos + ref - 1) >> 14; ++win)
+                    if (last_w == 0xffffffffu || (uint32_t)win > last_w) { c->lin.emplace_back((uint32_t)win, off); last_w = (uint32_t)win; }
+            }
+            p32(block);
+            p32((uint32_t)ctg);                              // refID
+            p32((uint32_t)pos);
+            *w++ = (uint8_t)ln;
+            *w++ = mapq;
+            p16((uint16_t)reg2bin(pos, pos + ref));
+            p16((uint16_t)nc);
+            p16(flag);
+            p32(RL);
+            p32(0xffffffffu);                                // next refID
+            p32(0xffffffffu);                                // next pos
+            p32(0);
+            memcpy(w, name, (size_t)ln); w += ln;
+            for (int k = 0; k < nc; ++k) p32(cig[k]);
+            uint64_t r = h;
+            // two random bases per byte (A C G T = 1 2 4 8): byte k of a group of 16 is made of bits 4k .. 4k + 3 of r
+            static const uint8_t two_bases[16] = {0x11, 0x21, 0x41, 0x81, 0x12, 0x22, 0x42, 0x82, 0x14, 0x24, 0x44, 0x84, 0x18, 0x28, 0x48, 0x88};
+            for (int k = 0; k < (RL + 1) / 2; k += 16) {
+                r = mix(r);
+                const int m = std::min(16, (RL + 1) / 2 - k);
+                for (int j = 0; j < m; ++j) w[j] = two_bases[(r >> (4 * j)) & 15];
+                w += m;
+            }
+            for (int k = 0; k < RL; k += 8) {                // qualities: runs of 8, 37 with occasional dips
+                r = mix(r);
+                const uint64_t q8 = ((r & 7) == 0 ? (uint64_t)(2 + (r >> 8) % 35) : 37) * 0x0101010101010101ull;
+                const int m = std::min(8, RL - k);
+                memcpy(w, &q8, (size_t)m);
+                w += m;
+            }
         }
-        put32(raw, block);
-        put32(raw, (uint32_t)ctg);                       // refID
-        put32(raw, (uint32_t)pos);
-        raw.push_back((uint8_t)ln);
-        raw.push_back(mapq);
-        put16(raw, (uint16_t)reg2bin(pos, pos + ref));
-        put16(raw, (uint16_t)nc);
-        put16(raw, flag);
-        put32(raw, RL);
-        put32(raw, 0xffffffffu);                         // next refID
-        put32(raw, 0xffffffffu);                         // next pos
-        put32(raw, 0);
-        raw.insert(raw.end(), name, name + ln);
-        for (int k = 0; k < nc; ++k) put32(raw, cig[k]);
-        uint64_t r = h;
-        for (int k = 0; k < (RL + 1) / 2; ++k) {         // two random bases per byte (A C G T = 1 2 4 8)
-            if ((k & 15) == 0) r = mix(r);
-            raw.push_back((uint8_t)((1u << ((r >> (4 * (k & 15))) & 3)) << 4 | (1u << ((r >> (4 * (k & 15) + 2)) & 3))));
-        }
-        uint8_t q = 37;
-        for (int k = 0; k < RL; ++k) {                   // qualities: long runs with occasional dips
-            if ((k & 7) == 0) { r = mix(r); q = (r & 7) == 0 ? (uint8_t)(2 + (r >> 8) % 35) : 37; }
-            raw.push_back(q);
-        }
-    }
+        buf.resize((size_t)(w - w0));
     };
 
     std::vector<Chunk> chunks((size_t)threads);
@@ -314,6 +377,7 @@ int main(int argc, char** argv)
         for (size_t k = 0; k < lens.size(); ++k) fprintf(fai, "%s\t%lld\t6\t60\t61\n", names[k].c_str(), (long long)lens[k]);
         fclose(fai);
     }
-    printf("{\"reads\": %lld, \"bam_bytes\": %llu}\n", (long long)n_total, (unsigned long long)(out_bytes + 28));
+    printf("{\"reads\": %lld, \"bam_bytes\": %llu, \"deflate\": \"%s level %d\"}\n", (long long)n_total,
+           (unsigned long long)(out_bytes + 28), g_ld.ok() ? "libdeflate" : "zlib", g_level);
     return 0;
 }
