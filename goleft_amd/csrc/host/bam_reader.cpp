@@ -2,7 +2,11 @@
 #include "bam_reader.hpp"
 
 #include <dlfcn.h>
+#include <fcntl.h>
+#include <unistd.h>
 #include <zlib.h>
+
+#include <cerrno>
 
 #include <algorithm>
 #include <atomic>
@@ -98,7 +102,7 @@ struct Member {
 };
 
 // Parses one BGZF member header at raw[off..]; returns 1 ok, 0 need more bytes, -1 corrupt.
-int parse_member(const std::vector<uint8_t>& raw, size_t off, Member* m)
+int parse_member(const Bytes& raw, size_t off, Member* m)
 {
     if (raw.size() - off < 18) return 0;
     const uint8_t* p = raw.data() + off;
@@ -189,7 +193,7 @@ BamReader::~BamReader()
     if (getenv("GOLEFT_BAM_TIMING"))
         fprintf(stderr, "bam_reader: read %.3f inflate %.3f (producer thread) | wait %.3f append %.3f hop %.3f pass1 %.3f pass2 %.3f s\n",
                 g_tm.read, g_tm.inflate, g_tm.wait, g_tm.append, g_tm.hop, g_tm.pass1, g_tm.pass2);
-    if (fp_) fclose(fp_);
+    if (fd_ >= 0) close(fd_);
 }
 
 // Producer side: reads the next kChunk compressed bytes, inflates every complete BGZF member
@@ -201,7 +205,7 @@ BamReader::~BamReader()
 static size_t kHead = 8u << 20;                        // (GOLEFT_BAM_HEAD_KB, read when a file is opened: tests shrink it)
 static size_t kChunkBytes = 64u << 20;                 // compressed bytes per batch (GOLEFT_BAM_CHUNK_KB)
 
-BamReader::Chunk BamReader::produce(std::vector<uint8_t> spare)
+BamReader::Chunk BamReader::produce(Bytes spare)
 {
     Chunk c;
     c.data = std::move(spare);                           // recycled pages: no fresh page faults per batch
@@ -213,9 +217,44 @@ BamReader::Chunk BamReader::produce(std::vector<uint8_t> spare)
     for (;;) {
         double t0 = Tm::now();
         if (!eof_) {
+            // every worker reads its slice of the batch at its own offset (one thread's read of 64 MB from the page cache
+            // took as long as all threads' inflate of it); a pipe is read in order by this thread
             const size_t old = raw_.size();
             raw_.resize(old + kChunk);
-            const size_t got = fread(raw_.data() + old, 1, kChunk, fp_);
+            uint8_t* const dst = raw_.data() + old;
+            auto read_at = [&](size_t b, size_t e) -> size_t {           // bytes read of [b, e): short only at the end of the file
+                size_t done = b;
+                while (done < e) {
+                    const ssize_t r = seekable_ ? pread(fd_, dst + done, e - done, (off_t)(file_off_ + done)) : read(fd_, dst + done, e - done);
+                    if (r < 0 && errno == EINTR) continue;
+                    if (r <= 0) break;
+                    done += (size_t)r;
+                }
+                return done - b;
+            };
+            size_t got = 0;
+            const size_t slice = 4u << 20;
+            const size_t ns = (kChunk + slice - 1) / slice;
+            if (seekable_ && threads_ > 1 && ns > 1) {
+                std::vector<size_t> part(ns, 0);
+                std::atomic<size_t> next{0};
+                if (!inflate_workers_) inflate_workers_.reset(new Workers(threads_ - 1));
+                inflate_workers_->run(std::min<size_t>((size_t)threads_, ns), [&](size_t) {
+                    for (;;) {
+                        const size_t i = next.fetch_add(1);
+                        if (i >= ns) return;
+                        part[i] = read_at(i * slice, std::min(kChunk, (i + 1) * slice));
+                    }
+                });
+                // the bytes in front of the first short slice are the file's; nothing follows a short read
+                for (size_t i = 0; i < ns; ++i) {
+                    got += part[i];
+                    if (part[i] < std::min(kChunk, (i + 1) * slice) - i * slice) break;
+                }
+            } else {
+                got = read_at(0, kChunk);
+            }
+            file_off_ += got;
             raw_.resize(old + got);
             if (got < kChunk) eof_ = true;
         }
@@ -262,7 +301,7 @@ BamReader::Chunk BamReader::produce(std::vector<uint8_t> spare)
             inflate_workers_->run((size_t)nt, [&](size_t) { work(); });
         }
         if (bad.load()) { c.err = "BGZF inflate/CRC failure in " + path_; c.data.clear(); c.end = true; return c; }
-        raw_.erase(raw_.begin(), raw_.begin() + (ptrdiff_t)off);
+        raw_.erase_front(off);
         g_tm.inflate += Tm::now() - t0;
         return c;
     }
@@ -283,7 +322,7 @@ bool BamReader::fill(std::string* err)
     if (!c.err.empty()) { if (err) *err = c.err; done_ = true; return false; }
     if (c.end) { done_ = true; return false; }
     const size_t rest = buf_.size() - cur_;              // decoded bytes not consumed yet: normally one partial record
-    std::vector<uint8_t> spare;
+    Bytes spare;
     if (rest <= kHead) {
         if (rest) memcpy(c.data.data() + kHead - rest, buf_.data() + cur_, rest);
         spare = std::move(buf_);
@@ -291,11 +330,11 @@ bool BamReader::fill(std::string* err)
         cur_ = kHead - rest;
     } else {                                             // (a record larger than the headroom, or a caller that holds on to a block's bytes)
         if (cur_ > 0) {
-            buf_.erase(buf_.begin(), buf_.begin() + (ptrdiff_t)cur_);
+            buf_.erase_front(cur_);
             cur_ = 0;
         }
         if (buf_.capacity() < buf_.size() + c.data.size()) buf_.reserve(3 * c.data.size() + buf_.size());
-        buf_.insert(buf_.end(), c.data.begin() + (ptrdiff_t)kHead, c.data.end());
+        buf_.append(c.data.data() + kHead, c.data.size() - kHead);
         spare = std::move(c.data);
     }
     g_tm.append += Tm::now() - t0;
@@ -303,7 +342,7 @@ bool BamReader::fill(std::string* err)
     // (small) one, so that opening a file for its header leaves the cores alone
     if (n_fills_++ == 0) { spare_ = std::move(spare); return true; }
     prefetch_ = std::async(std::launch::async,
-                           [this](std::vector<uint8_t> sp) { return produce(std::move(sp)); }, std::move(spare));
+                           [this](Bytes sp) { return produce(std::move(sp)); }, std::move(spare));
     return true;
 }
 
@@ -321,16 +360,42 @@ bool BamReader::need(size_t n, std::string* err)
     return true;
 }
 
+// The CPUs this process may really use: the hardware's, or fewer when a container's CPU quota says so (cgroup v2
+// cpu.max, v1 cfs_quota_us / cfs_period_us).  256 threads under a 16-CPU quota spend each 100 ms period's budget in its
+// first 6 ms and stand still for the rest -- every thread of the process with them, the ones feeding the device included.
+int usable_cpus()
+{
+    const int hw = (int)std::max(1u, std::thread::hardware_concurrency());
+    long long quota = -1, period = 100000;
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char q[32] = {0};
+        if (fscanf(f, "%31s %lld", q, &period) >= 1 && strcmp(q, "max") != 0) quota = atoll(q);
+        fclose(f);
+    } else if (FILE* g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+        if (fscanf(g, "%lld", &quota) != 1) quota = -1;
+        fclose(g);
+        if (FILE* h = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+            if (fscanf(h, "%lld", &period) != 1) period = 100000;
+            fclose(h);
+        }
+    }
+    if (quota <= 0 || period <= 0) return hw;
+    return (int)std::max<long long>(1, std::min<long long>(hw, (quota + period - 1) / period));
+}
+
 bool BamReader::open(const std::string& path, int threads, std::string* err)
 {
     path_ = path;
-    threads_ = threads > 0 ? threads : (int)std::max(1u, std::thread::hardware_concurrency());
+    threads_ = threads > 0 ? threads : usable_cpus();
     inflate_workers_.reset();                            // (started by the first batch that has work for them)
     parse_workers_.reset();
     if (const char* e = getenv("GOLEFT_BAM_CHUNK_KB")) kChunkBytes = (size_t)std::max(64, atoi(e)) << 10;
     if (const char* e = getenv("GOLEFT_BAM_HEAD_KB")) kHead = (size_t)std::max(0, atoi(e)) << 10;
-    fp_ = fopen(path.c_str(), "rb");
-    if (!fp_) { if (err) *err = "cannot open " + path; return false; }
+    if (fd_ >= 0) close(fd_);
+    fd_ = ::open(path.c_str(), O_RDONLY | O_CLOEXEC);
+    if (fd_ < 0) { if (err) *err = "cannot open " + path; return false; }
+    file_off_ = 0;
+    seekable_ = lseek(fd_, 0, SEEK_CUR) != (off_t)-1;
     if (!need(12, err) || memcmp(buf_.data() + cur_, "BAM\1", 4) != 0) {
         if (err && err->empty()) *err = path + " is not a BAM file";
         return false;
@@ -456,8 +521,9 @@ int BamReader::seek_contig_ex(int32_t tid, std::string* err)
     }
     if (best == ~0ull) return 0;                    // a well-formed index without a chunk for this reference: no records
     const uint64_t coff = best >> 16, uoff = best & 0xffff;
-    drop_prefetch();                              // the producer owns fp_/raw_ while a chunk is in flight
-    if (fseeko(fp_, (off_t)coff, SEEK_SET) != 0) { if (err) *err = "seek failed"; return -2; }
+    drop_prefetch();                              // the producer owns the file offset and raw_ while a chunk is in flight
+    if (!seekable_) { if (err) *err = "seek failed"; return -2; }
+    file_off_ = coff;
     raw_.clear();
     buf_.clear();
     cur_ = 0;
@@ -535,9 +601,27 @@ int BamReader::next_block(RecordBlock& out, size_t max_reads, std::string* err)
     out.clear();
     const double t_hop0 = Tm::now();
     const double wait0 = g_tm.wait + g_tm.append;
-    std::vector<size_t> at;                               // offset of every record's body, relative to cur_
+    std::vector<size_t>& at = at_;                        // offset of every record's body, relative to cur_ (kept: no growth after the first block)
+    at.clear();
     size_t p = 0;                                         // bytes hopped over, relative to cur_
     for (;;) {
+        if (!at.empty()) {
+            // the common case, without the calls below: a placed record of the block's reference that lies wholly in the
+            // decoded bytes.  The hop is a chain of dependent loads from lines other cores have just written; the line a
+            // few records ahead is asked for early, guessed from this record's size (records of one file are of a size).
+            const uint8_t* const b = buf_.data() + cur_;
+            const size_t have = buf_.size() - cur_;
+            while (at.size() < max_reads && p + 12 <= have) {
+                const uint32_t bs = rd32(b + p);
+                if (bs < 32 || p + 4 + (size_t)bs > have) break;
+                if ((int32_t)rd32(b + p + 4) != out.tid || (int32_t)rd32(b + p + 8) < 0) break;
+                __builtin_prefetch(b + p + 8 * (size_t)(4 + bs));
+                __builtin_prefetch(b + p + 16 * (size_t)(4 + bs));
+                ++n_records_;
+                at.push_back(p + 4);
+                p += 4 + (size_t)bs;
+            }
+        }
         const size_t have = buf_.size() - cur_;
         if (at.empty() && p) { cur_ += p; p = 0; continue; }           // records skipped so far are consumed
         // a block ends where the decoded bytes end: the record that straddles two batches opens the next block

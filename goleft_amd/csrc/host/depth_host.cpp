@@ -815,7 +815,7 @@ int run(const DArgs& args)
                 }
             }
         };
-        const unsigned nt = (unsigned)std::min<size_t>(std::max(1u, std::min(std::thread::hardware_concurrency(), 32u)), slices.size());
+        const unsigned nt = (unsigned)std::min<size_t>(std::max(1u, std::min((unsigned)gdh::usable_cpus(), 32u)), slices.size());
         std::vector<std::thread> th;
         for (unsigned t = 1; t < nt; ++t) th.emplace_back(work);
         work();
