@@ -84,6 +84,28 @@ def parse():
     return ap.parse_args()
 
 
+def usable_cpus():
+    """The CPUs this process can really keep busy: os.cpu_count(), or fewer under a container's CPU quota (cgroup v2
+    cpu.max / v1 cfs_quota_us).  The GPU boxes show 256 CPUs and grant 16 CPUs' worth of time (cpu.max 1600000 100000)."""
+    n = os.cpu_count() or 1
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:
+            q, per = (fh.read().split() + ["100000"])[:2]
+        if q != "max":
+            n = max(1, min(n, -(-int(q) // int(per))))
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as fh:
+                q = int(fh.read())
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fh:
+                per = int(fh.read())
+            if q > 0 and per > 0:
+                n = max(1, min(n, -(-q // per)))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def cpu_baseline(sample, W, mincov, cores):
     """Time the CPU oracle ("port": oracle/depth_oracle.c) on `sample` =
     [(name, length, Reads)], tiled in W-aligned 10 Mb regions like
@@ -956,7 +978,7 @@ def main():
         # EVERY contig of this rank against the C oracle, bit for bit: per-base vector, window sums / minima and
         # class runs (from the oracle's vector), 10 Mb tiles on all host cores
         from oracle import pyoracle as po
-        cores = os.cpu_count() or 8
+        cores = usable_cpus()
         t1 = time.perf_counter()
         ok, bad = True, []
         for t in mine:
@@ -985,7 +1007,7 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:      # a reported baseline, N = 1 only
         from oracle import pyoracle as po
-        cores = os.cpu_count() or 1
+        cores = usable_cpus()                     # threads actually used: what the container's CPU quota lets run at once
         sample = []
         for t in mine[:args.cpu_sample_contigs]:
             a = [x.cpu().numpy() for x in streams[t]]
@@ -997,7 +1019,7 @@ def main():
             if best is None or v > best[0]:
                 best = (v, b, sec)
         v, b, sec = best
-        out["cpu_baseline"] = {"value": v, "unit": "ref-bases/s", "cores": cores, "kind": "port",
+        out["cpu_baseline"] = {"value": v, "unit": "ref-bases/s", "cores": cores, "host_cpus": os.cpu_count(), "kind": "port",
                                "sample": "%s (%d ref bases) of the same stream, oracle/depth_oracle.c "
                                          "perbase_diff + callback, %d threads over 10 Mb tiles, %.1f s "
                                          "wall (%.0f core-seconds)"
