@@ -507,7 +507,7 @@ int gd_ingest_feed(gd_ctx* ctx, const uint8_t* bytes, size_t n);
 /* gd_ingest_feed with the bytes taken from an open file: n bytes from `offset` of `fd` are read (pread on the
  * context's worker threads, GD_OPT_PUSH_THREADS of them) straight into the page-locked staging buffers -- none
  * of the page faults of a mapping, no second copy.  The read runs on a thread of the context and the call returns
- * at once (fd must stay open): gd_ingest_decode / _release of the OLDER of two pending ranges and gd_ingest_begin of
+ * at once (fd must stay open): gd_ingest_decode / _release of the OLDEST pending range and gd_ingest_begin of
  * the next one proceed meanwhile; every other gd_ingest_* call waits for the read first and reports its error
  * (GD_E_INVALID: the file ended early or could not be read). */
 int gd_ingest_feed_fd(gd_ctx* ctx, int fd, uint64_t offset, size_t n);
