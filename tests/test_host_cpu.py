@@ -232,6 +232,42 @@ def test_bam_reader_inflate_back_ends(tmp_path, zlib_only):
     assert r.returncode != 0 and "BGZF inflate/CRC failure" in r.stderr, (r.stdout[-300:], r.stderr[-600:])
 
 
+SEEK_READ = r"""
+import sys
+import numpy as np
+sys.path.insert(0, %r)
+from goleft_amd import _hostlib as hl
+from oracle import bamio
+path, tid = sys.argv[1], int(sys.argv[2])
+want = bamio.read_bam(path)[2]
+_, got, n = hl.read_bam(path, threads=3, max_reads=900, seek_tid=tid)
+assert sorted(got) == [t for t in sorted(want) if t >= tid], (sorted(got), tid)
+for t in got:
+    for a, b in zip(got[t], (want[t].pos, want[t].flag, want[t].mapq, want[t].cigar_off, want[t].cigar)):
+        assert np.array_equal(a, b), t
+print("same", n)
+"""
+
+
+@pytest.mark.parametrize("tid", [0, 1, 2])
+def test_bam_reader_seek_lands_mid_file(tmp_path, tid):
+    """`seek_contig` through the .bai into a file of dozens of batches (64 KB each here): the stream goes on from the first
+    record of the reference asked for -- the file offset the parallel `pread`s start from, the member's inner offset, the
+    run rule starting over -- and delivers every later reference too."""
+    import subprocess
+    import sys
+    rng = np.random.default_rng(21)
+    contigs = [("a", 900_000), ("b", 600_000), ("c", 300_000)]
+    reads = {0: H.random_reads(rng, 900_000, 14_000, max_len=120), 1: H.random_reads(rng, 600_000, 9_000, max_len=100),
+             2: H.random_reads(rng, 300_000, 5_000, max_len=90)}
+    path = str(tmp_path / "seek.bam")
+    bamio.write_bam(path, contigs, reads, unplaced=5, index=True, level=1)
+    assert os.path.getsize(path) > 6 * 65536
+    env = dict(os.environ, GOLEFT_BAM_CHUNK_KB="64", GOLEFT_BAM_HEAD_KB="8")
+    r = subprocess.run([sys.executable, "-c", SEEK_READ % ROOT, path, str(tid)], capture_output=True, text=True, env=env)
+    assert r.returncode == 0 and "same" in r.stdout, (r.stdout[-300:], r.stderr[-1500:])
+
+
 def test_bam_reader_long_cigar_cg_tag(hostlib, tmp_path):
     rng = np.random.default_rng(5)
     n_ops = 70000                       # > 65535: stored through the CG:B,I convention
