@@ -1051,7 +1051,7 @@ def main():
             # decoders' BED files are compared byte for byte
             # (the pause: 1 s is enough after a run over a 13 GB file, profiles/r11i_pause_test.jsonl; the genome's run
             # releases four times the device memory)
-            res = bam_file_scope(which, W, device_reps=3, host_decoder=which != "genome", pause_s=4.0 if which == "genome" else 2.0)
+            res = bam_file_scope(which, W, device_reps=3, host_decoder=which != "genome", pause_s=8.0 if which == "genome" else 2.0)
             if "error" in res and which == "genome" and args.bam_scope == "auto":
                 res = dict(bam_file_scope("chr1-2", W), fell_back_from=res["error"])
             if which == "genome" and "error" not in res:
