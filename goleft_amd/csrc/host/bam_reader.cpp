@@ -391,6 +391,7 @@ bool BamReader::open(const std::string& path, int threads, std::string* err)
     parse_workers_.reset();
     if (const char* e = getenv("GOLEFT_BAM_CHUNK_KB")) kChunkBytes = (size_t)std::max(64, atoi(e)) << 10;
     if (const char* e = getenv("GOLEFT_BAM_HEAD_KB")) kHead = (size_t)std::max(0, atoi(e)) << 10;
+    drop_prefetch();                                     // (a reader that is opened again: nobody still reads the old file)
     if (fd_ >= 0) close(fd_);
     fd_ = ::open(path.c_str(), O_RDONLY | O_CLOEXEC);
     if (fd_ < 0) { if (err) *err = "cannot open " + path; return false; }
