@@ -268,6 +268,36 @@ def test_bam_reader_seek_lands_mid_file(tmp_path, tid):
     assert r.returncode == 0 and "same" in r.stdout, (r.stdout[-300:], r.stderr[-1500:])
 
 
+def test_bam_reader_seek_without_an_index_leaves_the_stream_alone(hostlib, tmp_path):
+    """No .bai next to the file, or a reference without records in it: `gdh_bam_seek_contig` says 0 and the stream goes on
+    from where it was (the CLI then reads the file from its start)."""
+    import ctypes as C
+    rng = np.random.default_rng(3)
+    contigs = [("a", 50_000), ("empty", 10_000), ("c", 20_000)]
+    reads = {0: H.random_reads(rng, 50_000, 800, max_len=90), 2: H.random_reads(rng, 20_000, 300, max_len=90)}
+    path = str(tmp_path / "noidx.bam")
+    bamio.write_bam(path, contigs, reads, unplaced=2)
+    lib = hostlib.load()
+    h = C.c_void_p()
+    assert lib.gdh_bam_open(path.encode(), 2, C.byref(h)) == 0
+    try:
+        assert lib.gdh_bam_seek_contig(h, 2) == 0                     # no index
+    finally:
+        lib.gdh_bam_close(h)
+    _, got, n = hostlib.read_bam(path, threads=2, seek_tid=2)          # ... and everything is still delivered
+    assert sorted(got) == [0, 2] and n == 800 + 300 + 2
+    bamio.write_bam(path, contigs, reads, unplaced=2, index=True)
+    h = C.c_void_p()
+    assert lib.gdh_bam_open(path.encode(), 2, C.byref(h)) == 0
+    try:
+        assert lib.gdh_bam_seek_contig(h, 1) == 0                     # indexed, no records of "empty"
+        assert lib.gdh_bam_seek_contig(h, 2) == 1
+    finally:
+        lib.gdh_bam_close(h)
+    _, got, _ = hostlib.read_bam(path, threads=2, seek_tid=2)
+    assert sorted(got) == [2] and np.array_equal(got[2][0], reads[2].pos)
+
+
 def test_bam_reader_long_cigar_cg_tag(hostlib, tmp_path):
     rng = np.random.default_rng(5)
     n_ops = 70000                       # > 65535: stored through the CG:B,I convention
