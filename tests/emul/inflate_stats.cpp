@@ -6,6 +6,7 @@
 // chunk sources come from memory and from the ring.
 //   clang++ -O2 -std=c++17 -shared -fPIC -o inflate_stats.so inflate_stats.cpp
 #include <cstdint>
+#include <cstring>
 struct InfStats {
     uint64_t iters;            // loop iterations of the wave
     uint64_t lane_mode[4];     // lane-iterations by mode at the top of the iteration: DECODE, COPY, HDR, DONE
@@ -13,6 +14,10 @@ struct InfStats {
     uint64_t hdr_lanes;        // lanes served by those runs
     uint64_t chunk_mem, chunk_ring, win_refill;    // lane-iterations with a chunk loaded from memory / read from the ring / an input slot loaded
     uint64_t mem_iters;        // iterations in which at least one lane loaded a chunk from memory
+    // what a per-lane cache of the last aligned block(s) a chunk source was loaded from would catch: chunk loads from memory
+    // whose 16 bytes lie inside a block the lane loaded from before -- [block size 64 / 128 / 256][1, 2 or 4 blocks kept]
+    uint64_t src_hit[3][3];
+    uint64_t mem_iters_after[3][3];   // iterations that would still have a lane loading from memory
 };
 static InfStats g_st;
 static uint64_t g_hdr_calls = 0;
@@ -20,13 +25,33 @@ static bool g_mem_seen = false;
 static unsigned probe_lane();
 // (the fibers of a wave run in lane order between two barriers, and every lane stays in the loop until the wave leaves it:
 // lane 0's probe at the top of an iteration closes the iteration before)
+static uint32_t g_blk[64][3][3][4];                        // [lane][size][ways]: block numbers kept, most recent first
+static bool g_miss_seen[3][3];
 static inline void inf_probe(int what, uint32_t v)
 {
+    if (what == 4) {
+        if (v == 0xffffffffu) return;
+        const unsigned lane = probe_lane();
+        for (int z = 0; z < 3; ++z)
+            for (int w = 0; w < 3; ++w) {
+                const uint32_t bs = 64u << z, ways = 1u << w;
+                const uint32_t b0 = v / bs, b1 = (v + 15u) / bs;          // the chunk's 16 bytes touch one or two blocks
+                uint32_t* keep = g_blk[lane][z][w];
+                auto has = [&](uint32_t b) { for (uint32_t k = 0; k < ways; ++k) if (keep[k] == b) return true; return false; };
+                auto put = [&](uint32_t b) { if (has(b)) return; for (uint32_t k = ways - 1; k > 0; --k) keep[k] = keep[k - 1]; keep[0] = b; };
+                if (has(b0) && has(b1)) g_st.src_hit[z][w]++;
+                else g_miss_seen[z][w] = true;
+                put(b0); put(b1);
+            }
+        return;
+    }
     if (what == 0) {
         if (probe_lane() == 0) {
             g_st.iters++;
             if (g_mem_seen) g_st.mem_iters++;
             g_mem_seen = false;
+            for (int z = 0; z < 3; ++z)
+                for (int w = 0; w < 3; ++w) { if (g_miss_seen[z][w]) g_st.mem_iters_after[z][w]++; g_miss_seen[z][w] = false; }
         }
         g_st.lane_mode[v & 3u]++;
     } else if (what == 1) {
@@ -58,6 +83,8 @@ extern "C" int emul_inflate_stats(const uint8_t* comp, const uint64_t* in_off, c
     g_st = InfStats{};
     g_hdr_calls = 0;
     g_mem_seen = false;
+    memset(g_blk, 0xff, sizeof g_blk);
+    memset(g_miss_seen, 0, sizeof g_miss_seen);
     emul::run(body_inflate, gd::INF_LANES, block);
     if (g_mem_seen) g_st.mem_iters++;
     g_st.hdr_runs = g_hdr_calls / gd::INF_LANES;

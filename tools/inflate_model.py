@@ -20,7 +20,8 @@ CLANG = "/opt/rocm/lib/llvm/bin/clang++"
 
 class Stats(C.Structure):
     _fields_ = [("iters", C.c_uint64), ("lane_mode", C.c_uint64 * 4), ("hdr_runs", C.c_uint64), ("hdr_lanes", C.c_uint64),
-                ("chunk_mem", C.c_uint64), ("chunk_ring", C.c_uint64), ("win_refill", C.c_uint64), ("mem_iters", C.c_uint64)]
+                ("chunk_mem", C.c_uint64), ("chunk_ring", C.c_uint64), ("win_refill", C.c_uint64), ("mem_iters", C.c_uint64),
+                ("src_hit", (C.c_uint64 * 3) * 3), ("mem_iters_after", (C.c_uint64 * 3) * 3)]
 
 
 def lib():
@@ -83,6 +84,10 @@ def main():
             if f == "lane_mode":
                 for k in range(4):
                     tot.lane_mode[k] += st.lane_mode[k]
+            elif f in ("src_hit", "mem_iters_after"):
+                for z in range(3):
+                    for w in range(3):
+                        getattr(tot, f)[z][w] += getattr(st, f)[z][w]
             else:
                 setattr(tot, f, getattr(tot, f) + getattr(st, f))
     assert (status[:n] == 0).all(), status[:n][status[:n] != 0][:8]
@@ -99,6 +104,11 @@ def main():
         "chunks_from_memory_per_member": tot.chunk_mem / n, "chunks_from_the_ring_per_member": tot.chunk_ring / n,
         "input_slots_loaded_per_member": tot.win_refill / n,
         "iterations_with_a_chunk_load_from_memory": tot.mem_iters / tot.iters,
+        # a per-lane cache of the aligned block(s) the last chunk sources were loaded from: the share of the loads from memory
+        # it would serve, and the share of iterations in which some lane would still load
+        "source_block_cache": {"%d B x %d" % (64 << z, 1 << w): {"loads_served": tot.src_hit[z][w] / max(1, tot.chunk_mem),
+                                                                  "iterations_still_loading": tot.mem_iters_after[z][w] / tot.iters}
+                               for z in range(3) for w in range(3)},
     }
     print(json.dumps(res, indent=None if a.json else 1))
 
