@@ -430,6 +430,7 @@ __global__ __launch_bounds__(INF_LANES) void gd_inflate_kernel(InflateJob job)
         const bool from_mem = cload && sa + 16u <= fl;     // completely stored -- else completely inside the ring
         GD_INFLATE_PROBE(2, from_mem ? 1u : (cload ? 2u : 0u));
         GD_INFLATE_PROBE(4, from_mem ? sa : 0xffffffffu);
+        GD_INFLATE_PROBE(5, from_mem ? deff : 0u);
         if (from_mem) cl = inf_load16_stream(ld_addr);
         inf_v4 cr = {0, 0, 0, 0};
         if (cload && !from_mem) {

@@ -18,6 +18,7 @@ struct InfStats {
     // whose 16 bytes lie inside a block the lane loaded from before -- [block size 64 / 128 / 256][1, 2 or 4 blocks kept]
     uint64_t src_hit[3][3];
     uint64_t mem_iters_after[3][3];   // iterations that would still have a lane loading from memory
+    uint64_t dist_le[8];              // chunk loads from memory whose source lies at most 128, 256, 512, 1 K, 2 K, 4 K, 8 K, 32 K bytes back
 };
 static InfStats g_st;
 static uint64_t g_hdr_calls = 0;
@@ -29,6 +30,12 @@ static uint32_t g_blk[64][3][3][4];                        // [lane][size][ways]
 static bool g_miss_seen[3][3];
 static inline void inf_probe(int what, uint32_t v)
 {
+    if (what == 5) {
+        if (v == 0) return;
+        static const uint32_t lim[8] = {128, 256, 512, 1024, 2048, 4096, 8192, 32768};
+        for (int k = 0; k < 8; ++k) if (v <= lim[k]) g_st.dist_le[k]++;
+        return;
+    }
     if (what == 4) {
         if (v == 0xffffffffu) return;
         const unsigned lane = probe_lane();

@@ -21,7 +21,7 @@ CLANG = "/opt/rocm/lib/llvm/bin/clang++"
 class Stats(C.Structure):
     _fields_ = [("iters", C.c_uint64), ("lane_mode", C.c_uint64 * 4), ("hdr_runs", C.c_uint64), ("hdr_lanes", C.c_uint64),
                 ("chunk_mem", C.c_uint64), ("chunk_ring", C.c_uint64), ("win_refill", C.c_uint64), ("mem_iters", C.c_uint64),
-                ("src_hit", (C.c_uint64 * 3) * 3), ("mem_iters_after", (C.c_uint64 * 3) * 3)]
+                ("src_hit", (C.c_uint64 * 3) * 3), ("mem_iters_after", (C.c_uint64 * 3) * 3), ("dist_le", C.c_uint64 * 8)]
 
 
 def lib():
@@ -84,6 +84,9 @@ def main():
             if f == "lane_mode":
                 for k in range(4):
                     tot.lane_mode[k] += st.lane_mode[k]
+            elif f == "dist_le":
+                for k in range(8):
+                    tot.dist_le[k] += st.dist_le[k]
             elif f in ("src_hit", "mem_iters_after"):
                 for z in range(3):
                     for w in range(3):
@@ -104,6 +107,9 @@ def main():
         "chunks_from_memory_per_member": tot.chunk_mem / n, "chunks_from_the_ring_per_member": tot.chunk_ring / n,
         "input_slots_loaded_per_member": tot.win_refill / n,
         "iterations_with_a_chunk_load_from_memory": tot.mem_iters / tot.iters,
+        # how far back the sources of the chunk loads from memory lie (cumulative shares)
+        "chunk_loads_from_memory_with_distance_at_most": {str(l): tot.dist_le[k] / max(1, tot.chunk_mem)
+                                                          for k, l in enumerate((128, 256, 512, 1024, 2048, 4096, 8192, 32768))},
         # a per-lane cache of the aligned block(s) the last chunk sources were loaded from: the share of the loads from memory
         # it would serve, and the share of iterations in which some lane would still load
         "source_block_cache": {"%d B x %d" % (64 << z, 1 << w): {"loads_served": tot.src_hit[z][w] / max(1, tot.chunk_mem),
