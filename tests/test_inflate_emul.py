@@ -287,3 +287,21 @@ def test_members_of_the_synthetic_bam(tmp_path):
     got, status = emul_inflate(payloads, [len(x) for x in parts], crcs, guarded=True)
     for i, x in enumerate(parts):
         assert status[i] == 0 and got[i] == x, (i, int(status[i]), len(x), info.get("deflate"))
+
+
+def test_literal_pairs_at_every_length_and_alignment():
+    """The loop emits two literals per iteration when the symbol behind a literal is a literal too.  Streams of nothing but
+    literals (Z_HUFFMAN_ONLY) of every length 0..200 -- a pair that would end one byte past the member must not be taken,
+    the pending bytes reach fifteen and sixteen in every phase against the 64-byte blocks (the members lie back to back:
+    every start alignment occurs) -- and literals between short matches (a pair is not taken on top of a chunk)."""
+    rng = np.random.default_rng(11)
+    parts, how = [], []
+    for n in range(0, 201):
+        parts.append(rng.integers(0, 256, n, dtype=np.uint8).tobytes()); how.append((1, zlib.Z_HUFFMAN_ONLY))
+    for n in (4095, 4096, 4097, 65280):
+        parts.append(rng.integers(0, 7, n, dtype=np.uint8).tobytes()); how.append((6, zlib.Z_HUFFMAN_ONLY))
+    for k in range(1, 40):                                    # k literals, a match of 3..20 bytes, k literals, ...
+        unit = rng.integers(0, 256, 20, dtype=np.uint8).tobytes()
+        x = b"".join(rng.integers(0, 256, k, dtype=np.uint8).tobytes() + unit[:3 + (i % 18)] for i in range(60))
+        parts.append(unit + x); how.append((6, zlib.Z_DEFAULT_STRATEGY))
+    check(parts, how)
