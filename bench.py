@@ -284,7 +284,7 @@ def bam_file_scope(which, W, device_reps=3, host_decoder=True, pause_s=0.0):
                        "and read once before; %.1f s between runs" % (W, pause_s),
                "file": which, "contigs": len(lengths), "ref_bases": ref_bases, "reads": info["reads"],
                "bam_bytes": info["bam_bytes"], "deflate": info.get("deflate", "zlib level 1"), "synth_bam_s": t_write, "read_once_s": t_settle, "pause_before_each_run_s": pause_s,
-               "written_to": tmp, "host_cores": os.cpu_count(), "unit": "ref-bases/s"}
+               "written_to": tmp, "host_cores": os.cpu_count(), "usable_cpus": usable_cpus(), "unit": "ref-bases/s"}
         beds = {}
         runs = [("device", {}, device_reps)] + ([("host", {"GOLEFT_GPU_DECODE": "0"}, 1)] if host_decoder else [])
         for decoder, env, reps in runs:
