@@ -639,13 +639,116 @@ __global__ __launch_bounds__(256) void gd_inflate_crc_kernel(InflateJob job)
     if ((c ^ 0xffffffffu) != job.crc[m]) job.status[m] = 18;
 }
 
+// The same check with ONE WAVE PER MEMBER (end of round 4).  With a lane per member every lane streams through its own
+// 64 KB: the lines a workgroup's 256 lanes are in the middle of (32 KB, 256 KB per CU at eight workgroups) do not stay in L1,
+// and with ~100 000 members in flight not in L2 either -- each 8-byte step fetches a line again; the kernel took a third
+// of the inflate kernel's own time (12 ms per 27 000 members next to 33 ms, profiles/r10..: `gd_inflate_crc_kernel`).  Here
+// the 64 lanes of a wave share one member: lane l takes the 1 KB that ends (63 - l) KB before the member's end (a CRC
+// register that starts at zero ignores leading zero bytes, so the slices are aligned to the END and the first one is
+// simply shorter; the lane that holds byte 0 starts from 0xffffffff instead), eight lines per lane over its 128 steps, all
+// of a wave's lines inside one 64 KB region.  CRC is linear over GF(2): the member's register is the XOR of every lane's
+// register advanced over the zero bytes that follow its slice -- (63 - l) KB, a fixed operator per lane: the product of
+// the 32 x 32 bit matrices Z^(1 KB * 2^j) for the set bits j of 63 - l, built once per workgroup by squaring the
+// one-zero-byte matrix fifteen times.  Workgroups of four waves walk the members in a grid-stride loop.
+__global__ __launch_bounds__(256) void gd_inflate_crc_wave_kernel(InflateJob job)
+{
+    __shared__ uint32_t s_crc[8][256];                     // as above
+    __shared__ uint32_t s_z[2][32];                        // squaring scratch: Z^(2^k) bytes, column b = image of bit b
+    __shared__ uint32_t s_zk[6][32];                       // Z^(1024 * 2^j), j = 0 .. 5
+    __shared__ uint32_t s_red[4][64];
+    {
+        uint32_t c = threadIdx.x;
+        for (int k = 0; k < 8; ++k) c = (c >> 1) ^ (0xedb88320u & (0u - (c & 1u)));
+        s_crc[0][threadIdx.x] = c;
+    }
+    __syncthreads();
+    {
+        uint32_t c = s_crc[0][threadIdx.x];
+        for (int k = 1; k < 8; ++k) {
+            c = (c >> 8) ^ s_crc[0][c & 0xffu];
+            s_crc[k][threadIdx.x] = c;
+        }
+        // one zero byte: c -> (c >> 8) ^ table[c & 0xff]
+        if (threadIdx.x < 32) {
+            const uint32_t v = 1u << threadIdx.x;
+            s_z[0][threadIdx.x] = (v >> 8) ^ s_crc[0][v & 0xffu];
+        }
+    }
+    __syncthreads();
+    for (int k = 0; k < 15; ++k) {                         // s_z[k & 1] = Z^(2^k) -> s_z[(k + 1) & 1] = its square
+        if (threadIdx.x < 32) {
+            const uint32_t* const M = s_z[k & 1];
+            const uint32_t v = M[threadIdx.x];
+            uint32_t y = 0;
+            for (int b = 0; b < 32; ++b) y ^= M[b] & (0u - ((v >> b) & 1u));
+            s_z[(k + 1) & 1][threadIdx.x] = y;
+            if (k + 1 >= 10) s_zk[k + 1 - 10][threadIdx.x] = y;
+        }
+        __syncthreads();
+    }
+    const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    for (uint32_t base = blockIdx.x * 4u; base < job.n; base += gridDim.x * 4u) {
+        const uint32_t m = base + w;
+        const bool live = m < job.n && job.status[m] == 0;
+        uint32_t c = 0;
+        if (live) {
+            const uint8_t* const out = job.out + job.out_off[m];
+            const int64_t olen = (int64_t)job.out_len[m];
+            // this lane's slice: [olen - (64 - lane) KB, olen - (63 - lane) KB), clipped at the member's start
+            const int64_t e = olen - (int64_t)(63u - lane) * 1024, b0 = e - 1024;
+            if (e > 0 || (olen == 0 && lane == 63u)) {       // (an empty member: the last lane carries the initial value alone)
+                int64_t k = b0 > 0 ? b0 : 0;
+                c = b0 <= 0 ? 0xffffffffu : 0u;            // the slice that holds byte 0 carries the CRC's initial value
+                for (; k + 8 <= e; k += 8) {
+                    uint32_t w0, w1;
+                    __builtin_memcpy(&w0, out + k, 4);
+                    __builtin_memcpy(&w1, out + k + 4, 4);
+                    w0 ^= c;
+                    c = s_crc[7][w0 & 0xffu] ^ s_crc[6][(w0 >> 8) & 0xffu] ^ s_crc[5][(w0 >> 16) & 0xffu] ^ s_crc[4][w0 >> 24] ^
+                        s_crc[3][w1 & 0xffu] ^ s_crc[2][(w1 >> 8) & 0xffu] ^ s_crc[1][(w1 >> 16) & 0xffu] ^ s_crc[0][w1 >> 24];
+                }
+                for (; k < e; ++k) c = s_crc[0][(c ^ out[k]) & 0xffu] ^ (c >> 8);
+                // ... advanced over the (63 - lane) KB that follow
+                const uint32_t after = 63u - lane;
+                for (int j = 0; j < 6; ++j)
+                    if ((after >> j) & 1u) {
+                        uint32_t y = 0;
+                        for (int b = 0; b < 32; ++b) y ^= s_zk[j][b] & (0u - ((c >> b) & 1u));
+                        c = y;
+                    }
+            }
+        }
+        s_red[w][lane] = c;
+        __syncthreads();
+        if (lane < 8u) {
+            uint32_t x = 0;
+            for (int q = 0; q < 8; ++q) x ^= s_red[w][lane * 8u + q];
+            s_red[w][lane * 8u] = x;                       // (only this lane reads or writes elements lane*8 .. lane*8+7 here)
+        }
+        __syncthreads();
+        if (lane == 0u && live) {
+            uint32_t x = 0;
+            for (int q = 0; q < 8; ++q) x ^= s_red[w][q * 8];
+            if ((x ^ 0xffffffffu) != job.crc[m]) job.status[m] = 18;
+        }
+        __syncthreads();                                    // s_red is written again in the next round
+    }
+}
+
+constexpr bool INF_CRC_WAVE = true;                        // which of the two CRC kernels inflate_launch uses
+
 // Both kernels on one stream.
 // lds_pad: bytes of LDS a workgroup claims on top of its own 38 KB -- an occupancy limiter for measurements (four
 // workgroups per CU as built; + 16 KB: three; + 42 KB: two), GD_OPT_INFLATE_LDS_PAD.
 inline void inflate_launch(const InflateJob& job, hipStream_t stream, unsigned lds_pad = 0)
 {
     hipLaunchKernelGGL(gd_inflate_kernel, dim3((job.n + INF_LANES - 1) / INF_LANES), dim3(INF_LANES), lds_pad, stream, job);
-    if (job.crc) hipLaunchKernelGGL(gd_inflate_crc_kernel, dim3((job.n + 255u) / 256u), dim3(256), 0, stream, job);
+    if (job.crc && INF_CRC_WAVE) {
+        const unsigned groups = (job.n + 3u) / 4u;
+        hipLaunchKernelGGL(gd_inflate_crc_wave_kernel, dim3(groups < 8192u ? groups : 8192u), dim3(256), 0, stream, job);
+    } else if (job.crc) {
+        hipLaunchKernelGGL(gd_inflate_crc_kernel, dim3((job.n + 255u) / 256u), dim3(256), 0, stream, job);
+    }
 }
 
 }  // namespace gd

@@ -14,6 +14,7 @@
 
 struct Dim3 { unsigned x = 1, y = 1, z = 1; };
 static Dim3 threadIdx, blockIdx;                           // of the running fiber (set at every switch)
+static Dim3 gridDim;                                       // set by whoever launches a kernel that asks for it
 namespace emul {
 struct Lane { ucontext_t ctx; std::vector<char> stack; bool done = false; unsigned gen = 0, ballots = 0; };
 static std::vector<Lane> lanes;

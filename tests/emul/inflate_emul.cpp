@@ -13,6 +13,7 @@
 static const gd::InflateJob* g_job = nullptr;
 static void body_inflate() { gd::gd_inflate_kernel(*g_job); }
 static void body_crc() { gd::gd_inflate_crc_kernel(*g_job); }
+static void body_crc_wave() { gd::gd_inflate_crc_wave_kernel(*g_job); }
 
 // The same with every buffer ending exactly INF_SLACK bytes (what the device buffers are allocated beyond their contents)
 // before an inaccessible page: a read or write past what the kernel may touch ends the process.
@@ -42,7 +43,17 @@ extern "C" int emul_inflate(const uint8_t* comp, const uint64_t* in_off, const u
     job.crc = crc; job.out = out; job.status = status; job.n = n;
     g_job = &job;
     for (unsigned b = 0; b < (n + gd::INF_LANES - 1) / gd::INF_LANES; ++b) emul::run(body_inflate, gd::INF_LANES, b);
-    if (crc)
+    if (crc) {
+        // both CRC kernels: the wave-per-member one on a copy of the status words (a small grid: the grid-stride loop runs),
+        // then the lane-per-member one -- and they must agree on every member
+        std::vector<uint32_t> before(status, status + n);
+        gridDim.x = n > 40 ? 3 : 1;
+        for (unsigned b = 0; b < gridDim.x; ++b) emul::run(body_crc_wave, 256u, b);
+        std::vector<uint32_t> wave(status, status + n);
+        memcpy(status, before.data(), n * sizeof(uint32_t));
         for (unsigned b = 0; b < (n + 255u) / 256u; ++b) emul::run(body_crc, 256u, b);
+        for (uint32_t i = 0; i < n; ++i)
+            if (wave[i] != status[i]) return -3;
+    }
     return 0;
 }

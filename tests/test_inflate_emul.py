@@ -64,10 +64,11 @@ def emul_inflate(payloads, sizes, crcs=None, guarded=False):
         rc = lib.emul_inflate_guarded(comp.ctypes.data, p, in_off.ctypes.data, in_len.ctypes.data, out_off.ctypes.data,
                                       out_len.ctypes.data, None if crc is None else crc.ctypes.data, out.ctypes.data, q,
                                       status.ctypes.data, n)
-        assert rc == 0, "the kernel wrote past the last member"
+        assert rc == 0, "the kernel wrote past the last member (-2), or the two CRC kernels disagree (-3): %d" % rc
     else:
-        lib.emul_inflate(comp.ctypes.data, in_off.ctypes.data, in_len.ctypes.data, out_off.ctypes.data, out_len.ctypes.data,
+        rc = lib.emul_inflate(comp.ctypes.data, in_off.ctypes.data, in_len.ctypes.data, out_off.ctypes.data, out_len.ctypes.data,
                          None if crc is None else crc.ctypes.data, out.ctypes.data, status.ctypes.data, n)
+        assert rc == 0, "the two CRC kernels disagree"
     assert (out[q:] == 0xee).all(), "the kernel wrote past the last member"
     return [out[int(out_off[i]):int(out_off[i]) + int(out_len[i])].tobytes() for i in range(n)], status
 
@@ -305,3 +306,20 @@ def test_literal_pairs_at_every_length_and_alignment():
         x = b"".join(rng.integers(0, 256, k, dtype=np.uint8).tobytes() + unit[:3 + (i % 18)] for i in range(60))
         parts.append(unit + x); how.append((6, zlib.Z_DEFAULT_STRATEGY))
     check(parts, how)
+
+
+def test_crc_kernels_at_slice_boundaries():
+    """The wave-per-member CRC kernel cuts a member into 1 KB slices aligned to its END: lengths around every kind of
+    boundary (one slice, a first slice of 1 / 1023 / 1024 bytes, BGZF's 65 280 and the format's 65 536), a wrong trailer
+    in each (both kernels must say 18; emul_inflate fails when they disagree)."""
+    rng = np.random.default_rng(5)
+    parts, how = [], []
+    for n in (1, 7, 8, 9, 1023, 1024, 1025, 2047, 2048, 2049, 3071, 4096, 32767, 32768, 65279, 65280, 65281, 65535, 65536):
+        parts.append(rng.integers(0, 256, n, dtype=np.uint8).tobytes()); how.append((0 if n > 40000 else 1, zlib.Z_DEFAULT_STRATEGY))
+    check(parts, how)
+    payloads = [deflate(x, lv, st) for x, (lv, st) in zip(parts, how)]
+    for flip in (0, 1):
+        crcs = [(zlib.crc32(x) ^ (1 << (i % 32) if (i + flip) % 2 else 0)) & 0xffffffff for i, x in enumerate(parts)]
+        got, status = emul_inflate(payloads, [len(x) for x in parts], crcs)
+        for i, x in enumerate(parts):
+            assert int(status[i]) == (18 if (i + flip) % 2 else 0) and got[i] == x, (i, len(x), int(status[i]))
