@@ -695,7 +695,9 @@ __global__ __launch_bounds__(256) void gd_inflate_crc_wave_kernel(InflateJob job
             const uint8_t* const out = job.out + job.out_off[m];
             const int64_t olen = (int64_t)job.out_len[m];
             // this lane's slice: [olen - (64 - lane) KB, olen - (63 - lane) KB), clipped at the member's start
-            const int64_t e = olen - (int64_t)(63u - lane) * 1024, b0 = e - 1024;
+            // (lane 0 takes whatever lies in front of the last 63 KB: nothing more than its 1 KB in a BGZF member, whose ISIZE is
+            // at most 64 KB -- but a trailer that claims more is then checked over all of its bytes too)
+            const int64_t e = olen - (int64_t)(63u - lane) * 1024, b0 = lane == 0u ? 0 : e - 1024;
             if (e > 0 || (olen == 0 && lane == 63u)) {       // (an empty member: the last lane carries the initial value alone)
                 int64_t k = b0 > 0 ? b0 : 0;
                 c = b0 <= 0 ? 0xffffffffu : 0u;            // the slice that holds byte 0 carries the CRC's initial value
