@@ -40,6 +40,35 @@ def test_inflate_varied_payloads():
         assert got == b"".join(parts)
 
 
+def test_inflate_crc_at_slice_boundaries():
+    """The CRC kernel gives a wave to each member and cuts it into 1 KB slices aligned to the member's end: lengths around
+    every boundary, each once with its own trailer (status 0) and once with one bit of the trailer's CRC flipped (18)."""
+    from goleft_amd.engine import DepthEngine
+    rng = np.random.default_rng(5)
+    sizes = (1, 7, 8, 9, 1023, 1024, 1025, 2047, 2048, 2049, 3071, 4096, 32767, 32768, 65279, 65280)
+    parts = [rng.integers(0, 256, n, dtype=np.uint8).tobytes() for n in sizes]
+    members = []
+    for x in parts:
+        first = []
+        m = bamio.bgzf_compress(x, level=1 if len(x) < 40000 else 0, sizes=first)
+        assert len(first) == 1
+        members.append(m[:first[0]])                                                               # (without the EOF member)
+    assert all(bamio.bgzf_decompress(m) == x for m, x in zip(members, parts))
+    damaged = []
+    for i, m in enumerate(members):
+        b = bytearray(m)
+        b[len(b) - 8 + (i % 4)] ^= 1 << (i % 8)                                                    # the trailer's CRC32
+        damaged.append(bytes(b))
+    with DepthEngine(0) as eng:
+        got, status = eng.inflate_bgzf(b"".join(members))
+        assert (status == 0).all() and got == b"".join(parts)
+        got, status = eng.inflate_bgzf(b"".join(damaged))
+        assert (status == 18).all() and got == b"".join(parts)
+        mixed = b"".join(d if i % 2 else m for i, (m, d) in enumerate(zip(members, damaged)))
+        got, status = eng.inflate_bgzf(mixed)
+        assert [int(v) for v in status] == [18 if i % 2 else 0 for i in range(len(sizes))] and got == b"".join(parts)
+
+
 @pytest.mark.parametrize("seed", range(4))
 def test_inflate_random_streams(seed):
     # many members of random size / entropy / compression level and strategy in one call,
