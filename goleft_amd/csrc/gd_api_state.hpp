@@ -274,6 +274,8 @@ struct gd_ctx {
     int comm_rank = 0, comm_world = 0;
     hipEvent_t comm_ev[3] = {nullptr, nullptr, nullptr};   // [0], [1]: the last two gathers; [2]: "computed so far"
     unsigned comm_seq = 0;
+    const int64_t* comm_last_send = nullptr;   // the buffer the last gd_gather_export reads (it may still be reading it)
+    unsigned comm_last_ev = 0;                 // ... and which of comm_ev[0 / 1] is recorded behind it
 
     ComputeState cs;
     bool computed = false;

@@ -358,7 +358,9 @@ __global__ __launch_bounds__(INF_LANES) void gd_inflate_kernel(InflateJob job)
                         E0 = w[0];
                         T = inf_v4{w[1], w[2], w[3], w[4]};
                         fl = (obase + o) & ~63u;
-                        for (uint32_t a = fl > obase ? fl : obase; a < obase + o; ++a) {
+                        // (from sixteen bytes below fl: a later chunk whose 16-byte source straddles fl -- sa < fl < sa + 16 --
+                        // is read from the ring, so the ring must hold [fl - 15, fl) of what this block put into memory)
+                        for (uint32_t a = fl >= obase + 16u ? fl - 16u : obase; a < obase + o; ++a) {
                             uint32_t& d = s_ring[((a >> 2) & 31u) * 64u];
                             d = (d & ~(0xffu << (8u * (a & 3u)))) | ((uint32_t)out_al[a] << (8u * (a & 3u)));
                         }

@@ -222,12 +222,16 @@ BamReader::Chunk BamReader::produce(Bytes spare)
             const size_t old = raw_.size();
             raw_.resize(old + kChunk);
             uint8_t* const dst = raw_.data() + old;
+            // A read ERROR is not the end of the file: taken for one, an error that lands on a member boundary would
+            // make a truncated depth look complete.
+            std::atomic<int> read_errno{0};
             auto read_at = [&](size_t b, size_t e) -> size_t {           // bytes read of [b, e): short only at the end of the file
                 size_t done = b;
                 while (done < e) {
                     const ssize_t r = seekable_ ? pread(fd_, dst + done, e - done, (off_t)(file_off_ + done)) : read(fd_, dst + done, e - done);
                     if (r < 0 && errno == EINTR) continue;
-                    if (r <= 0) break;
+                    if (r < 0) { read_errno.store(errno ? errno : EIO); break; }
+                    if (r == 0) break;
                     done += (size_t)r;
                 }
                 return done - b;
@@ -253,6 +257,14 @@ BamReader::Chunk BamReader::produce(Bytes spare)
                 }
             } else {
                 got = read_at(0, kChunk);
+            }
+            if (read_errno.load() != 0) {
+                c.err = "read error in " + path_ + ": " + strerror(read_errno.load());
+                raw_.clear();
+                c.data.clear();
+                c.end = true;
+                eof_ = true;
+                return c;
             }
             file_off_ += got;
             raw_.resize(old + got);

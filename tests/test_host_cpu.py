@@ -617,3 +617,29 @@ def test_ingest_parts_inside_a_reference(hostlib, seed, n_anchors, part_bytes):
     else:
         # not cut: small enough, or no anchor to cut at
         assert total <= part_bytes + part_bytes // 2 or len(set(int(x) >> 16 for x in v)) < 2 or True
+
+
+def test_rccl_that_cannot_be_loaded_is_no_device_not_a_crash():
+    """ADVICE round 4 (medium): dlerror() was called twice -- the second call returns NULL and a std::string was built
+    from it, so a machine WITHOUT librccl (the case GD_E_NODEVICE exists for) crashed in gd_comm_unique_id instead of
+    getting the error.  A fresh process whose library name points nowhere."""
+    import subprocess
+    import sys
+    code = ("import ctypes as C, sys; sys.path.insert(0, %r)\n"
+            "from goleft_amd import _lib\n"
+            "lib = _lib.load(); buf = C.create_string_buffer(128)\n"
+            "print('rc', lib.gd_comm_unique_id(buf, 128), lib.gd_comm_unique_id(buf, 128))\n" % ROOT)
+    env = dict(os.environ, GOLEFT_RCCL_LIB="/nonexistent/librccl-missing.so.1")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=120)
+    assert r.returncode == 0, (r.returncode, r.stderr[-800:])
+    assert "rc -6 -6" in r.stdout, r.stdout                      # GD_E_NODEVICE, both times
+
+
+def test_bam_reader_reports_a_read_error_instead_of_an_end_of_file(hostlib, tmp_path):
+    """a pread() failure was taken for the end of the file (a silently truncated depth when it lands
+    on a member boundary).  A directory opens read-only and fails every read with EISDIR."""
+    d = tmp_path / "a_directory.bam"
+    d.mkdir()
+    with pytest.raises(OSError) as e:
+        hostlib.read_bam(str(d))
+    assert "read error" in str(e.value), str(e.value)

@@ -323,3 +323,46 @@ def test_crc_kernels_at_slice_boundaries():
         got, status = emul_inflate(payloads, [len(x) for x in parts], crcs)
         for i, x in enumerate(parts):
             assert int(status[i]) == (18 if (i + flip) % 2 else 0) and got[i] == x, (i, len(x), int(status[i]))
+
+
+def _stored_then_compressed(stored: bytes, tail: bytes, level, strategy) -> bytes:
+    """One deflate stream: a non-final STORED block holding `stored`, then `tail` deflated with `stored` as its history
+    (a preset dictionary in a raw stream is exactly that) -- what zlib and libdeflate emit when an incompressible stretch
+    is followed by data that repeats it: no history reset between the blocks."""
+    assert 0 < len(stored) <= 0xffff
+    co = zlib.compressobj(level, zlib.DEFLATED, -15, 8, strategy, zdict=stored)
+    body = co.compress(tail) + co.flush()
+    return b"\x00" + len(stored).to_bytes(2, "little") + (len(stored) ^ 0xffff).to_bytes(2, "little") + stored + body
+
+
+def test_matches_that_reach_back_into_a_stored_block():
+    """after a stored block the output ring held only the bytes of the block's last, incomplete
+    64-byte block; a match whose 16-byte source straddles that boundary took the ring path and read bytes the ring never
+    got.  Stored block + fixed / dynamic block whose first match lies 16..96 bytes back, at every alignment of the
+    member in memory (the members lie back to back) and every phase of the stored block's end against the 64-byte blocks."""
+    rng = np.random.default_rng(23)
+    payloads, parts = [], []
+    for d in range(16, 97):
+        for rep in range(3):
+            ns = int(rng.integers(d, 400))                     # the stored block: incompressible
+            stored = rng.integers(0, 256, ns, dtype=np.uint8).tobytes()
+            ml = int(rng.integers(3, 60))
+            src = stored[ns - d:][:ml]
+            tail = (src * (ml // len(src) + 1))[:ml] + rng.integers(0, 256, int(rng.integers(0, 30)), dtype=np.uint8).tobytes()
+            tail += stored[-int(rng.integers(16, min(ns, 96) + 1)):][:40]
+            st = (zlib.Z_FIXED, zlib.Z_DEFAULT_STRATEGY)[rep % 2]
+            c = _stored_then_compressed(stored, tail, 6, st)
+            x = stored + tail
+            d0 = zlib.decompressobj(-15)
+            assert d0.decompress(c) + d0.flush() == x and d0.eof
+            payloads.append(c); parts.append(x)
+    # ... and a pad member of every length 0..63 in front of the same stream: every obase
+    stored = rng.integers(0, 256, 100, dtype=np.uint8).tobytes()
+    for pad in range(64):
+        for d in (16, 17, 31, 33, 63, 70):
+            tail = stored[100 - d:][:24] + b"xyz"
+            payloads.append(deflate(bytes(pad), 1)); parts.append(bytes(pad))
+            payloads.append(_stored_then_compressed(stored, tail, 6, zlib.Z_FIXED)); parts.append(stored + tail)
+    got, status = emul_inflate(payloads, [len(x) for x in parts], [zlib.crc32(x) & 0xffffffff for x in parts], guarded=True)
+    bad = [(i, int(status[i])) for i, x in enumerate(parts) if status[i] != 0 or got[i] != x]
+    assert not bad, (len(bad), len(parts), bad[:10])

@@ -33,7 +33,7 @@ def zlib_bgzf(raw):
 
 
 t0 = time.perf_counter()
-want = zlib_bgzf(data)
+want = None if os.environ.get("INFLATE_BENCH_NO_ZLIB") else zlib_bgzf(data)      # (counter passes: the yardstick ran in the trace pass)
 t_cpu = time.perf_counter() - t0
 with DepthEngine(0) as eng:
     eng.set_profiling(True)
@@ -48,8 +48,8 @@ with DepthEngine(0) as eng:
             ms = eng.kernel_ms(K_INFLATE)
             best = ms if best is None else min(best, ms)
         ms = best
-        print("lds pad %6d: members %d, %.1f MB -> %.1f MB; status ok %s; equal %s" % (pad, len(status), len(data) / 1e6, len(want) / 1e6,
-                                                                                   bool((status == 0).all()), got == want))
+        print("lds pad %6d: members %d, %.1f MB -> %.1f MB; status ok %s; equal %s" % (pad, len(status), len(data) / 1e6, len(got) / 1e6,
+                                                                                   bool((status == 0).all()), None if want is None else got == want))
         print("   kernel %.2f ms = %.2f GB/s of output (%.2f GB/s of BGZF); python zlib 1 thread %.2f s; call incl. H2D/D2H %.3f s"
-              % (ms, len(want) / ms / 1e6, len(data) / ms / 1e6, t_cpu, t_all), flush=True)
+              % (ms, len(got) / ms / 1e6, len(data) / ms / 1e6, t_cpu, t_all), flush=True)
 os.unlink(path)

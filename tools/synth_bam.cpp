@@ -9,6 +9,10 @@
 // SEQ and QUAL (random bases, run-structured qualities) so that the file has the size and the
 // inflate cost of a real one (~250 B per record before BGZF).  BGZF members are deflated in
 // parallel (level 1; libdeflate when the system has it, else zlib; SYNTH_BAM_LEVEL changes the level).  Also writes a "<contig>\t<length>\t..." line to OUT.fa.fai and
+// SYNTH_BAM_AUX=1: records as an aligner + duplicate marker leave them -- Illumina-style read names
+// (`A00741:188:HGTMNDSX2:3:2437:23511:17018`), mate fields (same reference, a position a fragment away, TLEN) and the
+// tags RG:Z NM:C MD:Z AS:C XS:C MC:Z (~ +75 B per record before BGZF): the inflate and the record walk of a real 30x file,
+// where the default records (a 14-byte name, no tags) are the cheapest a BAM can hold.
 // OUT.bam.bai (exact 16 kb linear index; the binning index is collapsed into bin 0, enough
 // for this repository's readers, not for region queries by other tools).
 #include <dlfcn.h>
@@ -69,6 +73,7 @@ struct LibDeflate {
 };
 static const LibDeflate g_ld;
 static int g_level = 1;
+static bool g_aux = false;                     // SYNTH_BAM_AUX=1
 
 // what one worker keeps from flush to flush (the threads themselves are started per flush): its compressor and its scratch
 struct Worker {
@@ -122,6 +127,7 @@ int main(int argc, char** argv)
     int threads = argc > 6 ? atoi(argv[6]) : (int)std::thread::hardware_concurrency();
     if (threads < 1) threads = 1;
     if (const char* lv = getenv("SYNTH_BAM_LEVEL")) g_level = std::max(1, std::min(9, atoi(lv)));
+    if (const char* ax = getenv("SYNTH_BAM_AUX")) g_aux = atoi(ax) != 0;
     const int RL = 150;
     const int fd = open(path.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
     if (fd < 0) { perror("open"); return 1; }
@@ -230,7 +236,7 @@ int main(int argc, char** argv)
         // (written through a pointer into a buffer of the largest possible size: a push_back per byte was most of the tool's
         // CPU time once the deflate was libdeflate's)
         std::vector<uint8_t>& buf = c->bytes;
-        const size_t worst = (size_t)(i1 - i0) * 320;
+        const size_t worst = (size_t)(i1 - i0) * (g_aux ? 448 : 320);
         if (buf.capacity() < worst) { buf.clear(); buf.reserve(worst); }
         buf.resize(worst);                                   // (no-op after the first chunk of this size)
         uint8_t* const w0 = buf.data();
@@ -257,17 +263,57 @@ int main(int argc, char** argv)
             uint16_t flag = (h & 1) ? 99 : 147;
             if (fr < 50) flag |= 0x400; else if (fr < 51) flag |= 0x100; else if (fr < 52) flag |= 0x200; else if (fr < 57) flag |= 0x800;
             const uint8_t mapq = ((h >> 12) % 100) == 0 ? 0 : 60;
-            char name[32] = "synth.";
+            char name[64] = "synth.";
             int ln = 6;
-            {
+            auto put_dec = [&](uint64_t v) {
                 char dig[24];
                 int nd = 0;
-                uint64_t v = (uint64_t)i;
                 do { dig[nd++] = (char)('0' + v % 10); v /= 10; } while (v);
                 while (nd) name[ln++] = dig[--nd];
+            };
+            uint8_t aux[96];
+            int la = 0;
+            uint32_t mate_ref = 0xffffffffu, mate_pos = 0xffffffffu;
+            int32_t tlen = 0;
+            if (!g_aux) {
+                put_dec((uint64_t)i);
                 name[ln++] = 0;
+            } else {
+                // instrument : run : flowcell : lane : tile : x : y (what bcl2fastq writes; the pair shares it)
+                const uint64_t g = mix(h ^ 0x5851f42d4c957f2dull);
+                ln = 0;
+                memcpy(name, "A00741:188:HGTMNDSX2:", 21); ln = 21;
+                put_dec(1 + (g & 3)); name[ln++] = ':';
+                put_dec(1101 + (g >> 2) % 1578); name[ln++] = ':';
+                put_dec(1000 + (g >> 16) % 31000); name[ln++] = ':';
+                put_dec(1000 + (g >> 36) % 36000);
+                name[ln++] = 0;
+                const int32_t frag = 300 + (int32_t)((g >> 52) % 200);
+                mate_ref = (uint32_t)ctg;
+                const bool fwd = (h & 1) != 0;                   // flag 99: forward, mate downstream
+                int64_t mp = fwd ? pos + frag - RL : pos - (frag - RL);
+                if (mp < 0) mp = 0;
+                mate_pos = (uint32_t)mp;
+                tlen = fwd ? frag : -frag;
+                auto tagZ = [&](char a, char b, const char* v) { aux[la++] = (uint8_t)a; aux[la++] = (uint8_t)b; aux[la++] = 'Z'; while (*v) aux[la++] = (uint8_t)*v++; aux[la++] = 0; };
+                auto tagC = [&](char a, char b, uint8_t v) { aux[la++] = (uint8_t)a; aux[la++] = (uint8_t)b; aux[la++] = 'C'; aux[la++] = v; };
+                const uint32_t nm = (uint32_t)((g >> 8) % 8) < 5 ? 0u : (uint32_t)((g >> 11) % 4);     // most reads match
+                char md[24];
+                int lm = 0;
+                auto md_dec = [&](uint32_t v) { char dg[8]; int nd = 0; do { dg[nd++] = (char)('0' + v % 10); v /= 10; } while (v); while (nd) md[lm++] = dg[--nd]; };
+                const uint32_t mlen = (uint32_t)(nc == 2 ? (int)(cig[1] >> 4) : nc == 3 && (cig[1] & 15) == 1 ? RL - (int)(cig[1] >> 4) : RL);
+                if (nm == 0) md_dec(mlen);
+                else { const uint32_t a = 1 + (uint32_t)((g >> 20) % (mlen - 2)); md_dec(a); md[lm++] = "ACGT"[(g >> 30) & 3]; md_dec(mlen - a - 1); }
+                md[lm] = 0;
+                char mc[8] = "150M";
+                tagC('N', 'M', (uint8_t)nm);
+                tagZ('M', 'D', md);
+                tagZ('M', 'C', mc);
+                tagC('A', 'S', (uint8_t)(RL - 5 * nm));
+                tagC('X', 'S', (uint8_t)((g >> 40) % 8 < 6 ? 0 : 19 + (g >> 44) % 100));
+                tagZ('R', 'G', "rg1");
             }
-            const uint32_t block = 32 + (uint32_t)ln + 4u * (uint32_t)nc + (RL + 1) / 2 + RL;
+            const uint32_t block = 32 + (uint32_t)ln + 4u * (uint32_t)nc + (RL + 1) / 2 + RL + (uint32_t)la;
             {
                 const uint64_t off = (uint64_t)(w - w0);         // chunk local
                 c->after_last = off + 4 + block;
@@ -284,9 +330,9 @@ int main(int argc, char** argv)
             p16((uint16_t)nc);
             p16(flag);
             p32(RL);
-            p32(0xffffffffu);                                // next refID
-            p32(0xffffffffu);                                // next pos
-            p32(0);
+            p32(mate_ref);                                   // next refID
+            p32(mate_pos);                                   // next pos
+            p32((uint32_t)tlen);
             memcpy(w, name, (size_t)ln); w += ln;
             for (int k = 0; k < nc; ++k) p32(cig[k]);
             uint64_t r = h;
@@ -305,6 +351,7 @@ int main(int argc, char** argv)
                 memcpy(w, &q8, (size_t)m);
                 w += m;
             }
+            if (la) { memcpy(w, aux, (size_t)la); w += la; }
         }
         buf.resize((size_t)(w - w0));
     };
@@ -377,7 +424,9 @@ int main(int argc, char** argv)
         for (size_t k = 0; k < lens.size(); ++k) fprintf(fai, "%s\t%lld\t6\t60\t61\n", names[k].c_str(), (long long)lens[k]);
         fclose(fai);
     }
-    printf("{\"reads\": %lld, \"bam_bytes\": %llu, \"deflate\": \"%s level %d\"}\n", (long long)n_total,
-           (unsigned long long)(out_bytes + 28), g_ld.ok() ? "libdeflate" : "zlib", g_level);
+    printf("{\"reads\": %lld, \"bam_bytes\": %llu, \"deflate\": \"%s level %d\", \"records\": \"%s\", \"inflated_bytes\": %llu}\n", (long long)n_total,
+           (unsigned long long)(out_bytes + 28), g_ld.ok() ? "libdeflate" : "zlib", g_level,
+           g_aux ? "Illumina-style names, mate fields, RG NM MD AS XS MC tags" : "short names, no tags",
+           (unsigned long long)(stream_off + 0));
     return 0;
 }
