@@ -79,6 +79,9 @@ def parse():
     ap.add_argument("--bam-scope", default="auto", choices=["auto", "genome", "chr1-2", "chr20-21", "off"],
                     help="N = 1, wgs workload: BAM file -> BED through the CLI (SURVEY 8d scope iii) on a synthetic BAM of this "
                          "size; auto = genome on a host with >= 64 cores and the room for a 46 GB file, else chr20-21")
+    ap.add_argument("--other-workloads", default="chr20,ont,cohort", metavar="W[,W...]",
+                    help="N = 1, wgs workload: after the headline, short runs of BASELINE.json's configs 2 (chr20), 5 (ont) and "
+                         "4 (cohort) -> `other_workloads` in the line; '' = off")
     ap.add_argument("--verify", action="store_true",
                     help="check one contig against the CPU oracle after timing")
     return ap.parse_args()
@@ -241,18 +244,46 @@ def read_once(path, threads=16, block=8 << 20):
     return time.perf_counter() - t0
 
 
-def bam_file_scope(which, W, device_reps=3, host_decoder=True, pause_s=0.0):
+def expected_beds(which, W, chrom=None, live=False):
+    """SHA-256 of the depth.bed / callable.bed that `goleft depth -w W` must write for the deterministic synthetic file
+    `which`, FROM THE ORACLE (oracle/synthbam.py: numpy twin of the generator's record function -> oracle/depth_oracle.c ->
+    the restated callback): the committed pair (tests/golden/synth_bam_expected.json, made by tools/expected_bed_sha.py on
+    the CPU) or, live=True, computed here -- as the checker of a finished run, outside anything timed."""
+    key = "%s:cov30:seed20:w%d%s" % (which, W, ":chrom=" + chrom if chrom else "")
+    if live:
+        from goleft_amd import synth
+        from oracle import synthbam
+        names = list(synth.HG19_NAMES)
+        lengths = {"genome": list(synth.HG19_LENGTHS), "chr1-2": list(synth.HG19_LENGTHS[:2]),
+                   "chr20-21": [synth.HG19_LENGTHS[names.index("chr20")], synth.HG19_LENGTHS[names.index("chr21")]]}[which]
+        t0 = time.perf_counter()
+        r = synthbam.expected_beds(lengths, W=W, chrom=chrom, threads=usable_cpus())
+        return dict(r, source="oracle, computed in this run (%.1f s)" % (time.perf_counter() - t0), key=key)
+    try:
+        with open(os.path.join(ROOT, "tests", "golden", "synth_bam_expected.json")) as fh:
+            r = json.load(fh).get(key)
+    except (OSError, ValueError):
+        r = None
+    return dict(r, source="oracle, committed: tests/golden/synth_bam_expected.json", key=key) if r else None
+
+
+def bam_file_scope(which, W, device_reps=3, host_decoder=True, pause_s=0.0, synth_env=None, paper=False, oracle_live=False):
     """SURVEY.md section 8d scope (iii), the only scope the reference itself runs and times (`time goleft depth ...`,
     indexcov/paper/cmp.sh:6): a BAM FILE -> depth.bed + callable.bed through the CLI twin, process start to exit.
     A synthetic but realistic coordinate-sorted BAM (tools/synth_bam.cpp: 150 bp records WITH SEQ and QUAL, BGZF, .bai)
     of `which` -- "genome": all 24 hg19 contigs, 30x, ~46 GB; "chr1-2": two chromosomes, ~7 GB; "chr20-21": ~1.4 GB --
     is written to $TMPDIR, read once untimed (read_once above), then read by `goleft-depth depth -w W` with the device
     decoder (best of device_reps runs; the file is in the page cache, as after any write) and once with the host decoder;
-    the BED files must be byte identical.  `pause_s`: seconds to wait before each run -- a process that starts while the
+    the BED files must be byte identical -- to each other AND to what the oracle makes of the same records
+    (`oracle_identical`: expected_beds above).  synth_env: how the file is made (SYNTH_BAM_LEVEL: deflate level,
+    SYNTH_BAM_AUX=1: Illumina-style names, mate fields and the tags of an aligned, duplicate-marked file).  paper: also the
+    reference's own timed invocation, `goleft depth --chrom <first contig> -p 20 -o -w 16384` (indexcov/paper/cmp.sh:6), on
+    the same file.  `pause_s`: seconds to wait before each run -- a process that starts while the
     driver is still clearing the device memory the previous one released waits for it in its first large hipMalloc
     (profiles/r11i_pause_test.jsonl, a 13 GB file: `gd_ingest_begin` 1.7-2.6 s and 2.5-3.4 s per run in 12 runs started
     back to back, 0.23-0.36 s and 1.06-1.26 s per run in 12 runs started 1, 2 or 4 s after the previous one's exit); one
     run of a real job has no such predecessor.  Reported next to -- never as -- `value`."""
+    import hashlib
     import shutil
     import subprocess
     from goleft_amd import synth
@@ -261,7 +292,8 @@ def bam_file_scope(which, W, device_reps=3, host_decoder=True, pause_s=0.0):
     names = list(synth.HG19_NAMES)
     lengths = {"genome": list(synth.HG19_LENGTHS), "chr1-2": list(synth.HG19_LENGTHS[:2]),
                "chr20-21": [synth.HG19_LENGTHS[names.index("chr20")], synth.HG19_LENGTHS[names.index("chr21")]]}[which]
-    need = int(sum(lengths) * 16)                      # ~15 B of BGZF per reference base at 30x, and the BED files
+    aux = bool(synth_env and synth_env.get("SYNTH_BAM_AUX") == "1")
+    need = int(sum(lengths) * (20 if aux else 16))      # ~15 (19) B of BGZF per reference base at 30x, and the BED files
     tmp = os.environ.get("TMPDIR") or "/tmp"
     # a RAM-backed directory when it has the room: the GPU boxes' /tmp is an overlay that takes 0.3 GB/s (150 s for the
     # genome's file), and the file is read from the page cache either way
@@ -271,11 +303,22 @@ def bam_file_scope(which, W, device_reps=3, host_decoder=True, pause_s=0.0):
     if free < need * 1.2:
         return {"error": "%s needs %.0f GB in %s, %.0f GB free" % (which, need / 1e9, tmp, free / 1e9)}
     d = tempfile.mkdtemp(prefix="gd_bamscope_", dir=tmp)
+
+    def sha_pair(stem):
+        h = []
+        for kind in ("depth", "callable"):
+            m = hashlib.sha256()
+            with open("%s.%s.bed" % (stem, kind), "rb") as fh:
+                for blk in iter(lambda: fh.read(1 << 24), b""):
+                    m.update(blk)
+            h.append(m.hexdigest())
+        return h
+
     try:
         bam = os.path.join(d, "synth.bam")
         t0 = time.perf_counter()
         info = json.loads(subprocess.check_output([gen, bam, "chrS", ",".join(str(x) for x in lengths), "30", "20"],
-                                                  timeout=900).decode())
+                                                  timeout=900, env=dict(os.environ, **(synth_env or {}))).decode())
         t_write = time.perf_counter() - t0
         t_settle = read_once(bam)
         ref_bases = int(sum(lengths))
@@ -283,43 +326,44 @@ def bam_file_scope(which, W, device_reps=3, host_decoder=True, pause_s=0.0):
                        "process start to exit (the scope the reference times: indexcov/paper/cmp.sh:6); file in the page cache "
                        "and read once before; %.1f s between runs" % (W, pause_s),
                "file": which, "contigs": len(lengths), "ref_bases": ref_bases, "reads": info["reads"],
-               "bam_bytes": info["bam_bytes"], "deflate": info.get("deflate", "zlib level 1"), "synth_bam_s": t_write, "read_once_s": t_settle, "pause_before_each_run_s": pause_s,
+               "bam_bytes": info["bam_bytes"], "deflate": info.get("deflate", "zlib level 1"),
+               "records": info.get("records", "short names, no tags"), "inflated_bytes": info.get("inflated_bytes"),
+               "synth_bam_s": t_write, "read_once_s": t_settle, "pause_before_each_run_s": pause_s,
                "written_to": tmp, "host_cores": os.cpu_count(), "usable_cpus": usable_cpus(), "unit": "ref-bases/s"}
         beds = {}
         runs = [("device", {}, device_reps)] + ([("host", {"GOLEFT_GPU_DECODE": "0"}, 1)] if host_decoder else [])
+
+        def one_run(decoder, env, extra, stem):
+            if pause_s:
+                time.sleep(pause_s)
+            t0 = time.perf_counter()
+            p = subprocess.run([exe, "depth"] + extra + ["-r", os.path.join(d, "synth.fa"), "--prefix", stem, bam],
+                               env=dict(os.environ, GOLEFT_DEPTH_TIMING="1", GOLEFT_INGEST_TIMING="1", **env),
+                               stderr=subprocess.PIPE, stdout=subprocess.DEVNULL, timeout=900)
+            dt = time.perf_counter() - t0
+            if p.returncode != 0:
+                raise RuntimeError("goleft-depth (%s decoder) exited with %d: %s" % (decoder, p.returncode, p.stderr.decode()[-400:]))
+            phases = {}
+            for ln in p.stderr.decode().strip().splitlines():
+                if ln.startswith("{"):
+                    phases.update(json.loads(ln))
+            if phases.get("decoder") != decoder:
+                raise RuntimeError("asked for the %s decoder, %r ran" % (decoder, phases.get("decoder")))
+            return dt, phases
+
         for decoder, env, reps in runs:
             walls, best, seen = [], None, []
+            stem = os.path.join(d, "out_" + decoder)
             for _ in range(reps):
-                if pause_s:
-                    time.sleep(pause_s)
-                t0 = time.perf_counter()
-                p = subprocess.run([exe, "depth", "-w", str(W), "-p", "0", "-r", os.path.join(d, "synth.fa"), "--prefix",
-                                    os.path.join(d, "out_" + decoder), bam],
-                                   env=dict(os.environ, GOLEFT_DEPTH_TIMING="1", GOLEFT_INGEST_TIMING="1", **env),
-                                   stderr=subprocess.PIPE, stdout=subprocess.DEVNULL, timeout=900)
-                dt = time.perf_counter() - t0
-                if p.returncode != 0:
-                    return dict(out, error="goleft-depth (%s decoder) exited with %d: %s" % (decoder, p.returncode, p.stderr.decode()[-400:]))
-                phases = {}
-                for ln in p.stderr.decode().strip().splitlines():
-                    if ln.startswith("{"):
-                        phases.update(json.loads(ln))
-                if phases.get("decoder") != decoder:
-                    return dict(out, error="asked for the %s decoder, %r ran" % (decoder, phases.get("decoder")))
+                try:
+                    dt, phases = one_run(decoder, env, ["-w", str(W), "-p", "0"], stem)
+                except RuntimeError as e:
+                    return dict(out, error=str(e))
                 walls.append(dt)
                 seen.append({k: phases.get(k) for k in ("lib_begin_s", "lib_read_s", "lib_wait_link_s", "setup_s")})
                 if best is None or dt < best[0]:
                     best = (dt, phases)
-            stem = os.path.join(d, "out_" + decoder)
-            h = []
-            for kind in ("depth", "callable"):
-                import hashlib
-                m = hashlib.sha256()
-                with open("%s.%s.bed" % (stem, kind), "rb") as fh:
-                    for blk in iter(lambda: fh.read(1 << 24), b""):
-                        m.update(blk)
-                h.append(m.hexdigest())
-            beds[decoder] = h
+            beds[decoder] = sha_pair(stem)
             out[decoder + "_decoder"] = {"wall_s": best[0], "all_wall_s": walls, "all_runs": seen, "ref_bases_per_s": ref_bases / best[0],
                                          "bgzf_GBps": info["bam_bytes"] / best[0] / 1e9,
                                          "phases": {k: v for k, v in best[1].items() if isinstance(v, (int, float))}}
@@ -328,6 +372,34 @@ def bam_file_scope(which, W, device_reps=3, host_decoder=True, pause_s=0.0):
         out["bgzf_GBps"] = out["device_decoder"]["bgzf_GBps"]
         out["outputs_identical"] = (beds["device"] == beds["host"]) if "host" in beds else None
         out["bed_sha256"] = beds["device"]
+        # ... and against the ORACLE's rows for the same records (not a second product path)
+        exp = expected_beds(which, W, live=oracle_live) or (expected_beds(which, W, live=True) if sum(lengths) < 3e8 else None)
+        out["oracle_identical"] = (exp["bed_sha256"] == beds["device"]) if exp else None
+        out["oracle_bed_sha256"] = exp["bed_sha256"] if exp else None
+        out["oracle_source"] = exp["source"] if exp else "no committed expectation for this file and too large to compute here"
+        if paper:
+            # the reference's own timed invocation (indexcov/paper/cmp.sh:6): one chromosome of a whole-genome BAM, found
+            # through the .bai
+            stem = os.path.join(d, "out_paper")
+            W2 = 16384
+            try:
+                best = None
+                for _ in range(2):
+                    dt, phases = one_run("device", {}, ["--chrom", "chrS", "-p", "20", "-o", "-w", str(W2)], stem)
+                    if best is None or dt < best[0]:
+                        best = (dt, phases)
+                got = sha_pair(stem + ".chrS")             # depth/depth.go:382-388: the prefix gains the chromosome
+                exp2 = expected_beds(which, W2, chrom="chrS")
+                out["paper_invocation"] = {
+                    "what": "`goleft-depth depth --chrom chrS -p 20 -o -w 16384` on the same file: the invocation the reference "
+                            "itself times (indexcov/paper/cmp.sh:6) -- a .bai seek + one chromosome (chr1-sized), process start to exit",
+                    "wall_s": best[0], "ref_bases": int(lengths[0]), "ref_bases_per_s": lengths[0] / best[0],
+                    "phases": {k: v for k, v in best[1].items() if isinstance(v, (int, float))},
+                    "bed_sha256": got, "oracle_identical": (exp2["bed_sha256"] == got) if exp2 else None,
+                    "oracle_source": exp2["source"] if exp2 else None}
+                out["paper_invocation_s"] = best[0]
+            except (RuntimeError, OSError) as e:
+                out["paper_invocation"] = {"error": str(e)}
         return out
     finally:
         shutil.rmtree(d, ignore_errors=True)
@@ -677,6 +749,107 @@ def run_case(args, scaling, world, rank, dev, local_rank, want_streams=False):
     return res
 
 
+def roofline_of(r, args, world):
+    """The roofline of the dominant kernel of one run_case() result, this rank's launch.  SURVEY.md 8(d): 4 B/read (pos)
+    + 4 B/read (the CSR offset, read on device) + 4 B per CIGAR op the kernel reads (the original ops on the short-read
+    path; deletion lists = the canonical op pairs on the long-read path) + 4 B/base + 8 B/window.  `achieved` / `frac` are
+    on that formula; the raw straight-line kernel really reads 3 B per read more (flag 2 + MAPQ 1): counting those too
+    gives `frac_bytes_really_read`."""
+    from goleft_amd import synth
+    ops_read = r["n_canonical_ops"] if r["n_canonical_ops"] else r["n_ops"]
+    raw_records = r["kernel"].endswith("<raw>")
+    alg_bytes = synth.algorithmic_bytes(r["n_reads"], ops_read, r["my_bases"] if r["perbase"] else 0,
+                                        r["my_windows"], raw=False)         # windows-only: no 4 B/base write (SURVEY 8d)
+    alg_bytes_read = synth.algorithmic_bytes(r["n_reads"], ops_read, r["my_bases"] if r["perbase"] else 0,
+                                             r["my_windows"], raw=raw_records)
+    scatter = r["path"] == 2
+    chunk = r["path"] == 3
+    # tile path: the tile kernel does all the arithmetic; chunk path: the long-read tile kernel (its deletion lists and
+    # tile indexes are rebuilt inside every step: `long_read_structures`); scatter path: expand + scan share it
+    avg_tile_s = (r["expand_ms"] + r["scan_ms"] if scatter else r["tile_ms"]) * 1e-3
+    achieved = alg_bytes / avg_tile_s / 1e9
+    traffic = None
+    tr = None
+    kname = r["kernel"]                             # gd_stats.tile_kernel: what did the per-base arithmetic
+    if world == 1 and args.workload == "wgs" and args.coverage == 30.0 and r["path"] == 1:
+        tr = load_traffic("wgs", kname)
+    elif world == 1 and args.workload == "ont" and args.coverage == 20.0 and chunk:
+        tr = load_traffic("ont", kname)
+    elif world == 1 and args.workload == "cohort" and args.samples == 200 and kname.startswith("gd_sums_stream_kernel"):
+        tr = load_traffic("cohort", kname)
+    elif world == 1 and args.workload == "chr20" and args.coverage == 30.0 and r["path"] == 1:
+        tr = load_traffic("chr20", kname)
+    if tr:
+        traffic = tr.get("hbm_bytes_per_launch")   # measured on this exact launch shape
+    roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                "formula": "SURVEY.md 8(d): 4 B/read pos + 4 B/read CSR offset + 4 B/op + 4 B/ref-base + 8 B/window",
+                "frac_survey_8d": achieved / HBM_PEAK_GBPS,
+                "frac_bytes_really_read": alg_bytes_read / avg_tile_s / 1e9 / HBM_PEAK_GBPS,
+                "bytes_really_read_per_launch": alg_bytes_read,
+                "kernel": kname,
+                "avg_kernel_ms": avg_tile_s * 1e3,
+                "algorithmic_bytes_per_launch": alg_bytes,
+                "bytes_per_ref_base": alg_bytes / r["my_bases"],
+                "cigar_ops_counted": ops_read}
+    if traffic:
+        roofline["traffic_frac_of_peak"] = traffic / avg_tile_s / 1e9 / HBM_PEAK_GBPS
+        roofline["traffic_source"] = "%s: %s" % (tr.get("file"), tr.get("source"))
+    kernels_ms = ({"prep": r["prep_ms"], "expand": r["expand_ms"], "scan": r["scan_ms"], "runs": r["runs_ms"]}
+                  if scatter else
+                  {"prep": r["prep_ms"], "ltile": r["tile_ms"], "runs": r["runs_ms"], "long_read_structures": r["ckpt_ms"]}
+                  if chunk else {"prep": r["prep_ms"], "tile": r["tile_ms"], "runs": r["runs_ms"]})
+    return {"roofline": roofline, "kernels_ms": kernels_ms, "raw_records": raw_records, "scatter": scatter, "chunk": chunk,
+            "avg_tile_s": avg_tile_s, "traffic": traffic, "tr": tr, "kernel": kname, "ops_read": ops_read,
+            "alg_bytes": alg_bytes, "alg_bytes_read": alg_bytes_read, "achieved": achieved}
+
+
+def other_workloads(args, dev, local_rank, which, steps=5, warmup=2):
+    """BASELINE.json's configs 2, 4 and 5 in the line the driver records: after the headline, a short
+    run of each -- the same run_case() as `--workload chr20|ont|cohort`, fewer steps -- with its inclusive step, the cold
+    step (`first_compute`), the roofline of its dominant kernel on its OWN SURVEY 8(d) bytes and the kernel split.
+    One at a time, each with the device to itself (the cohort's records alone are 154 GB)."""
+    import copy
+    import torch
+    out = {}
+    for w in which:
+        t0 = time.perf_counter()
+        a = copy.copy(args)
+        a.workload, a.steps, a.warmup, a.emulate_shards, a.verify = w, steps, warmup, "", False
+        a.coverage = 20.0 if w.startswith("ont") else 30.0
+        a.window = 1000
+        try:
+            r = run_case(a, "strong", 1, 0, dev, local_rank)
+            rf = roofline_of(r, a, 1)
+            ms = r["dt"] / a.steps * 1e3
+            sub = {"metric": ("ref bases/sec per-base depth, 20x ONT-like synthetic" if w.startswith("ont")
+                              else "ref bases/sec depth -> depthwed matrix, cohort x chr1" if w == "cohort"
+                              else "ref bases/sec per-base depth, 30x chr20 synthetic"),
+                   "baseline_config": {"chr20": 2, "cohort": 4, "ont": 5}.get(w),
+                   "workload": r["wname"], "value": r["total_bases"] * a.steps / r["dt"], "unit": "ref-bases/s",
+                   "ms_per_step": ms, "steps": a.steps, "warmup": a.warmup,
+                   "total_ref_bases": r["total_bases"], "reads": r["n_reads"], "cigar_ops": r["n_ops"],
+                   "window": r["W"], "roofline": rf["roofline"], "kernels_ms": rf["kernels_ms"],
+                   "device_path": "scatter" if rf["scatter"] else "chunk" if rf["chunk"] else "tile",
+                   "step": ("gd_rebuild_derived (deletion lists, read records, tile indexes from the records as they arrived) "
+                            "+ gd_compute" if r["derive"] else "gd_compute on the records as they arrived") +
+                           (" + gd_depthwed_device" if w == "cohort" else "")}
+            if r.get("first"):
+                sub["first_compute"] = dict(r["first"], warm_ms_per_step=ms, ratio_to_warm=r["first"]["ms"] / ms)
+                # what ONE `goleft depth` run pays for its input: the cold step, not the warm one
+                sub["value_first_compute"] = r["total_bases"] / (r["first"]["ms"] * 1e-3)
+            if r.get("wed_shape"):
+                sub["depthwed_matrix"] = r["wed_shape"]
+            r["eng"].close()
+            del r
+        except Exception as e:                           # never lose the headline line to a side measurement
+            sub = {"error": "%s: %s" % (type(e).__name__, e)}
+        torch.cuda.empty_cache()
+        sub["seconds_in_bench"] = time.perf_counter() - t0
+        out[w] = sub
+    return out
+
+
 def launch_ranks(args):
     """`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment: THIS process is the launcher.
     It starts N copies of itself, one rank per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 /
@@ -830,37 +1003,10 @@ def main():
     eng, streams, names, lengths, mine = r["eng"], r["streams"], r["names"], r["lengths"], r["mine"]
     dt, W, Q, mincov = r["dt"], r["W"], r["Q"], r["mincov"]
     value = r["total_bases"] * args.steps / dt
-    # roofline of the dominant kernel, this rank's launch.  SURVEY.md 8(d): 4 B/read (pos) + 4 B/read (the record
-    # word that stands where the CSR offset stood: flag | MAPQ | op count) + 4 B per CIGAR op the kernel reads (the
-    # canonical ops on the tile and long-read paths) + 4 B/base + 8 B/window
-    # (the raw straight-line kernel reads flag 2 + MAPQ 1 per read too and the ops as they arrived)
-    ops_read = r["n_canonical_ops"] if r["n_canonical_ops"] else r["n_ops"]
-    raw_records = r["kernel"].endswith("<raw>")
-    # `achieved` / `frac` are on SURVEY.md 8(d)'s formula, CSR term included (the offsets are read on device):
-    # 4 reads + 4 reads + 4 ops + 4 bases + 8 windows.  The raw kernel really reads 3 B per read more (flag 2 + MAPQ 1);
-    # counting those too gives `frac_bytes_really_read`.
-    alg_bytes = synth.algorithmic_bytes(r["n_reads"], ops_read, r["my_bases"] if r["perbase"] else 0,
-                                        r["my_windows"], raw=False)         # windows-only: no 4 B/base write
-    alg_bytes_read = synth.algorithmic_bytes(r["n_reads"], ops_read, r["my_bases"] if r["perbase"] else 0,
-                                             r["my_windows"], raw=raw_records)
-    scatter = r["path"] == 2
-    chunk = r["path"] == 3
-    # tile path: gd_tile_kernel does all the arithmetic; chunk path: the long-read tile kernel (the CIGAR
-    # checkpoints it uses are built when the records arrive, like the canonical CIGARs: `ingest_checkpoint_ms`);
-    # scatter path: expand + scan share it
-    avg_tile_s = (r["expand_ms"] + r["scan_ms"] if scatter else r["tile_ms"]) * 1e-3
-    achieved = alg_bytes / avg_tile_s / 1e9
-    traffic = None
-    tr = None
-    kname = r["kernel"]                             # gd_stats.tile_kernel: what did the per-base arithmetic
-    if world == 1 and args.workload == "wgs" and args.coverage == 30.0 and r["path"] == 1:
-        tr = load_traffic("wgs", kname)
-    elif world == 1 and args.workload == "ont" and args.coverage == 20.0 and chunk:
-        tr = load_traffic("ont", kname)
-    elif world == 1 and args.workload == "cohort" and args.samples == 200 and kname.startswith("gd_sums_stream_kernel"):
-        tr = load_traffic("cohort", kname)
-    if tr:
-        traffic = tr.get("hbm_bytes_per_launch")   # measured on this exact launch shape
+    rf = roofline_of(r, args, world)
+    raw_records, scatter, chunk = rf["raw_records"], rf["scatter"], rf["chunk"]
+    avg_tile_s, traffic, tr, kname = rf["avg_tile_s"], rf["traffic"], rf["tr"], rf["kernel"]
+    ops_read, alg_bytes, alg_bytes_read, achieved = rf["ops_read"], rf["alg_bytes"], rf["alg_bytes_read"], rf["achieved"]
 
     # PCIe-inclusive rate (results to host) -- reported, never `value`
     t1 = time.perf_counter()
@@ -915,21 +1061,8 @@ def main():
                               (" + depthwed matrix %s" % r["wed_shape"] if r["wed_shape"] else ""),
                    "tile_positions": r["tile_positions"], "lookback": r["lookback"],
                    "device_path": "scatter" if scatter else "chunk" if chunk else "tile"},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                     "formula": "SURVEY.md 8(d): 4 B/read pos + 4 B/read CSR offset + 4 B/op + 4 B/ref-base + 8 B/window",
-                     "frac_survey_8d": achieved / HBM_PEAK_GBPS,
-                     "frac_bytes_really_read": alg_bytes_read / avg_tile_s / 1e9 / HBM_PEAK_GBPS,
-                     "bytes_really_read_per_launch": alg_bytes_read,
-                     "kernel": kname,
-                     "avg_kernel_ms": avg_tile_s * 1e3,
-                     "algorithmic_bytes_per_launch": alg_bytes,
-                     "bytes_per_ref_base": alg_bytes / r["my_bases"],
-                     "cigar_ops_counted": ops_read},
-        "kernels_ms": ({"prep": r["prep_ms"], "expand": r["expand_ms"], "scan": r["scan_ms"], "runs": r["runs_ms"]}
-                       if scatter else
-                       {"prep": r["prep_ms"], "ltile": r["tile_ms"], "runs": r["runs_ms"]}
-                       if chunk else {"prep": r["prep_ms"], "tile": r["tile_ms"], "runs": r["runs_ms"]}),
+        "roofline": rf["roofline"],
+        "kernels_ms": rf["kernels_ms"],
         "with_d2h_windows_ref_bases_per_s": r["my_bases"] / (dt / args.steps + d2h) if world == 1 else None,
     }
     if r.get("first"):
@@ -970,10 +1103,6 @@ def main():
         out["sum_of_window_sums"] = int(_sh.local_results(eng, dev)[0].sum().item())
     if d2h_matrix is not None:
         out["with_d2h_matrix_ref_bases_per_s"] = r["my_bases"] / (dt / args.steps + d2h_matrix)
-    if traffic:
-        out["roofline"]["traffic_frac_of_peak"] = traffic / avg_tile_s / 1e9 / HBM_PEAK_GBPS
-        out["roofline"]["traffic_source"] = "%s: %s" % (tr.get("file"), tr.get("source"))
-
     if args.verify and rank == 0 and r["perbase"]:
         # EVERY contig of this rank against the C oracle, bit for bit: per-base vector, window sums / minima and
         # class runs (from the oracle's vector), 10 Mb tiles on all host cores
@@ -1040,6 +1169,11 @@ def main():
         except Exception as e:                       # never lose the headline line to a side measurement
             out["host_stream_scope_wgs"] = {"error": "%s: %s" % (type(e).__name__, e)}
 
+    if rank == 0 and world == 1 and args.workload == "wgs" and args.other_workloads.strip():
+        torch.cuda.empty_cache()
+        which_w = [w for w in (x.strip() for x in args.other_workloads.split(",")) if w in ("chr20", "ont", "ont-chr20", "cohort")]
+        out["other_workloads"] = other_workloads(args, dev, local_rank, which_w)
+
     if rank == 0 and world == 1 and args.workload == "wgs" and args.bam_scope != "off":
         which = args.bam_scope
         if which == "auto":
@@ -1051,16 +1185,32 @@ def main():
             # decoders' BED files are compared byte for byte
             # (the pause: 1 s is enough after a run over a 13 GB file, profiles/r11i_pause_test.jsonl; the genome's run
             # releases four times the device memory)
-            res = bam_file_scope(which, W, device_reps=3, host_decoder=which != "genome", pause_s=8.0 if which == "genome" else 2.0)
+            res = bam_file_scope(which, W, device_reps=3, host_decoder=which != "genome", pause_s=8.0 if which == "genome" else 2.0,
+                                 paper=which == "genome")
             if "error" in res and which == "genome" and args.bam_scope == "auto":
                 res = dict(bam_file_scope("chr1-2", W), fell_back_from=res["error"])
             if which == "genome" and "error" not in res:
-                chk = bam_file_scope("chr20-21", W, device_reps=1, host_decoder=True)
-                res["decoders_identical_on"] = {k: chk.get(k) for k in ("file", "ref_bases", "bam_bytes", "outputs_identical", "error")
-                                                if k in chk}
-                res["decoders_identical_on"]["device_wall_s"] = (chk.get("device_decoder") or {}).get("wall_s")
-                res["decoders_identical_on"]["host_wall_s"] = (chk.get("host_decoder") or {}).get("wall_s")
-                res["outputs_identical"] = chk.get("outputs_identical")
+                # a small file of the same make, written two ways -- as the genome's (libdeflate level 1, the cheapest records a
+                # BAM can hold) and as an aligner + duplicate marker + htslib leave one (level 6; names, mate fields, tags) --
+                # read by BOTH decoders: BED files byte identical to each other and to the oracle's rows
+                res["variants"] = {}
+                for vname, venv in (("libdeflate1_short_records", {}),
+                                    ("libdeflate6_aux_tags", {"SYNTH_BAM_LEVEL": "6", "SYNTH_BAM_AUX": "1"})):
+                    chk = bam_file_scope("chr20-21", W, device_reps=2, host_decoder=True, pause_s=2.0, synth_env=venv,
+                                         oracle_live=vname == "libdeflate1_short_records")
+                    v = {k: chk.get(k) for k in ("file", "ref_bases", "bam_bytes", "inflated_bytes", "deflate", "records", "outputs_identical",
+                                                 "oracle_identical", "oracle_source", "bed_sha256", "error") if k in chk}
+                    v["device_wall_s"] = (chk.get("device_decoder") or {}).get("wall_s")
+                    v["host_wall_s"] = (chk.get("host_decoder") or {}).get("wall_s")
+                    v["device_ref_bases_per_s"] = (chk.get("device_decoder") or {}).get("ref_bases_per_s")
+                    v["device_phases"] = (chk.get("device_decoder") or {}).get("phases")
+                    res["variants"][vname] = v
+                first = res["variants"]["libdeflate1_short_records"]
+                res["decoders_identical_on"] = {k: first.get(k) for k in ("file", "ref_bases", "bam_bytes", "outputs_identical",
+                                                                           "oracle_identical", "device_wall_s", "host_wall_s", "error") if k in first}
+                res["outputs_identical"] = all(v.get("outputs_identical") is True for v in res["variants"].values())
+                res["oracle_identical"] = (res.get("oracle_identical") is True and
+                                           all(v.get("oracle_identical") is True for v in res["variants"].values()))
             out["bam_file_scope"] = res
         except Exception as e:                       # never lose the headline line to a side measurement
             out["bam_file_scope"] = {"error": "%s: %s" % (type(e).__name__, e)}

@@ -75,3 +75,16 @@ def test_product_never_uses_the_oracle():
                     if re.search(r"import|include|dlopen|CDLL|-l|\.so|subprocess", code):
                         bad.append("%s:%d: %s" % (os.path.relpath(os.path.join(dirpath, f), H.ROOT), n, line.strip()))
     assert not bad, bad
+
+
+def test_genome_bed_of_the_bench_line_is_the_oracles():
+    """bam_file_scope: the SHA-256 pair of the BED files the CLI wrote for the genome-sized synthetic BAM on the MI355X
+    equals what the ORACLE makes of the same records (tests/golden/synth_bam_expected.json: oracle/synthbam.py's twin of the
+    generator's record function -> oracle/depth_oracle.c -> the restated callback, computed on the CPU by
+    tools/expected_bed_sha.py) -- file -> BED at BASELINE.json's full size is checked against the oracle, not only
+    against the product's other decoder."""
+    d = _latest("r*_bench_wgs_n1.json")
+    b = d["bam_file_scope"]
+    exp = json.load(open(os.path.join(H.ROOT, "tests", "golden", "synth_bam_expected.json")))
+    assert b["file"] == "genome" and b["bed_sha256"] == exp["genome:cov30:seed20:w1000"]["bed_sha256"]
+    assert exp["genome:cov30:seed20:w1000"]["rows"][0] == 3095689          # one depth row per 1 kb window of hg19's 24 contigs

@@ -5,7 +5,7 @@ cd /tmp 2>/dev/null && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 out=$R/gpurun_out/prof_$tag
 rm -rf $out; mkdir -p $out
-cmd="python $R/bench.py --no-cpu-baseline --no-host-stream --bam-scope off --steps 3 --warmup 1 $@"
+cmd="python $R/bench.py --no-cpu-baseline --no-host-stream --bam-scope off --other-workloads= --steps 3 --warmup 1 $@"
 i=3
 for pmc in "FETCH_SIZE" "WRITE_SIZE"; do
   rocprofv3 --kernel-trace --pmc $pmc --output-format csv -d $out/pmc$i -- $cmd > $out/pmc$i.log 2>&1
