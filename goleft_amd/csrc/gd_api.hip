@@ -875,6 +875,10 @@ int gd_set_option(gd_ctx* c, int option, int64_t value)
         if (value < 0 || value > 120 * 1024) return fail(c, GD_E_INVALID, "inflate LDS pad: 0 .. 122880 bytes");
         c->inflate_pad = (unsigned)value;
         break;
+    case GD_OPT_INFLATE_PROBE:
+        if (value < 0 || value > 3) return fail(c, GD_E_INVALID, "inflate probe: 0 .. 3 (measurement only)");
+        c->inflate_probe = (unsigned)value;
+        break;
     case GD_OPT_INGEST_PIECE_STREAMS:
         if (value < 1 || value > 4) return fail(c, GD_E_INVALID, "ingest piece streams: 1 .. 4");
         if (c->ing_n) return fail(c, GD_E_STATE, "a device BAM read is pending");

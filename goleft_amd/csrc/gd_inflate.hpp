@@ -68,6 +68,9 @@ struct InflateJob {
     uint8_t* out;                  // (readable up to 64 bytes past the last member)
     uint32_t* status;              // [n] 0 ok, else an error code (18: CRC32 mismatch)
     uint32_t n;
+    uint32_t probe;                // MEASUREMENT ONLY (GD_OPT_INFLATE_PROBE; 0 in every product path): bit 0 -- the source of a match is
+                                   // never loaded from memory (the ring's bytes instead: WRONG output, the decode itself does not
+                                   // depend on it); bit 1 -- whole 64-byte blocks are not stored.  What the kernel's time is made of.
 };
 
 constexpr size_t INF_SLACK = 256;  // bytes the inflate buffers are allocated beyond their contents
@@ -429,7 +432,7 @@ __global__ __launch_bounds__(INF_LANES) void gd_inflate_kernel(InflateJob job)
         inf_v4 cl = {0, 0, 0, 0};
         const bool cload = cpend && !csmall;
         const uint32_t sa = obase + co - deff;             // where the chunk's source begins (ao); it ends at or before co
-        const bool from_mem = cload && sa + 16u <= fl;     // completely stored -- else completely inside the ring
+        const bool from_mem = cload && sa + 16u <= fl && !(job.probe & 1u);   // completely stored -- else completely inside the ring
         GD_INFLATE_PROBE(2, from_mem ? 1u : (cload ? 2u : 0u));
         GD_INFLATE_PROBE(4, from_mem ? sa : 0xffffffffu);
         GD_INFLATE_PROBE(5, from_mem ? deff : 0u);
@@ -555,7 +558,8 @@ __global__ __launch_bounds__(INF_LANES) void gd_inflate_kernel(InflateJob job)
             // aligned 64-byte block, back to back (at most one block per iteration: the output grows by 16 bytes at most)
             if (ao >= fl + 64u) {
                 const uint32_t j0 = (fl >> 2) & 31u;       // 0 or 16
-                if (fl >= obase) {
+                if (job.probe & 2u) {
+                } else if (fl >= obase) {
 #pragma unroll
                     for (uint32_t q = 0; q < 4u; ++q) {
                         inf_v4 v;
@@ -641,22 +645,27 @@ __global__ __launch_bounds__(256) void gd_inflate_crc_kernel(InflateJob job)
     if ((c ^ 0xffffffffu) != job.crc[m]) job.status[m] = 18;
 }
 
-// The same check with ONE WAVE PER MEMBER (end of round 4).  With a lane per member every lane streams through its own
-// 64 KB: the lines a workgroup's 256 lanes are in the middle of (32 KB, 256 KB per CU at eight workgroups) do not stay in L1,
-// and with ~100 000 members in flight not in L2 either -- each 8-byte step fetches a line again; the kernel took a third
-// of the inflate kernel's own time (12 ms per 27 000 members next to 33 ms, profiles/r10..: `gd_inflate_crc_kernel`).  Here
-// the 64 lanes of a wave share one member: lane l takes the 1 KB that ends (63 - l) KB before the member's end (a CRC
-// register that starts at zero ignores leading zero bytes, so the slices are aligned to the END and the first one is
-// simply shorter; the lane that holds byte 0 starts from 0xffffffff instead), eight lines per lane over its 128 steps, all
-// of a wave's lines inside one 64 KB region.  CRC is linear over GF(2): the member's register is the XOR of every lane's
-// register advanced over the zero bytes that follow its slice -- (63 - l) KB, a fixed operator per lane: the product of
-// the 32 x 32 bit matrices Z^(1 KB * 2^j) for the set bits j of 63 - l, built once per workgroup by squaring the
-// one-zero-byte matrix fifteen times.  Workgroups of four waves walk the members in a grid-stride loop.
+// The same check with ONE WAVE PER MEMBER, every byte fetched ONCE (round 5).  With a lane per member every lane streams
+// through its own 64 KB: the lines a workgroup's 256 lanes are in the middle of stay neither in L1 nor, with ~100 000 members in
+// flight, in L2 -- each 8-byte step fetches its line again; that kernel took a third of the inflate kernel's own time.  Round 4's
+// first wave-per-member form gave lane l the 1 KB slice that ends (63 - l) KB before the member's end: 3.5 x faster (13.7 ms
+// against 48 ms for 108 k members, profiles/r12a_*), but a wave instruction still touched 64 different lines and FETCH_SIZE
+// said 102 GB for those members' 7 GB -- a line came back from memory for every 8-byte step that used it.  Here a wave
+// instruction reads ONE KILOBYTE OF CONTIGUOUS MEMORY: the member is cut into rows of 1 KB aligned to its END, lane l takes
+// the 16 bytes at l * 16 of every row (one 16-byte load), so a lane's bytes are 16 of every 1024.  CRC is linear over GF(2):
+// a lane carries its register over the 1008 bytes between two of its pieces with a FIXED operator (Z^1008 as four byte
+// tables: four look-ups), runs its 16 bytes through two slicing-by-8 steps, and at the end the member's register is the XOR of
+// every lane's register advanced over the (63 - l) * 16 bytes behind its last piece -- the product of the 32 x 32 bit
+// matrices Z^(16 * 2^j) for the set bits j of 63 - l.  Rows aligned to the END: the first row is simply shorter (bytes in
+// front of the member are zeros to a register that starts at zero), and the CRC's initial value 0xffffffff is the same as
+// inverting the member's first four bytes.  Workgroups of four waves walk the members in a grid-stride loop.
 __global__ __launch_bounds__(256) void gd_inflate_crc_wave_kernel(InflateJob job)
 {
-    __shared__ uint32_t s_crc[8][256];                     // as above
+    __shared__ uint32_t s_crc[8][256];                     // as above: s_crc[k][b] = b followed by k zero bytes
+    __shared__ uint32_t s_adv[4][256];                     // Z^1008 by bytes: s_adv[k][b] = (b << 8k) advanced over 1008 zero bytes
     __shared__ uint32_t s_z[2][32];                        // squaring scratch: Z^(2^k) bytes, column b = image of bit b
-    __shared__ uint32_t s_zk[6][32];                       // Z^(1024 * 2^j), j = 0 .. 5
+    __shared__ uint32_t s_zk[6][32];                       // Z^(16 * 2^j), j = 0 .. 5
+    __shared__ uint32_t s_z1008[32];
     __shared__ uint32_t s_red[4][64];
     {
         uint32_t c = threadIdx.x;
@@ -674,20 +683,22 @@ __global__ __launch_bounds__(256) void gd_inflate_crc_wave_kernel(InflateJob job
         if (threadIdx.x < 32) {
             const uint32_t v = 1u << threadIdx.x;
             s_z[0][threadIdx.x] = (v >> 8) ^ s_crc[0][v & 0xffu];
+            s_z1008[threadIdx.x] = v;                        // the identity: the product of Z^(2^k) over the set bits k of 1008 grows here
         }
     }
     __syncthreads();
-    for (int k = 0; k < 15; ++k) {                         // s_z[k & 1] = Z^(2^k) -> s_z[(k + 1) & 1] = its square
+    auto mat_vec = [](const uint32_t* M, uint32_t v) { uint32_t y = 0; for (int b = 0; b < 32; ++b) y ^= M[b] & (0u - ((v >> b) & 1u)); return y; };
+    for (int k = 0; k < 10; ++k) {                         // s_z[k & 1] = Z^(2^k)
+        const uint32_t* const M = s_z[k & 1];
         if (threadIdx.x < 32) {
-            const uint32_t* const M = s_z[k & 1];
-            const uint32_t v = M[threadIdx.x];
-            uint32_t y = 0;
-            for (int b = 0; b < 32; ++b) y ^= M[b] & (0u - ((v >> b) & 1u));
-            s_z[(k + 1) & 1][threadIdx.x] = y;
-            if (k + 1 >= 10) s_zk[k + 1 - 10][threadIdx.x] = y;
+            if (k >= 4) s_zk[k - 4][threadIdx.x] = M[threadIdx.x];               // Z^16 .. Z^512
+            if ((1008u >> k) & 1u) s_z1008[threadIdx.x] = mat_vec(M, s_z1008[threadIdx.x]);   // 1008 = 2^4 + 2^5 + 2^6 + 2^7 + 2^8 + 2^9
+            s_z[(k + 1) & 1][threadIdx.x] = mat_vec(M, M[threadIdx.x]);          // its square
         }
         __syncthreads();
     }
+    for (int k = 0; k < 4; ++k) s_adv[k][threadIdx.x] = mat_vec(s_z1008, (uint32_t)threadIdx.x << (8 * k));
+    __syncthreads();
     const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     for (uint32_t base = blockIdx.x * 4u; base < job.n; base += gridDim.x * 4u) {
         const uint32_t m = base + w;
@@ -695,31 +706,45 @@ __global__ __launch_bounds__(256) void gd_inflate_crc_wave_kernel(InflateJob job
         uint32_t c = 0;
         if (live) {
             const uint8_t* const out = job.out + job.out_off[m];
-            const int64_t olen = (int64_t)job.out_len[m];
-            // this lane's slice: [olen - (64 - lane) KB, olen - (63 - lane) KB), clipped at the member's start
-            // (lane 0 takes whatever lies in front of the last 63 KB: nothing more than its 1 KB in a BGZF member, whose ISIZE is
-            // at most 64 KB -- but a trailer that claims more is then checked over all of its bytes too)
-            const int64_t e = olen - (int64_t)(63u - lane) * 1024, b0 = lane == 0u ? 0 : e - 1024;
-            if (e > 0 || (olen == 0 && lane == 63u)) {       // (an empty member: the last lane carries the initial value alone)
-                int64_t k = b0 > 0 ? b0 : 0;
-                c = b0 <= 0 ? 0xffffffffu : 0u;            // the slice that holds byte 0 carries the CRC's initial value
-                for (; k + 8 <= e; k += 8) {
-                    uint32_t w0, w1;
-                    __builtin_memcpy(&w0, out + k, 4);
-                    __builtin_memcpy(&w1, out + k + 4, 4);
-                    w0 ^= c;
-                    c = s_crc[7][w0 & 0xffu] ^ s_crc[6][(w0 >> 8) & 0xffu] ^ s_crc[5][(w0 >> 16) & 0xffu] ^ s_crc[4][w0 >> 24] ^
-                        s_crc[3][w1 & 0xffu] ^ s_crc[2][(w1 >> 8) & 0xffu] ^ s_crc[1][(w1 >> 16) & 0xffu] ^ s_crc[0][w1 >> 24];
+            const int64_t n = (int64_t)job.out_len[m];
+            if (n < 4) {                                     // (shorter than the initial value: byte by byte, one lane)
+                if (lane == 63u) {
+                    c = 0xffffffffu;
+                    for (int64_t k = 0; k < n; ++k) c = s_crc[0][(c ^ out[k]) & 0xffu] ^ (c >> 8);
                 }
-                for (; k < e; ++k) c = s_crc[0][(c ^ out[k]) & 0xffu] ^ (c >> 8);
-                // ... advanced over the (63 - lane) KB that follow
+            } else {
+                const int64_t rows = (n + 1023) >> 10;
+                // this lane's piece of row r: [n - (rows - r) * 1024 + 16 * lane, + 16)
+                int64_t at = n - rows * 1024 + 16 * (int64_t)lane;
+                for (int64_t r = 0; r < rows; ++r, at += 1024) {
+                    if (at + 16 <= 0) continue;              // in front of the member: zeros to a register that is still zero
+                    inf_v4 q = {0, 0, 0, 0};
+                    if (at >= 0) q = inf_load16(out + at);
+                    if (at < 4) {
+                        // the piece that holds byte 0 (the bytes in front of it are another member's: loaded one by one), and
+                        // the CRC's initial value: the member's first four bytes inverted (they may lie in two lanes' pieces)
+                        uint32_t d[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+                        for (int k = 0; k < 16; ++k) {
+                            const int64_t pos = at + k;
+                            if (at < 0 && pos >= 0) d[k >> 2] |= (uint32_t)out[pos] << (8 * (k & 3));
+                            if (pos >= 0 && pos < 4) d[k >> 2] ^= 0xffu << (8 * (k & 3));
+                        }
+                        q = inf_v4{d[0], d[1], d[2], d[3]};
+                    }
+                    // over the 1008 bytes since this lane's last piece, then through the piece's 16 bytes
+                    c = s_adv[0][c & 0xffu] ^ s_adv[1][(c >> 8) & 0xffu] ^ s_adv[2][(c >> 16) & 0xffu] ^ s_adv[3][c >> 24];
+                    uint32_t w0 = q.x ^ c;
+                    c = s_crc[7][w0 & 0xffu] ^ s_crc[6][(w0 >> 8) & 0xffu] ^ s_crc[5][(w0 >> 16) & 0xffu] ^ s_crc[4][w0 >> 24] ^
+                        s_crc[3][q.y & 0xffu] ^ s_crc[2][(q.y >> 8) & 0xffu] ^ s_crc[1][(q.y >> 16) & 0xffu] ^ s_crc[0][q.y >> 24];
+                    w0 = q.z ^ c;
+                    c = s_crc[7][w0 & 0xffu] ^ s_crc[6][(w0 >> 8) & 0xffu] ^ s_crc[5][(w0 >> 16) & 0xffu] ^ s_crc[4][w0 >> 24] ^
+                        s_crc[3][q.w & 0xffu] ^ s_crc[2][(q.w >> 8) & 0xffu] ^ s_crc[1][(q.w >> 16) & 0xffu] ^ s_crc[0][q.w >> 24];
+                }
+                // ... advanced over the (63 - lane) * 16 bytes that follow this lane's last piece
                 const uint32_t after = 63u - lane;
                 for (int j = 0; j < 6; ++j)
-                    if ((after >> j) & 1u) {
-                        uint32_t y = 0;
-                        for (int b = 0; b < 32; ++b) y ^= s_zk[j][b] & (0u - ((c >> b) & 1u));
-                        c = y;
-                    }
+                    if ((after >> j) & 1u) c = mat_vec(s_zk[j], c);
             }
         }
         s_red[w][lane] = c;

@@ -233,6 +233,9 @@ enum { /* (1, 2: tile shapes other than 4096 positions x 256 threads -- measured
                                        kernel instead of a copy command (the copy engine and a kernel share the link); 0 (default) */
        GD_OPT_INFLATE_LDS_PAD = 16,   /* bytes of LDS every workgroup of the inflate kernel claims on top of its tables: 0 (default) ..
                                        122880.  An occupancy limiter for measurements (fewer members in flight per CU) */
+       GD_OPT_INFLATE_PROBE = 20,     /* MEASUREMENT ONLY, the inflated bytes are WRONG when set: 0 (default); bit 0: the inflate kernel never
+                                       loads a match's source from memory; bit 1: it stores no whole 64-byte blocks.  What bounds the kernel:
+                                       its decode, its loads or its stores (profiles/r12*) */
        GD_OPT_H2D_KERNEL = 8 };     /* how a committed staging block reaches HBM: 1 (default) one kernel whose workgroups
                                        read the page-locked block over the link (all five arrays in one launch; n > 1:
                                        with n workgroups), 0: five hipMemcpyAsync through a DMA engine */
