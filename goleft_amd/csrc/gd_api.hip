@@ -47,11 +47,7 @@ const char* gd_strerror(int s)
 int gd_abi_version(void) { return GD_ABI_VERSION; }
 int gd_build_features(void)
 {
-#ifdef GD_WITH_CANONICAL
-    return GD_FEATURE_CANONICAL;
-#else
     return 0;
-#endif
 }
 
 int gd_device_count(int* n)
@@ -827,9 +823,7 @@ int gd_set_option(gd_ctx* c, int option, int64_t value)
     case GD_OPT_NT_STORES: c->tile_opt = value ? 1 : 0; break;
     case GD_OPT_NORMALIZE:
         if (value < 0 || value > 2) return fail(c, GD_E_INVALID, "GD_OPT_NORMALIZE: 0, 1 or 2");
-#ifndef GD_WITH_CANONICAL
         if (value == 1) return fail(c, GD_E_INVALID, "GD_OPT_NORMALIZE = 1: this build holds no canonical records (csrc/Makefile: make CANONICAL=1)");
-#endif
         c->normalize = (int)value;
         break;
     case GD_OPT_FAST_KERNEL: c->fast_kernel = value != 0; break;

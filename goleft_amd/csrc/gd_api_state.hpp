@@ -54,7 +54,8 @@ struct ContigHost {
     uint4*    lrec = nullptr;          // n_reads + 2 long-read records {pos, end, list offset, deletions}; [n_reads + 1].x = the largest span
     uint32_t* lfq = nullptr;           // n_reads: flag << 8 | MAPQ
     uint2*    dl = nullptr;            // (canonical ops >> 1) + n_reads + 1 deletions {start, length}
-    uint32_t* pck = nullptr;           // tile indexes (gd_ptile_fill_kernel)
+    uint32_t* pck = nullptr;           // tile indexes (filled by gd_dels_raw_kernel)
+    uint32_t* ndel = nullptr;          // deletions per read
     int32_t   max_span = 0;
     uint64_t  n_dels = 0;              // deletions in dl
     bool ck_ok = false;                // lrec / lfq / dl / pck describe the current records
@@ -343,7 +344,7 @@ void drop_ck(ContigHost& h)
 {
     h.ck_blk.reset();                  // (hipFree of the block, when this was its last user, waits for the device)
     h.pck_blk.reset();
-    h.lrec = nullptr; h.lfq = nullptr; h.dl = nullptr; h.pck = nullptr;
+    h.lrec = nullptr; h.lfq = nullptr; h.dl = nullptr; h.pck = nullptr; h.ndel = nullptr;
     h.max_span = 0;
     h.n_dels = 0;
     h.ck_ok = false;
@@ -452,14 +453,6 @@ void launch_tile(gd_ctx* c, const gd::Job& job)
                 hipLaunchKernelGGL((gd::fast::gd_tile_fast_kernel<0, true>), dim3(grid), dim3(256), 0, c->stream, job);
             return;
         }
-#ifdef GD_WITH_CANONICAL
-        if (!c->keep_perbase)
-            hipLaunchKernelGGL((gd::fast::gd_tile_fast_kernel<2>), dim3(grid), dim3(256), 0, c->stream, job);
-        else if (c->tile_opt & 1)
-            hipLaunchKernelGGL((gd::fast::gd_tile_fast_kernel<1>), dim3(grid), dim3(256), 0, c->stream, job);
-        else
-            hipLaunchKernelGGL((gd::fast::gd_tile_fast_kernel<0>), dim3(grid), dim3(256), 0, c->stream, job);
-#endif
         return;
     }
     if (!c->keep_perbase)
@@ -525,47 +518,47 @@ int batch_host(gd_ctx* c, size_t words)
     return GD_OK;
 }
 
-// Long-read path: deletion lists, read records and tile indexes (gd_chunk.hpp) of a batch of contigs, from their
-// canonical CIGARs.  With `enqueue_only_before` (the caller is norm_batch, whose kernels are still in flight and whose
-// totals are not known yet) the lists are sized from the ORIGINAL op counts.  One host synchronisation for the sizes
-// of the tile indexes, one allocation for all of them.
+// Long-read path: deletion lists, read records and tile indexes (gd_chunk.hpp) of a batch of contigs, straight from the
+// records as they arrived: ONE allocation sized from the record counts alone (deletion lists: half the ops + a slot per
+// read; tile indexes: an entry per 64 ops + three per read -- gd_chunk.hpp pt_slot), ONE pass (gd_dels_raw_kernel fills the
+// index as it walks), one small kernel that puts every contig's deletion total and largest span into page-locked memory.
+// Until round 5 the index was three more launches with a host synchronisation and a second allocation between them.
 struct CkPending {
     std::vector<ContigHost*> hs;
-    BlockRef blk, keep_pck;
-    size_t o_jobs = 0, o_tot = 0, o_span = 0;
-    std::vector<size_t> o_lrec, o_lfq, o_dl, o_unit, o_ndel;
+    BlockRef blk;
+    size_t o_jobs = 0, o_tot = 0;
+    std::vector<size_t> o_lrec, o_lfq, o_dl, o_ndel, o_pck;
     uint32_t n_units = 0;
     gd::DelBatch B{};
 };
 
-// raw: straight from the records as they arrived (gd_dels_raw_kernel); else from the canonical CIGARs
-int ck_enqueue(gd_ctx* c, const std::vector<ContigHost*>& hs, bool ops_known, CkPending* P, bool raw = false)
+int ck_enqueue(gd_ctx* c, const std::vector<ContigHost*>& hs, CkPending* P)
 {
     P->hs = hs;
     const size_t nj = hs.size();
     if (nj == 0) return GD_OK;
     BlockRef keep = hs[0]->ck_blk;
-    P->keep_pck = hs[0]->pck_blk;
     for (ContigHost* h : hs) drop_ck(*h);
     Carve cv;
     uint64_t units = 0;
-    P->o_lrec.resize(nj); P->o_lfq.resize(nj); P->o_dl.resize(nj); P->o_unit.resize(nj); P->o_ndel.resize(nj);
+    P->o_lrec.resize(nj); P->o_lfq.resize(nj); P->o_dl.resize(nj); P->o_ndel.resize(nj); P->o_pck.resize(nj);
     for (size_t k = 0; k < nj; ++k) {
         const ContigHost& h = *hs[k];
         const size_t n = h.n_reads;
-        const size_t n_dl = ((ops_known && !raw ? h.n_nops : h.n_ops) >> 1) + n + 1;
+        const size_t n_dl = (h.n_ops >> 1) + n + 1;
+        const size_t n_pck = (h.n_ops >> 6) + 3 * n + 4;      // (< 2^32: at most 2^30 reads and 2^32 ops per contig)
         if (n_dl > 0xffffffffull) return fail(c, GD_E_RANGE, "too many deletions on one contig");
         P->o_lrec[k] = cv.take((n + 2) * sizeof(uint4));
         P->o_lfq[k] = cv.take((n + 1) * sizeof(uint32_t));
         P->o_ndel[k] = cv.take((n + 1) * sizeof(uint32_t));
         P->o_dl[k] = cv.take(n_dl * sizeof(uint2));
+        P->o_pck[k] = cv.take(n_pck * sizeof(uint32_t));
         units += (n + 63) / 64;
     }
     if (units > (1ull << 26) - 64) return fail(c, GD_E_RANGE, "too many records in one batch (internal error)");
     P->n_units = (uint32_t)units;
-    const size_t o_unit = cv.take((units + 2) * sizeof(uint32_t));
     P->o_jobs = cv.take(nj * sizeof(gd::DelJob) + (nj + 1) * sizeof(uint32_t));   // the jobs, then ubeg
-    P->o_tot = cv.take(3 * nj * sizeof(uint32_t));               // [index entries][deletions][largest span] per contig
+    P->o_tot = cv.take(3 * nj * sizeof(uint32_t));               // [unused][deletions][largest span] per contig
     if (int r = batch_block(c, std::move(keep), cv.at, &P->blk)) return r;
     char* const base = static_cast<char*>(P->blk->p);
     // job table (host copy kept in the context until the next batch)
@@ -578,8 +571,8 @@ int ck_enqueue(gd_ctx* c, const std::vector<ContigHost*>& hs, bool ops_known, Ck
         const uint32_t n = (uint32_t)h.n_reads, nu = (n + 63u) / 64u;
         gd::DelJob& j = jobs[k];
         j.pos = h.pos; j.flag = h.flag; j.mapq = h.mapq;
-        j.off = raw ? h.off : h.noff;
-        j.cigar = raw ? h.cigar : h.ncig;
+        j.off = h.off;
+        j.cigar = h.cigar;
         j.n_reads = n; j.n_units = nu;
         j.lrec = reinterpret_cast<uint4*>(base + P->o_lrec[k]);
         j.lfq = reinterpret_cast<uint32_t*>(base + P->o_lfq[k]);
@@ -587,8 +580,8 @@ int ck_enqueue(gd_ctx* c, const std::vector<ContigHost*>& hs, bool ops_known, Ck
         j.ndel = reinterpret_cast<uint32_t*>(base + P->o_ndel[k]);
         j.del_total = reinterpret_cast<uint32_t*>(base + P->o_tot) + nj + k;
         j.max_span = reinterpret_cast<int32_t*>(j.lrec + n + 1);
-        j.unit = reinterpret_cast<uint32_t*>(base + o_unit) + u;
-        j.pck = nullptr;
+        j.unit = nullptr;
+        j.pck = reinterpret_cast<uint32_t*>(base + P->o_pck[k]);
         j.total = reinterpret_cast<uint32_t*>(base + P->o_tot) + k;
         ubeg[k] = u;
         u += nu;
@@ -603,25 +596,14 @@ int ck_enqueue(gd_ctx* c, const std::vector<ContigHost*>& hs, bool ops_known, Ck
     for (size_t k = 0; k < nj; ++k)                          // lrec[n], lrec[n + 1] (the span accumulator)
         HIPCHK(c, hipMemsetAsync(base + P->o_lrec[k] + hs[k]->n_reads * sizeof(uint4), 0, 2 * sizeof(uint4), c->stream));
     HIPCHK(c, hipMemsetAsync(base + P->o_tot, 0, 2 * nj * sizeof(uint32_t), c->stream));
-    if (P->n_units) {
-        const unsigned grid = (P->n_units + 3u) / 4u;
-        if (raw) hipLaunchKernelGGL(gd::gd_dels_raw_kernel, dim3(grid), dim3(256), 0, c->stream, B);
-#ifdef GD_WITH_CANONICAL
-        else hipLaunchKernelGGL(gd::gd_dels_kernel, dim3(grid), dim3(256), 0, c->stream, B);
-#else
-        else return fail(c, GD_E_INVALID, "this build holds no canonical records (csrc/Makefile: make CANONICAL=1)");
-#endif
-        hipLaunchKernelGGL(gd::gd_ptile_count_kernel, dim3(grid), dim3(256), 0, c->stream, B);
-        if (int r = launch_scan(c, reinterpret_cast<uint32_t*>(base + o_unit), P->n_units)) return r;
-    } else {
-        HIPCHK(c, hipMemsetAsync(base + o_unit, 0, 2 * sizeof(uint32_t), c->stream));
-    }
+    if (P->n_units)
+        hipLaunchKernelGGL(gd::gd_dels_raw_kernel, dim3((P->n_units + 3u) / 4u), dim3(256), 0, c->stream, B);
     hipLaunchKernelGGL(gd::gd_ptile_totals_kernel, dim3((unsigned)((nj + 255) / 256)), dim3(256), 0, c->stream, B);
     HIPCHK(c, hipGetLastError());
     return GD_OK;
 }
 
-// host words the totals of a ck batch take in gd_ctx::h_batch: [n_jobs index sizes][n_jobs deletion counts][n_jobs spans]
+// host words the totals of a ck batch take in gd_ctx::h_batch: [n_jobs unused][n_jobs deletion counts][n_jobs spans]
 int ck_readback(gd_ctx* c, const CkPending& P, uint32_t* dst)
 {
     const size_t nj = P.hs.size();
@@ -634,34 +616,17 @@ int ck_readback(gd_ctx* c, const CkPending& P, uint32_t* dst)
     return GD_OK;
 }
 
-// after the synchronisation: allocate the tile indexes, fill them, publish
+// after the synchronisation: publish (the spans are the look-back of the tile table)
 int ck_finish(gd_ctx* c, CkPending& P, const uint32_t* tot)
 {
     const size_t nj = P.hs.size();
     if (nj == 0) return GD_OK;
-    char* const base = static_cast<char*>(P.blk->p);
-    Carve cv;
-    std::vector<size_t> o_pck(nj);
-    for (size_t k = 0; k < nj; ++k) {
-        const int32_t span = (int32_t)tot[2 * nj + k];
-        // the index's 32-bit offsets cannot have wrapped if even this bound fits
-        if ((uint64_t)P.hs[k]->n_reads * (((uint64_t)(uint32_t)span >> gd::PT_SHIFT) + 2) > 0xffffffffull)
-            return fail(c, GD_E_RANGE, "long-read path: %zu reads spanning up to %d bases -- the tile index would not fit 2^32 entries",
-                        P.hs[k]->n_reads, span);
-        o_pck[k] = cv.take(((size_t)tot[k] + 1) * sizeof(uint32_t));
-    }
-    BlockRef pck;
-    if (int r = batch_block(c, std::move(P.keep_pck), cv.at, &pck)) return r;
     gd::DelJob* jobs = reinterpret_cast<gd::DelJob*>(c->batch_tab_ck.data());
-    for (size_t k = 0; k < nj; ++k) jobs[k].pck = reinterpret_cast<uint32_t*>(static_cast<char*>(pck->p) + o_pck[k]);
-    HIPCHK(c, hipMemcpyAsync(base + P.o_jobs, c->batch_tab_ck.data(), nj * sizeof(gd::DelJob), hipMemcpyHostToDevice, c->stream));
-    if (P.n_units)
-        hipLaunchKernelGGL(gd::gd_ptile_fill_kernel, dim3((P.n_units + 3u) / 4u), dim3(256), 0, c->stream, P.B);
-    HIPCHK(c, hipGetLastError());
     for (size_t k = 0; k < nj; ++k) {
         ContigHost& h = *P.hs[k];
-        h.ck_blk = P.blk; h.pck_blk = pck;
-        h.lrec = jobs[k].lrec; h.lfq = jobs[k].lfq; h.dl = jobs[k].dl; h.pck = jobs[k].pck;
+        h.ck_blk = P.blk;
+        h.pck_blk.reset();
+        h.lrec = jobs[k].lrec; h.lfq = jobs[k].lfq; h.dl = jobs[k].dl; h.pck = jobs[k].pck; h.ndel = jobs[k].ndel;
         h.max_span = (int32_t)tot[2 * nj + k];
         h.n_dels = tot[nj + k];
         h.ck_ok = true;
@@ -669,17 +634,15 @@ int ck_finish(gd_ctx* c, CkPending& P, const uint32_t* tot)
     return GD_OK;
 }
 
-// Builds the long-read structures of contigs whose canonical CIGARs exist already.
-int ck_batch(gd_ctx* c, const std::vector<ContigHost*>& hs, bool raw = false)
+// Builds the long-read structures of a batch of contigs.
+int ck_batch(gd_ctx* c, const std::vector<ContigHost*>& hs)
 {
     if (hs.empty()) return GD_OK;
-    for (const ContigHost* h : hs)
-        if (!raw && !h->normed) return fail(c, GD_E_STATE, "long-read path: a contig has no canonical CIGARs (internal error)");
     HIPCHK(c, hipEventRecord(c->copy_done, c->copy_stream));
     HIPCHK(c, hipStreamWaitEvent(c->stream, c->copy_done, 0));
     if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[6], c->stream));
     CkPending P;
-    if (int r = ck_enqueue(c, hs, true, &P, raw)) return r;
+    if (int r = ck_enqueue(c, hs, &P)) return r;
     if (int r = batch_host(c, 3 * hs.size())) return r;
     if (int r = ck_readback(c, P, c->h_batch)) return r;
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -699,163 +662,12 @@ int ck_batch(gd_ctx* c, const std::vector<ContigHost*>& hs, bool raw = false)
 // also get their long-read structures, enqueued behind the same kernels.  Afterwards h.normed is set.
 int norm_batch(gd_ctx* c, const std::vector<ContigHost*>& hs, const std::vector<ContigHost*>& with_ck)
 {
-#ifndef GD_WITH_CANONICAL
     // Canonical records (gd_normalize.hpp: a rewritten copy of the CIGARs, record words, a position index) serve a host that
     // computes the SAME records many times; no caller in the reference does, and every default path reads the records as they
     // arrived.  They are an optional part of the build (csrc/Makefile: make CANONICAL=1) -- without it this is the one place
     // that could have built them.
     (void)hs; (void)with_ck;
     return fail(c, GD_E_INVALID, "this build holds no canonical records (csrc/Makefile: make CANONICAL=1)");
-#else
-    const size_t nj = hs.size();
-    if (nj == 0) return ck_batch(c, with_ck);
-    BlockRef keep = hs[0]->norm_blk;
-    for (ContigHost* h : hs) drop_norm(*h);
-    Carve cv;
-    std::vector<size_t> o_noff(nj), o_nrec(nj), o_ncig(nj), o_pidx(nj);
-    uint64_t units = 0, idxs = 0;
-    for (size_t k = 0; k < nj; ++k) {
-        const ContigHost& h = *hs[k];
-        const size_t n = h.n_reads;
-        o_noff[k] = cv.take((n + 1) * sizeof(uint32_t));
-        o_nrec[k] = cv.take((n + 4) * sizeof(uint32_t));
-        o_ncig[k] = cv.take(std::max<size_t>(h.n_ops, 1) * sizeof(uint32_t));
-        o_pidx[k] = cv.take(((size_t)(h.length >> 6) + 2) * sizeof(uint32_t));
-        units += (n + 63) / 64;
-        idxs += (uint64_t)(h.length >> 6) + 2;
-    }
-    if (units > (1ull << 26) - 64) return fail(c, GD_E_RANGE, "too many records in one batch (internal error)");
-    if (idxs > 0xfffffff0ull) return fail(c, GD_E_RANGE, "the contigs of one batch are too long for one position-index launch");
-    const size_t o_unit = cv.take((units + 2) * sizeof(uint32_t));
-    const size_t tab_bytes = nj * sizeof(gd::norm::NormJob) + 3 * (nj + 1) * sizeof(uint32_t);
-    const size_t o_tab = cv.take(tab_bytes);
-    const size_t o_out = cv.take(2 * nj * sizeof(uint32_t));             // [totals][status words]
-    // the fused pass: rows x 256 reads per workgroup (few ops per read -> many reads), a look-back word per workgroup
-    bool fused = c->fused_norm;
-    std::vector<uint32_t> rows(nj, 4u);
-    uint64_t n_blocks = 0;
-    for (size_t k = 0; k < nj; ++k) {
-        const ContigHost& h = *hs[k];
-        const uint64_t avg = h.n_reads ? (h.n_ops + h.n_reads - 1) / h.n_reads : 0;
-        rows[k] = avg <= 3 ? 4u : avg <= 6 ? 2u : 1u;
-        // long reads never fit the LDS staging: four waves of a workgroup walking them from memory between barriers
-        // measured slower than the unit-per-wave kernels (35 vs 24 ms on the 20x ONT genome): those batches keep them
-        if (avg > 6) fused = false;
-        n_blocks += (h.n_reads + rows[k] * 256u - 1) / (rows[k] * 256u);
-    }
-    const size_t o_bstat = cv.take((n_blocks + 1) * sizeof(unsigned long long) + 16);   // look-back words, then the ticket pair
-    BlockRef blk;
-    if (int r = batch_block(c, std::move(keep), cv.at, &blk)) return r;
-    char* const base = static_cast<char*>(blk->p);
-    static_assert(sizeof(gd::norm::NormJob) % 8 == 0, "the ubeg / ibeg tables follow the jobs");
-    c->batch_tab.assign(tab_bytes, 0);
-    gd::norm::NormJob* jobs = reinterpret_cast<gd::norm::NormJob*>(c->batch_tab.data());
-    uint32_t* ubeg = reinterpret_cast<uint32_t*>(c->batch_tab.data() + nj * sizeof(gd::norm::NormJob));
-    uint32_t* ibeg = ubeg + nj + 1;
-    uint32_t* bbeg = ibeg + nj + 1;
-    uint32_t u = 0, ix = 0, bb = 0;
-    for (size_t k = 0; k < nj; ++k) {
-        const ContigHost& h = *hs[k];
-        const uint32_t n = (uint32_t)h.n_reads, nu = (n + 63u) / 64u;
-        gd::norm::NormJob& j = jobs[k];
-        j.pos = h.pos;
-        j.pidx = reinterpret_cast<uint32_t*>(base + o_pidx[k]);
-        j.n_idx = (uint32_t)(h.length >> 6) + 2u;
-        j.off = h.off; j.cigar = h.cigar; j.flag = h.flag; j.mapq = h.mapq;
-        j.rec = reinterpret_cast<uint32_t*>(base + o_nrec[k]);
-        j.status = reinterpret_cast<uint32_t*>(base + o_out) + nj + k;
-        j.n_reads = n; j.n_units = nu;
-        j.noff = reinterpret_cast<uint32_t*>(base + o_noff[k]);
-        j.unit = reinterpret_cast<uint32_t*>(base + o_unit) + u;
-        j.ncig = reinterpret_cast<uint32_t*>(base + o_ncig[k]);
-        j.total = reinterpret_cast<uint32_t*>(base + o_out) + k;
-        j.rows = rows[k]; j.blk_beg = bb;
-        ubeg[k] = u; ibeg[k] = ix; bbeg[k] = bb;
-        u += nu; ix += j.n_idx;
-        bb += (uint32_t)(((uint64_t)n + rows[k] * 256u - 1) / (rows[k] * 256u));
-    }
-    ubeg[nj] = u; ibeg[nj] = ix; bbeg[nj] = bb;
-    gd::norm::NormBatch B{};
-    B.jobs = reinterpret_cast<const gd::norm::NormJob*>(base + o_tab);
-    B.ubeg = reinterpret_cast<const uint32_t*>(base + o_tab + nj * sizeof(gd::norm::NormJob));
-    B.ibeg = B.ubeg + nj + 1;
-    B.bbeg = B.ibeg + nj + 1;
-    B.n_jobs = (uint32_t)nj; B.n_units = u; B.n_idx = ix;
-    B.n_blocks = bb;
-    B.bstat = reinterpret_cast<unsigned long long*>(base + o_bstat);
-    B.ticket = reinterpret_cast<uint32_t*>(B.bstat + n_blocks + 1);
-    // records staged on the copy stream must have landed
-    HIPCHK(c, hipEventRecord(c->copy_done, c->copy_stream));
-    HIPCHK(c, hipStreamWaitEvent(c->stream, c->copy_done, 0));
-    HIPCHK(c, hipMemcpyAsync(base + o_tab, c->batch_tab.data(), tab_bytes, hipMemcpyHostToDevice, c->stream));
-    if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[5], c->stream));
-    hipLaunchKernelGGL(gd::norm::gd_norm_init_kernel, dim3((unsigned)((nj + 255) / 256)), dim3(256), 0, c->stream, B);
-    if (fused) {
-        // ONE pass: count, offsets (decoupled look-back), write and the position index (gd_norm_fused_kernel)
-        HIPCHK(c, hipMemsetAsync(base + o_bstat, 0, (n_blocks + 1) * sizeof(unsigned long long) + 16, c->stream));
-        for (size_t k = 0; k < nj; ++k)                       // a contig without records has no workgroup: its index is all zero
-            if (hs[k]->n_reads == 0)
-                HIPCHK(c, hipMemsetAsync(jobs[k].pidx, 0, (size_t)jobs[k].n_idx * sizeof(uint32_t), c->stream));
-        if (bb) hipLaunchKernelGGL(gd::norm::gd_norm_fused_kernel, dim3(bb), dim3(256), 0, c->stream, B);
-    } else {
-        if (u) {
-            hipLaunchKernelGGL(gd::norm::gd_norm_count_kernel, dim3((u + 3u) / 4u), dim3(256), 0, c->stream, B);
-            if (int r = launch_scan(c, reinterpret_cast<uint32_t*>(base + o_unit), u)) return r;
-            hipLaunchKernelGGL(gd::norm::gd_norm_write_kernel, dim3((u + 3u) / 4u), dim3(256), 0, c->stream, B);
-        }
-        hipLaunchKernelGGL(gd::norm::gd_pidx_kernel, dim3((ix + 255u) / 256u), dim3(256), 0, c->stream, B);
-    }
-    HIPCHK(c, hipGetLastError());
-    if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[6], c->stream));
-    // publish the pointers now: the long-read structures are enqueued from them
-    for (size_t k = 0; k < nj; ++k) {
-        ContigHost& h = *hs[k];
-        h.norm_blk = blk;
-        h.noff = jobs[k].noff; h.ncig = jobs[k].ncig; h.nrec = jobs[k].rec; h.pidx = jobs[k].pidx;
-    }
-    CkPending P;
-    const size_t nck = with_ck.size();
-    if (int r = batch_host(c, 2 * nj + 3 * nck + 2)) return r;
-    HIPCHK(c, hipMemcpyAsync(c->h_batch, base + o_out, 2 * nj * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-    uint32_t* const h_tick = c->h_batch + 2 * nj + 3 * with_ck.size();
-    h_tick[0] = h_tick[1] = 0;
-    if (fused) HIPCHK(c, hipMemcpyAsync(h_tick, B.ticket, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-    int rc = GD_OK;
-    if (nck) {
-        rc = ck_enqueue(c, with_ck, false, &P);
-        if (rc == GD_OK) rc = ck_readback(c, P, c->h_batch + 2 * nj);
-    }
-    hipError_t se = hipStreamSynchronize(c->stream);           // ONE wait: totals and status words (and the index sizes)
-    if (se != hipSuccess || rc != GD_OK) {
-        for (ContigHost* h : hs) drop_norm(*h);
-        if (rc != GD_OK) return rc;
-        return fail(c, GD_E_HIP, "normalisation failed: %s", hipGetErrorString(se));
-    }
-    if (fused && h_tick[1] != 0) {
-        for (ContigHost* h : hs) drop_norm(*h);
-        return fail(c, GD_E_HIP, "normalisation: a look-back gave up (internal error)");
-    }
-    for (size_t k = 0; k < nj; ++k) {
-        ContigHost& h = *hs[k];
-        h.n_nops = c->h_batch[k];
-        h.rec_ok = c->h_batch[nj + k] == 0;
-        h.normed = true;
-    }
-    if (nck)
-        if (int r = ck_finish(c, P, c->h_batch + 2 * nj)) return r;
-    if (c->profiling) {
-        HIPCHK(c, hipEventRecord(c->ev[7], c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        float ms = 0;
-        HIPCHK(c, hipEventElapsedTime(&ms, c->ev[5], c->ev[6]));
-        c->kernel_ms[GD_K_NORM] += ms;
-        if (nck) {
-            HIPCHK(c, hipEventElapsedTime(&ms, c->ev[6], c->ev[7]));
-            c->kernel_ms[GD_K_CKPT] += ms;
-        }
-    }
-    return GD_OK;
-#endif
 }
 
 bool wants_norm(const gd_ctx* c, uint64_t, uint64_t)
@@ -912,31 +724,29 @@ int norm_tids(gd_ctx* c, const std::vector<int32_t>& tids, bool force, bool ck_a
     return GD_OK;
 }
 
-// The long-read structures of the listed contigs that lack them: from the canonical CIGARs where a contig has them,
-// else straight from the records as they arrived -- no canonical arrays are built for it (GD_OPT_NORMALIZE 0 / 2).
+// The long-read structures of the listed contigs that lack them, straight from the records as they arrived.
 int ck_tids(gd_ctx* c, const std::vector<int32_t>& tids)
 {
+    // A launch holds fewer than 2^32 work-items (the dispatch packet's grid size is 32 bits; a larger grid wraps
+    // silently): at one wave per 64-read unit that is 2^26 units, so a very large job is several batches.
     constexpr uint64_t kMaxUnits = 48u << 20;
-    for (int pass = 0; pass < 2; ++pass) {
-        std::vector<ContigHost*> part;
-        uint64_t units = 0;
-        auto flush = [&]() -> int {
-            if (part.empty()) return GD_OK;
-            const int r = ck_batch(c, part, pass == 1);
-            part.clear(); units = 0;
-            return r;
-        };
-        for (int32_t tid : tids) {
-            ContigHost& h = c->contigs[tid];
-            if (h.length <= 0 || h.ck_ok || (h.normed ? pass != 0 : pass != 1)) continue;
-            if (!part.empty() && units + (h.n_reads + 63) / 64 > kMaxUnits)
-                if (int r = flush()) return r;
-            units += (h.n_reads + 63) / 64;
-            part.push_back(&h);
-        }
-        if (int r = flush()) return r;
+    std::vector<ContigHost*> part;
+    uint64_t units = 0;
+    auto flush = [&]() -> int {
+        if (part.empty()) return GD_OK;
+        const int r = ck_batch(c, part);
+        part.clear(); units = 0;
+        return r;
+    };
+    for (int32_t tid : tids) {
+        ContigHost& h = c->contigs[tid];
+        if (h.length <= 0 || h.ck_ok) continue;
+        if (!part.empty() && units + (h.n_reads + 63) / 64 > kMaxUnits)
+            if (int r = flush()) return r;
+        units += (h.n_reads + 63) / 64;
+        part.push_back(&h);
     }
-    return GD_OK;
+    return flush();
 }
 
 // RAII for the scratch device buffers of gd_ingest_bgzf

@@ -77,12 +77,31 @@ struct DelJob {
     uint32_t* del_total;      // out: deletions of the contig
     int32_t*  max_span;       // atomicMax of end - pos
     // the tile index (PT kernels below)
-    uint32_t* unit;           // this contig's slice of the batch's unit array: n_units + 1 entries per 64-read unit, then
-                              // (after the scan) exclusive offsets over the batch: unit[k] - unit[0] is the contig's own
-    uint32_t* pck;            // the index
-    uint32_t* total;          // out: its entries
+    uint32_t* unit;           // (canonical route only) this contig's slice of the batch's unit array
+    uint32_t* pck;            // the index: (n_ops >> 6) + 3 n_reads + 4 entries, read r's at pt_slot(off[r], r)
+    uint32_t* total;          // out: [0] unused, [n_jobs] deletions of the contig, [2 n_jobs] its largest span
 };
 constexpr uint32_t PT_NONE = 0xffffffffu;
+constexpr uint32_t PT_SEARCH = 0xfffffffeu;   // the read has deletions but no tile index (its slots were too few): the tile kernel bisects its list
+
+// Round 5: the tile index is filled BY THE PASS THAT WRITES THE DELETION LISTS.  It used to be three more launches (entries
+// per read, a scan over the 64-read units, a fill pass in which every read bisected its own list per boundary) with a host
+// synchronisation and an allocation between them -- 1.6-2.3 ms of an 8.2 ms preparation, and the only reason the first
+// compute's enqueue could not run through.  The walk knows where every deletion starts as it goes: entry k of a read =
+// deletions that start before boundary ((pos >> 12) + k) << 12, and a group of ops that covers the reference positions
+// (cur, cur + tot] fixes exactly the boundaries inside that range -- deletions of earlier groups start before them, later
+// ones behind.  A group crosses a boundary once in five (4096 bases, ~13 per op): one scalar compare per group otherwise.
+// Where the entries live needs no prefix sum either: read r of a contig owns the slots (o >> 6) + 3 r .. ((o + n) >> 6) + 3 r + 2
+// (o its CSR offset, n its ops) -- enough whenever its ops average <= 64 reference bases; a read that needs more (a
+// spliced read: three ops, 100 kb) is marked PT_SEARCH and the tile kernel bisects its (short) list.
+// entries of a read's tile index: boundaries ((pos >> 12) + k) << 12, k = 0 .. K - 1, from the one at or before pos to the one
+// behind end (reads without deletions have none)
+__device__ __forceinline__ uint32_t pt_entries(uint32_t p, uint32_t e, uint32_t n_del)
+{
+    return (n_del != 0u && e >= p) ? (e >> PT_SHIFT) - (p >> PT_SHIFT) + 2u : 0u;   // (e < p: a negative POS)
+}
+__device__ __forceinline__ uint32_t pt_slot(uint32_t o0, uint32_t r) { return (o0 >> 6) + 3u * r; }
+__device__ __forceinline__ uint32_t pt_cap(uint32_t o0, uint32_t n) { return ((o0 + n) >> 6) - (o0 >> 6) + 3u; }
 
 // The long-read contigs of one batch: job j owns the 64-read units [ubeg[j], ubeg[j + 1]) of the batch.
 struct DelBatch {
@@ -92,105 +111,6 @@ struct DelBatch {
     uint32_t n_units;
 };
 
-#ifdef GD_WITH_CANONICAL   // (deletion lists from CANONICAL CIGARs: only with canonical records in the build)
-__global__ __launch_bounds__(256) void gd_dels_kernel(DelBatch B)
-{
-    const int lane = threadIdx.x & 63;
-    const uint32_t gunit = blockIdx.x * 4u + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    if (gunit >= B.n_units) return;
-    const uint32_t ji = (uint32_t)__builtin_amdgcn_readfirstlane((int)norm::batch_find(B.ubeg, B.n_jobs, gunit));
-    const DelJob job = B.jobs[ji];
-    const uint32_t unit = gunit - B.ubeg[ji];
-    const uint32_t n_reads = job.n_reads;
-    const uint32_t* const cigar = job.cigar;
-
-    const uint32_t r = unit * 64u + (uint32_t)lane;
-    const bool valid = r < n_reads;
-    uint32_t p = 0, o0 = 0, n = 0, fq = 0;
-    if (valid) {
-        p = (uint32_t)job.pos[r];
-        o0 = job.off[r];
-        n = job.off[r + 1] - o0;
-        fq = ((uint32_t)job.flag[r] << 8) | (uint32_t)job.mapq[r];
-    }
-    const uint32_t doff = (o0 >> 1) + r;                  // this read's deletion list
-    uint32_t endp = p;                                    // reference position after the last op
-
-    // short CIGARs: lane serial
-    if (n != 0u && n <= SHORT_OPS) {
-        for (uint32_t k = 0; k < n; ++k) {
-            const uint32_t cg = cigar[o0 + k];
-            const uint32_t len = cg >> 4;
-            if ((cg & 0xfu) != 0u) job.dl[doff + (k >> 1)] = make_uint2(endp, len);   // N: deletion number k >> 1
-            endp = sat_pos(endp + len);
-        }
-    }
-
-    // long CIGARs: the wave walks one read at a time, DL_UNROLL groups of 64 ops in flight
-    unsigned long long todo = __ballot(n > SHORT_OPS);
-    while (todo != 0ull) {
-        const int j = __ffsll((long long)todo) - 1;
-        todo &= todo - 1ull;
-        const uint32_t pj = (uint32_t)__builtin_amdgcn_readlane((int)p, j);
-        const uint32_t oj = (uint32_t)__builtin_amdgcn_readlane((int)o0, j);
-        const uint32_t nj = (uint32_t)__builtin_amdgcn_readlane((int)n, j);
-        const uint32_t dj = (uint32_t)__builtin_amdgcn_readlane((int)doff, j);
-        uint32_t run = pj;                                // reference position at the start of the group
-        for (uint32_t b = 0; b < nj; b += DL_UNROLL * 64u) {
-            uint32_t cg[DL_UNROLL];
-#pragma unroll
-            for (int u = 0; u < DL_UNROLL; ++u) {
-                const uint32_t k = b + (uint32_t)u * 64u + (uint32_t)lane;
-                cg[u] = k < nj ? cigar[oj + k] : 0u;
-            }
-            uint32_t len[DL_UNROLL], mx = 0;
-#pragma unroll
-            for (int u = 0; u < DL_UNROLL; ++u) { len[u] = cg[u] >> 4; mx |= len[u]; }
-            // where each op starts: four interleaved plain 32-bit scans unless an op consumes more than
-            // 2^24 bases (64 * 2^24 < 2^31: no wrap), then saturating scans
-            uint32_t excl[DL_UNROLL], tot[DL_UNROLL];
-            if (__builtin_amdgcn_ballot_w64(mx > (1u << 24)) == 0ull) {
-                int t[DL_UNROLL];
-#pragma unroll
-                for (int u = 0; u < DL_UNROLL; ++u) t[u] = (int)len[u];
-                static_assert(DL_UNROLL == 4, "one scan4 group");
-                scan4(t[0], t[1], t[2], t[3]);
-#pragma unroll
-                for (int u = 0; u < DL_UNROLL; ++u) {
-                    excl[u] = (uint32_t)t[u] - len[u];
-                    tot[u] = (uint32_t)__builtin_amdgcn_readlane(t[u], 63);
-                }
-            } else {
-#pragma unroll
-                for (int u = 0; u < DL_UNROLL; ++u) {
-                    const uint32_t inc = wave_inclusive_scan_sat(sat_pos(len[u]));
-                    excl[u] = (uint32_t)wave_prev_lane((int)inc, 0);
-                    tot[u] = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < DL_UNROLL; ++u) {
-                const uint32_t k = b + (uint32_t)u * 64u + (uint32_t)lane;
-                if (k < nj && (cg[u] & 0xfu) != 0u) {     // N: deletion number k >> 1 (M and N alternate)
-                    job.dl[dj + (k >> 1)] = make_uint2(sat_pos(run + excl[u]), len[u]);
-                }
-                run = sat_pos(run + tot[u]);
-            }
-        }
-        if (lane == j) endp = run;
-    }
-    if (valid) {
-        job.lrec[r] = make_uint4(p, endp, doff, PT_NONE);
-        job.lfq[r] = fq;
-        job.ndel[r] = n >> 1;                              // M and N alternate and the last op is an M
-    }
-    const uint32_t smax = wave_max_u32(n != 0u ? endp - p : 0u);
-    if (lane == 0 && smax != 0u) atomicMax(job.max_span, (int32_t)smax);
-    const uint32_t dsum = (uint32_t)wave_total((int)(valid ? n >> 1 : 0u));
-    if (lane == 0 && dsum != 0u) atomicAdd(job.del_total, dsum);
-}
-
-#endif  // GD_WITH_CANONICAL
 
 // ---- the same structures straight from the records AS THEY ARRIVED ------------------------------------------------
 // One pass over the original CIGARs: what gd_normalize.hpp's count + write passes and gd_dels_kernel do in three
@@ -331,10 +251,13 @@ constexpr uint32_t WAVE_DELS_MIN = 24;     // reads with more ops than this are 
 // of it on the scalar unit the four SIMDs of a CU share: 10.4 ms for a 20x genome.)  What merging bought is the bound
 // "at most half the ops are deletions" behind the dense list offset (op offset >> 1) + r; a read with more D/N ops
 // than its slots hold (cap) -- D D D ..., no aligner's output -- is walked again by the merging walk, which fits.
+// ix / ixcap: the read's tile index slots (entries 1 .. K - 2 are written here, the caller adds the first and the last)
 __device__ __forceinline__ uint32_t serial_dels_plain(const uint32_t* __restrict__ ops, uint32_t n, uint32_t pos,
-                                                      uint2* __restrict__ out, uint32_t cap, uint32_t& endp)
+                                                      uint2* __restrict__ out, uint32_t cap, uint32_t& endp,
+                                                      uint32_t* __restrict__ ix, uint32_t ixcap)
 {
     uint32_t x = pos, w = 0;
+    const uint32_t pk = pos >> PT_SHIFT;
     for (uint32_t k = 0; k < n; ++k) {
         const uint32_t cg = ops[k], op = cg & 0xfu, len = cg >> 4;
         if (!((0x18du >> op) & 1u) || len == 0u) continue;
@@ -342,15 +265,20 @@ __device__ __forceinline__ uint32_t serial_dels_plain(const uint32_t* __restrict
             if (w < cap) out[w] = make_uint2(x, len);
             ++w;
         }
-        x = sat_pos(x + len);
+        const uint32_t y = sat_pos(x + len);
+        // boundaries in (x, y]: every deletion so far (this op too, if it is one) starts before them
+        for (uint32_t kk = (x >> PT_SHIFT) + 1u; kk <= (y >> PT_SHIFT) && kk - pk < ixcap; ++kk) ix[kk - pk] = w;
+        x = y;
     }
     endp = x;
     return w;                                                          // > cap: the caller walks the read again
 }
 
 __device__ __forceinline__ uint32_t wave_dels_plain(const uint32_t* __restrict__ ops, uint32_t n, int lane, uint32_t pos,
-                                                    uint2* __restrict__ out, uint32_t cap, uint32_t& endp, bool& again)
+                                                    uint2* __restrict__ out, uint32_t cap, uint32_t& endp, bool& again,
+                                                    uint32_t* __restrict__ ix, uint32_t ixcap)
 {
+    const uint32_t pk = pos >> PT_SHIFT;
     uint32_t cur = pos, w = 0u;                                         // wave uniform
     again = false;
     uint32_t nxt[DL_UNROLL];
@@ -390,12 +318,21 @@ __device__ __forceinline__ uint32_t wave_dels_plain(const uint32_t* __restrict__
             const unsigned long long dm = __builtin_amdgcn_ballot_w64(dnv[u]);
             const uint32_t cnt = (uint32_t)__popcll(dm);
             if (w + cnt > cap) { again = true; return 0u; }
+            const uint32_t start = cur + (uint32_t)sc[u] - lenv[u];
             if (dnv[u]) {
                 const uint32_t rk = __builtin_amdgcn_mbcnt_hi((uint32_t)(dm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)dm, 0u));
-                out[w + rk] = make_uint2(cur + (uint32_t)sc[u] - lenv[u], lenv[u]);
+                out[w + rk] = make_uint2(start, lenv[u]);
+            }
+            const uint32_t nxt_cur = cur + (uint32_t)__builtin_amdgcn_readlane(sc[u], 63);
+            if ((nxt_cur >> PT_SHIFT) != (cur >> PT_SHIFT)) {           // (wave uniform, one group in five) the tile index:
+                // boundaries in (cur, nxt_cur]: the deletions before this group, and those of it that start before the boundary
+                for (uint32_t kk = (cur >> PT_SHIFT) + 1u; kk <= (nxt_cur >> PT_SHIFT) && kk - pk < ixcap; ++kk) {
+                    const uint32_t before = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(dnv[u] && start < (kk << PT_SHIFT)));
+                    if (lane == 0) ix[kk - pk] = w + before;
+                }
             }
             w += cnt;
-            cur += (uint32_t)__builtin_amdgcn_readlane(sc[u], 63);
+            cur = nxt_cur;
         }
     }
     endp = cur;
@@ -421,8 +358,10 @@ __global__ __launch_bounds__(256) void gd_dels_raw_kernel(DelBatch B)
     }
     const uint32_t doff = (o0 >> 1) + r;                  // the read's slots: up to the next read's (o1 >> 1) + r + 1
     const uint32_t cap = ((o0 + n) >> 1) - (o0 >> 1) + 1u;
+    const uint32_t pb = pt_slot(o0, r), pcap = pt_cap(o0, n);   // ... and its tile index slots
     uint32_t endp = p, nd = 0;
     bool serial = n <= WAVE_DELS_MIN;
+    bool merged = false;                                  // the list holds MERGED deletions (the fallback walks): no index
     unsigned long long todo = __builtin_amdgcn_ballot_w64(!serial);
     while (todo != 0ull) {                                // long reads: the wave walks one at a time
         const int j = __ffsll((long long)todo) - 1;
@@ -432,19 +371,34 @@ __global__ __launch_bounds__(256) void gd_dels_raw_kernel(DelBatch B)
         const uint32_t nj = (uint32_t)__builtin_amdgcn_readlane((int)n, j);
         const uint32_t dj = (uint32_t)__builtin_amdgcn_readlane((int)doff, j);
         const uint32_t cj = (uint32_t)__builtin_amdgcn_readlane((int)cap, j);
+        const uint32_t bj = (uint32_t)__builtin_amdgcn_readlane((int)pb, j);
+        const uint32_t kj = (uint32_t)__builtin_amdgcn_readlane((int)pcap, j);
         uint32_t ej = pj;
         bool ovf, again;
-        uint32_t wj = wave_dels_plain(job.cigar + oj, nj, lane, pj, job.dl + dj, cj, ej, again);
+        uint32_t wj = wave_dels_plain(job.cigar + oj, nj, lane, pj, job.dl + dj, cj, ej, again, job.pck + bj, kj);
         ovf = false;
         if (again) wj = wave_dels(job.cigar + oj, nj, lane, pj, job.dl + dj, ej, ovf);   // merged runs always fit
-        if (lane == j) { nd = wj; endp = ej; serial = ovf; }
+        if (lane == j) { nd = wj; endp = ej; serial = ovf; merged = again; }
     }
     if (serial && n != 0u) {
-        nd = serial_dels_plain(job.cigar + o0, n, p, job.dl + doff, cap, endp);
-        if (nd > cap) nd = serial_dels(job.cigar + o0, n, p, job.dl + doff, endp);
+        nd = serial_dels_plain(job.cigar + o0, n, p, job.dl + doff, cap, endp, job.pck + pb, pcap);
+        merged = nd > cap;
+        if (merged) nd = serial_dels(job.cigar + o0, n, p, job.dl + doff, endp);
     }
     if (valid) {
-        job.lrec[r] = make_uint4(p, endp, doff, PT_NONE);
+        // the index's first entry (nothing starts before the boundary at or before pos) and its last (everything starts
+        // before the one behind the end); the walk wrote the ones between
+        uint32_t iw = PT_NONE;
+        const uint32_t K = pt_entries(p, endp, nd);
+        if (K != 0u) {
+            iw = PT_SEARCH;
+            if (!merged && K <= pcap) {
+                job.pck[pb] = 0u;
+                job.pck[pb + K - 1u] = nd;
+                iw = pb;
+            }
+        }
+        job.lrec[r] = make_uint4(p, endp, doff, iw);
         job.lfq[r] = fq;
         job.ndel[r] = nd;
     }
@@ -454,87 +408,26 @@ __global__ __launch_bounds__(256) void gd_dels_raw_kernel(DelBatch B)
     if (lane == 0 && dsum != 0u) atomicAdd(job.del_total, dsum);
 }
 
-// PT: the tile index.  Entries of read r: boundaries b_k = ((pos >> 12) + k) << 12 for k = 0 .. K - 1 with
-// K = (end >> 12) - (pos >> 12) + 2 (reads without deletions have none); entry k = number of the read's
-// deletions that start before b_k.  (M and N alternate and the last op is an M: a read of n canonical ops has
-// n >> 1 deletions.)
-__device__ __forceinline__ uint32_t pt_entries(uint32_t p, uint32_t e, uint32_t n_del)
-{
-    return (n_del != 0u && e >= p) ? (e >> PT_SHIFT) - (p >> PT_SHIFT) + 2u : 0u;   // (e < p: a negative POS)
-}
-
-// PT1: entries per read -> offsets inside the unit (parked in lrec.w) and unit totals.
-__global__ __launch_bounds__(256) void gd_ptile_count_kernel(DelBatch B)
-{
-    const int lane = threadIdx.x & 63;
-    const uint32_t gunit = blockIdx.x * 4u + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    if (gunit >= B.n_units) return;
-    const uint32_t ji = (uint32_t)__builtin_amdgcn_readfirstlane((int)norm::batch_find(B.ubeg, B.n_jobs, gunit));
-    const DelJob job = B.jobs[ji];
-    const uint32_t unit = gunit - B.ubeg[ji];
-    const uint32_t r = unit * 64u + (uint32_t)lane;
-    uint32_t K = 0;
-    if (r < job.n_reads) {
-        const uint4 rc = job.lrec[r];
-        K = pt_entries(rc.x, rc.y, job.ndel[r]);
-    }
-    const uint32_t incl = (uint32_t)wave_inclusive_scan((int)K);
-    if (r < job.n_reads) job.lrec[r].w = K != 0u ? incl - K : PT_NONE;
-    if (lane == 63) job.unit[unit] = incl;
-}
-
-// Between the scan of the unit totals and PT2: every contig's number of index entries, for the host to allocate.
+// Every contig's largest span next to its deletion total ([unused x n][deletions x n][spans x n]): ONE read-back for the
+// batch instead of one 4-byte copy per contig.
 __global__ __launch_bounds__(256) void gd_ptile_totals_kernel(DelBatch B)
 {
     const uint32_t ji = blockIdx.x * 256u + threadIdx.x;
     if (ji >= B.n_jobs) return;
     const DelJob job = B.jobs[ji];
-    *job.total = job.unit[job.n_units] - job.unit[0];
-    // the contig's largest span next to its totals ([entries x n][deletions x n][spans x n]): ONE read-back for the batch
-    // instead of one 4-byte copy per contig
+    *job.total = 0u;
     job.total[2u * B.n_jobs] = (uint32_t)*job.max_span;
 }
 
-// PT2: one lane per read fills its entries (a binary search of its own, sorted, deletion list per boundary).
-__global__ __launch_bounds__(256) void gd_ptile_fill_kernel(DelBatch B)
+// deletions of a sorted list that start before `bound` (a read without a tile index: PT_SEARCH)
+__device__ __forceinline__ uint32_t pt_count_before(const uint2* __restrict__ d, uint32_t n, uint32_t bound)
 {
-    const int lane = threadIdx.x & 63;
-    const uint32_t gunit = blockIdx.x * 4u + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    if (gunit >= B.n_units) return;
-    const uint32_t ji = (uint32_t)__builtin_amdgcn_readfirstlane((int)norm::batch_find(B.ubeg, B.n_jobs, gunit));
-    const DelJob job = B.jobs[ji];
-    const uint32_t r = (gunit - B.ubeg[ji]) * 64u + (uint32_t)lane;
-    if (r >= job.n_reads) return;
-    const uint4 rc = job.lrec[r];
-    if (rc.w == PT_NONE) return;
-    const uint32_t n_del = job.ndel[r];
-    const uint32_t K = pt_entries(rc.x, rc.y, n_del);
-    const uint32_t pb = job.unit[r >> 6] - job.unit[0] + rc.w;
-    job.lrec[r].w = pb;
-    const uint2* const d = job.dl + rc.z;
-    uint32_t lo = 0;                                       // boundaries grow: the previous answer is a lower bound
-    // a read's deletions are spread over its span: where the one before boundary b lies is GUESSED from that (two probes
-    // 8 entries either side of the guess bracket it, three bisection steps finish; a miss bisects the side it is on) --
-    // a plain bisection per boundary was ~70 dependent loads per read, 2.3 ms for a 20x genome's 6 M reads
-    const uint32_t span = rc.y > rc.x ? rc.y - rc.x : 1u;
-    for (uint32_t k = 0; k < K; ++k) {
-        const uint64_t b = (uint64_t)((rc.x >> PT_SHIFT) + k) << PT_SHIFT;
-        uint32_t hi = n_del;
-        if (lo < hi) {
-            const uint64_t rel = b > rc.x ? b - rc.x : 0u;
-            uint32_t g = (uint32_t)((rel * n_del) / span);
-            g = g < lo ? lo : (g >= n_del ? n_del - 1u : g);
-            const uint32_t pl = g > lo + 8u ? g - 8u : lo, ph = n_del - 1u - g > 8u ? g + 8u : n_del - 1u;
-            const uint32_t vl = d[pl].x, vh = d[ph].x;
-            if ((uint64_t)vl < b) { lo = pl + 1u; if ((uint64_t)vh >= b) hi = ph; else lo = ph + 1u; }
-            else hi = pl;
-        }
-        while (lo < hi) {
-            const uint32_t mid = lo + ((hi - lo) >> 1);
-            if ((uint64_t)d[mid].x < b) lo = mid + 1; else hi = mid;
-        }
-        job.pck[pb + k] = lo;
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        if (d[mid].x < bound) lo = mid + 1u; else hi = mid;
     }
+    return lo;
 }
 
 // ---------------------------------------------------------------------------
@@ -665,7 +558,13 @@ __global__ __launch_bounds__(NT) void gd_ltile2_kernel(Job job)
                 const uint32_t k0 = (uint32_t)t0 > rc.x ? ((uint32_t)t0 >> PT_SHIFT) - pk : 0u;   // t0 <= end: k0 <= K - 2
                 uint32_t k1 = k0 + (uint32_t)(T >> PT_SHIFT);
                 k1 = k1 < K - 1u ? k1 : K - 1u;
-                const uint32_t a = pck[rc.w + k0], b = pck[rc.w + k1];
+                uint32_t a, b;
+                if (rc.w != PT_SEARCH) { a = pck[rc.w + k0]; b = pck[rc.w + k1]; }
+                else {                                         // no index (a read whose slots were too few): its list is bisected
+                    const uint32_t nd = ti.ndel[ti.lo + idx];
+                    a = k0 != 0u ? pt_count_before(dl + rc.z, nd, (pk + k0) << PT_SHIFT) : 0u;
+                    b = k1 == K - 1u ? nd : pt_count_before(dl + rc.z, nd, (pk + k1) << PT_SHIFT);
+                }
                 const uint32_t j0 = a != 0u ? a - 1u : 0u;
                 cur = rc.z + j0;
                 rem = b - j0;

@@ -60,6 +60,7 @@ struct ContigDev {
     const uint32_t* lfq;      // flag << 8 | MAPQ per read
     const uint2*    dl;       // deletion lists {start, length}
     const uint32_t* pck;      // tile indexes: deletions starting before every 4096-base boundary a read spans
+    const uint32_t* ndel;     // deletions of every read (the tile kernel bisects the list of a read without an index)
     const uint32_t* rec;      // record words (gd_normalize.hpp) of the canonical records, null otherwise
     const uint32_t* pidx;     // position index: first read with pos >= 64 k (gd_pidx_kernel, or gd_index_records_kernel as the
                               // records arrived); null: search `pos`
@@ -85,7 +86,8 @@ struct __attribute__((aligned(16))) TileInfo {
     uint32_t n_ops;           // CIGAR ops of the contig
     uint32_t clo, chi;        // CIGAR op range [off[lo], off[hi]) of those reads
     int32_t  tile;            // global tile id (the slow list of a fast run is compacted)
-    int32_t  pad_[3];
+    int32_t  pad_;
+    const uint32_t* ndel;     // long-read path: deletions per read (ContigDev::ndel)
     const uint4*    lrec;     // long-read path (ContigDev::lrec, ::lfq, ::dl, ::pck)
     const uint32_t* lfq;
     const uint2*    dl;
@@ -280,7 +282,8 @@ __global__ void gd_prep_kernel(Job job)
     ti.n_reads = c.n_reads; ti.n_ops = c.n_ops;
     ti.ctg = lo;
     ti.tile = t;
-    ti.pad_[0] = ti.pad_[1] = ti.pad_[2] = 0;
+    ti.pad_ = 0;
+    ti.ndel = c.ndel;
     ti.lrec = c.lrec; ti.lfq = c.lfq; ti.dl = c.dl; ti.pck = c.pck;
     ti.t0 = (t - c.tile_beg) * T;
     int32_t tend = ti.t0 + T < c.length ? ti.t0 + T : c.length;
