@@ -267,7 +267,7 @@ def expected_beds(which, W, chrom=None, live=False):
     return dict(r, source="oracle, committed: tests/golden/synth_bam_expected.json", key=key) if r else None
 
 
-def bam_file_scope(which, W, device_reps=3, host_decoder=True, pause_s=0.0, synth_env=None, paper=False, oracle_live=False):
+def bam_file_scope(which, W, device_reps=3, host_decoder=True, pause_s=0.0, synth_env=None, paper=False, oracle_live=False, devices=None):
     """SURVEY.md section 8d scope (iii), the only scope the reference itself runs and times (`time goleft depth ...`,
     indexcov/paper/cmp.sh:6): a BAM FILE -> depth.bed + callable.bed through the CLI twin, process start to exit.
     A synthetic but realistic coordinate-sorted BAM (tools/synth_bam.cpp: 150 bp records WITH SEQ and QUAL, BGZF, .bai)
@@ -331,7 +331,13 @@ def bam_file_scope(which, W, device_reps=3, host_decoder=True, pause_s=0.0, synt
                "synth_bam_s": t_write, "read_once_s": t_settle, "pause_before_each_run_s": pause_s,
                "written_to": tmp, "host_cores": os.cpu_count(), "usable_cpus": usable_cpus(), "unit": "ref-bases/s"}
         beds = {}
-        runs = [("device", {}, device_reps)] + ([("host", {"GOLEFT_GPU_DECODE": "0"}, 1)] if host_decoder else [])
+        # devices: GOLEFT_DEVICES for the CLI -- one engine context + worker thread per listed device, contigs by LPT, rows
+        # merged in input order by the main thread (the in-process counterpart of the reference's -p pool,
+        # depth/depth.go:392-421)
+        dev_env = {"GOLEFT_DEVICES": devices} if devices else {}
+        if devices:
+            out["devices"] = devices
+        runs = [("device", dev_env, device_reps)] + ([("host", {"GOLEFT_GPU_DECODE": "0"}, 1)] if host_decoder else [])
 
         def one_run(decoder, env, extra, stem):
             if pause_s:
@@ -536,17 +542,61 @@ def run_case(args, scaling, world, rank, dev, local_rank, want_streams=False):
         # on a fixed capacity, buffers are allocated once and the engine is told to fill the send
         # buffer itself (gd_set_export)
         eng.compute()
-        native = os.environ.get("GOLEFT_BENCH_NATIVE_GATHER") == "1"
+        # The collective a cgo host would call is the library's own (gd_comm_init / gd_gather_export: RCCL opened by the C
+        # ABI, include/goleft_depth.h) -- the default since round 5; the 128-byte id travels through the process group
+        # that exists anyway.  Every rank must take the same road: the ranks agree (MIN over "it came up here") and fall
+        # back to torch.distributed's gather together when RCCL cannot be opened through the library anywhere
+        # (GD_E_NODEVICE) or the communicator does not come up; GOLEFT_BENCH_NATIVE_GATHER=0 asks for the fallback.
+        native = os.environ.get("GOLEFT_BENCH_NATIVE_GATHER", "1") != "0"
+        native_note = "asked for" if not native else ""
         if native:
-            # the library's own collective (gd_comm_init / gd_gather_export: RCCL opened by the C ABI, what a cgo host
-            # calls); the 128-byte id travels through the process group that exists anyway
             from goleft_amd.engine import comm_unique_id
-            box = [comm_unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(box, src=0)
-            eng.comm_init(rank, world, box[0])
+            fdev = dev if dist.get_backend() == "nccl" else "cpu"   # (dry runs over gloo: host tensors)
+            ok, box = 1, [None]
+            if rank == 0:
+                try:
+                    box = [comm_unique_id()]
+                except Exception as e:                  # GdError: RCCL not available through the library
+                    ok, native_note = 0, "gd_comm_unique_id: %s" % e
+            flag = torch.tensor([ok], dtype=torch.int32, device=fdev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()):
+                dist.broadcast_object_list(box, src=0)
+                try:
+                    eng.comm_init(rank, world, box[0])
+                except Exception as e:
+                    ok, native_note = 0, "gd_comm_init: %s" % e
+                flag = torch.tensor([ok], dtype=torch.int32, device=fdev)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                if not int(flag.item()) and ok:
+                    eng.comm_destroy()
+            native = bool(int(flag.item()))
+            if not native and not native_note:
+                native_note = "another rank could not bring the library's communicator up"
         gath = shard.RootGather(assignment, lengths, W, rank, world, dev, bounds_cap=0, native=native)
         gath.reserve(eng.device_runs()[1])
         gath.attach(eng)
+        gath.fallback_note = native_note
+        if native:
+            # one step through EACH collective before anything is timed: what rank 0 received through the library's
+            # gather must be what torch.distributed's gather delivers for the same export blocks
+            eng.compute(); gath.step_exported(); gath.drain()
+            torch.cuda.synchronize()
+            got = gath.recv.clone() if rank == 0 else None
+            ref = shard.RootGather(assignment, lengths, W, rank, world, dev, bounds_cap=gath.cap_b, native=False)
+            ref.attach(eng)
+            eng.compute(); ref.step_exported(); ref.drain()
+            torch.cuda.synchronize()
+            same = 1
+            if rank == 0:
+                same = int(bool(torch.equal(got, ref.recv)))
+            t = torch.tensor([same], dtype=torch.int32, device=dev if dist.get_backend() == "nccl" else "cpu")
+            dist.broadcast(t, src=0)
+            gath.native_verified = bool(int(t.item()))
+            del ref
+            gath.attach(eng)                            # (the export block points at this gather's buffers again)
+            if not gath.native_verified:
+                raise SystemExit("bench.py: gd_gather_export delivered other words than torch.distributed's gather")
 
     def step(inclusive=True):
         if derive and inclusive:
@@ -681,6 +731,8 @@ def run_case(args, scaling, world, rank, dev, local_rank, want_streams=False):
                  "lpt_speedup_ceiling": sum(loads) / max(loads),
                  "gather_bytes_per_rank": int(gath.total * 8), "bounds_capacity": int(gath.cap_b),
                  "collective": "gd_gather_export (RCCL from the C ABI)" if gath.native else "torch.distributed gather",
+                 "collective_verified_against_torch_gather": getattr(gath, "native_verified", None),
+                 "collective_fallback_reason": getattr(gath, "fallback_note", "") or None,
                  "pipelined": "in the timed loop a step is finish(k-1); flip(); launch(k); post(): the asynchronous, "
                               "double-buffered gather of step k-1 and its host-side cost run under the kernels of step k; "
                               "compute_ms / gather_ms here are measured one after the other"}
@@ -1234,6 +1286,39 @@ def main():
         except Exception as e:                       # never lose the headline line to the secondary case
             out["cohort_weak_scaling"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if world > 1:
+        torch.cuda.empty_cache()
+        dist.barrier()                                  # every rank has closed its engine: the devices are free
+        file_ngpu = args.workload == "wgs" and args.scaling == "strong" and not single and \
+            os.environ.get("GOLEFT_BENCH_SKIP_FILE_NGPU") != "1"
+        store = None
+        if file_ngpu:
+            try:
+                store = dist.distributed_c10d._get_default_store()   # the ranks wait on the HOST (a barrier would spin a kernel on every device)
+            except Exception:
+                store = None
+        if rank == 0 and file_ngpu:
+            # the file scope over the node's N devices: ONE `goleft-depth` process, GOLEFT_DEVICES=0..N-1 (what a user of
+            # an N-GPU node runs); BED files checked against the oracle's.  The other ranks wait at the barrier below.
+            try:
+                torch.cuda.empty_cache()
+                which = "genome" if (os.cpu_count() or 1) >= 64 else "chr20-21"
+                res = bam_file_scope(which, W, device_reps=2, host_decoder=False, pause_s=8.0 if which == "genome" else 2.0,
+                                     devices=",".join(str(i) for i in range(world)))
+                out["bam_file_scope_ngpu"] = {k: res.get(k) for k in ("what", "file", "devices", "ref_bases", "bam_bytes", "deflate", "records",
+                                                                       "wall_s", "value", "unit", "bgzf_GBps", "bed_sha256", "oracle_identical",
+                                                                       "oracle_source", "synth_bam_s", "error") if k in res}
+                out["bam_file_scope_ngpu"]["all_wall_s"] = (res.get("device_decoder") or {}).get("all_wall_s")
+                out["bam_file_scope_ngpu"]["phases"] = (res.get("device_decoder") or {}).get("phases")
+            except Exception as e:                       # never lose the headline line to a side measurement
+                out["bam_file_scope_ngpu"] = {"error": "%s: %s" % (type(e).__name__, e)}
+            if store is not None:
+                store.set("goleft_file_ngpu_done", "1")
+        elif file_ngpu and store is not None:
+            import datetime
+            try:
+                store.wait(["goleft_file_ngpu_done"], datetime.timedelta(minutes=30))
+            except Exception:
+                pass
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:

@@ -129,6 +129,8 @@ void gd_destroy(gd_ctx* c)
     for (hipStream_t st : c->ing_stream) if (st) (void)hipStreamDestroy(st);
     for (hipStream_t st : c->ing_dma) if (st) (void)hipStreamDestroy(st);
     if (c->ing_hp) (void)hipStreamDestroy(c->ing_hp);
+    if (c->ing_walk) (void)hipStreamDestroy(c->ing_walk);
+    if (c->ing_walk_ev) (void)hipEventDestroy(c->ing_walk_ev);
     for (auto& evs : c->ing_dma_ev) for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
     for (auto& b : c->ing_bufs) b.drop_all();
     if (c->h_walk) (void)hipHostFree(c->h_walk);
@@ -868,6 +870,14 @@ int gd_set_option(gd_ctx* c, int option, int64_t value)
     case GD_OPT_INFLATE_LDS_PAD:
         if (value < 0 || value > 120 * 1024) return fail(c, GD_E_INVALID, "inflate LDS pad: 0 .. 122880 bytes");
         c->inflate_pad = (unsigned)value;
+        break;
+    case GD_OPT_INGEST_BATCHES:
+        if (value < 1 || value > 64) return fail(c, GD_E_INVALID, "ingest batches: 1 .. 64 inflate launches per range");
+        c->ing_batches = (int)value;
+        break;
+    case GD_OPT_INGEST_WALK_CUS:
+        if (c->ing_walk) return fail(c, GD_E_STATE, "the ingest streams exist already: set GD_OPT_INGEST_WALK_CUS before the first gd_ingest_begin");
+        c->ing_walk_cus = value != 0;
         break;
     case GD_OPT_INFLATE_PROBE:
         if (value < 0 || value > 3) return fail(c, GD_E_INVALID, "inflate probe: 0 .. 3 (measurement only)");

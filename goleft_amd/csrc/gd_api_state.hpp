@@ -245,6 +245,10 @@ struct gd_ctx {
     hipStream_t ing_dma[3] = {nullptr, nullptr, nullptr};   // GD_OPT_INGEST_DMA > 1: a staged piece leaves in slices on several streams (DMA engines)
     hipEvent_t ing_dma_ev[8][3] = {};
     int ing_dma_n = 1;
+    hipStream_t ing_walk = nullptr;                     // GD_OPT_INGEST_WALK_CUS: the record walks' stream, masked to the copy kernel's CUs
+    int ing_walk_cus = 0;
+    hipEvent_t ing_walk_ev = nullptr;
+    int ing_batches = 8;                                // GD_OPT_INGEST_BATCHES
     hipStream_t ing_hp = nullptr;                       // GD_OPT_INGEST_DMA 0: the piece leaves with a copy kernel on a high-priority stream
     hipStream_t ing_stream[8] = {};                     // inflate launches rotate over these (two pending ranges x 4)
     unsigned ing_launch_seq = 0;

@@ -646,6 +646,8 @@ int run(const DArgs& args)
             GDCHK_ON(sh.ctx, gd_set_option(sh.ctx, GD_OPT_INGEST_CU_SPLIT, 8));
         if (getenv("GOLEFT_INGEST_PIECE_STREAMS")) GDCHK_ON(sh.ctx, gd_set_option(sh.ctx, GD_OPT_INGEST_PIECE_STREAMS, env_int("GOLEFT_INGEST_PIECE_STREAMS", 1)));
         if (getenv("GOLEFT_INGEST_CU_SPLIT")) GDCHK_ON(sh.ctx, gd_set_option(sh.ctx, GD_OPT_INGEST_CU_SPLIT, env_int("GOLEFT_INGEST_CU_SPLIT", 0)));
+        if (getenv("GOLEFT_INGEST_BATCHES")) GDCHK_ON(sh.ctx, gd_set_option(sh.ctx, GD_OPT_INGEST_BATCHES, env_int("GOLEFT_INGEST_BATCHES", 8)));
+        if (getenv("GOLEFT_INGEST_WALK_CUS")) GDCHK_ON(sh.ctx, gd_set_option(sh.ctx, GD_OPT_INGEST_WALK_CUS, env_int("GOLEFT_INGEST_WALK_CUS", 0)));
         if (getenv("GOLEFT_INGEST_HYBRID")) GDCHK_ON(sh.ctx, gd_set_option(sh.ctx, GD_OPT_INGEST_HYBRID, env_int("GOLEFT_INGEST_HYBRID", 0)));
         if (getenv("GOLEFT_INFLATE_LDS_PAD")) GDCHK_ON(sh.ctx, gd_set_option(sh.ctx, GD_OPT_INFLATE_LDS_PAD, env_int("GOLEFT_INFLATE_LDS_PAD", 0)));
         if (env_int("GOLEFT_TRUST_BGZF", 0)) GDCHK_ON(sh.ctx, gd_set_option(sh.ctx, GD_OPT_INGEST_CRC, 0));

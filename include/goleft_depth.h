@@ -233,6 +233,11 @@ enum { /* (1, 2: tile shapes other than 4096 positions x 256 threads -- measured
                                        kernel instead of a copy command (the copy engine and a kernel share the link); 0 (default) */
        GD_OPT_INFLATE_LDS_PAD = 16,   /* bytes of LDS every workgroup of the inflate kernel claims on top of its tables: 0 (default) ..
                                        122880.  An occupancy limiter for measurements (fewer members in flight per CU) */
+       GD_OPT_INGEST_BATCHES = 21,    /* inflate launches per fed range: 8 (default), 1 .. 64 -- the members of a range are handed to the
+                                       inflate kernel in this many launches as their bytes arrive */
+       GD_OPT_INGEST_WALK_CUS = 22,   /* with GD_OPT_INGEST_CU_SPLIT: 1: the record walks of a decode run on the copy kernel's CUs (a
+                                       CU-masked stream of their own) instead of beside the inflate workgroups, whose LDS leaves a
+                                       walk one workgroup per CU; 0 (default) */
        GD_OPT_INFLATE_PROBE = 20,     /* MEASUREMENT ONLY, the inflated bytes are WRONG when set: 0 (default); bit 0: the inflate kernel never
                                        loads a match's source from memory; bit 1: it stores no whole 64-byte blocks.  What bounds the kernel:
                                        its decode, its loads or its stores (profiles/r12*) */

@@ -58,6 +58,29 @@ def test_wgs_bench_line_has_the_contract_fields():
     assert e["8"]["projected_speedup"] >= 6.0                           # north_star: >= 6x aggregate at 8 GPUs
     for k in ("host_stream_scope", "host_stream_scope_wgs"):
         assert set(d[k]["variants"]) == {"push", "in_place"} and d[k]["value"] > 3e9
+    # round 5: BASELINE.json's configs 2, 4 and 5 ride in the same line, each with its cold step and its own roofline
+    ow = d["other_workloads"]
+    assert set(ow) == {"chr20", "ont", "cohort"}
+    for name, cfg, kernel in (("chr20", 2, "gd_tile_fast_kernel<raw>"), ("cohort", 4, "gd_sums_stream_kernel<raw>"), ("ont", 5, "gd_ltile2_kernel")):
+        w = ow[name]
+        assert "error" not in w, (name, w.get("error"))
+        assert w["baseline_config"] == cfg and w["unit"] == "ref-bases/s" and w["roofline"]["kernel"] == kernel
+        r = w["roofline"]
+        assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["avg_kernel_ms"] * 1e-3) / 1e9) / r["achieved"] < 1e-6
+        assert abs(w["value"] - w["total_ref_bases"] / (w["ms_per_step"] * 1e-3)) / w["value"] < 1e-6
+        assert w["first_compute"]["ms"] > 0 and w["first_compute"]["reruns"] == 0 and w["value_first_compute"] > 0
+        assert w["value"] >= 1e9                                        # every config clears BASELINE.json's 1-GPU target
+    assert sum(w["seconds_in_bench"] for w in ow.values()) < 60
+    assert ow["ont"]["kernels_ms"]["long_read_structures"] > 0 and ow["ont"]["device_path"] == "chunk"
+    # ... the BAM-file scope is checked against the ORACLE (not only decoder against decoder), on records as an aligner leaves
+    # them too, and holds the reference's own timed invocation
+    assert b["oracle_identical"] is True and b["oracle_bed_sha256"] == b["bed_sha256"]
+    assert set(b["variants"]) == {"libdeflate1_short_records", "libdeflate6_aux_tags"}
+    for v in b["variants"].values():
+        assert v["outputs_identical"] is True and v["oracle_identical"] is True and v["device_wall_s"] < v["host_wall_s"]
+    assert "tags" in b["variants"]["libdeflate6_aux_tags"]["records"] and "level 6" in b["variants"]["libdeflate6_aux_tags"]["deflate"]
+    pi = b["paper_invocation"]
+    assert pi["oracle_identical"] is True and 0 < b["paper_invocation_s"] == pi["wall_s"] < 2.0 and pi["ref_bases"] == 249250621
 
 
 def test_product_never_uses_the_oracle():
