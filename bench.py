@@ -11,11 +11,9 @@ A step = one pass of the hot path over the rank's HBM-resident record streams AS
 THEY CROSSED THE C ABI (pos / flag / MAPQ / CSR offsets / BAM-encoded CIGAR ops,
 nothing derived): gd_compute (prep + tile + run-ordering kernels, synchronous)
 -- the short-read tile kernel reads those records directly -- and, where the
-path needs derived structures (long reads: canonical CIGARs, deletion lists,
-tile indexes; the cohort's streaming sums: canonical records), their
-construction (gd_normalize(force)) INSIDE every step: what one `goleft depth`
-run pays per input.  "compute_only" in the line is the same step with the
-derived structures kept from step to step (what round 2 reported as `value`).
+path needs derived structures (long reads: deletion lists, read records, tile
+indexes), their construction (gd_rebuild_derived) INSIDE every step: what one `goleft depth`
+run pays per input.
 When ONE genome is shared by N > 1 GPUs a step also holds the gather of window
 sums/minima and run boundaries to rank 0 over RCCL (the only exchange the path
 has):
@@ -668,41 +666,6 @@ def run_case(args, scaling, world, rank, dev, local_rank, want_streams=False):
         # deletion lists built straight from the records: a deletion is what an (M, N) pair of canonical ops was
         incl_canon = 2 * int(st_incl.n_deletions) + n_reads
 
-    # ---- the same step with the derived structures KEPT from step to step (round 2's `value`) --------------
-    only = None
-    from goleft_amd.engine import has_canonical
-    if world == 1 and has_canonical():              # (an optional part of the build: csrc/Makefile CANONICAL=1)
-        eng.set_profiling(True)
-        t1 = time.perf_counter()
-        eng.normalize(True)                         # one batch: one allocation, one launch set, one synchronisation
-        torch.cuda.synchronize()
-        wall_first = time.perf_counter() - t1
-        eng.set_profiling(True)
-        t1 = time.perf_counter()
-        eng.normalize(True)                         # again, into the block it already holds
-        torch.cuda.synchronize()
-        wall = time.perf_counter() - t1
-        nk, ck = eng.kernel_ms(K_NORM), eng.kernel_ms(K_CKPT)
-        eng.set_profiling(False)
-        for _ in range(args.warmup):
-            step(False)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            step(False)
-        torch.cuda.synchronize()
-        dt_only = time.perf_counter() - t1
-        k_only = []
-        eng.set_profiling(True)
-        for _ in range(args.steps):
-            step(False)
-            k_only.append(eng.kernel_ms(K_TILE) + eng.kernel_ms(K_EXPAND) + eng.kernel_ms(K_SCAN))
-        eng.set_profiling(False)
-        sto = eng.stats()
-        only = {"dt": dt_only, "tile_ms": float(np.mean(k_only)), "kernel": TK_NAMES[int(sto.tile_kernel)],
-                "n_canonical_ops": int(sto.n_canonical_ops), "normalise_wall_ms": wall * 1e3,
-                "normalise_wall_first_ms": wall_first * 1e3, "normalise_kernels_ms": nk, "checkpoint_kernels_ms": ck}
-
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -792,7 +755,7 @@ def run_case(args, scaling, world, rank, dev, local_rank, want_streams=False):
         "tile_ms": float(np.mean(tile_ms)), "prep_ms": float(np.mean(prep_ms)),
         "runs_ms": float(np.mean(runs_ms)), "tile_positions": st.tile_positions, "lookback": st.lookback,
         "expand_ms": float(np.mean(expand_ms)), "scan_ms": float(np.mean(scan_ms)), "path": int(st.path),
-        "ckpt_ms": float(np.mean(ckpt_ms)), "norm_ms": float(np.mean(norm_ms)), "only": only, "derive": derive,
+        "ckpt_ms": float(np.mean(ckpt_ms)), "norm_ms": float(np.mean(norm_ms)), "derive": derive,
         "n_canonical_ops": incl_canon, "n_slow_tiles": incl_slow, "kernel": TK_NAMES[incl_kernel],
         "perbase": not cohort, "wed_shape": wed.get("shape"), "split": split, "emu": emu, "first": first,
     }
@@ -818,7 +781,7 @@ def roofline_of(r, args, world):
     chunk = r["path"] == 3
     # tile path: the tile kernel does all the arithmetic; chunk path: the long-read tile kernel (its deletion lists and
     # tile indexes are rebuilt inside every step: `long_read_structures`); scatter path: expand + scan share it
-    avg_tile_s = (r["expand_ms"] + r["scan_ms"] if scatter else r["tile_ms"]) * 1e-3
+    avg_tile_s = max((r["expand_ms"] + r["scan_ms"] if scatter else r["tile_ms"]) * 1e-3, 1e-9)   # (a rank without contigs: nothing ran)
     achieved = alg_bytes / avg_tile_s / 1e9
     traffic = None
     tr = None
@@ -842,7 +805,7 @@ def roofline_of(r, args, world):
                 "kernel": kname,
                 "avg_kernel_ms": avg_tile_s * 1e3,
                 "algorithmic_bytes_per_launch": alg_bytes,
-                "bytes_per_ref_base": alg_bytes / r["my_bases"],
+                "bytes_per_ref_base": alg_bytes / max(1, r["my_bases"]),
                 "cigar_ops_counted": ops_read}
     if traffic:
         roofline["traffic_frac_of_peak"] = traffic / avg_tile_s / 1e9 / HBM_PEAK_GBPS
@@ -1120,27 +1083,6 @@ def main():
     if r.get("first"):
         out["first_compute"] = dict(r["first"], warm_ms_per_step=dt / args.steps * 1e3,
                                     ratio_to_warm=r["first"]["ms"] / (dt / args.steps * 1e3))
-    o = r["only"]
-    if o is not None:
-        # the step with the derived structures kept (round 2's headline), and what building them costs
-        ops_o = o["n_canonical_ops"] if o["n_canonical_ops"] else r["n_ops"]
-        alg_o = synth.algorithmic_bytes(r["n_reads"], ops_o, r["my_bases"] if r["perbase"] else 0, r["my_windows"], raw=False)
-        out["compute_only"] = {
-            "value": r["total_bases"] * args.steps / o["dt"], "unit": "ref-bases/s", "ms_per_step": o["dt"] / args.steps * 1e3,
-            "what": "the same step with canonical records / long-read structures kept from step to step",
-            "roofline": {"bound": "hbm", "achieved": alg_o / (o["tile_ms"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": alg_o / (o["tile_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, "kernel": o["kernel"],
-                         "avg_kernel_ms": o["tile_ms"], "algorithmic_bytes_per_launch": alg_o}}
-        nb = synth.normalise_bytes(r["n_reads"], r["n_ops"], ops_o, r["my_bases"])
-        out["roofline_ingest"] = {
-            "what": "gd_normalize: canonical CIGARs + record words + position index of every contig, ONE batch "
-                    "(one allocation, one launch set, one synchronisation)",
-            "bound": "hbm", "achieved": nb / (o["normalise_kernels_ms"] * 1e-3) / 1e9 if o["normalise_kernels_ms"] else None,
-            "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": nb / (o["normalise_kernels_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS if o["normalise_kernels_ms"] else None,
-            "kernels_ms": o["normalise_kernels_ms"], "wall_ms": o["normalise_wall_ms"],
-            "wall_ms_first_call_with_allocation": o["normalise_wall_first_ms"],
-            "long_read_structures_kernels_ms": o["checkpoint_kernels_ms"], "algorithmic_bytes": nb}
     if r.get("emu"):
         out["emulated_sharding"] = {
             "what": "every LPT shard of the N-GPU job (BASELINE.json config 3: one genome, contigs by LPT) computed on THIS "

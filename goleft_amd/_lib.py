@@ -41,7 +41,6 @@ _P = C.c_void_p
 SYMBOLS = {
     "gd_strerror": (C.c_char_p, [C.c_int]),
     "gd_abi_version": (C.c_int, []),
-    "gd_build_features": (C.c_int, []),
     "gd_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "gd_create": (C.c_int, [C.c_int, C.POINTER(_P)]),
     "gd_destroy": (None, [_P]),
@@ -105,10 +104,8 @@ SYMBOLS = {
     "gd_window_offset": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "gd_device_runs": (C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_size_t)]),
     "gd_set_option": (C.c_int, [_P, C.c_int, C.c_int64]),
-    "gd_normalize": (C.c_int, [_P, C.c_int]),
     "gd_drop_derived": (C.c_int, [_P]),
     "gd_rebuild_derived": (C.c_int, [_P]),
-    "gd_canonical_cigars": (C.c_int, [_P, C.c_int32, _P, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
     "gd_set_export": (C.c_int, [_P, _P, C.c_int64, C.c_int64]),
     "gd_wait_event": (C.c_int, [_P, _P]),
     "gd_get_stats": (C.c_int, [_P, C.POINTER(GdStats)]),

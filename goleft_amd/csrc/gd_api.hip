@@ -45,10 +45,6 @@ const char* gd_strerror(int s)
 }
 
 int gd_abi_version(void) { return GD_ABI_VERSION; }
-int gd_build_features(void)
-{
-    return 0;
-}
 
 int gd_device_count(int* n)
 {
@@ -607,7 +603,7 @@ static int commit_block(gd_ctx* c, const gd_batch* b, int32_t tid, size_t n_read
     }
     HIPCHK(c, hipEventRecord(s.done, cs));
     s.busy = true;
-    if (h.normed || h.ck_ok) {                          // the canonical CIGARs / checkpoints no longer cover the stream
+    if (h.ck_ok) {                          // the long-read structures no longer cover the stream
         HIPCHK(c, hipStreamSynchronize(c->stream));
         drop_norm(h);
     }
@@ -694,7 +690,7 @@ int gd_adopt_device(gd_ctx* c, int32_t tid, const gd_batch* d, size_t n_reads, s
     if (n_ops > 0xffffffffull) return fail(c, GD_E_RANGE, "more than 2^32 CIGAR ops");
     // depth <= records of the contig; the window reduction adds four depths in 32 bits
     if (n_reads >= kMaxReadsPerContig) return fail(c, GD_E_RANGE, "more than 2^30 records on one contig");
-    // The canonical CIGARs are built from the arrays right away, on this context's stream: whatever
+    // The arrays are checked and indexed right away, on this context's stream: whatever
     // stream of the caller produced them must have finished.  A device-wide wait makes that true for
     // any producer (a few microseconds per contig, at ingest time).
     HIPCHK(c, hipDeviceSynchronize());
@@ -725,9 +721,6 @@ int gd_adopt_device(gd_ctx* c, int32_t tid, const gd_batch* d, size_t n_reads, s
     free_contig(h);
     h = t;
     c->computed = false;
-    // GD_OPT_NORMALIZE = 1: canonical records are built as part of taking the records in
-    if (n_reads && wants_norm(c, n_reads, n_ops))
-        if (int r = norm_tids(c, std::vector<int32_t>{tid}, false, false)) return r;
     return GD_OK;
 }
 
@@ -823,11 +816,6 @@ int gd_set_option(gd_ctx* c, int option, int64_t value)
     if (!c) return GD_E_INVALID;
     switch (option) {
     case GD_OPT_NT_STORES: c->tile_opt = value ? 1 : 0; break;
-    case GD_OPT_NORMALIZE:
-        if (value < 0 || value > 2) return fail(c, GD_E_INVALID, "GD_OPT_NORMALIZE: 0, 1 or 2");
-        if (value == 1) return fail(c, GD_E_INVALID, "GD_OPT_NORMALIZE = 1: this build holds no canonical records (csrc/Makefile: make CANONICAL=1)");
-        c->normalize = (int)value;
-        break;
     case GD_OPT_FAST_KERNEL: c->fast_kernel = value != 0; break;
     case GD_OPT_COPY_THREADS:
         if (value < 1 || value > 16) return fail(c, GD_E_INVALID, "copy threads: 1..16");
@@ -838,7 +826,6 @@ int gd_set_option(gd_ctx* c, int option, int64_t value)
         c->h2d_kernel = value != 0;
         if (value > 1) c->h2d_grid = (unsigned)value;
         break;
-    case GD_OPT_FUSED_NORMALIZE: c->fused_norm = value != 0; break;
     case GD_OPT_INGEST_CRC: c->ingest_crc = value != 0; break;
     case GD_OPT_INGEST_DMA:
         if (value < 0 || value > 4) return fail(c, GD_E_INVALID, "ingest DMA streams: 1 .. 4 (0: a copy kernel on a high-priority stream)");
@@ -891,21 +878,6 @@ int gd_set_option(gd_ctx* c, int option, int64_t value)
     default: return fail(c, GD_E_INVALID, "unknown option %d", option);
     }
     c->computed = false;
-    return GD_OK;
-}
-
-int gd_canonical_cigars(gd_ctx* c, int32_t tid, uint32_t* cigar_off, uint32_t* cigar, size_t cap_ops, size_t* n_ops)
-{
-    if (!c || !n_ops) return GD_E_INVALID;
-    if (int r = set_device(c)) return r;
-    if (tid < 0 || (size_t)tid >= c->contigs.size()) return fail(c, GD_E_RANGE, "tid %d out of range", tid);
-    const ContigHost& h = c->contigs[tid];
-    if (!h.normed) return fail(c, GD_E_STATE, "contig %d has no canonical CIGARs (GD_OPT_NORMALIZE off, long-read data, or records committed since)", tid);
-    *n_ops = h.n_nops;
-    if (h.n_nops > cap_ops) return GD_E_CAPACITY;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (cigar_off) HIPCHK(c, hipMemcpy(cigar_off, h.noff, (h.n_reads + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    if (cigar && h.n_nops) HIPCHK(c, hipMemcpy(cigar, h.ncig, h.n_nops * sizeof(uint32_t), hipMemcpyDeviceToHost));
     return GD_OK;
 }
 

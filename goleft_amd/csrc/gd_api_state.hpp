@@ -1,6 +1,6 @@
 // gd_api_state.hpp -- what a gd_ctx holds and the helpers every part of the C ABI shares: per-contig
 // record streams, the pinned staging ring, the device job state, launch helpers of the tile kernels,
-// the CIGAR normalisation (gd_normalize.hpp) and the state of a device BAM read.  Included by gd_api.hip
+// the long-read structures (gd_chunk.hpp) and the state of a device BAM read.  Included by gd_api.hip
 // only (one translation unit: the kernels of gd_kernels.hpp are not inline).
 #pragma once
 
@@ -18,7 +18,7 @@ constexpr int kTileT = 4096;              // reference positions per tile, 256 t
 constexpr int kAutoLongSpan = 32768;      // GD_PATH_AUTO leaves the short-read tile path above this read span
 constexpr int kMaxSpan = 1 << 27;   // tile-relative byte offsets of the tile kernel stay in 32 bits
 
-// One device allocation shared by the derived arrays of a batch of contigs (canonical records, position
+// One device allocation shared by the derived arrays of a batch of contigs (long-read structures, position
 // indexes, long-read structures): a batch is built with one hipMalloc and no per-contig host round trip; the
 // block goes back to HBM when the last contig that points into it drops its share.
 struct DevBlock {
@@ -40,26 +40,18 @@ struct ContigHost {
     size_t cap_reads = 0, cap_ops = 0;
     bool adopted = false;
     int32_t last_pos = -0x7fffffff;
-    // canonical CIGARs of the records (gd_normalize.hpp): slices of norm_blk
-    BlockRef norm_blk, ck_blk, pck_blk;
-    uint32_t* noff = nullptr;          // n_reads + 1 CSR offsets into ncig
-    uint32_t* ncig = nullptr;          // canonical ops (capacity n_ops)
-    uint32_t* nrec = nullptr;          // record words (flag | MAPQ | op count), n_reads + 4 (the kernel loads 16 bytes per lane)
-    bool rec_ok = false;               // every record fits its word: the straight-line kernel may run
-    size_t n_nops = 0;                 // canonical ops
-    bool normed = false;               // noff/ncig describe the current records
-    uint32_t* pidx = nullptr;          // position index: pidx[k] = first read with pos >= 64 k, k = 0 .. (length >> 6) + 1
-    // long-read path (gd_chunk.hpp): deletion lists of the canonical CIGARs above, read records (slices of ck_blk), the
-    // tile indexes (a slice of pck_blk)
+    // long-read path (gd_chunk.hpp): deletion lists, read records and tile indexes, built straight from the records
+    // (slices of ck_blk)
+    BlockRef ck_blk;
     uint4*    lrec = nullptr;          // n_reads + 2 long-read records {pos, end, list offset, deletions}; [n_reads + 1].x = the largest span
     uint32_t* lfq = nullptr;           // n_reads: flag << 8 | MAPQ
-    uint2*    dl = nullptr;            // (canonical ops >> 1) + n_reads + 1 deletions {start, length}
+    uint2*    dl = nullptr;            // (ops >> 1) + n_reads + 1 deletions {start, length}
     uint32_t* pck = nullptr;           // tile indexes (filled by gd_dels_raw_kernel)
     uint32_t* ndel = nullptr;          // deletions per read
     int32_t   max_span = 0;
     uint64_t  n_dels = 0;              // deletions in dl
     bool ck_ok = false;                // lrec / lfq / dl / pck describe the current records
-    // built as the records arrive (gd_index_records_kernel): the same position index without canonical records
+    // built as the records arrive (gd_index_records_kernel): the position index, ridx[k] = first read with pos >= 64 k
     uint32_t* ridx = nullptr;          // (length >> 6) + 2 entries; valid up to entry pos[ridx_reads - 1] >> 6
     size_t ridx_reads = 0;             // records it covers (== n_reads: gd_prep_kernel uses it)
     bool ing_left = false;             // device BAM read in parts: a record of another reference has ended this one's records
@@ -137,7 +129,6 @@ struct ComputeState {
     std::vector<int32_t> tids;          // contigs of the job
     uint64_t n_reads = 0, n_ops = 0, n_units = 0, n_groups = 0;
     int64_t tile_beg = 0, base_off = 0, win_off = 0, bases = 0;
-    bool all_normed = true;             // every contig of the job has canonical records whose word fits
     bool raw_aligned = true;            // ... arrays aligned for the raw straight-line kernel's vector loads
     int32_t it_kernel = 0;              // GD_TK_*: the kernel of the attempt in flight
     int reruns = 0, used_lookback = 0;
@@ -167,8 +158,6 @@ struct gd_ctx {
     // tuning knobs (gd_set_option; defaults are what the measurements of DESIGN.md section 4 chose)
     bool fast_kernel = true;            // GD_OPT_FAST_KERNEL: the straight-line tile kernel (gd_tile_fast.hpp) for
                                         // ordinary tiles, the generic one for the rest; 0 = generic for every tile
-    int normalize = 2;                  // GD_OPT_NORMALIZE: canonical records (gd_normalize.hpp) 0 never for the tile path,
-                                        // 1 when records arrive, 2 only for what needs them (long-read path, streaming sums)
     std::vector<uint8_t> batch_tab, batch_tab_ck;   // host copies of the job tables of the last norm_batch / ck batch
     uint32_t* h_batch = nullptr; size_t cap_h_batch = 0;   // pinned: per-contig totals / status words coming back
     int tile_opt = 1;                   // bit 0: non-temporal per-base stores (2 % faster: the vector is
@@ -259,7 +248,6 @@ struct gd_ctx {
     uint64_t ing_range_hint = 0;                       // GD_OPT_INGEST_RANGE_HINT: bytes of the largest range the caller will feed
     unsigned inflate_probe = 0;                        // GD_OPT_INFLATE_PROBE (measurement only)
     unsigned inflate_pad = 0;                          // GD_OPT_INFLATE_LDS_PAD: extra LDS per inflate workgroup (occupancy limiter)
-    bool fused_norm = true;                            // GD_OPT_FUSED_NORMALIZE: gd_normalize as one pass (0: count / scan / write / index launches)
     int32_t bam_n_ref = 0;                             // GD_OPT_BAM_REFS: references of the BAM being read (0: unknown)
     int push_threads = 16;
     FillPool* pool = nullptr; int pool_workers = 0;    // host worker threads (gd_push fills, gd_commit validates), created on first use
@@ -347,22 +335,13 @@ int ensure_dev(gd_ctx* c, Tp** p, size_t* cap, size_t need, bool keep = false, s
 void drop_ck(ContigHost& h)
 {
     h.ck_blk.reset();                  // (hipFree of the block, when this was its last user, waits for the device)
-    h.pck_blk.reset();
     h.lrec = nullptr; h.lfq = nullptr; h.dl = nullptr; h.pck = nullptr; h.ndel = nullptr;
     h.max_span = 0;
     h.n_dels = 0;
     h.ck_ok = false;
 }
 
-void drop_norm(ContigHost& h)
-{
-    drop_ck(h);                        // built from the canonical arrays
-    h.norm_blk.reset();
-    h.noff = nullptr; h.ncig = nullptr; h.nrec = nullptr; h.pidx = nullptr;
-    h.rec_ok = false;
-    h.n_nops = 0;
-    h.normed = false;
-}
+void drop_norm(ContigHost& h) { drop_ck(h); }   // everything derived from the records
 
 void free_contig(ContigHost& h)
 {
@@ -450,11 +429,11 @@ void launch_tile(gd_ctx* c, const gd::Job& job)
             hipLaunchKernelGGL((gd::gd_tile_slow_kernel<4096, 256, 0>), dim3(sgrid), dim3(256), 0, c->stream, job);
         if (job.fast == 2u) {                                // the records as they arrived
             if (!c->keep_perbase)
-                hipLaunchKernelGGL((gd::fast::gd_tile_fast_kernel<2, true>), dim3(grid), dim3(256), 0, c->stream, job);
+                hipLaunchKernelGGL((gd::fast::gd_tile_fast_kernel<2>), dim3(grid), dim3(256), 0, c->stream, job);
             else if (c->tile_opt & 1)
-                hipLaunchKernelGGL((gd::fast::gd_tile_fast_kernel<1, true>), dim3(grid), dim3(256), 0, c->stream, job);
+                hipLaunchKernelGGL((gd::fast::gd_tile_fast_kernel<1>), dim3(grid), dim3(256), 0, c->stream, job);
             else
-                hipLaunchKernelGGL((gd::fast::gd_tile_fast_kernel<0, true>), dim3(grid), dim3(256), 0, c->stream, job);
+                hipLaunchKernelGGL((gd::fast::gd_tile_fast_kernel<0>), dim3(grid), dim3(256), 0, c->stream, job);
             return;
         }
         return;
@@ -629,7 +608,6 @@ int ck_finish(gd_ctx* c, CkPending& P, const uint32_t* tot)
     for (size_t k = 0; k < nj; ++k) {
         ContigHost& h = *P.hs[k];
         h.ck_blk = P.blk;
-        h.pck_blk.reset();
         h.lrec = jobs[k].lrec; h.lfq = jobs[k].lfq; h.dl = jobs[k].dl; h.pck = jobs[k].pck; h.ndel = jobs[k].ndel;
         h.max_span = (int32_t)tot[2 * nj + k];
         h.n_dels = tot[nj + k];
@@ -661,71 +639,10 @@ int ck_batch(gd_ctx* c, const std::vector<ContigHost*>& hs)
     return GD_OK;
 }
 
-// Builds the canonical CIGARs, record words and position indexes (gd_normalize.hpp) of a batch of contigs on the
-// compute stream: one allocation, one launch set, one host synchronisation.  Contigs listed in `with_ck` (a subset)
-// also get their long-read structures, enqueued behind the same kernels.  Afterwards h.normed is set.
-int norm_batch(gd_ctx* c, const std::vector<ContigHost*>& hs, const std::vector<ContigHost*>& with_ck)
-{
-    // Canonical records (gd_normalize.hpp: a rewritten copy of the CIGARs, record words, a position index) serve a host that
-    // computes the SAME records many times; no caller in the reference does, and every default path reads the records as they
-    // arrived.  They are an optional part of the build (csrc/Makefile: make CANONICAL=1) -- without it this is the one place
-    // that could have built them.
-    (void)hs; (void)with_ck;
-    return fail(c, GD_E_INVALID, "this build holds no canonical records (csrc/Makefile: make CANONICAL=1)");
-}
-
-bool wants_norm(const gd_ctx* c, uint64_t, uint64_t)
-{
-    return c->normalize == 1 && c->path != GD_PATH_SCATTER;     // (mode 2: gd_compute builds what its path needs)
-}
-
-// What GD_PATH_AUTO sends to the long-read path (contig-wise: its structures are built with the canonical records).
+// What GD_PATH_AUTO sends to the long-read path (contig-wise).
 bool long_shaped(const gd_ctx* c, const ContigHost& h)
 {
     return c->path == GD_PATH_CHUNK || (c->path == GD_PATH_AUTO && (c->span_forces_long || h.n_ops > 6 * h.n_reads));
-}
-
-// Normalises the listed contigs that need it (all of them with `force`), long-read shaped ones with their
-// deletion lists and tile indexes.
-int norm_tids(gd_ctx* c, const std::vector<int32_t>& tids, bool force, bool ck_all)
-{
-    std::vector<ContigHost*> hs, ck;
-    for (int32_t tid : tids) {
-        ContigHost& h = c->contigs[tid];
-        if (h.length <= 0) continue;
-        const bool wants_ck = ck_all || long_shaped(c, h);
-        if (force || !h.normed) { hs.push_back(&h); if (wants_ck) ck.push_back(&h); }
-        else if (wants_ck && !h.ck_ok) ck.push_back(&h);
-    }
-    if (hs.empty() && ck.empty()) return GD_OK;
-    // A launch holds fewer than 2^32 work-items (the dispatch packet's grid size is 32 bits; a larger grid wraps
-    // silently): at one wave per 64-read unit that is 2^26 units, so a cohort of 10^10 reads is several batches.
-    constexpr uint64_t kMaxUnits = 48u << 20;
-    auto in = [](const std::vector<ContigHost*>& v, const ContigHost* h) { return std::find(v.begin(), v.end(), h) != v.end(); };
-    // contigs normalised earlier that only lack the long-read structures go in batches of their own
-    std::vector<ContigHost*> ck_old;
-    for (ContigHost* h : ck) if (!in(hs, h)) ck_old.push_back(h);
-    for (size_t i = 0; i < hs.size();) {
-        std::vector<ContigHost*> part, part_ck;
-        uint64_t units = 0;
-        while (i < hs.size() && (part.empty() || units + (hs[i]->n_reads + 63) / 64 <= kMaxUnits)) {
-            units += (hs[i]->n_reads + 63) / 64;
-            part.push_back(hs[i]);
-            if (in(ck, hs[i])) part_ck.push_back(hs[i]);
-            ++i;
-        }
-        if (int r = norm_batch(c, part, part_ck)) return r;
-    }
-    for (size_t i = 0; i < ck_old.size();) {
-        std::vector<ContigHost*> part;
-        uint64_t units = 0;
-        while (i < ck_old.size() && (part.empty() || units + (ck_old[i]->n_reads + 63) / 64 <= kMaxUnits)) {
-            units += (ck_old[i]->n_reads + 63) / 64;
-            part.push_back(ck_old[i++]);
-        }
-        if (int r = ck_batch(c, part)) return r;
-    }
-    return GD_OK;
 }
 
 // The long-read structures of the listed contigs that lack them, straight from the records as they arrived.

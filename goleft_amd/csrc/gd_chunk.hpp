@@ -15,18 +15,15 @@
 // the tile.  What the tile kernel needs is therefore not the CIGAR but the read's
 // DELETION LIST in reference coordinates:
 //
-//   DL  gd_dels_kernel   one pass over a contig's canonical CIGARs (gd_normalize.hpp: M and N
-//       alternate) WHEN ITS RECORDS ARRIVE, not in gd_compute: every N op becomes {start, length}
-//       (8 bytes -- what the (M, N) op pair took) at a dense per-read offset, and each read gets
-//       one 16-byte record {pos, end, offset of its list, offset of its tile index}.  Independent
-//       of the read filter (-Q, flag mask), which the tile kernel applies.  List offsets need no
-//       prefix sum: the canonical CSR offset o of read r gives (o >> 1) + r, which never overlaps
-//       the next read's.
-//   PT  gd_ptile_count_kernel / gd_ptile_fill_kernel   the read's TILE INDEX: for every 4096-base
-//       boundary b the read spans (from the one at or before pos to the one after end), the number
-//       of its deletions that start before b -- 4 bytes per (read, 4 kb of reference), 80 MB for a
-//       20x ONT genome.  A tile finds the deletions of an overlapping read that can touch it with
-//       TWO lookups (no checkpoint search, no chunk that merely brushes the tile).
+//   DL  gd_dels_raw_kernel   ONE pass over a contig's CIGARs as they arrived, at the first compute of the records:
+//       every D/N op becomes {start, length} (8 bytes) at a dense per-read offset, each read gets one 16-byte record
+//       {pos, end, offset of its list, offset of its tile index} and -- in the same pass -- its TILE INDEX: for every
+//       4096-base boundary b the read spans (from the one at or before pos to the one after end), the number of its
+//       deletions that start before b: 4 bytes per (read, 4 kb of reference), 80 MB for a 20x ONT genome.  A tile finds
+//       the deletions of an overlapping read that can touch it with TWO lookups (no checkpoint search, no chunk that
+//       merely brushes the tile).  Independent of the read filter (-Q, flag mask), which the tile kernel applies.  Neither
+//       the list offsets nor the index offsets need a prefix sum: the CSR offset o of read r gives (o >> 1) + r and
+//       (o >> 6) + 3 r, which never overlap the next read's.
 //   LT2 gd_ltile2_kernel per tile: the candidate reads (start within one maximum span before
 //       the tile) are tested lane-parallel from their records; a lane whose read overlaps looks
 //       its deletion range up and queues it in pieces of 64; lanes then load one deletion each
@@ -61,8 +58,8 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
 // DL: one wave per unit of 64 consecutive reads of ONE contig.
 struct DelJob {
     const int32_t*  pos;
-    const uint32_t* off;      // CSR offsets of the CANONICAL ops (gd_normalize.hpp)
-    const uint32_t* cigar;    // canonical ops: M (0) and N (3) alternate, lengths >= 1, the last one is an M
+    const uint32_t* off;      // CSR offsets of the ops as they arrived
+    const uint32_t* cigar;    // BAM-encoded ops, any form
     const uint16_t* flag;
     const uint8_t*  mapq;
     uint32_t  n_reads;
@@ -77,7 +74,7 @@ struct DelJob {
     uint32_t* del_total;      // out: deletions of the contig
     int32_t*  max_span;       // atomicMax of end - pos
     // the tile index (PT kernels below)
-    uint32_t* unit;           // (canonical route only) this contig's slice of the batch's unit array
+    uint32_t* unit;           // (unused)
     uint32_t* pck;            // the index: (n_ops >> 6) + 3 n_reads + 4 entries, read r's at pt_slot(off[r], r)
     uint32_t* total;          // out: [0] unused, [n_jobs] deletions of the contig, [2 n_jobs] its largest span
 };
@@ -113,10 +110,10 @@ struct DelBatch {
 
 
 // ---- the same structures straight from the records AS THEY ARRIVED ------------------------------------------------
-// One pass over the original CIGARs: what gd_normalize.hpp's count + write passes and gd_dels_kernel do in three
-// (a 20x ONT genome: 19 GB of ops read twice and 10 GB of canonical ops written and read again before the first
-// deletion list existed -- 24 + 3 ms in front of a 4.6 ms tile kernel; a run computes its input once).  The walk is
-// the canonical one without the output: I/S/H/P and zero-length ops vanish, neighbouring D/N ops merge into ONE
+// One pass over the original CIGARs (round 2 went through a rewritten, "canonical" copy of the CIGARs first: a 20x ONT
+// genome's 19 GB of ops read twice and 10 GB written and read again before the first deletion list existed -- 24 + 3 ms in
+// front of a 4.6 ms tile kernel; a run computes its input once).  The merging walk below keeps that copy's rules without
+// writing it: I/S/H/P and zero-length ops vanish, neighbouring D/N ops merge into ONE
 // deletion, one that no M follows is dropped, and a read ends where its last M ends.
 
 // one lane, op by op (short CIGARs; ops longer than 2^22 bases or runs that overflow)

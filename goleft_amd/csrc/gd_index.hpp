@@ -1,39 +1,21 @@
-// gd_normalize.hpp -- canonical CIGARs, built once when a contig's records arrive.
+// gd_index.hpp -- what is built as records ARRIVE, and two helpers the batch kernels share.
 //
-// `samtools depth` (no -J, no -q; /root/reference/depth/depth.go:45) distinguishes exactly two kinds
-// of CIGAR op: M/=/X add 1 to every reference position they cover, D/N advance the reference without
-// counting; I/S/H/P touch no reference position at all.  The canonical form keeps just that:
-//
-//   * I, S, H, P and zero-length ops are dropped;
-//   * neighbouring M/=/X ops (neighbours once the dropped ops are gone) merge into ONE `M`,
-//     neighbouring D/N ops into ONE `N` (a merged length that would not fit the 28-bit BAM length field
-//     starts a new op of the same kind instead -- pathological input only);
-//   * D/N ops after the last M are dropped (they cover nothing that is counted); a read without any
-//     counted base has no ops at all.  Leading D/N ops stay: they shift where the first M begins.
-//
-// The result uses the BAM encoding (len << 4 | op, op = 0 `M` or 3 `N`), so every kernel that walks
-// CIGARs reads it unchanged and produces the identical depth -- but a 150 bp read with soft clips or an
-// insertion is now the single op `kM` (98 % of short reads instead of 92 %), which is what the tile
-// kernel's straight-line path handles, and a long read carries about half as many ops.
-//
-// One launch set for ALL contigs of a batch (the 64-read units of the batch's contigs are numbered through; a
-// wave finds its contig in a small table), no host round trip in between: (N1) one lane per read counts its
-// canonical ops, a wave scan gives the offsets inside each 64-read unit and the unit totals; (N2) the unit
-// totals of the whole batch are scanned (a contig's offsets are differences against its first unit's);
-// (N3) one lane per read walks its ops again and writes them at unit offset + local offset.  Every array comes
-// out of one allocation sized up front -- the canonical array at the size of the original (it can only
-// shrink) -- so the host waits once, for the per-contig totals.
+//   gd_index_records_kernel   one pass over what just became resident (gd_adopt_device's check pass, every committed
+//                             block once its copy has landed, what the device BAM walk wrote): coordinate order and CSR
+//                             offsets are checked, the POSITION INDEX ridx[k] = first read with pos >= 64 k is written
+//                             (gd_prep_kernel looks the tiles' read ranges up there instead of searching), and the
+//                             largest reference span of any record of <= 64 ops is kept, so that the first gd_compute
+//                             runs with the data's look-back (no re-run);
+//   batch_find                the job a 64-read unit of a batch belongs to (gd_chunk.hpp);
+//   gd_unit_scan / gd_scan_*  exclusive prefix sums over small device arrays (multidepth's block finder, gd_api_aux.inc).
+// (Until round 5 this file was gd_normalize.hpp and also held the canonical-record kernels: a rewritten copy of the
+// records for a host that computes the same records many times.  No caller in the reference does -- a `goleft depth` run
+// computes each input once, /root/reference/depth/depth.go:392-421 -- and every path reads the records as they arrived;
+// they were removed.)
 #pragma once
 
 namespace gd {
 namespace norm {
-
-// The record word of a read, written next to its canonical CIGAR: everything the tile kernel needs
-// besides `pos` and the ops themselves, in the 4 bytes the CSR offset would take --
-//     flag (12 bits, SAMv1 defines 12) << 20 | MAPQ << 12 | number of canonical ops (0..4094)
-// The op offsets are recovered in the kernel by a prefix sum over the tile's reads.  A contig with a FLAG
-// above 0xfff or a read of 4095 or more canonical ops is marked (status bit) and runs the generic kernel.
-constexpr uint32_t REC_NMAX = 0xfffu;
 
 // last j with beg[j] <= x (beg[0] = 0, n >= 1, entries ascending)
 __device__ __forceinline__ uint32_t batch_find(const uint32_t* __restrict__ beg, uint32_t n, uint32_t x)
@@ -45,45 +27,6 @@ __device__ __forceinline__ uint32_t batch_find(const uint32_t* __restrict__ beg,
     }
     return lo;
 }
-
-struct NormJob {
-    const int32_t*  pos;      // positions (the index kernel)
-    uint32_t* pidx;           // position index, n_idx entries
-    uint32_t  n_idx;
-    uint32_t  pad_;
-    const uint32_t* off;      // original CSR offsets (n_reads + 1)
-    const uint32_t* cigar;    // original ops
-    const uint16_t* flag;
-    const uint8_t*  mapq;
-    uint32_t* rec;            // record words (n_reads)
-    uint32_t* status;         // bit 0: a record that does not fit its word
-    uint32_t  n_reads;
-    uint32_t  n_units;        // ceil(n_reads / 64)
-    uint32_t* noff;           // canonical CSR offsets (n_reads + 1)
-    uint32_t* unit;           // this contig's slice of the batch's unit array: n_units + 1 unit totals, then (after
-                              // N2) exclusive offsets over the BATCH -- unit[k] - unit[0] is the contig's own offset,
-                              // unit[n_units] - unit[0] its total (all modulo 2^32: a contig holds < 2^32 ops)
-    uint32_t* ncig;           // canonical ops
-    uint32_t* total;          // out: canonical ops of the contig
-    uint32_t  rows;           // fused pass: a workgroup takes rows x 256 consecutive reads (4, 2 or 1: few ops per read -> many reads)
-    uint32_t  blk_beg;        // fused pass: first workgroup of this contig
-};
-
-// The contigs of one batch: job j owns units [ubeg[j], ubeg[j + 1]) and index entries [ibeg[j], ibeg[j + 1]).
-struct NormBatch {
-    const NormJob*  jobs;
-    const uint32_t* ubeg;     // n_jobs + 1
-    const uint32_t* ibeg;     // n_jobs + 1
-    uint32_t n_jobs;
-    uint32_t n_units;         // ubeg[n_jobs]
-    uint32_t n_idx;           // ibeg[n_jobs]
-    // fused pass (gd_norm_fused_kernel)
-    const uint32_t* bbeg;     // n_jobs + 1: first workgroup of every job
-    uint32_t n_blocks;        // bbeg[n_jobs]
-    unsigned long long* bstat;   // n_blocks look-back words, zeroed before the launch
-    uint32_t* ticket;         // [0] workgroups handed out so far, [1] set when a look-back gave up (never expected)
-};
-
 
 // N2: exclusive scan of the unit totals, in place; v[n] = grand total.  One workgroup.
 __global__ __launch_bounds__(1024) void gd_unit_scan_kernel(uint32_t* __restrict__ v, uint32_t n)

@@ -61,7 +61,7 @@ struct ContigDev {
     const uint2*    dl;       // deletion lists {start, length}
     const uint32_t* pck;      // tile indexes: deletions starting before every 4096-base boundary a read spans
     const uint32_t* ndel;     // deletions of every read (the tile kernel bisects the list of a read without an index)
-    const uint32_t* rec;      // record words (gd_normalize.hpp) of the canonical records, null otherwise
+    const uint32_t* rec;      // (unused since round 5: the record words of canonical records) always null
     const uint32_t* pidx;     // position index: first read with pos >= 64 k (gd_pidx_kernel, or gd_index_records_kernel as the
                               // records arrived); null: search `pos`
     uint32_t pidx_last;       // entries above this one read as n_reads (an index built block by block has no tail)
@@ -101,7 +101,7 @@ struct __attribute__((aligned(16))) TileInfo {
 struct __attribute__((aligned(16))) TileFast {
     const int32_t*  pos;      // at read lo
     const uint32_t* rec;      // record words (flag | MAPQ | op count), at read lo; fast == 2: the CSR offsets, at read lo
-    const uint32_t* cig;      // canonical ops (fast == 2: the ops as they arrived), at op clo
+    const uint32_t* cig;      // the ops as they arrived, at op clo
     const uint16_t* flag;     // fast == 2: at read lo
     const uint8_t*  mapq;     // fast == 2: at read lo
     int32_t*  out;            // per-base output at t0 (null: windows-only)
@@ -224,7 +224,7 @@ __device__ __forceinline__ void lower_bound_pair(const int32_t* a, uint32_t n, i
 // lower_bound(a[0..n), key) from a GUESS of where it lies: two probes 8192 elements either side of the guess
 // bracket it (a 30x genome's cumulative read count wanders a few thousand reads around the interpolated one), 14
 // bisection steps finish; a miss bisects the side the answer is on.  ONE such search per tile: for records without
-// a position index (gd_normalize.hpp builds one; a first compute has none) the pair of plain searches every tile
+// a position index (gd_index.hpp builds one as records arrive; without one the pair of plain searches every tile
 // ran moved 3.8 GB of 64-byte sectors, most of them TLB misses -- 0.29 ms per genome.
 __device__ __forceinline__ uint32_t lower_bound_hint(const int32_t* a, uint32_t n, int32_t key, uint32_t guess)
 {
@@ -515,7 +515,7 @@ __global__ __launch_bounds__(256) void gd_regions_bounds_kernel(const RegionTab*
 
 }  // namespace gd
 
-#include "gd_normalize.hpp"
+#include "gd_index.hpp"
 #include "gd_tile_common.hpp"
 #include "gd_tile_generic.hpp"
 #include "gd_tile_fast.hpp"

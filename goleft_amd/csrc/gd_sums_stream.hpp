@@ -1,5 +1,5 @@
 // gd_sums_stream.hpp -- the sums-only output (GD_OUT_SUMS_ONLY: all that depth.bed's mean column and the
-// depthwed matrix need, BASELINE.json config 4) as ONE STREAMING PASS over the canonical records.
+// depthwed matrix need, BASELINE.json config 4) as ONE STREAMING PASS over the records as they arrived.
 //
 // The sum of the depth over a window equals the sum over reads of their overlap with the window
 // (/root/reference/depth/depth.go:181-189, :293-305: `mean` of the per-base lines of a window).  The tile
@@ -7,8 +7,8 @@
 // table, a verified look-back that re-examines 5 % of the reads, ops staged in LDS, and per-read 64-bit LDS
 // atomics onto the 16 window accumulators of a tile -- 64 lanes hitting 2-3 addresses.  Nothing here is
 // positional except the window index, and the records are coordinate sorted, so:
-//   * one wave takes 256 CONSECUTIVE reads of one contig (4 per lane: 16 bytes of `pos`, 16 bytes of record
-//     words, the reads' first canonical op each), every read exactly once: no tiles, no look-back;
+//   * one wave takes 256 CONSECUTIVE reads of one contig (4 per lane: 16 bytes of `pos`, 16 + 4 bytes of CSR offsets,
+//     four flags, four MAPQs, the reads' first ops), every read exactly once: no tiles, no look-back;
 //   * a read adds to its start window and -- when it crosses the boundary -- the next; a lane folds its four
 //     reads into three consecutive windows kb, kb+1, kb+2 in registers;
 //   * the lanes' kb are non-decreasing, so a window's total over the wave is a difference of ONE plain wave
@@ -70,10 +70,9 @@ constexpr int SQ_CAP = 256;                // queued odd reads per wave (a round
 // wait to vmcnt(0))
 typedef const __attribute__((address_space(1))) uint32_t* gptr_u32;
 
-// The wave's queue of odd reads {POS, index of the first canonical op, op count}, 64 at a time: walk the canonical
-// ops, M (0) counted, N (3) skipped, every M interval on its own.  (Inlined, at its one call site and the final one: as a
-// function call it cost the kernel 25 vector registers, one resident wave per SIMD in six and a tenth of its speed.)
-template <bool RAW>
+// The wave's queue of odd reads {POS, index of the first op, op count}, 64 at a time: walk the ops -- any BAM op: M = X
+// counted, D N advance, I S H P nothing -- every counted interval on its own.  (Inlined, at its one call site and the final
+// one: as a function call it cost the kernel 25 vector registers, one resident wave per SIMD in six and a tenth of its speed.)
 __device__ __forceinline__ void drain_queue(const uint4* Q, uint32_t cnt, int lane, gptr_u32 cigar, uint32_t length,
                                          Acc acc, uint32_t W, uint32_t wm, uint32_t ws)
 {
@@ -88,24 +87,18 @@ __device__ __forceinline__ void drain_queue(const uint4* Q, uint32_t cnt, int la
             uint32_t x = (uint32_t)pu;
             for (uint32_t k = 0; k < nu && x < length; ++k) {
                 const uint32_t o = ops[k], ol = o >> 4;
-                if (RAW) {                                     // any BAM op: M = X counted, D N advance, I S H P nothing
-                    const uint32_t op = o & 0xfu;
-                    if (!((0x18du >> op) & 1u)) continue;
-                    const uint32_t xe = x + ol;
-                    if (((0x181u >> op) & 1u) && ol != 0u) add_interval_direct(acc, W, wm, ws, x, xe < length ? xe : length);
-                    x = xe;
-                } else {
-                    const uint32_t xe = x + ol;
-                    if ((o & 0xfu) == 0u) add_interval_direct(acc, W, wm, ws, x, xe < length ? xe : length);
-                    x = xe;
-                }
+                const uint32_t op = o & 0xfu;
+                if (!((0x18du >> op) & 1u)) continue;
+                const uint32_t xe = x + ol;
+                if (((0x181u >> op) & 1u) && ol != 0u) add_interval_direct(acc, W, wm, ws, x, xe < length ? xe : length);
+                x = xe;
             }
         } else {
             long long x = pu;                                  // a negative POS (no aligner writes one): the long form
             for (uint32_t k = 0; k < nu; ++k) {
                 const uint32_t o = ops[k], ol = o >> 4;
-                if (RAW && !((0x18du >> (o & 0xfu)) & 1u)) continue;
-                if (RAW ? (bool)((0x181u >> (o & 0xfu)) & 1u) : (o & 0xfu) == 0u) {
+                if (!((0x18du >> (o & 0xfu)) & 1u)) continue;
+                if ((0x181u >> (o & 0xfu)) & 1u) {
                     const long long e64 = x + (long long)ol;
                     const uint32_t s = x > 0 ? (x < (long long)length ? (uint32_t)x : length) : 0u;
                     const uint32_t e = e64 < (long long)length ? (e64 > 0 ? (uint32_t)e64 : 0u) : length;
@@ -121,12 +114,12 @@ __device__ __forceinline__ void drain_queue(const uint4* Q, uint32_t cnt, int la
 // one group of 256 reads on its way through the wave's pipeline
 struct Stage {
     typedef unsigned int v4u __attribute__((ext_vector_type(4)));
-    v4u pv, rv;            // POS and record words of the lane's four reads (RAW: their CSR offsets)
-    uint32_t ob;           // first canonical op of the group (wave uniform); RAW: the CSR offset after the lane's last read
-    uint32_t obase;        // ops of the lanes before this one; RAW: bit u = read u is kept
-    uint32_t cg[U];        // first op of each read; RAW: the ONE counted op of a read that has just one (else 0xffffffff)
-    unsigned int fw0, fw1, mq;   // RAW: the four flags (two per word) and MAPQs as loaded
-    uint32_t g0;           // RAW: first read of the group (wave uniform)
+    v4u pv, rv;            // POS and CSR offsets of the lane's four reads
+    uint32_t ob;           // the CSR offset after the lane's last read
+    uint32_t obase;        // bit u = read u is kept
+    uint32_t cg[U];        // the ONE counted op of a read that has just one (else 0xffffffff)
+    unsigned int fw0, fw1, mq;   // the four flags (two per word) and MAPQs as loaded
+    uint32_t g0;           // first read of the group (wave uniform)
 };
 
 // A wave that took one group per launch slot spent its life in dependent round trips (which contig? its
@@ -137,12 +130,11 @@ struct Stage {
 // group g+2 are in flight.  The loop is unrolled three times so that a stage's registers are never copied while
 // their loads are outstanding (a copy is a wait).
 //
-// RAW: the same pass over the records AS THEY ARRIVED (pos / flag / MAPQ / CSR offsets / BAM ops): a cohort's
-// samples are computed once each, and building canonical records first moved 28 bytes per read to save 3 here
-// (181 ms for 200 x chr1 in front of a 25 ms kernel).  A read FITS the lane's three windows when it has ONE counted
+// The pass reads the records AS THEY ARRIVED (pos / flag / MAPQ / CSR offsets / BAM ops): a cohort's samples are computed
+// once each, and building canonical records first (rounds 2-4 kept that as an option) moved 28 bytes per read to save 3
+// here (181 ms for 200 x chr1 in front of a 25 ms kernel).  A read FITS the lane's three windows when it has ONE counted
 // op and nothing before it that consumes the reference: 150M, 20S130M, 100M50S, 5H145M, 70M3I, 150M2D (97 % of
 // short reads); everything else takes the queue and the general op walk.
-template <bool RAW>
 __global__ __launch_bounds__(256) void gd_sums_stream_kernel(Job job)
 {
     __shared__ uint4 s_q[4 * SQ_CAP];
@@ -168,7 +160,6 @@ __global__ __launch_bounds__(256) void gd_sums_stream_kernel(Job job)
     int64_t* const wsum = job.win_sum + c.win_off;
     const gptr_u32 off = (gptr_u32)c.off;
     const gptr_u32 cigar = (gptr_u32)c.cigar;
-    const uint32_t fmask = job.flag_mask << 20;
     const int Q_ = job.Q;
 
     const uint32_t r_first = (unit - c.grp_beg) * (GROUP * GPW);   // first read of this wave
@@ -176,12 +167,11 @@ __global__ __launch_bounds__(256) void gd_sums_stream_kernel(Job job)
     r_end = r_end < n_reads ? r_end : n_reads;
     // one descriptor pair for the wave's whole range: reads past it load 0 = no ops
     const rsrc_t r_pos = make_rsrc(c.pos + r_first, (r_end - r_first) * 4u);
-    const rsrc_t r_rec = RAW ? make_rsrc(c.off + r_first, (r_end - r_first + 1u) * 4u)       // (+ the end of the last read)
-                             : make_rsrc(c.rec + r_first, (r_end - r_first) * 4u);
-    // RAW: flags (16 bits) and MAPQs (8 bits), four per lane in one load each; the ranges are rounded up to whole
+    const rsrc_t r_rec = make_rsrc(c.off + r_first, (r_end - r_first + 1u) * 4u);       // (+ the end of the last read)
+    // flags (16 bits) and MAPQs (8 bits), four per lane in one load each; the ranges are rounded up to whole
     // dwords (at most 2 / 3 bytes past the wave's last read, inside the same aligned word: gd_tile_fast.hpp)
-    const rsrc_t r_flag = make_rsrc(RAW ? (const void*)(c.flag + r_first) : nullptr, RAW ? ((r_end - r_first + 1u) & ~1u) * 2u : 0u);
-    const rsrc_t r_mapq = make_rsrc(RAW ? (const void*)(c.mapq + r_first) : nullptr, RAW ? ((r_end - r_first + 3u) & ~3u) : 0u);
+    const rsrc_t r_flag = make_rsrc((const void*)(c.flag + r_first), ((r_end - r_first + 1u) & ~1u) * 2u);
+    const rsrc_t r_mapq = make_rsrc((const void*)(c.mapq + r_first), ((r_end - r_first + 3u) & ~3u));
 
     uint4* const Q = &s_q[(threadIdx.x >> 6) * SQ_CAP];
     uint32_t qn = 0;                                             // queued odd reads (wave uniform)
@@ -199,21 +189,16 @@ __global__ __launch_bounds__(256) void gd_sums_stream_kernel(Job job)
     auto load_records = [&](Stage& S, uint32_t g) {
         S.pv = __builtin_amdgcn_raw_buffer_load_b128(r_pos, (int)(g - r_first) * 4 + lane * 16, 0, 0);
         S.rv = __builtin_amdgcn_raw_buffer_load_b128(r_rec, (int)(g - r_first) * 4 + lane * 16, 0, 0);
-        if (RAW) {
-            typedef unsigned int v2u_t __attribute__((ext_vector_type(2)));
-            S.g0 = g;
-            S.ob = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r_rec, (int)(g - r_first) * 4 + lane * 16 + 16, 0, 0);
-            const v2u_t fv = __builtin_amdgcn_raw_buffer_load_b64(r_flag, (int)(g - r_first) * 2 + lane * 8, 0, 0);
-            S.fw0 = fv.x; S.fw1 = fv.y;
-            S.mq = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r_mapq, (int)(g - r_first) + lane * 4, 0, 0);
-        } else {
-            S.ob = g < r_end ? off[g] : 0u;
-        }
+        typedef unsigned int v2u_t __attribute__((ext_vector_type(2)));
+        S.g0 = g;
+        S.ob = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r_rec, (int)(g - r_first) * 4 + lane * 16 + 16, 0, 0);
+        const v2u_t fv = __builtin_amdgcn_raw_buffer_load_b64(r_flag, (int)(g - r_first) * 2 + lane * 8, 0, 0);
+        S.fw0 = fv.x; S.fw1 = fv.y;
+        S.mq = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r_mapq, (int)(g - r_first) + lane * 4, 0, 0);
     };
-    // stage 2: where the group's ops are -- a prefix sum of the op counts in the record words -- and the first op
-    // of each read (the only one of 98 % of short reads)
+    // stage 2: where the group's ops are (the CSR offsets say it) and the first two ops of each read
     auto fetch_ops = [&](Stage& S) {
-        if (RAW) {
+        {
             const uint32_t o[U + 1] = {S.rv.x, S.rv.y, S.rv.z, S.rv.w, S.ob};
             uint32_t n[U];
             bool keep[U];
@@ -256,34 +241,6 @@ __global__ __launch_bounds__(256) void gd_sums_stream_kernel(Job job)
                 kb |= k ? 1u << u : 0u;
             }
             S.obase = kb;
-            return;
-        }
-        const uint32_t rec[U] = {S.rv.x, S.rv.y, S.rv.z, S.rv.w};
-        uint32_t n[U], ex[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) n[u] = rec[u] & norm::REC_NMAX;
-        ex[0] = 0; ex[1] = n[0]; ex[2] = ex[1] + n[1]; ex[3] = ex[2] + n[2];
-        const uint32_t ltot = ex[3] + n[3];
-        S.obase = (uint32_t)wave_inclusive_scan((int)ltot) - ltot;
-        const gptr_u32 cig = cigar + S.ob;                         // canonical ops of this group's reads, in read order
-        // a lane whose four reads have one op each (nearly all lanes of a short-read sample) finds them side by side:
-        // ONE 16-byte load; the others gather theirs read by read
-        typedef unsigned int v4u_t __attribute__((ext_vector_type(4)));
-        typedef const __attribute__((address_space(1))) v4u_t* gptr_v4;
-        const bool four = ((n[0] & n[1] & n[2] & n[3]) == 1u) & ((n[0] | n[1] | n[2] | n[3]) == 1u);
-        v4u_t o4 = {0u, 0u, 0u, 0u};
-        if (four) o4 = *(gptr_v4)(cig + S.obase);
-        const uint32_t o[U] = {o4.x, o4.y, o4.z, o4.w};
-        bool keep[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            keep[u] = ((rec[u] & fmask) == 0) & ((int)((rec[u] >> 12) & 0xffu) >= Q_) & (n[u] != 0u);
-            S.cg[u] = keep[u] ? o[u] : 0u;
-        }
-        if (__builtin_amdgcn_ballot_w64(!four & (ltot != 0u)) != 0ull) {
-#pragma unroll
-            for (int u = 0; u < U; ++u)
-                if (!four & keep[u]) S.cg[u] = cig[S.obase + ex[u]];
         }
     };
     // stage 3: the group's reads onto their windows
@@ -292,7 +249,7 @@ __global__ __launch_bounds__(256) void gd_sums_stream_kernel(Job job)
         const uint32_t rec[U] = {S.rv.x, S.rv.y, S.rv.z, S.rv.w};
         uint32_t n[U], ex[U];
         bool keep[U];
-        if (RAW) {
+        {
             const uint32_t oe[U] = {S.rv.y, S.rv.z, S.rv.w, S.ob};
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -300,13 +257,6 @@ __global__ __launch_bounds__(256) void gd_sums_stream_kernel(Job job)
                 n[u] = keep[u] ? oe[u] - rec[u] : 0u;
                 ex[u] = rec[u];                                    // the read's first op, an index into the contig's ops
             }
-        } else {
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                n[u] = rec[u] & norm::REC_NMAX;
-                keep[u] = ((rec[u] & fmask) == 0) & ((int)((rec[u] >> 12) & 0xffu) >= Q_) & (n[u] != 0u);
-            }
-            ex[0] = 0; ex[1] = n[0]; ex[2] = ex[1] + n[1]; ex[3] = ex[2] + n[2];
         }
 
         // this lane's window base: the start window of its first read (sorted records: non-decreasing over the
@@ -322,15 +272,15 @@ __global__ __launch_bounds__(256) void gd_sums_stream_kernel(Job job)
         uint32_t odd = 0;                                          // bit u: read u of this lane is queued
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            // canonical: a single op is an M of 1 <= len < 2^28.  [s, e) clipped to the contig, in 32 bits.  A kept
-            // read FITS when it is one M of fewer than 2^22 bases (the wave's prefix sums stay below 2^32 whatever
+            // [s, e) clipped to the contig, in 32 bits.  A kept
+            // read FITS when it is one counted op of fewer than 2^22 bases (the wave's prefix sums stay below 2^32 whatever
             // the window) at a non-negative POS that ends inside the lane's three windows; every other read --
             // several ops, a long or sparse read, a negative POS -- is an EMPTY interval here and goes to the queue
             const uint32_t len = S.cg[u] >> 4;
             const uint32_t s = p[u] > 0 ? (uint32_t)p[u] : 0u;
             const uint32_t eu = s + len;                           // < 2^31 + 2^28
             const uint32_t ec = eu < length ? eu : length;
-            const bool fits = keep[u] & (RAW ? S.cg[u] != 0xffffffffu : n[u] == 1u) & (len < (1u << 22)) & (p[u] >= 0) & (ec <= nb2);
+            const bool fits = keep[u] & (S.cg[u] != 0xffffffffu) & (len < (1u << 22)) & (p[u] >= 0) & (ec <= nb2);
             const uint32_t e = fits ? ec : s;
             const uint32_t l1 = s > nb0 ? s : nb0, l2 = s > nb1 ? s : nb1;
             const uint32_t h0 = e < nb0 ? e : nb0, h1 = e < nb1 ? e : nb1;
@@ -350,14 +300,14 @@ __global__ __launch_bounds__(256) void gd_sums_stream_kernel(Job job)
             odd &= odd - 1u;
             const unsigned long long m = __builtin_amdgcn_ballot_w64(mine);
             const uint32_t np = (uint32_t)__popcll(m);
-            if (qn + np > (uint32_t)SQ_CAP) { drain_queue<RAW>(Q, qn, lane, cigar, length, acc, W, wm, ws); qn = 0; }
+            if (qn + np > (uint32_t)SQ_CAP) { drain_queue(Q, qn, lane, cigar, length, acc, W, wm, ws); qn = 0; }
             if (mine) {
                 const uint32_t rk = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32),
                                              __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
                 const int32_t pu = u == 0 ? p[0] : u == 1 ? p[1] : u == 2 ? p[2] : p[3];
                 const uint32_t nu = u == 0 ? n[0] : u == 1 ? n[1] : u == 2 ? n[2] : n[3];
                 const uint32_t xu = u == 0 ? ex[0] : u == 1 ? ex[1] : u == 2 ? ex[2] : ex[3];
-                Q[rk] = make_uint4((uint32_t)pu, RAW ? xu : S.ob + S.obase + xu, nu, 0u);
+                Q[rk] = make_uint4((uint32_t)pu, xu, nu, 0u);
             }
             qn += np;
         }
@@ -398,7 +348,7 @@ __global__ __launch_bounds__(256) void gd_sums_stream_kernel(Job job)
         if (g + 2u * GROUP >= r_end) break;
         load_records(B, g + 4u * GROUP); fetch_ops(A); work(C, g + 2u * GROUP);
     }
-    if (qn != 0u) drain_queue<RAW>(Q, qn, lane, cigar, length, acc, W, wm, ws);
+    if (qn != 0u) drain_queue(Q, qn, lane, cigar, length, acc, W, wm, ws);
     // the wave's accumulators -> memory, once
     __builtin_amdgcn_wave_barrier();
 #pragma unroll

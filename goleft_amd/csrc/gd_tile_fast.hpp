@@ -1,35 +1,31 @@
 // gd_tile_fast.hpp -- K1, the tile kernel of the short-read path: the straight-line kernel for ORDINARY
 // tiles (all T = 4096 positions inside the contig, at most one batch of 1024 candidate reads, at most
-// 1024 canonical CIGAR ops -- 99.99 % of a 30x genome; gd_prep_kernel lists every other tile for
+// 1280 CIGAR ops -- 99.99 % of a 30x genome; gd_prep_kernel lists every other tile for
 // gd_tile_slow_kernel).  Same algorithm and results as gd_tile_generic.hpp; it replaces, like it, the
 // per-read CIGAR walk of `samtools depth` (/root/reference/depth/depth.go:45) and the per-line window /
 // class reductions of the callback (depth/depth.go:293-323).
 //
 // The generic kernel was bound by instruction issue, not bytes (~456 VALU + ~400
 // SALU wave-instructions per wave and tile, 5 workgroups per CU).  What is different here:
-//   * CIGARs are canonical (gd_normalize.hpp): a read with ONE op is one counted interval, no op decode,
-//     no zero-length / non-M special cases: 98 % of short reads take five VALU ops from record to marks;
-//   * the few multi-op reads (deletions, skips) go to ONE workgroup queue (an LDS counter, one atomic
-//     per wave that has any) and are walked after a barrier by as many lanes as there are entries --
-//     one dense walk per TILE instead of one sparse walk per WAVE;
+//   * it reads the records AS THEY ARRIVED (pos, flag, MAPQ, CSR offsets, BAM-encoded ops in any form) -- nothing
+//     derived has to exist before the first gd_compute: a `goleft depth` run computes every input exactly once, so
+//     a pass that rewrites the records first costs more than it saves (rounds 2-4 kept such a pass, "canonical
+//     records", as an option; round 5 removed it).  A lane's four reads bring their CSR offsets (no prefix sum
+//     over op counts), flag and MAPQ come as one 8-byte and one 4-byte load per lane, reads of ONE OR TWO ops of
+//     any kind (150M, 20S130M, 100M50S, 5H145M ... 97 % of short reads) are one interval computed inline: no op
+//     decode loop, no zero-length / non-M special cases;
+//   * everything longer goes to ONE workgroup queue (an LDS counter, one atomic per wave that has any) and is
+//     walked after a barrier by as many lanes as there are entries -- one dense walk per TILE instead of one
+//     sparse walk per WAVE;
 //   * no pass 1: a wave scans its quarter, publishes the quarter's total, and only adds the carry of
-//     the quarters before it after the barrier -- the 4 x ds_read_b128 + reduction of the old pass 1
-//     are gone, the barrier count is unchanged;
+//     the quarters before it after the barrier;
 //   * nothing is derived on the (CU-shared) scalar unit: pointers at the tile's first read / op and
 //     every wave's window / run-break state come resolved from gd_prep_kernel (TileFast);
-//   * LDS: 16 KB difference array + 4 KB op staging (reused as the class-boundary bitmaps of phases B
-//     and C) + 1.5 KB queue = 22 KB => 7 workgroups (28 waves) per CU instead of 5.
-//
-// RAW = true: the same kernel on the records AS THEY ARRIVED (pos, flag, MAPQ, CSR offsets, BAM-encoded ops in
-// any form) -- nothing derived has to exist before the first gd_compute.  A `goleft depth` run computes every
-// input exactly once, so a pass that rewrites the records first (gd_normalize.hpp: ~28 bytes per read moved to
-// save 3 bytes per read here) costs more than it saves; this variant reads 11 + 4.4 bytes per read instead of
-// 8 + 4.2.  What differs: a lane's four reads bring their CSR offsets (no prefix sum over op counts), flag and
-// MAPQ come as one 8-byte and one 4-byte load per lane, reads of ONE OR TWO ops of any kind (150M, 20S130M,
-// 100M50S, 5H145M ... 97 % of short reads) are one interval computed inline, everything longer takes the
-// workgroup queue and the generic op walk.  gd_prep_kernel rounds the tile's first read down to a multiple of
-// four so that every vector load is naturally aligned (the contig's arrays must be: 16 / 16 / 8 / 4 bytes for
-// pos / offsets / flag / MAPQ, else the generic kernel runs).
+//   * LDS: 16 KB difference array + 5 KB op staging (reused as the class-boundary bitmaps of phases B
+//     and C) + 1.4 KB queue = 23 004 bytes => 7 workgroups (28 waves) per CU instead of 5.
+// gd_prep_kernel rounds the tile's first read down to a multiple of four so that every vector load is naturally
+// aligned (the contig's arrays must be: 16 / 16 / 8 / 4 bytes for pos / offsets / flag / MAPQ, else the generic
+// kernel runs).
 #pragma once
 
 #ifndef GD_LOAD_AUX
@@ -44,19 +40,17 @@ constexpr int NT = 256;
 constexpr int NW = NT / WAVE;          // 4 waves
 constexpr int CHUNK = T / NW;          // 1024 positions per wave
 constexpr int ROWS = CHUNK / 256;      // 4 rows of 256 positions per wave
-constexpr int CQ = 1024;               // staged canonical ops
-constexpr int CQ_RAW = 1280;           // staged ops, records as they arrived (7 % more ops per read: 1024 would put 1-2 % of a 30x genome's tiles on the slow list)
+constexpr int CQ = 1280;               // staged ops (1024 would put 1-2 % of a 30x genome's tiles on the slow list)
 constexpr int U = 4;                   // reads per lane
-constexpr int QCAP = 128;              // queued multi-op reads per tile (more: walked in place)
-constexpr int QCAP_RAW = 120;          // ... raw variant: 23 004 bytes of LDS = seven workgroups per CU at any allocation granularity up to 512
+constexpr int QCAP = 120;              // queued multi-op reads per tile (more: walked in place); 23 004 bytes of LDS = seven workgroups per CU at any allocation granularity up to 512
 constexpr int NWORDS = T / 32;
 
 // ST: per-base stores 0 plain, 1 non-temporal, 2 none (windows-only output).
-template <int ST, bool RAW = false>
+template <int ST>
 __global__ __launch_bounds__(NT) void gd_tile_fast_kernel(Job job)
 {
-    constexpr int CQN = RAW ? CQ_RAW : CQ;
-    constexpr int QCAPN = RAW ? QCAP_RAW : QCAP;
+    constexpr int CQN = CQ;
+    constexpr int QCAPN = QCAP;
     __shared__ __attribute__((aligned(16))) int32_t s_diffp[T + 4];   // [3] = index -1
     __shared__ __attribute__((aligned(16))) uint32_t s_cig[CQN];      // phase A: staged ops; B, C: boundary bitmaps
     __shared__ uint32_t s_q[3 * QCAPN];                                // ps4 | first op (staged index) | n ops
@@ -85,7 +79,7 @@ __global__ __launch_bounds__(NT) void gd_tile_fast_kernel(Job job)
     tf.nrd = tp->nrd;
     if ((int32_t)tf.nrd < 0) return;                   // on the slow list
     tf.pos = tp->pos; tf.rec = tp->rec; tf.cig = tp->cig;
-    if (RAW) { tf.flag = tp->flag; tf.mapq = tp->mapq; tf.clo = tp->clo; }
+    tf.flag = tp->flag; tf.mapq = tp->mapq; tf.clo = tp->clo;
     tf.out = tp->out; tf.wsum = tp->wsum; tf.wmin = tp->wmin;
     tf.t0 = tp->t0; tf.nst = tp->nst; tf.ctg = tp->ctg;
 
@@ -95,32 +89,27 @@ __global__ __launch_bounds__(NT) void gd_tile_fast_kernel(Job job)
     const int seen0 = __hip_atomic_load(&job.counters->max_span, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     constexpr int T4 = T * 4;
 
-    // ---- loads first: every lane takes FOUR CONSECUTIVE reads -- 16 bytes of `pos`, 16 bytes of record
-    // words (flag | MAPQ | op count) -- and the workgroup the tile's op range: one memory round trip,
-    // two + four vector loads per lane.  The descriptors end at the tile's last read: dwords past it
+    // ---- loads first: every lane takes FOUR CONSECUTIVE reads -- 16 bytes of `pos`, 16 + 4 bytes of CSR
+    // offsets, their flags and MAPQs -- and the workgroup the tile's op range: one memory round trip.  The descriptors end at the tile's last read: dwords past it
     // read 0 (gfx950 checks the range of a multi-dword raw buffer load per dword: tools/probe/oob_x4.hip),
     // i.e. no ops => dropped.
     const uint32_t nrd = tf.nrd;
     const rsrc_t r_pos = make_rsrc(tf.pos, nrd * 4u);
-    // RAW: tf.rec points at the CSR offsets of the tile's first read; entry nrd (the end of the last read) is read too
-    const rsrc_t r_rec = make_rsrc(tf.rec, (RAW && nrd != 0u ? nrd + 1u : nrd) * 4u);   // (no reads: no array either)
+    // tf.rec points at the CSR offsets of the tile's first read; entry nrd (the end of the last read) is read too
+    const rsrc_t r_rec = make_rsrc(tf.rec, (nrd != 0u ? nrd + 1u : nrd) * 4u);   // (no reads: no array either)
     const rsrc_t r_cig = make_rsrc(tf.cig, tf.nst * 4u);
     const int tid4 = tid * 4;
     typedef unsigned int v4u __attribute__((ext_vector_type(4)));
     typedef unsigned int v2u __attribute__((ext_vector_type(2)));
     const v4u pv = __builtin_amdgcn_raw_buffer_load_b128(r_pos, tid * 16, 0, GD_LOAD_AUX);
     const v4u rv = __builtin_amdgcn_raw_buffer_load_b128(r_rec, tid * 16, 0, GD_LOAD_AUX);
-    uint32_t o4 = 0, mv = 0;
-    v2u fv = {0u, 0u};
-    if (RAW) {
-        // flag: four 16-bit values, MAPQ: four bytes per lane.  The ranges are rounded up to whole dwords (the range
-        // check is per dword): at most 2 / 3 bytes past the tile's last read, inside the same aligned word.
-        const rsrc_t r_flag = make_rsrc(tf.flag, ((nrd + 1u) & ~1u) * 2u);
-        const rsrc_t r_mapq = make_rsrc(tf.mapq, (nrd + 3u) & ~3u);
-        o4 = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r_rec, tid * 16 + 16, 0, GD_LOAD_AUX);
-        fv = __builtin_amdgcn_raw_buffer_load_b64(r_flag, tid * 8, 0, GD_LOAD_AUX);
-        mv = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r_mapq, tid4, 0, GD_LOAD_AUX);
-    }
+    // flag: four 16-bit values, MAPQ: four bytes per lane.  The ranges are rounded up to whole dwords (the range
+    // check is per dword): at most 2 / 3 bytes past the tile's last read, inside the same aligned word.
+    const rsrc_t r_flag = make_rsrc(tf.flag, ((nrd + 1u) & ~1u) * 2u);
+    const rsrc_t r_mapq = make_rsrc(tf.mapq, (nrd + 3u) & ~3u);
+    const uint32_t o4 = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r_rec, tid * 16 + 16, 0, GD_LOAD_AUX);
+    const v2u fv = __builtin_amdgcn_raw_buffer_load_b64(r_flag, tid * 8, 0, GD_LOAD_AUX);
+    const uint32_t mv = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r_mapq, tid4, 0, GD_LOAD_AUX);
     uint32_t cgv[CQN / NT];
 #pragma unroll
     for (int k = 0; k < CQN / NT; ++k)
@@ -134,25 +123,16 @@ __global__ __launch_bounds__(NT) void gd_tile_fast_kernel(Job job)
         for (int i = 0; i < T / 4 / NT; ++i) d4[tid + i * NT] = z;
         if (tid == 0) { d4[T / 4] = z; s_qn = 0; s_hasb = 0; }
     }
-    // ---- where each read's ops are: prefix sum of the op counts (reads and ops are in the same order);
-    // RAW: the CSR offsets say it
+    // ---- where each read's ops are: the CSR offsets say it
     const uint32_t rec[U] = {rv.x, rv.y, rv.z, rv.w};
-    uint32_t n[U], ex[U];                               // op count, ops of this lane's reads before it
-    uint32_t ltot = 0, lincl = 0;
-    if (RAW) {
+    uint32_t n[U], ex[U];                               // op count, staged index of the read's first op
+    {
         const uint32_t oe[U] = {rv.y, rv.z, rv.w, o4};
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             n[u] = (uint32_t)(tid4 + u) < nrd ? oe[u] - rec[u] : 0u;
-            ex[u] = rec[u] - tf.clo;                    // staged index of the read's first op
+            ex[u] = rec[u] - tf.clo;
         }
-    } else {
-#pragma unroll
-        for (int u = 0; u < U; ++u) n[u] = rec[u] & norm::REC_NMAX;
-        ex[0] = 0; ex[1] = n[0]; ex[2] = ex[1] + n[1]; ex[3] = ex[2] + n[2];
-        ltot = ex[3] + n[3];
-        lincl = (uint32_t)wave_inclusive_scan((int)ltot);
-        if (lane == 63) s_wcnt[wv] = lincl;             // ops of this wave's 256 reads
     }
     // stage the ops
 #pragma unroll
@@ -163,43 +143,31 @@ __global__ __launch_bounds__(NT) void gd_tile_fast_kernel(Job job)
     uint32_t smax = 0;
     {
         const int neg4t0 = (int)(0u - ((uint32_t)tf.t0 << 2));     // (p << 2) + neg4t0 = 4 * (p - t0)
-        uint32_t obase = lincl - ltot;                             // first op of this lane's reads (staged index)
-        if (!RAW) {
-#pragma unroll
-            for (int w = 0; w < NW - 1; ++w) obase += w < wv ? s_wcnt[w] : 0u;
-        }
         const int32_t p[U] = {(int32_t)pv.x, (int32_t)pv.y, (int32_t)pv.z, (int32_t)pv.w};
-        const uint32_t fmask = job.flag_mask << 20;
         uint32_t cg[U], idx[U];
         bool keep[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            idx[u] = obase + ex[u];
-            if (RAW) {
-                const uint32_t fw = u < 2 ? fv.x : fv.y;
-                const uint32_t f = (u & 1) ? fw >> 16 : fw & 0xffffu;
-                const uint32_t mq = (mv >> (8 * u)) & 0xffu;
-                keep[u] = ((f & job.flag_mask) == 0) & ((int)mq >= job.Q) & (n[u] != 0);   // n = 0 past the tile's reads
-            } else {
-                keep[u] = ((rec[u] & fmask) == 0) & ((int)((rec[u] >> 12) & 0xffu) >= job.Q) & (n[u] != 0);
-            }
+            idx[u] = ex[u];
+            const uint32_t fw = u < 2 ? fv.x : fv.y;
+            const uint32_t f = (u & 1) ? fw >> 16 : fw & 0xffffu;
+            const uint32_t mq = (mv >> (8 * u)) & 0xffu;
+            keep[u] = ((f & job.flag_mask) == 0) & ((int)mq >= job.Q) & (n[u] != 0);   // n = 0 past the tile's reads
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) cg[u] = s_cig[keep[u] ? idx[u] : 0u];   // slot 0 is always addressable
-        uint32_t cg2[U] = {0u, 0u, 0u, 0u};                        // RAW: the second op of a two-op read (else 0 = "0M": neutral)
-        if (RAW) {
+        uint32_t cg2[U];                                           // the second op of a two-op read (else 0 = "0M": neutral)
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const uint32_t x = s_cig[(keep[u] & (n[u] == 2u)) ? idx[u] + 1u : 0u];
-                cg2[u] = n[u] == 2u ? x : 0u;
-            }
+        for (int u = 0; u < U; ++u) {
+            const uint32_t x = s_cig[(keep[u] & (n[u] == 2u)) ? idx[u] + 1u : 0u];
+            cg2[u] = n[u] == 2u ? x : 0u;
         }
         int ps4[U];
         bool cx[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             ps4[u] = (int)(((uint32_t)p[u] << 2) + (uint32_t)neg4t0);
-            if (RAW) {
+            {
                 // one or two ops of any kind are at most ONE counted interval: M/=/X lengths add up (two of them
                 // are adjacent), a leading D/N shifts the start, I/S/H/P and a trailing D/N cover nothing
                 const uint32_t oa = cg[u] & 0xfu, la = cg[u] >> 4, ob = cg2[u] & 0xfu, lb = cg2[u] >> 4;
@@ -217,18 +185,6 @@ __global__ __launch_bounds__(NT) void gd_tile_fast_kernel(Job job)
                 const int e4 = s4 + (int)(L << 2);
                 if (simple & (L != 0u) & (e4 >= 0) & (s4 < T4)) {
                     const int cs4 = s4 > -4 ? s4 : -4;
-                    atomicAdd(lds_at(s_diff, cs4), 1);
-                    if (e4 < T4) atomicAdd(lds_at(s_diff, e4), -1);
-                }
-            } else {
-                const uint32_t len = cg[u] >> 4;                   // canonical: a single op is an M of len >= 1
-                const bool simple = keep[u] & (n[u] == 1u);
-                cx[u] = keep[u] & (n[u] > 1u);
-                const uint32_t rs = simple ? len : 0u;
-                smax = rs > smax ? rs : smax;
-                const int e4 = ps4[u] + (int)(len << 2);
-                if (simple & (e4 >= 0)) {                          // reaches t0-1 or beyond
-                    const int cs4 = ps4[u] > -4 ? ps4[u] : -4;
                     atomicAdd(lds_at(s_diff, cs4), 1);
                     if (e4 < T4) atomicAdd(lds_at(s_diff, e4), -1);
                 }

@@ -1,5 +1,5 @@
 // gd_tile_generic.hpp -- K1, the generic tile kernel (short-read path): any tile shape (T, NT), tiles
-// clipped at a contig end, tiles deeper than one batch of reads, CIGARs in any form (canonical or not),
+// clipped at a contig end, tiles deeper than one batch of reads, CIGARs in any form,
 // any window size.  It runs every tile when the straight-line kernel is switched off
 // (GD_OPT_FAST_KERNEL = 0), the tiles gd_prep_kernel lists as `slow` otherwise, and -- as
 // gd_tile_sums_kernel -- the sums-only output.  Same algorithm and results as gd_tile_fast.hpp: phase A
@@ -608,7 +608,7 @@ __device__ __forceinline__ void tile_body(const Job& job, const TileInfo& ti, co
     phase_c<T, NT>(job, tile, t0, ti.ctg, tid, lane, wv, s_bmap, s_clo, s_chi, s_wcnt, &s_hasb, &s_base);
 }
 
-// Every tile, one workgroup each (GD_OPT_FAST_KERNEL = 0, or records without canonical CIGARs / record words).
+// Every tile, one workgroup each (GD_OPT_FAST_KERNEL = 0, or contig arrays the straight-line kernel's vector loads cannot take).
 template <int T, int NT, int OPT>
 __global__ __launch_bounds__(NT) void gd_tile_kernel(Job job)
 {

@@ -16,7 +16,7 @@ from ._lib import GdBatch, GdParams, GdRun, GdStats
 CLASS_NAMES = ("NO_COVERAGE", "LOW_COVERAGE", "CALLABLE", "EXCESSIVE_COVERAGE")
 K_PREP, K_TILE, K_RUNS, K_EXPAND, K_SCAN, K_CKPT, K_SEQSTATS, K_MDFLAGS, K_INFLATE, K_NORM = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9
 # gd_set_option keys (include/goleft_depth.h)
-OPT_NT_STORES, OPT_NORMALIZE, OPT_FAST_KERNEL, OPT_COPY_THREADS, OPT_PUSH_THREADS, OPT_H2D_KERNEL, OPT_PUSH_CHUNK, OPT_BAM_REFS, OPT_FUSED_NORMALIZE = 3, 4, 5, 6, 7, 8, 9, 10, 11
+OPT_NT_STORES, OPT_FAST_KERNEL, OPT_COPY_THREADS, OPT_PUSH_THREADS, OPT_H2D_KERNEL, OPT_PUSH_CHUNK, OPT_BAM_REFS = 3, 5, 6, 7, 8, 9, 10
 OPT_INGEST_INDEX = 14
 PATH_AUTO, PATH_TILE, PATH_SCATTER, PATH_CHUNK = 0, 1, 2, 3
 # gd_stats.tile_kernel (include/goleft_depth.h GD_TK_*)
@@ -136,10 +136,6 @@ class DepthEngine:
     # -- compute ----------------------------------------------------------
     def compute(self):
         self._chk(self._lib.gd_compute(self._ctx))
-
-    def normalize(self, force: bool = False):
-        """gd_normalize: canonical records (+ long-read structures) of the selected contigs, one batch."""
-        self._chk(self._lib.gd_normalize(self._ctx, 1 if force else 0))
 
     def drop_derived(self):
         """gd_drop_derived: back to the state right after the records arrived."""
@@ -534,18 +530,6 @@ class DepthEngine:
         """gd_set_option (OPT_* above): tuning / diagnostic switches; results never change."""
         self._chk(self._lib.gd_set_option(self._ctx, int(option), int(value)))
 
-    def canonical_cigars(self, tid: int, n_reads: int):
-        """(cigar_off u32[n_reads + 1], cigar u32[n_ops]) of the canonical CIGARs of the contig's n_reads
-        records (diagnostic)."""
-        n = C.c_size_t(0)
-        rc = self._lib.gd_canonical_cigars(self._ctx, tid, None, None, 0, C.byref(n))
-        if rc not in (0, -8):
-            self._chk(rc)
-        off = np.zeros(int(n_reads) + 1, np.uint32)
-        cig = np.zeros(max(1, n.value), np.uint32)
-        self._chk(self._lib.gd_canonical_cigars(self._ctx, tid, off.ctypes.data, cig.ctypes.data, len(cig), C.byref(n)))
-        return off, cig[:n.value]
-
     def set_export(self, device_ptr: int, max_windows: int, cap_bounds: int):
         """gd_set_export: every compute() also writes the packed block
         [n_bounds][sums][mins][bounds] into caller-owned device memory (0 switches it off)."""
@@ -577,12 +561,6 @@ class DepthEngine:
         o, n = C.c_size_t(), C.c_size_t()
         self._chk(self._lib.gd_window_offset(self._ctx, tid, C.byref(o), C.byref(n)))
         return o.value, n.value
-
-
-def has_canonical() -> bool:
-    """gd_build_features() & GD_FEATURE_CANONICAL: canonical records (gd_normalize, GD_OPT_NORMALIZE = 1) are part of
-    this build of the library (goleft_amd/csrc/Makefile: make CANONICAL=1; the default build leaves them out)."""
-    return bool(_lib.load().gd_build_features() & 1)
 
 
 def device_count() -> int:

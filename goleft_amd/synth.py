@@ -176,13 +176,6 @@ def algorithmic_bytes(n_reads: int, n_ops: int, n_bases: int, n_windows: int, ra
     return (11 if raw else 8) * n_reads + 4 * n_ops + 4 * n_bases + 8 * n_windows
 
 
-def normalise_bytes(n_reads: int, n_ops: int, n_canonical_ops: int, n_bases: int) -> int:
-    """What one pass that builds the canonical records has to move at least: in pos 4 + CSR offset 4 +
-    flag 2 + MAPQ 1 per read and 4 per original op; out record word 4 + canonical offset 4 per read,
-    4 per canonical op, 4 per 64 reference positions (position index)."""
-    return 11 * n_reads + 4 * n_ops + 8 * n_reads + 4 * n_canonical_ops + n_bases // 16
-
-
 # ---------------------------------------------------------------------------
 # Long-read model (BASELINE.json config 5: 20x ONT, N50 ~ 20 kb, indel-heavy)
 # ---------------------------------------------------------------------------

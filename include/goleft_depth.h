@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define GD_ABI_VERSION 13
+#define GD_ABI_VERSION 14
 
 typedef enum {
     GD_OK = 0,
@@ -108,7 +108,7 @@ typedef struct {
     int32_t  reruns;         /* times the last gd_compute re-ran (span / run capacity) */
     int32_t  path;           /* GD_PATH_TILE / _SCATTER / _CHUNK: what the last gd_compute ran */
     int32_t  n_slow_tiles;   /* tile path with GD_OPT_FAST_KERNEL: tiles that took the generic kernel instead */
-    uint64_t n_canonical_ops; /* ops of the canonical CIGARs the tile / long-read path read (0: it read the original ones) */
+    uint64_t n_canonical_ops; /* (ABI 13: ops of canonical CIGARs; always 0 since ABI 14 -- every path reads the original ops) */
     int32_t  tile_kernel;    /* GD_TK_*: the kernel that did the per-base arithmetic of the last gd_compute */
     int32_t  reserved_;
     uint64_t n_deletions;    /* long-read path: entries of the deletion lists the tile kernel read (8 bytes each) */
@@ -117,11 +117,11 @@ typedef struct {
 /* gd_stats.tile_kernel */
 enum { GD_TK_NONE = 0,
        GD_TK_GENERIC = 1,      /* gd_tile_kernel: any tile shape, CIGARs in any form */
-       GD_TK_FAST = 2,         /* gd_tile_fast_kernel on canonical records (+ the generic kernel for the slow list) */
+       GD_TK_FAST = 2,         /* (ABI 13: the straight-line kernel on canonical records; not reported since ABI 14) */
        GD_TK_FAST_RAW = 3,     /* gd_tile_fast_kernel on the records as they arrived (+ the slow list) */
        GD_TK_LONG = 4,         /* gd_ltile2_kernel (long-read path) */
        GD_TK_SCATTER = 5,      /* gd_expand_scatter_kernel + gd_scan_kernel */
-       GD_TK_SUMS_STREAM = 6,  /* gd_sums_stream_kernel (GD_OUT_SUMS_ONLY over canonical records) */
+       GD_TK_SUMS_STREAM = 6,  /* (ABI 13: the streaming sums kernel over canonical records; not reported since ABI 14) */
        GD_TK_TILE_SUMS = 7,    /* gd_tile_sums_kernel (GD_OUT_SUMS_ONLY otherwise) */
        GD_TK_SUMS_STREAM_RAW = 8 };  /* gd_sums_stream_kernel over the records as they arrived */
 
@@ -157,13 +157,6 @@ enum { GD_PATH_AUTO = 0, GD_PATH_TILE = 1, GD_PATH_SCATTER = 2, GD_PATH_CHUNK = 
 
 const char* gd_strerror(int status);
 int         gd_abi_version(void);
-/* Optional parts of this build, a mask of GD_FEATURE_*.  GD_FEATURE_CANONICAL: canonical records (gd_normalize,
- * GD_OPT_NORMALIZE = 1, gd_canonical_cigars, the kernels that read them) -- a rewritten copy of the records for a host
- * that computes the SAME records many times.  No caller in the reference does (a `goleft depth` run computes each input
- * once) and every default path reads the records as they arrived, so the default build leaves them out
- * (goleft_amd/csrc/Makefile: make CANONICAL=1 builds them in; without, those calls return GD_E_INVALID). */
-enum { GD_FEATURE_CANONICAL = 1 };
-int         gd_build_features(void);
 int         gd_device_count(int* n);
 
 /* Create a context bound to one HIP device (hipSetDevice is re-issued inside
@@ -185,17 +178,8 @@ int gd_set_path(gd_ctx* ctx, int path);
  * environment: these are calls. */
 enum { /* (1, 2: tile shapes other than 4096 positions x 256 threads -- measured slower everywhere, retired) */
        GD_OPT_NT_STORES = 3,        /* 1 (default): non-temporal per-base stores; 0: plain */
-       GD_OPT_NORMALIZE = 4,        /* canonical records (I/S/H/P and zero-length ops dropped, neighbouring M/=/X
-                                       merged, neighbouring D/N merged -- exactly what `samtools depth` without -J
-                                       distinguishes -- plus record words and a position index; gd_normalize.hpp):
-                                       2 (default): built by the first gd_compute whose kernel reads them -- the
-                                       long-read path and the streaming sums of GD_OUT_SUMS_ONLY; the short-read tile
-                                       path reads the records AS THEY ARRIVED (a `goleft depth` run computes each
-                                       input once: a pass that rewrites ~28 bytes per read to save 3 bytes per read
-                                       in the tile kernel does not pay); 1: built when records arrive (gd_adopt_device,
-                                       gd_ingest_finish, the first gd_compute after gd_commit) -- for a host that
-                                       computes the same records many times; 0: never for the tile path.
-                                       gd_normalize builds them on request under every setting. */
+       /* (4: canonical records -- a rewritten copy of the records for a host that computes the same records many times; no
+          caller in the reference does, every path reads the records as they arrived: removed in ABI 14) */
        GD_OPT_FAST_KERNEL = 5,      /* 1 (default): ordinary tiles run the straight-line tile kernel, the rest the
                                        generic one; 0: the generic kernel for every tile */
        GD_OPT_COPY_THREADS = 6,     /* host threads filling the staging buffer of gd_ingest_feed: 1 (default) .. 16 */
@@ -206,8 +190,7 @@ enum { /* (1, 2: tile shapes other than 4096 positions x 256 threads -- measured
                                        record walk takes the first record of ANOTHER reference as the end of a contig's
                                        records only when its refID is one a sorted BAM can hold there (greater than the
                                        contig's and below this number, or -1); anything else is a damaged record */
-       GD_OPT_FUSED_NORMALIZE = 11, /* 1 (default): gd_normalize builds canonical CIGARs, record words and position index in ONE
-                                       pass (offsets by decoupled look-back); 0: count / scan / write / index launches */
+       /* (11: how the canonical records were built: removed in ABI 14) */
        GD_OPT_INGEST_CRC = 12,      /* 1 (default): gd_ingest_* checks the CRC32 of every BGZF member after inflating it, as htslib
                                        does; 0: the file is trusted (a second pass over the inflated bytes is saved) */
        GD_OPT_INGEST_DMA = 13,      /* gd_ingest_feed*: streams a staged piece is split over: 1 (default) .. 4; 0: a copy kernel on a
@@ -246,25 +229,15 @@ enum { /* (1, 2: tile shapes other than 4096 positions x 256 threads -- measured
                                        with n workgroups), 0: five hipMemcpyAsync through a DMA engine */
 int gd_set_option(gd_ctx* ctx, int option, int64_t value);
 
-/* Builds the canonical records of every selected contig that lacks them (force != 0: of every selected contig,
- * again) in ONE batch -- one device allocation, one launch set over all contigs, one host synchronisation -- and,
- * for contigs the long-read path will take (GD_PATH_CHUNK, or GD_PATH_AUTO and more than 6 CIGAR ops per record),
- * their deletion lists and tile indexes.  gd_compute does this by itself when its kernel needs them; a host that
- * will compute the same records repeatedly calls it once (then the tile path reads 8 + 4.2 instead of 11 + 4.4
- * bytes per read).  gd_drop_derived forgets everything built from the records: the state right after they
- * arrived (measurement: one gd_compute from there is what one `goleft depth` run pays). */
-int gd_normalize(gd_ctx* ctx, int force);
+/* What is built FROM the records: nothing on the short-read tile path and for the streaming sums (their kernels read the
+ * records as they arrived); on the long-read path (GD_PATH_CHUNK, or GD_PATH_AUTO and more than 6 CIGAR ops per record)
+ * deletion lists, read records and tile indexes -- by the first gd_compute that needs them, in one pass over the original
+ * CIGARs, kept until the records change.  gd_drop_derived forgets them: the state right after the records arrived
+ * (measurement: one gd_compute from there is what one `goleft depth` run pays).  gd_rebuild_derived builds the ones the
+ * selected contigs currently hold again, into the device block they already occupy -- the work a fresh input costs,
+ * without the allocator's.  (ABI 13 also had gd_normalize / gd_canonical_cigars: canonical records, removed.) */
 int gd_drop_derived(gd_ctx* ctx);
-/* Measurement: rebuilds every derived structure the selected contigs currently hold from their records, into the
- * device blocks they already occupy (canonical records as gd_normalize(force); long-read structures that the
- * long-read path built straight from the records, the same way again) -- the work a fresh input costs, without
- * the allocator's. */
 int gd_rebuild_derived(gd_ctx* ctx);
-
-/* Diagnostic: the canonical CIGARs of contig tid (GD_OPT_NORMALIZE) as CSR offsets (n_reads + 1) and ops
- * (BAM encoding, op 0 = M or 3 = N) into host memory.  *n_ops receives the op count; GD_E_CAPACITY if cap_ops
- * is too small; GD_E_STATE if the contig's records have not been normalised (yet). */
-int gd_canonical_cigars(gd_ctx* ctx, int32_t tid, uint32_t* cigar_off, uint32_t* cigar, size_t cap_ops, size_t* n_ops);
 
 /* Which results gd_compute materialises in HBM.  GD_OUT_PERBASE (default): the
  * int32 per-base vector (12.4 GB for a human genome), needed by gd_perbase,
@@ -274,7 +247,7 @@ int gd_canonical_cigars(gd_ctx* ctx, int32_t tid, uint32_t* cigar_off, uint32_t*
 enum { GD_OUT_PERBASE = 1,
        /* Window sums ONLY (no per-base vector, no minima, no class runs): all that depth.bed's mean
         * column and the depthwed matrix need.  The short-read path then makes ONE streaming pass over the
-        * canonical records, every read adding its overlap with the one or two windows it touches -- no tiles,
+        * records as they arrived, every read adding its overlap with the one or two windows it touches -- no tiles,
         * no per-base scan at all (window_size >= 32; smaller windows and the long-read path silently run the
         * regular windows-only kernels).  gd_callable and minima report GD_E_STATE.  Excludes
         * GD_OUT_PERBASE. */

@@ -114,38 +114,6 @@ def perbase_numpy(r: Reads, q: int, start: int, end: int,
 # --------------------------------------------------------------------------
 # (b) second restatement of depth/depth.go:238-364 (string output)
 # --------------------------------------------------------------------------
-def canonical_cigars(r: "Reads"):
-    """(cigar_off, cigar) of the canonical form the engine builds at ingest (csrc/gd_normalize.hpp): what
-    `samtools depth` without -J can tell apart (depth/depth.go:45) -- I/S/H/P and zero-length ops dropped,
-    neighbouring M/=/X merged into one M (op 0), neighbouring D/N into one N (op 3; a merged length
-    that would exceed the 28-bit field splits off full-length ops), D/N after the last M dropped.
-    Pure Python, op by op: the independent restatement the device result is compared with."""
-    LEN_MAX = 0x0fffffff
-    off = [0]
-    out = []
-    for i in range(r.n):
-        ops = []                                   # [kind, len], kind 0 = M, 1 = N
-        for k in range(int(r.cigar_off[i]), int(r.cigar_off[i + 1])):
-            cg = int(r.cigar[k])
-            op, ln = cg & 0xf, cg >> 4
-            if ln == 0 or op not in (0, 2, 3, 7, 8):
-                continue
-            kind = 0 if op in (0, 7, 8) else 1
-            if ops and ops[-1][0] == kind:
-                ops[-1][1] += ln
-            else:
-                ops.append([kind, ln])
-        while ops and ops[-1][0] == 1:
-            ops.pop()
-        for kind, ln in ops:
-            while ln > LEN_MAX:                    # full-length pieces first, the remainder last
-                out.append((LEN_MAX << 4) | (0 if kind == 0 else 3))
-                ln -= LEN_MAX
-            out.append((ln << 4) | (0 if kind == 0 else 3))
-        off.append(len(out))
-    return np.asarray(off, np.uint32), np.asarray(out, np.uint32)
-
-
 def cov_class(depth: int, mincov: int, maxmean: int) -> str:
     """depth/depth.go:223-234."""
     if depth == 0:

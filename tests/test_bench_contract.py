@@ -37,11 +37,6 @@ def test_wgs_bench_line_has_the_contract_fields():
     assert d["value"] >= 1e9                                            # BASELINE.json's target at one GPU
     # round 3: the step starts from the records as they crossed the ABI; what round 2 called `value` is a side field
     assert "as they arrived" in d["config"]["step"] and d["roofline"]["kernel"].endswith("<raw>")
-    if "compute_only" in d:                                             # (a build with canonical records: csrc/Makefile CANONICAL=1)
-        o = d["compute_only"]
-        assert o["value"] > d["value"] * 0.9 and o["roofline"]["kernel"] == "gd_tile_fast_kernel"
-        g = d["roofline_ingest"]
-        assert g["bound"] == "hbm" and g["kernels_ms"] > 0 and g["wall_ms"] < g["kernels_ms"] * 1.5   # one batch: no host overhead
     # round 4: the roofline is on SURVEY.md 8(d)'s byte count; the cold step and the BAM-file scope are in the line
     assert abs(d["roofline"]["frac_survey_8d"] - d["roofline"]["frac"]) < 1e-12
     assert d["roofline"]["frac_bytes_really_read"] > d["roofline"]["frac"]

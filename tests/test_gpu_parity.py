@@ -8,24 +8,17 @@ from oracle import pyoracle as po
 pytestmark = pytest.mark.gpu
 
 
-PATH_IDS = {"tile": 1, "tile-canonical": 1, "scatter": 2, "chunk": 3, "chunk-canonical": 3}
+PATH_IDS = {"tile": 1, "scatter": 2, "chunk": 3}
 
 
-@pytest.fixture(scope="module", params=["tile", "tile-canonical", "chunk", "chunk-canonical", "scatter"])
+@pytest.fixture(scope="module", params=["tile", "chunk", "scatter"])
 def eng(request):
-    """Every parity test runs on all three device algorithms (GD_PATH_TILE: LDS tiles
-    re-walking whole CIGARs, the short-read path -- once on the records as they arrived, the
-    default (gd_tile_fast_kernel<raw>), once on canonical records built at arrival
-    (GD_OPT_NORMALIZE = 1: gd_tile_fast_kernel); GD_PATH_CHUNK: LDS tiles over deletion lists,
-    the long-read path -- lists built straight from the records (default) or from canonical CIGARs
-    (GD_OPT_NORMALIZE = 1); GD_PATH_SCATTER: global scatter + in-place scan)."""
-    from goleft_amd.engine import DepthEngine, OPT_NORMALIZE, has_canonical
-    if request.param.endswith("-canonical") and not has_canonical():
-        pytest.skip("canonical records are not part of this build (csrc/Makefile: make CANONICAL=1)")
+    """Every parity test runs on all three device algorithms, each on the records as they arrived (GD_PATH_TILE: LDS
+    tiles re-walking whole CIGARs, the short-read path; GD_PATH_CHUNK: LDS tiles over deletion lists, the long-read
+    path; GD_PATH_SCATTER: global scatter + in-place scan)."""
+    from goleft_amd.engine import DepthEngine
     e = DepthEngine(0)
     e.set_path(PATH_IDS[request.param])
-    if request.param.endswith("-canonical"):
-        e.set_option(OPT_NORMALIZE, 1)
     e.path_name = request.param
     yield e
     e.close()
@@ -373,11 +366,11 @@ def test_windows_only_output(auto_eng):
     assert np.array_equal(eng.perbase(0), want)
 
 
-@pytest.mark.parametrize("stream", [1, 2, 0])
+@pytest.mark.parametrize("stream", [1, 0])
 @pytest.mark.parametrize("W", [32, 100, 250, 1000, 4096, 5000, 1 << 20])
 def test_sums_only_output(W, stream):
     """gd_set_outputs(GD_OUT_SUMS_ONLY): window sums from read/window overlaps, no per-base scan -- the
-    streaming kernel over the canonical records (gd_sums_stream.hpp; stream=1, the default) and the tile
+    streaming kernel over the records as they arrived (gd_sums_stream.hpp; stream=1, the default) and the tile
     kernel it replaces (GD_OPT_FAST_KERNEL = 0); they equal the sums of the regular path; minima, class runs
     and the per-base vector report GD_E_STATE; the depthwed matrix is unchanged."""
     from goleft_amd import synth
@@ -390,13 +383,8 @@ def test_sums_only_output(W, stream):
              3: H.random_reads(rng, lengths[3], 6000, max_len=90, long_reads=True),
              4: H.random_reads(rng, lengths[4], 20000, max_len=60)}     # deep: several record batches per tile
     with DepthEngine(0) as eng:
-        # stream 1: the streaming kernel over the records as they arrived (the default); 2: over canonical records
-        # built at arrival; 0: the tile kernel
+        # stream 1: the streaming kernel over the records as they arrived (the default); 0: the tile kernel
         eng.set_option(OPT_FAST_KERNEL, 1 if stream else 0)
-        if stream == 2:
-            if not E.has_canonical():
-                pytest.skip("canonical records are not part of this build")
-            eng.set_option(E.OPT_NORMALIZE, 1)
         eng.set_params(window_size=W, min_mapq=1, min_cov=4)
         eng.set_path(PATH_TILE)
         eng.set_outputs(sums_only=True)
@@ -404,7 +392,7 @@ def test_sums_only_output(W, stream):
         for t, r in reads.items():
             eng.push(t, r.pos, r.flag, r.mapq, r.cigar_off, r.cigar)
         eng.compute()
-        assert eng.stats().tile_kernel == {1: E.TK_SUMS_STREAM_RAW, 2: E.TK_SUMS_STREAM, 0: E.TK_TILE_SUMS}[stream]
+        assert eng.stats().tile_kernel == {1: E.TK_SUMS_STREAM_RAW, 0: E.TK_TILE_SUMS}[stream]
         for t, L in enumerate(lengths):
             want = po.perbase_c(reads.get(t, H.empty_reads()), 1, 0, L)
             ws, _ = H.oracle_windows(want, W)

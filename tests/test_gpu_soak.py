@@ -100,7 +100,7 @@ def _concat(a, b):
 def test_soak_one_context_many_jobs(seed):
     import torch
     from goleft_amd.engine import (DepthEngine, GdError, PATH_AUTO, PATH_TILE, PATH_SCATTER, PATH_CHUNK,
-                                   OPT_NT_STORES, OPT_NORMALIZE, OPT_FAST_KERNEL, has_canonical)
+                                   OPT_NT_STORES, OPT_FAST_KERNEL)
     with DepthEngine(0) as eng:
         for job in range(JOBS):
             if ONLY and job not in ONLY:
@@ -124,12 +124,9 @@ def test_soak_one_context_many_jobs(seed):
             if path == PATH_SCATTER:
                 mode = "full"            # the scatter path needs the per-base vector (GD_E_INVAL otherwise)
             opts = (int(rng.integers(0, 2)), int(rng.random() < 0.8), int(rng.random() < 0.8))
-            if not has_canonical():
-                opts = (opts[0], 2 * opts[1], opts[2])       # (GD_OPT_NORMALIZE = 1 needs canonical records in the build)
             adopt = bool(rng.random() < 0.3)
             split = bool(rng.random() < 0.3)
             eng.set_option(OPT_NT_STORES, opts[0])
-            eng.set_option(OPT_NORMALIZE, opts[1])
             eng.set_option(OPT_FAST_KERNEL, opts[2])
             eng.set_path(path)
             eng.set_outputs(perbase=(mode == "full"), sums_only=(mode == "sums"))

@@ -50,11 +50,8 @@ def test_tile_kernels_keep_seven_workgroups_per_cu(kernels):
 
 
 def test_streaming_and_ingest_kernels(kernels):
-    for name, r in pick(kernels, "gd_sums_stream_kernel<").items():
+    for name, r in pick(kernels, "gd_sums_stream_kernel").items():
         assert r["scratch"] == 0 and r["lds"] * 6 <= LDS_PER_CU and r["vgpr"] <= 84, (name, r)     # six waves per SIMD
-    # (canonical records are an optional part of the build: csrc/Makefile CANONICAL=1)
-    for name, r in {k: v for k, v in kernels.items() if "gd_norm_fused_kernel" in k}.items():
-        assert r["scratch"] == 0 and r["vgpr"] <= 64 and r["lds"] * 8 <= LDS_PER_CU, (name, r)     # __launch_bounds__(256, 8)
     for name, r in {**pick(kernels, "gd_dels_raw_kernel"), **pick(kernels, "gd_prep_kernel<"), **pick(kernels, "gd_tile_slow_kernel<"),
                     **pick(kernels, "gd_h2d_kernel"), **pick(kernels, "gd_bam_walk_kernel<"),
                     **pick(kernels, "gd_index_records_kernel"), **pick(kernels, "gd_readback_kernel")}.items():
