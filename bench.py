@@ -865,6 +865,18 @@ def other_workloads(args, dev, local_rank, which, steps=5, warmup=2):
     return out
 
 
+def flush_c_stdio():
+    """fflush(NULL): what C libraries of this process wrote with stdio -- RCCL prints a version banner (`ROCm version : ...`,
+    `Librccl path : ...`) through it when it is loaded -- leaves the process buffer now instead of at exit, where it would
+    land BEHIND the JSON line on a stdout that is a pipe (the driver reads the line from there)."""
+    try:
+        import ctypes
+        sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+
+
 def launch_ranks(args):
     """`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment: THIS process is the launcher.
     It starts N copies of itself, one rank per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 /
@@ -1261,10 +1273,12 @@ def main():
                 store.wait(["goleft_file_ngpu_done"], datetime.timedelta(minutes=30))
             except Exception:
                 pass
-        dist.barrier()
+        flush_c_stdio()                                 # (RCCL's version banner sits in the C library's buffer: out with it NOW,
+        dist.barrier()                                  #  on every rank, before rank 0 prints the line -- which must come last)
         dist.destroy_process_group()
+    flush_c_stdio()
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

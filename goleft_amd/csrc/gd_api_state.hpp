@@ -176,6 +176,7 @@ struct gd_ctx {
     bool ingest_span_dirty = false;     // [1] may have grown since the host last read it
     int32_t ingest_span = 0;            // the host's copy (0: nothing measured)
     bool ingest_index = true;           // GD_OPT_INGEST_INDEX
+    double alloc_in_enqueue = 0;        // seconds of device allocation inside the last enqueue (the long-read block): counted as `prepare`
     double timing[4] = {0, 0, 0, 0};    // gd_compute_timing: allocations + contig table, enqueue, wait, total of the last gd_compute
 
     // device job state
@@ -485,7 +486,11 @@ int batch_block(gd_ctx* c, BlockRef keep, size_t need, BlockRef* out)
     if (keep && keep.use_count() == 1 && keep->bytes >= need) { *out = std::move(keep); return GD_OK; }
     keep.reset();
     BlockRef b = std::make_shared<DevBlock>();
+    const auto ta = std::chrono::steady_clock::now();
     HIPCHK(c, hipMalloc(&b->p, need ? need : 1));
+    // (a first large allocation can wait for the driver to clear memory another process -- or this one -- just released:
+    // 0.4 ms on one box, half a second on another; gd_compute_timing reports it with the other device allocations)
+    c->alloc_in_enqueue += std::chrono::duration<double>(std::chrono::steady_clock::now() - ta).count();
     b->bytes = need ? need : 1;
     *out = std::move(b);
     return GD_OK;

@@ -546,6 +546,116 @@ static int read_records(const DArgs& args, gdh::BamReader& bam, const std::vecto
     return 0;
 }
 
+// One engine context per device (created since the start of run(), EarlyContexts), configured for this job: parameters,
+// how the BAM's bytes reach the device, the contig table, the outputs the rows need, and the contigs LPT gave the shard.
+// `S` is the Shards object of the caller (named S so that the body reads like the rest of run()).
+static int configure_shards(const std::vector<int>& devices, EarlyContexts* early, const std::vector<std::vector<int32_t>>& assignment,
+                            const std::vector<int64_t>& lens, const gd_params& P, bool need_perbase, Shards* shards,
+                            std::vector<int>* shard_of)
+{
+    Shards& S = *shards;
+    const size_t n_shards = assignment.size();
+    S.v.resize(n_shards);
+    for (size_t k = 0; k < n_shards; ++k) {
+        Shard& sh = S.v[k];
+        sh.device = devices[k];
+        sh.wanted = assignment[k];
+        for (int32_t t : sh.wanted) (*shard_of)[(size_t)t] = (int)k;
+        const int rc = early->take(k, &sh.ctx);               // (created since the start of run(), on its own thread)
+        if (rc != GD_OK) {
+            fprintf(stderr, "goleft depth: no usable MI355X device %d (%s); this build has no CPU path\n", sh.device, gd_strerror(rc));
+            return 1;
+        }
+        GDCHK_ON(sh.ctx, gd_set_params(sh.ctx, &P));
+        GDCHK_ON(sh.ctx, gd_set_option(sh.ctx, GD_OPT_COPY_THREADS, env_int("GOLEFT_COPY_THREADS", 4)));   // staging copies of the device BAM read
+        // How the BAM's bytes reach the device: a copy KERNEL on CUs of its own (every 8th), the inflate launches on the
+        // others (CU-masked streams).  One copy engine moves 21-22 GB/s next to the inflate kernels (and its reads of host
+        // memory slow the pread into the staging buffers down: 0.8-2.1 s per genome by box against 0.65 s); the kernel on 32
+        // dedicated CUs moves 35 GB/s.  GOLEFT_INGEST_DMA=1 brings the copy engine back, GOLEFT_INGEST_CU_SPLIT=0 the
+        // unmasked streams (profiles/r11d_, r11e_scope3_genome.json).
+        GDCHK_ON(sh.ctx, gd_set_option(sh.ctx, GD_OPT_INGEST_DMA, env_int("GOLEFT_INGEST_DMA", 0)));
+        if (!getenv("GOLEFT_INGEST_CU_SPLIT") && env_int("GOLEFT_INGEST_DMA", 0) == 0)
+            GDCHK_ON(sh.ctx, gd_set_option(sh.ctx, GD_OPT_INGEST_CU_SPLIT, 8));
+        if (getenv("GOLEFT_INGEST_PIECE_STREAMS")) GDCHK_ON(sh.ctx, gd_set_option(sh.ctx, GD_OPT_INGEST_PIECE_STREAMS, env_int("GOLEFT_INGEST_PIECE_STREAMS", 1)));
+        if (getenv("GOLEFT_INGEST_CU_SPLIT")) GDCHK_ON(sh.ctx, gd_set_option(sh.ctx, GD_OPT_INGEST_CU_SPLIT, env_int("GOLEFT_INGEST_CU_SPLIT", 0)));
+        if (getenv("GOLEFT_INGEST_BATCHES")) GDCHK_ON(sh.ctx, gd_set_option(sh.ctx, GD_OPT_INGEST_BATCHES, env_int("GOLEFT_INGEST_BATCHES", 8)));
+        if (getenv("GOLEFT_INGEST_WALK_CUS")) GDCHK_ON(sh.ctx, gd_set_option(sh.ctx, GD_OPT_INGEST_WALK_CUS, env_int("GOLEFT_INGEST_WALK_CUS", 0)));
+        if (getenv("GOLEFT_INGEST_HYBRID")) GDCHK_ON(sh.ctx, gd_set_option(sh.ctx, GD_OPT_INGEST_HYBRID, env_int("GOLEFT_INGEST_HYBRID", 0)));
+        if (getenv("GOLEFT_INFLATE_LDS_PAD")) GDCHK_ON(sh.ctx, gd_set_option(sh.ctx, GD_OPT_INFLATE_LDS_PAD, env_int("GOLEFT_INFLATE_LDS_PAD", 0)));
+        if (env_int("GOLEFT_TRUST_BGZF", 0)) GDCHK_ON(sh.ctx, gd_set_option(sh.ctx, GD_OPT_INGEST_CRC, 0));
+        if (const int pt = env_int("GOLEFT_PUSH_THREADS", 0)) GDCHK_ON(sh.ctx, gd_set_option(sh.ctx, GD_OPT_PUSH_THREADS, pt));
+        GDCHK_ON(sh.ctx, gd_set_contigs(sh.ctx, (int)lens.size(), lens.data()));
+        GDCHK_ON(sh.ctx, gd_set_option(sh.ctx, GD_OPT_BAM_REFS, (int64_t)lens.size()));   // engine contigs = the BAM's references
+        if (!need_perbase) GDCHK_ON(sh.ctx, gd_set_outputs(sh.ctx, 0));   // windows + class runs are all the rows need
+        if (!lens.empty() && !sh.wanted.empty())
+            GDCHK_ON(sh.ctx, gd_select_contigs(sh.ctx, (int)sh.wanted.size(), sh.wanted.data()));
+    }
+    return 0;
+}
+
+// The common case -- a whole-genome run: every region a fused tile of a known contig, no --stats -- formats its rows on
+// all cores (a `%.4g` per window: 0.15 us each, half a second for a genome on one core): the contigs' results come off the
+// device one after another, the tiles are cut into slices, every slice is formatted into its own buffer, the buffers are
+// written in input order (what --ordered gives: depth/depth.go:394-421).
+static int emit_fused_genome(const std::vector<Region>& regions, const std::vector<int64_t>& lens,
+                             const std::function<gd_ctx*(int)>& ctx_of, int W, FILE* fhd, FILE* fca, bool* io_ok)
+{
+    gd_ctx* ctx = nullptr;                          // the context GDCHK reports on
+#define GDCHK(call) GDCHK_ON(ctx, call)
+    struct Group { size_t r0, r1; std::vector<int64_t> sums; std::vector<gd_run> runs; };
+    std::vector<Group> groups;
+    for (size_t i = 0; i < regions.size();) {
+        size_t j = i;
+        while (j < regions.size() && regions[j].tid == regions[i].tid) ++j;
+        groups.push_back(Group{i, j, {}, {}});
+        i = j;
+    }
+    for (Group& g : groups) {
+        const int tid = regions[g.r0].tid;
+        ctx = ctx_of(tid);
+        size_t n = 0;
+        g.sums.resize((size_t)((lens[(size_t)tid] + W - 1) / W));
+        GDCHK(gd_windows(ctx, tid, g.sums.data(), nullptr, g.sums.size(), &n));
+        const int rc = gd_callable(ctx, tid, nullptr, 0, &n);
+        if (rc != GD_OK && rc != GD_E_CAPACITY) GDCHK(rc);
+        g.runs.resize(n);
+        if (n) GDCHK(gd_callable(ctx, tid, g.runs.data(), g.runs.size(), &n));
+    }
+    struct Slice { const Group* g; size_t r0, r1; RowWriter w; };
+    std::vector<Slice> slices;
+    constexpr size_t kSlice = 8;                        // tiles (10 Mb each at the default window) per slice
+    for (const Group& g : groups)
+        for (size_t i = g.r0; i < g.r1; i += kSlice) slices.push_back(Slice{&g, i, std::min(i + kSlice, g.r1), {}});
+    std::atomic<size_t> next{0};
+    auto work = [&]() {
+        for (size_t k; (k = next.fetch_add(1)) < slices.size();) {
+            Slice& sl = slices[k];
+            const std::vector<gd_run>& ru = sl.g->runs;
+            // runs are split at multiples of step, so each belongs to exactly one tile
+            size_t cur = (size_t)(std::lower_bound(ru.begin(), ru.end(), regions[sl.r0].start,
+                                                   [](const gd_run& a, int64_t x) { return a.start < x; }) - ru.begin());
+            for (size_t i = sl.r0; i < sl.r1; ++i) {
+                const Region& r = regions[i];
+                while (cur < ru.size() && ru[cur].start < r.start) ++cur;
+                size_t e = cur;
+                while (e < ru.size() && ru[e].start < r.end) ++e;
+                const size_t w0 = (size_t)(r.start / W), w1 = (size_t)((r.end + W - 1) / W);
+                format_region(&sl.w, r.chrom.c_str(), r.start, r.end, W, sl.g->sums.data() + w0, w1 - w0, ru.data() + cur,
+                              e - cur, nullptr);
+                cur = e;
+            }
+        }
+    };
+    const unsigned nt = (unsigned)std::min<size_t>(std::max(1u, std::min((unsigned)gdh::usable_cpus(), 32u)), slices.size());
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < nt; ++t) th.emplace_back(work);
+    work();
+    for (auto& t : th) t.join();
+    for (Slice& sl : slices) *io_ok = flush_rows(&sl.w, fhd, fca) && *io_ok;
+#undef GDCHK
+    return 0;
+}
+
 int run(const DArgs& args)
 {
     const auto t_run = std::chrono::steady_clock::now();
@@ -623,41 +733,7 @@ int run(const DArgs& args)
     P.min_cov = args.min_cov;
     P.max_mean_depth = args.max_mean_depth;
     P.step = args.bed.empty() ? step : 0;
-    S.v.resize(n_shards);
-    for (size_t k = 0; k < n_shards; ++k) {
-        Shard& sh = S.v[k];
-        sh.device = devices[k];
-        sh.wanted = assignment[k];
-        for (int32_t t : sh.wanted) shard_of[(size_t)t] = (int)k;
-        const int rc = early.take(k, &sh.ctx);               // (created since the start of run(), on its own thread)
-        if (rc != GD_OK) {
-            fprintf(stderr, "goleft depth: no usable MI355X device %d (%s); this build has no CPU path\n", sh.device, gd_strerror(rc));
-            return 1;
-        }
-        GDCHK_ON(sh.ctx, gd_set_params(sh.ctx, &P));
-        GDCHK_ON(sh.ctx, gd_set_option(sh.ctx, GD_OPT_COPY_THREADS, env_int("GOLEFT_COPY_THREADS", 4)));   // staging copies of the device BAM read
-        // How the BAM's bytes reach the device: a copy KERNEL on CUs of its own (every 8th), the inflate launches on the
-        // others (CU-masked streams).  One copy engine moves 21-22 GB/s next to the inflate kernels (and its reads of host
-        // memory slow the pread into the staging buffers down: 0.8-2.1 s per genome by box against 0.65 s); the kernel on 32
-        // dedicated CUs moves 35 GB/s.  GOLEFT_INGEST_DMA=1 brings the copy engine back, GOLEFT_INGEST_CU_SPLIT=0 the
-        // unmasked streams (profiles/r11d_, r11e_scope3_genome.json).
-        GDCHK_ON(sh.ctx, gd_set_option(sh.ctx, GD_OPT_INGEST_DMA, env_int("GOLEFT_INGEST_DMA", 0)));
-        if (!getenv("GOLEFT_INGEST_CU_SPLIT") && env_int("GOLEFT_INGEST_DMA", 0) == 0)
-            GDCHK_ON(sh.ctx, gd_set_option(sh.ctx, GD_OPT_INGEST_CU_SPLIT, 8));
-        if (getenv("GOLEFT_INGEST_PIECE_STREAMS")) GDCHK_ON(sh.ctx, gd_set_option(sh.ctx, GD_OPT_INGEST_PIECE_STREAMS, env_int("GOLEFT_INGEST_PIECE_STREAMS", 1)));
-        if (getenv("GOLEFT_INGEST_CU_SPLIT")) GDCHK_ON(sh.ctx, gd_set_option(sh.ctx, GD_OPT_INGEST_CU_SPLIT, env_int("GOLEFT_INGEST_CU_SPLIT", 0)));
-        if (getenv("GOLEFT_INGEST_BATCHES")) GDCHK_ON(sh.ctx, gd_set_option(sh.ctx, GD_OPT_INGEST_BATCHES, env_int("GOLEFT_INGEST_BATCHES", 8)));
-        if (getenv("GOLEFT_INGEST_WALK_CUS")) GDCHK_ON(sh.ctx, gd_set_option(sh.ctx, GD_OPT_INGEST_WALK_CUS, env_int("GOLEFT_INGEST_WALK_CUS", 0)));
-        if (getenv("GOLEFT_INGEST_HYBRID")) GDCHK_ON(sh.ctx, gd_set_option(sh.ctx, GD_OPT_INGEST_HYBRID, env_int("GOLEFT_INGEST_HYBRID", 0)));
-        if (getenv("GOLEFT_INFLATE_LDS_PAD")) GDCHK_ON(sh.ctx, gd_set_option(sh.ctx, GD_OPT_INFLATE_LDS_PAD, env_int("GOLEFT_INFLATE_LDS_PAD", 0)));
-        if (env_int("GOLEFT_TRUST_BGZF", 0)) GDCHK_ON(sh.ctx, gd_set_option(sh.ctx, GD_OPT_INGEST_CRC, 0));
-        if (const int pt = env_int("GOLEFT_PUSH_THREADS", 0)) GDCHK_ON(sh.ctx, gd_set_option(sh.ctx, GD_OPT_PUSH_THREADS, pt));
-        GDCHK_ON(sh.ctx, gd_set_contigs(sh.ctx, (int)lens.size(), lens.data()));
-        GDCHK_ON(sh.ctx, gd_set_option(sh.ctx, GD_OPT_BAM_REFS, (int64_t)lens.size()));   // engine contigs = the BAM's references
-        if (!need_perbase) GDCHK_ON(sh.ctx, gd_set_outputs(sh.ctx, 0));   // windows + class runs are all the rows need
-        if (!contigs.empty() && !sh.wanted.empty())
-            GDCHK_ON(sh.ctx, gd_select_contigs(sh.ctx, (int)sh.wanted.size(), sh.wanted.data()));
-    }
+    if (int rc = configure_shards(devices, &early, assignment, lens, P, need_perbase, &S, &shard_of)) return rc;
     auto ctx_of = [&](int tid) -> gd_ctx* { return S.v[(size_t)shard_of[(size_t)tid]].ctx; };
     auto on_every_shard = [&](const char* what, const std::function<int(Shard&)>& fn) { return run_on_every_shard(S, what, fn); };
 
@@ -765,65 +841,12 @@ int run(const DArgs& args)
     };
     gd_ctx* ctx = seq_ctx;                          // the context GDCHK reports on
 #define GDCHK(call) GDCHK_ON(ctx, call)
-    // The common case -- a whole-genome run: every region a fused tile of a known contig, no --stats -- formats its
-    // rows on all cores (a `%.4g` per window: 0.15 us each, half a second for a genome on one core): the contigs'
-    // results come off the device one after another, the tiles are cut into slices, every slice is formatted
-    // into its own buffer, the buffers are written in input order.
+    // the common case (a whole-genome run without --stats): emit_fused_genome formats the rows on all cores
     bool sliced_rows = !fa && args.bed.empty() && !regions.empty();
     for (size_t i = 0; sliced_rows && i < regions.size(); ++i)
         if (regions[i].tid < 0 || !is_fused(regions[i])) sliced_rows = false;
-    if (sliced_rows) {
-        struct Group { size_t r0, r1; std::vector<int64_t> sums; std::vector<gd_run> runs; };
-        std::vector<Group> groups;
-        for (size_t i = 0; i < regions.size();) {
-            size_t j = i;
-            while (j < regions.size() && regions[j].tid == regions[i].tid) ++j;
-            groups.push_back(Group{i, j, {}, {}});
-            i = j;
-        }
-        for (Group& g : groups) {
-            const int tid = regions[g.r0].tid;
-            ctx = ctx_of(tid);
-            size_t n = 0;
-            g.sums.resize((size_t)((contigs[(size_t)tid].length + W - 1) / W));
-            GDCHK(gd_windows(ctx, tid, g.sums.data(), nullptr, g.sums.size(), &n));
-            const int rc = gd_callable(ctx, tid, nullptr, 0, &n);
-            if (rc != GD_OK && rc != GD_E_CAPACITY) GDCHK(rc);
-            g.runs.resize(n);
-            if (n) GDCHK(gd_callable(ctx, tid, g.runs.data(), g.runs.size(), &n));
-        }
-        struct Slice { const Group* g; size_t r0, r1; RowWriter w; };
-        std::vector<Slice> slices;
-        constexpr size_t kSlice = 8;                        // tiles (10 Mb each at the default window) per slice
-        for (const Group& g : groups)
-            for (size_t i = g.r0; i < g.r1; i += kSlice) slices.push_back(Slice{&g, i, std::min(i + kSlice, g.r1), {}});
-        std::atomic<size_t> next{0};
-        auto work = [&]() {
-            for (size_t k; (k = next.fetch_add(1)) < slices.size();) {
-                Slice& sl = slices[k];
-                const std::vector<gd_run>& ru = sl.g->runs;
-                // runs are split at multiples of step, so each belongs to exactly one tile
-                size_t cur = (size_t)(std::lower_bound(ru.begin(), ru.end(), regions[sl.r0].start,
-                                                       [](const gd_run& a, int64_t x) { return a.start < x; }) - ru.begin());
-                for (size_t i = sl.r0; i < sl.r1; ++i) {
-                    const Region& r = regions[i];
-                    while (cur < ru.size() && ru[cur].start < r.start) ++cur;
-                    size_t e = cur;
-                    while (e < ru.size() && ru[e].start < r.end) ++e;
-                    const size_t w0 = (size_t)(r.start / W), w1 = (size_t)((r.end + W - 1) / W);
-                    format_region(&sl.w, r.chrom.c_str(), r.start, r.end, W, sl.g->sums.data() + w0, w1 - w0, ru.data() + cur,
-                                  e - cur, nullptr);
-                    cur = e;
-                }
-            }
-        };
-        const unsigned nt = (unsigned)std::min<size_t>(std::max(1u, std::min((unsigned)gdh::usable_cpus(), 32u)), slices.size());
-        std::vector<std::thread> th;
-        for (unsigned t = 1; t < nt; ++t) th.emplace_back(work);
-        work();
-        for (auto& t : th) t.join();
-        for (Slice& sl : slices) io_ok = flush_rows(&sl.w, fhd, fca) && io_ok;
-    }
+    if (sliced_rows)
+        if (int rc = emit_fused_genome(regions, lens, ctx_of, W, fhd, fca, &io_ok)) return rc;
     for (const Region& r : regions) {
         if (sliced_rows) break;
         if (stats_rc != GD_OK) { ctx = seq_ctx; GDCHK(stats_rc); }
