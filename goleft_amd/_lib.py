@@ -138,11 +138,12 @@ def load():
     global _LIB
     if _LIB is not None:
         return _LIB
-    if not os.path.exists(SO_PATH):
+    so = os.environ.get("GOLEFT_DEPTH_SO") or SO_PATH      # (measurement: a kernel variant built beside the product library)
+    if not os.path.exists(so):
         raise ImportError(
             "goleft_amd: %s is missing -- run `python -c 'import __graft_entry__ as g; g.build()'` "
-            "(hipcc --offload-arch=gfx950). There is no CPU fallback." % SO_PATH)
-    lib = C.CDLL(SO_PATH)
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback." % so)
+    lib = C.CDLL(so)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)   # AttributeError if the .so does not export it
         fn.restype = res

@@ -103,6 +103,19 @@ int gd_create(int device_id, gd_ctx** out)
     if ((e = hipMalloc(reinterpret_cast<void**>(&c->d_ingest), 4 * sizeof(uint32_t))) != hipSuccess) return bail(e);
     if ((e = hipMemset(c->d_ingest, 0, 4 * sizeof(uint32_t))) != hipSuccess) return bail(e);
     if ((e = hipHostMalloc(reinterpret_cast<void**>(&c->h_ingest), 4 * sizeof(uint32_t), hipHostMallocDefault)) != hipSuccess) return bail(e);
+    // Warm-up: one compute of an EMPTY two-tile contig runs every kernel of the tile path once (prep, slow list, straight-
+    // line tile kernel, run ordering, read-back) and makes the small fixed-size allocations -- the first launch of a kernel in
+    // a process costs tens of microseconds that a job of chr20's size (0.14 ms a step) saw as 1.3 x in its first, usually
+    // only, compute.  A context comes up on a thread of its own while the host reads the BAM header (0.2-0.3 s): the
+    // millisecond belongs there.  Nothing of it stays: no contigs, no records, default look-back.
+    {
+        const int64_t len = 2 * 4096;
+        if (gd_set_contigs(c, 1, &len) == GD_OK) (void)gd_compute(c);
+        (void)gd_set_contigs(c, 0, nullptr);
+        c->stats = gd_stats{};
+        c->err.clear();
+        for (double& t : c->timing) t = 0;
+    }
     *out = c;
     return GD_OK;
 }
