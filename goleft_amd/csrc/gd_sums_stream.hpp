@@ -21,16 +21,6 @@
 // Integer adds commute: the result is bit-identical to the per-base sums.
 #pragma once
 
-// Measurement switches of the round-5 experiment (profiles/r12g_*): GD_SUMS_INLINE_QUEUE 0 = every odd read is queued by
-// index and its ops are read again by the drain (rounds 2-4); GD_SUMS_WAVES = waves per SIMD the compiler is asked to fit
-// (0: whatever the registers come to).
-#ifndef GD_SUMS_INLINE_QUEUE
-#define GD_SUMS_INLINE_QUEUE 1
-#endif
-#ifndef GD_SUMS_WAVES
-#define GD_SUMS_WAVES 6
-#endif
-
 namespace gd {
 namespace sums {
 
@@ -90,25 +80,13 @@ __device__ __forceinline__ void drain_queue(const uint4* Q, uint32_t cnt, int la
     for (uint32_t i = (uint32_t)lane; i < cnt; i += 64u) {
         const uint4 it = Q[i];
         const int32_t pu = (int32_t)it.x;
-        // An item carries the read's ops ITSELF when they are at most three of fewer than 1024 bases (M D M, M I M, S M S: nearly
-        // every odd read of a short-read sample): {POS, op 0, op 1 | op 2 << 14, n}.  Until round 5 every item was {POS, index
-        // of the first op, n} and the drain read the ops again -- at the END of the wave, 63 KB of records after the lines that
-        // hold them had been streamed through: a 64-byte fetch per odd read, 135 of them per wave = the 1.18 x of FETCH_SIZE over
-        // the bytes read that the round-4 counters showed.  Other reads (bit 31 of the count) still go to memory.
-        const bool in_mem = (it.w >> 31) != 0u;
-        const uint32_t iy = it.y, i1 = it.z & 0x3fffu, i2 = it.z >> 14;
-        const gptr_u32 ops = cigar + (in_mem ? iy : 0u);
-        const uint32_t nu = it.w & 0x7fffffffu;
-        auto op_at = [=](uint32_t k) -> uint32_t {
-            uint32_t v = k == 0u ? iy : k == 1u ? i1 : i2;
-            if (in_mem) v = ops[k];
-            return v;
-        };
+        const gptr_u32 ops = cigar + it.y;
+        const uint32_t nu = it.z;
         if (pu >= 0) {
             // 32 bits: x stays below the contig length (the walk stops there), an op is < 2^28
             uint32_t x = (uint32_t)pu;
             for (uint32_t k = 0; k < nu && x < length; ++k) {
-                const uint32_t o = op_at(k), ol = o >> 4;
+                const uint32_t o = ops[k], ol = o >> 4;
                 const uint32_t op = o & 0xfu;
                 if (!((0x18du >> op) & 1u)) continue;
                 const uint32_t xe = x + ol;
@@ -118,7 +96,7 @@ __device__ __forceinline__ void drain_queue(const uint4* Q, uint32_t cnt, int la
         } else {
             long long x = pu;                                  // a negative POS (no aligner writes one): the long form
             for (uint32_t k = 0; k < nu; ++k) {
-                const uint32_t o = op_at(k), ol = o >> 4;
+                const uint32_t o = ops[k], ol = o >> 4;
                 if (!((0x18du >> (o & 0xfu)) & 1u)) continue;
                 if ((0x181u >> (o & 0xfu)) & 1u) {
                     const long long e64 = x + (long long)ol;
@@ -138,7 +116,7 @@ struct Stage {
     typedef unsigned int v4u __attribute__((ext_vector_type(4)));
     v4u pv, rv;            // POS and CSR offsets of the lane's four reads
     uint32_t ob;           // the CSR offset after the lane's last read
-    uint32_t obase;        // bit u = read u is kept (and not queued yet)
+    uint32_t obase;        // bit u = read u is kept
     uint32_t cg[U];        // the ONE counted op of a read that has just one (else 0xffffffff)
     unsigned int fw0, fw1, mq;   // the four flags (two per word) and MAPQs as loaded
     uint32_t g0;           // first read of the group (wave uniform)
@@ -157,11 +135,7 @@ struct Stage {
 // here (181 ms for 200 x chr1 in front of a 25 ms kernel).  A read FITS the lane's three windows when it has ONE counted
 // op and nothing before it that consumes the reference: 150M, 20S130M, 100M50S, 5H145M, 70M3I, 150M2D (97 % of
 // short reads); everything else takes the queue and the general op walk.
-#if GD_SUMS_WAVES
-__global__ __launch_bounds__(256, GD_SUMS_WAVES) void gd_sums_stream_kernel(Job job)
-#else
 __global__ __launch_bounds__(256) void gd_sums_stream_kernel(Job job)
-#endif
 {
     __shared__ uint4 s_q[4 * SQ_CAP];
     __shared__ unsigned long long s_acc[4 * NACC];
@@ -241,20 +215,15 @@ __global__ __launch_bounds__(256) void gd_sums_stream_kernel(Job job)
             const bool four = ((n[0] & n[1] & n[2] & n[3]) == 1u) & ((n[0] | n[1] | n[2] | n[3]) == 1u);
             v4u_t o4 = {0u, 0u, 0u, 0u};
             if (four) o4 = *(gptr_v4)(cigar + o[0]);
-            // c1: the second op of a two-op read; of a THREE-op read its second and third op packed 14 bits each (0xffffffff:
-            // one of them is 1024 bases or longer) -- what the queue item of such a read carries
             uint32_t c0[U] = {o4.x, o4.y, o4.z, o4.w}, c1[U] = {0u, 0u, 0u, 0u};
             if (__builtin_amdgcn_ballot_w64(!four) != 0ull) {
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
-                    uint32_t c2 = 0u;
                     if (!four & keep[u]) c0[u] = cigar[o[u]];
-                    if (!four & keep[u] & ((n[u] == 2u) | (GD_SUMS_INLINE_QUEUE && n[u] == 3u))) c1[u] = cigar[o[u] + 1u];
-                    if (GD_SUMS_INLINE_QUEUE && (!four & keep[u] & (n[u] == 3u))) c2 = cigar[o[u] + 2u];   // (the same lines: no fetch of its own)
-                    if (GD_SUMS_INLINE_QUEUE && n[u] == 3u) c1[u] = (c1[u] | c2) < (1u << 14) ? c1[u] | (c2 << 14) : 0xffffffffu;
+                    if (!four & keep[u] & (n[u] == 2u)) c1[u] = cigar[o[u] + 1u];
                 }
             }
-            uint32_t kb = 0, rd = 0;
+            uint32_t kb = 0;
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const uint32_t oa = c0[u] & 0xfu, ob2 = c1[u] & 0xfu;
@@ -268,32 +237,8 @@ __global__ __launch_bounds__(256) void gd_sums_stream_kernel(Job job)
                     else if (!ca & !cb) eff = 0u;                                    // nothing counted at all
                 }
                 const bool k = keep[u] & (eff != 0u);
-                // an odd read (several ops) of at most three ops of fewer than 1024 bases each is queued HERE, with its ops in
-                // the item: the drain then reads no memory for it (see drain_queue)
-                const bool rides = GD_SUMS_INLINE_QUEUE && (k & (eff == 0xffffffffu) & (c0[u] < (1u << 14)) &
-                                   (n[u] == 3u ? c1[u] != 0xffffffffu : (n[u] == 2u) & (c1[u] < (1u << 14))));
                 S.cg[u] = eff == 0xffffffffu ? eff : eff << 4;
                 kb |= k ? 1u << u : 0u;
-                rd |= rides ? 1u << u : 0u;
-            }
-            // read slot by read slot (no select over the four slots: that cost thirteen registers); a queue that cannot take
-            // a slot's reads leaves them to `work`, which queues them by index and drains
-            const int32_t pq[U] = {(int32_t)S.pv.x, (int32_t)S.pv.y, (int32_t)S.pv.z, (int32_t)S.pv.w};
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const bool r = (rd >> u) & 1u;
-                const unsigned long long m = __builtin_amdgcn_ballot_w64(r);
-                if (m != 0ull) {                                    // (wave uniform: one slot in two has an odd read somewhere)
-                    const uint32_t np = (uint32_t)__popcll(m);
-                    if (qn + np <= (uint32_t)SQ_CAP) {
-                        if (r) {
-                            const uint32_t rk = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                            Q[rk] = make_uint4((uint32_t)pq[u], c0[u], c1[u], n[u]);   // (two ops: the third is 0 = "0M")
-                            kb &= ~(1u << u);                       // queued: `work` does not see it
-                        }
-                        qn += np;
-                    }
-                }
             }
             S.obase = kb;
         }
@@ -362,9 +307,7 @@ __global__ __launch_bounds__(256) void gd_sums_stream_kernel(Job job)
                 const int32_t pu = u == 0 ? p[0] : u == 1 ? p[1] : u == 2 ? p[2] : p[3];
                 const uint32_t nu = u == 0 ? n[0] : u == 1 ? n[1] : u == 2 ? n[2] : n[3];
                 const uint32_t xu = u == 0 ? ex[0] : u == 1 ? ex[1] : u == 2 ? ex[2] : ex[3];
-                // (the reads that reach this point -- long or sparse ones, more or longer ops than an item holds, a full queue
-                // in fetch_ops -- are walked from memory)
-                Q[rk] = make_uint4((uint32_t)pu, xu, 0u, nu | 0x80000000u);
+                Q[rk] = make_uint4((uint32_t)pu, xu, nu, 0u);
             }
             qn += np;
         }

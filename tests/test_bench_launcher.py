@@ -56,3 +56,20 @@ def test_refuses_more_ranks_than_devices():
     assert p.returncode != 0
     assert "refusing to run 2 ranks" in p.stderr
     assert not [l for l in p.stdout.splitlines() if l.startswith("{")]
+
+
+def test_the_json_line_is_the_last_thing_on_a_piped_stdout():
+    """RCCL prints a version banner through C stdio when it is loaded; on a stdout that is a pipe that text sits in the C
+    library's buffer until the process exits -- BEHIND the line rank 0 printed from Python.  bench.flush_c_stdio() empties
+    the buffer first (round 5: the two-rank dry runs ended with `Librccl path : ...` as their last line)."""
+    import subprocess
+    import sys
+    code = ("import ctypes, json, sys; sys.path.insert(0, %r)\n"
+            "import bench\n"
+            "libc = ctypes.CDLL(None); libc.printf(b'ROCm version : banner\\nLibrccl path : banner\\n')\n"
+            "bench.flush_c_stdio()\n"
+            "print(json.dumps({'metric': 'x'}), flush=True)\n" % H.ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-500:]
+    lines = r.stdout.strip().splitlines()
+    assert lines[-1] == '{"metric": "x"}' and "Librccl path : banner" in lines[:-1], lines
