@@ -162,7 +162,6 @@ void gd_destroy(gd_ctx* c)
     if (c->h_counters) (void)hipHostFree(c->h_counters);
     if (c->h_bounds) (void)hipHostFree(c->h_bounds);
     if (c->h_batch) (void)hipHostFree(c->h_batch);
-    if (c->h_ctgs_pin) (void)hipHostFree(c->h_ctgs_pin);
     drop_pool(c);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);

@@ -160,7 +160,6 @@ struct gd_ctx {
                                         // ordinary tiles, the generic one for the rest; 0 = generic for every tile
     std::vector<uint8_t> batch_tab, batch_tab_ck;   // host copies of the job tables of the last norm_batch / ck batch
     uint32_t* h_batch = nullptr; size_t cap_h_batch = 0;   // pinned: per-contig totals / status words coming back
-    uint32_t* h_ctgs_pin = nullptr; size_t cap_ctgs_pin = 0;   // pinned: the contig table on its way to the device (words)
     int tile_opt = 1;                   // bit 0: non-temporal per-base stores (2 % faster: the vector is
                                         // never re-read by the kernel)
     bool lookback_pinned = false;       // max_span_hint given: never shrink below it

@@ -271,28 +271,19 @@ __device__ __forceinline__ uint32_t serial_dels_plain(const uint32_t* __restrict
     return w;                                                          // > cap: the caller walks the read again
 }
 
-// nxt: the read's FIRST batch of ops, already loaded (or on its way) -- and on return the first batch of the NEXT read the wave
-// walks (ops_next / n_next; n_next = 0: none), whose loads are issued while this read's last batch is worked on.  A wave
-// walks its long reads one after the other, and until round 5 every read began with a load nobody had asked for in advance:
-// a memory round trip per read, a quarter of the 3.7 us a read of 840 ops takes.
-__device__ __forceinline__ void dels_first_batch(const uint32_t* __restrict__ ops, uint32_t n, int lane, uint32_t (&nxt)[DL_UNROLL])
+__device__ __forceinline__ uint32_t wave_dels_plain(const uint32_t* __restrict__ ops, uint32_t n, int lane, uint32_t pos,
+                                                    uint2* __restrict__ out, uint32_t cap, uint32_t& endp, bool& again,
+                                                    uint32_t* __restrict__ ix, uint32_t ixcap)
 {
+    const uint32_t pk = pos >> PT_SHIFT;
+    uint32_t cur = pos, w = 0u;                                         // wave uniform
+    again = false;
+    uint32_t nxt[DL_UNROLL];
 #pragma unroll
     for (int u = 0; u < DL_UNROLL; ++u) {
         const uint32_t k = (uint32_t)u * 64u + (uint32_t)lane;
         nxt[u] = k < n ? ops[k] : 0u;
     }
-}
-
-__device__ __forceinline__ uint32_t wave_dels_plain(const uint32_t* __restrict__ ops, uint32_t n, int lane, uint32_t pos,
-                                                    uint2* __restrict__ out, uint32_t cap, uint32_t& endp, bool& again,
-                                                    uint32_t* __restrict__ ix, uint32_t ixcap, uint32_t (&nxt)[DL_UNROLL],
-                                                    const uint32_t* __restrict__ ops_next, uint32_t n_next, bool& next_loaded)
-{
-    const uint32_t pk = pos >> PT_SHIFT;
-    uint32_t cur = pos, w = 0u;                                         // wave uniform
-    again = false;
-    next_loaded = false;
     for (uint32_t b0 = 0; b0 < n; b0 += DL_UNROLL * 64u) {
         uint32_t cgv[DL_UNROLL];
 #pragma unroll
@@ -303,9 +294,6 @@ __device__ __forceinline__ uint32_t wave_dels_plain(const uint32_t* __restrict__
                 const uint32_t k = b0 + (uint32_t)(DL_UNROLL + u) * 64u + (uint32_t)lane;
                 nxt[u] = k < n ? ops[k] : 0u;
             }
-        } else if (n_next != 0u) {                                      // the last batch of this read: the next read's first
-            dels_first_batch(ops_next, n_next, lane, nxt);
-            next_loaded = true;
         }
         uint32_t lenv[DL_UNROLL];
         bool dnv[DL_UNROLL], big = false;
@@ -371,8 +359,6 @@ __global__ __launch_bounds__(256) void gd_dels_raw_kernel(DelBatch B)
     uint32_t endp = p, nd = 0;
     bool serial = n <= WAVE_DELS_MIN;
     bool merged = false;                                  // the list holds MERGED deletions (the fallback walks): no index
-    uint32_t first[DL_UNROLL] = {0u, 0u, 0u, 0u};        // the first batch of ops of the read the wave walks next
-    bool have_first = false;                              // (wave uniform)
     unsigned long long todo = __builtin_amdgcn_ballot_w64(!serial);
     while (todo != 0ull) {                                // long reads: the wave walks one at a time
         const int j = __ffsll((long long)todo) - 1;
@@ -384,15 +370,9 @@ __global__ __launch_bounds__(256) void gd_dels_raw_kernel(DelBatch B)
         const uint32_t cj = (uint32_t)__builtin_amdgcn_readlane((int)cap, j);
         const uint32_t bj = (uint32_t)__builtin_amdgcn_readlane((int)pb, j);
         const uint32_t kj = (uint32_t)__builtin_amdgcn_readlane((int)pcap, j);
-        // the long read the wave walks after this one (its first ops are asked for during this one's last batch)
-        const int jn = todo != 0ull ? __ffsll((long long)todo) - 1 : 0;
-        const uint32_t on = (uint32_t)__builtin_amdgcn_readlane((int)o0, jn);
-        const uint32_t nn = todo != 0ull ? (uint32_t)__builtin_amdgcn_readlane((int)n, jn) : 0u;
-        if (!have_first) dels_first_batch(job.cigar + oj, nj, lane, first);
         uint32_t ej = pj;
         bool ovf, again;
-        uint32_t wj = wave_dels_plain(job.cigar + oj, nj, lane, pj, job.dl + dj, cj, ej, again, job.pck + bj, kj, first,
-                                      job.cigar + on, nn, have_first);
+        uint32_t wj = wave_dels_plain(job.cigar + oj, nj, lane, pj, job.dl + dj, cj, ej, again, job.pck + bj, kj);
         ovf = false;
         if (again) wj = wave_dels(job.cigar + oj, nj, lane, pj, job.dl + dj, ej, ovf);   // merged runs always fit
         if (lane == j) { nd = wj; endp = ej; serial = ovf; merged = again; }

@@ -364,7 +364,7 @@ __global__ void gd_prep_kernel(Job job)
 
 __global__ __launch_bounds__(64) void gd_copy_words_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, uint32_t n)
 {
-    for (uint32_t i = blockIdx.x * 64u + threadIdx.x; i < n; i += gridDim.x * 64u) dst[i] = src[i];
+    for (uint32_t i = threadIdx.x; i < n; i += 64u) dst[i] = src[i];
 }
 
 // What the host reads after a compute: the counter block and the boundaries that exist (at most `spec`), stored
