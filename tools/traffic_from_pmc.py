@@ -13,7 +13,9 @@ Reads the counter_collection CSVs of the separate `--pmc FETCH_SIZE` and
 `--pmc WRITE_SIZE` passes made by tools/prof.sh and applies the corrections of
 MI355X_MICROARCH.md (section HBM): both counters are in KiB; on gfx950
 FETCH_SIZE reports half of the bytes of a wide coalesced streaming read, so it
-is doubled; WRITE_SIZE is taken as is.  Values are means per dispatch.
+is doubled; WRITE_SIZE is taken as is.  Values are means per dispatch -- over the dispatches of the WORKLOAD: since
+round 5 `gd_create` runs one compute on an 8 kb contig to warm the runtime's copy and fill paths, and those launches
+(a grid below 1 % of the kernel's largest) are left out of the mean and counted in `dispatches_left_out`.
 """
 import csv
 import glob
@@ -27,12 +29,18 @@ bench_args = sys.argv[4] if len(sys.argv) > 4 else ""
 label = sys.argv[5] if len(sys.argv) > 5 else "+".join(kernels)
 fetch_kib = write_kib = 0.0
 n_disp = {}
+left_out = {}
 for kname in kernels:
-    acc = {"FETCH_SIZE": [], "WRITE_SIZE": []}
+    raw = {"FETCH_SIZE": [], "WRITE_SIZE": []}
     for f in glob.glob(os.path.join(root, "pmc*", "**", "*counter_collection.csv"), recursive=True):
         for row in csv.DictReader(open(f)):
-            if ("::" + kname) in row["Kernel_Name"] and row["Counter_Name"] in acc:
-                acc[row["Counter_Name"]].append(float(row["Counter_Value"]))
+            if ("::" + kname) in row["Kernel_Name"] and row["Counter_Name"] in raw:
+                raw[row["Counter_Name"]].append((float(row.get("Grid_Size") or 0), float(row["Counter_Value"])))
+    acc = {}
+    for k, v in raw.items():
+        top = max((g for g, _ in v), default=0.0)
+        acc[k] = [x for g, x in v if g >= 0.01 * top]
+        left_out[kname + ":" + k] = len(v) - len(acc[k])
     fetch_kib += sum(acc["FETCH_SIZE"]) / len(acc["FETCH_SIZE"])      # mean per dispatch, summed over the kernels
     write_kib += sum(acc["WRITE_SIZE"]) / len(acc["WRITE_SIZE"])
     n_disp[kname] = {k: len(v) for k, v in acc.items()}
@@ -41,7 +49,7 @@ write_b = write_kib * 1024
 res = {
     "kernel": label, "kernels_matched": kernels,
     "fetch_size_kib_raw": fetch_kib, "write_size_kib_raw": write_kib,
-    "dispatches": n_disp,
+    "dispatches": n_disp, "dispatches_left_out": left_out,
     "hbm_read_bytes_per_launch": read_b, "hbm_write_bytes_per_launch": write_b,
     "hbm_bytes_per_launch": read_b + write_b,
     "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/prof.sh), "
