@@ -56,6 +56,21 @@
 #define GD_INFLATE_PROBE(what, value)
 #endif
 
+// MEASUREMENT BUILDS ONLY (-DGD_INFLATE_TIMING; tools/r12_inflate_sections.sh): the cycles a wave spends in each section of
+// the symbol loop, summed over all waves into g_inflate_sections (read back through gd_debug_inflate_sections).  The
+// product is compiled without it.
+#ifdef GD_INFLATE_TIMING
+__device__ unsigned long long g_inflate_sections[16];
+#define GD_INF_T(k) do { const uint64_t t_ = __builtin_readcyclecounter(); tsum[k] += t_ - tlast; tlast = t_; } while (0)
+#else
+#define GD_INF_T(k)
+#endif
+// 1: the two loads of an iteration -- the source of the chunk planned at the end of the one before, the next 16 input
+// bytes -- are issued FIRST, above the loop's bookkeeping and the block-header path.  0: behind them (rounds 3-4; kept for the A/B).
+#ifndef GD_INFLATE_HOIST
+#define GD_INFLATE_HOIST 1
+#endif
+
 namespace gd {
 
 struct InflateJob {
@@ -300,12 +315,20 @@ __global__ __launch_bounds__(INF_LANES) void gd_inflate_kernel(InflateJob job)
     uint8_t* const out_al = out - obase;                   // 64-byte aligned: block [fl, fl + 64) lives at out_al + fl
     uint32_t fl = 0;
     uint32_t E0 = 0;                                       // the four bytes before T: bytes [o - 20, o - 16)
+#ifdef GD_INFLATE_TIMING
+    uint64_t tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter(), titer = 0;
+#endif
     auto ring_byte = [&](uint32_t a) -> uint32_t { return (s_ring[((a >> 2) & 31u) * 64u] >> (8u * (a & 3u))) & 0xffu; };
     // the bytes [lo, hi) of the ring to memory, one by one (a member's first block when the member starts inside it, its
     // last bytes, what is pending when a stored block starts)
     auto ring_bytes_out = [&](uint32_t lo, uint32_t hi) { for (uint32_t a = lo; a < hi; ++a) out_al[a] = (uint8_t)ring_byte(a); };
 
     for (uint32_t it = 0;; ++it) {
+        // the iteration's two loads: the source of the chunk the previous iteration planned (cl; from_mem: it is completely
+        // below fl, else it lies inside the ring), the 16 input bytes behind the window (in16, want_in)
+        inf_v4 cl = {0, 0, 0, 0}, in16 = {0, 0, 0, 0};
+        bool cload = false, from_mem = false, want_in = false;
+        uint32_t sa = 0;
         const uint64_t live = __ballot(mode != DONE);
         if (live == 0) break;
         // A backstop, not a budget: a member is at most 65 536 output bytes (one iteration each at least, 16 per chunk of a
@@ -316,6 +339,19 @@ __global__ __launch_bounds__(INF_LANES) void gd_inflate_kernel(InflateJob job)
             if (mode != DONE) err = 19;
             break;
         }
+#if GD_INFLATE_HOIST
+        // ---- (0) the iteration's two loads, issued before anything else (but the loop's exits: a load that a path around the body
+        //      leaves pending is waited for at the top of the loop): behind the stores of the iteration before (a chunk
+        //      may read what the previous chunk wrote), in flight across the loop's bookkeeping, a block header and the decode ----
+        cload = cpend && !csmall;
+        sa = obase + co - deff;                            // where the chunk's source begins (ao); it ends at or before co
+        from_mem = cload && sa + 16u <= fl && !(job.probe & 1u);   // completely stored -- else completely inside the ring
+        if (from_mem) cl = inf_load16_stream(ld_addr);
+        // (the slot 64 bytes behind win_hi has been consumed; a lane that waits for its block header may ask too: the header
+        // path drops the request when it restarts the window)
+        want_in = mode != DONE && (uint32_t)(p - in_beg) + 48u >= win_hi;
+        if (want_in) in16 = inf_load16(in_beg + win_hi);
+#endif
         // ---- block header (a divergent side path; lanes wait for each other to build together) ----
         const uint64_t hm = __ballot(mode == HDR);
         GD_INFLATE_PROBE(0, mode);
@@ -424,19 +460,22 @@ __global__ __launch_bounds__(INF_LANES) void gd_inflate_kernel(InflateJob job)
                 if (mode == DONE && err == 0 && o != olen) err = 17;
                 need(56);                                  // what the decode below may consume
                 win_restart((uint32_t)(p - in_beg));       // the header was read past the window
+                want_in = false;                           // (16 bytes asked for before the header belong behind the OLD window)
             }
         }
+        GD_INF_T(0);
 
         // ---- (1) the iteration's two loads: the chunk of a match in progress, the input word of the refill at the
         //      end of the iteration (its address does not depend on what the decode consumes) ----
-        inf_v4 cl = {0, 0, 0, 0};
-        const bool cload = cpend && !csmall;
-        const uint32_t sa = obase + co - deff;             // where the chunk's source begins (ao); it ends at or before co
-        const bool from_mem = cload && sa + 16u <= fl && !(job.probe & 1u);   // completely stored -- else completely inside the ring
+#if !GD_INFLATE_HOIST
+        cload = cpend && !csmall;
+        sa = obase + co - deff;                            // where the chunk's source begins (ao); it ends at or before co
+        from_mem = cload && sa + 16u <= fl && !(job.probe & 1u);   // completely stored -- else completely inside the ring
+        if (from_mem) cl = inf_load16_stream(ld_addr);
+#endif
         GD_INFLATE_PROBE(2, from_mem ? 1u : (cload ? 2u : 0u));
         GD_INFLATE_PROBE(4, from_mem ? sa : 0xffffffffu);
         GD_INFLATE_PROBE(5, from_mem ? deff : 0u);
-        if (from_mem) cl = inf_load16_stream(ld_addr);
         inf_v4 cr = {0, 0, 0, 0};
         if (cload && !from_mem) {
             const uint32_t rj = sa >> 2, rs = sa & 3u;
@@ -448,10 +487,11 @@ __global__ __launch_bounds__(INF_LANES) void gd_inflate_kernel(InflateJob job)
             cr.w = __builtin_amdgcn_alignbyte(r4, r3, rs);
         }
         const uint32_t poff = (uint32_t)(p - in_beg);
-        const bool want_in = mode != DONE && poff + 48u >= win_hi;   // the slot 64 bytes behind win_hi has been consumed
-        inf_v4 in16 = {0, 0, 0, 0};
-        GD_INFLATE_PROBE(3, want_in);
+#if !GD_INFLATE_HOIST
+        want_in = mode != DONE && poff + 48u >= win_hi;    // the slot 64 bytes behind win_hi has been consumed
         if (want_in) in16 = inf_load16(in_beg + win_hi);
+#endif
+        GD_INFLATE_PROBE(3, want_in);
         const uint32_t wj = poff >> 2;
         const uint32_t wd0 = s_win[((wj + 0u) & 15u) * 64u], wd1 = s_win[((wj + 1u) & 15u) * 64u], wd2 = s_win[((wj + 2u) & 15u) * 64u];
 
@@ -477,6 +517,13 @@ __global__ __launch_bounds__(INF_LANES) void gd_inflate_kernel(InflateJob job)
         const uint32_t e2 = ds < 4u ? 0u : (ds >> 1) - 1u;
         const uint32_t mdist = ds < 4u ? 1u + ds : 1u + ((2u + (ds & 1u)) << e2) + ((lo2 >> l2) & ((1u << e2) - 1u));
         const uint32_t used2 = used1 + l2 + e2;            // <= 48
+        GD_INF_T(1);
+        // Both loads are waited for HERE, by every lane: their uses below sit in branches (a lane without a chunk to append,
+        // without a slot to fill, skips them), and a load the compiler cannot prove finished on every path costs a
+        // `s_waitcnt vmcnt(0)` at the top of the next iteration -- in front of that iteration's loads, behind the block
+        // stores of this one.  (gfx9 encoding: vmcnt 0, expcnt and lgkmcnt untouched.)
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        GD_INF_T(2);
 
         // ---- (3) the chunk loaded (or built) in the previous iteration goes into T ----
         const bool cp = cpend;
@@ -531,6 +578,7 @@ __global__ __launch_bounds__(INF_LANES) void gd_inflate_kernel(InflateJob job)
             }
             if (mode == DONE) p = in_beg;
         }
+        GD_INF_T(3);
         // ---- (6) refill from the word loaded at the top (before the store: nothing else is in flight then) ----
         if (want_in) { win_put(win_hi, in16); win_hi += 16u; }   // (the slot's first byte is >= 32 bytes ahead: nobody reads it yet)
         if (mode != DONE) {
@@ -542,6 +590,7 @@ __global__ __launch_bounds__(INF_LANES) void gd_inflate_kernel(InflateJob job)
             if (p > in_end + 16) { err = 1; mode = DONE; p = in_beg; }   // ran off the member's input
         }
 
+        GD_INF_T(4);
         // what this iteration produced goes into the ring: the 20 bytes [o - 20, o) (E0, T) as five aligned dwords from the
         // dword that holds byte o - 20 on -- up to three bytes more than T needs on either side: in front bytes that are
         // there already, behind bytes that the next write replaces before anything reads them
@@ -574,6 +623,7 @@ __global__ __launch_bounds__(INF_LANES) void gd_inflate_kernel(InflateJob job)
             }
         }
         if (flush) pend = 0;
+        GD_INF_T(5);
 
         // ---- (5) a match in progress: its next chunk, loaded (next iteration) after the store above ----
         csmall = false;
@@ -601,8 +651,17 @@ __global__ __launch_bounds__(INF_LANES) void gd_inflate_kernel(InflateJob job)
             cpend = true;
             if (rem == 0u) mode = DECODE;
         }
-
+        GD_INF_T(6);
+#ifdef GD_INFLATE_TIMING
+        ++titer;
+#endif
     }
+#ifdef GD_INFLATE_TIMING
+    if (lane == 0) {
+        for (int k = 0; k < 7; ++k) atomicAdd(&::g_inflate_sections[k], (unsigned long long)tsum[k]);
+        atomicAdd(&::g_inflate_sections[7], (unsigned long long)titer);
+    }
+#endif
     // the member's last bytes: what never completed a 64-byte block
     if (mine && err == 0u) ring_bytes_out(fl > obase ? fl : obase, obase + olen);
     if (mine) job.status[m] = err;

@@ -114,6 +114,7 @@ static inline uint32_t emul_brev(uint32_t x)
 #define __brev emul_brev
 #define __builtin_amdgcn_alignbyte emul_alignbyte
 #define __builtin_amdgcn_perm emul_perm
+#define __builtin_amdgcn_s_waitcnt(x) ((void)0)
 typedef int hipStream_t;
 struct dim3 { unsigned x; dim3(unsigned a) : x(a) {} };
 #define hipLaunchKernelGGL(...) ((void)0)

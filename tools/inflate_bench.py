@@ -56,4 +56,18 @@ with DepthEngine(0) as eng:
                                                                                    bool((status == 0).all()), None if (want is None or probe) else got == want))
         print("   kernel %.2f ms = %.2f GB/s of output (%.2f GB/s of BGZF); python zlib 1 thread %.2f s; call incl. H2D/D2H %.3f s"
               % (ms, len(got) / ms / 1e6, len(data) / ms / 1e6, t_cpu, t_all), flush=True)
+        # a measurement build (-DGD_INFLATE_TIMING, loaded through GOLEFT_DEPTH_SO): where the waves' cycles went
+        import ctypes
+        from goleft_amd import _lib
+        dbg = getattr(_lib.load(), "gd_debug_inflate_sections", None) if os.environ.get("GOLEFT_DEPTH_SO") else None
+        if dbg is not None:
+            buf = (ctypes.c_ulonglong * 16)()
+            dbg.restype = ctypes.c_int
+            if dbg(buf) == 0 and buf[7]:
+                names = ["top: exits, this iteration's loads, block headers", "ring / window reads, decode of three symbols", "wait for the two loads (vmcnt 0)",
+                         "append the chunk, the symbol's branch", "window put, refill of the bit buffer", "ring write, 64-byte block stores", "plan the next chunk"]
+                tot = float(sum(buf[k] for k in range(7)))
+                print("   sections over %d wave-iterations (%.0f cycles each):" % (buf[7], tot / buf[7]))
+                for k in range(7):
+                    print("     %5.1f %%  %7.0f cycles  %s" % (100.0 * buf[k] / tot, buf[k] / buf[7], names[k]))
 os.unlink(path)
