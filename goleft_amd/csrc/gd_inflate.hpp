@@ -823,6 +823,10 @@ __global__ __launch_bounds__(256) void gd_inflate_crc_wave_kernel(InflateJob job
     }
 }
 
+}  // namespace gd
+#include "gd_inflate_pair.hpp"
+namespace gd {
+
 constexpr bool INF_CRC_WAVE = true;                        // which of the two CRC kernels inflate_launch uses
 
 // Both kernels on one stream.
@@ -830,7 +834,10 @@ constexpr bool INF_CRC_WAVE = true;                        // which of the two C
 // workgroups per CU as built; + 16 KB: three; + 42 KB: two), GD_OPT_INFLATE_LDS_PAD.
 inline void inflate_launch(const InflateJob& job, hipStream_t stream, unsigned lds_pad = 0)
 {
-    hipLaunchKernelGGL(gd_inflate_kernel, dim3((job.n + INF_LANES - 1) / INF_LANES), dim3(INF_LANES), lds_pad, stream, job);
+    if (job.probe & 4u)                                    // (measurement: the two-wave kernel, gd_inflate_pair.hpp)
+        hipLaunchKernelGGL(gd_inflate_pair_kernel, dim3((job.n + INF_LANES - 1) / INF_LANES), dim3(2 * INF_LANES), lds_pad, stream, job);
+    else
+        hipLaunchKernelGGL(gd_inflate_kernel, dim3((job.n + INF_LANES - 1) / INF_LANES), dim3(INF_LANES), lds_pad, stream, job);
     if (job.crc && INF_CRC_WAVE) {
         const unsigned groups = (job.n + 3u) / 4u;
         hipLaunchKernelGGL(gd_inflate_crc_wave_kernel, dim3(groups < 8192u ? groups : 8192u), dim3(256), 0, stream, job);

@@ -16,25 +16,35 @@ struct Dim3 { unsigned x = 1, y = 1, z = 1; };
 static Dim3 threadIdx, blockIdx;                           // of the running fiber (set at every switch)
 static Dim3 gridDim;                                       // set by whoever launches a kernel that asks for it
 namespace emul {
-struct Lane { ucontext_t ctx; std::vector<char> stack; bool done = false; unsigned gen = 0, ballots = 0; };
+// A lane waits for a generation counter to move on: the workgroup's (a barrier) or its wave's (a ballot -- the 64 lanes of a
+// wave are in step on the machine, the waves of a workgroup are not: a kernel whose waves run different loops, like the
+// decoder and the writer wave of gd_inflate_pair_kernel, ballots per wave).
+struct Lane { ucontext_t ctx; std::vector<char> stack; bool done = false; const unsigned* wait_ctr = nullptr; unsigned wait_val = 0, ballots = 0; };
+constexpr unsigned MAX_WAVES = 4, WAVE = 64;
 static std::vector<Lane> lanes;
 static ucontext_t sched_ctx;
-static unsigned cur = 0, bar_gen = 0;
-static uint64_t ballot_acc[3] = {0, 0, 0};
+static unsigned cur = 0, bar_gen = 0, wbar_gen[MAX_WAVES];
+static uint64_t ballot_acc[MAX_WAVES][3];
 static void (*s_body)() = nullptr;
 
 static void trampoline() { s_body(); lanes[cur].done = true; }
-// all lanes that are still running must call this together
-static void barrier()
+static void wait_on(const unsigned* ctr)
 {
-    const unsigned my = bar_gen;
-    lanes[cur].gen = my + 1;
-    while (bar_gen == my) swapcontext(&lanes[cur].ctx, &sched_ctx);   // the scheduler opens the barrier when everyone is here
+    Lane& l = lanes[cur];
+    l.wait_ctr = ctr;
+    l.wait_val = *ctr;
+    while (*ctr == l.wait_val) swapcontext(&l.ctx, &sched_ctx);   // the scheduler opens the barrier when everyone is here
+    l.wait_ctr = nullptr;
 }
+// all lanes of the workgroup that are still running must call this together
+static void barrier() { wait_on(&bar_gen); }
+// all lanes of the caller's wave that are still running must call this together
+static void wave_barrier() { wait_on(&wbar_gen[cur / WAVE]); }
 static void run(void (*body)(), unsigned n, unsigned block)
 {
     lanes.assign(n, Lane());
-    bar_gen = 0; ballot_acc[0] = ballot_acc[1] = ballot_acc[2] = 0;
+    bar_gen = 0;
+    for (unsigned w = 0; w < MAX_WAVES; ++w) { wbar_gen[w] = 0; ballot_acc[w][0] = ballot_acc[w][1] = ballot_acc[w][2] = 0; }
     s_body = body;
     for (unsigned t = 0; t < n; ++t) {
         Lane& l = lanes[t];
@@ -46,14 +56,21 @@ static void run(void (*body)(), unsigned n, unsigned block)
         makecontext(&l.ctx, trampoline, 0);
     }
     for (;;) {
-        unsigned alive = 0, waiting = 0;
-        for (unsigned t = 0; t < n; ++t)
-            if (!lanes[t].done) { ++alive; if (lanes[t].gen == bar_gen + 1) ++waiting; }
+        unsigned alive = 0, at_bar = 0, w_alive[MAX_WAVES] = {0, 0, 0, 0}, w_at[MAX_WAVES] = {0, 0, 0, 0};
+        for (unsigned t = 0; t < n; ++t) {
+            const Lane& l = lanes[t];
+            if (l.done) continue;
+            ++alive; ++w_alive[t / WAVE];
+            if (l.wait_ctr == &bar_gen && *l.wait_ctr == l.wait_val) ++at_bar;
+            if (l.wait_ctr == &wbar_gen[t / WAVE] && *l.wait_ctr == l.wait_val) ++w_at[t / WAVE];
+        }
         if (alive == 0) break;
-        if (waiting == alive) ++bar_gen;                    // everybody still running is at the barrier: open it
+        if (at_bar == alive) ++bar_gen;                     // everybody still running is at the barrier: open it
+        for (unsigned w = 0; w < MAX_WAVES; ++w)
+            if (w_alive[w] != 0 && w_at[w] == w_alive[w]) ++wbar_gen[w];
         for (unsigned t = 0; t < n; ++t) {
             Lane& l = lanes[t];
-            if (l.done || l.gen == bar_gen + 1) continue;   // finished, or waiting at a barrier that is still closed
+            if (l.done || (l.wait_ctr && *l.wait_ctr == l.wait_val)) continue;   // finished, or waiting at a barrier that is still closed
             cur = t;
             threadIdx.x = t;
             blockIdx.x = block;
@@ -66,15 +83,15 @@ static void run(void (*body)(), unsigned n, unsigned block)
 static inline void emul_syncthreads() { emul::barrier(); }
 static inline uint64_t emul_ballot(bool p)
 {
-    // Three accumulators in turn and ONE barrier per ballot.  Ballot k uses accumulator k % 3 and clears (k + 1) % 3 on
-    // the way in: that one was last read in ballot k - 2, and every lane has read it before it arrived at barrier
-    // k - 1, which is behind whoever enters ballot k; nobody adds to it before passing barrier k, i.e. before every
-    // lane has entered ballot k and cleared it.
-    const unsigned k = emul::lanes[emul::cur].ballots++;
-    emul::ballot_acc[(k + 1u) % 3u] = 0;
-    if (p) emul::ballot_acc[k % 3u] |= 1ull << threadIdx.x;
-    emul::barrier();
-    return emul::ballot_acc[k % 3u];
+    // Per WAVE.  Three accumulators in turn and ONE barrier per ballot.  Ballot k uses accumulator k % 3 and clears
+    // (k + 1) % 3 on the way in: that one was last read in ballot k - 2, and every lane has read it before it arrived at
+    // barrier k - 1, which is behind whoever enters ballot k; nobody adds to it before passing barrier k, i.e. before
+    // every lane has entered ballot k and cleared it.
+    const unsigned k = emul::lanes[emul::cur].ballots++, w = emul::cur / emul::WAVE;
+    emul::ballot_acc[w][(k + 1u) % 3u] = 0;
+    if (p) emul::ballot_acc[w][k % 3u] |= 1ull << (threadIdx.x % emul::WAVE);
+    emul::wave_barrier();
+    return emul::ballot_acc[w][k % 3u];
 }
 static inline uint32_t emul_alignbyte(uint32_t hi, uint32_t lo, uint32_t s)
 {
@@ -107,7 +124,7 @@ static inline uint32_t emul_brev(uint32_t x)
 #define __device__
 #define __forceinline__ inline
 #define __shared__ static
-#define __launch_bounds__(n)
+#define __launch_bounds__(...)
 #define __syncthreads emul_syncthreads
 #define __ballot emul_ballot
 #define __popcll __builtin_popcountll
@@ -115,6 +132,7 @@ static inline uint32_t emul_brev(uint32_t x)
 #define __builtin_amdgcn_alignbyte emul_alignbyte
 #define __builtin_amdgcn_perm emul_perm
 #define __builtin_amdgcn_s_waitcnt(x) ((void)0)
+#define GD_EMUL_HOST 1
 typedef int hipStream_t;
 struct dim3 { unsigned x; dim3(unsigned a) : x(a) {} };
 #define hipLaunchKernelGGL(...) ((void)0)
