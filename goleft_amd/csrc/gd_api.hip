@@ -880,7 +880,7 @@ int gd_set_option(gd_ctx* c, int option, int64_t value)
         c->ing_walk_cus = value != 0;
         break;
     case GD_OPT_INFLATE_PROBE:
-        if (value < 0 || value > 15) return fail(c, GD_E_INVALID, "inflate probe: 0 .. 15 (measurement only)");
+        if (value < 0 || value > 3) return fail(c, GD_E_INVALID, "inflate probe: 0 .. 3 (measurement only)");
         c->inflate_probe = (unsigned)value;
         break;
     case GD_OPT_INGEST_PIECE_STREAMS:

@@ -48,6 +48,20 @@
 //     the ring's last 96 bytes and is read from there.
 // 82.8 -> 54.3 ms for those 108 k members, WRITE_SIZE 66 -> 8.1 GB (1.15 x the output), FETCH_SIZE 126 -> 92 GB
 // (profiles/r10u_…, r10v_…, r10w_inflate_output_ring.txt).
+//
+// Round 5: what bounds it (profiles/r12j_..., r12k_..., r12l_..., r12m_...).  The section counters of the measurement build
+// (-DGD_INFLATE_TIMING) put an iteration at ~4 400 cycles, 0.4 % of them waiting for the two loads: a wave issues one
+// instruction per four cycles whatever its kind, and the ~750 instructions of an iteration (450 vector, 250 scalar, 50 LDS /
+// memory) plus the dependent LDS look-ups of three Huffman decodes are those cycles -- at ONE wave per SIMD, because 608 bytes
+// of LDS per member allow four waves per CU.  A kernel that split a member's work over two waves with the same LDS (a decoder
+// wave that turns the stream into 32-bit tokens, a writer wave that owns T, the ring, the chunk loads and the block stores;
+// a six-token queue per lane between them; commits 886121a, fdd3ff3) was bit exact in the emulation and on the GPU and NOT
+// faster: 50.2 against 49.6 ms at deflate level 1, 69.4 against 72.2 at level 6 -- although its decoder alone runs at
+// 40.0 ms and the pair without the writer's match-source loads at 41.5.  With issue slots to spare the next bound is right
+// behind the first: the 16-byte source loads of ~100 000 members in flight each pull a line that no cache still holds
+// (FETCH_SIZE 92 GB for 7 GB of output = 1.85 TB/s of scattered 64-byte fetches), and asking for them a whole step ahead
+// changed nothing -- it is their NUMBER, not their latency.  One lane per member ends at ~145 GB/s of output on this part;
+// the two-wave kernel was removed again.
 #pragma once
 
 // A probe for the host emulation (tests/emul/inflate_stats.cpp counts what the lanes of a wave do in every iteration);
@@ -64,11 +78,6 @@ __device__ unsigned long long g_inflate_sections[16];
 #define GD_INF_T(k) do { const uint64_t t_ = __builtin_readcyclecounter(); tsum[k] += t_ - tlast; tlast = t_; } while (0)
 #else
 #define GD_INF_T(k)
-#endif
-// 1: the two loads of an iteration -- the source of the chunk planned at the end of the one before, the next 16 input
-// bytes -- are issued FIRST, above the loop's bookkeeping and the block-header path.  0: behind them (rounds 3-4; kept for the A/B).
-#ifndef GD_INFLATE_HOIST
-#define GD_INFLATE_HOIST 1
 #endif
 
 namespace gd {
@@ -324,11 +333,6 @@ __global__ __launch_bounds__(INF_LANES) void gd_inflate_kernel(InflateJob job)
     auto ring_bytes_out = [&](uint32_t lo, uint32_t hi) { for (uint32_t a = lo; a < hi; ++a) out_al[a] = (uint8_t)ring_byte(a); };
 
     for (uint32_t it = 0;; ++it) {
-        // the iteration's two loads: the source of the chunk the previous iteration planned (cl; from_mem: it is completely
-        // below fl, else it lies inside the ring), the 16 input bytes behind the window (in16, want_in)
-        inf_v4 cl = {0, 0, 0, 0}, in16 = {0, 0, 0, 0};
-        bool cload = false, from_mem = false, want_in = false;
-        uint32_t sa = 0;
         const uint64_t live = __ballot(mode != DONE);
         if (live == 0) break;
         // A backstop, not a budget: a member is at most 65 536 output bytes (one iteration each at least, 16 per chunk of a
@@ -339,19 +343,21 @@ __global__ __launch_bounds__(INF_LANES) void gd_inflate_kernel(InflateJob job)
             if (mode != DONE) err = 19;
             break;
         }
-#if GD_INFLATE_HOIST
-        // ---- (0) the iteration's two loads, issued before anything else (but the loop's exits: a load that a path around the body
-        //      leaves pending is waited for at the top of the loop): behind the stores of the iteration before (a chunk
-        //      may read what the previous chunk wrote), in flight across the loop's bookkeeping, a block header and the decode ----
-        cload = cpend && !csmall;
-        sa = obase + co - deff;                            // where the chunk's source begins (ao); it ends at or before co
-        from_mem = cload && sa + 16u <= fl && !(job.probe & 1u);   // completely stored -- else completely inside the ring
+        // ---- (0) the iteration's two loads -- the source of the chunk the previous iteration planned (cl; from_mem: it is
+        //      completely below fl, else it lies inside the ring), the 16 input bytes behind the window (in16, want_in) --
+        //      issued before anything else (but the loop's exits: a load that a path around the body leaves pending is waited
+        //      for at the top of the loop): behind the stores of the iteration before (a chunk may read what the previous
+        //      chunk wrote), in flight across the loop's bookkeeping, a block header and the decode.  Round 5: they used to
+        //      follow the header path (51.3 -> 48.8 ms on 108 k members, profiles/r12j_...) ----
+        inf_v4 cl = {0, 0, 0, 0}, in16 = {0, 0, 0, 0};
+        const bool cload = cpend && !csmall;
+        const uint32_t sa = obase + co - deff;             // where the chunk's source begins (ao); it ends at or before co
+        const bool from_mem = cload && sa + 16u <= fl && !(job.probe & 1u);   // completely stored -- else completely inside the ring
         if (from_mem) cl = inf_load16_stream(ld_addr);
         // (the slot 64 bytes behind win_hi has been consumed; a lane that waits for its block header may ask too: the header
         // path drops the request when it restarts the window)
-        want_in = mode != DONE && (uint32_t)(p - in_beg) + 48u >= win_hi;
+        bool want_in = mode != DONE && (uint32_t)(p - in_beg) + 48u >= win_hi;
         if (want_in) in16 = inf_load16(in_beg + win_hi);
-#endif
         // ---- block header (a divergent side path; lanes wait for each other to build together) ----
         const uint64_t hm = __ballot(mode == HDR);
         GD_INFLATE_PROBE(0, mode);
@@ -465,14 +471,7 @@ __global__ __launch_bounds__(INF_LANES) void gd_inflate_kernel(InflateJob job)
         }
         GD_INF_T(0);
 
-        // ---- (1) the iteration's two loads: the chunk of a match in progress, the input word of the refill at the
-        //      end of the iteration (its address does not depend on what the decode consumes) ----
-#if !GD_INFLATE_HOIST
-        cload = cpend && !csmall;
-        sa = obase + co - deff;                            // where the chunk's source begins (ao); it ends at or before co
-        from_mem = cload && sa + 16u <= fl && !(job.probe & 1u);   // completely stored -- else completely inside the ring
-        if (from_mem) cl = inf_load16_stream(ld_addr);
-#endif
+        // ---- (1) what the loads issued at (0) do not cover: a chunk whose source lies in the ring, the window's dwords ----
         GD_INFLATE_PROBE(2, from_mem ? 1u : (cload ? 2u : 0u));
         GD_INFLATE_PROBE(4, from_mem ? sa : 0xffffffffu);
         GD_INFLATE_PROBE(5, from_mem ? deff : 0u);
@@ -487,10 +486,6 @@ __global__ __launch_bounds__(INF_LANES) void gd_inflate_kernel(InflateJob job)
             cr.w = __builtin_amdgcn_alignbyte(r4, r3, rs);
         }
         const uint32_t poff = (uint32_t)(p - in_beg);
-#if !GD_INFLATE_HOIST
-        want_in = mode != DONE && poff + 48u >= win_hi;    // the slot 64 bytes behind win_hi has been consumed
-        if (want_in) in16 = inf_load16(in_beg + win_hi);
-#endif
         GD_INFLATE_PROBE(3, want_in);
         const uint32_t wj = poff >> 2;
         const uint32_t wd0 = s_win[((wj + 0u) & 15u) * 64u], wd1 = s_win[((wj + 1u) & 15u) * 64u], wd2 = s_win[((wj + 2u) & 15u) * 64u];
@@ -823,10 +818,6 @@ __global__ __launch_bounds__(256) void gd_inflate_crc_wave_kernel(InflateJob job
     }
 }
 
-}  // namespace gd
-#include "gd_inflate_pair.hpp"
-namespace gd {
-
 constexpr bool INF_CRC_WAVE = true;                        // which of the two CRC kernels inflate_launch uses
 
 // Both kernels on one stream.
@@ -834,10 +825,7 @@ constexpr bool INF_CRC_WAVE = true;                        // which of the two C
 // workgroups per CU as built; + 16 KB: three; + 42 KB: two), GD_OPT_INFLATE_LDS_PAD.
 inline void inflate_launch(const InflateJob& job, hipStream_t stream, unsigned lds_pad = 0)
 {
-    if (job.probe & 4u)                                    // (measurement: the two-wave kernel, gd_inflate_pair.hpp)
-        hipLaunchKernelGGL(gd_inflate_pair_kernel, dim3((job.n + INF_LANES - 1) / INF_LANES), dim3(2 * INF_LANES), lds_pad, stream, job);
-    else
-        hipLaunchKernelGGL(gd_inflate_kernel, dim3((job.n + INF_LANES - 1) / INF_LANES), dim3(INF_LANES), lds_pad, stream, job);
+    hipLaunchKernelGGL(gd_inflate_kernel, dim3((job.n + INF_LANES - 1) / INF_LANES), dim3(INF_LANES), lds_pad, stream, job);
     if (job.crc && INF_CRC_WAVE) {
         const unsigned groups = (job.n + 3u) / 4u;
         hipLaunchKernelGGL(gd_inflate_crc_wave_kernel, dim3(groups < 8192u ? groups : 8192u), dim3(256), 0, stream, job);

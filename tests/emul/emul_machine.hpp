@@ -17,8 +17,8 @@ static Dim3 threadIdx, blockIdx;                           // of the running fib
 static Dim3 gridDim;                                       // set by whoever launches a kernel that asks for it
 namespace emul {
 // A lane waits for a generation counter to move on: the workgroup's (a barrier) or its wave's (a ballot -- the 64 lanes of a
-// wave are in step on the machine, the waves of a workgroup are not: a kernel whose waves run different loops, like the
-// decoder and the writer wave of gd_inflate_pair_kernel, ballots per wave).
+// wave are in step on the machine, the waves of a workgroup are not: a kernel whose waves run different loops -- the
+// decoder / writer pair of the round-5 experiment, commits 886121a and fdd3ff3 in the history -- ballots per wave).
 struct Lane { ucontext_t ctx; std::vector<char> stack; bool done = false; const unsigned* wait_ctr = nullptr; unsigned wait_val = 0, ballots = 0; };
 constexpr unsigned MAX_WAVES = 4, WAVE = 64;
 static std::vector<Lane> lanes;

@@ -13,7 +13,6 @@
 // ---- a launch: the workgroups one after another ----------------------------------------------------------------------
 static const gd::InflateJob* g_job = nullptr;
 static void body_inflate() { gd::gd_inflate_kernel(*g_job); }
-static void body_inflate_pair() { gd::gd_inflate_pair_kernel(*g_job); }
 static void body_crc() { gd::gd_inflate_crc_kernel(*g_job); }
 static void body_crc_wave() { gd::gd_inflate_crc_wave_kernel(*g_job); }
 
@@ -45,26 +44,6 @@ extern "C" int emul_inflate(const uint8_t* comp, const uint64_t* in_off, const u
     job.crc = crc; job.out = out; job.status = status; job.n = n;
     g_job = &job;
     for (unsigned b = 0; b < (n + gd::INF_LANES - 1) / gd::INF_LANES; ++b) emul::run(body_inflate, gd::INF_LANES, b);
-    {
-        // the two-wave kernel (gd_inflate_pair.hpp) on the same members, into a buffer of its own that ends at an
-        // inaccessible page: the same status words, and for every member that inflated the same bytes
-        uint64_t out_bytes = 0;
-        for (uint32_t i = 0; i < n; ++i) out_bytes = std::max<uint64_t>(out_bytes, out_off[i] + out_len[i]);
-        emul::Guarded o2(out_bytes + gd::INF_SLACK);
-        memset(o2.p, 0xee, out_bytes + gd::INF_SLACK);
-        std::vector<uint32_t> st2(n, 0xdeadu);
-        gd::InflateJob j2 = job;
-        j2.out = o2.p; j2.status = st2.data();
-        g_job = &j2;
-        for (unsigned b = 0; b < (n + gd::INF_LANES - 1) / gd::INF_LANES; ++b) emul::run(body_inflate_pair, 2 * gd::INF_LANES, b);
-        g_job = &job;
-        for (uint32_t i = 0; i < n; ++i) {
-            if (st2[i] != status[i]) return -4;
-            if (status[i] == 0 && memcmp(o2.p + out_off[i], out + out_off[i], out_len[i]) != 0) return -5;
-        }
-        for (size_t k = 0; k < gd::INF_SLACK; ++k)
-            if (o2.p[out_bytes + k] != 0xee) return -6;    // wrote past the last member
-    }
     if (crc) {
         // both CRC kernels: the wave-per-member one on a copy of the status words (a small grid: the grid-stride loop runs),
         // then the lane-per-member one -- and they must agree on every member

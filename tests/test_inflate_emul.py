@@ -25,7 +25,7 @@ pytestmark = pytest.mark.skipif(CLANG is None, reason="the kernel source needs c
 def _lib():
     src = os.path.join(EMUL_DIR, "inflate_emul.cpp")
     so = os.path.join(EMUL_DIR, "inflate_emul.so")
-    hdrs = [os.path.join(H.ROOT, "goleft_amd", "csrc", h) for h in ("gd_inflate.hpp", "gd_inflate_pair.hpp")] + [os.path.join(EMUL_DIR, "emul_machine.hpp")]
+    hdrs = [os.path.join(H.ROOT, "goleft_amd", "csrc", h) for h in ("gd_inflate.hpp",)] + [os.path.join(EMUL_DIR, "emul_machine.hpp")]
     if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(x) for x in [src] + hdrs):
         subprocess.check_call([CLANG, "-O2", "-std=c++17", "-shared", "-fPIC", "-o", so, src])
     lib = C.CDLL(so)
@@ -64,12 +64,11 @@ def emul_inflate(payloads, sizes, crcs=None, guarded=False):
         rc = lib.emul_inflate_guarded(comp.ctypes.data, p, in_off.ctypes.data, in_len.ctypes.data, out_off.ctypes.data,
                                       out_len.ctypes.data, None if crc is None else crc.ctypes.data, out.ctypes.data, q,
                                       status.ctypes.data, n)
-        assert rc == 0, ("the kernel wrote past the last member (-2), the two CRC kernels disagree (-3), the two-wave kernel's status words (-4) "
-                         "or bytes (-5) differ from the one-wave kernel's, or it wrote past the last member (-6): %d" % rc)
+        assert rc == 0, "the kernel wrote past the last member (-2), or the two CRC kernels disagree (-3): %d" % rc
     else:
         rc = lib.emul_inflate(comp.ctypes.data, in_off.ctypes.data, in_len.ctypes.data, out_off.ctypes.data, out_len.ctypes.data,
                          None if crc is None else crc.ctypes.data, out.ctypes.data, status.ctypes.data, n)
-        assert rc == 0, "the two CRC kernels disagree (-3), or the two-wave kernel differs from the one-wave kernel (-4 status, -5 bytes, -6 out of bounds): %d" % rc
+        assert rc == 0, "the two CRC kernels disagree (-3): %d" % rc
     assert (out[q:] == 0xee).all(), "the kernel wrote past the last member"
     return [out[int(out_off[i]):int(out_off[i]) + int(out_len[i])].tobytes() for i in range(n)], status
 

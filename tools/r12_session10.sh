@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round 5, GPU sessions 10-11: the two-wave inflate kernel (a decoder wave and a writer wave per 64 members,
-# gd_inflate_pair.hpp; GD_OPT_INFLATE_PROBE bit 2) against the one-wave kernel.  Probes: 4 two waves; 5 / 6: without the
+# gd_inflate_pair.hpp of commits 886121a / fdd3ff3, removed since; GD_OPT_INFLATE_PROBE bit 2) against the one-wave kernel.  Probes: 4 two waves; 5 / 6: without the
 # writer's match-source loads / block stores; 12: the writer throws the tokens away (the decoder's own pace).
 #   tools/r12_session10.sh <tag> [probes] [also level 6: 0|1]
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo

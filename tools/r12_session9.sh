@@ -1,7 +1,8 @@
 #!/bin/bash
 # Round 5, ninth GPU session: the inflate kernel with its two loads issued above the loop's bookkeeping and the block-header
 # path (GD_INFLATE_HOIST 1, the product) against the round-4 order (0), the section cycles of both from the measurement
-# builds (-DGD_INFLATE_TIMING), and the genome file -> BED with either library.   tools/r12_session9.sh <tag>
+# builds (-DGD_INFLATE_TIMING), and the genome file -> BED with either library (the variant libraries of commit 573965c:
+# GD_INFLATE_HOIST was a macro then).   tools/r12_session9.sh <tag>
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
 R=$PWD; T=${1:-r12j}; O=$R/gpurun_out; mkdir -p $O; export TMPDIR=/tmp
 LOG=$O/${T}.log; : > $LOG
