@@ -5,6 +5,8 @@
 #pragma once
 
 #include <memory>
+#include <atomic>
+#include <mutex>
 #include <thread>
 
 namespace {

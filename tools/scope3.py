@@ -70,6 +70,7 @@ def main():
         variants.insert(1, ("device", dict(kv.split("=", 1) for kv in v.split(","))))
     for vi, (decoder, env) in enumerate(variants):
         best = None
+        runs = []
         for rep in range(args.host_reps if decoder == "host" else 3):   # the file is in the page cache after the write
             time.sleep(args.pause)
             t0 = time.perf_counter()
@@ -79,19 +80,23 @@ def main():
                                env=dict(os.environ, GOLEFT_DEPTH_TIMING="1", GOLEFT_INGEST_TIMING="1", **env), stderr=subprocess.PIPE)
             dt = time.perf_counter() - t0
             assert p.returncode == 0, p.stderr.decode()
+            if os.environ.get("SCOPE3_KEEP_STDERR"):       # (measurement builds print marks of their own)
+                with open(os.environ["SCOPE3_KEEP_STDERR"], "a") as f:
+                    f.write("== %s %s run %d\n%s\n" % (decoder, env, rep, p.stderr.decode()))
             lines = p.stderr.decode().strip().splitlines()
             phases = json.loads(lines[-1])
             assert phases["decoder"] == decoder, phases
             for ln in lines[:-1]:                          # GOLEFT_INGEST_TIMING: the device read's own phases
                 if ln.startswith("{"):
                     phases.update(json.loads(ln))
+            runs.append({"wall_s": dt, "lib_begin_s": phases.get("lib_begin_s"), "read_s": phases.get("read_s"), "setup_s": phases.get("setup_s")})
             if best is None or dt < best[0]:
                 best = (dt, phases)
         dt, phases = best
         stem = os.path.join(d, "out_" + decoder) + ((".%s" % args.name) if args.paper else "")   # depth/depth.go:382-388
         beds[decoder] = open(stem + ".depth.bed").read() + open(stem + ".callable.bed").read()
         out[decoder + "_decoder" + (("_%d" % vi) if vi and decoder == "device" else "")] = {"env": env, "wall_s": dt, "ref_bases_per_s": args.length / dt,
-                                     "bam_MB_per_s": info["bam_bytes"] / 1e6 / dt, "phases": phases}
+                                     "bam_MB_per_s": info["bam_bytes"] / 1e6 / dt, "phases": phases, "all_runs": runs}
     out["outputs_identical"] = beds["device"] == beds["host"] if "host" in beds else None
     out["depth_rows"] = beds["device"].count("\n")
     if args.rocprof:
