@@ -656,6 +656,173 @@ static int emit_fused_genome(const std::vector<Region>& regions, const std::vect
     return 0;
 }
 
+// Rows in input order for everything emit_fused_genome does not cover: fused tiles one contig at a time (its window sums and
+// class runs fetched once), --bed rows and tiles cut by a disagreeing .fai through the region reductions (collected and
+// reduced in batches: one gd_regions call for up to kBatch of them instead of several launches, allocations and
+// synchronisations per row), regions of references the BAM header does not know (all-zero rows and a non-zero exit code,
+// depth/depth.go:395-399), and the --stats columns (the bases of the current contig live in HBM -- gd_seq_load --, per
+// region one gd_seq_stats call counts GC / CpG / lower-case bases of every emitted window; depth/depth.go:244-252, :199).
+// add / finish: 0, or 1 after the failed call has been reported.
+class RegionRows {
+public:
+    bool io_ok = true;
+    int exit_code = 0;
+
+    RegionRows(const std::vector<int64_t>& lens, Shards& S, const std::vector<int>& shard_of, gdh::FastaStats* fa, int W, FILE* fhd,
+               FILE* fca)
+        : lens_(lens), S_(S), shard_of_(shard_of), fa_(fa), W_(W), fhd_(fhd), fca_(fca), stats_contract_(gdh_get_stats_contract()),
+          seq_ctx_(S.v[0].ctx)                                 // --stats: the FASTA windows are counted on the first device
+    {
+    }
+
+    int add(const Region& r, bool fused)
+    {
+        gd_ctx* ctx = seq_ctx_;                                // the context GDCHK reports on
+#define GDCHK(call) GDCHK_ON(ctx, call)
+        if (stats_rc_ != GD_OK) GDCHK(stats_rc_);
+        if (r.tid < 0) {
+            GDCHK(flush_batch());
+            // samtools would fail on an unknown reference name: the callback then sees an
+            // empty stream (all-zero rows) and the exit code becomes non-zero (:395-399)
+            fprintf(stderr, "ERROR with command: region %s:%" PRId64 "-%" PRId64 " not in the BAM header\n",
+                    r.chrom.c_str(), r.start + 1, r.end);
+            exit_code = std::max(exit_code, 1);
+            gd_run nr{(int32_t)r.start, (int32_t)r.end, GD_NO_COVERAGE};
+            emit_region(r.chrom.c_str(), r.start, r.end, nullptr, 0, &nr, r.end > r.start ? 1 : 0);
+        } else if (fused) {
+            ctx = ctx_of(r.tid);
+            GDCHK(flush_batch());
+            if (cached_tid_ != r.tid) {
+                size_t n = 0;
+                csums_.resize((size_t)((lens_[(size_t)r.tid] + W_ - 1) / W_));
+                GDCHK(gd_windows(ctx, r.tid, csums_.data(), nullptr, csums_.size(), &n));
+                int rc = gd_callable(ctx, r.tid, nullptr, 0, &n);
+                if (rc != GD_OK && rc != GD_E_CAPACITY) GDCHK(rc);
+                cruns_.resize(n);
+                if (n) GDCHK(gd_callable(ctx, r.tid, cruns_.data(), cruns_.size(), &n));
+                cached_tid_ = r.tid;
+                run_cursor_ = 0;
+            }
+            // runs are split at multiples of step, so each belongs to exactly one tile
+            while (run_cursor_ < cruns_.size() && cruns_[run_cursor_].start < r.start) ++run_cursor_;
+            size_t e = run_cursor_;
+            while (e < cruns_.size() && cruns_[e].start < r.end) ++e;
+            const size_t w0 = (size_t)(r.start / W_), w1 = (size_t)((r.end + W_ - 1) / W_);
+            emit_region(r.chrom.c_str(), r.start, r.end, csums_.data() + w0, w1 - w0, cruns_.data() + run_cursor_, e - run_cursor_);
+            run_cursor_ = e;
+        } else if (r.end > r.start) {
+            ctx = ctx_of(r.tid);
+            if (!batch_.empty() && shard_of_[(size_t)batch_[0]->tid] != shard_of_[(size_t)r.tid]) {
+                ctx = ctx_of(batch_[0]->tid);
+                GDCHK(flush_batch());
+            }
+            batch_.push_back(&r);
+            if (batch_.size() >= kBatch) GDCHK(flush_batch());
+        }
+        if (rows_.hd.size() + rows_.ca.size() > (8u << 20)) io_ok = flush_rows(&rows_, fhd_, fca_) && io_ok;
+        return 0;
+    }
+
+    int finish()
+    {
+        gd_ctx* ctx = batch_.empty() ? seq_ctx_ : ctx_of(batch_[0]->tid);
+        GDCHK(flush_batch());
+        ctx = seq_ctx_;
+        if (stats_rc_ != GD_OK) GDCHK(stats_rc_);
+#undef GDCHK
+        io_ok = flush_rows(&rows_, fhd_, fca_) && io_ok;
+        return 0;
+    }
+
+private:
+    static constexpr size_t kBatch = 4096;
+    const std::vector<int64_t>& lens_;
+    Shards& S_;
+    const std::vector<int>& shard_of_;
+    gdh::FastaStats* const fa_;
+    const int W_;
+    FILE *const fhd_, *const fca_;
+    const int stats_contract_;
+    gd_ctx* const seq_ctx_;
+    RowWriter rows_;
+    std::vector<int64_t> sums_, csums_;
+    std::vector<gd_run> runs_, cruns_;
+    int cached_tid_ = -1;                                      // whole-contig results of the current contig
+    size_t run_cursor_ = 0;
+    std::vector<const Region*> batch_;                         // regions of ONE shard (flushed when the shard changes)
+    std::string seq_chrom_, seq_bases_;
+    bool seq_known_ = false;
+    int64_t seq_line_bases_ = 0;
+    int stats_rc_ = GD_OK;
+
+    gd_ctx* ctx_of(int tid) const { return S_.v[(size_t)shard_of_[(size_t)tid]].ctx; }
+
+    void emit_region(const char* chrom, int64_t rs, int64_t re, const int64_t* su, size_t n_su, const gd_run* ru, size_t n_ru)
+    {
+        if (!fa_) { format_region(&rows_, chrom, rs, re, W_, su, n_su, ru, n_ru, nullptr); return; }
+        StatsPlan sp;
+        RowWriter probe;
+        format_region(&probe, chrom, rs, re, W_, su, n_su, ru, n_ru, &sp);
+        if (seq_chrom_ != chrom || seq_chrom_.empty()) {
+            seq_chrom_ = chrom;
+            seq_known_ = fa_->contig_bases(chrom, &seq_bases_, &seq_line_bases_);
+            if (seq_known_ && stats_rc_ == GD_OK)
+                stats_rc_ = gd_seq_load(seq_ctx_, reinterpret_cast<const uint8_t*>(seq_bases_.data()), (int64_t)seq_bases_.size());
+            seq_bases_.clear();
+            seq_bases_.shrink_to_fit();
+        }
+        const size_t n = sp.s.size();
+        std::vector<uint32_t> gc(n, 0), cpg(n, 0), low(n, 0), acgt(n, 0), lacgt(n, 0);
+        if (seq_known_ && n && stats_rc_ == GD_OK) {
+            const bool raw = (stats_contract_ & GDH_STATS_CPG_RAW_LINES) && seq_line_bases_ > 0 && seq_line_bases_ < 0x7fffffff;
+            stats_rc_ = gd_seq_stats_ex(seq_ctx_, n, sp.s.data(), sp.e.data(), raw ? (int32_t)seq_line_bases_ : 0,
+                                        gc.data(), cpg.data(), low.data(), acgt.data(), lacgt.data());
+        }
+        sp.cols.resize(n);
+        for (size_t k = 0; k < n; ++k) {
+            char buf[96];
+            gdh_format_stats(stats_contract_, seq_known_ ? 1 : 0, sp.s[k], sp.e[k], gc[k], cpg[k], low[k], acgt[k], lacgt[k],
+                             buf, sizeof buf);                               // :199
+            sp.cols[k] = buf;
+        }
+        sp.collecting = false;
+        format_region(&rows_, chrom, rs, re, W_, su, n_su, ru, n_ru, &sp);
+    }
+
+    // the collected regions through one gd_regions call; GD_* status
+    int flush_batch()
+    {
+        if (batch_.empty()) return GD_OK;
+        gd_ctx* const ctx = ctx_of(batch_[0]->tid);
+        const size_t nb = batch_.size();
+        std::vector<int32_t> b_tid(nb);
+        std::vector<int64_t> b_start(nb), b_end(nb);
+        size_t nw = 0;
+        for (size_t k = 0; k < nb; ++k) {
+            b_tid[k] = batch_[k]->tid; b_start[k] = batch_[k]->start; b_end[k] = batch_[k]->end;
+            nw += (size_t)((batch_[k]->end - 1) / W_ - batch_[k]->start / W_ + 1);
+        }
+        std::vector<size_t> woff(nb + 1), roff(nb + 1);
+        sums_.resize(nw);
+        runs_.resize(std::max<size_t>(runs_.size(), 4 * nb + 1024));
+        int rc = gd_regions(ctx, nb, b_tid.data(), b_start.data(), b_end.data(), sums_.data(), nullptr, nw, woff.data(),
+                            runs_.data(), runs_.size(), roff.data());
+        if (rc == GD_E_CAPACITY && woff[nb] <= nw && roff[nb] > runs_.size()) {
+            runs_.resize(roff[nb]);
+            rc = gd_regions(ctx, nb, b_tid.data(), b_start.data(), b_end.data(), sums_.data(), nullptr, nw, woff.data(),
+                            runs_.data(), runs_.size(), roff.data());
+        }
+        if (rc != GD_OK) return rc;
+        for (size_t k = 0; k < nb; ++k) {
+            emit_region(batch_[k]->chrom.c_str(), batch_[k]->start, batch_[k]->end, sums_.data() + woff[k], woff[k + 1] - woff[k],
+                        runs_.data() + roff[k], roff[k + 1] - roff[k]);
+            if (rows_.hd.size() + rows_.ca.size() > (8u << 20)) io_ok = flush_rows(&rows_, fhd_, fca_) && io_ok;
+        }
+        batch_.clear();
+        return GD_OK;
+    }
+};
+
 int run(const DArgs& args)
 {
     const auto t_run = std::chrono::steady_clock::now();
@@ -757,145 +924,21 @@ int run(const DArgs& args)
     }
 
     // ---- rows, in input order (what --ordered gives; Q4) -------------------------
-    RowWriter rows;
-    std::vector<int64_t> sums;
-    std::vector<gd_run> runs;
-    int cached_tid = -1;            // whole-contig results of the current contig
-    std::vector<int64_t> csums;
-    std::vector<gd_run> cruns;
-    size_t run_cursor = 0;
     bool io_ok = true;
-    // --stats: the bases of the current contig live in HBM (gd_seq_load); per region one
-    // gd_seq_stats call counts GC / CpG / lower-case bases of every emitted window
-    std::string seq_chrom, seq_bases;
-    bool seq_known = false;
-    int64_t seq_line_bases = 0;
-    const int stats_contract = gdh_get_stats_contract();
-    int stats_rc = GD_OK;
-    gd_ctx* const seq_ctx = S.v[0].ctx;              // --stats: the FASTA windows are counted on the first device
-    auto emit_region = [&](const char* chrom, int64_t rs, int64_t re, const int64_t* su, size_t n_su,
-                           const gd_run* ru, size_t n_ru) {
-        if (!fa) { format_region(&rows, chrom, rs, re, W, su, n_su, ru, n_ru, nullptr); return; }
-        StatsPlan sp;
-        RowWriter probe;
-        format_region(&probe, chrom, rs, re, W, su, n_su, ru, n_ru, &sp);
-        if (seq_chrom != chrom || seq_chrom.empty()) {
-            seq_chrom = chrom;
-            seq_known = fa->contig_bases(chrom, &seq_bases, &seq_line_bases);
-            if (seq_known && stats_rc == GD_OK)
-                stats_rc = gd_seq_load(seq_ctx, reinterpret_cast<const uint8_t*>(seq_bases.data()), (int64_t)seq_bases.size());
-            seq_bases.clear();
-            seq_bases.shrink_to_fit();
-        }
-        const size_t n = sp.s.size();
-        std::vector<uint32_t> gc(n, 0), cpg(n, 0), low(n, 0), acgt(n, 0), lacgt(n, 0);
-        if (seq_known && n && stats_rc == GD_OK) {
-            const bool raw = (stats_contract & GDH_STATS_CPG_RAW_LINES) && seq_line_bases > 0 && seq_line_bases < 0x7fffffff;
-            stats_rc = gd_seq_stats_ex(seq_ctx, n, sp.s.data(), sp.e.data(), raw ? (int32_t)seq_line_bases : 0,
-                                       gc.data(), cpg.data(), low.data(), acgt.data(), lacgt.data());
-        }
-        sp.cols.resize(n);
-        for (size_t k = 0; k < n; ++k) {
-            char buf[96];
-            gdh_format_stats(stats_contract, seq_known ? 1 : 0, sp.s[k], sp.e[k], gc[k], cpg[k], low[k], acgt[k], lacgt[k],
-                             buf, sizeof buf);                               // :199
-            sp.cols[k] = buf;
-        }
-        sp.collecting = false;
-        format_region(&rows, chrom, rs, re, W, su, n_su, ru, n_ru, &sp);
-    };
-    // Regions that need the region reductions (every --bed row, tiles cut by a disagreeing .fai) are
-    // collected and reduced in batches: one gd_regions call for up to kBatch of them instead of several
-    // launches, allocations and synchronisations per row.  Output order is the input order.
-    constexpr size_t kBatch = 4096;
-    std::vector<const Region*> batch;               // regions of ONE shard (flushed when the shard changes)
-    auto flush_batch = [&]() -> int {
-        if (batch.empty()) return GD_OK;
-        gd_ctx* const ctx = ctx_of(batch[0]->tid);
-        const size_t nb = batch.size();
-        std::vector<int32_t> b_tid(nb);
-        std::vector<int64_t> b_start(nb), b_end(nb);
-        size_t nw = 0;
-        for (size_t k = 0; k < nb; ++k) {
-            b_tid[k] = batch[k]->tid; b_start[k] = batch[k]->start; b_end[k] = batch[k]->end;
-            nw += (size_t)((batch[k]->end - 1) / W - batch[k]->start / W + 1);
-        }
-        std::vector<size_t> woff(nb + 1), roff(nb + 1);
-        sums.resize(nw);
-        runs.resize(std::max<size_t>(runs.size(), 4 * nb + 1024));
-        int rc = gd_regions(ctx, nb, b_tid.data(), b_start.data(), b_end.data(), sums.data(), nullptr, nw, woff.data(),
-                            runs.data(), runs.size(), roff.data());
-        if (rc == GD_E_CAPACITY && woff[nb] <= nw && roff[nb] > runs.size()) {
-            runs.resize(roff[nb]);
-            rc = gd_regions(ctx, nb, b_tid.data(), b_start.data(), b_end.data(), sums.data(), nullptr, nw, woff.data(),
-                            runs.data(), runs.size(), roff.data());
-        }
-        if (rc != GD_OK) return rc;
-        for (size_t k = 0; k < nb; ++k) {
-            emit_region(batch[k]->chrom.c_str(), batch[k]->start, batch[k]->end, sums.data() + woff[k], woff[k + 1] - woff[k],
-                        runs.data() + roff[k], roff[k + 1] - roff[k]);
-            if (rows.hd.size() + rows.ca.size() > (8u << 20)) io_ok = flush_rows(&rows, fhd, fca) && io_ok;
-        }
-        batch.clear();
-        return GD_OK;
-    };
-    gd_ctx* ctx = seq_ctx;                          // the context GDCHK reports on
-#define GDCHK(call) GDCHK_ON(ctx, call)
     // the common case (a whole-genome run without --stats): emit_fused_genome formats the rows on all cores
     bool sliced_rows = !fa && args.bed.empty() && !regions.empty();
     for (size_t i = 0; sliced_rows && i < regions.size(); ++i)
         if (regions[i].tid < 0 || !is_fused(regions[i])) sliced_rows = false;
-    if (sliced_rows)
+    if (sliced_rows) {
         if (int rc = emit_fused_genome(regions, lens, ctx_of, W, fhd, fca, &io_ok)) return rc;
-    for (const Region& r : regions) {
-        if (sliced_rows) break;
-        if (stats_rc != GD_OK) { ctx = seq_ctx; GDCHK(stats_rc); }
-        if (r.tid >= 0) ctx = ctx_of(r.tid);
-        if (r.tid < 0) {
-            GDCHK(flush_batch());
-            // samtools would fail on an unknown reference name: the callback then sees an
-            // empty stream (all-zero rows) and the exit code becomes non-zero (:395-399)
-            fprintf(stderr, "ERROR with command: region %s:%" PRId64 "-%" PRId64 " not in the BAM header\n",
-                    r.chrom.c_str(), r.start + 1, r.end);
-            exit_code = std::max(exit_code, 1);
-            gd_run nr{(int32_t)r.start, (int32_t)r.end, GD_NO_COVERAGE};
-            emit_region(r.chrom.c_str(), r.start, r.end, nullptr, 0, &nr, r.end > r.start ? 1 : 0);
-        } else {
-            const int64_t clen = contigs[(size_t)r.tid].length;
-            const bool fused = is_fused(r);
-            if (fused) {
-                GDCHK(flush_batch());
-                if (cached_tid != r.tid) {
-                    size_t n = 0;
-                    csums.resize((size_t)((clen + W - 1) / W));
-                    GDCHK(gd_windows(ctx, r.tid, csums.data(), nullptr, csums.size(), &n));
-                    int rc = gd_callable(ctx, r.tid, nullptr, 0, &n);
-                    if (rc != GD_OK && rc != GD_E_CAPACITY) GDCHK(rc);
-                    cruns.resize(n);
-                    if (n) GDCHK(gd_callable(ctx, r.tid, cruns.data(), cruns.size(), &n));
-                    cached_tid = r.tid;
-                    run_cursor = 0;
-                }
-                // runs are split at multiples of step, so each belongs to exactly one tile
-                while (run_cursor < cruns.size() && cruns[run_cursor].start < r.start) ++run_cursor;
-                size_t e = run_cursor;
-                while (e < cruns.size() && cruns[e].start < r.end) ++e;
-                const size_t w0 = (size_t)(r.start / W), w1 = (size_t)((r.end + W - 1) / W);
-                emit_region(r.chrom.c_str(), r.start, r.end, csums.data() + w0, w1 - w0,
-                            cruns.data() + run_cursor, e - run_cursor);
-                run_cursor = e;
-            } else if (r.end > r.start) {
-                if (!batch.empty() && shard_of[(size_t)batch[0]->tid] != shard_of[(size_t)r.tid]) GDCHK(flush_batch());
-                batch.push_back(&r);
-                if (batch.size() >= kBatch) GDCHK(flush_batch());
-            }
-        }
-        if (rows.hd.size() + rows.ca.size() > (8u << 20)) io_ok = flush_rows(&rows, fhd, fca) && io_ok;
+    } else {
+        RegionRows rr(lens, S, shard_of, fa, W, fhd, fca);
+        for (const Region& r : regions)
+            if (int rc = rr.add(r, r.tid >= 0 && is_fused(r))) return rc;
+        if (int rc = rr.finish()) return rc;
+        io_ok = rr.io_ok;
+        exit_code = std::max(exit_code, rr.exit_code);
     }
-    GDCHK(flush_batch());
-    if (stats_rc != GD_OK) { ctx = seq_ctx; GDCHK(stats_rc); }
-#undef GDCHK
-    io_ok = flush_rows(&rows, fhd, fca) && io_ok;
     closer.done = true;
     if (fclose(fca) != 0) io_ok = false;
     if (fclose(fhd) != 0) io_ok = false;
