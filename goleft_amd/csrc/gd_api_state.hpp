@@ -215,8 +215,8 @@ struct gd_ctx {
     // gd_ingest_begin .. gd_ingest_finish.  Two ranges may be pending: ing_q[0] is the oldest (the one
     // gd_ingest_decode / _finish / _release act on), the last one is being fed -- so the inflate tail of
     // one range overlaps the upload of the next.
-    static constexpr int kIngestDepth = 3;              // ranges that may be pending: one being decoded, one inflating, one being fed
-    IngestState* ing_q[kIngestDepth] = {nullptr, nullptr, nullptr};
+    static constexpr int kIngestDepth = 4;              // ranges that may be pending: one being decoded, one or two inflating, one being fed
+    IngestState* ing_q[kIngestDepth] = {};
     int ing_n = 0;
     double ing_secs[7] = {0, 0, 0, 0, 0, 0, 0};         // gd_ingest_timing
     std::thread ing_feeder;                             // gd_ingest_feed_fd: the read of the newest range in progress

@@ -385,6 +385,9 @@ inline int ingest_references_on_device(gd_ctx* ctx, const FileMap& fm, const std
     // had to wait for the inflate tail of the pass that had JUST been fed before the next pass could be announced, and the
     // link stood still for that long (it matters once the link is fast: GD_OPT_INGEST_CU_SPLIT).
     std::vector<size_t> fed;                               // passes fed and not yet decoded, oldest first
+    // (GOLEFT_INGEST_DEPTH: 2 .. 4 passes in flight, measurement switch; the library holds up to four)
+    size_t depth = 3;
+    if (const char* e = getenv("GOLEFT_INGEST_DEPTH")) depth = (size_t)std::min(4, std::max(2, atoi(e)));
     for (size_t pk = 0; pk < passes.size(); ++pk) {
         const IngestPass& ps = passes[pk];
         const uint64_t beg = ps.beg, end = ps.end;
@@ -421,7 +424,7 @@ inline int ingest_references_on_device(gd_ctx* ctx, const FileMap& fm, const std
         const double t3 = now();
         fed.push_back(pk);
         // this pass is on its way (upload + inflate are asynchronous): now decode the oldest one, once two are behind it
-        if (fed.size() > 2) {
+        if (fed.size() > depth - 1) {
             rc = decode_pass(passes[fed.front()]);
             if (rc != GD_OK) return rc;
             fed.erase(fed.begin());
