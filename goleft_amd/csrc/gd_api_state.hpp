@@ -215,7 +215,9 @@ struct gd_ctx {
     // gd_ingest_begin .. gd_ingest_finish.  Two ranges may be pending: ing_q[0] is the oldest (the one
     // gd_ingest_decode / _finish / _release act on), the last one is being fed -- so the inflate tail of
     // one range overlaps the upload of the next.
-    static constexpr int kIngestDepth = 4;              // ranges that may be pending: one being decoded, one or two inflating, one being fed
+    // ranges that may be pending: one being decoded, one inflating, one being fed (include/goleft_depth.h: a fourth
+    // gd_ingest_begin is refused).  Four were measured -- 2.42 against 2.44 s per genome read, profiles/r12u_... -- and not kept.
+    static constexpr int kIngestDepth = 3;
     IngestState* ing_q[kIngestDepth] = {};
     int ing_n = 0;
     double ing_secs[7] = {0, 0, 0, 0, 0, 0, 0};         // gd_ingest_timing

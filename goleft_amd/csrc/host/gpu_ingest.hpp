@@ -385,9 +385,10 @@ inline int ingest_references_on_device(gd_ctx* ctx, const FileMap& fm, const std
     // had to wait for the inflate tail of the pass that had JUST been fed before the next pass could be announced, and the
     // link stood still for that long (it matters once the link is fast: GD_OPT_INGEST_CU_SPLIT).
     std::vector<size_t> fed;                               // passes fed and not yet decoded, oldest first
-    // (GOLEFT_INGEST_DEPTH: 2 .. 4 passes in flight, measurement switch; the library holds up to four)
+    // (GOLEFT_INGEST_DEPTH: 2 or 3 passes in flight, measurement switch; the library holds up to three -- a build that held
+    // four was measured, profiles/r12u_...: no difference)
     size_t depth = 3;
-    if (const char* e = getenv("GOLEFT_INGEST_DEPTH")) depth = (size_t)std::min(4, std::max(2, atoi(e)));
+    if (const char* e = getenv("GOLEFT_INGEST_DEPTH")) depth = (size_t)std::min(3, std::max(2, atoi(e)));
     for (size_t pk = 0; pk < passes.size(); ++pk) {
         const IngestPass& ps = passes[pk];
         const uint64_t beg = ps.beg, end = ps.end;

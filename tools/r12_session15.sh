@@ -1,5 +1,6 @@
 #!/bin/bash
-# Round 5, GPU session 15: four ranges in flight instead of three (GOLEFT_INGEST_DEPTH=4).   tools/r12_session15.sh <tag>
+# Round 5, GPU session 15: four ranges in flight instead of three (GOLEFT_INGEST_DEPTH=4 on the build of commit b7eb1c8, whose
+# library held four pending ranges; the library is back at three: the ABI refuses a fourth gd_ingest_begin).   tools/r12_session15.sh <tag>
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
 R=$PWD; T=${1:-r12u}; O=$R/gpurun_out; mkdir -p $O; export TMPDIR=/tmp
 LOG=$O/${T}.log; : > $LOG
