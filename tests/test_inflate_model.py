@@ -35,3 +35,23 @@ def test_model_of_a_small_synthetic_bam(tmp_path):
     cdf = d["chunk_loads_from_memory_with_distance_at_most"]
     vals = [cdf[k] for k in sorted(cdf, key=int)]
     assert vals == sorted(vals) and abs(vals[-1] - 1.0) < 1e-9 and vals[0] < 0.2   # (sources closer than 128 bytes come from the ring)
+
+
+def test_huffman_self_synchronisation_tool(tmp_path):
+    """tools/huffman_sync.py: its DEFLATE parser reproduces zlib's output length for every member it looks at (asserted inside),
+    and a decoder started at a wrong bit offset falls into step within a few dozen symbols -- the figure DESIGN.md section 7
+    builds the wave-per-member design on."""
+    exe = os.path.join(H.ROOT, "goleft_amd", "synth-bam")
+    if not os.path.exists(exe):
+        pytest.skip("goleft_amd/synth-bam is not built")
+    bam = str(tmp_path / "m.bam")
+    subprocess.check_call([exe, bam, "chrS", "1500000", "30", "20"], stdout=subprocess.DEVNULL)
+    out = subprocess.check_output([sys.executable, os.path.join(H.ROOT, "tools", "huffman_sync.py"), bam, "--members", "4", "--starts", "60",
+                                   "--skip", "7"], timeout=600)
+    d = json.loads(out.decode())
+    assert d["members"] == 4 and d["huffman_blocks_per_member"] >= 1.0 and d["symbols_per_member"] > 5000
+    s = d["symbols_until_in_step"]
+    assert 1 <= s["median"] <= 30 and s["median"] <= s["p90"] <= s["p99"] <= s["max"] < 2000
+    assert d["ran_into_an_invalid_code_or_the_block_end_first"] < 0.05
+    q = d["sequential_symbol_steps_per_member"]
+    assert q["64_lanes_speculative"] < q["one_lane"] / 10
