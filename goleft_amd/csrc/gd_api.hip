@@ -879,9 +879,9 @@ int gd_set_option(gd_ctx* c, int option, int64_t value)
         if (c->ing_walk) return fail(c, GD_E_STATE, "the ingest streams exist already: set GD_OPT_INGEST_WALK_CUS before the first gd_ingest_begin");
         c->ing_walk_cus = value != 0;
         break;
-    case GD_OPT_INFLATE_PROBE:
-        if (value < 0 || value > 3) return fail(c, GD_E_INVALID, "inflate probe: 0 .. 3 (measurement only)");
-        c->inflate_probe = (unsigned)value;
+    case GD_OPT_INFLATE_KERNEL:
+        if (value < 0 || value > 1) return fail(c, GD_E_INVALID, "inflate kernel: 0 (a workgroup per member) or 1 (a lane per member)");
+        c->inflate_kernel = (int)value;
         break;
     case GD_OPT_INGEST_PIECE_STREAMS:
         if (value < 1 || value > 4) return fail(c, GD_E_INVALID, "ingest piece streams: 1 .. 4");

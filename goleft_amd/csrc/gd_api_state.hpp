@@ -251,7 +251,7 @@ struct gd_ctx {
     unsigned h2d_grid = 512;                           // ... its workgroups
     bool ingest_crc = true;                            // GD_OPT_INGEST_CRC
     uint64_t ing_range_hint = 0;                       // GD_OPT_INGEST_RANGE_HINT: bytes of the largest range the caller will feed
-    unsigned inflate_probe = 0;                        // GD_OPT_INFLATE_PROBE (measurement only)
+    int inflate_kernel = 0;                            // GD_OPT_INFLATE_KERNEL
     unsigned inflate_pad = 0;                          // GD_OPT_INFLATE_LDS_PAD: extra LDS per inflate workgroup (occupancy limiter)
     int32_t bam_n_ref = 0;                             // GD_OPT_BAM_REFS: references of the BAM being read (0: unknown)
     int push_threads = 16;

@@ -92,9 +92,8 @@ struct InflateJob {
     uint8_t* out;                  // (readable up to 64 bytes past the last member)
     uint32_t* status;              // [n] 0 ok, else an error code (18: CRC32 mismatch)
     uint32_t n;
-    uint32_t probe;                // MEASUREMENT ONLY (GD_OPT_INFLATE_PROBE; 0 in every product path): bit 0 -- the source of a match is
-                                   // never loaded from memory (the ring's bytes instead: WRONG output, the decode itself does not
-                                   // depend on it); bit 1 -- whole 64-byte blocks are not stored.  What the kernel's time is made of.
+    uint32_t only_status;          // 0: every member.  Else the lane-per-member kernel inflates only the members whose status word
+                                   // holds this value (WV_FALLBACK: what the workgroup-per-member kernel left to it) and leaves the rest alone
 };
 
 constexpr size_t INF_SLACK = 256;  // bytes the inflate buffers are allocated beyond their contents
@@ -268,7 +267,8 @@ __global__ __launch_bounds__(INF_LANES) void gd_inflate_kernel(InflateJob job)
     }
     __syncthreads();
     const uint32_t m = blockIdx.x * INF_LANES + threadIdx.x;
-    const bool mine = m < job.n;
+    const bool mine = m < job.n && (job.only_status == 0u || job.status[m] == job.only_status);
+    if (job.only_status != 0u && __ballot(mine) == 0) return;   // (a wave with nothing left to it -- nearly all of them)
     const uint32_t mm = mine ? m : 0u;
     const uint8_t* const in_beg = job.comp + job.in_off[mm];
     const uint8_t* const in_end = in_beg + job.in_len[mm];
@@ -352,7 +352,7 @@ __global__ __launch_bounds__(INF_LANES) void gd_inflate_kernel(InflateJob job)
         inf_v4 cl = {0, 0, 0, 0}, in16 = {0, 0, 0, 0};
         const bool cload = cpend && !csmall;
         const uint32_t sa = obase + co - deff;             // where the chunk's source begins (ao); it ends at or before co
-        const bool from_mem = cload && sa + 16u <= fl && !(job.probe & 1u);   // completely stored -- else completely inside the ring
+        const bool from_mem = cload && sa + 16u <= fl;     // completely stored -- else completely inside the ring
         if (from_mem) cl = inf_load16_stream(ld_addr);
         // (the slot 64 bytes behind win_hi has been consumed; a lane that waits for its block header may ask too: the header
         // path drops the request when it restarts the window)
@@ -602,8 +602,7 @@ __global__ __launch_bounds__(INF_LANES) void gd_inflate_kernel(InflateJob job)
             // aligned 64-byte block, back to back (at most one block per iteration: the output grows by 16 bytes at most)
             if (ao >= fl + 64u) {
                 const uint32_t j0 = (fl >> 2) & 31u;       // 0 or 16
-                if (job.probe & 2u) {
-                } else if (fl >= obase) {
+                if (fl >= obase) {
 #pragma unroll
                     for (uint32_t q = 0; q < 4u; ++q) {
                         inf_v4 v;
@@ -820,11 +819,29 @@ __global__ __launch_bounds__(256) void gd_inflate_crc_wave_kernel(InflateJob job
 
 constexpr bool INF_CRC_WAVE = true;                        // which of the two CRC kernels inflate_launch uses
 
-// Both kernels on one stream.
-// lds_pad: bytes of LDS a workgroup claims on top of its own 38 KB -- an occupancy limiter for measurements (four
-// workgroups per CU as built; + 16 KB: three; + 42 KB: two), GD_OPT_INFLATE_LDS_PAD.
-inline void inflate_launch(const InflateJob& job, hipStream_t stream, unsigned lds_pad = 0)
+}  // namespace gd
+
+#include "gd_inflate_wave.hpp"
+
+namespace gd {
+
+constexpr int INF_WAVE_NW = 4;                             // waves per member of the workgroup-per-member kernel
+
+// The kernels of one inflate on one stream: a workgroup per member (gd_inflate_wave.hpp), the lane-per-member kernel for what
+// that one left (WV_FALLBACK), the CRC check.
+// kernel: 0 -- the default; 1 -- the lane-per-member kernel alone (rounds 3-5; GD_OPT_INFLATE_KERNEL, a measurement and a
+// second implementation for the tests to compare with).
+// lds_pad: bytes of LDS a lane-per-member workgroup claims on top of its own 38 KB -- an occupancy limiter for measurements.
+inline void inflate_launch(const InflateJob& job_in, hipStream_t stream, unsigned lds_pad = 0, int kernel = 0)
 {
+    InflateJob job = job_in;
+    if (job.n == 0) return;
+    if (kernel == 0) {
+        hipLaunchKernelGGL(gd_inflate_wave_kernel<INF_WAVE_NW>, dim3(job.n), dim3(64 * INF_WAVE_NW), 0, stream, job);
+        job.only_status = WV_FALLBACK;
+    } else {
+        job.only_status = 0;
+    }
     hipLaunchKernelGGL(gd_inflate_kernel, dim3((job.n + INF_LANES - 1) / INF_LANES), dim3(INF_LANES), lds_pad, stream, job);
     if (job.crc && INF_CRC_WAVE) {
         const unsigned groups = (job.n + 3u) / 4u;

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define GD_ABI_VERSION 14
+#define GD_ABI_VERSION 15
 
 typedef enum {
     GD_OK = 0,
@@ -221,9 +221,11 @@ enum { /* (1, 2: tile shapes other than 4096 positions x 256 threads -- measured
        GD_OPT_INGEST_WALK_CUS = 22,   /* with GD_OPT_INGEST_CU_SPLIT: 1: the record walks of a decode run on the copy kernel's CUs (a
                                        CU-masked stream of their own) instead of beside the inflate workgroups, whose LDS leaves a
                                        walk one workgroup per CU; 0 (default) */
-       GD_OPT_INFLATE_PROBE = 20,     /* MEASUREMENT ONLY, the inflated bytes are WRONG when set: 0 (default); bit 0: the inflate kernel never
-                                       loads a match's source from memory; bit 1: it stores no whole 64-byte blocks.  What bounds the kernel:
-                                       its decode, its loads or its stores (profiles/r12*) */
+       GD_OPT_INFLATE_KERNEL = 20,    /* which kernel inflates BGZF members: 0 (default) a workgroup per member with the member's output
+                                       in LDS (gd_inflate_wave.hpp; members it does not take go to the other kernel on the same stream);
+                                       1: a lane per member (gd_inflate.hpp, rounds 3-5).  Both produce zlib's bytes; the second one is
+                                       kept as the fallback, as a yardstick and as a second implementation for the tests.  (ABI 14 had a
+                                       measurement switch with this number that produced wrong bytes: gone) */
        GD_OPT_H2D_KERNEL = 8 };     /* how a committed staging block reaches HBM: 1 (default) one kernel whose workgroups
                                        read the page-locked block over the link (all five arrays in one launch; n > 1:
                                        with n workgroups), 0: five hipMemcpyAsync through a DMA engine */

@@ -93,6 +93,26 @@ static inline uint64_t emul_ballot(bool p)
     emul::wave_barrier();
     return emul::ballot_acc[w][k % 3u];
 }
+// v_readlane / a shuffle: every lane of the wave publishes its value, then reads another lane's (all running lanes of the wave call together)
+namespace emul { static uint32_t xchg[MAX_WAVES][WAVE]; }
+static inline uint32_t emul_readlane(uint32_t v, uint32_t l)
+{
+    const unsigned w = emul::cur / emul::WAVE;
+    emul::xchg[w][threadIdx.x % emul::WAVE] = v;
+    emul::wave_barrier();
+    const uint32_t r = emul::xchg[w][l % emul::WAVE];
+    emul::wave_barrier();
+    return r;
+}
+static inline uint32_t emul_shfl_up(uint32_t v, uint32_t d)
+{
+    const unsigned w = emul::cur / emul::WAVE, lane = threadIdx.x % emul::WAVE;
+    emul::xchg[w][lane] = v;
+    emul::wave_barrier();
+    const uint32_t r = lane >= d ? emul::xchg[w][lane - d] : v;
+    emul::wave_barrier();
+    return r;
+}
 static inline uint32_t emul_alignbyte(uint32_t hi, uint32_t lo, uint32_t s)
 {
     return (uint32_t)((((uint64_t)hi << 32) | lo) >> (8 * (s & 3u)));
@@ -128,6 +148,7 @@ static inline uint32_t emul_brev(uint32_t x)
 #define __syncthreads emul_syncthreads
 #define __ballot emul_ballot
 #define __popcll __builtin_popcountll
+#define __popc __builtin_popcount
 #define __brev emul_brev
 #define __builtin_amdgcn_alignbyte emul_alignbyte
 #define __builtin_amdgcn_perm emul_perm

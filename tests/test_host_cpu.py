@@ -37,7 +37,7 @@ def test_device_abi_exports_every_declared_symbol():
     assert sorted(_lib.SYMBOLS) == names
     for n in names:
         assert getattr(lib, n) is not None
-    assert lib.gd_abi_version() == 14
+    assert lib.gd_abi_version() == 15
     assert lib.gd_strerror(-7) == b"records not coordinate sorted"
 
 

@@ -15,9 +15,8 @@ from goleft_amd.engine import DepthEngine, K_INFLATE
 
 length = sys.argv[1] if len(sys.argv) > 1 else "10000000"      # one contig length, or several separated by commas
 pads = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0]      # GD_OPT_INFLATE_LDS_PAD values to time
-# GD_OPT_INFLATE_PROBE values to time (measurement only: 1 = no match source is loaded from memory, 2 = no 64-byte block is
-# stored, 3 = both; the bytes are then wrong and the comparison is skipped) -- what the kernel's time is made of
-probes = [int(x) for x in os.environ.get("INFLATE_BENCH_PROBES", "0").split(",")]
+# GD_OPT_INFLATE_KERNEL values to time: 0 = a workgroup per member (the default), 1 = a lane per member (rounds 3-5)
+probes = [int(x) for x in os.environ.get("INFLATE_BENCH_KERNELS", "0,1").split(",")]
 path = "/tmp/gd_inflate_test.bam"
 subprocess.check_call([os.path.join(ROOT, "goleft_amd", "synth-bam"), path, "chr20", length, "30", "20"],
                       stdout=subprocess.DEVNULL)
@@ -43,7 +42,7 @@ with DepthEngine(0) as eng:
     eng.inflate_bgzf(data[:1 << 20] if False else data)          # warm-up (allocations, code load)
     for pad, probe in [(a, b) for a in pads for b in probes]:
         eng.set_option(16, pad)                                  # GD_OPT_INFLATE_LDS_PAD
-        eng.set_option(20, probe)                                # GD_OPT_INFLATE_PROBE
+        eng.set_option(20, probe)                                # GD_OPT_INFLATE_KERNEL
         best = None
         for _ in range(3):
             t0 = time.perf_counter()
@@ -52,8 +51,8 @@ with DepthEngine(0) as eng:
             ms = eng.kernel_ms(K_INFLATE)
             best = ms if best is None else min(best, ms)
         ms = best
-        print("lds pad %6d probe %d: members %d, %.1f MB -> %.1f MB; status ok %s; equal %s" % (pad, probe, len(status), len(data) / 1e6, len(got) / 1e6,
-                                                                                   bool((status == 0).all()), None if (want is None or probe) else got == want))
+        print("lds pad %6d kernel %d: members %d, %.1f MB -> %.1f MB; status ok %s; equal %s" % (pad, probe, len(status), len(data) / 1e6, len(got) / 1e6,
+                                                                                   bool((status == 0).all()), None if want is None else got == want))
         print("   kernel %.2f ms = %.2f GB/s of output (%.2f GB/s of BGZF); python zlib 1 thread %.2f s; call incl. H2D/D2H %.3f s"
               % (ms, len(got) / ms / 1e6, len(data) / ms / 1e6, t_cpu, t_all), flush=True)
         # a measurement build (-DGD_INFLATE_TIMING, loaded through GOLEFT_DEPTH_SO): where the waves' cycles went
