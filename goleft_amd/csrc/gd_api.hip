@@ -880,7 +880,7 @@ int gd_set_option(gd_ctx* c, int option, int64_t value)
         c->ing_walk_cus = value != 0;
         break;
     case GD_OPT_INFLATE_KERNEL:
-        if (value < 0 || value > 1) return fail(c, GD_E_INVALID, "inflate kernel: 0 (a workgroup per member) or 1 (a lane per member)");
+        if (value < 0 || value > 1) return fail(c, GD_E_INVALID, "inflate kernel: 0 (a lane per member) or 1 (a workgroup per member)");
         c->inflate_kernel = (int)value;
         break;
     case GD_OPT_INGEST_PIECE_STREAMS:

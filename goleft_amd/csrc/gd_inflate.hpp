@@ -825,18 +825,21 @@ constexpr bool INF_CRC_WAVE = true;                        // which of the two C
 
 namespace gd {
 
-constexpr int INF_WAVE_NW = 4;                             // waves per member of the workgroup-per-member kernel
+#ifndef GD_INF_WAVE_NW
+#define GD_INF_WAVE_NW 4
+#endif
+constexpr int INF_WAVE_NW = GD_INF_WAVE_NW;                             // waves per member of the workgroup-per-member kernel
 
 // The kernels of one inflate on one stream: a workgroup per member (gd_inflate_wave.hpp), the lane-per-member kernel for what
 // that one left (WV_FALLBACK), the CRC check.
-// kernel: 0 -- the default; 1 -- the lane-per-member kernel alone (rounds 3-5; GD_OPT_INFLATE_KERNEL, a measurement and a
-// second implementation for the tests to compare with).
+// kernel (GD_OPT_INFLATE_KERNEL): 0 -- the lane-per-member kernel alone, the default; 1 -- the workgroup-per-member kernel first
+// (round 6: a sixth of the memory traffic, but slower on an MI355X -- DESIGN.md 3.5), the lane-per-member kernel for what it left.
 // lds_pad: bytes of LDS a lane-per-member workgroup claims on top of its own 38 KB -- an occupancy limiter for measurements.
 inline void inflate_launch(const InflateJob& job_in, hipStream_t stream, unsigned lds_pad = 0, int kernel = 0)
 {
     InflateJob job = job_in;
     if (job.n == 0) return;
-    if (kernel == 0) {
+    if (kernel == 1) {
         hipLaunchKernelGGL(gd_inflate_wave_kernel<INF_WAVE_NW>, dim3(job.n), dim3(64 * INF_WAVE_NW), 0, stream, job);
         job.only_status = WV_FALLBACK;
     } else {

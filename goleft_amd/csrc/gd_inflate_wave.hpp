@@ -33,17 +33,17 @@ namespace gd {
 constexpr uint32_t WV_FALLBACK = 100u;                     // status: left to the lane-per-member kernel
 
 constexpr int WV_RL = 10, WV_RD = 8;                       // root bits of the lit/len and the distance table
-constexpr int WV_LSUB = 320, WV_DSUB = 160;                // second-level entries (checked when the tables are built)
+constexpr int WV_LSUB = 256, WV_DSUB = 160;                // second-level entries (checked when the tables are built)
 constexpr int WV_OUT = 0;                                  // [16 zero bytes][65536][16]: the member's output
 constexpr int WV_OUT_BYTES = 16 + 65536 + 16;
 constexpr int WV_LIT = WV_OUT + WV_OUT_BYTES;              // u16 [1024 + WV_LSUB]
 constexpr int WV_DIST = WV_LIT + 2 * ((1 << WV_RL) + WV_LSUB);   // u16 [256 + WV_DSUB]
 constexpr int WV_MISC = WV_DIST + 2 * ((1 << WV_RD) + WV_DSUB);  // u32 [32]
-constexpr int WV_LANE = WV_MISC + 128;                     // u32 start[NL], cross[NL], cnt[NL]
-constexpr int WV_X_BYTES = 8192 + 704 + 512;               // region X: scratch of header / tables / scan, then bitmap + stage; selectors
+constexpr int WV_LANE = WV_MISC + 128;                     // u32 cross[NL], cnt[NL]
+constexpr int WV_X_BYTES = 8192 + 512;                     // region X: scratch of header / tables / scan, then the bitmap; selectors
 template <int NW> struct WvLayout {
     static constexpr int NL = 64 * NW;
-    static constexpr int X = WV_LANE + 12 * NL;
+    static constexpr int X = WV_LANE + (8 * NL > 1408 ? 8 * NL : 1408);   // (pass B2 keeps 704 piece starts there)
     static constexpr int BYTES = X + WV_X_BYTES;
 };
 // region X before pass B1
@@ -60,8 +60,7 @@ constexpr int WX_DELTA = 2944;                             // i16 [2][16]: offs 
 constexpr int WX_SCAN = 3072;                              // u32 [2][NL]
 // region X from pass B1 on
 constexpr int WX_BITMAP = 0;                               // u32 [2048]: bit p = a piece starts at output byte p
-constexpr int WX_STAGE = 8192;                             // u16 [352]: piece starts of the 1 KB window being resolved (pieces are >= 3 bytes)
-constexpr int WX_PERM = 8192 + 704;                        // u32 [16][8]: byte-permute selectors of a chunk with period d (all blocks)
+constexpr int WX_PERM = 8192;                              // u32 [16][8]: byte-permute selectors of a chunk with period d (all blocks)
 enum : int { WM_FLAG0 = 0, WM_FLAG1, WM_TYPE, WM_FINAL, WM_NLEN, WM_NDIST, WM_HDREND, WM_ERR, WM_STORED, WM_EOB, WM_TOTAL, WM_ENDPOS, WM_FAIL };
 enum : uint32_t { WS_RUN = 0, WS_CROSSED = 1, WS_EOB = 2, WS_BAD = 3, WS_INACTIVE = 4 };
 
@@ -93,6 +92,29 @@ __device__ __forceinline__ uint32_t wv_load4(const uint8_t* p)
     uint32_t v;
     __builtin_memcpy(&v, p, 4);
     return v;
+}
+
+// Inclusive prefix sum over the 64 lanes of a wave.
+__device__ __forceinline__ uint32_t wv_wave_incl_scan(uint32_t v, int lane)
+{
+#ifdef GD_EMUL_HOST
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t up = WV_SHFL_UP(v, d);
+        if (lane >= d) v += up;
+    }
+    return v;
+#else
+    // row_shr within rows of 16 (bound_ctrl: zero comes in), then the row totals across rows through permlane-free broadcasts
+    (void)lane;
+    int x = (int)v;
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true);   // row_shr:1
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true);   // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true);   // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, true);   // row_shr:8
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, true);   // row_bcast:15 into rows 1 and 3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, true);   // row_bcast:31 into rows 2 and 3
+    return (uint32_t)x;
+#endif
 }
 
 // Canonical code: E[l - 1] = end of the codes of length <= l, left-aligned in 15 bits (non-decreasing, <= 32768).  The code of
@@ -169,7 +191,14 @@ template <int R> __device__ __forceinline__ WvSub<R> wv_sub_setup(const WvCanon&
 }
 
 // One run of a lane over its subsequence: symbols from bit `pos` until one starts at or behind `bound`, the block ends, or the
-// stream is invalid.  WRITE: literals to their place, matches as pieces (pass B1).
+// stream is invalid.
+// WRITE = false (pass A): the payload is read from LDS -- `in` points into the output area, which nothing else uses yet -- one
+// unaligned 8-byte read per symbol (>= 57 bits behind the position; a symbol takes 48 at most).
+// WRITE = true (pass B1): literals go to their place, matches are left as pieces; the output area is being written, so the
+// payload comes from memory: a two-word window in registers, the word behind it asked for at the top of EVERY iteration and
+// taken at its bottom -- a loaded value that crosses the loop's back edge is waited for where the compiler copies it, i.e. at
+// once (the lane-per-member kernel learnt that in round 3), and in lock step the wave pays the slowest lane's round trip in
+// every iteration; asked for again and again, the word comes from L1 while the symbol is decoded.
 struct WvRun { uint32_t pos, cnt, state; };
 
 template <bool WRITE>
@@ -184,99 +213,126 @@ __device__ __forceinline__ WvRun wv_run(const uint8_t* in, uint32_t start, uint3
     r.pos = start;
     r.cnt = 0;
     r.state = go ? WS_RUN : WS_INACTIVE;
-    // the lane's window on the payload: the 8-byte words qi, qi + 1 (q0, q1) and the next one, asked for a window ahead
     uint32_t qi = start >> 6;
-    uint64_t q0 = 0, q1 = 0, q2 = 0;
-    if (go) { q0 = wv_load8(in + 8u * qi); q1 = wv_load8(in + 8u * qi + 8u); q2 = wv_load8(in + 8u * qi + 16u); }
+    uint64_t q0 = 0, q1 = 0;
+    if (WRITE && go) { q0 = wv_load8(in + 8u * qi); q1 = wv_load8(in + 8u * qi + 8u); }
     for (;;) {
         const bool act = r.state == WS_RUN;
         if (__ballot(act) == 0) break;
+        uint64_t nx = 0;
+        if (WRITE && act) nx = wv_load8(in + 8u * qi + 16u);
+        // One symbol, every lane the same instructions: 32 bits at the position (w0: a lit/len code and its extra bits are
+        // 20 at most), the lit/len entry, 32 bits behind code + extra bits (w1: a distance code and its extra bits, 28 at
+        // most), the distance entry -- whether the symbol is a match or not; branches only where a second-level entry is
+        // needed (a ballot: rare) and, in pass B1, where bytes are written.
+        uint32_t c0, c1, c2 = 0, sh;
+        if (WRITE) {
+            const bool up = (r.pos & 32u) != 0u;
+            c0 = up ? (uint32_t)(q0 >> 32) : (uint32_t)q0;
+            c1 = up ? (uint32_t)q1 : (uint32_t)(q0 >> 32);
+            c2 = up ? (uint32_t)(q1 >> 32) : (uint32_t)q1;
+            sh = r.pos & 31u;
+        } else {
+            const uint64_t raw = act ? wv_load8(in + (r.pos >> 3)) : 0ull;
+            c0 = (uint32_t)raw;
+            c1 = (uint32_t)(raw >> 32);
+            sh = r.pos & 7u;
+        }
+        const uint32_t w0 = __builtin_amdgcn_alignbit(c1, c0, sh);
+        uint32_t e = lit[w0 & ((1u << WV_RL) - 1u)];
+        {
+            const bool two = act && (e & 0xf0u) == 0xf0u && (e & 15u) != 0u;
+            if (__ballot(two)) { if (two) e = lit[(1u << WV_RL) + ((e >> 8) << 1) + __builtin_amdgcn_ubfe(w0, WV_RL, e & 15u)]; }
+        }
+        const uint32_t nb = e & 15u, t = (e >> 5) & 7u;
+        const bool flag = (e & 16u) != 0u, ismatch = flag && t < 6u;
+        const uint32_t used = nb + t;                      // (a literal: t = 0)
+        const uint32_t mlen = 3u + (e >> 8) + __builtin_amdgcn_ubfe(w0, nb, t);
+        uint32_t w1;
+        if (WRITE) {
+            const uint32_t s2 = sh + used;                 // <= 51
+            w1 = s2 >= 32u ? __builtin_amdgcn_alignbit(c2, c1, s2) : __builtin_amdgcn_alignbit(c1, c0, s2);
+        } else {
+            w1 = __builtin_amdgcn_alignbit(c1, c0, sh + used);   // <= 27
+        }
+        uint32_t d = dis[w1 & ((1u << WV_RD) - 1u)];
+        {
+            const bool two = act && ismatch && (d & 16u) != 0u && (d & 15u) != 0u;
+            if (__ballot(two)) { if (two) d = dis[(1u << WV_RD) + (d >> 5) + __builtin_amdgcn_ubfe(w1, WV_RD, d & 15u)]; }
+        }
+        const uint32_t nd = d & 15u, ds = (d >> 5) & 31u;
+        const uint32_t de = ds < 4u ? 0u : (ds >> 1) - 1u;
+        const bool bad = flag && (t == 7u || (ismatch && (d & 16u) != 0u));
+        const bool eob = flag && t == 6u;
         if (act) {
-            if ((r.pos >> 6) != qi) { q0 = q1; q1 = q2; ++qi; q2 = wv_load8(in + 8u * qi + 16u); }
-            const uint32_t off = r.pos & 63u;
-            const uint64_t bits = (q0 >> off) | ((q1 << 1) << (63u - off));
-            uint32_t e = lit[(uint32_t)bits & ((1u << WV_RL) - 1u)];
-            if ((e & 0xf0u) == 0xf0u && (e & 15u)) e = lit[(1u << WV_RL) + ((e >> 8) << 1) + (((uint32_t)bits >> WV_RL) & ((1u << (e & 15u)) - 1u))];
-            const uint32_t nb = e & 15u;
-            if (!(e & 16u)) {                              // a literal
-                if (WRITE) out[o] = (uint8_t)(e >> 8);
-                ++o;
-                ++r.cnt;
-                r.pos += nb;
-            } else {
-                const uint32_t t = (e >> 5) & 7u;
-                if (t == 6u) {
-                    r.pos += nb;
-                    r.state = WS_EOB;
-                } else if (t == 7u) {
-                    r.state = WS_BAD;
-                } else {
-                    const uint32_t mlen = 3u + (e >> 8) + (((uint32_t)(bits >> nb)) & ((1u << t) - 1u));
-                    const uint32_t used = nb + t;          // <= 20
-                    const uint64_t db = bits >> used;
-                    uint32_t d = dis[(uint32_t)db & ((1u << WV_RD) - 1u)];
-                    if ((d & 16u) && (d & 15u)) d = dis[(1u << WV_RD) + (d >> 5) + (((uint32_t)db >> WV_RD) & ((1u << (d & 15u)) - 1u))];
-                    if (d & 16u) {
-                        r.state = WS_BAD;
-                    } else {
-                        const uint32_t nd = d & 15u, ds = (d >> 5) & 31u;
-                        const uint32_t de = ds < 4u ? 0u : (ds >> 1) - 1u;
-                        const uint32_t mdist = ds < 4u ? 1u + ds : 1u + ((2u + (ds & 1u)) << de) + ((uint32_t)(db >> nd) & ((1u << de) - 1u));
-                        r.pos += used + nd + de;
-                        r.cnt += mlen;
-                        if (WRITE) {
-                            if (mdist > o) { fail = 1u; r.state = WS_BAD; }
-                            else {
-                                // pieces of <= 16 bytes, each a 3-byte token in its own first bytes: bit 0 = periodic;
-                                // bits 1-4 length - 1; plain: bits 5-19 distance - 1 (>= 16); periodic (distance p < 16): bits 5-8 p,
-                                // bits 9-16 c = how far behind the ANCHOR the piece starts -- the anchor is the start of the match
-                                // (the piece is the pattern in front of the anchor repeated from phase 0: c is a multiple of p), or
-                                // the piece itself (c = 0) for a tail that cannot start at phase 0
-                                uint32_t rem = mlen, p = o;
-                                if (mdist >= 16u) {
-                                    while (rem) {
-                                        const uint32_t n = rem > 16u ? (rem - 16u < 3u ? 13u : 16u) : rem;
-                                        const uint32_t tok = ((n - 1u) << 1) | ((mdist - 1u) << 5);
-                                        out[p] = (uint8_t)tok; out[p + 1u] = (uint8_t)(tok >> 8); out[p + 2u] = (uint8_t)(tok >> 16);
-                                        WV_LDS_OR(&bitmap[p >> 5], 1u << (p & 31u));
-                                        p += n; rem -= n;
-                                    }
-                                } else {
-                                    // whole periods in 16 bytes: mdist * (16 / mdist)
-                                    const uint32_t lp = mdist >= 9u ? mdist : (uint32_t)((0xFDBEFEFF0ull >> (4u * mdist)) & 15ull) + 1u;
-                                    uint32_t c = 0;
-                                    bool offphase = false;
-                                    while (rem) {
-                                        uint32_t n = rem < lp ? rem : lp;
-                                        const uint32_t cc = offphase ? 0u : c;     // (a tail that does not start at phase 0: its own anchor)
-                                        const uint32_t left = rem - n;
-                                        if (left == 1u || left == 2u) {
-                                            if (rem <= 16u) n = rem;           // the tail joins this piece
-                                            else { n -= 3u - left; offphase = true; }   // ... or this piece leaves it three bytes
-                                        }
-                                        const uint32_t tok = 1u | ((n - 1u) << 1) | (mdist << 5) | (cc << 9);
-                                        out[p] = (uint8_t)tok; out[p + 1u] = (uint8_t)(tok >> 8); out[p + 2u] = (uint8_t)(tok >> 16);
-                                        WV_LDS_OR(&bitmap[p >> 5], 1u << (p & 31u));
-                                        p += n; rem -= n; c += n;
-                                    }
+            if (WRITE) {
+                if (!flag) out[o] = (uint8_t)(e >> 8);
+                else if (ismatch && !bad) {
+                    const uint32_t mdist = ds < 4u ? 1u + ds : 1u + ((2u + (ds & 1u)) << de) + __builtin_amdgcn_ubfe(w1, nd, de);
+                    if (mdist > o) { fail = 1u; }
+                    else {
+                        // pieces of <= 16 bytes, each a 3-byte token in its own first bytes: bit 0 = periodic;
+                        // bits 1-4 length - 1; plain: bits 5-19 distance - 1 (>= 16); periodic (distance p < 16): bits 5-8 p,
+                        // bits 9-16 c = how far behind the ANCHOR the piece starts -- the anchor is the start of the match
+                        // (the piece is the pattern in front of the anchor repeated from phase 0: c is a multiple of p), or
+                        // the piece itself (c = 0) for a tail that cannot start at phase 0
+                        uint32_t rem = mlen, p = o;
+                        if (mdist >= 16u) {
+                            while (rem) {
+                                const uint32_t n = rem > 16u ? (rem - 16u < 3u ? 13u : 16u) : rem;
+                                const uint32_t tok = ((n - 1u) << 1) | ((mdist - 1u) << 5);
+                                out[p] = (uint8_t)tok; out[p + 1u] = (uint8_t)(tok >> 8); out[p + 2u] = (uint8_t)(tok >> 16);
+                                WV_LDS_OR(&bitmap[p >> 5], 1u << (p & 31u));
+                                p += n; rem -= n;
+                            }
+                        } else {
+                            // whole periods in 16 bytes: mdist * (16 / mdist)
+                            const uint32_t lp = mdist >= 9u ? mdist : (uint32_t)((0xFDBEFEFF0ull >> (4u * mdist)) & 15ull) + 1u;
+                            uint32_t c = 0;
+                            bool offphase = false;
+                            while (rem) {
+                                uint32_t n = rem < lp ? rem : lp;
+                                const uint32_t cc = offphase ? 0u : c;     // (a tail that does not start at phase 0: its own anchor)
+                                const uint32_t left = rem - n;
+                                if (left == 1u || left == 2u) {
+                                    if (rem <= 16u) n = rem;           // the tail joins this piece
+                                    else { n -= 3u - left; offphase = true; }   // ... or this piece leaves it three bytes
                                 }
+                                const uint32_t tok = 1u | ((n - 1u) << 1) | (mdist << 5) | (cc << 9);
+                                out[p] = (uint8_t)tok; out[p + 1u] = (uint8_t)(tok >> 8); out[p + 2u] = (uint8_t)(tok >> 16);
+                                WV_LDS_OR(&bitmap[p >> 5], 1u << (p & 31u));
+                                p += n; rem -= n; c += n;
                             }
                         }
-                        o += mlen;
                     }
                 }
             }
-            if (r.state == WS_RUN) {
-                if (r.pos > endbits || r.cnt > 65536u) r.state = WS_BAD;
-                else if (r.pos >= bound) r.state = WS_CROSSED;
-            } else if (r.state == WS_EOB && r.pos > endbits) r.state = WS_BAD;
+            const uint32_t inc = ismatch ? mlen : (flag ? 0u : 1u);
+            r.pos += ismatch ? used + nd + de : nb;
+            r.cnt += inc;
+            o += inc;
+            r.state = bad ? WS_BAD : eob ? (r.pos > endbits ? WS_BAD : WS_EOB) : (r.pos > endbits || r.cnt > 65536u) ? WS_BAD : r.pos >= bound ? WS_CROSSED : WS_RUN;
+            if (WRITE && fail) r.state = WS_BAD;
+        }
+        if (WRITE) {
+#ifndef GD_EMUL_HOST
+            __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0): the word asked for at the top (gfx9 encoding; lgkmcnt untouched)
+#endif
+            if (act && (r.pos >> 6) != qi) { q0 = q1; q1 = nx; ++qi; }
         }
     }
     return r;
 }
 
+// MEASUREMENT BUILDS ONLY (-DGD_INFLATE_TIMING): the cycles a workgroup spends in each phase, summed into g_inflate_sections[8..15]
+#ifdef GD_INFLATE_TIMING
+#define WV_T(k) do { const uint64_t t_ = __builtin_readcyclecounter(); wsum[k] += t_ - wlast; wlast = t_; } while (0)
+#else
+#define WV_T(k)
+#endif
+
 template <int NW>
-__global__ __launch_bounds__(64 * NW, 2) void gd_inflate_wave_kernel(InflateJob job)
+__global__ __launch_bounds__(64 * NW, (NW + 1) / 2) void gd_inflate_wave_kernel(InflateJob job)
 {
     constexpr int NL = 64 * NW;
     constexpr int XO = WvLayout<NW>::X;
@@ -287,8 +343,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gd_inflate_wave_kernel(InflateJob 
     const uint32_t ilen = job.in_len[m], olen = job.out_len[m], endbits = ilen * 8u;
     uint8_t* const out = sm + WV_OUT + 16;
     uint32_t* const misc = reinterpret_cast<uint32_t*>(sm + WV_MISC);
-    uint32_t* const l_start = reinterpret_cast<uint32_t*>(sm + WV_LANE);
-    uint32_t* const l_cross = l_start + NL;
+    uint32_t* const l_cross = reinterpret_cast<uint32_t*>(sm + WV_LANE);
     uint32_t* const l_cnt = l_cross + NL;                  // bytes produced | state << 24
     uint8_t* const X = sm + XO;
     uint16_t* const lit = reinterpret_cast<uint16_t*>(sm + WV_LIT);
@@ -308,12 +363,19 @@ __global__ __launch_bounds__(64 * NW, 2) void gd_inflate_wave_kernel(InflateJob 
         }
         reinterpret_cast<uint32_t*>(X + WX_PERM)[i] = w;
     }
+#ifdef GD_INFLATE_TIMING
+    uint64_t wsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, wlast = __builtin_readcyclecounter();
+#endif
     uint32_t bitpos = 0, opos = 0;
     bool fallback = olen > 65536u || ilen > (1u << 20);
     bool done = false;
     __syncthreads();
 
+    uint32_t nblocks = 0;
     while (!fallback && !done) {
+        // (a member of very many blocks -- tens of thousands of empty ones are valid -- pays this kernel's per-block set-up every
+        // time: the other kernel's)
+        if (++nblocks > 48u) { fallback = true; break; }
         // ================= the block header =================
         const uint32_t hb = bitpos >> 3;
         for (int i = tid; i < 1088 / 4; i += NL) {
@@ -456,6 +518,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gd_inflate_wave_kernel(InflateJob 
             }
         }
         __syncthreads();
+        WV_T(0);
         const uint32_t type = misc[WM_TYPE], fin = misc[WM_FINAL], nlen = misc[WM_NLEN];
         bitpos = misc[WM_HDREND];
         if (misc[WM_ERR] != 0u || bitpos > endbits) { fallback = true; break; }
@@ -591,6 +654,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gd_inflate_wave_kernel(InflateJob 
         }
         (void)nlen;
         __syncthreads();
+        WV_T(1);
 
         // ================= pass A: where every lane's subsequence really starts, and what it produces =================
         const uint32_t body = bitpos;
@@ -599,9 +663,21 @@ __global__ __launch_bounds__(64 * NW, 2) void gd_inflate_wave_kernel(InflateJob 
         const uint32_t b0 = body + (uint32_t)tid * S, bound = b0 + S;
         uint32_t nofail = 0;
         uint32_t mystart = b0;
+        // the rest of the payload (and 16 bytes behind it: a run reads 8 bytes at a position up to 48 bits past the end) goes
+        // into the part of the output area that is still free -- behind what the blocks before produced, which pass B2 will
+        // read; it fits whenever what is left of the payload is not longer than what it still has to produce
+        const uint32_t sfrom = body >> 3, sbytes = ilen + 16u - sfrom, sat = (opos + 15u) & ~15u;
+        if (sat + sbytes > 65536u + 16u) { fallback = true; break; }
+        for (uint32_t i = (uint32_t)tid * 16u; i < sbytes; i += 16u * NL) {
+            inf_v4 v;
+            __builtin_memcpy(&v, in + sfrom + i, 16);
+            __builtin_memcpy(out + sat + i, &v, 16);
+        }
+        const uint8_t* const lin = out + sat - sfrom;      // payload byte k at lin[k]
+        __syncthreads();
         {
-            const WvRun r = wv_run<false>(in, b0, bound, endbits, b0 < endbits, sm, XO, 0, nofail);
-            l_start[tid] = b0; l_cross[tid] = r.pos; l_cnt[tid] = r.cnt | (r.state << 24);
+            const WvRun r = wv_run<false>(lin, b0, bound, endbits, b0 < endbits, sm, XO, 0, nofail);
+            l_cross[tid] = r.pos; l_cnt[tid] = r.cnt | (r.state << 24);
         }
         __syncthreads();
         for (uint32_t it = 0;; ++it) {
@@ -618,11 +694,12 @@ __global__ __launch_bounds__(64 * NW, 2) void gd_inflate_wave_kernel(InflateJob 
             if (!any) break;
             if (it > (uint32_t)NL + 2u) { fallback = true; break; }   // (cannot happen: a pass fixes at least one lane for good)
             // every lane takes part (the run loop ballots); lanes with nothing to redo are done at once
-            const WvRun r = wv_run<false>(in, from, bound, endbits, redo, sm, XO, 0, nofail);
-            if (redo) { mystart = from; l_start[tid] = from; l_cross[tid] = r.pos; l_cnt[tid] = r.cnt | (r.state << 24); }
+            const WvRun r = wv_run<false>(lin, from, bound, endbits, redo, sm, XO, 0, nofail);
+            if (redo) { mystart = from; l_cross[tid] = r.pos; l_cnt[tid] = r.cnt | (r.state << 24); }
             __syncthreads();
         }
         if (fallback) break;
+        WV_T(2);
         // ================= the lanes' output offsets: an exclusive scan =================
         // a lane counts when every lane in front of it crossed into its successor; value: bytes | (blocks what follows) << 31
         {
@@ -656,33 +733,31 @@ __global__ __launch_bounds__(64 * NW, 2) void gd_inflate_wave_kernel(InflateJob 
             // ================= pass B1: literals to their place, matches as pieces =================
             for (int i = tid; i < 2048 / 4; i += NL) reinterpret_cast<inf_v4*>(X + WX_BITMAP)[i] = inf_v4{0, 0, 0, 0};
             __syncthreads();
+            WV_T(3);
             uint32_t fail = 0;
             const bool go = valid && (st == WS_CROSSED || st == WS_EOB);
             const WvRun r = wv_run<true>(in, mystart, bound, endbits, go, sm, XO, opos + excl, fail);
             if (fail || (go && (r.cnt != (mine & 0xffffffu) || r.state != st))) misc[WM_FAIL] = 1u;
             __syncthreads();
             if (misc[WM_FAIL]) { fallback = true; break; }
+            WV_T(4);
             // ================= pass B2: the pieces in output order =================
+            // (the lanes' arrays are free until the next block's pass A: they hold the piece starts of the window being resolved)
             if (wave == 0) {
                 const uint32_t* const bitmap = reinterpret_cast<const uint32_t*>(X + WX_BITMAP);
-                uint16_t* const stage = reinterpret_cast<uint16_t*>(X + WX_STAGE);
+                uint16_t* const stage = reinterpret_cast<uint16_t*>(sm + WV_LANE);   // [704]: pieces are >= 3 bytes, a window is 2 KB
                 const uint32_t w_lo = opos >> 5, w_hi = (opos + total + 31u) >> 5;
                 uint32_t carry_end = 0;                    // end of the last piece of the batch before
-                for (uint32_t w0 = w_lo; w0 < w_hi; w0 += 32u) {
-                    uint32_t word = lane < 32 && w0 + (uint32_t)lane < w_hi ? bitmap[w0 + (uint32_t)lane] : 0u;
+                for (uint32_t w0 = w_lo; w0 < w_hi; w0 += 64u) {
+                    uint32_t word = w0 + (uint32_t)lane < w_hi ? bitmap[w0 + (uint32_t)lane] : 0u;
                     const uint32_t c = (uint32_t)__popc(word);
-                    uint32_t incl2 = c;
-#pragma unroll
-                    for (int d = 1; d < 64; d <<= 1) {
-                        const uint32_t up = WV_SHFL_UP(incl2, d);
-                        if (lane >= d) incl2 += up;
-                    }
+                    const uint32_t incl2 = wv_wave_incl_scan(c, lane);
                     const uint32_t npc = WV_READLANE(incl2, 63);
                     uint32_t at = incl2 - c;
                     while (__ballot(word != 0u)) {
                         if (word) {
-                            const uint32_t b = (uint32_t)__builtin_ctz(word);
-                            stage[at++] = (uint16_t)(((w0 + (uint32_t)lane) << 5) + b);
+                            const uint32_t bq = (uint32_t)__builtin_ctz(word);
+                            stage[at++] = (uint16_t)(((w0 + (uint32_t)lane) << 5) + bq);
                             word &= word - 1u;
                         }
                     }
@@ -699,39 +774,47 @@ __global__ __launch_bounds__(64 * NW, 2) void gd_inflate_wave_kernel(InflateJob 
                         const uint32_t endv = dst + n;
                         uint32_t prev_end = WV_SHFL_UP(endv, 1);
                         if (lane == 0) prev_end = carry_end;
-                        const bool gap = s_lo >= prev_end;  // the source lies in the literals right behind the previous piece
+                        // the selectors of a periodic piece, once per batch
+                        inf_v4 sel0 = {0, 0, 0, 0}, sel1 = {0, 0, 0, 0};
+                        if (__ballot(per)) {
+                            if (per) {
+                                sel0 = *reinterpret_cast<const inf_v4*>(X + WX_PERM + p * 32u);
+                                sel1 = *reinterpret_cast<const inf_v4*>(X + WX_PERM + p * 32u + 16u);
+                            }
+                        }
+                        // ready at once: the source lies in the literals right behind the previous piece; ready when
+                        // everything below the first unresolved piece of the batch is resolved and the source ends there
+                        bool open_ = act;
+                        const bool gap = s_lo >= prev_end;
                         uint64_t U = __ballot(act);
                         while (U) {
                             const uint32_t first = (uint32_t)__builtin_ctzll(U);
                             const uint32_t F = WV_READLANE(dst, first);
-                            const bool ready = ((U >> lane) & 1ull) && (s_hi <= F || (uint32_t)lane == first || gap);
+                            const bool ready = open_ && (s_hi <= F || gap || (uint32_t)lane == first);
                             if (ready) {
                                 inf_v4 v;
                                 __builtin_memcpy(&v, out + (int)src, 16);
                                 if (per) {
                                     // the last p bytes of v, repeated from phase 0
-                                    const inf_v4 s0 = *reinterpret_cast<const inf_v4*>(X + WX_PERM + p * 32u);
-                                    const inf_v4 s1 = *reinterpret_cast<const inf_v4*>(X + WX_PERM + p * 32u + 16u);
                                     inf_v4 q;
-                                    q.x = __builtin_amdgcn_perm(v.y, v.x, s0.x) | __builtin_amdgcn_perm(v.w, v.z, s1.x);
-                                    q.y = __builtin_amdgcn_perm(v.y, v.x, s0.y) | __builtin_amdgcn_perm(v.w, v.z, s1.y);
-                                    q.z = __builtin_amdgcn_perm(v.y, v.x, s0.z) | __builtin_amdgcn_perm(v.w, v.z, s1.z);
-                                    q.w = __builtin_amdgcn_perm(v.y, v.x, s0.w) | __builtin_amdgcn_perm(v.w, v.z, s1.w);
+                                    q.x = __builtin_amdgcn_perm(v.y, v.x, sel0.x) | __builtin_amdgcn_perm(v.w, v.z, sel1.x);
+                                    q.y = __builtin_amdgcn_perm(v.y, v.x, sel0.y) | __builtin_amdgcn_perm(v.w, v.z, sel1.y);
+                                    q.z = __builtin_amdgcn_perm(v.y, v.x, sel0.z) | __builtin_amdgcn_perm(v.w, v.z, sel1.z);
+                                    q.w = __builtin_amdgcn_perm(v.y, v.x, sel0.w) | __builtin_amdgcn_perm(v.w, v.z, sel1.w);
                                     v = q;
                                 }
                                 uint8_t* d8 = out + dst;
-                                uint32_t w[4] = {v.x, v.y, v.z, v.w};
-                                if (n == 16u) __builtin_memcpy(d8, w, 16);
+                                if (n == 16u) __builtin_memcpy(d8, &v, 16);
                                 else {
-                                    uint32_t k = 0;
-                                    if (n & 8u) { __builtin_memcpy(d8, w, 8); k = 2; d8 += 8; }
-                                    if (n & 4u) { __builtin_memcpy(d8, &w[k], 4); ++k; d8 += 4; }
-                                    uint32_t last = w[k];
-                                    if (n & 2u) { const uint16_t h = (uint16_t)last; __builtin_memcpy(d8, &h, 2); last >>= 16; d8 += 2; }
-                                    if (n & 1u) *d8 = (uint8_t)last;
+                                    uint32_t a0 = v.x, a1 = v.y;
+                                    if (n & 8u) { const uint64_t lo = (uint64_t)a0 | ((uint64_t)a1 << 32); __builtin_memcpy(d8, &lo, 8); a0 = v.z; a1 = v.w; d8 += 8; }
+                                    if (n & 4u) { __builtin_memcpy(d8, &a0, 4); a0 = a1; d8 += 4; }
+                                    if (n & 2u) { const uint16_t h = (uint16_t)a0; __builtin_memcpy(d8, &h, 2); a0 >>= 16; d8 += 2; }
+                                    if (n & 1u) *d8 = (uint8_t)a0;
                                 }
+                                open_ = false;
                             }
-                            U &= ~__ballot(ready);
+                            U = __ballot(open_);
                             WV_WAVE_SYNC();
                         }
                         carry_end = WV_READLANE(endv, (npc - s0 < 64u ? npc - s0 : 64u) - 1u);
@@ -739,6 +822,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gd_inflate_wave_kernel(InflateJob 
                 }
             }
             __syncthreads();
+            WV_T(5);
             opos += total;
             bitpos = misc[WM_ENDPOS];
             if (fin) done = true;
@@ -761,6 +845,13 @@ __global__ __launch_bounds__(64 * NW, 2) void gd_inflate_wave_kernel(InflateJob 
         if (tail0 + (uint32_t)tid < olen && tid < 16) g[tail0 + tid] = out[tail0 + tid];
     }
     if (tid == 0) job.status[m] = fallback ? WV_FALLBACK : 0u;
+#ifdef GD_INFLATE_TIMING
+    WV_T(6);
+    if (tid == 0) {
+        for (int k = 0; k < 7; ++k) atomicAdd(&::g_inflate_sections[8 + k], (unsigned long long)wsum[k]);
+        atomicAdd(&::g_inflate_sections[15], 1ull);
+    }
+#endif
 }
 
 }  // namespace gd

@@ -221,11 +221,12 @@ enum { /* (1, 2: tile shapes other than 4096 positions x 256 threads -- measured
        GD_OPT_INGEST_WALK_CUS = 22,   /* with GD_OPT_INGEST_CU_SPLIT: 1: the record walks of a decode run on the copy kernel's CUs (a
                                        CU-masked stream of their own) instead of beside the inflate workgroups, whose LDS leaves a
                                        walk one workgroup per CU; 0 (default) */
-       GD_OPT_INFLATE_KERNEL = 20,    /* which kernel inflates BGZF members: 0 (default) a workgroup per member with the member's output
-                                       in LDS (gd_inflate_wave.hpp; members it does not take go to the other kernel on the same stream);
-                                       1: a lane per member (gd_inflate.hpp, rounds 3-5).  Both produce zlib's bytes; the second one is
-                                       kept as the fallback, as a yardstick and as a second implementation for the tests.  (ABI 14 had a
-                                       measurement switch with this number that produced wrong bytes: gone) */
+       GD_OPT_INFLATE_KERNEL = 20,    /* which kernel inflates BGZF members: 0 (default) a lane per member (gd_inflate.hpp); 1: a workgroup
+                                       per member with the member's output in LDS (gd_inflate_wave.hpp, round 6; members it does not take
+                                       go to the other kernel on the same stream).  Both produce zlib's bytes.  The second one moves a
+                                       sixth of the bytes through memory and is the slower of the two on an MI355X (DESIGN.md 3.5 has the
+                                       measurements and why); it is kept as a second implementation the tests compare the first with.
+                                       (ABI 14 had a measurement switch with this number that produced wrong bytes: gone) */
        GD_OPT_H2D_KERNEL = 8 };     /* how a committed staging block reaches HBM: 1 (default) one kernel whose workgroups
                                        read the page-locked block over the link (all five arrays in one launch; n > 1:
                                        with n workgroups), 0: five hipMemcpyAsync through a DMA engine */

@@ -20,7 +20,7 @@ namespace emul {
 // wave are in step on the machine, the waves of a workgroup are not: a kernel whose waves run different loops -- the
 // decoder / writer pair of the round-5 experiment, commits 886121a and fdd3ff3 in the history -- ballots per wave).
 struct Lane { ucontext_t ctx; std::vector<char> stack; bool done = false; const unsigned* wait_ctr = nullptr; unsigned wait_val = 0, ballots = 0; };
-constexpr unsigned MAX_WAVES = 4, WAVE = 64;
+constexpr unsigned MAX_WAVES = 8, WAVE = 64;
 static std::vector<Lane> lanes;
 static ucontext_t sched_ctx;
 static unsigned cur = 0, bar_gen = 0, wbar_gen[MAX_WAVES];
@@ -56,7 +56,7 @@ static void run(void (*body)(), unsigned n, unsigned block)
         makecontext(&l.ctx, trampoline, 0);
     }
     for (;;) {
-        unsigned alive = 0, at_bar = 0, w_alive[MAX_WAVES] = {0, 0, 0, 0}, w_at[MAX_WAVES] = {0, 0, 0, 0};
+        unsigned alive = 0, at_bar = 0, w_alive[MAX_WAVES] = {}, w_at[MAX_WAVES] = {};
         for (unsigned t = 0; t < n; ++t) {
             const Lane& l = lanes[t];
             if (l.done) continue;
@@ -152,6 +152,8 @@ static inline uint32_t emul_brev(uint32_t x)
 #define __brev emul_brev
 #define __builtin_amdgcn_alignbyte emul_alignbyte
 #define __builtin_amdgcn_perm emul_perm
+#define __builtin_amdgcn_alignbit(hi, lo, s) ((uint32_t)((((uint64_t)(hi) << 32) | (uint32_t)(lo)) >> ((s) & 31u)))
+#define __builtin_amdgcn_ubfe(v, off, w) (((w) & 31u) == 0u ? 0u : (((uint32_t)(v) >> ((off) & 31u)) & ((1u << ((w) & 31u)) - 1u)))
 #define __builtin_amdgcn_s_waitcnt(x) ((void)0)
 #define GD_EMUL_HOST 1
 typedef int hipStream_t;

@@ -14,7 +14,7 @@
 static const gd::InflateJob* g_job = nullptr;
 static void body_inflate() { gd::gd_inflate_kernel(*g_job); }
 static void body_inflate_wave() { gd::gd_inflate_wave_kernel<gd::INF_WAVE_NW>(*g_job); }
-static int g_kernel = 0;                                   // 0: as gd::inflate_launch does by default; 1: the lane-per-member kernel alone
+static int g_kernel = 0;                                   // GD_OPT_INFLATE_KERNEL: 0 the lane-per-member kernel alone; 1 the workgroup-per-member kernel first
 static uint32_t g_fallbacks = 0;
 extern "C" void emul_inflate_kernel(int k) { g_kernel = k; }
 extern "C" uint32_t emul_inflate_fallbacks() { return g_fallbacks; }   // members the last launch left to the lane-per-member kernel
@@ -49,7 +49,7 @@ extern "C" int emul_inflate(const uint8_t* comp, const uint64_t* in_off, const u
     job.crc = crc; job.out = out; job.status = status; job.n = n;
     g_job = &job;
     g_fallbacks = 0;
-    if (g_kernel == 0) {
+    if (g_kernel == 1) {
         for (unsigned b = 0; b < n; ++b) emul::run(body_inflate_wave, 64u * gd::INF_WAVE_NW, b);
         for (uint32_t i = 0; i < n; ++i) g_fallbacks += status[i] == gd::WV_FALLBACK;
         job.only_status = gd::WV_FALLBACK;

@@ -13,21 +13,29 @@ from tests import helpers as H
 
 pytestmark = pytest.mark.gpu
 
+OPT_INFLATE_KERNEL = 20
+# GD_OPT_INFLATE_KERNEL: 0 a lane per member (the default), 1 a workgroup per member first (gd_inflate_wave.hpp) -- every inflate
+# test runs on either and must see zlib's bytes and the same status words
+KERNELS = pytest.mark.parametrize("kernel", [0, 1], ids=["lane-per-member", "workgroup-per-member"])
 
+
+@KERNELS
 @pytest.mark.parametrize("level", [0, 1, 6, 9])
-def test_inflate_equals_zlib(tmp_path, level):
+def test_inflate_equals_zlib(tmp_path, level, kernel):
     from goleft_amd.engine import DepthEngine
     contigs, reads, _ = H.load_golden_bam("t")
     p = str(tmp_path / "a.bam")
     bamio.write_bam(p, contigs, reads, unplaced=2, level=level)      # level 0: stored blocks; the EOF member: a fixed block
     data = open(p, "rb").read()
     with DepthEngine(0) as eng:
+        eng.set_option(OPT_INFLATE_KERNEL, kernel)
         got, status = eng.inflate_bgzf(data)
     assert (status == 0).all()
     assert got == bamio.bgzf_decompress(data)
 
 
-def test_inflate_varied_payloads():
+@KERNELS
+def test_inflate_varied_payloads(kernel):
     from goleft_amd.engine import DepthEngine
     rng = np.random.default_rng(5)
     parts = [b"", b"A", b"ACGT" * 5000, rng.integers(0, 256, 60000, dtype=np.uint8).tobytes(),
@@ -35,12 +43,14 @@ def test_inflate_varied_payloads():
     for level in (1, 9):
         data = b"".join(bamio.bgzf_compress(x, level=level) for x in parts)
         with DepthEngine(0) as eng:
+            eng.set_option(OPT_INFLATE_KERNEL, kernel)
             got, status = eng.inflate_bgzf(data)
         assert (status == 0).all()
         assert got == b"".join(parts)
 
 
-def test_inflate_crc_at_slice_boundaries():
+@KERNELS
+def test_inflate_crc_at_slice_boundaries(kernel):
     """The CRC kernel gives a wave to each member and cuts it into 1 KB slices aligned to the member's end: lengths around
     every boundary, each once with its own trailer (status 0) and once with one bit of the trailer's CRC flipped (18)."""
     from goleft_amd.engine import DepthEngine
@@ -60,6 +70,7 @@ def test_inflate_crc_at_slice_boundaries():
         b[len(b) - 8 + (i % 4)] ^= 1 << (i % 8)                                                    # the trailer's CRC32
         damaged.append(bytes(b))
     with DepthEngine(0) as eng:
+        eng.set_option(OPT_INFLATE_KERNEL, kernel)
         got, status = eng.inflate_bgzf(b"".join(members))
         assert (status == 0).all() and got == b"".join(parts)
         got, status = eng.inflate_bgzf(b"".join(damaged))
@@ -69,8 +80,9 @@ def test_inflate_crc_at_slice_boundaries():
         assert [int(v) for v in status] == [18 if i % 2 else 0 for i in range(len(sizes))] and got == b"".join(parts)
 
 
+@KERNELS
 @pytest.mark.parametrize("seed", range(4))
-def test_inflate_random_streams(seed):
+def test_inflate_random_streams(seed, kernel):
     # many members of random size / entropy / compression level and strategy in one call,
     # incl. Z_FIXED (fixed Huffman blocks), Z_RLE and Z_HUFFMAN_ONLY streams
     from goleft_amd.engine import DepthEngine
@@ -103,17 +115,20 @@ def test_inflate_random_streams(seed):
                      + struct.pack("<II", zlib.crc32(x) & 0xFFFFFFFF, len(x)))
         parts.append(x)
     with DepthEngine(0) as eng:
+        eng.set_option(OPT_INFLATE_KERNEL, kernel)
         got, status = eng.inflate_bgzf(b"".join(blobs))
     assert (status == 0).all()
     assert got == b"".join(parts)
 
 
-def test_inflate_reports_corrupt_members():
+@KERNELS
+def test_inflate_reports_corrupt_members(kernel):
     from goleft_amd.engine import DepthEngine
     good = bamio.bgzf_compress(b"hello world, " * 1000, level=6)
     bad = bytearray(good)
     bad[40] ^= 0x55                                        # inside the deflate payload of the first member
     with DepthEngine(0) as eng:
+        eng.set_option(OPT_INFLATE_KERNEL, kernel)
         got, status = eng.inflate_bgzf(bytes(bad))
         assert status[0] != 0                              # a broken stream or, if it still decodes, its CRC32
         # a payload that inflates cleanly but to other bytes: only the CRC can tell
@@ -137,13 +152,15 @@ def ingest_contig(eng, path, tid):
     return eng.ingest_bgzf(tid, data, 0, anchors)
 
 
+@KERNELS
 @pytest.mark.parametrize("name", ["t", "hla"])
-def test_ingest_fixture_bam(tmp_path, name):
+def test_ingest_fixture_bam(tmp_path, name, kernel):
     from goleft_amd.engine import DepthEngine
     contigs, reads, _ = H.load_golden_bam(name)
     p = str(tmp_path / "a.bam")
     bamio.write_bam(p, contigs, reads, unplaced=3, index=True)
     with DepthEngine(0) as eng:
+        eng.set_option(OPT_INFLATE_KERNEL, kernel)
         eng.set_params(window_size=100, min_mapq=1, min_cov=4)
         eng.set_contigs([c[1] for c in contigs])
         n = {tid: ingest_contig(eng, p, tid) for tid in range(len(contigs))}
@@ -518,7 +535,8 @@ def test_ingest_a_reference_in_parts(tmp_path):
         assert np.array_equal(eng.perbase(0), want)
 
 
-def test_inflate_a_member_of_fifty_thousand_empty_blocks():
+@KERNELS
+def test_inflate_a_member_of_fifty_thousand_empty_blocks(kernel):
     """a VALID member may consist of tens of thousands of empty blocks (10 bits each with the fixed
     code), each of which waits up to 32 iterations of the symbol loop for the other lanes' headers -- more iterations
     than the loop's former backstop of 2^20 allowed, which refused the member (err 19) although zlib inflates it."""
@@ -542,6 +560,7 @@ def test_inflate_a_member_of_fifty_thousand_empty_blocks():
               struct.pack("<II", zlib.crc32(payload) & 0xffffffff, len(payload)))
     data = member + bamio.bgzf_compress(b"ACGT" * 1000)      # (another member in the same wave, and the EOF marker)
     with DepthEngine(0) as eng:
+        eng.set_option(OPT_INFLATE_KERNEL, kernel)
         got, status = eng.inflate_bgzf(data)
     assert (status == 0).all(), status
     assert got == payload + b"ACGT" * 1000

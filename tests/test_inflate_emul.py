@@ -36,6 +36,27 @@ def _lib():
     return lib
 
 
+# GD_OPT_INFLATE_KERNEL under the emulation: 0 the lane-per-member kernel alone (the product's default), 1 the
+# workgroup-per-member kernel (gd_inflate_wave.hpp) with the lane-per-member kernel behind it for the members it left.
+# Every test of this file runs on the default; the ones marked `both_kernels` run on either.
+@pytest.fixture(autouse=True)
+def _kernel(request):
+    k = getattr(request, "param", 0)
+    _lib().emul_inflate_kernel(k)
+    yield k
+    _lib().emul_inflate_kernel(0)
+
+
+both_kernels = pytest.mark.parametrize("_kernel", [0, 1], indirect=True, ids=["lane-per-member", "workgroup-per-member"])
+
+
+def fallbacks() -> int:
+    """members the last emulated launch of the workgroup-per-member kernel left to the lane-per-member kernel"""
+    lib = _lib()
+    lib.emul_inflate_fallbacks.restype = C.c_uint32
+    return int(lib.emul_inflate_fallbacks())
+
+
 def deflate(x: bytes, level=6, strategy=zlib.Z_DEFAULT_STRATEGY) -> bytes:
     co = zlib.compressobj(level, zlib.DEFLATED, -15, 8, strategy)
     return co.compress(x) + co.flush()
@@ -107,6 +128,7 @@ def random_part(rng, n):
     return x.tobytes()
 
 
+@both_kernels
 def test_short_members_and_every_small_distance():
     """Members shorter than the 16-byte window, a member of every length 0..48, every period 1..40 at lengths that
     end a chunk exactly at, one before and one past the member's end."""
@@ -121,6 +143,7 @@ def test_short_members_and_every_small_distance():
     check(parts, how)
 
 
+@both_kernels
 def test_stored_fixed_and_empty_blocks():
     rng = np.random.default_rng(2)
     parts, how = [], []
@@ -148,6 +171,7 @@ def test_random_members_of_every_kind(seed):
     check(parts, how)
 
 
+@both_kernels
 def test_damaged_payloads_are_refused_or_inflate_to_what_zlib_makes_of_them():
     """Bit flips in the payload: the kernel reports an error (a decoder code, or 18 from the CRC kernel), or -- when the
     damaged stream is still a valid one -- delivers exactly zlib's bytes; it never writes outside the member (the guard
@@ -229,6 +253,7 @@ def _libdeflate():
     return ld
 
 
+@both_kernels
 @pytest.mark.skipif(_libdeflate() is None, reason="no libdeflate.so.0 on this system")
 def test_streams_libdeflate_writes():
     """tools/synth_bam.cpp deflates with libdeflate when the system has it (as htslib does when built against it), and
@@ -262,6 +287,7 @@ def test_streams_libdeflate_writes():
         assert status[i] == 0 and got[i] == x, (i, int(status[i]), len(x))
 
 
+@both_kernels
 def test_members_of_the_synthetic_bam(tmp_path):
     """The file bench.py's `bam_file_scope` reads (tools/synth_bam.cpp -> goleft_amd/synth-bam), member by member: what the
     emulated kernel makes of each payload is what zlib makes of it, and the CRC the kernel checks is the trailer's."""
@@ -335,6 +361,7 @@ def _stored_then_compressed(stored: bytes, tail: bytes, level, strategy) -> byte
     return b"\x00" + len(stored).to_bytes(2, "little") + (len(stored) ^ 0xffff).to_bytes(2, "little") + stored + body
 
 
+@both_kernels
 def test_matches_that_reach_back_into_a_stored_block():
     """after a stored block the output ring held only the bytes of the block's last, incomplete
     64-byte block; a match whose 16-byte source straddles that boundary took the ring path and read bytes the ring never
@@ -366,3 +393,66 @@ def test_matches_that_reach_back_into_a_stored_block():
     got, status = emul_inflate(payloads, [len(x) for x in parts], [zlib.crc32(x) & 0xffffffff for x in parts], guarded=True)
     bad = [(i, int(status[i])) for i, x in enumerate(parts) if status[i] != 0 or got[i] != x]
     assert not bad, (len(bad), len(parts), bad[:10])
+
+
+def _bamlike(rng, n):
+    """records the way a BAM holds them: a fixed-shape head, a name that differs from the previous one in a few digits, packed
+    bases (random), qualities in plateaus -- matches at a record's distance, runs, and literals"""
+    out, k = [], 0
+    while sum(len(x) for x in out) < n:
+        k += int(rng.integers(1, 400))
+        head = np.array([0, 0, 0, 0], np.uint8).tobytes() + int(k).to_bytes(4, "little") + bytes([15, 60, 73, 18, 1, 0, 99, 0, 151, 0, 0, 0])
+        name = b"A00741:188:HGTMNDSX2:3:%04d:%05d:%05d\0" % (int(rng.integers(1101, 2678)), int(rng.integers(1000, 33000)), int(rng.integers(1000, 37000)))
+        seq = (rng.integers(0, 4, 76, dtype=np.uint8) * 0 + (1 << rng.integers(0, 4, 76)).astype(np.uint8) * 17 % 255).astype(np.uint8).tobytes()
+        qual = b"".join(bytes([int(rng.integers(2, 41))]) * int(rng.integers(1, 60)) for _ in range(6))[:151].ljust(151, b"%")
+        out.append(head + name + seq + qual)
+    return b"".join(out)[:n]
+
+
+def test_the_workgroup_per_member_kernel_takes_real_members_itself():
+    """What GD_OPT_INFLATE_KERNEL = 1 is for: full-size members of BAM-like records -- one Huffman block (libdeflate's way), several
+    (zlib at level 6 on 64 KB), with a stored block in between -- are inflated by the workgroup-per-member kernel ITSELF (no
+    fallback), byte for byte zlib's, next to the lane-per-member kernel on the same streams."""
+    rng = np.random.default_rng(11)
+    parts = [_bamlike(rng, 65280) for _ in range(4)] + [_bamlike(rng, int(rng.integers(2000, 60000))) for _ in range(4)]
+    pay = [deflate(x, lv) for x, lv in zip(parts, (1, 6, 9, 4, 1, 6, 9, 2))]
+    # several blocks in one member: a sync flush every 9 KB (dynamic blocks with history across them), one of them stored
+    x = _bamlike(rng, 65000)
+    co = zlib.compressobj(6, zlib.DEFLATED, -15)
+    multi = b"".join(co.compress(x[i:i + 9000]) + co.flush(zlib.Z_SYNC_FLUSH) for i in range(0, 54000, 9000))
+    co2 = co.copy()
+    multi += co.compress(x[54000:]) + co.flush()
+    parts.append(x); pay.append(multi)
+    y = rng.integers(0, 256, 3000, dtype=np.uint8).tobytes()
+    parts.append(y + x[:30000]); pay.append(_stored_then_compressed(y, x[:30000], 6, zlib.Z_DEFAULT_STRATEGY))
+    crcs = [zlib.crc32(x) & 0xffffffff for x in parts]
+    res = {}
+    for k in (0, 1):
+        _lib().emul_inflate_kernel(k)
+        got, status = emul_inflate(pay, [len(x) for x in parts], crcs, guarded=True)
+        assert (status == 0).all() and got == parts, (k, status)
+        res[k] = fallbacks()
+    assert res[1] == 0, "the workgroup-per-member kernel left %d of %d members to the other kernel" % (res[1], len(parts))
+
+
+def test_the_workgroup_per_member_kernel_hands_over_what_it_does_not_take():
+    """Members it must not judge go to the lane-per-member kernel with WV_FALLBACK and come back with THAT kernel's status: a
+    payload cut short, a distance that reaches in front of the member, an over-subscribed code, an incompressible member (its
+    payload does not fit beside the output it has to produce)."""
+    rng = np.random.default_rng(12)
+    x = _bamlike(rng, 40000)
+    good = deflate(x, 6)
+    noise = rng.integers(0, 256, 65280, dtype=np.uint8).tobytes()
+    cases = [(good[:len(good) // 2], len(x)),                # truncated
+             (deflate(b"abcdefgh" * 100, 6)[:-4] + b"\xff\xff\xff\xff", 800),
+             (good, len(x) - 7),                              # inflates to more than the member says
+             (deflate(noise, 1), len(noise))]                 # stored / barely compressed: handled by either kernel
+    _lib().emul_inflate_kernel(0)
+    want_got, want_status = emul_inflate([c for c, _ in cases], [n for _, n in cases], None, guarded=True)
+    _lib().emul_inflate_kernel(1)
+    got, status = emul_inflate([c for c, _ in cases], [n for _, n in cases], None, guarded=True)
+    assert list(status) == list(want_status), (list(status), list(want_status))
+    assert status[3] == 0 and got[3] == noise
+    for i in range(len(cases)):
+        if want_status[i] == 0:
+            assert got[i] == want_got[i]

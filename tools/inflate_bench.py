@@ -15,7 +15,7 @@ from goleft_amd.engine import DepthEngine, K_INFLATE
 
 length = sys.argv[1] if len(sys.argv) > 1 else "10000000"      # one contig length, or several separated by commas
 pads = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0]      # GD_OPT_INFLATE_LDS_PAD values to time
-# GD_OPT_INFLATE_KERNEL values to time: 0 = a workgroup per member (the default), 1 = a lane per member (rounds 3-5)
+# GD_OPT_INFLATE_KERNEL values to time: 0 = a lane per member (the default), 1 = a workgroup per member (round 6)
 probes = [int(x) for x in os.environ.get("INFLATE_BENCH_KERNELS", "0,1").split(",")]
 path = "/tmp/gd_inflate_test.bam"
 subprocess.check_call([os.path.join(ROOT, "goleft_amd", "synth-bam"), path, "chr20", length, "30", "20"],
@@ -69,4 +69,11 @@ with DepthEngine(0) as eng:
                 print("   sections over %d wave-iterations (%.0f cycles each):" % (buf[7], tot / buf[7]))
                 for k in range(7):
                     print("     %5.1f %%  %7.0f cycles  %s" % (100.0 * buf[k] / tot, buf[k] / buf[7], names[k]))
+            if buf[15]:
+                names = ["block header (stage, code lengths)", "tables", "pass A (speculative run + restarts)", "scan, bitmap clear", "pass B1 (literals, pieces)",
+                         "pass B2 (pieces in output order)", "store, status"]
+                tot = float(sum(buf[8 + k] for k in range(7)))
+                print("   workgroup-per-member kernel, %d members (%.0f cycles each, first wave's clock):" % (buf[15], tot / buf[15]))
+                for k in range(7):
+                    print("     %5.1f %%  %8.0f cycles  %s" % (100.0 * buf[8 + k] / tot, buf[8 + k] / buf[15], names[k]))
 os.unlink(path)
