@@ -109,3 +109,25 @@ def test_genome_bed_of_the_bench_line_is_the_oracles():
     exp = json.load(open(os.path.join(H.ROOT, "tests", "golden", "synth_bam_expected.json")))
     assert b["file"] == "genome" and b["bed_sha256"] == exp["genome:cov30:seed20:w1000"]["bed_sha256"]
     assert exp["genome:cov30:seed20:w1000"]["rows"][0] == 3095689          # one depth row per 1 kb window of hg19's 24 contigs
+
+
+def test_reference_children_hook_runs_with_a_samtools_on_path(tmp_path, monkeypatch):
+    """BASELINE.md section 3 / VERDICT r5 item 5: where a samtools exists, bench.py times the reference's own children
+    (`samtools depth -Q q -d 2500 -r chr:s-e bam`, depth/depth.go:45) by itself.  Here: a stand-in executable that answers
+    `--version` and `depth` the way samtools does (there is none in this image); the repository's own shim is not taken for one."""
+    import importlib
+    import stat
+    bench = importlib.import_module("bench")
+    fake = tmp_path / "samtools"
+    fake.write_text("#!/bin/sh\nif [ \"$1\" = --version ]; then echo 'samtools 9.9-standin'; exit 0; fi\n"
+                    "r=$7; echo \"$r\" >&2; printf 'chrS\\t1\\t3\\nchrS\\t2\\t4\\n'\n")
+    fake.chmod(fake.stat().st_mode | stat.S_IEXEC)
+    monkeypatch.setenv("PATH", str(tmp_path) + os.pathsep + os.environ.get("PATH", ""))
+    monkeypatch.delenv("SAMTOOLS", raising=False)
+    st = bench.real_samtools()
+    assert st and st[0] == str(fake) and "standin" in st[1]
+    out = bench.reference_children(st[0], "x.bam", [("chrS", 25_000_000)], 1000, 1, 2)
+    assert out["kind"] == "reference" and out["cores"] == 2 and out["value"] > 0 and out["text_bytes"] == 3 * 18
+    assert "3 tiles" in out["sample"]
+    monkeypatch.setenv("SAMTOOLS", os.path.join(bench.ROOT, "goleft_amd", "shim", "samtools"))
+    assert bench.real_samtools() is None
