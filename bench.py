@@ -81,6 +81,9 @@ def parse():
     ap.add_argument("--other-workloads", default="chr20,ont,cohort", metavar="W[,W...]",
                     help="N = 1, wgs workload: after the headline, short runs of BASELINE.json's configs 2 (chr20), 5 (ont) and "
                          "4 (cohort) -> `other_workloads` in the line; '' = off")
+    ap.add_argument("--allow-gather-fallback", action="store_true",
+                    help="N > 1: when the library's own collective (gd_gather_export) cannot be used, time torch.distributed's gather instead "
+                         "and exit 0; without this flag such a run still prints its line and then exits with status 3 -- a fallback is never silent")
     ap.add_argument("--verify", action="store_true",
                     help="check one contig against the CPU oracle after timing")
     return ap.parse_args()
@@ -603,17 +606,27 @@ def run_case(args, scaling, world, rank, dev, local_rank, want_streams=False):
         # (GD_E_NODEVICE) or the communicator does not come up; GOLEFT_BENCH_NATIVE_GATHER=0 asks for the fallback.
         native = os.environ.get("GOLEFT_BENCH_NATIVE_GATHER", "1") != "0"
         native_note = "asked for" if not native else ""
+        comm_lib = None
         if native:
-            from goleft_amd.engine import comm_unique_id
+            from goleft_amd.engine import comm_library, comm_unique_id
             fdev = dev if dist.get_backend() == "nccl" else "cpu"   # (dry runs over gloo: host tensors)
             ok, box = 1, [None]
-            if rank == 0:
+            # EVERY rank asks, locally, whether the library can open RCCL here, and the ranks agree before any of them enters
+            # the collective gd_comm_init: a rank that cannot would return at once and leave the others waiting in
+            # ncclCommInitRank
+            comm_lib = comm_library()
+            if comm_lib is None:
+                ok, native_note = 0, "gd_comm_library: RCCL cannot be opened through the library on rank %d" % rank
+            flag = torch.tensor([ok], dtype=torch.int32, device=fdev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) and rank == 0:
                 try:
                     box = [comm_unique_id()]
                 except Exception as e:                  # GdError: RCCL not available through the library
                     ok, native_note = 0, "gd_comm_unique_id: %s" % e
-            flag = torch.tensor([ok], dtype=torch.int32, device=fdev)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()):
+                flag = torch.tensor([ok], dtype=torch.int32, device=fdev)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             if int(flag.item()):
                 dist.broadcast_object_list(box, src=0)
                 try:
@@ -631,6 +644,7 @@ def run_case(args, scaling, world, rank, dev, local_rank, want_streams=False):
         gath.reserve(eng.device_runs()[1])
         gath.attach(eng)
         gath.fallback_note = native_note
+        gath.comm_lib = comm_lib
         if native:
             # one step through EACH collective before anything is timed: what rank 0 received through the library's
             # gather must be what torch.distributed's gather delivers for the same export blocks
@@ -752,6 +766,8 @@ def run_case(args, scaling, world, rank, dev, local_rank, want_streams=False):
                  "collective": "gd_gather_export (RCCL from the C ABI)" if gath.native else "torch.distributed gather",
                  "collective_verified_against_torch_gather": getattr(gath, "native_verified", None),
                  "collective_fallback_reason": getattr(gath, "fallback_note", "") or None,
+                 # which RCCL the library's collective used: the one the process had already (torch's own copy: ONE RCCL per process) or its own
+                 "collective_library": ({"path": gath.comm_lib[0], "already_in_the_process": gath.comm_lib[1]} if getattr(gath, "comm_lib", None) else None),
                  "pipelined": "in the timed loop a step is finish(k-1); flip(); launch(k); post(): the asynchronous, "
                               "double-buffered gather of step k-1 and its host-side cost run under the kernels of step k; "
                               "compute_ms / gather_ms here are measured one after the other"}
@@ -1376,6 +1392,13 @@ def main():
     flush_c_stdio()
     if rank == 0:
         print(json.dumps(out), flush=True)
+    # a fallback is never silent: the line is out, the status says what it was measured with
+    fb = (r_split or {}).get("collective_fallback_reason") if world > 1 else None
+    if fb and fb != "asked for" and not args.allow_gather_fallback:
+        if rank == 0:
+            print("bench.py: the library's collective (gd_gather_export) was NOT used -- %s; the line above was measured with torch.distributed's "
+                  "gather.  Exit status 3 (pass --allow-gather-fallback to accept that)." % fb, file=sys.stderr, flush=True)
+        sys.exit(3)
 
 
 if __name__ == "__main__":

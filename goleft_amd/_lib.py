@@ -112,6 +112,7 @@ SYMBOLS = {
     "gd_set_profiling": (C.c_int, [_P, C.c_int]),
     "gd_kernel_ms": (C.c_int, [_P, C.c_int, C.POINTER(C.c_float)]),
     "gd_comm_unique_id": (C.c_int, [_P, C.c_size_t]),
+    "gd_comm_library": (C.c_int, [C.c_char_p, C.c_size_t, C.POINTER(C.c_int)]),
     "gd_comm_init": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_size_t]),
     "gd_comm_destroy": (C.c_int, [_P]),
     "gd_gather_export": (C.c_int, [_P, _P, _P, C.c_size_t, C.c_int]),

@@ -569,6 +569,17 @@ def device_count() -> int:
     return n.value
 
 
+def comm_library():
+    """gd_comm_library: (path of the RCCL the library's collective uses, whether the process had it mapped already -- torch's
+    own copy) or None when there is none (GD_E_NODEVICE).  Local: no other rank takes part."""
+    buf = C.create_string_buffer(1024)
+    shared = C.c_int(0)
+    rc = _lib.load().gd_comm_library(buf, 1024, C.byref(shared))
+    if rc != 0:
+        return None
+    return buf.value.decode(), bool(shared.value)
+
+
 def comm_unique_id() -> bytes:
     """gd_comm_unique_id: 128 bytes that every rank of a communicator must be given (RCCL's ncclUniqueId)."""
     buf = (C.c_char * 128)()

@@ -569,6 +569,11 @@ int gd_wait_event(gd_ctx* ctx, void* hip_event);
  *   gd_gather_wait      the host waits until every gather issued so far has landed */
 #define GD_COMM_ID_BYTES 128
 int gd_comm_unique_id(void* id, size_t bytes);
+/* Which RCCL the calls above use: its path into `out` (NUL terminated, cut to `cap`); *shared = 1 when the process had one
+ * mapped already -- a host that imported torch has torch's own copy, and that one is used: never two RCCLs in one process --
+ * 0 when the library opened librccl.so.1 by name.  GD_E_NODEVICE: none on this machine.  Local and cheap: every rank can
+ * ask BEFORE any rank enters the collective gd_comm_init (a rank that cannot open RCCL would leave the others waiting there). */
+int gd_comm_library(char* out, size_t cap, int* shared);
 int gd_comm_init(gd_ctx* ctx, int rank, int world, const void* id, size_t bytes);
 int gd_comm_destroy(gd_ctx* ctx);
 int gd_gather_export(gd_ctx* ctx, const int64_t* send, int64_t* recv, size_t words, int root);

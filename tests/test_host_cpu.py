@@ -643,3 +643,20 @@ def test_bam_reader_reports_a_read_error_instead_of_an_end_of_file(hostlib, tmp_
     with pytest.raises(OSError) as e:
         hostlib.read_bam(str(d))
     assert "read error" in str(e.value), str(e.value)
+
+
+def test_rccl_stand_in_of_the_gather_tests_builds_and_exports_what_the_library_binds():
+    """tests/stubs/rccl_stub.cpp serves the library's native gather a world of several processes on one GPU
+    (tests/test_gpu_gather_world.py).  Here, without a GPU: it compiles, and it exports every entry point
+    goleft_amd/csrc/gd_api_comm.inc looks up -- a symbol the library binds and the stand-in lacks would turn the GPU test into
+    "RCCL is not available"."""
+    import re
+    src = os.path.join(ROOT, "tests", "stubs", "rccl_stub.cpp")
+    so = os.path.join(ROOT, "tests", "stubs", "librccl_stub.so")
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["hipcc", "-O2", "-shared", "-fPIC", "-o", so, src, "-lrt"])
+    bound = set(re.findall(r'sym\("(nccl\w+)"\)', open(os.path.join(ROOT, "goleft_amd", "csrc", "gd_api_comm.inc")).read()))
+    assert len(bound) == 8
+    names = subprocess.check_output(["nm", "-D", "--defined-only", so]).decode()
+    for n in bound:
+        assert re.search(r"\bT %s\b" % n, names), n
