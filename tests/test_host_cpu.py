@@ -651,6 +651,7 @@ def test_rccl_stand_in_of_the_gather_tests_builds_and_exports_what_the_library_b
     goleft_amd/csrc/gd_api_comm.inc looks up -- a symbol the library binds and the stand-in lacks would turn the GPU test into
     "RCCL is not available"."""
     import re
+    import subprocess
     src = os.path.join(ROOT, "tests", "stubs", "rccl_stub.cpp")
     so = os.path.join(ROOT, "tests", "stubs", "librccl_stub.so")
     if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
