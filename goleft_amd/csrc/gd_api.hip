@@ -827,6 +827,22 @@ int gd_set_option(gd_ctx* c, int option, int64_t value)
 {
     if (c && c->cs.pending) return fail(c, GD_E_STATE, "a compute is in flight: gd_compute_finish first");
     if (!c) return GD_E_INVALID;
+#ifndef GD_MEASURE
+    // The switches of measurement builds (-DGD_MEASURE; include/goleft_depth.h lists them apart): every one of them was measured
+    // neutral or worse (DESIGN.md / HISTORY.md), a release library holds them at their defaults and says so when asked for
+    // anything else.
+    {
+        bool other = false;
+        switch (option) {
+        case GD_OPT_INGEST_DMA: other = value > 1; break;
+        case GD_OPT_INGEST_PIECE_STREAMS: other = value != 1; break;
+        case GD_OPT_INGEST_HYBRID: case GD_OPT_INGEST_WALK_CUS: case GD_OPT_INFLATE_LDS_PAD: other = value != 0; break;
+        case GD_OPT_INGEST_BATCHES: other = value != 8; break;
+        default: break;
+        }
+        if (other) return fail(c, GD_E_INVALID, "option %d = %lld is a switch of measurement builds (-DGD_MEASURE); this library keeps it at its default", option, (long long)value);
+    }
+#endif
     switch (option) {
     case GD_OPT_NT_STORES: c->tile_opt = value ? 1 : 0; break;
     case GD_OPT_FAST_KERNEL: c->fast_kernel = value != 0; break;

@@ -50,7 +50,7 @@
 // (profiles/r10u_…, r10v_…, r10w_inflate_output_ring.txt).
 //
 // Round 5: what bounds it (profiles/r12j_..., r12k_..., r12l_..., r12m_...).  The section counters of the measurement build
-// (-DGD_INFLATE_TIMING) put an iteration at ~4 400 cycles, 0.4 % of them waiting for the two loads: a wave issues one
+// (-DGD_MEASURE) put an iteration at ~4 400 cycles, 0.4 % of them waiting for the two loads: a wave issues one
 // instruction per four cycles whatever its kind, and the ~750 instructions of an iteration (450 vector, 250 scalar, 50 LDS /
 // memory) plus the dependent LDS look-ups of three Huffman decodes are those cycles -- at ONE wave per SIMD, because 608 bytes
 // of LDS per member allow four waves per CU.  A kernel that split a member's work over two waves with the same LDS (a decoder
@@ -70,10 +70,10 @@
 #define GD_INFLATE_PROBE(what, value)
 #endif
 
-// MEASUREMENT BUILDS ONLY (-DGD_INFLATE_TIMING; tools/r12_inflate_sections.sh): the cycles a wave spends in each section of
+// MEASUREMENT BUILDS ONLY (-DGD_MEASURE; tools/r12_inflate_sections.sh): the cycles a wave spends in each section of
 // the symbol loop, summed over all waves into g_inflate_sections (read back through gd_debug_inflate_sections).  The
 // product is compiled without it.
-#ifdef GD_INFLATE_TIMING
+#ifdef GD_MEASURE
 __device__ unsigned long long g_inflate_sections[16];
 #define GD_INF_T(k) do { const uint64_t t_ = __builtin_readcyclecounter(); tsum[k] += t_ - tlast; tlast = t_; } while (0)
 #else
@@ -324,7 +324,7 @@ __global__ __launch_bounds__(INF_LANES) void gd_inflate_kernel(InflateJob job)
     uint8_t* const out_al = out - obase;                   // 64-byte aligned: block [fl, fl + 64) lives at out_al + fl
     uint32_t fl = 0;
     uint32_t E0 = 0;                                       // the four bytes before T: bytes [o - 20, o - 16)
-#ifdef GD_INFLATE_TIMING
+#ifdef GD_MEASURE
     uint64_t tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter(), titer = 0;
 #endif
     auto ring_byte = [&](uint32_t a) -> uint32_t { return (s_ring[((a >> 2) & 31u) * 64u] >> (8u * (a & 3u))) & 0xffu; };
@@ -646,11 +646,11 @@ __global__ __launch_bounds__(INF_LANES) void gd_inflate_kernel(InflateJob job)
             if (rem == 0u) mode = DECODE;
         }
         GD_INF_T(6);
-#ifdef GD_INFLATE_TIMING
+#ifdef GD_MEASURE
         ++titer;
 #endif
     }
-#ifdef GD_INFLATE_TIMING
+#ifdef GD_MEASURE
     if (lane == 0) {
         for (int k = 0; k < 7; ++k) atomicAdd(&::g_inflate_sections[k], (unsigned long long)tsum[k]);
         atomicAdd(&::g_inflate_sections[7], (unsigned long long)titer);

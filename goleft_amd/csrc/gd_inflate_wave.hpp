@@ -324,8 +324,8 @@ __device__ __forceinline__ WvRun wv_run(const uint8_t* in, uint32_t start, uint3
     return r;
 }
 
-// MEASUREMENT BUILDS ONLY (-DGD_INFLATE_TIMING): the cycles a workgroup spends in each phase, summed into g_inflate_sections[8..15]
-#ifdef GD_INFLATE_TIMING
+// MEASUREMENT BUILDS ONLY (-DGD_MEASURE): the cycles a workgroup spends in each phase, summed into g_inflate_sections[8..15]
+#ifdef GD_MEASURE
 #define WV_T(k) do { const uint64_t t_ = __builtin_readcyclecounter(); wsum[k] += t_ - wlast; wlast = t_; } while (0)
 #else
 #define WV_T(k)
@@ -363,7 +363,7 @@ __global__ __launch_bounds__(64 * NW, (NW + 1) / 2) void gd_inflate_wave_kernel(
         }
         reinterpret_cast<uint32_t*>(X + WX_PERM)[i] = w;
     }
-#ifdef GD_INFLATE_TIMING
+#ifdef GD_MEASURE
     uint64_t wsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, wlast = __builtin_readcyclecounter();
 #endif
     uint32_t bitpos = 0, opos = 0;
@@ -845,7 +845,7 @@ __global__ __launch_bounds__(64 * NW, (NW + 1) / 2) void gd_inflate_wave_kernel(
         if (tail0 + (uint32_t)tid < olen && tid < 16) g[tail0 + tid] = out[tail0 + tid];
     }
     if (tid == 0) job.status[m] = fallback ? WV_FALLBACK : 0u;
-#ifdef GD_INFLATE_TIMING
+#ifdef GD_MEASURE
     WV_T(6);
     if (tid == 0) {
         for (int k = 0; k < 7; ++k) atomicAdd(&::g_inflate_sections[8 + k], (unsigned long long)wsum[k]);

@@ -173,63 +173,56 @@ int gd_default_params(gd_params* p);
 /* Choose the device algorithm (GD_PATH_*); default GD_PATH_AUTO. */
 int gd_set_path(gd_ctx* ctx, int path);
 
-/* Tuning / diagnostic switches (defaults are what the measurements in DESIGN.md chose; results are bit
- * identical under every setting).  A C library behind cgo takes no behaviour from the process
- * environment: these are calls. */
-enum { /* (1, 2: tile shapes other than 4096 positions x 256 threads -- measured slower everywhere, retired) */
-       GD_OPT_NT_STORES = 3,        /* 1 (default): non-temporal per-base stores; 0: plain */
-       /* (4: canonical records -- a rewritten copy of the records for a host that computes the same records many times; no
-          caller in the reference does, every path reads the records as they arrived: removed in ABI 14) */
+/* Switches (defaults are what the measurements in DESIGN.md chose; results are bit identical under every setting).  A C
+ * library behind cgo takes no behaviour from the process environment: these are calls.
+ * (Numbers 1, 2, 4, 11 belonged to tile shapes and to "canonical records", measured slower / without a caller: retired.) */
+enum { GD_OPT_NT_STORES = 3,        /* 1 (default): non-temporal per-base stores; 0: plain */
        GD_OPT_FAST_KERNEL = 5,      /* 1 (default): ordinary tiles run the straight-line tile kernel, the rest the
                                        generic one; 0: the generic kernel for every tile */
        GD_OPT_COPY_THREADS = 6,     /* host threads filling the staging buffer of gd_ingest_feed: 1 (default) .. 16 */
        GD_OPT_PUSH_THREADS = 7,     /* host threads of gd_push copying into a pinned ring block: 16 (default), 1 .. 64
                                        (one core moves ~11 GB/s into pinned memory; the link takes five times that) */
+       GD_OPT_H2D_KERNEL = 8,       /* how a committed staging block reaches HBM: 1 (default) one kernel whose workgroups
+                                       read the page-locked block over the link (all five arrays in one launch; n > 1:
+                                       with n workgroups), 0: five hipMemcpyAsync through a DMA engine */
        GD_OPT_PUSH_CHUNK = 9,       /* records per staging block of gd_push: 2^20 (default), 4096 .. 2^24 */
        GD_OPT_BAM_REFS = 10,        /* gd_ingest_*: number of references in the BAM header (0, the default: unknown).  The
                                        record walk takes the first record of ANOTHER reference as the end of a contig's
                                        records only when its refID is one a sorted BAM can hold there (greater than the
                                        contig's and below this number, or -1); anything else is a damaged record */
-       /* (11: how the canonical records were built: removed in ABI 14) */
        GD_OPT_INGEST_CRC = 12,      /* 1 (default): gd_ingest_* checks the CRC32 of every BGZF member after inflating it, as htslib
                                        does; 0: the file is trusted (a second pass over the inflated bytes is saved) */
-       GD_OPT_INGEST_DMA = 13,      /* gd_ingest_feed*: streams a staged piece is split over: 1 (default) .. 4; 0: a copy kernel on a
-                                       high-priority stream instead.  Measured on MI355X next to the
-                                       inflate kernels: one stream 24-27 GB/s, two to four streams slower */
+       GD_OPT_INGEST_DMA = 13,      /* gd_ingest_feed*: how a staged piece crosses the link: 1 (default) a copy command on one stream;
+                                       0: a copy kernel on a high-priority stream (what the CLI uses, with GD_OPT_INGEST_CU_SPLIT).
+                                       (2 .. 4, slices of a piece on several streams, measured slower: measurement builds only) */
        GD_OPT_INGEST_INDEX = 14,    /* 1 (default): records are indexed as they arrive -- gd_adopt_device's check pass, a pass over
                                        every committed block once it has landed, the device BAM read's write pass: a position
                                        index (first read at or past every 64th position: the prep kernel looks its tiles' read
                                        ranges up instead of searching) and the largest reference span of any record (the first
                                        gd_compute starts with the right look-back instead of learning it; still verified).
                                        0: neither (the prep kernel searches, the look-back starts at max_span_hint or 512) */
-       GD_OPT_INGEST_PIECE_STREAMS = 15, /* gd_ingest_feed*: WHOLE staged pieces (64 MB) alternate over this many streams, two staging
-                                       buffers each: 1 (default) .. 4.  One copy engine moves 20 - 25 GB/s next to the inflate
-                                       kernels; this asks for several at once (GD_OPT_INGEST_DMA > 1 cuts ONE piece into slices
-                                       instead, which was measured slower) */
        GD_OPT_INGEST_RANGE_HINT = 18, /* bytes of the LARGEST range gd_ingest_begin will be given (0, the default: unknown): the range
                                        buffers are allocated for it on first use instead of growing -- freeing and allocating --
                                        whenever a later range is larger than the ones before */
        GD_OPT_INGEST_CU_SPLIT = 19,   /* with GD_OPT_INGEST_DMA = 0: every n-th CU (2 .. 64; 0, the default: off) runs only the copy kernel that
                                        pulls staged pieces over the link, the other CUs only the inflate launches (CU-masked
                                        streams); set before the first gd_ingest_begin */
-       GD_OPT_INGEST_HYBRID = 17,     /* with GD_OPT_INGEST_PIECE_STREAMS >= 2: 1: the pieces of every stream but the first leave through a copy
-                                       kernel instead of a copy command (the copy engine and a kernel share the link); 0 (default) */
-       GD_OPT_INFLATE_LDS_PAD = 16,   /* bytes of LDS every workgroup of the inflate kernel claims on top of its tables: 0 (default) ..
-                                       122880.  An occupancy limiter for measurements (fewer members in flight per CU) */
-       GD_OPT_INGEST_BATCHES = 21,    /* inflate launches per fed range: 8 (default), 1 .. 64 -- the members of a range are handed to the
-                                       inflate kernel in this many launches as their bytes arrive */
-       GD_OPT_INGEST_WALK_CUS = 22,   /* with GD_OPT_INGEST_CU_SPLIT: 1: the record walks of a decode run on the copy kernel's CUs (a
-                                       CU-masked stream of their own) instead of beside the inflate workgroups, whose LDS leaves a
-                                       walk one workgroup per CU; 0 (default) */
        GD_OPT_INFLATE_KERNEL = 20,    /* which kernel inflates BGZF members: 0 (default) a lane per member (gd_inflate.hpp); 1: a workgroup
                                        per member with the member's output in LDS (gd_inflate_wave.hpp, round 6; members it does not take
                                        go to the other kernel on the same stream).  Both produce zlib's bytes.  The second one moves a
                                        sixth of the bytes through memory and is the slower of the two on an MI355X (DESIGN.md 3.5 has the
                                        measurements and why); it is kept as a second implementation the tests compare the first with.
                                        (ABI 14 had a measurement switch with this number that produced wrong bytes: gone) */
-       GD_OPT_H2D_KERNEL = 8 };     /* how a committed staging block reaches HBM: 1 (default) one kernel whose workgroups
-                                       read the page-locked block over the link (all five arrays in one launch; n > 1:
-                                       with n workgroups), 0: five hipMemcpyAsync through a DMA engine */
+
+       /* ---- MEASUREMENT BUILDS ONLY (the library compiled with -DGD_MEASURE) ----
+        * Each of these was built, measured neutral or worse on an MI355X and left at its default (HISTORY.md has the numbers).
+        * A release library accepts the default value and answers GD_E_INVALID to any other; it also contains none of the
+        * timing code of such builds (section cycle counters in the inflate kernels, marks in gd_ingest_begin). */
+       GD_OPT_INGEST_PIECE_STREAMS = 15, /* whole staged pieces alternate over this many streams: 1 (default) .. 4 */
+       GD_OPT_INFLATE_LDS_PAD = 16,   /* bytes of LDS a lane-per-member inflate workgroup claims on top of its own (an occupancy limiter): 0 */
+       GD_OPT_INGEST_HYBRID = 17,     /* with several piece streams: the pieces of every stream but the first leave through a copy kernel: 0 */
+       GD_OPT_INGEST_BATCHES = 21,    /* inflate launches per fed range: 8 */
+       GD_OPT_INGEST_WALK_CUS = 22 }; /* with GD_OPT_INGEST_CU_SPLIT: the record walks on the copy kernel's CUs: 0 */
 int gd_set_option(gd_ctx* ctx, int option, int64_t value);
 
 /* What is built FROM the records: nothing on the short-read tile path and for the streaming sums (their kernels read the

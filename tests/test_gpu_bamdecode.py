@@ -564,3 +564,17 @@ def test_inflate_a_member_of_fifty_thousand_empty_blocks(kernel):
         got, status = eng.inflate_bgzf(data)
     assert (status == 0).all(), status
     assert got == payload + b"ACGT" * 1000
+
+
+def test_measurement_switches_are_refused_by_a_release_library():
+    """include/goleft_depth.h lists the switches of measurement builds (-DGD_MEASURE) apart: the library that ships keeps them at
+    their defaults, accepts the default and answers GD_E_INVALID to anything else (a cgo host could set a
+    switch that was only ever meant for a measurement)."""
+    from goleft_amd.engine import DepthEngine, GdError
+    with DepthEngine(0) as eng:
+        for opt, v in ((15, 2), (16, 4096), (17, 1), (21, 4), (22, 1), (13, 3)):
+            with pytest.raises(GdError) as ei:
+                eng.set_option(opt, v)
+            assert ei.value.status == -1, (opt, v, ei.value.status)
+        for opt, v in ((15, 1), (16, 0), (17, 0), (21, 8), (22, 0), (13, 0), (13, 1)):
+            eng.set_option(opt, v)

@@ -55,7 +55,7 @@ with DepthEngine(0) as eng:
                                                                                    bool((status == 0).all()), None if want is None else got == want))
         print("   kernel %.2f ms = %.2f GB/s of output (%.2f GB/s of BGZF); python zlib 1 thread %.2f s; call incl. H2D/D2H %.3f s"
               % (ms, len(got) / ms / 1e6, len(data) / ms / 1e6, t_cpu, t_all), flush=True)
-        # a measurement build (-DGD_INFLATE_TIMING, loaded through GOLEFT_DEPTH_SO): where the waves' cycles went
+        # a measurement build (-DGD_MEASURE, loaded through GOLEFT_DEPTH_SO): where the waves' cycles went
         import ctypes
         from goleft_amd import _lib
         dbg = getattr(_lib.load(), "gd_debug_inflate_sections", None) if os.environ.get("GOLEFT_DEPTH_SO") else None

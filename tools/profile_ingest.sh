@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round 5, first GPU session: the ingest kernels AS THEY ARE AT HEAD under rocprofv3 (VERDICT r4 "next" item 1a).
-#   tools/r12_profile_ingest.sh <tag>            (run through gpurun; everything lands under gpurun_out/<tag>_*)
+#   tools/profile_ingest.sh <tag>            (run through gpurun; everything lands under gpurun_out/<tag>_*)
 # 1. the GPU suite; 2. gd_inflate_kernel / gd_inflate_crc_wave_kernel on two chr20 files' members (108 k members, the
 # shape of profiles/r10w) written four ways (libdeflate 1 / 6, zlib 1, libdeflate 6 with aux tags): --kernel-trace --stats,
 # then FETCH_SIZE / WRITE_SIZE in passes of their own; 3. one genome read (file -> BED) with its phases, a kernel trace and
