@@ -572,7 +572,6 @@ int ck_enqueue(gd_ctx* c, const std::vector<ContigHost*>& hs, CkPending* P)
         j.ndel = reinterpret_cast<uint32_t*>(base + P->o_ndel[k]);
         j.del_total = reinterpret_cast<uint32_t*>(base + P->o_tot) + nj + k;
         j.max_span = reinterpret_cast<int32_t*>(j.lrec + n + 1);
-        j.unit = nullptr;
         j.pck = reinterpret_cast<uint32_t*>(base + P->o_pck[k]);
         j.total = reinterpret_cast<uint32_t*>(base + P->o_tot) + k;
         ubeg[k] = u;

@@ -74,9 +74,8 @@ struct DelJob {
     uint32_t* del_total;      // out: deletions of the contig
     int32_t*  max_span;       // atomicMax of end - pos
     // the tile index (PT kernels below)
-    uint32_t* unit;           // (unused)
     uint32_t* pck;            // the index: (n_ops >> 6) + 3 n_reads + 4 entries, read r's at pt_slot(off[r], r)
-    uint32_t* total;          // out: [0] unused, [n_jobs] deletions of the contig, [2 n_jobs] its largest span
+    uint32_t* total;          // out: [n_jobs] deletions of the contig, [2 n_jobs] its largest span ([0 .. n_jobs) is reserved: the layout is the host's)
 };
 constexpr uint32_t PT_NONE = 0xffffffffu;
 constexpr uint32_t PT_SEARCH = 0xfffffffeu;   // the read has deletions but no tile index (its slots were too few): the tile kernel bisects its list

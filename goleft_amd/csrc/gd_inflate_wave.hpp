@@ -71,6 +71,7 @@ enum : uint32_t { WS_RUN = 0, WS_CROSSED = 1, WS_EOB = 2, WS_BAD = 3, WS_INACTIV
 #define WV_UNIFORM(v) (v)
 #define WV_WAVE_SYNC() emul::wave_barrier()
 #define WV_LDS_OR(p, v) (*(p) |= (v))
+#define WV_LANE_IN(mask, lane) ((((uint64_t)(mask)) >> (lane)) & 1ull)
 #else
 #define WV_READLANE(v, l) ((uint32_t)__builtin_amdgcn_readlane((int)(v), (int)(l)))
 #define WV_SHFL_UP(v, d) ((uint32_t)__shfl_up((int)(v), (unsigned)(d), 64))
@@ -79,6 +80,8 @@ enum : uint32_t { WS_RUN = 0, WS_CROSSED = 1, WS_EOB = 2, WS_BAD = 3, WS_INACTIV
 // move them across this point
 #define WV_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
 #define WV_LDS_OR(p, v) ((void)__hip_atomic_fetch_or((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))
+// is this lane's bit set in a lane mask that lives in scalar registers: the mask becomes the execution mask, no vector compare
+#define WV_LANE_IN(mask, lane) __builtin_amdgcn_inverse_ballot_w64((uint64_t)(mask))
 #endif
 
 __device__ __forceinline__ uint64_t wv_load8(const uint8_t* p)
@@ -327,8 +330,14 @@ __device__ __forceinline__ WvRun wv_run(const uint8_t* in, uint32_t start, uint3
 // MEASUREMENT BUILDS ONLY (-DGD_MEASURE): the cycles a workgroup spends in each phase, summed into g_inflate_sections[8..15]
 #ifdef GD_MEASURE
 #define WV_T(k) do { const uint64_t t_ = __builtin_readcyclecounter(); wsum[k] += t_ - wlast; wlast = t_; } while (0)
+// ... and inside pass B2 (g_inflate_b2): cycles of the bitmap expansion, of a batch's set-up, of its rounds; windows, batches, rounds
+__device__ unsigned long long g_inflate_b2[8];
+#define WV_B(k) do { const uint64_t t_ = __builtin_readcyclecounter(); bsum[k] += t_ - blast; blast = t_; } while (0)
+#define WV_BN(k) (++bsum[k])
 #else
 #define WV_T(k)
+#define WV_B(k)
+#define WV_BN(k)
 #endif
 
 template <int NW>
@@ -365,6 +374,7 @@ __global__ __launch_bounds__(64 * NW, (NW + 1) / 2) void gd_inflate_wave_kernel(
     }
 #ifdef GD_MEASURE
     uint64_t wsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, wlast = __builtin_readcyclecounter();
+    uint64_t bsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, blast = 0;
 #endif
     uint32_t bitpos = 0, opos = 0;
     bool fallback = olen > 65536u || ilen > (1u << 20);
@@ -748,7 +758,11 @@ __global__ __launch_bounds__(64 * NW, (NW + 1) / 2) void gd_inflate_wave_kernel(
                 uint16_t* const stage = reinterpret_cast<uint16_t*>(sm + WV_LANE);   // [704]: pieces are >= 3 bytes, a window is 2 KB
                 const uint32_t w_lo = opos >> 5, w_hi = (opos + total + 31u) >> 5;
                 uint32_t carry_end = 0;                    // end of the last piece of the batch before
+#ifdef GD_MEASURE
+                blast = __builtin_readcyclecounter();
+#endif
                 for (uint32_t w0 = w_lo; w0 < w_hi; w0 += 64u) {
+                    WV_BN(3);
                     uint32_t word = w0 + (uint32_t)lane < w_hi ? bitmap[w0 + (uint32_t)lane] : 0u;
                     const uint32_t c = (uint32_t)__popc(word);
                     const uint32_t incl2 = wv_wave_incl_scan(c, lane);
@@ -762,7 +776,9 @@ __global__ __launch_bounds__(64 * NW, (NW + 1) / 2) void gd_inflate_wave_kernel(
                         }
                     }
                     WV_WAVE_SYNC();
+                    WV_B(0);
                     for (uint32_t s0 = 0; s0 < npc; s0 += 64u) {
+                        WV_BN(4);
                         const bool act = s0 + (uint32_t)lane < npc;
                         const uint32_t dst = act ? stage[s0 + (uint32_t)lane] : 0xfffffu;
                         const uint32_t tok = act ? wv_load4(out + dst) & 0xffffffu : 0u;
@@ -783,18 +799,33 @@ __global__ __launch_bounds__(64 * NW, (NW + 1) / 2) void gd_inflate_wave_kernel(
                             }
                         }
                         // ready at once: the source lies in the literals right behind the previous piece; ready when
-                        // everything below the first unresolved piece of the batch is resolved and the source ends there
-                        bool open_ = act;
+                        // everything below the first unresolved piece of the batch is resolved and the source ends there.
+                        // The round loop runs on lane MASKS (scalar registers): which lanes are periodic, which store 16 / 8 / 4 /
+                        // 2 / 1 bytes is fixed per batch, so a round is one compare, a few scalar operations, one 16-byte read
+                        // and the stores that some ready lane needs -- the first form of this loop tested every lane's bits again
+                        // in every round and took ~100 instructions (profiles/r13f_*).
                         const bool gap = s_lo >= prev_end;
+                        const bool part = act && n != 16u;
+                        const uint64_t MG = __ballot(act && gap), MP = __ballot(act && per), M16 = __ballot(act && n == 16u);
+                        const uint64_t B8 = __ballot((n & 8u) != 0u), B4 = __ballot((n & 4u) != 0u), B2 = __ballot((n & 2u) != 0u);
+                        const uint64_t M8 = __ballot(part && (n & 8u)), M4 = __ballot(part && (n & 4u)), M2 = __ballot(part && (n & 2u)),
+                                       M1 = __ballot(part && (n & 1u));
+                        const uint8_t* const s8 = out + (int)src;
+                        uint8_t* const a8 = out + dst;
+                        uint8_t* const a4 = a8 + (n & 8u);
+                        uint8_t* const a2 = a4 + (n & 4u);
+                        uint8_t* const a1 = a2 + (n & 2u);
                         uint64_t U = __ballot(act);
+                        WV_B(1);
                         while (U) {
+                            WV_BN(5);
                             const uint32_t first = (uint32_t)__builtin_ctzll(U);
                             const uint32_t F = WV_READLANE(dst, first);
-                            const bool ready = open_ && (s_hi <= F || gap || (uint32_t)lane == first);
-                            if (ready) {
-                                inf_v4 v;
-                                __builtin_memcpy(&v, out + (int)src, 16);
-                                if (per) {
+                            const uint64_t R = (__ballot(s_hi <= F) | MG | (1ull << first)) & U;
+                            inf_v4 v = {0, 0, 0, 0};
+                            if (WV_LANE_IN(R, lane)) __builtin_memcpy(&v, s8, 16);
+                            if (R & MP) {
+                                if (WV_LANE_IN(R & MP, lane)) {
                                     // the last p bytes of v, repeated from phase 0
                                     inf_v4 q;
                                     q.x = __builtin_amdgcn_perm(v.y, v.x, sel0.x) | __builtin_amdgcn_perm(v.w, v.z, sel1.x);
@@ -803,20 +834,21 @@ __global__ __launch_bounds__(64 * NW, (NW + 1) / 2) void gd_inflate_wave_kernel(
                                     q.w = __builtin_amdgcn_perm(v.y, v.x, sel0.w) | __builtin_amdgcn_perm(v.w, v.z, sel1.w);
                                     v = q;
                                 }
-                                uint8_t* d8 = out + dst;
-                                if (n == 16u) __builtin_memcpy(d8, &v, 16);
-                                else {
-                                    uint32_t a0 = v.x, a1 = v.y;
-                                    if (n & 8u) { const uint64_t lo = (uint64_t)a0 | ((uint64_t)a1 << 32); __builtin_memcpy(d8, &lo, 8); a0 = v.z; a1 = v.w; d8 += 8; }
-                                    if (n & 4u) { __builtin_memcpy(d8, &a0, 4); a0 = a1; d8 += 4; }
-                                    if (n & 2u) { const uint16_t h = (uint16_t)a0; __builtin_memcpy(d8, &h, 2); a0 >>= 16; d8 += 2; }
-                                    if (n & 1u) *d8 = (uint8_t)a0;
-                                }
-                                open_ = false;
                             }
-                            U = __ballot(open_);
+                            if (WV_LANE_IN(R & M16, lane)) __builtin_memcpy(a8, &v, 16);
+                            if (R & ~M16) {
+                                if (WV_LANE_IN(R & M8, lane)) { const uint64_t lo = (uint64_t)v.x | ((uint64_t)v.y << 32); __builtin_memcpy(a8, &lo, 8); }
+                                const uint32_t x4 = WV_LANE_IN(B8, lane) ? v.z : v.x, y4 = WV_LANE_IN(B8, lane) ? v.w : v.y;
+                                if (WV_LANE_IN(R & M4, lane)) __builtin_memcpy(a4, &x4, 4);
+                                const uint32_t x2 = WV_LANE_IN(B4, lane) ? y4 : x4;
+                                if (WV_LANE_IN(R & M2, lane)) { const uint16_t h = (uint16_t)x2; __builtin_memcpy(a2, &h, 2); }
+                                const uint32_t x1 = WV_LANE_IN(B2, lane) ? x2 >> 16 : x2;
+                                if (WV_LANE_IN(R & M1, lane)) *a1 = (uint8_t)x1;
+                            }
+                            U &= ~R;
                             WV_WAVE_SYNC();
                         }
+                        WV_B(2);
                         carry_end = WV_READLANE(endv, (npc - s0 < 64u ? npc - s0 : 64u) - 1u);
                     }
                 }
@@ -850,6 +882,7 @@ __global__ __launch_bounds__(64 * NW, (NW + 1) / 2) void gd_inflate_wave_kernel(
     if (tid == 0) {
         for (int k = 0; k < 7; ++k) atomicAdd(&::g_inflate_sections[8 + k], (unsigned long long)wsum[k]);
         atomicAdd(&::g_inflate_sections[15], 1ull);
+        for (int k = 0; k < 6; ++k) atomicAdd(&gd::g_inflate_b2[k], (unsigned long long)bsum[k]);
     }
 #endif
 }

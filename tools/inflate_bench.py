@@ -76,4 +76,10 @@ with DepthEngine(0) as eng:
                 print("   workgroup-per-member kernel, %d members (%.0f cycles each, first wave's clock):" % (buf[15], tot / buf[15]))
                 for k in range(7):
                     print("     %5.1f %%  %8.0f cycles  %s" % (100.0 * buf[8 + k] / tot, buf[8 + k] / buf[15], names[k]))
+                b2 = (ctypes.c_ulonglong * 8)()
+                f2 = getattr(_lib.load(), "gd_debug_inflate_b2", None)
+                if f2 is not None and f2(b2) == 0 and b2[4]:
+                    n = float(buf[15])
+                    print("     pass B2 per member: %.1f windows, %.1f batches, %.1f rounds; cycles: bitmap -> piece starts %.0f, batch set-up %.0f (%.0f each), rounds %.0f (%.0f each)"
+                          % (b2[3] / n, b2[4] / n, b2[5] / n, b2[0] / n, b2[1] / n, b2[1] / max(1, b2[4]), b2[2] / n, b2[2] / max(1, b2[5])))
 os.unlink(path)
