@@ -288,7 +288,7 @@ def test_streams_libdeflate_writes():
 
 
 @both_kernels
-def test_members_of_the_synthetic_bam(tmp_path):
+def test_members_of_the_synthetic_bam(tmp_path, _kernel):
     """The file bench.py's `bam_file_scope` reads (tools/synth_bam.cpp -> goleft_amd/synth-bam), member by member: what the
     emulated kernel makes of each payload is what zlib makes of it, and the CRC the kernel checks is the trailer's."""
     import json
@@ -311,7 +311,13 @@ def test_members_of_the_synthetic_bam(tmp_path):
         parts.append(x); payloads.append(c); crcs.append(crc)
         off += bsize + 1
     assert len(parts) > 150 and parts[-1] == b""                # the EOF member too
+    if _kernel == 1:
+        # (256 fibers per member: every sixth member, the first ones and the last)
+        keep = sorted(set(range(0, len(parts), 6)) | {1, 2, len(parts) - 2, len(parts) - 1})
+        parts, payloads, crcs = [parts[i] for i in keep], [payloads[i] for i in keep], [crcs[i] for i in keep]
     got, status = emul_inflate(payloads, [len(x) for x in parts], crcs, guarded=True)
+    if _kernel == 1:
+        assert fallbacks() <= 2                                 # (the empty EOF member is a fixed block of nothing: either kernel's)
     for i, x in enumerate(parts):
         assert status[i] == 0 and got[i] == x, (i, int(status[i]), len(x), info.get("deflate"))
 
