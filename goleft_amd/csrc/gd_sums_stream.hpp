@@ -64,6 +64,10 @@ constexpr int U = 4;                       // reads per lane and group
 constexpr uint32_t GROUP = 64u * U;        // reads per group: one pass of a wave
 constexpr uint32_t GPW = 16;               // consecutive groups per wave: 4096 reads (64 or 256: slower, r02o)
 constexpr int SQ_CAP = 256;                // queued odd reads per wave (a round adds at most 64)
+#ifndef GD_SUMS_DRAIN_AT
+#define GD_SUMS_DRAIN_AT 256
+#endif
+constexpr int SQ_DRAIN_AT = GD_SUMS_DRAIN_AT;   // the queue is walked when it would hold more than this
 
 // pointers read from the contig table are generic to the compiler; as GLOBAL ones their loads return in order with
 // the buffer loads and the waits between pipeline stages can be partial (one FLAT load outstanding forces every
@@ -300,7 +304,7 @@ __global__ __launch_bounds__(256) void gd_sums_stream_kernel(Job job)
             odd &= odd - 1u;
             const unsigned long long m = __builtin_amdgcn_ballot_w64(mine);
             const uint32_t np = (uint32_t)__popcll(m);
-            if (qn + np > (uint32_t)SQ_CAP) { drain_queue(Q, qn, lane, cigar, length, acc, W, wm, ws); qn = 0; }
+            if (qn + np > (uint32_t)SQ_DRAIN_AT) { drain_queue(Q, qn, lane, cigar, length, acc, W, wm, ws); qn = 0; }
             if (mine) {
                 const uint32_t rk = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32),
                                              __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));

@@ -14,6 +14,8 @@ Short-read model (configs 2/3: 150 bp, 30x):
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 
 READ_LEN = 150
@@ -119,6 +121,10 @@ def _assemble(xp, pos, kind_r, u3, u4, f5, u6):
 
     RL = READ_LEN
     kind = (kind_r >= 9200) * 1 + (kind_r >= 9700) * 1 + (kind_r >= 9900) * 1   # 0..3
+    if os.environ.get("GOLEFT_SYNTH_PLAIN") == "1":          # MEASUREMENTS ONLY: every read `150M` (what a kernel's rare paths cost)
+        kind = kind * 0
+    elif os.environ.get("GOLEFT_SYNTH_PLAIN") == "2":        # ... `150M` or `kS(150-k)M`: no read of three ops
+        kind = kind * (kind <= 1)
     k_clip = 1 + u3 % 30
     a_del = 20 + u3 % 111
     d_len = 1 + u4 % 10
