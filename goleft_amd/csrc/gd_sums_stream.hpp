@@ -83,6 +83,25 @@ __device__ __forceinline__ void drain_queue(const uint4* Q, uint32_t cnt, int la
     __builtin_amdgcn_wave_barrier();
     for (uint32_t i = (uint32_t)lane; i < cnt; i += 64u) {
         const uint4 it = Q[i];
+        if (it.x & 0x80000000u) {
+            // a read of THREE ops whose ops came with it (bit 31 of POS, which is non-negative): `M D M`, `M I M`, `S M S` -- the
+            // odd reads of a short-read sample.  Fetched when the group's ops were (round 6): walked from memory at the wave's
+            // end, 60 us later, every one of them was a line that had left L2 long ago -- 27 GB of 181 fetched for a cohort's
+            // 154 GB of records, ALL of the kernel's over-fetch (profiles/r13k_cohort_overfetch.txt: the same kernel on data
+            // without such reads fetches 1.00 x its bytes)
+            uint32_t x = it.x & 0x7fffffffu;
+            const uint32_t o3[3] = {it.y, it.z, it.w};
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const uint32_t o = o3[k], ol = o >> 4, op = o & 0xfu;
+                if (((0x18du >> op) & 1u) && x < length) {
+                    const uint32_t xe = x + ol;
+                    if (((0x181u >> op) & 1u) && ol != 0u) add_interval_direct(acc, W, wm, ws, x, xe < length ? xe : length);
+                    x = xe;
+                }
+            }
+            continue;
+        }
         const int32_t pu = (int32_t)it.x;
         const gptr_u32 ops = cigar + it.y;
         const uint32_t nu = it.z;
@@ -219,14 +238,41 @@ __global__ __launch_bounds__(256) void gd_sums_stream_kernel(Job job)
             const bool four = ((n[0] & n[1] & n[2] & n[3]) == 1u) & ((n[0] | n[1] | n[2] | n[3]) == 1u);
             v4u_t o4 = {0u, 0u, 0u, 0u};
             if (four) o4 = *(gptr_v4)(cigar + o[0]);
-            uint32_t c0[U] = {o4.x, o4.y, o4.z, o4.w}, c1[U] = {0u, 0u, 0u, 0u};
+            uint32_t c0[U] = {o4.x, o4.y, o4.z, o4.w}, c1[U] = {0u, 0u, 0u, 0u}, c2[U] = {0u, 0u, 0u, 0u};
+            const int32_t pq[U] = {(int32_t)S.pv.x, (int32_t)S.pv.y, (int32_t)S.pv.z, (int32_t)S.pv.w};
+            uint32_t three = 0;                                  // bit u: read u has three ops and goes to the queue WITH them
             if (__builtin_amdgcn_ballot_w64(!four) != 0ull) {
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
+                    const bool t3 = !four & keep[u] & (n[u] == 3u) & (pq[u] >= 0);
                     if (!four & keep[u]) c0[u] = cigar[o[u]];
-                    if (!four & keep[u] & (n[u] == 2u)) c1[u] = cigar[o[u] + 1u];
+                    if (!four & keep[u] & ((n[u] == 2u) | t3)) c1[u] = cigar[o[u] + 1u];
+                    if (t3) c2[u] = cigar[o[u] + 2u];
+                    three |= t3 ? 1u << u : 0u;
                 }
             }
+            // (one queue slot per lane and round, as in `work` below.  No drain here: when the queue has no room -- a wave of
+            // nothing but such reads -- the reads left over stay ordinary odd reads and take `work`'s way, ops by index; the
+            // drain's code exists once per `work` and once at the end, and four more copies of it cost more than they saved)
+            uint32_t odd3 = three;
+            while (__builtin_amdgcn_ballot_w64(odd3 != 0u) != 0ull) {
+                const bool mine = odd3 != 0u;
+                const int u = mine ? __ffs((int)odd3) - 1 : 0;
+                const unsigned long long m = __builtin_amdgcn_ballot_w64(mine);
+                const uint32_t np = (uint32_t)__popcll(m);
+                if (qn + np > (uint32_t)SQ_CAP) break;
+                odd3 &= odd3 - 1u;
+                if (mine) {
+                    const uint32_t rk = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                    const uint32_t pu = (uint32_t)(u == 0 ? pq[0] : u == 1 ? pq[1] : u == 2 ? pq[2] : pq[3]);
+                    const uint32_t a0 = u == 0 ? c0[0] : u == 1 ? c0[1] : u == 2 ? c0[2] : c0[3];
+                    const uint32_t a1 = u == 0 ? c1[0] : u == 1 ? c1[1] : u == 2 ? c1[2] : c1[3];
+                    const uint32_t a2 = u == 0 ? c2[0] : u == 1 ? c2[1] : u == 2 ? c2[2] : c2[3];
+                    Q[rk] = make_uint4(pu | 0x80000000u, a0, a1, a2);
+                }
+                qn += np;
+            }
+            three &= ~odd3;
             uint32_t kb = 0;
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -240,7 +286,7 @@ __global__ __launch_bounds__(256) void gd_sums_stream_kernel(Job job)
                     else if (!ka & cb) eff = c1[u] >> 4;                             // S M | H M | I M
                     else if (!ca & !cb) eff = 0u;                                    // nothing counted at all
                 }
-                const bool k = keep[u] & (eff != 0u);
+                const bool k = keep[u] & (eff != 0u) & !((three >> u) & 1u);   // (a queued three-op read is done with)
                 S.cg[u] = eff == 0xffffffffu ? eff : eff << 4;
                 kb |= k ? 1u << u : 0u;
             }
