@@ -68,6 +68,9 @@ constexpr int SQ_CAP = 256;                // queued odd reads per wave (a round
 #define GD_SUMS_DRAIN_AT 256
 #endif
 constexpr int SQ_DRAIN_AT = GD_SUMS_DRAIN_AT;   // the queue is walked when it would hold more than this
+#ifndef GD_SUMS_WAVES
+#define GD_SUMS_WAVES 1
+#endif
 
 // pointers read from the contig table are generic to the compiler; as GLOBAL ones their loads return in order with
 // the buffer loads and the waits between pipeline stages can be partial (one FLAT load outstanding forces every
@@ -158,7 +161,7 @@ struct Stage {
 // here (181 ms for 200 x chr1 in front of a 25 ms kernel).  A read FITS the lane's three windows when it has ONE counted
 // op and nothing before it that consumes the reference: 150M, 20S130M, 100M50S, 5H145M, 70M3I, 150M2D (97 % of
 // short reads); everything else takes the queue and the general op walk.
-__global__ __launch_bounds__(256) void gd_sums_stream_kernel(Job job)
+__global__ __launch_bounds__(256, GD_SUMS_WAVES) void gd_sums_stream_kernel(Job job)
 {
     __shared__ uint4 s_q[4 * SQ_CAP];
     __shared__ unsigned long long s_acc[4 * NACC];
