@@ -270,67 +270,81 @@ __device__ __forceinline__ uint32_t serial_dels_plain(const uint32_t* __restrict
     return w;                                                          // > cap: the caller walks the read again
 }
 
+// Round 6: FOUR CONSECUTIVE ops per lane.  The walk above it replaced took a batch of 256 ops as four groups of 64 -- one op per
+// lane and group: four wave prefix sums, four ballots, four rank computations and four boundary tests per batch, ~175
+// instructions -- and the pass is bound by exactly that (18.7 M batches per genome x 175 instructions is 5.4 of its 7.0 ms at
+// one vector instruction per four cycles and SIMD; halving its list bytes changed nothing, HISTORY.md).  Here a lane loads its
+// four ops with ONE 16-byte load through a buffer descriptor over the read's ops (past the end: zeros = ops that consume
+// nothing), adds them up locally, and the wave needs two prefix sums per batch: of the consumed lengths and of the D/N counts.
 __device__ __forceinline__ uint32_t wave_dels_plain(const uint32_t* __restrict__ ops, uint32_t n, int lane, uint32_t pos,
                                                     uint2* __restrict__ out, uint32_t cap, uint32_t& endp, bool& again,
                                                     uint32_t* __restrict__ ix, uint32_t ixcap)
 {
+    typedef unsigned int v4u_t __attribute__((ext_vector_type(4)));
     const uint32_t pk = pos >> PT_SHIFT;
     uint32_t cur = pos, w = 0u;                                         // wave uniform
     again = false;
-    uint32_t nxt[DL_UNROLL];
+    const rsrc_t rs = make_rsrc(ops, n * 4u);
+    // THREE batches in flight.  With one (what every form of this walk had) a wave holds 1 KB of loads in the air, the
+    // device's 8 192 resident waves 8 MB -- and 8 MB per ~2 us of loaded-memory latency IS the 4.2 TB/s the pass ran at,
+    // whatever its instruction count or the bytes it wrote (both were halved in turn this round and changed nothing).  Three
+    // slots, the loop unrolled by three so that no register with a load outstanding is ever copied.
+    auto load = [&](uint32_t b) -> v4u_t { return __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(b * 4u) + lane * 16, 0, 0); };
+    bool stop = false;
+    auto batch = [&](v4u_t& slot, uint32_t b0) {
+        const v4u_t cg = slot;
+        if (b0 + 768u < n) slot = load(b0 + 768u);
+        const uint32_t c4[4] = {cg.x, cg.y, cg.z, cg.w};
+        uint32_t len[4], cons[4];
+        bool dn[4], big = false;
 #pragma unroll
-    for (int u = 0; u < DL_UNROLL; ++u) {
-        const uint32_t k = (uint32_t)u * 64u + (uint32_t)lane;
-        nxt[u] = k < n ? ops[k] : 0u;
+        for (int e = 0; e < 4; ++e) {
+            const uint32_t op = c4[e] & 0xfu;
+            len[e] = c4[e] >> 4;
+            const bool c = ((0x18du >> op) & 1u) && len[e] != 0u;
+            dn[e] = c && !((0x181u >> op) & 1u);
+            big = big || (c && len[e] > (1u << 22));
+            cons[e] = c ? len[e] : 0u;
+        }
+        if (__builtin_amdgcn_ballot_w64(big) != 0ull || cur >= POS_CAP - (1u << 30)) { again = true; stop = true; return; }
+        const uint32_t p1 = cons[0], p2 = p1 + cons[1], p3 = p2 + cons[2], tot = p3 + cons[3];   // <= 4 * 2^22
+        const uint32_t nd4 = (uint32_t)dn[0] + (uint32_t)dn[1] + (uint32_t)dn[2] + (uint32_t)dn[3];
+        const uint32_t incl = (uint32_t)wave_inclusive_scan((int)tot);     // the batch advances by < 2^30
+        const uint32_t cincl = (uint32_t)wave_inclusive_scan((int)nd4);
+        const uint32_t gtot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        const uint32_t cnt = (uint32_t)__builtin_amdgcn_readlane((int)cincl, 63);
+        if (w + cnt > cap) { again = true; stop = true; return; }
+        const uint32_t s0 = cur + incl - tot, s1 = s0 + p1, s2 = s0 + p2, s3 = s0 + p3;
+        uint32_t k = w + cincl - nd4;
+        if (dn[0]) out[k++] = make_uint2(s0, len[0]);
+        if (dn[1]) out[k++] = make_uint2(s1, len[1]);
+        if (dn[2]) out[k++] = make_uint2(s2, len[2]);
+        if (dn[3]) out[k] = make_uint2(s3, len[3]);
+        const uint32_t nxt_cur = cur + gtot;
+        if ((nxt_cur >> PT_SHIFT) != (cur >> PT_SHIFT)) {               // (wave uniform) the tile index:
+            // boundaries in (cur, nxt_cur]: the deletions before this batch, and those of it that start before the boundary
+            for (uint32_t kk = (cur >> PT_SHIFT) + 1u; kk <= (nxt_cur >> PT_SHIFT) && kk - pk < ixcap; ++kk) {
+                const uint32_t bnd = kk << PT_SHIFT;
+                const uint32_t mine = (uint32_t)(dn[0] && s0 < bnd) + (uint32_t)(dn[1] && s1 < bnd) + (uint32_t)(dn[2] && s2 < bnd) +
+                                      (uint32_t)(dn[3] && s3 < bnd);
+                const uint32_t before = (uint32_t)wave_total((int)mine);
+                if (lane == 0) ix[kk - pk] = w + before;
+            }
+        }
+        w += cnt;
+        cur = nxt_cur;
+    };
+    v4u_t A = load(0u), B = {0u, 0u, 0u, 0u}, C = {0u, 0u, 0u, 0u};
+    if (n > 256u) B = load(256u);
+    if (n > 512u) C = load(512u);
+    for (uint32_t b0 = 0; b0 < n && !stop; b0 += 768u) {
+        batch(A, b0);
+        if (stop || b0 + 256u >= n) break;
+        batch(B, b0 + 256u);
+        if (stop || b0 + 512u >= n) break;
+        batch(C, b0 + 512u);
     }
-    for (uint32_t b0 = 0; b0 < n; b0 += DL_UNROLL * 64u) {
-        uint32_t cgv[DL_UNROLL];
-#pragma unroll
-        for (int u = 0; u < DL_UNROLL; ++u) cgv[u] = nxt[u];
-        if (b0 + DL_UNROLL * 64u < n) {
-#pragma unroll
-            for (int u = 0; u < DL_UNROLL; ++u) {
-                const uint32_t k = b0 + (uint32_t)(DL_UNROLL + u) * 64u + (uint32_t)lane;
-                nxt[u] = k < n ? ops[k] : 0u;
-            }
-        }
-        uint32_t lenv[DL_UNROLL];
-        bool dnv[DL_UNROLL], big = false;
-        int sc[DL_UNROLL];
-#pragma unroll
-        for (int u = 0; u < DL_UNROLL; ++u) {
-            const uint32_t op = cgv[u] & 0xfu;
-            lenv[u] = cgv[u] >> 4;
-            const bool cons = ((0x18du >> op) & 1u) && lenv[u] != 0u;
-            dnv[u] = cons && !((0x181u >> op) & 1u);
-            big = big || (cons && lenv[u] > (1u << 22));
-            sc[u] = cons ? (int)lenv[u] : 0;
-        }
-        if (__builtin_amdgcn_ballot_w64(big) != 0ull || cur >= POS_CAP - (1u << 30)) { again = true; return 0u; }
-        static_assert(DL_UNROLL == 4, "one scan4 group");
-        scan4(sc[0], sc[1], sc[2], sc[3]);                             // each <= 64 * 2^22: the batch advances by < 2^30
-#pragma unroll
-        for (int u = 0; u < DL_UNROLL; ++u) {
-            const unsigned long long dm = __builtin_amdgcn_ballot_w64(dnv[u]);
-            const uint32_t cnt = (uint32_t)__popcll(dm);
-            if (w + cnt > cap) { again = true; return 0u; }
-            const uint32_t start = cur + (uint32_t)sc[u] - lenv[u];
-            if (dnv[u]) {
-                const uint32_t rk = __builtin_amdgcn_mbcnt_hi((uint32_t)(dm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)dm, 0u));
-                out[w + rk] = make_uint2(start, lenv[u]);
-            }
-            const uint32_t nxt_cur = cur + (uint32_t)__builtin_amdgcn_readlane(sc[u], 63);
-            if ((nxt_cur >> PT_SHIFT) != (cur >> PT_SHIFT)) {           // (wave uniform, one group in five) the tile index:
-                // boundaries in (cur, nxt_cur]: the deletions before this group, and those of it that start before the boundary
-                for (uint32_t kk = (cur >> PT_SHIFT) + 1u; kk <= (nxt_cur >> PT_SHIFT) && kk - pk < ixcap; ++kk) {
-                    const uint32_t before = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(dnv[u] && start < (kk << PT_SHIFT)));
-                    if (lane == 0) ix[kk - pk] = w + before;
-                }
-            }
-            w += cnt;
-            cur = nxt_cur;
-        }
-    }
+    if (stop) return 0u;
     endp = cur;
     return w;
 }
