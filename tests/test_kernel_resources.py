@@ -64,3 +64,11 @@ def test_inflate_kernel_keeps_four_workgroups_per_cu(kernels):
     (name, r), = pick(kernels, "gd_inflate_kernel").items()
     assert r["lds"] * 4 <= LDS_PER_CU and r["vgpr"] <= 256, (name, r)      # LDS decides; two waves per SIMD at most
     assert r["scratch"] <= 512, (name, r)                    # the code lengths of a dynamic block (a lane's private array)
+
+
+def test_workgroup_per_member_inflate_keeps_two_members_per_cu(kernels):
+    """gd_inflate_wave_kernel<4>: a member's 64 KB of output, its tables, the lanes' words and the piece bitmap in LDS -- two
+    workgroups of four waves per CU, so at most half of the LDS and 256 registers a lane (two waves per SIMD), no scratch (an
+    indexed array in pass B2 once cost it a memory round trip per piece: profiles/r13f_inflate_two_kernels.txt)."""
+    (name, r), = pick(kernels, "gd_inflate_wave_kernel<").items()
+    assert r["lds"] * 2 <= LDS_PER_CU and r["vgpr"] <= 256 and r["scratch"] == 0, (name, r)
