@@ -59,7 +59,8 @@ def test_wgs_bench_line_has_the_contract_fields():
     # round 5: BASELINE.json's configs 2, 4 and 5 ride in the same line, each with its cold step and its own roofline
     ow = d["other_workloads"]
     assert set(ow) == {"chr20", "ont", "cohort"}
-    for name, cfg, kernel in (("chr20", 2, "gd_tile_fast_kernel<raw>"), ("cohort", 4, "gd_sums_stream_kernel<raw>"), ("ont", 5, "gd_ltile2_kernel")):
+    for name, cfg, kernel in (("chr20", 2, "gd_tile_fast_kernel<raw>"), ("cohort", 4, "gd_sums_stream_kernel<raw>"),
+                              ("ont", 5, "gd_dels_raw_kernel + gd_ltile2_kernel (the inclusive step)")):
         w = ow[name]
         assert "error" not in w, (name, w.get("error"))
         assert w["baseline_config"] == cfg and w["unit"] == "ref-bases/s" and w["roofline"]["kernel"] == kernel
@@ -70,6 +71,16 @@ def test_wgs_bench_line_has_the_contract_fields():
         assert w["value"] >= 1e9                                        # every config clears BASELINE.json's 1-GPU target
     assert sum(w["seconds_in_bench"] for w in ow.values()) < 60
     assert ow["ont"]["kernels_ms"]["long_read_structures"] > 0 and ow["ont"]["device_path"] == "chunk"
+    # round 6: the long-read roofline is on SURVEY 8(d)'s ORIGINAL op count over the inclusive step, each
+    # of the two kernels' own figures a sub-key; every roofline also says what fraction of the ACHIEVABLE rate it is
+    ro = ow["ont"]["roofline"]
+    assert ro["cigar_ops_counted"] == ow["ont"]["cigar_ops"] and abs(ro["avg_kernel_ms"] - ow["ont"]["ms_per_step"]) < 1e-9
+    assert set(ro["kernels"]) == {"gd_dels_raw_kernel", "gd_ltile2_kernel"} and ro["kernels"]["gd_ltile2_kernel"]["cigar_ops_counted"] < ro["cigar_ops_counted"]
+    assert abs(d["roofline"]["frac_of_achievable"] - d["roofline"]["achieved"] / 6290.0) < 1e-9
+    # ... and the genome as an aligner leaves it is in the driver's line
+    g6 = b["genome_libdeflate6_aux_tags"]
+    assert g6["oracle_identical"] is True and g6["ref_bases"] == 3095677412 and g6["wall_s"] > 0 and "level 6" in g6["deflate"]
+    assert d["cpu_baseline"]["reference_pipeline"] is not None
     # ... the BAM-file scope is checked against the ORACLE (not only decoder against decoder), on records as an aligner leaves
     # them too, and holds the reference's own timed invocation
     assert b["oracle_identical"] is True and b["oracle_bed_sha256"] == b["bed_sha256"]
