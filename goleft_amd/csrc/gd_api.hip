@@ -449,7 +449,11 @@ int gd_acquire(gd_ctx* c, size_t reads_cap, size_t ops_cap, gd_batch* out)
 {
     if (!c || !out) return GD_E_INVALID;
     if (int r = set_device(c)) return r;
+    // the cursor moves here, not at the commit: a producer may hold several blocks (its threads fill block k+1 while
+    // block k is validated and committed); a slot that comes round while still held means every slot is out
     RingSlot& s = c->ring[c->ring_next];
+    if (s.held)
+        return fail(c, GD_E_STATE, "all %d staging blocks are held: gd_commit one (n_reads 0 gives it back unused)", kRingSlots);
     if (s.busy) {
         HIPCHK(c, hipEventSynchronize(s.done));
         s.busy = false;
@@ -475,6 +479,8 @@ int gd_acquire(gd_ctx* c, size_t reads_cap, size_t ops_cap, gd_batch* out)
         s.b.ops_cap = ops_cap;
     }
     s.b.slot = c->ring_next;
+    s.held = true;
+    c->ring_next = (c->ring_next + 1) % kRingSlots;
     *out = s.b;
     return GD_OK;
 }
@@ -517,7 +523,8 @@ static int commit_block(gd_ctx* c, const gd_batch* b, int32_t tid, size_t n_read
     if (tid < 0 || (size_t)tid >= c->contigs.size()) return fail(c, GD_E_RANGE, "tid %d out of range", tid);
     if (n_reads > b->reads_cap || n_ops > b->ops_cap) return fail(c, GD_E_INVALID, "batch overflow");
     RingSlot& s = c->ring[b->slot];
-    c->ring_next = (b->slot + 1) % kRingSlots;
+    if (!s.held) return fail(c, GD_E_STATE, "batch was committed already");
+    s.held = false;                                      // (whatever happens below, the block goes back to the ring)
     if (n_reads == 0) return GD_OK;
     ContigHost& h = c->contigs[tid];
     if (h.adopted) return fail(c, GD_E_STATE, "contig %d holds adopted device records", tid);
@@ -758,6 +765,7 @@ int gd_reset(gd_ctx* c)
         h.length = len;
     }
     c->bounds.clear();
+    for (auto& s : c->ring) s.held = false;                // (blocks handed out before the reset are not part of anything)
     c->computed = false;
     c->lookback = c->params.max_span_hint > 0 ? c->params.max_span_hint : kDefaultLookback;
     c->span_forces_long = false;

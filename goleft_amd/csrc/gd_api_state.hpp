@@ -67,7 +67,8 @@ struct ContigHost {
 struct RingSlot {
     gd_batch b{};
     hipEvent_t done = nullptr;
-    bool busy = false;
+    bool busy = false;       // its copy may still be in flight (`done`)
+    bool held = false;       // handed out by gd_acquire, not committed yet
 };
 
 }  // namespace

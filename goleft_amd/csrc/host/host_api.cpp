@@ -64,59 +64,86 @@ int gdh_produce_in_place(void* vctx, int32_t tid, const int32_t* pos, const uint
     if (threads < 1) threads = 1;
     if (chunk < 4096) chunk = 4096;
     if (int r = gd_reserve(ctx, tid, n_reads, n_ops)) return r;   // (a decoder has the count from the .bai metadata bin)
-    // `threads` producers for the whole call (like decoder goroutines): each writes its share of every block, a
-    // spin barrier separates "block filled" from "block committed, next one acquired"
-    std::atomic<int> arrived{0}, phase{0}, status{GD_OK};
-    gd_batch b{};
-    size_t i = 0, n = 0, o0 = 0, o1 = 0;
-    bool done = n_reads == 0;
-    auto next_block = [&]() -> int {                      // (one thread)
-        if (i >= n_reads) { done = true; return GD_OK; }
-        n = std::min(chunk, n_reads - i);
-        o0 = cigar_off[i]; o1 = cigar_off[i + n];
-        if (o1 < o0 || o1 > n_ops) return GD_E_INVALID;   // (before anything is sized or copied by these offsets)
-        return gd_acquire(ctx, n, o1 - o0, &b);
+    if (!n_reads) return GD_OK;
+    // `threads` producers for the whole call (like decoder goroutines), each writing its share of every block, and
+    // this thread, the only one that talks to the context: it holds up to kDepth blocks (gd_acquire hands out the next
+    // one before the last is committed), so the producers write block k+1 while block k is validated and sent
+    constexpr int kDepth = 3;
+    struct Block {
+        gd_batch b{};
+        size_t i = 0, n = 0, o0 = 0, o1 = 0;
+        std::atomic<int> filled{0};
+    } blocks[kDepth];
+    const size_t n_blocks = (n_reads + chunk - 1) / chunk;
+    std::atomic<size_t> acquired{0};          // blocks [0, acquired) are described in `blocks` and may be written
+    std::atomic<int> status{GD_OK};
+    std::atomic<bool> stop{false};
+    auto acquire = [&](size_t j) -> int {
+        Block& k = blocks[j % kDepth];
+        k.i = j * chunk;
+        k.n = std::min(chunk, n_reads - k.i);
+        k.o0 = cigar_off[k.i]; k.o1 = cigar_off[k.i + k.n];
+        if (k.o1 < k.o0 || k.o1 > n_ops) return GD_E_INVALID;   // (before anything is sized or copied by these offsets)
+        if (int r = gd_acquire(ctx, k.n, k.o1 - k.o0, &k.b)) return r;
+        k.filled.store(0, std::memory_order_relaxed);
+        acquired.store(j + 1, std::memory_order_release);
+        return GD_OK;
     };
-    if (int r = next_block()) return r;
-    auto part = [&](int k) {
-        const size_t a = n * (size_t)k / (size_t)threads, e = n * (size_t)(k + 1) / (size_t)threads;
+    auto part = [&](const Block& k, int w) {
+        const size_t a = k.n * (size_t)w / (size_t)threads, e = k.n * (size_t)(w + 1) / (size_t)threads;
         if (e <= a) return;
-        memcpy(b.pos + a, pos + i + a, (e - a) * sizeof(int32_t));
-        memcpy(b.flag + a, flag + i + a, (e - a) * sizeof(uint16_t));
-        memcpy(b.mapq + a, mapq + i + a, (e - a) * sizeof(uint8_t));
-        const uint32_t* so = cigar_off + i;
-        for (size_t r = a; r < e; ++r) b.cigar_off[r] = so[r] - (uint32_t)o0;
-        if (e == n) b.cigar_off[n] = so[n] - (uint32_t)o0;
+        const gd_batch& b = k.b;
+        memcpy(b.pos + a, pos + k.i + a, (e - a) * sizeof(int32_t));
+        memcpy(b.flag + a, flag + k.i + a, (e - a) * sizeof(uint16_t));
+        memcpy(b.mapq + a, mapq + k.i + a, (e - a) * sizeof(uint8_t));
+        const uint32_t* so = cigar_off + k.i;
+        for (size_t r = a; r < e; ++r) b.cigar_off[r] = so[r] - (uint32_t)k.o0;
+        if (e == k.n) b.cigar_off[k.n] = so[k.n] - (uint32_t)k.o0;
         const size_t ca = so[a], ce = so[e];
         // a share's ops must lie inside the block's [o0, o1): offsets that leave it would write outside the pinned block
         // before gd_commit's validation ever sees them
-        if (ca < o0 || ce > o1 || ce < ca) { status.store(GD_E_INVALID); return; }
-        if (ce > ca) memcpy(b.cigar + (ca - o0), cigar + ca, (ce - ca) * sizeof(uint32_t));
+        if (ca < k.o0 || ce > k.o1 || ce < ca) { status.store(GD_E_INVALID); stop.store(true); return; }
+        if (ce > ca) memcpy(b.cigar + (ca - k.o0), cigar + ca, (ce - ca) * sizeof(uint32_t));
     };
-    auto worker = [&](int k) {
-        int my = 0;
-        while (!done) {
-            part(k);
-            // barrier: the last producer to arrive commits the block and acquires the next
-            if (arrived.fetch_add(1) + 1 == threads) {
-                int rc = status.load();
-                if (rc == GD_OK) rc = gd_commit(ctx, &b, tid, n, o1 - o0);
-                i += n;
-                if (rc == GD_OK) rc = next_block(); else done = true;
-                if (rc != GD_OK) { status.store(rc); done = true; }
-                arrived.store(0);
-                phase.fetch_add(1);
-            } else {
-                while (phase.load() == my) std::this_thread::yield();
+    auto producer = [&](int w) {
+        for (size_t j = 0; j < n_blocks; ++j) {
+            while (acquired.load(std::memory_order_acquire) <= j) {
+                if (stop.load(std::memory_order_relaxed)) return;
+                std::this_thread::yield();
             }
-            ++my;
+            Block& k = blocks[j % kDepth];
+            part(k, w);
+            k.filled.fetch_add(1, std::memory_order_release);
         }
     };
+    size_t next = 0, held_from = 0;           // blocks [held_from, next) are held
+    int rc = GD_OK;
+    for (; next < n_blocks && next < (size_t)kDepth && rc == GD_OK; ) {
+        rc = acquire(next);
+        if (rc == GD_OK) ++next;
+    }
     std::vector<std::thread> th;
-    for (int k = 1; k < threads; ++k) th.emplace_back(worker, k);
-    worker(0);
+    if (rc == GD_OK)
+        for (int w = 0; w < threads; ++w) th.emplace_back(producer, w);
+    for (size_t j = 0; j < n_blocks && rc == GD_OK; ++j) {
+        Block& k = blocks[j % kDepth];
+        while (k.filled.load(std::memory_order_acquire) < threads) {
+            if (stop.load(std::memory_order_relaxed)) break;
+            std::this_thread::yield();
+        }
+        if ((rc = status.load()) != GD_OK) break;
+        rc = gd_commit(ctx, &k.b, tid, k.n, k.o1 - k.o0);
+        held_from = j + 1;
+        if (rc == GD_OK && next < n_blocks) {
+            rc = acquire(next);
+            if (rc == GD_OK) ++next;
+        }
+    }
+    if (rc != GD_OK) stop.store(true);
     for (auto& t : th) t.join();
-    return status.load();
+    for (size_t j = held_from; j < next; ++j)             // (an error: the blocks still out go back unused)
+        (void)gd_commit(ctx, &blocks[j % kDepth].b, tid, 0, 0);
+    return rc != GD_OK ? rc : status.load();
 }
 
 static int g_fast_exit = 0;

@@ -264,15 +264,22 @@ int gd_select_contigs(gd_ctx* ctx, int n, const int32_t* tids);
 /* ---- record ingest: pinned ring buffers -> HBM (replaces the BGZF/BAM read
  * that each `samtools depth` child performs) --------------------------------*/
 
-/* Borrow a pinned staging block with at least the given capacities.  Blocks
- * until a ring slot is free. */
+/* Borrow a pinned staging block with at least the given capacities.  Waits
+ * for the block's previous copy if that is still in flight.  A producer may
+ * hold up to three blocks at a time (its threads write block k+1 while
+ * gd_commit validates and sends block k -- gdh_produce_in_place does); blocks
+ * go back to the ring in the order they were handed out, and GD_E_STATE
+ * answers a gd_acquire that comes round to a block still held.  gd_commit
+ * with n_reads 0 gives a block back unused; gd_reset gives all of them back. */
 int gd_acquire(gd_ctx* ctx, size_t reads_cap, size_t ops_cap, gd_batch* out);
 
 /* Append n_reads records (n_ops ops) of contig tid from a block obtained from
  * gd_acquire; the H2D copy is asynchronous on the copy stream and the block
  * returns to the ring when it completes.  Records of one contig must be
  * committed in coordinate order (GD_E_UNSORTED); a negative position is
- * GD_E_RANGE (a placed BAM record has POS >= 0). */
+ * GD_E_RANGE (a placed BAM record has POS >= 0).  The order of the commits is
+ * the order of the records; whether it succeeds or not, the block is no longer
+ * the caller's afterwards (a second commit of it is GD_E_STATE). */
 int gd_commit(gd_ctx* ctx, const gd_batch* b, int32_t tid, size_t n_reads, size_t n_ops);
 
 /* Optional: room for n_reads more records / n_ops more CIGAR ops of contig tid in one step.  A producer that knows
