@@ -215,7 +215,7 @@ def host_stream_scope(local_rank, W, Q, mincov, genome=False, reps=3, opts=()):
     torch.cuda.empty_cache()
     nbytes = sum(int(a.nbytes) for rec in recs for a in rec)
     n_reads = sum(int(rec[0].shape[0]) for rec in recs)
-    fillers = min(16, max(2, (os.cpu_count() or 4) // 4))
+    fillers = int(os.environ.get("GOLEFT_BENCH_FILLERS", "0")) or min(16, max(2, (os.cpu_count() or 4) // 4))
     from goleft_amd import _hostlib
     hostlib = _hostlib.load()
 

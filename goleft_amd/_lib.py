@@ -53,6 +53,8 @@ SYMBOLS = {
     "gd_set_contigs": (C.c_int, [_P, C.c_int, _P]),
     "gd_select_contigs": (C.c_int, [_P, C.c_int, _P]),
     "gd_acquire": (C.c_int, [_P, C.c_size_t, C.c_size_t, C.POINTER(GdBatch)]),
+    "gd_check_commits": (C.c_int, [_P]),
+    "gd_get_option": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int64)]),
     "gd_commit": (C.c_int, [_P, C.POINTER(GdBatch), C.c_int32, C.c_size_t, C.c_size_t]),
     "gd_reserve": (C.c_int, [_P, C.c_int32, C.c_size_t, C.c_size_t]),
     "gd_push": (C.c_int, [_P, C.c_int32, _P, _P, _P, _P, _P, C.c_size_t, C.c_size_t]),

@@ -10,7 +10,6 @@
 
 #include <algorithm>
 #include <atomic>
-#include <chrono>
 #include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
@@ -399,7 +398,7 @@ FillPool* ctx_pool(gd_ctx* c)
 
 // gd_index_records_kernel over the reads [r0, r1) of a contig that are resident (or will be, in stream order) on `st`:
 // position index (allocated on first use), spans, and -- check != 0 -- the record checks.
-static int index_records(gd_ctx* c, ContigHost& h, size_t r0, size_t r1, int32_t prev_pos, bool check, hipStream_t st)
+static int index_records(gd_ctx* c, ContigHost& h, size_t r0, size_t r1, int32_t prev_pos, bool check, hipStream_t st, bool committed = false)
 {
     if (r1 <= r0) return GD_OK;
     const size_t n_idx = (size_t)(h.length >> 6) + 2;
@@ -411,6 +410,7 @@ static int index_records(gd_ctx* c, ContigHost& h, size_t r0, size_t r1, int32_t
     j.ridx = idx ? h.ridx : nullptr;
     j.n_idx = (uint32_t)n_idx;
     j.out = c->d_ingest;
+    j.bad_out = c->d_ingest + (committed ? 3 : 0);
     j.r0 = (uint32_t)r0; j.r1 = (uint32_t)r1;
     j.n_reads_total = (uint32_t)r1;
     j.n_ops_total = (uint32_t)std::min<size_t>(h.n_ops, 0xffffffffu);
@@ -429,11 +429,26 @@ static int index_records(gd_ctx* c, ContigHost& h, size_t r0, size_t r1, int32_t
 // copy command (a device-to-host copy queues on the copy engine behind whatever a read in progress has put there).
 static int read_ingest_words(gd_ctx* c, hipStream_t st, uint32_t (&w)[3])
 {
-    hipLaunchKernelGGL(gd::gd_copy_words_kernel, dim3(1), dim3(64), 0, st, c->d_ingest, c->h_ingest, 3u);
+    hipLaunchKernelGGL(gd::gd_copy_words_kernel, dim3(1), dim3(64), 0, st, c->d_ingest, c->h_ingest, 4u);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(st));
     w[0] = c->h_ingest[0]; w[1] = c->h_ingest[1]; w[2] = c->h_ingest[2];
     return GD_OK;
+}
+
+// GD_OPT_COMMIT_CHECK = 1: what the index pass found in the blocks committed since the last look (h_ingest[3], just read
+// on a stream that is behind the copy stream).  A failure stays on the device word: the records are part of the contig,
+// gd_compute keeps refusing until gd_reset.
+static int commit_verdict(gd_ctx* c)
+{
+    c->commit_checks_pending = false;
+    const uint32_t bad = c->h_ingest[3];
+    if (!bad) return GD_OK;
+    c->commit_checks_pending = true;
+    const int lo = c->commit_tid_lo, hi = c->commit_tid_hi;
+    if (bad & 4u) return fail(c, GD_E_RANGE, "contigs %d..%d: a committed record has a negative position (a placed BAM record has POS >= 0); gd_reset", lo, hi);
+    if (bad & 1u) return fail(c, GD_E_UNSORTED, "contigs %d..%d: committed records are not coordinate sorted; gd_reset", lo, hi);
+    return fail(c, GD_E_INVALID, "contigs %d..%d: cigar_off of committed records not monotone; gd_reset", lo, hi);
 }
 
 // The spans the index kernel has measured so far become the look-back of the next gd_compute (verified there as ever).
@@ -520,11 +535,11 @@ static int commit_block(gd_ctx* c, const gd_batch* b, int32_t tid, size_t n_read
     if (int r = set_device(c)) return r;
     if (b->slot < 0 || b->slot >= kRingSlots || c->ring[b->slot].b.pos != b->pos)
         return fail(c, GD_E_INVALID, "batch was not obtained from gd_acquire");
-    if (tid < 0 || (size_t)tid >= c->contigs.size()) return fail(c, GD_E_RANGE, "tid %d out of range", tid);
-    if (n_reads > b->reads_cap || n_ops > b->ops_cap) return fail(c, GD_E_INVALID, "batch overflow");
     RingSlot& s = c->ring[b->slot];
     if (!s.held) return fail(c, GD_E_STATE, "batch was committed already");
     s.held = false;                                      // (whatever happens below, the block goes back to the ring)
+    if (tid < 0 || (size_t)tid >= c->contigs.size()) return fail(c, GD_E_RANGE, "tid %d out of range", tid);
+    if (n_reads > b->reads_cap || n_ops > b->ops_cap) return fail(c, GD_E_INVALID, "batch overflow");
     if (n_reads == 0) return GD_OK;
     ContigHost& h = c->contigs[tid];
     if (h.adopted) return fail(c, GD_E_STATE, "contig %d holds adopted device records", tid);
@@ -539,8 +554,14 @@ static int commit_block(gd_ctx* c, const gd_batch* b, int32_t tid, size_t n_read
     // ~13 ms for the record-by-record loop, which was a quarter of the whole host-to-results path); only a block
     // that fails them is walked again to say where.
     int32_t last = h.last_pos;
+    const bool on_device = !validated && c->commit_check_device && c->h2d_kernel && n_reads >= 4096;
     if (validated) last = b->pos[n_reads - 1];           // (gd_push: its filler threads checked the block while copying)
-    else {
+    else if (on_device) {
+        // the seam with what is there already is looked at here; the rest by the index pass once the block has landed
+        if (b->pos[0] < 0) return fail(c, GD_E_RANGE, "contig %d record %zu: negative position %d (a placed BAM record has POS >= 0)", tid, (size_t)h.n_reads, b->pos[0]);
+        if (b->pos[0] < last) return fail(c, GD_E_UNSORTED, "contig %d record %zu: pos %d < %d", tid, (size_t)h.n_reads, b->pos[0], last);
+        last = b->pos[n_reads - 1];
+    } else {
         const int32_t* __restrict__ const p = b->pos;
         const uint32_t* __restrict__ const o = b->cigar_off;
         // records [a, e): positions non-decreasing (from the record before), offsets non-decreasing
@@ -552,9 +573,9 @@ static int commit_block(gd_ctx* c, const gd_batch* b, int32_t tid, size_t n_read
         };
         uint32_t bad = (uint32_t)(p[0] < 0);                 // sorted: p[0] is the smallest
         FillPool* const pool = n_reads >= (1u << 18) ? ctx_pool(c) : nullptr;
-        if (pool) {                                          // a large block: the context's worker threads, 256 k records each
+        if (pool) {                                          // a large block: the context's worker threads, 64 k records each
             std::vector<FillPool::Item> work;
-            const size_t piece = 1u << 18;
+            const size_t piece = 1u << 16;
             for (size_t a = 0; a < n_reads; a += piece) {
                 const size_t e = std::min(n_reads, a + piece);
                 work.push_back({nullptr, p + a, (e - a) * 4, 0u, 3, a ? p[a - 1] : last});
@@ -624,7 +645,7 @@ static int commit_block(gd_ctx* c, const gd_batch* b, int32_t tid, size_t n_read
         const size_t r0 = h.n_reads;
         const int32_t before = h.last_pos;
         h.n_ops += n_ops;                                  // (index_records reads the contig's totals)
-        const int ri = index_records(c, h, r0, r0 + n_reads, before, false, cs);
+        const int ri = index_records(c, h, r0, r0 + n_reads, before, on_device, cs, true);
         h.n_ops -= n_ops;
         if (ri) return ri;
     }
@@ -638,7 +659,23 @@ static int commit_block(gd_ctx* c, const gd_batch* b, int32_t tid, size_t n_read
     h.n_ops += n_ops;
     h.last_pos = last;
     c->computed = false;
+    if (on_device) {
+        if (!c->commit_checks_pending) { c->commit_tid_lo = c->commit_tid_hi = tid; c->commit_checks_pending = true; }
+        c->commit_tid_lo = std::min(c->commit_tid_lo, tid);
+        c->commit_tid_hi = std::max(c->commit_tid_hi, tid);
+    }
     return GD_OK;
+}
+
+int gd_check_commits(gd_ctx* c)
+{
+    if (!c) return GD_E_INVALID;
+    if (c->cs.pending) return fail(c, GD_E_STATE, "a compute is in flight: gd_compute_finish first");
+    if (!c->commit_checks_pending) return GD_OK;
+    if (int r = set_device(c)) return r;
+    uint32_t w[3];
+    if (int r = read_ingest_words(c, c->copy_stream, w)) return r;
+    return commit_verdict(c);
 }
 
 int gd_push(gd_ctx* c, int32_t tid, const int32_t* pos, const uint16_t* flag, const uint8_t* mapq,
@@ -766,6 +803,7 @@ int gd_reset(gd_ctx* c)
     }
     c->bounds.clear();
     for (auto& s : c->ring) s.held = false;                // (blocks handed out before the reset are not part of anything)
+    c->commit_checks_pending = false;                      // (... and their verdicts go with the records: d_ingest is cleared below)
     c->computed = false;
     c->lookback = c->params.max_span_hint > 0 ? c->params.max_span_hint : kDefaultLookback;
     c->span_forces_long = false;
@@ -888,6 +926,10 @@ int gd_set_option(gd_ctx* c, int option, int64_t value)
         c->push_threads = (int)value;
         break;
     case GD_OPT_INGEST_INDEX: c->ingest_index = value != 0; break;
+    case GD_OPT_COMMIT_CHECK:
+        if (value != 0 && value != 1) return fail(c, GD_E_INVALID, "commit check: 0 (host, in gd_commit) or 1 (device, deferred)");
+        c->commit_check_device = value == 1;
+        break;
     case GD_OPT_INGEST_HYBRID: c->ing_hybrid = value != 0; break;
     case GD_OPT_INGEST_CU_SPLIT:
         if (value < 0 || value > 64 || value == 1) return fail(c, GD_E_INVALID, "ingest CU split: 0 (off) or 2 .. 64");
@@ -922,6 +964,34 @@ int gd_set_option(gd_ctx* c, int option, int64_t value)
     default: return fail(c, GD_E_INVALID, "unknown option %d", option);
     }
     c->computed = false;
+    return GD_OK;
+}
+
+int gd_get_option(gd_ctx* c, int option, int64_t* value)
+{
+    if (!c || !value) return GD_E_INVALID;
+    switch (option) {
+    case GD_OPT_NT_STORES: *value = c->tile_opt & 1; break;
+    case GD_OPT_FAST_KERNEL: *value = c->fast_kernel; break;
+    case GD_OPT_COPY_THREADS: *value = c->ing_copy_threads; break;
+    case GD_OPT_H2D_KERNEL: *value = c->h2d_kernel ? (int64_t)std::max(1u, c->h2d_grid) : 0; break;
+    case GD_OPT_INGEST_CRC: *value = c->ingest_crc; break;
+    case GD_OPT_INGEST_DMA: *value = c->ing_dma_n; break;
+    case GD_OPT_BAM_REFS: *value = c->bam_n_ref; break;
+    case GD_OPT_PUSH_CHUNK: *value = (int64_t)c->push_chunk; break;
+    case GD_OPT_PUSH_THREADS: *value = c->push_threads; break;
+    case GD_OPT_INGEST_INDEX: *value = c->ingest_index; break;
+    case GD_OPT_COMMIT_CHECK: *value = c->commit_check_device; break;
+    case GD_OPT_INGEST_HYBRID: *value = c->ing_hybrid; break;
+    case GD_OPT_INGEST_CU_SPLIT: *value = c->ing_cu_split; break;
+    case GD_OPT_INGEST_RANGE_HINT: *value = (int64_t)c->ing_range_hint; break;
+    case GD_OPT_INFLATE_LDS_PAD: *value = c->inflate_pad; break;
+    case GD_OPT_INGEST_BATCHES: *value = c->ing_batches; break;
+    case GD_OPT_INGEST_WALK_CUS: *value = c->ing_walk_cus; break;
+    case GD_OPT_INFLATE_KERNEL: *value = c->inflate_kernel; break;
+    case GD_OPT_INGEST_PIECE_STREAMS: *value = c->ing_piece_streams; break;
+    default: return fail(c, GD_E_INVALID, "unknown option %d", option);
+    }
     return GD_OK;
 }
 

@@ -156,6 +156,9 @@ struct gd_ctx {
     std::vector<int32_t> selected;      // empty = all
     RingSlot ring[kRingSlots];
     int ring_next = 0;
+    bool commit_check_device = false;   // GD_OPT_COMMIT_CHECK
+    bool commit_checks_pending = false; // blocks whose verdict (d_ingest[3]) nobody has read yet
+    int32_t commit_tid_lo = 0, commit_tid_hi = 0;   // ... the contigs they belong to
     std::string err;
 
     // tuning knobs (gd_set_option; defaults are what the measurements of DESIGN.md section 4 chose)

@@ -112,6 +112,7 @@ struct IndexJob {
     uint32_t* ridx;           // null: no index wanted
     uint32_t n_idx;           // its entries ((length >> 6) + 2); records placed past the contig's end write none
     uint32_t* out;            // [3]
+    uint32_t* bad_out;        // where the check bits are ORed: out (gd_adopt_device) or the word of the committed blocks
     uint32_t r0, r1;
     uint32_t n_reads_total;   // records of the contig once this block is in (offset checks at its last record)
     uint32_t n_ops_total;
@@ -167,7 +168,7 @@ __global__ __launch_bounds__(256) void gd_index_records_kernel(IndexJob j)
         const uint32_t any = (__builtin_amdgcn_ballot_w64((bad & 1u) != 0u) != 0ull ? 1u : 0u) |
                              (__builtin_amdgcn_ballot_w64((bad & 2u) != 0u) != 0ull ? 2u : 0u) |
                              (__builtin_amdgcn_ballot_w64((bad & 4u) != 0u) != 0ull ? 4u : 0u);
-        if (any != 0u && (threadIdx.x & 63u) == 0u) atomicOr(j.out, any);
+        if (any != 0u && (threadIdx.x & 63u) == 0u) atomicOr(j.bad_out, any);
     }
     if (j.walk_ops) {
 #pragma unroll

@@ -18,6 +18,7 @@ K_PREP, K_TILE, K_RUNS, K_EXPAND, K_SCAN, K_CKPT, K_SEQSTATS, K_MDFLAGS, K_INFLA
 # gd_set_option keys (include/goleft_depth.h)
 OPT_NT_STORES, OPT_FAST_KERNEL, OPT_COPY_THREADS, OPT_PUSH_THREADS, OPT_H2D_KERNEL, OPT_PUSH_CHUNK, OPT_BAM_REFS = 3, 5, 6, 7, 8, 9, 10
 OPT_INGEST_INDEX = 14
+OPT_COMMIT_CHECK = 23
 PATH_AUTO, PATH_TILE, PATH_SCATTER, PATH_CHUNK = 0, 1, 2, 3
 # gd_stats.tile_kernel (include/goleft_depth.h GD_TK_*)
 TK_NONE, TK_GENERIC, TK_FAST, TK_FAST_RAW, TK_LONG, TK_SCATTER, TK_SUMS_STREAM, TK_TILE_SUMS, TK_SUMS_STREAM_RAW = range(9)
@@ -525,6 +526,15 @@ class DepthEngine:
         p, n = C.c_void_p(), C.c_int64()
         self._chk(self._lib.gd_device_perbase(self._ctx, tid, C.byref(p), C.byref(n)))
         return p.value, n.value
+
+    def get_option(self, option: int) -> int:
+        v = C.c_int64(0)
+        self._chk(self._lib.gd_get_option(self._ctx, int(option), C.byref(v)))
+        return int(v.value)
+
+    def check_commits(self):
+        """gd_check_commits: the verdict on the blocks committed under OPT_COMMIT_CHECK = 1 (raises GdError)."""
+        self._chk(self._lib.gd_check_commits(self._ctx))
 
     def set_option(self, option: int, value: int):
         """gd_set_option (OPT_* above): tuning / diagnostic switches; results never change."""

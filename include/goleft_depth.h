@@ -213,6 +213,14 @@ enum { GD_OPT_NT_STORES = 3,        /* 1 (default): non-temporal per-base stores
                                        sixth of the bytes through memory and is the slower of the two on an MI355X (DESIGN.md 3.5 has the
                                        measurements and why); it is kept as a second implementation the tests compare the first with.
                                        (ABI 14 had a measurement switch with this number that produced wrong bytes: gone) */
+       GD_OPT_COMMIT_CHECK = 23,      /* where the records of a gd_commit are checked (coordinate order, no negative position, CSR
+                                       offsets non-decreasing): 0 (default) on the host, inside gd_commit -- a second pass by CPU
+                                       threads over a block the producer has just written; 1: by the pass that indexes the block
+                                       on the device once it has landed (it runs anyway), for blocks of 4096 records or more.
+                                       gd_commit then returns before the verdict exists: it comes from gd_check_commits, or
+                                       from the next gd_compute, which refuses to run on records that failed (the context
+                                       needs a gd_reset then).  For producers that are short of CPU -- a decoder's threads --
+                                       and do not need the verdict block by block; gdh_produce_in_place runs this way */
 
        /* ---- MEASUREMENT BUILDS ONLY (the library compiled with -DGD_MEASURE) ----
         * Each of these was built, measured neutral or worse on an MI355X and left at its default (HISTORY.md has the numbers).
@@ -224,6 +232,8 @@ enum { GD_OPT_NT_STORES = 3,        /* 1 (default): non-temporal per-base stores
        GD_OPT_INGEST_BATCHES = 21,    /* inflate launches per fed range: 8 */
        GD_OPT_INGEST_WALK_CUS = 22 }; /* with GD_OPT_INGEST_CU_SPLIT: the record walks on the copy kernel's CUs: 0 */
 int gd_set_option(gd_ctx* ctx, int option, int64_t value);
+/* The value an option has now (a library that scopes a setting puts it back afterwards). */
+int gd_get_option(gd_ctx* ctx, int option, int64_t* value);
 
 /* What is built FROM the records: nothing on the short-read tile path and for the streaming sums (their kernels read the
  * records as they arrived); on the long-read path (GD_PATH_CHUNK, or GD_PATH_AUTO and more than 6 CIGAR ops per record)
@@ -281,6 +291,12 @@ int gd_acquire(gd_ctx* ctx, size_t reads_cap, size_t ops_cap, gd_batch* out);
  * the order of the records; whether it succeeds or not, the block is no longer
  * the caller's afterwards (a second commit of it is GD_E_STATE). */
 int gd_commit(gd_ctx* ctx, const gd_batch* b, int32_t tid, size_t n_reads, size_t n_ops);
+
+/* With GD_OPT_COMMIT_CHECK = 1: waits for the committed blocks to land and returns what their checks found --
+ * GD_OK, GD_E_UNSORTED, GD_E_RANGE (a negative position) or GD_E_INVALID (CSR offsets) -- for everything
+ * committed since the last call (or the last gd_compute / gd_reset).  Nothing to report and nothing waited
+ * for when no block has been checked on the device. */
+int gd_check_commits(gd_ctx* ctx);
 
 /* Optional: room for n_reads more records / n_ops more CIGAR ops of contig tid in one step.  A producer that knows
  * its totals (the .bai metadata pseudo-bin holds a reference's mapped-record count) spares the device arrays their

@@ -154,3 +154,134 @@ def test_csr_offsets_that_dip_exactly_at_a_work_item_cut_are_refused():
         eng.push(0, r.pos, r.flag, r.mapq, r.cigar_off, r.cigar)
         eng.compute()
         assert np.array_equal(eng.perbase(0), po.perbase_c(r, 1, 0, L))
+
+
+def test_a_producer_holds_three_blocks_and_the_fourth_is_refused():
+    """gd_acquire hands out the next block before the last one is committed (include/goleft_depth.h: up to three held,
+    so a decoder's threads write block k+1 while gd_commit validates and sends block k): three blocks filled up front
+    and committed afterwards give the depth of one gd_push; the acquire that comes round to a held block, and the
+    second commit of one block, are GD_E_STATE; n_reads 0 and gd_reset give blocks back."""
+    import ctypes as C
+    import numpy as np
+    from goleft_amd import synth
+    from goleft_amd.engine import DepthEngine, GdError
+    from oracle import pyoracle as po
+    L = 600_000
+    r = po.Reads(*synth.short_reads_numpy(L, synth.n_reads_for(L), 5))
+    want = po.perbase_c(r, 1, 0, L)
+
+    def fill(b, a, e):
+        n, o0, o1 = e - a, int(r.cigar_off[a]), int(r.cigar_off[e])
+        for name, src, ct in (("pos", r.pos[a:e], C.c_int32), ("flag", r.flag[a:e], C.c_uint16), ("mapq", r.mapq[a:e], C.c_uint8),
+                              ("cigar_off", r.cigar_off[a:e + 1] - r.cigar_off[a], C.c_uint32), ("cigar", r.cigar[o0:o1], C.c_uint32)):
+            src = np.ascontiguousarray(src)
+            C.memmove(getattr(b, name), src.ctypes.data, src.nbytes)
+        return n, o1 - o0
+
+    cuts = [0, r.n // 3, 2 * r.n // 3, r.n]
+    with DepthEngine(0) as eng:
+        eng.set_params(window_size=1000)
+        eng.set_contigs([L])
+        held = []
+        for a, e in zip(cuts[:-1], cuts[1:]):
+            b = eng.acquire(e - a, int(r.cigar_off[e] - r.cigar_off[a]))
+            held.append((b, fill(b, a, e)))
+        assert len({b.slot for b, _ in held}) == 3
+        spare = eng.acquire(16, 16)                          # the fourth slot
+        with pytest.raises(GdError) as ei:
+            eng.acquire(16, 16)                              # comes round to the first, still held
+        assert ei.value.status == -4, ei.value.status
+        eng.commit(spare, 0, 0, 0)                           # given back unused
+        for b, (n, m) in held:
+            eng.commit(b, 0, n, m)
+        with pytest.raises(GdError) as ei:
+            eng.commit(held[0][0], 0, *held[0][1])
+        assert ei.value.status == -4, ei.value.status
+        eng.compute()
+        assert np.array_equal(eng.perbase(0), want)
+        # blocks held across a reset are the ring's again
+        for _ in range(3):
+            eng.acquire(16, 16)
+        eng.reset()
+        for _ in range(2):
+            for a, e in zip(cuts[:-1], cuts[1:]):
+                b = eng.acquire(e - a, int(r.cigar_off[e] - r.cigar_off[a]))
+                eng.commit(b, 0, *fill(b, a, e))
+            eng.compute()
+            assert np.array_equal(eng.perbase(0), want)
+            eng.reset()
+
+
+def test_commits_checked_on_the_device_give_the_host_checks_answers_later():
+    """GD_OPT_COMMIT_CHECK = 1: gd_commit leaves a block's checks (coordinate order, negative positions, CSR offsets) to
+    the pass that indexes it on the device; gd_check_commits -- or the next gd_compute -- gives the answer the host
+    check gives inside gd_commit, for a fault in the middle of a block, at a block's first record (the seam: at once)
+    and at its last, and keeps giving it until gd_reset; good records give the depth of a gd_push; the option reads
+    back, and gdh_produce_in_place leaves it as it found it."""
+    import ctypes as C
+    import numpy as np
+    from goleft_amd import _hostlib, synth
+    from goleft_amd.engine import DepthEngine, GdError, OPT_COMMIT_CHECK
+    from oracle import pyoracle as po
+    L = 400_000
+    r = po.Reads(*synth.short_reads_numpy(L, synth.n_reads_for(L), 3))
+    want = po.perbase_c(r, 1, 0, L)
+    cuts = [0, r.n // 2, r.n]
+    assert r.n // 2 >= 4096
+
+    def feed(eng, pos, off, tid=0):
+        for a, e in zip(cuts[:-1], cuts[1:]):
+            o0, o1 = int(off[a]), int(r.cigar_off[e])
+            b = eng.acquire(e - a, o1 - int(r.cigar_off[a]))
+            for name, src in (("pos", pos[a:e]), ("flag", r.flag[a:e]), ("mapq", r.mapq[a:e]),
+                              ("cigar_off", off[a:e + 1] - r.cigar_off[a]), ("cigar", r.cigar[int(r.cigar_off[a]):o1])):
+                src = np.ascontiguousarray(src)
+                C.memmove(getattr(b, name), src.ctypes.data, src.nbytes)
+            eng.commit(b, tid, e - a, o1 - int(r.cigar_off[a]))
+
+    with DepthEngine(0) as eng:
+        eng.set_params(window_size=1000)
+        eng.set_contigs([L, L])
+        assert eng.get_option(OPT_COMMIT_CHECK) == 0
+        eng.set_option(OPT_COMMIT_CHECK, 1)
+        assert eng.get_option(OPT_COMMIT_CHECK) == 1
+        eng.check_commits()                                  # nothing committed: nothing to say
+        feed(eng, r.pos, r.cigar_off)
+        eng.check_commits()
+        eng.compute()
+        assert np.array_equal(eng.perbase(0), want)
+        mid = cuts[1] + 1000
+        for what, status in (("order", -7), ("negative", -5), ("offsets", -1), ("last", -7)):
+            pos, off = r.pos.copy(), r.cigar_off.copy()
+            if what == "order":
+                pos[mid] = pos[mid - 1] - 1
+            elif what == "negative":
+                pos[0] = 0
+                pos[1:3] = -1                                # (out of order as well: the negative position is what is reported)
+            elif what == "offsets":
+                off[mid] = off[mid - 1] - 1
+            else:
+                pos[r.n - 1] = pos[r.n - 2] - 1
+            eng.reset()
+            feed(eng, pos, off, tid=1)                       # gd_commit has nothing to say yet
+            for _ in range(2):
+                with pytest.raises(GdError) as ei:
+                    eng.check_commits()
+                assert ei.value.status == status, (what, ei.value.status)
+            with pytest.raises(GdError):
+                eng.compute()
+        # the seam with the records in front is the host's business even then
+        eng.reset()
+        pos = r.pos.copy()
+        pos[cuts[1]] = pos[cuts[1] - 1] - 1
+        with pytest.raises(GdError) as ei:
+            feed(eng, pos, r.cigar_off)
+        assert ei.value.status == -7
+        eng.reset()
+        eng.set_option(OPT_COMMIT_CHECK, 0)
+        host = _hostlib.load()
+        rc = host.gdh_produce_in_place(eng._ctx, 0, r.pos.ctypes.data, r.flag.ctypes.data, r.mapq.ctypes.data,
+                                       r.cigar_off.ctypes.data, r.cigar.ctypes.data, r.n, r.n_ops, 4, 8192)
+        assert rc == 0 and eng.get_option(OPT_COMMIT_CHECK) == 0
+        eng.compute()
+        assert np.array_equal(eng.perbase(0), want)

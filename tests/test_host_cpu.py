@@ -661,3 +661,12 @@ def test_rccl_stand_in_of_the_gather_tests_builds_and_exports_what_the_library_b
     names = subprocess.check_output(["nm", "-D", "--defined-only", so]).decode()
     for n in bound:
         assert re.search(r"\bT %s\b" % n, names), n
+
+
+def test_graft_entry_build_is_what_the_driver_runs():
+    """__graft_entry__.build() -- the driver's "does it build" step -- compiles everything (make: up to date here),
+    builds the checker and holds the library's ABI version against include/goleft_depth.h."""
+    import sys
+    sys.path.insert(0, ROOT)
+    import __graft_entry__
+    __graft_entry__.build()
