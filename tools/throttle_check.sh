@@ -1,0 +1,31 @@
+#!/bin/bash
+# Does the container's CPU quota (cpu.max) stop the file -> BED read?  The genome BAM of bench.py's bam_file_scope, the CLI three
+# times, cgroup throttle counters around every run.   gpurun --timeout 1500 -- 'bash tools/throttle_check.sh'
+R=${GRAFT_REPO_ROOT:-/root/repo}
+export TMPDIR=/tmp
+D=$(mktemp -d /tmp/thr.XXXX)
+LENS=$(python3 -c "import sys; sys.path.insert(0,'$R'); from goleft_amd import synth; print(','.join(str(x) for x in synth.HG19_LENGTHS))")
+cat /sys/fs/cgroup/cpu.max
+s=$SECONDS
+$R/goleft_amd/synth-bam $D/synth.bam chrS $LENS 30 20 > $D/info.json || exit 1
+echo "synth-bam $((SECONDS-s)) s"; ls -l $D | head
+cat $D/synth.bam > /dev/null
+stat() { awk '/nr_throttled|throttled_usec|usage_usec/ {printf "%s ", $2}' /sys/fs/cgroup/cpu.stat; }
+for i in 1 2 3; do
+  sleep 2
+  a=($(stat)); t0=$(date +%s%N)
+  GOLEFT_DEPTH_TIMING=1 $R/goleft_amd/goleft-depth depth -w 1000 -p 0 -r $D/synth.fa --prefix $D/out $D/synth.bam 2> $D/err.$i > /dev/null &
+  pid=$!
+  # per-thread CPU time (utime + stime, clock ticks) of the CLI, sampled until it exits: the last sample is kept
+  while kill -0 $pid 2>/dev/null; do
+    for t in /proc/$pid/task/*; do awk -v t=${t##*/} '{n=split($0,f," "); print t, f[n-38]+f[n-37]}' $t/stat 2>/dev/null; done > $D/threads.tmp
+    [ -s $D/threads.tmp ] && mv $D/threads.tmp $D/threads.$i
+    sleep 0.1
+  done
+  wait $pid
+  t1=$(date +%s%N); b=($(stat))
+  echo "run $i: wall $(( (t1 - t0) / 1000000 )) ms, cpu $(( (${b[0]} - ${a[0]}) / 1000 )) ms, throttled ${a[1]} -> ${b[1]} periods, $(( (${b[2]} - ${a[2]}) / 1000 )) ms"
+  echo "  threads at the last sample (ticks of 10 ms): $(sort -k2 -n -r $D/threads.$i | awk '{printf "%s ", $2}')"
+done
+grep -h "^{" $D/err.3 | head -5
+rm -rf $D
