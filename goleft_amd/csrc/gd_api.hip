@@ -149,6 +149,7 @@ void gd_destroy(gd_ctx* c)
     for (auto& evs : c->ing_dma_ev) for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
     for (auto& b : c->ing_bufs) b.drop_all();
     if (c->h_walk) (void)hipHostFree(c->h_walk);
+    if (c->d_rectab) (void)hipFree(c->d_rectab);
     if (c->h_ingest) (void)hipHostFree(c->h_ingest);
     for (auto& h : c->contigs) free_contig(h);
     for (auto& s : c->ring) {

@@ -262,6 +262,7 @@ struct gd_ctx {
     FillPool* pool = nullptr; int pool_workers = 0;    // host worker threads (gd_push fills, gd_commit validates), created on first use
     size_t push_chunk = 1u << 20;                      // GD_OPT_PUSH_CHUNK: records per staging block of gd_push                             // GD_OPT_PUSH_THREADS: threads of gd_push filling a ring block
     uint32_t* d_scan_tmp = nullptr; size_t cap_scan_tmp = 0;   // launch_scan: block totals
+    void* d_rectab = nullptr; size_t cap_rectab = 0;           // ... and the record table the counting walk leaves for the extraction (device, grow-only)
     uint8_t* h_walk = nullptr; size_t cap_walk = 0;            // gd_ingest_decode: per-segment tables of the record walk (page-locked host memory
                                                                // the walk kernels read and write over the link: no copy command)
     uint32_t* h_ingest = nullptr;                              // page-locked: d_ingest's words as the host reads them (gd_copy_words_kernel)

@@ -11,6 +11,9 @@
 //                          last position, a sortedness flag; stops at the contig's end
 //   gd_bam_extract_kernel  the same walk, writing pos / flag / mapq / cigar_off / cigar at the
 //                          segment's base (exclusive prefix sums of the counts, host side)
+//   gd_bam_extract_tab_kernel  (round 6) the counting walk leaves WHERE every record starts and how many ops
+//                          its segment holds in front of it; the extraction is then a thread per record -- no
+//                          chain, no LDS, no barrier -- and the second walk is not run
 // Only the fields `samtools depth -Q q` consults are extracted.
 #pragma once
 
@@ -40,6 +43,11 @@ struct BamSegJob {
     uint8_t*  mapq;
     uint32_t* cigar_off;           // [n_records + 1]; [n_records] is written by the host
     uint32_t* cigar;
+    // the record table (null: none).  Written by the count pass, read by gd_bam_extract_tab_kernel: two words per record,
+    // {start - seg_beg[s], ops of the segment in front of it}, segment s at entry tab_base[s] (room for (seg_end - seg_beg)
+    // / 36 + 1 records: a record is 36 bytes at least; the host keeps segments under 4 GB)
+    uint32_t* tab;
+    const uint64_t* tab_base;      // [n_seg]
 };
 
 __device__ __forceinline__ uint32_t ld32(const uint8_t* p)
@@ -192,7 +200,21 @@ __global__ __launch_bounds__(64) void gd_bam_walk_kernel(BamSegJob j)
         if (lane < n) {
             const uint64_t o = s_off[lane];
             r = j.data + o + 4;
-            const bool ok = bam_record_cigar(r, ld32(j.data + o), &cg, &nc);
+            // the counting walk needs the op count alone, and the record's fixed fields and stored CIGAR are nearly always
+            // inside the window it was found in: read there, it costs no trip to memory (block_size, refID, POS and
+            // l_read_name lie inside by the chain's own condition); the CG:B,I placeholder and records that leave the
+            // window go the long way
+            const uint32_t rel = (uint32_t)(o - wbase);
+            const uint32_t l_read_name = s_win[rel + 12u];
+            bool ok, near = false;
+            if (!EXTRACT && rel + 44u + l_read_name <= (uint32_t)BW_WIN) {
+                const uint32_t block_size = ld32(s_win + rel);
+                const uint32_t n_cigar = (uint32_t)s_win[rel + 16u] | ((uint32_t)s_win[rel + 17u] << 8);
+                const uint32_t c0 = ld32(s_win + rel + 36u + l_read_name), c1 = ld32(s_win + rel + 40u + l_read_name);
+                const bool placeholder = n_cigar == 2u && (c0 & 0xfu) == 4u && (c0 >> 4) == ld32(s_win + rel + 20u) && (c1 & 0xfu) == 3u;
+                if (!placeholder) { near = true; ok = 32ull + l_read_name + 4ull * n_cigar <= block_size; nc = n_cigar; }
+            }
+            if (!near) ok = bam_record_cigar(r, ld32(j.data + o), &cg, &nc);
             s_bad[lane] = ok ? 0u : 1u;
             s_nc[lane] = ok ? nc : 0u;
         }
@@ -206,6 +228,10 @@ __global__ __launch_bounds__(64) void gd_bam_walk_kernel(BamSegJob j)
         }
         if (bad) {                                                          // a corrupt record: the host refuses the file
             if (lane == 0) { fl |= 2u; s_done = 1; }
+        } else if (!EXTRACT && j.tab && lane < n) {
+            uint32_t* const e = j.tab + 2ull * (j.tab_base[s] + ri + lane);
+            e[0] = (uint32_t)(s_off[lane] - j.seg_beg[s]);
+            e[1] = (uint32_t)(oi + before);
         } else if (EXTRACT && lane < n) {
             const uint64_t rr = ri + lane, oo = oi + before;
             j.pos[rr] = (int32_t)ld32(r + 4);
@@ -226,6 +252,31 @@ __global__ __launch_bounds__(64) void gd_bam_walk_kernel(BamSegJob j)
         j.first_pos[s] = first;
         j.last_pos[s] = last;
         j.flags[s] = fl;
+    }
+}
+
+// A THREAD PER RECORD over the table the counting walk left: a workgroup per anchor segment (its record count, bases and
+// table entry come from the walk's tables), the fields and the CIGAR (the stored one or the CG tag's, found again) copied
+// to the contig's arrays.  The records of neighbouring threads are neighbours in the stream and in the output.
+__global__ __launch_bounds__(256) void gd_bam_extract_tab_kernel(BamSegJob j)
+{
+    const uint32_t s = blockIdx.x;
+    if (s >= j.n_seg) return;
+    const uint32_t n = j.n_rec[s];
+    const uint64_t beg = j.seg_beg[s], rb = j.rec_base[s], ob = j.op_base[s];
+    const uint32_t* const tab = j.tab + 2ull * j.tab_base[s];
+    for (uint32_t k = threadIdx.x; k < n; k += 256u) {
+        const uint64_t o = beg + tab[2u * k];
+        const uint8_t* const r = j.data + o + 4;
+        const uint8_t* cg = nullptr;
+        uint32_t nc = 0;
+        (void)bam_record_cigar(r, ld32(j.data + o), &cg, &nc);      // (the walk has seen it succeed)
+        const uint64_t rr = rb + k, oo = ob + tab[2u * k + 1u];
+        j.pos[rr] = (int32_t)ld32(r + 4);
+        j.mapq[rr] = r[9];
+        j.flag[rr] = (uint16_t)((uint32_t)r[14] | ((uint32_t)r[15] << 8));
+        j.cigar_off[rr] = (uint32_t)oo;
+        for (uint32_t q = 0; q < nc; ++q) j.cigar[oo + q] = ld32(cg + 4 * (uint64_t)q);
     }
 }
 

@@ -34,7 +34,21 @@ def _lib():
     lib.emul_bam_walk.argtypes = ([C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int32, C.c_int32] + [C.c_void_p] * 7 +
                                   [C.c_uint64, C.c_uint64] + [C.c_void_p] * 5)
     lib.emul_bam_walk.restype = C.c_int
+    lib.emul_bam_walk_mode(C.c_int(MODE))
     return lib
+
+
+# how the records are extracted: 1 (what gd_api_ingest.inc does) the counting walk leaves a table of record starts and
+# gd_bam_extract_tab_kernel takes a thread per record; 0 the second walk (kept for segments of 4 GB and more)
+MODE = 1
+
+
+@pytest.fixture(params=[1, 0], ids=["record-table", "second-walk"])
+def both_extractions(request):
+    global MODE
+    MODE = request.param
+    yield request.param
+    MODE = 1
 
 
 def record_starts(d: bytes):
@@ -95,7 +109,7 @@ def make_stream(tmp_path, seed, long_cigars=False):
 
 
 @pytest.mark.parametrize("long_cigars", [False, True])
-def test_walk_delivers_the_records(tmp_path, long_cigars):
+def test_walk_delivers_the_records(tmp_path, long_cigars, both_extractions):
     data, contigs, reads = make_stream(tmp_path, 1, long_cigars)
     starts, n_ref = record_starts(data)
     for tid in (0, 2):

@@ -14,10 +14,10 @@ stat() { awk '/nr_throttled|throttled_usec|usage_usec/ {printf "%s ", $2}' /sys/
 for i in 1 2 3; do
   sleep 2
   a=($(stat)); t0=$(date +%s%N)
-  GOLEFT_DEPTH_TIMING=1 $R/goleft_amd/goleft-depth depth -w 1000 -p 0 -r $D/synth.fa --prefix $D/out $D/synth.bam 2> $D/err.$i > /dev/null &
+  GOLEFT_DEPTH_TIMING=1 GOLEFT_INGEST_TIMING=1 $R/goleft_amd/goleft-depth depth -w 1000 -p 0 -r $D/synth.fa --prefix $D/out $D/synth.bam 2> $D/err.$i > /dev/null &
   pid=$!
   # per-thread CPU time (utime + stime, clock ticks) of the CLI, sampled until it exits: the last sample is kept
-  while kill -0 $pid 2>/dev/null; do
+  while [ -n "$SAMPLE" ] && kill -0 $pid 2>/dev/null; do
     for t in /proc/$pid/task/*; do awk -v t=${t##*/} '{n=split($0,f," "); print t, f[n-38]+f[n-37]}' $t/stat 2>/dev/null; done > $D/threads.tmp
     [ -s $D/threads.tmp ] && mv $D/threads.tmp $D/threads.$i
     sleep 0.1
@@ -25,7 +25,13 @@ for i in 1 2 3; do
   wait $pid
   t1=$(date +%s%N); b=($(stat))
   echo "run $i: wall $(( (t1 - t0) / 1000000 )) ms, cpu $(( (${b[0]} - ${a[0]}) / 1000 )) ms, throttled ${a[1]} -> ${b[1]} periods, $(( (${b[2]} - ${a[2]}) / 1000 )) ms"
-  echo "  threads at the last sample (ticks of 10 ms): $(sort -k2 -n -r $D/threads.$i | awk '{printf "%s ", $2}')"
+  [ -n "$SAMPLE" ] && echo "  threads at the last sample (ticks of 10 ms): $(sort -k2 -n -r $D/threads.$i | awk '{printf "%s ", $2}')"
+  grep -h "^{" $D/err.$i | grep -o '"lib_count_walk_s[^}]*\|"read_s[^,]*'  | tr "\n" " "; echo
 done
-grep -h "^{" $D/err.3 | head -5
+if [ -n "$PROF" ]; then     # PROF=tag: one more run under rocprofv3 --kernel-trace --stats; the ingest kernels' rows are kept
+  ( cd /tmp && GOLEFT_SLOW_EXIT=1 rocprofv3 --kernel-trace --stats --output-format csv -d $D/prof -o x -- $R/goleft_amd/goleft-depth depth -w 1000 -p 0 -r $D/synth.fa --prefix $D/out $D/synth.bam > $D/prof.log 2>&1 ); tail -3 $D/prof.log
+  f=$(find $D/prof -name "*kernel_stats.csv" | head -1)
+  mkdir -p $R/gpurun_out; [ -n "$f" ] && cp $f $R/gpurun_out/${PROF}_genome_read_kernel_stats.csv && cut -d, -f1-6 $f | cut -c1-150 | head -14
+fi
+sha256sum $D/out.depth.bed $D/out.callable.bed | cut -c1-16
 rm -rf $D
