@@ -11,7 +11,7 @@ $R/goleft_amd/synth-bam $D/synth.bam chrS $LENS 30 20 > $D/info.json || exit 1
 echo "synth-bam $((SECONDS-s)) s"; ls -l $D | head
 cat $D/synth.bam > /dev/null
 stat() { awk '/nr_throttled|throttled_usec|usage_usec/ {printf "%s ", $2}' /sys/fs/cgroup/cpu.stat; }
-for i in 1 2 3; do
+for i in ${RUNS:-1 2 3}; do
   sleep 2
   a=($(stat)); t0=$(date +%s%N)
   GOLEFT_DEPTH_TIMING=1 GOLEFT_INGEST_TIMING=1 $R/goleft_amd/goleft-depth depth -w 1000 -p 0 -r $D/synth.fa --prefix $D/out $D/synth.bam 2> $D/err.$i > /dev/null &
@@ -26,7 +26,7 @@ for i in 1 2 3; do
   t1=$(date +%s%N); b=($(stat))
   echo "run $i: wall $(( (t1 - t0) / 1000000 )) ms, cpu $(( (${b[0]} - ${a[0]}) / 1000 )) ms, throttled ${a[1]} -> ${b[1]} periods, $(( (${b[2]} - ${a[2]}) / 1000 )) ms"
   [ -n "$SAMPLE" ] && echo "  threads at the last sample (ticks of 10 ms): $(sort -k2 -n -r $D/threads.$i | awk '{printf "%s ", $2}')"
-  grep -h "^{" $D/err.$i | grep -o '"lib_count_walk_s[^}]*\|"read_s[^,]*'  | tr "\n" " "; echo
+  grep -h "^{" $D/err.$i | grep -o '"lib_wait_link_s[^,]*\|"lib_read_s[^,]*\|"lib_count_walk_s[^,]*\|"read_s[^,]*'  | tr "\n" " "; echo
 done
 if [ -n "$PROF" ]; then     # PROF=tag: one more run under rocprofv3 --kernel-trace --stats; the ingest kernels' rows are kept
   ( cd /tmp && GOLEFT_SLOW_EXIT=1 rocprofv3 --kernel-trace --stats --output-format csv -d $D/prof -o x -- $R/goleft_amd/goleft-depth depth -w 1000 -p 0 -r $D/synth.fa --prefix $D/out $D/synth.bam > $D/prof.log 2>&1 ); tail -3 $D/prof.log
