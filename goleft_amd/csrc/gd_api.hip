@@ -254,8 +254,11 @@ int gd_set_contigs(gd_ctx* c, int n, const int64_t* lengths)
     c->lookback = c->params.max_span_hint > 0 ? c->params.max_span_hint : kDefaultLookback;
     c->span_forces_long = false;
     HIPCHK(c, hipMemsetAsync(c->d_ingest, 0, 4 * sizeof(uint32_t), c->stream));   // spans of records that are gone
+    HIPCHK(c, hipStreamSynchronize(c->stream));            // (the next block's index pass runs on the copy stream: not before this)
     c->ingest_span = 0;
     c->ingest_span_dirty = false;
+    for (auto& s : c->ring) s.held = false;
+    c->commit_checks_pending = false;
     return GD_OK;
 }
 
@@ -809,6 +812,7 @@ int gd_reset(gd_ctx* c)
     c->lookback = c->params.max_span_hint > 0 ? c->params.max_span_hint : kDefaultLookback;
     c->span_forces_long = false;
     HIPCHK(c, hipMemsetAsync(c->d_ingest, 0, 4 * sizeof(uint32_t), c->stream));   // spans of records that are gone
+    HIPCHK(c, hipStreamSynchronize(c->stream));            // (the next block's index pass runs on the copy stream: not before this)
     c->ingest_span = 0;
     c->ingest_span_dirty = false;
     return GD_OK;
