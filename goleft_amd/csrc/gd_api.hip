@@ -126,7 +126,7 @@ int gd_create(int device_id, gd_ctx** out)
     return GD_OK;
 }
 
-namespace { void drop_pool(gd_ctx* c); }
+namespace { static void drop_pool(gd_ctx* c); }
 
 void gd_destroy(gd_ctx* c)
 {
@@ -384,10 +384,10 @@ struct FillPool {
     }
 };
 
-void drop_pool(gd_ctx* c) { delete c->pool; c->pool = nullptr; c->pool_workers = 0; }
+static void drop_pool(gd_ctx* c) { delete c->pool; c->pool = nullptr; c->pool_workers = 0; }
 
 // the context's pool, with push_threads - 1 workers (the calling thread works too)
-FillPool* ctx_pool(gd_ctx* c)
+static FillPool* ctx_pool(gd_ctx* c)
 {
     const int want = c->push_threads - 1;
     if (c->pool && c->pool_workers != want) { delete c->pool; c->pool = nullptr; }

@@ -41,6 +41,20 @@ def test_device_abi_exports_every_declared_symbol():
     assert lib.gd_strerror(-7) == b"records not coordinate sorted"
 
 
+def test_device_library_exports_no_c_symbol_the_header_does_not_declare():
+    """The other direction: a helper defined inside the extern "C" block without `static` is an exported C symbol of the
+    library (round 6 found ctx_pool, drop_pool, rccl and rccl_in_process there).  The mangled names are the host stubs
+    of the kernels, which the HIP runtime needs."""
+    import shutil
+    import subprocess
+    from goleft_amd import _lib
+    nm = shutil.which("nm") or "/opt/rocm/lib/llvm/bin/llvm-nm"
+    out = subprocess.check_output([nm, "-D", "--defined-only", _lib.SO_PATH]).decode()
+    exported = sorted(ln.split()[2] for ln in out.splitlines() if len(ln.split()) == 3 and ln.split()[1] == "T" and not ln.split()[2].startswith("_Z"))
+    extra = [n for n in exported if n not in _declared("goleft_depth.h", "gd_") and n not in ("_init", "_fini")]
+    assert extra == [], extra
+
+
 def test_host_abi_exports_every_declared_symbol(hostlib):
     lib = hostlib.load()
     names = _declared("goleft_depth_host.h", "gdh_")
