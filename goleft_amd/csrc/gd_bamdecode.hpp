@@ -265,7 +265,7 @@ __global__ __launch_bounds__(256) void gd_bam_extract_tab_kernel(BamSegJob j)
     const uint32_t n = j.n_rec[s];
     const uint64_t beg = j.seg_beg[s], rb = j.rec_base[s], ob = j.op_base[s];
     const uint32_t* const tab = j.tab + 2ull * j.tab_base[s];
-    for (uint32_t k = threadIdx.x; k < n; k += 256u) {
+    for (uint32_t k = threadIdx.x; k < n; k += blockDim.x) {
         const uint64_t o = beg + tab[2u * k];
         const uint8_t* const r = j.data + o + 4;
         const uint8_t* cg = nullptr;

@@ -50,7 +50,8 @@ extern "C" int emul_bam_walk(const uint8_t* data, uint64_t n_bytes, const uint64
     j.rec_base = rbase.data(); j.op_base = obase.data();
     j.pos = reinterpret_cast<int32_t*>(g_pos.p + 4); j.flag = reinterpret_cast<uint16_t*>(g_flag.p + 2); j.mapq = g_mapq.p + 1;
     j.cigar_off = reinterpret_cast<uint32_t*>(g_off.p + 4); j.cigar = reinterpret_cast<uint32_t*>(g_cig.p + 4);
-    if (g_tab) { for (unsigned b = 0; b < n_seg; ++b) emul::run(body_extract_tab, 256, b); }
+    // (gd_bam_extract_tab_kernel strides by its block size: 256 on the device, one wave's worth of fibers here)
+    if (g_tab) { blockDim.x = 64; for (unsigned b = 0; b < n_seg; ++b) emul::run(body_extract_tab, 64, b); }
     else { for (unsigned b = 0; b < n_seg; ++b) emul::run(body_extract, 64, b); }
     memcpy(pos, j.pos, N * 4); memcpy(flag, j.flag, N * 2); memcpy(mapq, j.mapq, N);
     memcpy(cigar_off, j.cigar_off, N * 4); memcpy(cigar, j.cigar, M * 4);

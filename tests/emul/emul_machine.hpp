@@ -14,7 +14,7 @@
 
 struct Dim3 { unsigned x = 1, y = 1, z = 1; };
 static Dim3 threadIdx, blockIdx;                           // of the running fiber (set at every switch)
-static Dim3 gridDim;                                       // set by whoever launches a kernel that asks for it
+static Dim3 gridDim, blockDim;                             // set by whoever launches a kernel that asks for them
 namespace emul {
 // A lane waits for a generation counter to move on: the workgroup's (a barrier) or its wave's (a ballot -- the 64 lanes of a
 // wave are in step on the machine, the waves of a workgroup are not: a kernel whose waves run different loops -- the
