@@ -471,8 +471,9 @@ int gd_inflate_bgzf(gd_ctx* ctx, const uint8_t* data, size_t n_bytes, size_t n_m
  * (coffset << 16 | uoffset, as stored in the .bai) of record starts inside the range,
  * strictly ascending, anchors[0] = the contig's first record -- the .bai linear index
  * provides one per 16 kb of reference (SAMv1 5.2).  The device inflates the members (one
- * lane each), one lane per anchor walks the records up to the next anchor (a record of
- * another reference ends the walk) and {pos, flag, mapq, CIGAR (CG:B,I resolved)} become
+ * lane each), one wave per anchor walks the records up to the next anchor (a record of
+ * another reference ends the walk; it counts them and notes where each starts), a thread
+ * per record then extracts, and {pos, flag, mapq, CIGAR (CG:B,I resolved)} become
  * the contig's record arrays in HBM, replacing what it held -- the state gd_push / gd_commit
  * would have left, without any decode on the host.  Every member's CRC32 is verified.
  * Errors: GD_E_INVALID (corrupt member or record, CRC mismatch, anchor that is not a record
@@ -532,7 +533,7 @@ int gd_ingest_decode_part(gd_ctx* ctx, int32_t tid, int32_t ref_id, const uint64
 /* Where the device BAM read of this context has spent its wall clock so far, in seconds (measurement only):
  * out[0] reading into the staging buffers, [1] waiting for a staging buffer to leave for the device, [2] gd_ingest_begin
  * (allocations, member table), [3] decode: waiting for the inflate launches, [4] decode: the counting walk, [5] decode:
- * allocating the contig's arrays, [6] decode: the extracting walk.  Fills min(n, 7) values. */
+ * allocating the contig's arrays, [6] decode: the extraction (a thread per record over the walk's table).  Fills min(n, 7) values. */
 int gd_ingest_timing(gd_ctx* ctx, double* out, size_t n);
 int gd_ingest_abort(gd_ctx* ctx);
 /* Page-locked host memory for the byte range handed to gd_ingest_bgzf (read the file
