@@ -339,6 +339,10 @@ struct FillPool {
         }
     }
     std::atomic<int> active{0};
+    // how long a worker spins for the next batch before it sleeps: gd_push's blocks follow each other within a fraction of a
+    // millisecond (20 000); the pieces of a device BAM read are 2 ms apart, and fifteen workers spinning through that use up
+    // CPU time a container's quota then takes from the threads that read the file (gd_ingest_feed_fd sets 500)
+    std::atomic<int> spin_limit{20000};
     void start(int n)
     {
         for (int k = 0; k < n; ++k)
@@ -347,7 +351,7 @@ struct FillPool {
                 for (;;) {
                     // the next block of a push follows within a fraction of a millisecond: spin that long before sleeping
                     // (a condition-variable wake-up costs tens of microseconds per worker and block)
-                    for (int spin = 0; spin < 20000 && gen.load(std::memory_order_relaxed) == seen && !quit.load(std::memory_order_relaxed); ++spin)
+                    for (int spin = 0; spin < spin_limit.load(std::memory_order_relaxed) && gen.load(std::memory_order_relaxed) == seen && !quit.load(std::memory_order_relaxed); ++spin)
                         __builtin_ia32_pause();
                     {
                         std::unique_lock<std::mutex> lk(mu);
@@ -931,6 +935,10 @@ int gd_set_option(gd_ctx* c, int option, int64_t value)
         c->push_threads = (int)value;
         break;
     case GD_OPT_INGEST_INDEX: c->ingest_index = value != 0; break;
+    case GD_OPT_INGEST_COPY_GRID:
+        if (value < 1 || value > 4096) return fail(c, GD_E_INVALID, "ingest copy grid: 1 .. 4096 workgroups");
+        c->ing_copy_grid = (unsigned)value;
+        break;
     case GD_OPT_COMMIT_CHECK:
         if (value != 0 && value != 1) return fail(c, GD_E_INVALID, "commit check: 0 (host, in gd_commit) or 1 (device, deferred)");
         c->commit_check_device = value == 1;
@@ -987,6 +995,7 @@ int gd_get_option(gd_ctx* c, int option, int64_t* value)
     case GD_OPT_PUSH_THREADS: *value = c->push_threads; break;
     case GD_OPT_INGEST_INDEX: *value = c->ingest_index; break;
     case GD_OPT_COMMIT_CHECK: *value = c->commit_check_device; break;
+    case GD_OPT_INGEST_COPY_GRID: *value = c->ing_copy_grid; break;
     case GD_OPT_INGEST_HYBRID: *value = c->ing_hybrid; break;
     case GD_OPT_INGEST_CU_SPLIT: *value = c->ing_cu_split; break;
     case GD_OPT_INGEST_RANGE_HINT: *value = (int64_t)c->ing_range_hint; break;

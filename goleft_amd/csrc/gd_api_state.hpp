@@ -247,6 +247,7 @@ struct gd_ctx {
     int ing_walk_cus = 0;
     hipEvent_t ing_walk_ev = nullptr;
     int ing_batches = 8;                                // GD_OPT_INGEST_BATCHES
+    unsigned ing_copy_grid = 16;                        // GD_OPT_INGEST_COPY_GRID: workgroups of the copy kernel that pulls a staged piece over the link
     hipStream_t ing_hp = nullptr;                       // GD_OPT_INGEST_DMA 0: the piece leaves with a copy kernel on a high-priority stream
     hipStream_t ing_stream[8] = {};                     // inflate launches rotate over these (two pending ranges x 4)
     unsigned ing_launch_seq = 0;

@@ -581,6 +581,7 @@ static int configure_shards(const std::vector<int>& devices, EarlyContexts* earl
         if (getenv("GOLEFT_INGEST_BATCHES")) GDCHK_ON(sh.ctx, gd_set_option(sh.ctx, GD_OPT_INGEST_BATCHES, env_int("GOLEFT_INGEST_BATCHES", 8)));
         if (getenv("GOLEFT_INGEST_WALK_CUS")) GDCHK_ON(sh.ctx, gd_set_option(sh.ctx, GD_OPT_INGEST_WALK_CUS, env_int("GOLEFT_INGEST_WALK_CUS", 0)));
         if (getenv("GOLEFT_INGEST_HYBRID")) GDCHK_ON(sh.ctx, gd_set_option(sh.ctx, GD_OPT_INGEST_HYBRID, env_int("GOLEFT_INGEST_HYBRID", 0)));
+        if (getenv("GOLEFT_INGEST_COPY_GRID")) GDCHK_ON(sh.ctx, gd_set_option(sh.ctx, GD_OPT_INGEST_COPY_GRID, env_int("GOLEFT_INGEST_COPY_GRID", 16)));   // workgroups of the copy kernel
         if (getenv("GOLEFT_INFLATE_KERNEL")) GDCHK_ON(sh.ctx, gd_set_option(sh.ctx, GD_OPT_INFLATE_KERNEL, env_int("GOLEFT_INFLATE_KERNEL", 0)));
         if (getenv("GOLEFT_INFLATE_LDS_PAD")) GDCHK_ON(sh.ctx, gd_set_option(sh.ctx, GD_OPT_INFLATE_LDS_PAD, env_int("GOLEFT_INFLATE_LDS_PAD", 0)));
         if (env_int("GOLEFT_TRUST_BGZF", 0)) GDCHK_ON(sh.ctx, gd_set_option(sh.ctx, GD_OPT_INGEST_CRC, 0));

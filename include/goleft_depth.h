@@ -213,6 +213,12 @@ enum { GD_OPT_NT_STORES = 3,        /* 1 (default): non-temporal per-base stores
                                        sixth of the bytes through memory and is the slower of the two on an MI355X (DESIGN.md 3.5 has the
                                        measurements and why); it is kept as a second implementation the tests compare the first with.
                                        (ABI 14 had a measurement switch with this number that produced wrong bytes: gone) */
+       GD_OPT_INGEST_COPY_GRID = 25,  /* with GD_OPT_INGEST_DMA = 0: workgroups (of 256 threads) of the copy kernel that pulls a staged piece
+                                       over the link: 16 (default), 1 .. 4096.  The link needs ~100 KB of reads in flight; a large grid
+                                       keeps MEGABYTES of reads to host memory outstanding, and every other kernel on the device then
+                                       runs 2.6 times slower (measured: inflate launches 62.7 ms with 512 workgroups, 24.1 ms behind a
+                                       copy engine; the genome read 2.11 s with 512, 1.52 - 1.70 s with 8 .. 32, 1.76 s with 4 where
+                                       the link starts to starve) */
        GD_OPT_COMMIT_CHECK = 23,      /* where the records of a gd_commit are checked (coordinate order, no negative position, CSR
                                        offsets non-decreasing): 0 (default) on the host, inside gd_commit -- a second pass by CPU
                                        threads over a block the producer has just written; 1: by the pass that indexes the block
