@@ -585,7 +585,15 @@ static int configure_shards(const std::vector<int>& devices, EarlyContexts* earl
         if (getenv("GOLEFT_INFLATE_KERNEL")) GDCHK_ON(sh.ctx, gd_set_option(sh.ctx, GD_OPT_INFLATE_KERNEL, env_int("GOLEFT_INFLATE_KERNEL", 0)));
         if (getenv("GOLEFT_INFLATE_LDS_PAD")) GDCHK_ON(sh.ctx, gd_set_option(sh.ctx, GD_OPT_INFLATE_LDS_PAD, env_int("GOLEFT_INFLATE_LDS_PAD", 0)));
         if (env_int("GOLEFT_TRUST_BGZF", 0)) GDCHK_ON(sh.ctx, gd_set_option(sh.ctx, GD_OPT_INGEST_CRC, 0));
-        if (const int pt = env_int("GOLEFT_PUSH_THREADS", 0)) GDCHK_ON(sh.ctx, gd_set_option(sh.ctx, GD_OPT_PUSH_THREADS, pt));
+        // the context's worker threads (they pread the file's pieces into the staging buffers): 16 unless the container grants
+        // few CPUs -- under a 16-CPU quota sixteen of them and the member lister's threads together ran into the quota (the
+        // kernel then stops EVERY thread until the period ends: 6 - 13 throttled periods per genome, the file's pieces read at
+        // half the rate); ten of them still read faster than the link takes the bytes
+        {
+            const int cpus = gdh::usable_cpus();
+            const int pt = env_int("GOLEFT_PUSH_THREADS", cpus <= 16 ? std::max(4, cpus * 5 / 8) : 0);
+            if (pt) GDCHK_ON(sh.ctx, gd_set_option(sh.ctx, GD_OPT_PUSH_THREADS, pt));
+        }
         GDCHK_ON(sh.ctx, gd_set_contigs(sh.ctx, (int)lens.size(), lens.data()));
         GDCHK_ON(sh.ctx, gd_set_option(sh.ctx, GD_OPT_BAM_REFS, (int64_t)lens.size()));   // engine contigs = the BAM's references
         if (!need_perbase) GDCHK_ON(sh.ctx, gd_set_outputs(sh.ctx, 0));   // windows + class runs are all the rows need

@@ -353,6 +353,11 @@ inline int ingest_references_on_device(gd_ctx* ctx, const FileMap& fm, const std
     std::condition_variable cv;
     size_t n_listed = 0, n_taken = 0;                      // the lister stays at most two passes ahead
     bool stop = false;
+    // threads that walk a pass's BGZF members (one pread per member: all system time).  Four keep two passes ahead of a
+    // 45 GB/s read; sixteen spent 7 CPU-seconds per genome more than four (they contend inside the kernel) and, under a
+    // container's CPU quota, got the whole process throttled
+    const unsigned list_threads = getenv("GOLEFT_LIST_THREADS") ? (unsigned)std::max(1, atoi(getenv("GOLEFT_LIST_THREADS")))
+                                                                : (usable_cpus() <= 16 ? 4u : 8u);
     std::thread lister([&]() {
         for (size_t k = 0; k < passes.size(); ++k) {
             {
@@ -367,7 +372,7 @@ inline int ingest_references_on_device(gd_ctx* ctx, const FileMap& fm, const std
                 for (size_t r = ps.first; r <= ps.last; ++r)
                     for (uint64_t v : lin[(size_t)refs[r]])
                         if ((v >> 16) >= ps.beg && (v >> 16) < ps.end) member_starts.push_back(v >> 16);
-                listed[k].ok = list_members(fm.p + ps.beg, (size_t)(ps.end - ps.beg), ps.beg, member_starts, &listed[k].mt, 16,
+                listed[k].ok = list_members(fm.p + ps.beg, (size_t)(ps.end - ps.beg), ps.beg, member_starts, &listed[k].mt, list_threads,
                                             64u << 20, from_mapping ? -1 : fm.fd) &&
                                listed[k].mt.n != 0;
             }

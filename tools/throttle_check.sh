@@ -42,5 +42,6 @@ if [ -n "$PROF" ]; then     # PROF=tag: one more run under rocprofv3 --kernel-tr
   f=$(find $D/prof -name "*kernel_stats.csv" | head -1)
   mkdir -p $R/gpurun_out; [ -n "$f" ] && cp $f $R/gpurun_out/${PROF}_genome_read_kernel_stats.csv && cut -d, -f1-6 $f | cut -c1-150 | head -14
 fi
+if [ -n "$THREADS" ]; then python $R/tools/thread_cpu.py $R/goleft_amd/goleft-depth depth -w 1000 -p 0 -r $D/synth.fa --prefix $D/out $D/synth.bam; fi
 sha256sum $D/out.depth.bed $D/out.callable.bed | cut -c1-16
 rm -rf $D
