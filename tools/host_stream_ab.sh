@@ -4,11 +4,12 @@
 tag=${1:-hs}
 mkdir -p gpurun_out
 python - > gpurun_out/${tag}_host_stream.json 2> gpurun_out/${tag}_host_stream.err <<'PY'
-import json, sys
+import json, os, sys
 sys.path.insert(0, ".")
 import bench
-out = {"chr20": bench.host_stream_scope(0, 1000, 1, 4),
-       "wgs": bench.host_stream_scope(0, 1000, 1, 4, genome=True, reps=2)}
+opts = tuple(os.environ.get("OPTS", "").split())       # OPTS="8=16": gd_set_option pairs (8 = GD_OPT_H2D_KERNEL: the copy kernel's grid)
+out = {"chr20": bench.host_stream_scope(0, 1000, 1, 4, opts=opts),
+       "wgs": bench.host_stream_scope(0, 1000, 1, 4, genome=True, reps=2, opts=opts)}
 print(json.dumps(out, indent=1))
 PY
 echo "exit $?"
