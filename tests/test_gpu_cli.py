@@ -235,3 +235,31 @@ def test_device_decoder_reads_a_reference_in_parts(workdir, capfd):
         assert '"decoder": "device"' in capfd.readouterr().err
         outs[kb] = (read(prefix, "depth"), read(prefix, "callable"))
         assert outs[kb][0] == hd and outs[kb][1] == ca, kb
+
+
+def test_device_decoder_output_does_not_depend_on_how_the_file_is_fed(workdir, capfd):
+    """The knobs of the device BAM read that round 6's last day turned -- workgroups of the copy kernel that pulls the staged
+    pieces over the link (GOLEFT_INGEST_COPY_GRID = GD_OPT_INGEST_COPY_GRID: 16 by default, the 512 of rounds 4-6 slowed
+    every other kernel 2.6 times), threads that list the BGZF members, pread workers -- change when bytes arrive, never what
+    comes out: the BED files of every setting are the oracle's."""
+    from goleft_amd import synth
+    La, Lb = 5_000_000, 1_200_000
+    ra = po.Reads(*synth.short_reads_numpy(La, synth.n_reads_for(La, 12.0), 15))
+    rb = po.Reads(*synth.short_reads_numpy(Lb, synth.n_reads_for(Lb, 7.0), 16))
+    contigs = [("chrA", La), ("chrB", Lb)]
+    bam = workdir / "fed.bam"
+    bamio.write_bam(str(bam), contigs, {0: ra, 1: rb}, index=True, unplaced=2)
+    (workdir / "fed.fa.fai").write_text("".join("%s\t%d\t6\t60\t61\n" % c for c in contigs))
+    hd, ca = po.depth_run_oracle(contigs, {0: ra, 1: rb}, W=500, Q=1, mincov=4)
+    for i, env in enumerate(({}, {"GOLEFT_INGEST_COPY_GRID": "1"}, {"GOLEFT_INGEST_COPY_GRID": "700"},
+                             {"GOLEFT_LIST_THREADS": "1", "GOLEFT_PUSH_THREADS": "2"},
+                             {"GOLEFT_LIST_THREADS": "16", "GOLEFT_PUSH_THREADS": "16", "GOLEFT_INGEST_COPY_GRID": "64"})):
+        prefix = workdir / ("fed%d" % i)
+        os.environ.update(env, GOLEFT_DEPTH_TIMING="1")
+        try:
+            assert run_depth(["-w", 500, "-r", workdir / "fed.fa", "--prefix", prefix, bam]) == 0, env
+        finally:
+            for k in list(env) + ["GOLEFT_DEPTH_TIMING"]:
+                del os.environ[k]
+        assert '"decoder": "device"' in capfd.readouterr().err
+        assert read(prefix, "depth") == hd and read(prefix, "callable") == ca, env
