@@ -40,6 +40,8 @@ done
 if [ -n "$PROF" ]; then     # PROF=tag: one more run under rocprofv3 --kernel-trace --stats; the ingest kernels' rows are kept
   ( cd /tmp && GOLEFT_SLOW_EXIT=1 rocprofv3 --kernel-trace --stats --output-format csv -d $D/prof -o x -- $R/goleft_amd/goleft-depth depth -w 1000 -p 0 -r $D/synth.fa --prefix $D/out $D/synth.bam > $D/prof.log 2>&1 ); tail -3 $D/prof.log
   f=$(find $D/prof -name "*kernel_stats.csv" | head -1)
+  tr=$(find $D/prof -name "*kernel_trace.csv" | head -1)
+  [ -n "$tr" ] && python $R/tools/timeline.py $tr --slice-ms 50 2>/dev/null | awk 'NR<3 || ($2+$5+$14)>0' | cut -c1-86,120-150 | head -60
   mkdir -p $R/gpurun_out; [ -n "$f" ] && cp $f $R/gpurun_out/${PROF}_genome_read_kernel_stats.csv && cut -d, -f1-6 $f | cut -c1-150 | head -14
 fi
 if [ -n "$THREADS" ]; then python $R/tools/thread_cpu.py $R/goleft_amd/goleft-depth depth -w 1000 -p 0 -r $D/synth.fa --prefix $D/out $D/synth.bam; fi
